@@ -1,0 +1,349 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+The product package (orb_slam2_ssd_semantic_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liborb_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4")])
+assert KP_DTYPE.itemsize == 28 and CAND_DTYPE.itemsize == 12
+
+
+def build(force=False):
+    """Compile the oracle with gcc (never the reference's build system)."""
+    src = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "orb_oracle.h", "orc_pattern.inc")]
+    if (not force and os.path.exists(_LIB)
+            and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in src)):
+        return _LIB
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liborb_oracle.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB)
+    u8p, i32p, f32p, u32p = (C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                             C.POINTER(C.c_uint32))
+    vp = C.c_void_p
+    L.orc_create.restype = vp
+    L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+    L.orc_destroy.argtypes = [vp]
+    L.orc_nlevels.argtypes = [vp]
+    L.orc_get_scales.argtypes = [vp, vp, vp, vp, vp]
+    L.orc_get_features_per_level.argtypes = [vp, vp]
+    L.orc_get_umax.argtypes = [vp]
+    L.orc_get_pattern.restype = vp
+    L.orc_level_sizes.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.orc_cell_grid.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp]
+    L.orc_resize_linear_u8.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    L.orc_resize_tables.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp]
+    L.orc_copy_make_border101.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+    L.orc_fast9.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.orc_fast_score_map.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.orc_distribute_octtree.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                         C.c_int, vp]
+    L.orc_fast_atan2.restype = C.c_float
+    L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+    L.orc_ic_moments.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.orc_ic_angle.restype = C.c_float
+    L.orc_ic_angle.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.orc_gaussian_blur7.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]
+    L.orc_sincos.argtypes = [C.c_float, vp, vp]
+    L.orc_descriptor.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]
+    L.orc_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]
+    for f in ("orc_tap_level", "orc_tap_blurred"):
+        getattr(L, f).restype = vp
+        getattr(L, f).argtypes = [vp, C.c_int, vp, vp, vp]
+    for f in ("orc_tap_candidates", "orc_tap_selected"):
+        getattr(L, f).restype = vp
+        getattr(L, f).argtypes = [vp, C.c_int, vp]
+    L.orc_tap_blur_ties.restype = C.c_long
+    L.orc_tap_blur_ties.argtypes = [vp]
+    L.orc_tap_octree_tie_breaks.argtypes = [vp]
+    L.orc_set_blur_mode.argtypes = [vp, C.c_int]
+    L.orc_hamming.argtypes = [vp, vp]
+    L.orc_three_maxima.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.orc_rot_bin.argtypes = [C.c_float, C.c_float]
+    L.orc_match_bf.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.orc_search_by_bow.argtypes = ([vp, C.c_int, vp, vp, vp, vp, vp, C.c_int] * 2
+                                    + [C.c_float, C.c_int, C.c_int, C.c_int, vp, vp])
+    L.orc_hamming_csr.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 2
+    return img
+
+
+class OracleExtractor:
+    """CPU twin of ORB_SLAM2::ORBextractor (include/ORBextractor.h:35-116)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.h = self.L.orc_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self.h:
+            raise ValueError("orc_create failed")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def scales(self):
+        out = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        self.L.orc_get_scales(self.h, *[_p(o) for o in out])
+        return out
+
+    def features_per_level(self):
+        out = np.zeros(self.nlevels, np.int32)
+        self.L.orc_get_features_per_level(self.h, _p(out))
+        return out
+
+    def level_sizes(self, w, h):
+        lw = np.zeros(self.nlevels, np.int32)
+        lh = np.zeros(self.nlevels, np.int32)
+        self.L.orc_level_sizes(self.h, w, h, _p(lw), _p(lh))
+        return lw, lh
+
+    def set_blur_mode(self, mode):
+        self.L.orc_set_blur_mode(self.h, mode)
+
+    def __call__(self, image, cap=None):
+        """operator(): returns (keypoints[KP_DTYPE], descriptors[N,32] u8)."""
+        image = _u8(image)
+        h, w = image.shape
+        cap = cap or (self.nfeatures + 4 * self.nlevels + 64)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        rc = self.L.orc_extract(self.h, _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"orc_extract rc={rc} n={n.value}")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def _tap_img(self, fn, level):
+        w, h, s = C.c_int(), C.c_int(), C.c_int()
+        p = fn(self.h, level, C.byref(w), C.byref(h), C.byref(s))
+        if not p:
+            return None
+        buf = (C.c_uint8 * (s.value * h.value)).from_address(p)
+        return np.frombuffer(buf, np.uint8).reshape(h.value, s.value)[:, :w.value].copy()
+
+    def level(self, level):
+        return self._tap_img(self.L.orc_tap_level, level)
+
+    def blurred(self, level):
+        return self._tap_img(self.L.orc_tap_blurred, level)
+
+    def _tap_cand(self, fn, level):
+        n = C.c_int()
+        p = fn(self.h, level, C.byref(n))
+        if not p or n.value == 0:
+            return np.zeros(0, CAND_DTYPE)
+        buf = (C.c_uint8 * (12 * n.value)).from_address(p)
+        return np.frombuffer(buf, CAND_DTYPE).copy()
+
+    def candidates(self, level):
+        return self._tap_cand(self.L.orc_tap_candidates, level)
+
+    def selected(self, level):
+        return self._tap_cand(self.L.orc_tap_selected, level)
+
+    def blur_ties(self):
+        return self.L.orc_tap_blur_ties(self.h)
+
+    def octree_tie_breaks(self):
+        return self.L.orc_tap_octree_tie_breaks(self.h)
+
+
+# ---- stage-level free functions -------------------------------------------------------------------
+def umax():
+    out = np.zeros(16, np.int32)
+    lib().orc_get_umax(_p(out))
+    return out
+
+
+def pattern():
+    p = lib().orc_get_pattern()
+    return np.frombuffer((C.c_int8 * 1024).from_address(p), np.int8).copy()
+
+
+def cell_grid(lw, lh):
+    v = [C.c_int() for _ in range(4)]
+    ok = lib().orc_cell_grid(lw, lh, *[C.byref(x) for x in v])
+    return (ok,) + tuple(x.value for x in v)
+
+
+def resize_linear(src, dw, dh):
+    src = _u8(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def resize_tables(ssize, dsize, is_x):
+    ofs = np.zeros(dsize, np.int32)
+    coef = np.zeros(2 * dsize, np.int16)
+    lib().orc_resize_tables(ssize, dsize, int(is_x), _p(ofs), _p(coef))
+    return ofs, coef.reshape(dsize, 2)
+
+
+def copy_make_border101(src, border):
+    src = _u8(src)
+    h, w = src.shape
+    dst = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+    lib().orc_copy_make_border101(_p(src), w, h, src.strides[0], _p(dst), dst.strides[0], border)
+    return dst
+
+
+def fast9(img, threshold, nonmax=True):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros(max(1, w * h), CAND_DTYPE)
+    n = lib().orc_fast9(_p(img), w, h, img.strides[0], threshold, int(nonmax), _p(out), out.size)
+    assert n >= 0
+    return out[:n].copy()
+
+
+def fast_score_map(img):
+    img = _u8(img)
+    h, w = img.shape
+    sc = np.zeros((h, w), np.uint8)
+    lib().orc_fast_score_map(_p(img), w, h, img.strides[0], _p(sc), w)
+    return sc
+
+
+def distribute_octtree(cands, minx, maxx, miny, maxy, N):
+    cands = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+    out = np.zeros(max(1, cands.size), CAND_DTYPE)
+    st = np.zeros(3, np.int32)
+    n = lib().orc_distribute_octtree(_p(cands), cands.size, minx, maxx, miny, maxy, N, _p(out), out.size, _p(st))
+    if n < 0:
+        raise RuntimeError(f"orc_distribute_octtree rc={n}")
+    return out[:n].copy(), dict(iterations=int(st[0]), phaseb_passes=int(st[1]), tie_breaks=int(st[2]))
+
+
+def fast_atan2(y, x):
+    return np.float32(lib().orc_fast_atan2(float(y), float(x)))
+
+
+def ic_moments(img, x, y):
+    img = _u8(img)
+    a, b = C.c_int(), C.c_int()
+    lib().orc_ic_moments(_p(img), img.strides[0], x, y, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def ic_angle(img, x, y):
+    img = _u8(img)
+    return np.float32(lib().orc_ic_angle(_p(img), img.strides[0], x, y))
+
+
+def gaussian_blur7(img, mode=0):
+    img = _u8(img)
+    h, w = img.shape
+    dst = np.zeros((h, w), np.uint8)
+    ties = C.c_long()
+    lib().orc_gaussian_blur7(_p(img), w, h, img.strides[0], _p(dst), w, mode, C.byref(ties))
+    return dst, ties.value
+
+
+def sincos(angle_deg):
+    a, b = C.c_float(), C.c_float()
+    lib().orc_sincos(float(angle_deg), C.byref(a), C.byref(b))
+    return np.float32(a.value), np.float32(b.value)
+
+
+def descriptor(blurred, x, y, angle_deg):
+    blurred = _u8(blurred)
+    d = np.zeros(32, np.uint8)
+    lib().orc_descriptor(_p(blurred), blurred.strides[0], x, y, float(angle_deg), _p(d))
+    return d
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_hamming(_p(a), _p(b))
+
+
+def three_maxima(counts):
+    counts = np.ascontiguousarray(counts, np.int32)
+    i = [C.c_int() for _ in range(3)]
+    lib().orc_three_maxima(_p(counts), counts.size, *[C.byref(x) for x in i])
+    return tuple(x.value for x in i)
+
+
+def rot_bin(a1, a2):
+    return lib().orc_rot_bin(float(a1), float(a2))
+
+
+def match_bf(q, t, q_angle=None, t_angle=None, nnratio=0.9, th=100, check_ori=True):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    qa = None if q_angle is None else np.ascontiguousarray(q_angle, np.float32)
+    ta = None if t_angle is None else np.ascontiguousarray(t_angle, np.float32)
+    m = np.full(len(q), -1, np.int32)
+    b = np.zeros(len(q), np.int32)
+    s = np.zeros(len(q), np.int32)
+    n = C.c_int()
+    rc = lib().orc_match_bf(_p(q), len(q), _p(t), len(t), _p(qa), _p(ta), nnratio, th, int(check_ori), _p(m),
+                            _p(b), _p(s), C.byref(n))
+    assert rc == 0
+    return m, b, s, n.value
+
+
+def search_by_bow(descKF, validKF, angKF, fvKF, descF, validF, angF, fvF, nnratio=0.7, th_low=50,
+                  strict_lt=False, check_ori=True):
+    """fvKF / fvF = (node[nn], off[nn+1], idx[...]) CSR feature vectors with ascending node ids."""
+    descKF = np.ascontiguousarray(descKF, np.uint8).reshape(-1, 32)
+    descF = np.ascontiguousarray(descF, np.uint8).reshape(-1, 32)
+    vk = None if validKF is None else np.ascontiguousarray(validKF, np.uint8)
+    vf = None if validF is None else np.ascontiguousarray(validF, np.uint8)
+    ak = np.ascontiguousarray(angKF, np.float32)
+    af = np.ascontiguousarray(angF, np.float32)
+    nk, ok, ik = [np.ascontiguousarray(a, np.uint32) for a in fvKF]
+    nf, of, if_ = [np.ascontiguousarray(a, np.uint32) for a in fvF]
+    m = np.full(len(descF), -1, np.int32)
+    n = C.c_int()
+    rc = lib().orc_search_by_bow(_p(descKF), len(descKF), _p(vk), _p(ak), _p(nk), _p(ok), _p(ik), len(nk),
+                                 _p(descF), len(descF), _p(vf), _p(af), _p(nf), _p(of), _p(if_), len(nf),
+                                 nnratio, th_low, int(strict_lt), int(check_ori), _p(m), C.byref(n))
+    assert rc == 0
+    return m, n.value
+
+
+def hamming_csr(q, t, off, cand):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(off, np.uint32)
+    cand = np.ascontiguousarray(cand, np.uint32)
+    bi = np.zeros(len(q), np.int32)
+    b = np.zeros(len(q), np.int32)
+    s = np.zeros(len(q), np.int32)
+    rc = lib().orc_hamming_csr(_p(q), len(q), _p(t), len(t), _p(off), _p(cand), _p(bi), _p(b), _p(s))
+    assert rc == 0
+    return bi, b, s

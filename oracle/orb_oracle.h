@@ -1,0 +1,146 @@
+/*
+ * orb_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE)
+ *
+ * A plain-C restatement of the ORB front-end of Ewenwan/ORB_SLAM2_SSD_Semantic:
+ *   ORBextractor  (/root/reference/src/ORBextractor.cc, include/ORBextractor.h)
+ *   ORBmatcher    Hamming core (/root/reference/src/ORBmatcher.cc)
+ * plus the OpenCV-3.2 generic-path arithmetic those files call (cv::resize
+ * INTER_LINEAR, copyMakeBorder, cv::FAST, GaussianBlur, fastAtan2, cvRound),
+ * restated from the published algorithms because OpenCV is a non-vendored,
+ * un-pinned third-party dependency.
+ *
+ * PARITY STATUS: **parity unpinned** by the reference -- the reference ships no
+ * tests, no golden vectors and cannot be built here (no OpenCV / DBoW2).  The
+ * oracle is pinned instead by (a) known-answer tables derived from the reference
+ * source itself (umax, features-per-level, level sizes, grid geometry, pattern
+ * checksum, DescriptorDistance, ComputeThreeMaxima) and (b) independent
+ * definition-level twins (tests/twins.py).  See DESIGN.md "Oracle".
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call this library.  The product (orb_slam2_ssd_semantic_amd/csrc)
+ * never does.
+ *
+ * Two places where the real reference binary is itself not reproducible and
+ * this oracle DEFINES the contract (documented in DESIGN.md):
+ *   1. DistributeOctTree sorts pair<int,ExtractorNode*> (ORBextractor.cc:686):
+ *      equal-size nodes are ordered by heap address.  Contract here: ties keep
+ *      creation order (stable), iterated from the back as :687 does.
+ *   2. cos/sin at ORBextractor.cc:97 resolve to glibc cosf/sinf (CPU/glibc
+ *      dependent last-bit).  Contract here: orc_sincos(), a fixed fp64
+ *      algorithm rounded once to fp32.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::KeyPoint field order (T1 in SURVEY 8(a)); 28 bytes. */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+
+/* FAST / quadtree candidate: integer pixel position stored as float like cv::KeyPoint. */
+typedef struct {
+    float x, y, response;
+} orc_cand;
+
+typedef struct orc_extractor orc_extractor;
+
+/* ---- E0: constructor tables (ORBextractor.cc:399-466) ---- */
+orc_extractor *orc_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th);
+void orc_destroy(orc_extractor *e);
+int orc_nlevels(const orc_extractor *e);
+void orc_get_scales(const orc_extractor *e, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2);
+void orc_get_features_per_level(const orc_extractor *e, int *out);
+void orc_get_umax(int out[16]);
+const signed char *orc_get_pattern(void); /* 1024 x int8 */
+/* level sizes for a w x h input (ORBextractor.cc:1121-1122) */
+void orc_level_sizes(const orc_extractor *e, int w, int h, int *lw, int *lh);
+/* FAST cell grid of one level (ORBextractor.cc:780-796): returns 0 if the level is too small */
+int orc_cell_grid(int lw, int lh, int *ncols, int *nrows, int *wcell, int *hcell);
+
+/* ---- E2: cv::resize INTER_LINEAR 8UC1 and copyMakeBorder REFLECT_101 (9.2) ---- */
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw, int dh,
+                          int dstride);
+void orc_resize_tables(int ssize, int dsize, int is_x, int *ofs, int16_t *coef /* 2*dsize */);
+void orc_copy_make_border101(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride,
+                             int border);
+
+/* ---- E3a: cv::FAST(img, kps, threshold, nonmax=true), FAST-9/16 ---- */
+/* returns number of keypoints written (raster order), -1 if cap is too small */
+int orc_fast9(const uint8_t *img, int w, int h, int stride, int threshold, int nonmax, orc_cand *out, int cap);
+/* threshold-independent corner score map: score(x,y) = max(A_dark, A_bright) - 1 clamped to [0,255]
+ * on the detectable interior [3,w-3)x[3,h-3), 0 elsewhere (kernel twin). */
+void orc_fast_score_map(const uint8_t *img, int w, int h, int stride, uint8_t *score, int score_stride);
+
+/* ---- E4: DistributeOctTree (ORBextractor.cc:540-765) ---- */
+typedef struct {
+    int iterations;   /* breadth-first passes executed */
+    int phaseb_passes;/* largest-first passes executed */
+    int tie_breaks;   /* number of equal-size adjacent pairs crossed by the >=N break (tie-sensitive) */
+} orc_octree_stats;
+int orc_distribute_octtree(const orc_cand *in, int n, int minx, int maxx, int miny, int maxy, int N,
+                           orc_cand *out, int cap, orc_octree_stats *st);
+
+/* ---- E6: IC_Angle (ORBextractor.cc:59-88) + cv::fastAtan2 ---- */
+float orc_fast_atan2(float y, float x);
+void orc_ic_moments(const uint8_t *img, int stride, int x, int y, int *m10, int *m01);
+float orc_ic_angle(const uint8_t *img, int stride, int x, int y);
+
+/* ---- E7: GaussianBlur 7x7 sigma 2 REFLECT_101, 8-bit fixed-point kernel ----
+ * mode 0 = canonical integer formula (half-up); mode 1 = emulate the x86 SSE2 column kernel
+ * (half-to-even on columns x < (w & ~3)).  *ties (optional) counts exact-half pixels. */
+void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, int mode,
+                        long *ties);
+
+/* ---- E8: steered BRIEF (ORBextractor.cc:92-131) ---- */
+void orc_sincos(float angle_deg, float *cos_a, float *sin_b); /* canonical (float)cos/(float)sin of angle*pi/180 */
+void orc_descriptor(const uint8_t *blurred, int stride, int x, int y, float angle_deg, uint8_t desc[32]);
+
+/* ---- E1: operator() (ORBextractor.cc:1052-1114) ---- */
+/* returns 0 ok, -1 bad args/size, -2 cap too small. Empty image (w==0||h==0) -> 0 with *n_out untouched. */
+int orc_extract(orc_extractor *e, const uint8_t *gray, int w, int h, int stride, orc_keypoint *kps,
+                uint8_t *desc, int cap, int *n_out);
+/* stage taps of the last orc_extract call (pointers owned by e, valid until next call) */
+const uint8_t *orc_tap_level(const orc_extractor *e, int level, int *w, int *h, int *stride);
+const uint8_t *orc_tap_blurred(const orc_extractor *e, int level, int *w, int *h, int *stride);
+const orc_cand *orc_tap_candidates(const orc_extractor *e, int level, int *n);
+const orc_cand *orc_tap_selected(const orc_extractor *e, int level, int *n);
+long orc_tap_blur_ties(const orc_extractor *e);
+int orc_tap_octree_tie_breaks(const orc_extractor *e);
+void orc_set_blur_mode(orc_extractor *e, int mode);
+
+/* ---- M0: DescriptorDistance (ORBmatcher.cc:1968-1984) ---- */
+int orc_hamming(const uint8_t a[32], const uint8_t b[32]);
+
+/* ---- M5: ComputeThreeMaxima (ORBmatcher.cc:1912-1957) on bin counts ---- */
+void orc_three_maxima(const int *counts, int L, int *ind1, int *ind2, int *ind3);
+/* rotation bin (ORBmatcher.cc:308-313) */
+int orc_rot_bin(float angle1, float angle2);
+
+/* ---- M3: brute-force best/2nd-best + ratio + rotation histogram ---- */
+int orc_match_bf(const uint8_t *q, int nq, const uint8_t *t, int nt, const float *q_angle, const float *t_angle,
+                 float nnratio, int th, int check_ori, int32_t *match_q2t, int32_t *best, int32_t *second,
+                 int *nmatches);
+
+/* ---- M1/M2: SearchByBoW (ORBmatcher.cc:217-363, 665-812) over CSR feature vectors ---- */
+int orc_search_by_bow(const uint8_t *descKF, int nKF, const uint8_t *validKF, const float *angKF,
+                      const uint32_t *nodeKF, const uint32_t *offKF, const uint32_t *idxKF, int nnodesKF,
+                      const uint8_t *descF, int nF, const uint8_t *validF, const float *angF,
+                      const uint32_t *nodeF, const uint32_t *offF, const uint32_t *idxF, int nnodesF,
+                      float nnratio, int th_low, int strict_lt, int check_ori, int32_t *matchF2KF,
+                      int *nmatches);
+
+/* ---- 8(f).1: CSR batched Hamming best/2nd-best (core of the SearchByProjection family) ---- */
+int orc_hamming_csr(const uint8_t *q, int nq, const uint8_t *t, int nt, const uint32_t *off /* nq+1 */,
+                    const uint32_t *cand, int32_t *best_idx, int32_t *best, int32_t *second);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
