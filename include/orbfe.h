@@ -1,0 +1,221 @@
+/*
+ * orbfe.h -- C-ABI of the MI355X-native ORB front-end (liborbfe.so).
+ *
+ * Drop-in boundary for ONE hot path of Ewenwan/ORB_SLAM2_SSD_Semantic:
+ *   ORB_SLAM2::ORBextractor::operator()      (reference include/ORBextractor.h:53-55, src/ORBextractor.cc:1052)
+ *   ORB_SLAM2::ORBmatcher Hamming core        (reference include/ORBmatcher.h:41-112, src/ORBmatcher.cc)
+ * The reference has no FFI: the "operator API" is two C++ classes.  The C++ shim in
+ * orb_slam2_ssd_semantic_amd/shim/ re-declares those classes with identical signatures on top of
+ * this header (INTEGRATION.md shows the binding).  Plain C, POD only, caller-owned buffers, every
+ * call returns an orbfe_status (0 = ok, negative = error); nothing throws or aborts.
+ *
+ * Threading: a handle is used by one thread at a time (like an ORBextractor instance, which mutates
+ * mvImagePyramid); different handles may be used concurrently (stereo: src/Frame.cc:121-122;
+ * matchers are created per call site from three SLAM threads).  There is no global
+ * mutable state.
+ *
+ * All compute runs in hand-written HIP kernels for gfx950.  There is NO CPU fallback: without a
+ * usable HIP device orbfe_create / orbfe_matcher_create fail with ORBFE_ERR_NODEVICE.
+ */
+#ifndef ORBFE_H
+#define ORBFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBFE_VERSION 100 /* 0.1.0 */
+
+typedef int32_t orbfe_status;
+enum {
+    ORBFE_OK = 0,
+    ORBFE_ERR_ARG = -1,      /* null pointer / negative size / inconsistent arguments          */
+    ORBFE_ERR_SIZE = -2,     /* image larger than planned or too small for the 8-level grid    */
+    ORBFE_ERR_CAP = -3,      /* caller's keypoint capacity too small; *n_out holds the need    */
+    ORBFE_ERR_HIP = -4,      /* a HIP runtime call failed (see orbfe_last_error)               */
+    ORBFE_ERR_NOMEM = -5,    /* device or host allocation failed                               */
+    ORBFE_ERR_NODEVICE = -6, /* no usable HIP device: there is no CPU path                     */
+    ORBFE_ERR_STATE = -7     /* call made in the wrong state (e.g. taps before any extract)    */
+};
+
+/* = cv::KeyPoint field order (T1): {Point2f pt; float size, angle, response; int octave, class_id}. 28 B. */
+typedef struct orbfe_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbfe_keypoint;
+
+/* Constructor arguments of ORBextractor (include/ORBextractor.h:45-46, values read from the settings
+ * YAML at src/Tracking.cc:198-206) plus planning sizes for the device buffers. */
+typedef struct orbfe_params {
+    int32_t nfeatures;      /* ORBextractor.nFeatures   (TUM3.yaml:41-54: 1000) */
+    float scale_factor;     /* ORBextractor.scaleFactor (1.2)                   */
+    int32_t nlevels;        /* ORBextractor.nLevels     (8), 1..16              */
+    int32_t ini_th_fast;    /* ORBextractor.iniThFAST   (20)                    */
+    int32_t min_th_fast;    /* ORBextractor.minThFAST   (7)                     */
+    int32_t max_width;      /* largest image width this handle will see  (<= 4096) */
+    int32_t max_height;     /* largest image height this handle will see (<= 4096) */
+    int32_t max_batch;      /* frames per batched call (>= 1)                   */
+    int32_t device;         /* HIP device ordinal, -1 = current device          */
+    int32_t blur_rounding;  /* 0 = canonical half-up; 1 = emulate the x86 SSE2 column kernel */
+} orbfe_params;
+
+typedef struct orbfe_handle orbfe_handle;   /* one ORBextractor instance */
+typedef struct orbfe_matcher orbfe_matcher; /* scratch + stream for ORBmatcher calls */
+
+/* ---------------------------------------------------------------------------------------------
+ * Library
+ * ------------------------------------------------------------------------------------------- */
+int32_t orbfe_version(void);
+const char *orbfe_strerror(orbfe_status s);
+/* thread-local text of the last failure on the calling thread ("" if none) */
+const char *orbfe_last_error(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int32_t orbfe_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Extractor  (replaces ORBextractor: ctor src/ORBextractor.cc:399-466, operator() :1052-1114)
+ * ------------------------------------------------------------------------------------------- */
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) */
+orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out);
+void orbfe_destroy(orbfe_handle *h);
+
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+ * (include/ORBextractor.h:58-78); nlevels floats each, any pointer may be NULL. */
+orbfe_status orbfe_get_scales(const orbfe_handle *h, float *scale, float *inv_scale, float *sigma2,
+                              float *inv_sigma2);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:426-439); nlevels ints */
+orbfe_status orbfe_get_features_per_level(const orbfe_handle *h, int32_t *out);
+/* upper bound of keypoints one frame can produce: nfeatures + 2*nlevels rounded up to 64 */
+int32_t orbfe_keypoint_capacity(const orbfe_handle *h);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors) for one 8-bit gray frame in HOST
+ * memory (mask is ignored by the reference, :1052).  kps/desc are caller-owned with room for `cap`
+ * keypoints; *n_out receives the count.  w==0 || h==0 || gray==NULL -> ORBFE_OK, outputs untouched
+ * (:1055-1056).  Order of the output is the reference's (level-major, quadtree list order). */
+orbfe_status orbfe_extract(orbfe_handle *h, const uint8_t *gray, int32_t w, int32_t ht, int32_t stride,
+                           orbfe_keypoint *kps, uint8_t *desc /* cap x 32 */, int32_t cap, int32_t *n_out);
+
+/* Batched keyframe mode, HOST buffers: frames are independent.  grays[i] points to
+ * frame i (all w x ht, same stride).  Frame i writes kps[i*cap ..], desc[i*cap*32 ..], n_out[i]. */
+orbfe_status orbfe_extract_batch(orbfe_handle *h, const uint8_t *const *grays, int32_t nframes, int32_t w,
+                                 int32_t ht, int32_t stride, orbfe_keypoint *kps, uint8_t *desc, int32_t cap,
+                                 int32_t *n_out);
+
+/* Batched keyframe mode, DEVICE buffers (HBM-resident input, what bench.py times):
+ *   d_gray   : nframes frames, frame i at d_gray + i*frame_stride, row pitch `stride`
+ *   d_kps    : nframes*cap orbfe_keypoint      d_desc : nframes*cap*32 bytes     d_n_out : nframes int32
+ * All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the handle's own stream)
+ * and the call returns without synchronising.  Slots >= n_out[i] of a frame are zero-filled so the
+ * padded buffers can be all-gathered as they are. */
+orbfe_status orbfe_extract_batch_device(orbfe_handle *h, const uint8_t *d_gray, int32_t nframes, int32_t w,
+                                        int32_t ht, int32_t stride, size_t frame_stride,
+                                        orbfe_keypoint *d_kps, uint8_t *d_desc, int32_t cap,
+                                        int32_t *d_n_out, void *stream);
+/* block until everything enqueued by this handle on its own stream has finished */
+orbfe_status orbfe_synchronize(orbfe_handle *h);
+
+/* mvImagePyramid[level] of the LAST extract call, frame `frame` of the batch (include/ORBextractor.h:80;
+ * read by Frame::ComputeStereoMatches src/Frame.cc:649,761-778).  with_border != 0 returns the
+ * (w+38) x (h+38) BORDER_REFLECT_101-padded image (src/ORBextractor.cc:1136-1142), else w x h. */
+orbfe_status orbfe_get_level_size(const orbfe_handle *h, int32_t level, int32_t *w, int32_t *ht);
+orbfe_status orbfe_get_pyramid_level(orbfe_handle *h, int32_t frame, int32_t level, uint8_t *dst,
+                                     int32_t dst_stride, int32_t with_border);
+
+/* ---- stage taps of the last extract call (parity tests / debugging; host copies) ---- */
+/* 7x7 sigma-2 blurred level (the private clone of src/ORBextractor.cc:1094-1095) */
+orbfe_status orbfe_tap_blurred_level(orbfe_handle *h, int32_t frame, int32_t level, uint8_t *dst,
+                                     int32_t dst_stride);
+/* FAST candidates handed to DistributeOctTree for one level, reference order (cell-row-major, raster):
+ * xyr = n x {x, y, response} floats in detection-window coordinates (src/ORBextractor.cc:831-833) */
+orbfe_status orbfe_tap_candidates(orbfe_handle *h, int32_t frame, int32_t level, float *xyr, int32_t cap,
+                                  int32_t *n);
+/* keypoints kept by DistributeOctTree for one level, list order, level coordinates (border added) */
+orbfe_status orbfe_tap_selected(orbfe_handle *h, int32_t frame, int32_t level, float *xyr, int32_t cap,
+                                int32_t *n);
+
+/* ---- timing of the last batched call (HIP events on the stream the kernels ran on) ---- */
+enum {
+    ORBFE_T_PYRAMID = 0, /* all resize launches                                  */
+    ORBFE_T_FAST = 1,    /* FAST score + per-cell NMS + threshold fallback       */
+    ORBFE_T_OCTREE = 2,  /* DistributeOctTree                                    */
+    ORBFE_T_BLUR = 3,    /* 7x7 Gaussian                                         */
+    ORBFE_T_DESC = 4,    /* IC_Angle + rBRIEF + keypoint assembly                */
+    ORBFE_T_TOTAL = 5,   /* first launch -> last launch                          */
+    ORBFE_T_COUNT = 6
+};
+/* enable != 0: record events around each stage of subsequent calls (adds a few us per call) */
+orbfe_status orbfe_set_profiling(orbfe_handle *h, int32_t enable);
+/* milliseconds per stage of the last profiled call; synchronises the stream */
+orbfe_status orbfe_get_stage_ms(orbfe_handle *h, float ms[ORBFE_T_COUNT]);
+
+/* ---------------------------------------------------------------------------------------------
+ * Matcher  (replaces the Hamming core of ORBmatcher, src/ORBmatcher.cc)
+ * ------------------------------------------------------------------------------------------- */
+#define ORBFE_TH_HIGH 100     /* ORBmatcher::TH_HIGH      src/ORBmatcher.cc:39 */
+#define ORBFE_TH_LOW 50       /* ORBmatcher::TH_LOW       src/ORBmatcher.cc:40 */
+#define ORBFE_HISTO_LENGTH 30 /* ORBmatcher::HISTO_LENGTH src/ORBmatcher.cc:41 */
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1968-1984): host scalar, no device involved */
+int32_t orbfe_hamming(const uint8_t a[32], const uint8_t b[32]);
+
+orbfe_status orbfe_matcher_create(int32_t device /* -1 = current */, orbfe_matcher **out);
+void orbfe_matcher_destroy(orbfe_matcher *m);
+
+/* BASELINE config 3 "brute-force Hamming match to previous frame" (SURVEY 8(a) M3): for every query
+ * row the best / second-best distance over ALL train rows with the update idiom of
+ * src/ORBmatcher.cc:280-289 (ties: lowest train index), accepted when best <= th and
+ * (float)best < nnratio*(float)second, then the rotation-consistency histogram (:308-316, :338-360,
+ * ComputeThreeMaxima :1912-1957) when check_ori != 0.  HOST buffers.
+ *   match_q2t[nq] : train index or -1        best/second[nq] : may be NULL        *nmatches : kept */
+orbfe_status orbfe_match_bf(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
+                            const float *q_angle, const float *t_angle, float nnratio, int32_t th,
+                            int32_t check_ori, int32_t *match_q2t, int32_t *best, int32_t *second,
+                            int32_t *nmatches);
+/* same, DEVICE buffers, enqueued on `stream` (NULL = matcher's stream), no synchronisation;
+ * d_nmatches is one int32 in device memory */
+orbfe_status orbfe_match_bf_device(orbfe_matcher *m, const uint8_t *d_q, int32_t nq, const uint8_t *d_t,
+                                   int32_t nt, const float *d_q_angle, const float *d_t_angle, float nnratio,
+                                   int32_t th, int32_t check_ori, int32_t *d_match_q2t, int32_t *d_best,
+                                   int32_t *d_second, int32_t *d_nmatches, void *stream);
+/* batched form of the above: pair p matches frame p (queries) against frame p+1's predecessor layout:
+ *   queries  = d_desc + qframe[p]*cap*32 (nq = d_n[qframe[p]]),  train = d_desc + tframe[p]*cap*32
+ * with angles taken from d_kps (orbfe_keypoint.angle).  Outputs are npairs x cap. Used by bench.py. */
+orbfe_status orbfe_match_bf_frames_device(orbfe_matcher *m, const orbfe_keypoint *d_kps, const uint8_t *d_desc,
+                                          const int32_t *d_n, int32_t cap, const int32_t *d_qframe,
+                                          const int32_t *d_tframe, int32_t npairs, float nnratio, int32_t th,
+                                          int32_t check_ori, int32_t *d_match_q2t /* npairs*cap */,
+                                          int32_t *d_nmatches /* npairs */, void *stream);
+
+/* ORBmatcher::SearchByBoW (KeyFrame*, Frame&, ...) src/ORBmatcher.cc:217-363   [strict_lt = 0, validF = NULL]
+ * ORBmatcher::SearchByBoW (KeyFrame*, KeyFrame*, ...) src/ORBmatcher.cc:665-812 [strict_lt = 1]
+ * DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) is passed as CSR: node[nnodes] ascending,
+ * off[nnodes+1], idx[off[nnodes]].  Each feature index must occur in at most one node (true for
+ * FeatureVectors produced by DBoW2 transform()); otherwise ORBFE_ERR_ARG.
+ *   validKF[nKF] : 1 where the KF feature has a good MapPoint (pMP && !pMP->isBad()), NULL = all
+ *   validF[nF]   : same for the second keyframe (M2), NULL for a Frame (M1)
+ *   matchF2KF[nF]: KF feature index whose MapPoint is assigned to F feature i, -1 = none
+ * HOST buffers. */
+orbfe_status orbfe_search_by_bow(orbfe_matcher *m, const uint8_t *descKF, int32_t nKF, const uint8_t *validKF,
+                                 const float *angKF, const uint32_t *nodeKF, const uint32_t *offKF,
+                                 const uint32_t *idxKF, int32_t nnodesKF, const uint8_t *descF, int32_t nF,
+                                 const uint8_t *validF, const float *angF, const uint32_t *nodeF,
+                                 const uint32_t *offF, const uint32_t *idxF, int32_t nnodesF, float nnratio,
+                                 int32_t th_low, int32_t strict_lt, int32_t check_ori, int32_t *matchF2KF,
+                                 int32_t *nmatches);
+
+/* batched best / second-best over per-query candidate lists (CSR), the inner loop of the
+ * SearchByProjection / SearchForTriangulation / SearchBySim3 / Fuse family (src/ORBmatcher.cc:63,378,827,
+ * 1031,1198,1334,1578,1757): the pose/grid gating stays on the host, the Hamming work comes here.
+ * best_idx[nq] = candidate (train row) with the minimum distance, first in list order on ties, -1 if
+ * the list is empty; best/second initialised to 256.  HOST buffers. */
+orbfe_status orbfe_hamming_csr(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
+                               const uint32_t *off, const uint32_t *cand, int32_t *best_idx, int32_t *best,
+                               int32_t *second);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBFE_H */

@@ -1,0 +1,10 @@
+"""MI355X-native ORB front-end (ORBextractor + ORBmatcher Hamming core) behind a C-ABI.
+
+Product path: liborbfe.so (hand-written HIP for gfx950), bound through ctypes.  Nothing in this
+package imports the CPU oracle under oracle/ -- that is test infrastructure.
+"""
+from .extractor import ORBextractor  # noqa: F401
+from .matcher import ORBmatcher, feature_vector_to_csr  # noqa: F401
+from ._ffi import KP_DTYPE, OrbfeError  # noqa: F401
+
+__all__ = ["ORBextractor", "ORBmatcher", "feature_vector_to_csr", "KP_DTYPE", "OrbfeError"]

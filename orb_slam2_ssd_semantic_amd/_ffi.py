@@ -1,0 +1,115 @@
+"""ctypes binding of liborbfe.so (the C-ABI declared in include/orbfe.h).
+
+The library is HIP-only: loading works anywhere hipcc's runtime is present, but creating an
+extractor / matcher without a GPU fails loudly with ORBFE_ERR_NODEVICE -- there is no fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+ORBFE_OK, ORBFE_ERR_ARG, ORBFE_ERR_SIZE, ORBFE_ERR_CAP = 0, -1, -2, -3
+ORBFE_ERR_HIP, ORBFE_ERR_NOMEM, ORBFE_ERR_NODEVICE, ORBFE_ERR_STATE = -4, -5, -6, -7
+STAGES = ("pyramid", "fast", "octree", "blur", "describe", "total")
+
+# every extern "C" symbol include/orbfe.h declares (tests check the .so exports each of them)
+SYMBOLS = (
+    "orbfe_version", "orbfe_strerror", "orbfe_last_error", "orbfe_device_count", "orbfe_create", "orbfe_destroy",
+    "orbfe_get_scales", "orbfe_get_features_per_level", "orbfe_keypoint_capacity", "orbfe_extract",
+    "orbfe_extract_batch", "orbfe_extract_batch_device", "orbfe_synchronize", "orbfe_get_level_size",
+    "orbfe_get_pyramid_level", "orbfe_tap_blurred_level", "orbfe_tap_candidates", "orbfe_tap_selected",
+    "orbfe_set_profiling", "orbfe_get_stage_ms", "orbfe_hamming", "orbfe_matcher_create",
+    "orbfe_matcher_destroy", "orbfe_match_bf", "orbfe_match_bf_device", "orbfe_match_bf_frames_device",
+    "orbfe_search_by_bow", "orbfe_hamming_csr",
+)
+
+
+class OrbfeParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("max_width", C.c_int32),
+                ("max_height", C.c_int32), ("max_batch", C.c_int32), ("device", C.c_int32),
+                ("blur_rounding", C.c_int32)]
+
+
+class OrbfeError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        super().__init__(f"{what}: status {status}")
+
+
+_lib = None
+
+
+def lib():
+    """Load (building if needed) liborbfe.so.  torch is imported first when available so that both
+    share ONE HIP runtime (same libamdhip64 SONAME) and device pointers can be exchanged."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        import torch  # noqa: F401  (plumbing only: device memory, streams, torch.distributed)
+    except Exception:  # pragma: no cover
+        pass
+    path = _build.build()
+    L = C.CDLL(path)
+    vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+    L.orbfe_version.restype = i32
+    L.orbfe_strerror.restype = C.c_char_p
+    L.orbfe_strerror.argtypes = [i32]
+    L.orbfe_last_error.restype = C.c_char_p
+    L.orbfe_device_count.restype = i32
+    L.orbfe_create.argtypes = [C.POINTER(OrbfeParams), C.POINTER(vp)]
+    L.orbfe_destroy.argtypes = [vp]
+    L.orbfe_destroy.restype = None
+    L.orbfe_get_scales.argtypes = [vp, vp, vp, vp, vp]
+    L.orbfe_get_features_per_level.argtypes = [vp, vp]
+    L.orbfe_keypoint_capacity.argtypes = [vp]
+    L.orbfe_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp]
+    L.orbfe_extract_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+    L.orbfe_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, sz, vp, vp, i32, vp, vp]
+    L.orbfe_synchronize.argtypes = [vp]
+    L.orbfe_get_level_size.argtypes = [vp, i32, vp, vp]
+    L.orbfe_get_pyramid_level.argtypes = [vp, i32, i32, vp, i32, i32]
+    L.orbfe_tap_blurred_level.argtypes = [vp, i32, i32, vp, i32]
+    L.orbfe_tap_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.orbfe_tap_selected.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.orbfe_set_profiling.argtypes = [vp, i32]
+    L.orbfe_get_stage_ms.argtypes = [vp, vp]
+    L.orbfe_hamming.argtypes = [vp, vp]
+    L.orbfe_matcher_create.argtypes = [i32, C.POINTER(vp)]
+    L.orbfe_matcher_destroy.argtypes = [vp]
+    L.orbfe_matcher_destroy.restype = None
+    L.orbfe_match_bf.argtypes = [vp, vp, i32, vp, i32, vp, vp, f32, i32, i32, vp, vp, vp, vp]
+    L.orbfe_match_bf_device.argtypes = [vp, vp, i32, vp, i32, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp]
+    L.orbfe_match_bf_frames_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, f32, i32, i32, vp, vp, vp]
+    L.orbfe_search_by_bow.argtypes = ([vp] + [vp, i32, vp, vp, vp, vp, vp, i32] * 2 + [f32, i32, i32, i32, vp, vp])
+    L.orbfe_hamming_csr.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if f.restype is C.c_int:  # default -> orbfe_status / int32
+            f.restype = i32
+    _lib = L
+    return L
+
+
+def library_path():
+    return _build.LIB
+
+
+def last_error():
+    return lib().orbfe_last_error().decode("utf-8", "replace")
+
+
+def check(status, what):
+    if status != ORBFE_OK:
+        raise OrbfeError(status, f"{what}: {lib().orbfe_strerror(status).decode()} ({last_error()})")
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

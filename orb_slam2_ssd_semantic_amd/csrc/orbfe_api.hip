@@ -1,0 +1,770 @@
+// orbfe_api.hip -- host side of the extractor C-ABI (include/orbfe.h): constructor tables, per-size plan,
+// device buffers, stream/event plumbing.  All pixel work happens in orbfe_kernels.hip; there is no CPU path.
+//
+// Reference behaviour restated here (paths relative to /root/reference):
+//   constructor tables            src/ORBextractor.cc:399-466
+//   level sizes / pyramid layout  src/ORBextractor.cc:1117-1145
+//   FAST cell grid + skip rules   src/ORBextractor.cc:771-816
+//   quadtree roots                src/ORBextractor.cc:545-564
+//   cv::resize coefficient tables OpenCV 3.2 imgwarp.cpp
+#include <math.h>
+#include <stdarg.h>
+
+#include <algorithm>
+
+#include "orbfe_common.h"
+#include "orbfe_kernels.h"
+
+// ---------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------
+static thread_local char t_err[512] = "";
+
+void orbfe_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *orbfe_last_error(void) { return t_err; }
+extern "C" int32_t orbfe_version(void) { return ORBFE_VERSION; }
+
+extern "C" const char *orbfe_strerror(orbfe_status s)
+{
+    switch (s) {
+    case ORBFE_OK: return "ok";
+    case ORBFE_ERR_ARG: return "invalid argument";
+    case ORBFE_ERR_SIZE: return "image size outside the planned range or too small for the pyramid grid";
+    case ORBFE_ERR_CAP: return "keypoint capacity too small";
+    case ORBFE_ERR_HIP: return "HIP runtime error";
+    case ORBFE_ERR_NOMEM: return "out of memory";
+    case ORBFE_ERR_NODEVICE: return "no usable HIP device (this library has no CPU path)";
+    case ORBFE_ERR_STATE: return "call not valid in the current state";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int32_t orbfe_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(int d) : dev(d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// device buffer that only grows
+// ---------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            bytes = 0;
+            if (e != hipSuccess) return e;
+        }
+        need = (need + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct PinBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipHostMalloc(&p, need, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------------
+struct orbfe_handle {
+    orbfe_params prm;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // constructor tables (src/ORBextractor.cc:404-439)
+    float scale[ORBFE_MAX_LEVELS], inv_scale[ORBFE_MAX_LEVELS], sigma2[ORBFE_MAX_LEVELS], inv_sigma2[ORBFE_MAX_LEVELS];
+    int feat[ORBFE_MAX_LEVELS];
+    // plan for the current frame size
+    OrbPlan plan;
+    bool plan_valid = false;
+    std::vector<OrbCell> cells;
+    std::vector<OrbTab> tabs;
+    DevBuf d_plan, d_cells, d_tabs;
+    // per-batch blocks
+    DevBuf d_pyr, d_blur, d_cell_cnt, d_cell_keys, d_cell_off, d_keys, d_knode, d_sel, d_nsel, d_nkeys;
+    // host-API staging
+    DevBuf d_stage, d_okps, d_odesc, d_on;
+    PinBuf h_stage, h_okps, h_odesc, h_on;
+    // last call (for taps / mvImagePyramid)
+    const uint8_t *last_gray = nullptr;
+    int64_t last_gray_fstride = 0;
+    int32_t last_gray_pitch = 0;
+    int32_t last_nframes = 0;
+    // profiling
+    bool profiling = false, have_times = false;
+    hipEvent_t ev[ORBFE_T_COUNT + 1];
+    bool ev_ok = false;
+};
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }  // cvRound: half-to-even
+
+static void host_umax(int umax[16])
+{
+    // src/ORBextractor.cc:449-465
+    int v, v0;
+    const int vmax = (int)floorf(ORBFE_HALF_PATCH * sqrtf(2.f) / 2 + 1);
+    const int vmin = (int)ceilf(ORBFE_HALF_PATCH * sqrtf(2.f) / 2);
+    const double hp2 = ORBFE_HALF_PATCH * ORBFE_HALF_PATCH;
+    for (v = 0; v < 16; ++v) umax[v] = 0;
+    for (v = 0; v <= vmax; ++v) umax[v] = (int)lrint(sqrt(hp2 - v * v));
+    for (v = ORBFE_HALF_PATCH, v0 = 0; v >= vmin; --v) {
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
+}
+
+// cv::resize coefficient table of one axis
+static void resize_axis(int ssize, int dsize, bool is_x, OrbTab *out)
+{
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (is_x) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        auto sat = [](int v) { return (int16_t)std::min(32767, std::max(-32768, v)); };
+        out[d].s = (int16_t)s;
+        out[d].c0 = sat(cv_round_f((1.f - f) * 2048));
+        out[d].c1 = sat(cv_round_f(f * 2048));
+        out[d].pad = 0;
+    }
+}
+
+static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
+{
+    if (h->plan_valid && h->plan.w == w && h->plan.h == ht) return ORBFE_OK;
+    const int nl = h->prm.nlevels;
+    OrbPlan P;
+    memset(&P, 0, sizeof(P));
+    P.nlevels = nl;
+    P.w = w;
+    P.h = ht;
+    P.ini_th = std::min(255, std::max(0, h->prm.ini_th_fast));
+    P.min_th = std::min(255, std::max(0, h->prm.min_th_fast));
+    P.blur_rounding = h->prm.blur_rounding;
+    std::vector<OrbCell> cells;
+    std::vector<OrbTab> tabs;
+    int64_t off = 0;
+    int key_off = 0, sel_off = 0, cell_cap = 1, max_sel = 0;
+    for (int l = 0; l < nl; ++l) {
+        OrbLevel &L = P.lv[l];
+        L.w = cv_round_f((float)w * h->inv_scale[l]);   // src/ORBextractor.cc:1122
+        L.h = cv_round_f((float)ht * h->inv_scale[l]);
+        L.pitch = orb_align_up(L.w, 64);
+        L.off = (int32_t)off;
+        off = orb_align_up64(off + (int64_t)L.pitch * L.h, 256);
+        if (off > 0x7FFFFFFF) { orbfe_set_error("pyramid slice exceeds 2 GiB"); return ORBFE_ERR_SIZE; }
+        // FAST grid (src/ORBextractor.cc:780-796)
+        const int minb = ORBFE_EDGE - 3;
+        const int maxbx = L.w - ORBFE_EDGE + 3, maxby = L.h - ORBFE_EDGE + 3;
+        const float width = (float)(maxbx - minb), height = (float)(maxby - minb);
+        const float W = 30;
+        if (width < W || height < W) {
+            orbfe_set_error("level %d (%dx%d) is smaller than one 30-px FAST cell plus borders", l, L.w, L.h);
+            return ORBFE_ERR_SIZE;
+        }
+        L.ncols = (int)(width / W);
+        L.nrows = (int)(height / W);
+        L.wcell = (int)ceilf(width / L.ncols);
+        L.hcell = (int)ceilf(height / L.nrows);
+        L.cell0 = (int)cells.size();
+        int key_cap = 0;
+        for (int i = 0; i < L.nrows; ++i) {
+            const float iniY = (float)(minb + i * L.hcell);
+            float maxY = iniY + L.hcell + 6;
+            if (iniY >= maxby - 3) continue;  // :803
+            if (maxY > maxby) maxY = (float)maxby;
+            for (int j = 0; j < L.ncols; ++j) {
+                const float iniX = (float)(minb + j * L.wcell);
+                float maxX = iniX + L.wcell + 6;
+                if (iniX >= maxbx - 6) continue;  // :812
+                if (maxX > maxbx) maxX = (float)maxbx;
+                OrbCell c;
+                c.level = (uint16_t)l;
+                c.x0 = (uint16_t)iniX;
+                c.y0 = (uint16_t)iniY;
+                c.tw = (uint16_t)((int)maxX - (int)iniX);
+                c.th = (uint16_t)((int)maxY - (int)iniY);
+                c.ox = (uint16_t)(j * L.wcell);
+                c.oy = (uint16_t)(i * L.hcell);
+                c.pad = 0;
+                if (c.tw > ORBFE_TILE_MAX || c.th > ORBFE_TILE_MAX) {
+                    orbfe_set_error("FAST tile %dx%d exceeds %d", c.tw, c.th, ORBFE_TILE_MAX);
+                    return ORBFE_ERR_SIZE;
+                }
+                // strict 3x3 NMS keeps at most one keypoint per 2x2 block of the detectable interior
+                const int iw = std::max(0, (int)c.tw - 6), ih = std::max(0, (int)c.th - 6);
+                const int worst = ((iw + 1) / 2) * ((ih + 1) / 2);
+                cell_cap = std::max(cell_cap, worst);
+                key_cap += worst;
+                cells.push_back(c);
+            }
+        }
+        L.ncells = (int)cells.size() - L.cell0;
+        L.nfeat = h->feat[l];
+        // quadtree roots (src/ORBextractor.cc:545-559)
+        L.nini = (int)roundf((float)(maxbx - minb) / (float)(maxby - minb));
+        if (L.nini < 1 || L.nini > 4) {
+            orbfe_set_error("level %d aspect ratio gives %d quadtree roots (supported: 1..4)", l, L.nini);
+            return ORBFE_ERR_SIZE;
+        }
+        L.hx = (float)(maxbx - minb) / L.nini;
+        for (int i = 0; i <= L.nini; ++i) L.root_x[i] = (int)(L.hx * (float)i);
+        L.key_off = key_off;
+        L.key_cap = key_cap;
+        key_off += orb_align_up(std::max(key_cap, 1), 64);
+        L.sel_cap = std::max(L.nfeat + 2, 4 * L.nini);
+        L.sel_off = sel_off;
+        sel_off += orb_align_up(L.sel_cap, 64);
+        max_sel = std::max(max_sel, L.sel_cap);
+        L.scale = h->scale[l];
+        L.patch_size = (float)(int)(ORBFE_PATCH * h->scale[l]);  // :846
+        if (l >= 1) {
+            const OrbLevel &S = P.lv[l - 1];
+            L.xtab = (int)tabs.size();
+            tabs.resize(tabs.size() + L.w);
+            resize_axis(S.w, L.w, true, &tabs[L.xtab]);
+            L.ytab = (int)tabs.size();
+            tabs.resize(tabs.size() + L.h);
+            resize_axis(S.h, L.h, false, &tabs[L.ytab]);
+        }
+        if (L.w > 4095 + 2 * ORBFE_MINB || L.h > 4095 + 2 * ORBFE_MINB) {
+            orbfe_set_error("level %d exceeds the 12-bit key coordinate range", l);
+            return ORBFE_ERR_SIZE;
+        }
+    }
+    P.ncells = (int)cells.size();
+    P.cell_cap = cell_cap;
+    P.keys_per_frame = key_off;
+    P.sel_per_frame = sel_off;
+    int M = 64;
+    while (M < max_sel + 1) M <<= 1;
+    if (M > 4096) {
+        orbfe_set_error("nfeatures too large: %d quadtree nodes per level exceed 4096", max_sel);
+        return ORBFE_ERR_ARG;
+    }
+    P.node_cap = M;
+    P.pyr_frame_bytes = off;
+    if (tabs.empty()) tabs.resize(1);
+
+    ORBFE_HIP(h->d_plan.ensure(sizeof(OrbPlan)));
+    ORBFE_HIP(h->d_cells.ensure(cells.size() * sizeof(OrbCell)));
+    ORBFE_HIP(h->d_tabs.ensure(tabs.size() * sizeof(OrbTab)));
+    // synchronous copies: plans change rarely (frame size change), never inside the timed region
+    ORBFE_HIP(hipStreamSynchronize(h->stream));
+    ORBFE_HIP(hipMemcpy(h->d_plan.p, &P, sizeof(OrbPlan), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(h->d_cells.p, cells.data(), cells.size() * sizeof(OrbCell), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(h->d_tabs.p, tabs.data(), tabs.size() * sizeof(OrbTab), hipMemcpyHostToDevice));
+    ORBFE_HIP(orbk_prepare_octree(M));
+    h->plan = P;
+    h->cells.swap(cells);
+    h->tabs.swap(tabs);
+    h->plan_valid = true;
+    return ORBFE_OK;
+}
+
+static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
+{
+    const OrbPlan &P = h->plan;
+    const size_t B = (size_t)nframes;
+    ORBFE_HIP(h->d_pyr.ensure(B * (size_t)P.pyr_frame_bytes));
+    ORBFE_HIP(h->d_blur.ensure(B * (size_t)P.pyr_frame_bytes));
+    ORBFE_HIP(h->d_cell_cnt.ensure(B * P.ncells * sizeof(int32_t)));
+    ORBFE_HIP(h->d_cell_keys.ensure(B * P.ncells * (size_t)P.cell_cap * sizeof(uint32_t)));
+    ORBFE_HIP(h->d_cell_off.ensure(B * P.ncells * sizeof(int32_t)));
+    ORBFE_HIP(h->d_keys.ensure(B * (size_t)P.keys_per_frame * sizeof(uint32_t)));
+    ORBFE_HIP(h->d_knode.ensure(B * (size_t)P.keys_per_frame * sizeof(uint16_t)));
+    ORBFE_HIP(h->d_sel.ensure(B * (size_t)P.sel_per_frame * sizeof(uint32_t)));
+    ORBFE_HIP(h->d_nsel.ensure(B * P.nlevels * sizeof(int32_t)));
+    ORBFE_HIP(h->d_nkeys.ensure(B * P.nlevels * sizeof(int32_t)));
+    return ORBFE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// create / destroy / getters
+// ---------------------------------------------------------------------------------------------------
+extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
+{
+    if (!p || !out) { orbfe_set_error("null argument"); return ORBFE_ERR_ARG; }
+    *out = nullptr;
+    if (p->nlevels < 1 || p->nlevels > ORBFE_MAX_LEVELS || p->nfeatures < 0 || !(p->scale_factor > 1.0f) ||
+        p->max_batch < 1 || p->max_width < 1 || p->max_height < 1 || p->max_width > 4096 || p->max_height > 4096) {
+        orbfe_set_error("bad orbfe_params (nlevels 1..16, scale_factor > 1, max size <= 4096, max_batch >= 1)");
+        return ORBFE_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        orbfe_set_error("no HIP device visible; liborbfe has no CPU fallback");
+        return ORBFE_ERR_NODEVICE;
+    }
+    int dev = p->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) { orbfe_set_error("device %d out of range (%d visible)", dev, ndev); return ORBFE_ERR_ARG; }
+
+    orbfe_handle *h = new (std::nothrow) orbfe_handle();
+    if (!h) return ORBFE_ERR_NOMEM;
+    h->prm = *p;
+    h->device = dev;
+    DeviceGuard g(dev);
+    // src/ORBextractor.cc:404-421
+    const int nl = p->nlevels;
+    h->scale[0] = 1.0f;
+    h->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; ++i) {
+        h->scale[i] = h->scale[i - 1] * p->scale_factor;
+        h->sigma2[i] = h->scale[i] * h->scale[i];
+    }
+    for (int i = 0; i < nl; ++i) {
+        h->inv_scale[i] = 1.0f / h->scale[i];
+        h->inv_sigma2[i] = 1.0f / h->sigma2[i];
+    }
+    // src/ORBextractor.cc:426-439
+    const float factor = 1.0f / p->scale_factor;
+    float desired = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; ++l) {
+        h->feat[l] = cv_round_f(desired);
+        sum += h->feat[l];
+        desired *= factor;
+    }
+    h->feat[nl - 1] = std::max(p->nfeatures - sum, 0);
+
+    auto fail = [&](orbfe_status s) {
+        orbfe_destroy(h);
+        return s;
+    };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        orbfe_set_error("hipStreamCreate failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(ORBFE_ERR_HIP);
+    }
+    for (int i = 0; i <= ORBFE_T_COUNT; ++i)
+        if (hipEventCreate(&h->ev[i]) != hipSuccess) { orbfe_set_error("hipEventCreate failed"); return fail(ORBFE_ERR_HIP); }
+    h->ev_ok = true;
+    int umax[16];
+    host_umax(umax);
+    if (orbk_upload_constants(umax) != hipSuccess) {
+        orbfe_set_error("constant upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(ORBFE_ERR_HIP);
+    }
+    orbfe_status s = build_plan(h, p->max_width, p->max_height);
+    if (s != ORBFE_OK) return fail(s);
+    s = ensure_batch_buffers(h, p->max_batch);
+    if (s != ORBFE_OK) return fail(s);
+    *out = h;
+    return ORBFE_OK;
+}
+
+extern "C" void orbfe_destroy(orbfe_handle *h)
+{
+    if (!h) return;
+    DeviceGuard g(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_pyr, &h->d_blur, &h->d_cell_cnt, &h->d_cell_keys,
+                      &h->d_cell_off, &h->d_keys, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
+                      &h->d_okps, &h->d_odesc, &h->d_on};
+    for (DevBuf *b : bufs) b->release();
+    PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
+    for (PinBuf *b : pins) b->release();
+    if (h->ev_ok)
+        for (int i = 0; i <= ORBFE_T_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" orbfe_status orbfe_get_scales(const orbfe_handle *h, float *scale, float *inv_scale, float *sigma2,
+                                         float *inv_sigma2)
+{
+    if (!h) return ORBFE_ERR_ARG;
+    for (int i = 0; i < h->prm.nlevels; ++i) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv_scale) inv_scale[i] = h->inv_scale[i];
+        if (sigma2) sigma2[i] = h->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->inv_sigma2[i];
+    }
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_get_features_per_level(const orbfe_handle *h, int32_t *out)
+{
+    if (!h || !out) return ORBFE_ERR_ARG;
+    for (int i = 0; i < h->prm.nlevels; ++i) out[i] = h->feat[i];
+    return ORBFE_OK;
+}
+
+extern "C" int32_t orbfe_keypoint_capacity(const orbfe_handle *h)
+{
+    if (!h) return 0;
+    int total = 0;
+    for (int l = 0; l < h->plan.nlevels; ++l) total += h->plan.lv[l].sel_cap;
+    return orb_align_up(total, 64);
+}
+
+extern "C" orbfe_status orbfe_set_profiling(orbfe_handle *h, int32_t enable)
+{
+    if (!h) return ORBFE_ERR_ARG;
+    h->profiling = enable != 0;
+    h->have_times = false;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_get_stage_ms(orbfe_handle *h, float ms[ORBFE_T_COUNT])
+{
+    if (!h || !ms) return ORBFE_ERR_ARG;
+    if (!h->have_times) { orbfe_set_error("no profiled call yet"); return ORBFE_ERR_STATE; }
+    DeviceGuard g(h->device);
+    ORBFE_HIP(hipEventSynchronize(h->ev[ORBFE_T_TOTAL]));
+    for (int i = 0; i < ORBFE_T_TOTAL; ++i) ORBFE_HIP(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    ORBFE_HIP(hipEventElapsedTime(&ms[ORBFE_T_TOTAL], h->ev[0], h->ev[ORBFE_T_TOTAL]));
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_synchronize(orbfe_handle *h)
+{
+    if (!h) return ORBFE_ERR_ARG;
+    DeviceGuard g(h->device);
+    ORBFE_HIP(hipStreamSynchronize(h->stream));
+    return ORBFE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the batched device path (everything else funnels into this)
+// ---------------------------------------------------------------------------------------------------
+static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframes, int w, int ht, int stride,
+                              size_t frame_stride, orbfe_keypoint *d_kps, uint8_t *d_desc, int cap,
+                              int32_t *d_n_out, hipStream_t st)
+{
+    if (w > h->prm.max_width || ht > h->prm.max_height) {
+        orbfe_set_error("frame %dx%d larger than planned %dx%d", w, ht, h->prm.max_width, h->prm.max_height);
+        return ORBFE_ERR_SIZE;
+    }
+    orbfe_status s = build_plan(h, w, ht);
+    if (s != ORBFE_OK) return s;
+    s = ensure_batch_buffers(h, nframes);
+    if (s != ORBFE_OK) return s;
+    OrbLaunch a;
+    a.h_plan = &h->plan;
+    a.d_plan = (const OrbPlan *)h->d_plan.p;
+    a.d_cells = (const OrbCell *)h->d_cells.p;
+    a.d_tabs = (const OrbTab *)h->d_tabs.p;
+    a.nframes = nframes;
+    a.d_gray = d_gray;
+    a.gray_fstride = (int64_t)frame_stride;
+    a.gray_pitch = stride;
+    a.d_pyr = (uint8_t *)h->d_pyr.p;
+    a.d_blur = (uint8_t *)h->d_blur.p;
+    a.pyr_fstride = h->plan.pyr_frame_bytes;
+    a.d_cell_cnt = (int32_t *)h->d_cell_cnt.p;
+    a.d_cell_keys = (uint32_t *)h->d_cell_keys.p;
+    a.d_cell_off = (int32_t *)h->d_cell_off.p;
+    a.d_keys = (uint32_t *)h->d_keys.p;
+    a.d_knode = (uint16_t *)h->d_knode.p;
+    a.d_sel = (uint32_t *)h->d_sel.p;
+    a.d_nsel = (int32_t *)h->d_nsel.p;
+    a.d_nkeys = (int32_t *)h->d_nkeys.p;
+    a.d_kps = d_kps;
+    a.d_desc = d_desc;
+    a.cap = cap;
+    a.d_n_out = d_n_out;
+    const bool prof = h->profiling;
+    if (prof) ORBFE_HIP(hipEventRecord(h->ev[0], st));
+    ORBFE_HIP(orbk_launch_pyramid(a, st));
+    if (prof) ORBFE_HIP(hipEventRecord(h->ev[1], st));
+    ORBFE_HIP(orbk_launch_fast(a, st));
+    if (prof) ORBFE_HIP(hipEventRecord(h->ev[2], st));
+    ORBFE_HIP(orbk_launch_octree(a, st));
+    if (prof) ORBFE_HIP(hipEventRecord(h->ev[3], st));
+    ORBFE_HIP(orbk_launch_blur(a, st));
+    if (prof) ORBFE_HIP(hipEventRecord(h->ev[4], st));
+    ORBFE_HIP(orbk_launch_describe(a, st));
+    if (prof) {
+        ORBFE_HIP(hipEventRecord(h->ev[5], st));
+        h->have_times = true;
+    }
+    h->last_gray = d_gray;
+    h->last_gray_fstride = (int64_t)frame_stride;
+    h->last_gray_pitch = stride;
+    h->last_nframes = nframes;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_extract_batch_device(orbfe_handle *h, const uint8_t *d_gray, int32_t nframes,
+                                                   int32_t w, int32_t ht, int32_t stride, size_t frame_stride,
+                                                   orbfe_keypoint *d_kps, uint8_t *d_desc, int32_t cap,
+                                                   int32_t *d_n_out, void *stream)
+{
+    if (!h || !d_gray || !d_kps || !d_desc || !d_n_out || nframes < 1 || w < 1 || ht < 1 || stride < w || cap < 1 ||
+        frame_stride < (size_t)stride * (size_t)(ht - 1) + (size_t)w) {
+        orbfe_set_error("bad argument to orbfe_extract_batch_device");
+        return ORBFE_ERR_ARG;
+    }
+    DeviceGuard g(h->device);
+    return run_batch(h, d_gray, nframes, w, ht, stride, frame_stride, d_kps, d_desc, cap, d_n_out,
+                     stream ? (hipStream_t)stream : h->stream);
+}
+
+// host buffers: stage through pinned memory in chunks of max_batch frames
+static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, int nframes, int w, int ht,
+                                 int stride, orbfe_keypoint *kps, uint8_t *desc, int cap, int32_t *n_out)
+{
+    DeviceGuard g(h->device);
+    const int chunk_max = h->prm.max_batch;
+    const int pitch = orb_align_up(w, 64);
+    const size_t fbytes = (size_t)pitch * ht;
+    orbfe_status worst = ORBFE_OK;
+    for (int f0 = 0; f0 < nframes; f0 += chunk_max) {
+        const int nb = std::min(chunk_max, nframes - f0);
+        ORBFE_HIP(h->h_stage.ensure(fbytes * nb));
+        ORBFE_HIP(h->d_stage.ensure(fbytes * nb));
+        ORBFE_HIP(h->d_okps.ensure(sizeof(orbfe_keypoint) * (size_t)cap * nb));
+        ORBFE_HIP(h->d_odesc.ensure((size_t)32 * cap * nb));
+        ORBFE_HIP(h->d_on.ensure(sizeof(int32_t) * nb));
+        ORBFE_HIP(h->h_okps.ensure(sizeof(orbfe_keypoint) * (size_t)cap * nb));
+        ORBFE_HIP(h->h_odesc.ensure((size_t)32 * cap * nb));
+        ORBFE_HIP(h->h_on.ensure(sizeof(int32_t) * nb));
+        for (int f = 0; f < nb; ++f) {
+            uint8_t *dst = (uint8_t *)h->h_stage.p + fbytes * f;
+            const uint8_t *src = grays[f0 + f];
+            for (int y = 0; y < ht; ++y) memcpy(dst + (size_t)y * pitch, src + (size_t)y * stride, (size_t)w);
+        }
+        ORBFE_HIP(hipMemcpyAsync(h->d_stage.p, h->h_stage.p, fbytes * nb, hipMemcpyHostToDevice, h->stream));
+        orbfe_status s = run_batch(h, (const uint8_t *)h->d_stage.p, nb, w, ht, pitch, fbytes,
+                                   (orbfe_keypoint *)h->d_okps.p, (uint8_t *)h->d_odesc.p, cap, (int32_t *)h->d_on.p,
+                                   h->stream);
+        if (s != ORBFE_OK) return s;
+        ORBFE_HIP(hipMemcpyAsync(h->h_on.p, h->d_on.p, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, h->stream));
+        ORBFE_HIP(hipMemcpyAsync(h->h_okps.p, h->d_okps.p, sizeof(orbfe_keypoint) * (size_t)cap * nb,
+                                 hipMemcpyDeviceToHost, h->stream));
+        ORBFE_HIP(hipMemcpyAsync(h->h_odesc.p, h->d_odesc.p, (size_t)32 * cap * nb, hipMemcpyDeviceToHost, h->stream));
+        ORBFE_HIP(hipStreamSynchronize(h->stream));
+        for (int f = 0; f < nb; ++f) {
+            const int n = ((int32_t *)h->h_on.p)[f];
+            n_out[f0 + f] = n;
+            if (n > cap) { worst = ORBFE_ERR_CAP; continue; }
+            memcpy(kps + (size_t)(f0 + f) * cap, (orbfe_keypoint *)h->h_okps.p + (size_t)f * cap,
+                   sizeof(orbfe_keypoint) * (size_t)n);
+            memcpy(desc + (size_t)(f0 + f) * cap * 32, (uint8_t *)h->h_odesc.p + (size_t)f * cap * 32, (size_t)32 * n);
+        }
+    }
+    if (worst == ORBFE_ERR_CAP) orbfe_set_error("cap=%d too small; n_out holds the required counts", cap);
+    return worst;
+}
+
+extern "C" orbfe_status orbfe_extract(orbfe_handle *h, const uint8_t *gray, int32_t w, int32_t ht, int32_t stride,
+                                      orbfe_keypoint *kps, uint8_t *desc, int32_t cap, int32_t *n_out)
+{
+    if (!h) { orbfe_set_error("null handle"); return ORBFE_ERR_ARG; }
+    if (!gray || w == 0 || ht == 0) return ORBFE_OK;  // empty image: silent return, outputs untouched (:1055-1056)
+    if (!kps || !desc || !n_out || w < 0 || ht < 0 || stride < w || cap < 1) {
+        orbfe_set_error("bad argument to orbfe_extract");
+        return ORBFE_ERR_ARG;
+    }
+    return extract_host(h, &gray, 1, w, ht, stride, kps, desc, cap, n_out);
+}
+
+extern "C" orbfe_status orbfe_extract_batch(orbfe_handle *h, const uint8_t *const *grays, int32_t nframes, int32_t w,
+                                            int32_t ht, int32_t stride, orbfe_keypoint *kps, uint8_t *desc,
+                                            int32_t cap, int32_t *n_out)
+{
+    if (!h) { orbfe_set_error("null handle"); return ORBFE_ERR_ARG; }
+    if (nframes == 0 || w == 0 || ht == 0) return ORBFE_OK;
+    if (!grays || !kps || !desc || !n_out || nframes < 0 || w < 0 || ht < 0 || stride < w || cap < 1) {
+        orbfe_set_error("bad argument to orbfe_extract_batch");
+        return ORBFE_ERR_ARG;
+    }
+    for (int i = 0; i < nframes; ++i)
+        if (!grays[i]) { orbfe_set_error("grays[%d] is null", i); return ORBFE_ERR_ARG; }
+    return extract_host(h, grays, nframes, w, ht, stride, kps, desc, cap, n_out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mvImagePyramid + stage taps
+// ---------------------------------------------------------------------------------------------------
+static orbfe_status check_tap(orbfe_handle *h, int frame, int level)
+{
+    if (!h) return ORBFE_ERR_ARG;
+    if (!h->plan_valid || h->last_nframes == 0) { orbfe_set_error("no extract call yet"); return ORBFE_ERR_STATE; }
+    if (frame < 0 || frame >= h->last_nframes || level < 0 || level >= h->plan.nlevels) {
+        orbfe_set_error("frame/level out of range");
+        return ORBFE_ERR_ARG;
+    }
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_get_level_size(const orbfe_handle *h, int32_t level, int32_t *w, int32_t *ht)
+{
+    if (!h || !h->plan_valid || level < 0 || level >= h->plan.nlevels) return ORBFE_ERR_ARG;
+    if (w) *w = h->plan.lv[level].w;
+    if (ht) *ht = h->plan.lv[level].h;
+    return ORBFE_OK;
+}
+
+static inline int host_reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+static orbfe_status fetch_level(orbfe_handle *h, const uint8_t *base, int pitch, int w, int ht, uint8_t *dst,
+                                int dst_stride, int border)
+{
+    std::vector<uint8_t> tmp((size_t)w * ht);
+    ORBFE_HIP(hipStreamSynchronize(h->stream));
+    ORBFE_HIP(hipMemcpy2D(tmp.data(), (size_t)w, base, (size_t)pitch, (size_t)w, (size_t)ht, hipMemcpyDeviceToHost));
+    for (int y = -border; y < ht + border; ++y) {
+        const uint8_t *s = tmp.data() + (size_t)host_reflect101(y, ht) * w;
+        uint8_t *d = dst + (size_t)(y + border) * dst_stride;
+        if (border == 0) memcpy(d, s, (size_t)w);
+        else
+            for (int x = -border; x < w + border; ++x) d[x + border] = s[host_reflect101(x, w)];  // :1136-1142
+    }
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_get_pyramid_level(orbfe_handle *h, int32_t frame, int32_t level, uint8_t *dst,
+                                                int32_t dst_stride, int32_t with_border)
+{
+    orbfe_status s = check_tap(h, frame, level);
+    if (s != ORBFE_OK) return s;
+    if (!dst) return ORBFE_ERR_ARG;
+    DeviceGuard g(h->device);
+    const OrbLevel &L = h->plan.lv[level];
+    const int border = with_border ? ORBFE_EDGE : 0;
+    if (dst_stride < L.w + 2 * border) return ORBFE_ERR_ARG;
+    if (level == 0)
+        return fetch_level(h, h->last_gray + (int64_t)frame * h->last_gray_fstride, h->last_gray_pitch, L.w, L.h, dst,
+                           dst_stride, border);
+    return fetch_level(h, (uint8_t *)h->d_pyr.p + (int64_t)frame * h->plan.pyr_frame_bytes + L.off, L.pitch, L.w, L.h,
+                       dst, dst_stride, border);
+}
+
+extern "C" orbfe_status orbfe_tap_blurred_level(orbfe_handle *h, int32_t frame, int32_t level, uint8_t *dst,
+                                                int32_t dst_stride)
+{
+    orbfe_status s = check_tap(h, frame, level);
+    if (s != ORBFE_OK) return s;
+    if (!dst) return ORBFE_ERR_ARG;
+    DeviceGuard g(h->device);
+    const OrbLevel &L = h->plan.lv[level];
+    if (dst_stride < L.w) return ORBFE_ERR_ARG;
+    return fetch_level(h, (uint8_t *)h->d_blur.p + (int64_t)frame * h->plan.pyr_frame_bytes + L.off, L.pitch, L.w, L.h,
+                       dst, dst_stride, 0);
+}
+
+extern "C" orbfe_status orbfe_tap_candidates(orbfe_handle *h, int32_t frame, int32_t level, float *xyr, int32_t cap,
+                                             int32_t *n)
+{
+    orbfe_status s = check_tap(h, frame, level);
+    if (s != ORBFE_OK) return s;
+    if (!n) return ORBFE_ERR_ARG;
+    DeviceGuard g(h->device);
+    const OrbPlan &P = h->plan;
+    const OrbLevel &L = P.lv[level];
+    ORBFE_HIP(hipStreamSynchronize(h->stream));
+    int32_t nk = 0;
+    ORBFE_HIP(hipMemcpy(&nk, (int32_t *)h->d_nkeys.p + (size_t)frame * P.nlevels + level, sizeof(int32_t),
+                        hipMemcpyDeviceToHost));
+    *n = nk;
+    if (nk > cap) return ORBFE_ERR_CAP;
+    if (nk == 0) return ORBFE_OK;
+    if (!xyr) return ORBFE_ERR_ARG;
+    std::vector<uint32_t> keys((size_t)nk);
+    ORBFE_HIP(hipMemcpy(keys.data(), (uint32_t *)h->d_keys.p + (size_t)frame * P.keys_per_frame + L.key_off,
+                        sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nk; ++i) {
+        xyr[3 * i] = (float)orb_key_x(keys[i]);
+        xyr[3 * i + 1] = (float)orb_key_y(keys[i]);
+        xyr[3 * i + 2] = (float)orb_key_r(keys[i]);
+    }
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_tap_selected(orbfe_handle *h, int32_t frame, int32_t level, float *xyr, int32_t cap,
+                                           int32_t *n)
+{
+    orbfe_status s = check_tap(h, frame, level);
+    if (s != ORBFE_OK) return s;
+    if (!n) return ORBFE_ERR_ARG;
+    DeviceGuard g(h->device);
+    const OrbPlan &P = h->plan;
+    const OrbLevel &L = P.lv[level];
+    ORBFE_HIP(hipStreamSynchronize(h->stream));
+    int32_t ns = 0;
+    ORBFE_HIP(hipMemcpy(&ns, (int32_t *)h->d_nsel.p + (size_t)frame * P.nlevels + level, sizeof(int32_t),
+                        hipMemcpyDeviceToHost));
+    *n = ns;
+    if (ns > cap) return ORBFE_ERR_CAP;
+    if (ns == 0) return ORBFE_OK;
+    if (!xyr) return ORBFE_ERR_ARG;
+    std::vector<uint32_t> keys((size_t)ns);
+    ORBFE_HIP(hipMemcpy(keys.data(), (uint32_t *)h->d_sel.p + (size_t)frame * P.sel_per_frame + L.sel_off,
+                        sizeof(uint32_t) * (size_t)ns, hipMemcpyDeviceToHost));
+    for (int i = 0; i < ns; ++i) {
+        xyr[3 * i] = (float)orb_key_x(keys[i]);
+        xyr[3 * i + 1] = (float)orb_key_y(keys[i]);
+        xyr[3 * i + 2] = (float)orb_key_r(keys[i]);
+    }
+    return ORBFE_OK;
+}

@@ -1,0 +1,99 @@
+// orbfe_common.h -- internal definitions shared by the HIP translation units of liborbfe.so.
+// Product code: never includes anything from oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "orbfe.h"
+
+#define ORBFE_MAX_LEVELS 16
+#define ORBFE_EDGE 19        // EDGE_THRESHOLD   (reference src/ORBextractor.cc:54)
+#define ORBFE_HALF_PATCH 15  // HALF_PATCH_SIZE  (:53)
+#define ORBFE_PATCH 31       // PATCH_SIZE       (:52)
+#define ORBFE_MINB 16        // minBorderX/Y = EDGE_THRESHOLD-3 (:780)
+#define ORBFE_TILE_MAX 72    // FAST cell tile edge upper bound (cell+6 <= 66 when nCols == 1)
+
+// ---- thread-local error text ---------------------------------------------------------------------
+void orbfe_set_error(const char *fmt, ...);
+
+#define ORBFE_HIP(call)                                                                          \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            orbfe_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,    \
+                            __LINE__);                                                           \
+            return e__ == hipErrorOutOfMemory ? ORBFE_ERR_NOMEM : ORBFE_ERR_HIP;                 \
+        }                                                                                        \
+    } while (0)
+
+// ---- device-visible plan -------------------------------------------------------------------------
+// One entry per pyramid level.  Level 0 is read in place from the caller's frame (pitch = stride);
+// levels >= 1 live in the handle's pyramid block at byte offset `off` of each frame's slice.
+struct OrbLevel {
+    int32_t w, h;          // level size                      (src/ORBextractor.cc:1121-1122)
+    int32_t pitch;         // row pitch in bytes inside the pyramid / blurred blocks
+    int32_t off;           // byte offset inside one frame's pyramid (and blurred) slice
+    int32_t ncols, nrows;  // FAST grid                        (:792-796)
+    int32_t wcell, hcell;
+    int32_t cell0, ncells; // this level's cells in the frame's cell table (skipped cells removed)
+    int32_t nfeat;         // mnFeaturesPerLevel[l]            (:426-439)
+    int32_t nini;          // quadtree roots                   (:545)
+    float hx;              // root width                       (:547)
+    int32_t key_off;       // first key slot of this level in a frame's key scratch
+    int32_t key_cap;       // worst-case number of FAST candidates of this level
+    int32_t sel_off;       // first slot of this level in a frame's selected-keypoint scratch
+    int32_t sel_cap;
+    int32_t xtab, ytab;    // offsets into the resize tables (entries), level >= 1
+    float scale;           // mvScaleFactor[l]
+    float patch_size;      // (float)(int)(PATCH_SIZE * scale)  (:846)
+    int32_t root_x[5];     // root box x boundaries, nini+1 entries (nini <= 4)
+};
+
+// one FAST cell = one cv::FAST call of the reference (:798-838)
+struct OrbCell {
+    uint16_t level;
+    uint16_t x0, y0;  // tile origin in level coordinates (iniX, iniY)
+    uint16_t tw, th;  // tile size (maxX-iniX, maxY-iniY)
+    uint16_t ox, oy;  // j*wCell, i*hCell: added to tile-relative keypoints (:831-832)
+    uint16_t pad;
+};
+
+// bilinear resize table entry: source index + the two 11-bit coefficients
+struct OrbTab {
+    int16_t s;   // sx / sy (un-clamped for y)
+    int16_t c0;  // (1-f)*2048 rounded half-even
+    int16_t c1;  // f*2048
+    int16_t pad;
+};
+
+struct OrbPlan {
+    int32_t nlevels;
+    int32_t w, h;              // level-0 size this plan was built for
+    int32_t ncells;            // cells per frame (all levels)
+    int32_t cell_cap;          // key slots per cell
+    int32_t keys_per_frame;    // key scratch entries per frame
+    int32_t sel_per_frame;     // selected-keypoint scratch entries per frame
+    int32_t node_cap;          // quadtree node capacity (power of two)
+    int32_t ini_th, min_th;
+    int32_t blur_rounding;
+    int64_t pyr_frame_bytes;   // bytes of one frame's pyramid slice (levels 1..n-1; level 0 kept too when owned)
+    OrbLevel lv[ORBFE_MAX_LEVELS];
+};
+
+// packed FAST candidate: x (12 bit) | y (12 bit) << 12 | response (8 bit) << 24, detection-window coords
+__host__ __device__ inline uint32_t orb_pack_key(int x, int y, int r)
+{
+    return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)r << 24);
+}
+__host__ __device__ inline int orb_key_x(uint32_t k) { return (int)(k & 0xFFFu); }
+__host__ __device__ inline int orb_key_y(uint32_t k) { return (int)((k >> 12) & 0xFFFu); }
+__host__ __device__ inline int orb_key_r(uint32_t k) { return (int)(k >> 24); }
+
+static inline int orb_align_up(int v, int a) { return (v + a - 1) / a * a; }
+static inline int64_t orb_align_up64(int64_t v, int64_t a) { return (v + a - 1) / a * a; }

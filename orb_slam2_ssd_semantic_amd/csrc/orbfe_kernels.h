@@ -1,0 +1,42 @@
+// orbfe_kernels.h -- launcher interface between the host API (orbfe_api.hip) and the kernels.
+#pragma once
+#include "orbfe_common.h"
+
+// everything one batched extractor call needs on the device
+struct OrbLaunch {
+    const OrbPlan *h_plan;  // host copy
+    const OrbPlan *d_plan;  // device copy
+    const OrbCell *d_cells;
+    const OrbTab *d_tabs;
+    int32_t nframes;
+    // input frames (level 0, read in place)
+    const uint8_t *d_gray;
+    int64_t gray_fstride;
+    int32_t gray_pitch;
+    // handle-owned blocks, one slice per frame
+    uint8_t *d_pyr;
+    uint8_t *d_blur;
+    int64_t pyr_fstride;
+    int32_t *d_cell_cnt;
+    uint32_t *d_cell_keys;
+    int32_t *d_cell_off;
+    uint32_t *d_keys;
+    uint16_t *d_knode;
+    uint32_t *d_sel;
+    int32_t *d_nsel;
+    int32_t *d_nkeys;
+    // outputs
+    orbfe_keypoint *d_kps;
+    uint8_t *d_desc;
+    int32_t cap;
+    int32_t *d_n_out;
+};
+
+hipError_t orbk_upload_constants(const int *umax16);
+size_t orbk_octree_lds_bytes(int node_cap);
+hipError_t orbk_prepare_octree(int node_cap);
+hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st);
+hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st);
+hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st);
+hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st);
+hipError_t orbk_launch_describe(const OrbLaunch &a, hipStream_t st);

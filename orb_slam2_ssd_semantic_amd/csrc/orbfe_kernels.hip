@@ -1,0 +1,845 @@
+// orbfe_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the ORB extractor.
+//
+// Reference behaviour restated (paths relative to /root/reference):
+//   K1 k_pyr_resize      ComputePyramid + cv::resize INTER_LINEAR   src/ORBextractor.cc:1117-1145
+//   K2 k_fast_cells      per-cell cv::FAST + NMS + minTh fallback   src/ORBextractor.cc:798-838
+//   K3 k_octree          DistributeOctTree / DivideNode             src/ORBextractor.cc:478-765
+//   K4 k_blur7           GaussianBlur 7x7 sigma 2 REFLECT_101       src/ORBextractor.cc:1094-1095
+//   K5 k_orient_describe IC_Angle + computeOrbDescriptor + rescale  src/ORBextractor.cc:59-131, 846-857, 1103-1110
+//
+// Integer / byte work bounded by HBM and LDS, no MFMA.  Float steps that decide an output bit use
+// explicitly rounded single operations (__fmul_rn/__fadd_rn/__fdiv_rn, no FMA contraction).
+#include "orbfe_common.h"
+#include "orbfe_kernels.h"
+#include "orbfe_pattern.inc"
+
+__constant__ signed char c_pattern[1024];
+// umax[v] of the circular patch (src/ORBextractor.cc:449-465): {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}
+__constant__ int c_umax[16];
+
+hipError_t orbk_upload_constants(const int *umax16)
+{
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), orbfe_pattern31_host, 1024);
+    if (e != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------------
+struct FrameSrc {
+    const uint8_t *l0;   // level-0 frames (caller's buffer)
+    int64_t l0_fstride;  // bytes between frames
+    int32_t l0_pitch;    // row pitch of level 0
+    uint8_t *pyr;        // levels >= 1 (handle-owned)
+    int64_t pyr_fstride;
+};
+
+__device__ __forceinline__ const uint8_t *level_ptr(const FrameSrc &fs, const OrbLevel &L, int level, int b,
+                                                    int *pitch)
+{
+    if (level == 0) {
+        *pitch = fs.l0_pitch;
+        return fs.l0 + (int64_t)b * fs.l0_fstride;
+    }
+    *pitch = L.pitch;
+    return fs.pyr + (int64_t)b * fs.pyr_fstride + L.off;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over the block (blockDim.x multiple of 64, <= 1024); s_wave = 17 ints of LDS
+__device__ __forceinline__ int block_excl_scan(int v, int *s_wave, int *total)
+{
+    const int incl = wave_incl_scan(v);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 63) s_wave[wid] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        int t = s_wave[w];
+        if (w < wid) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    // cv::borderInterpolate(BORDER_REFLECT_101); len >= 2 in every use here, |overshoot| <= 3
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * len - 2 - p;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1  bilinear pyramid level:  dst(level) = resize(src(level-1))      
+// One thread per destination pixel, 64x4 tiles; coefficient tables precomputed on the host in fp64/fp32
+// exactly as cv::resize does.  All arithmetic is int32.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_resize(const OrbPlan *__restrict__ plan, FrameSrc fs, int level,
+                                                    const OrbTab *__restrict__ tabs)
+{
+    const OrbLevel &D = plan->lv[level];
+    const OrbLevel &S = plan->lv[level - 1];
+    const int b = blockIdx.z;
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= D.w || dy >= D.h) return;
+    int sp;
+    const uint8_t *src = level_ptr(fs, S, level - 1, b, &sp);
+    uint8_t *dst = fs.pyr + (int64_t)b * fs.pyr_fstride + D.off;
+    const OrbTab tx = tabs[D.xtab + dx];
+    const OrbTab ty = tabs[D.ytab + dy];
+    const int sx0 = tx.s, sx1 = min(tx.s + 1, S.w - 1);
+    const int sy0 = min(max((int)ty.s, 0), S.h - 1), sy1 = min(max((int)ty.s + 1, 0), S.h - 1);
+    const uint8_t *r0 = src + (int64_t)sy0 * sp, *r1 = src + (int64_t)sy1 * sp;
+    const int h0 = r0[sx0] * tx.c0 + r0[sx1] * tx.c1;
+    const int h1 = r1[sx0] * tx.c0 + r1[sx1] * tx.c1;
+    const int v = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    dst[(int64_t)dy * D.pitch + dx] = (uint8_t)v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2  FAST-9/16 per cell.  One workgroup = one cv::FAST call of the reference.
+//   tile -> LDS, arc strength A(x,y) = max(A_dark, A_bright) for every interior pixel -> LDS,
+//   corner at t <=> A > t, cv score = A-1; 3x3 strict NMS at iniTh; if the cell is empty, again at minTh
+//   (the strength map is threshold independent, so the fallback costs no second scoring pass);
+//   survivors are emitted in raster order through a block scan (output order is part of the contract).
+// ---------------------------------------------------------------------------------------------------
+#define TP ORBFE_TILE_MAX
+
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+__device__ __forceinline__ int fast_arc_strength(const uint8_t *p /* LDS, pitch TP */)
+{
+    const int v = p[0];
+    int d[16];
+    d[0] = v - p[3 * TP + 0];
+    d[1] = v - p[3 * TP + 1];
+    d[2] = v - p[2 * TP + 2];
+    d[3] = v - p[1 * TP + 3];
+    d[4] = v - p[0 * TP + 3];
+    d[5] = v - p[-1 * TP + 3];
+    d[6] = v - p[-2 * TP + 2];
+    d[7] = v - p[-3 * TP + 1];
+    d[8] = v - p[-3 * TP + 0];
+    d[9] = v - p[-3 * TP - 1];
+    d[10] = v - p[-2 * TP - 2];
+    d[11] = v - p[-1 * TP - 3];
+    d[12] = v - p[0 * TP - 3];
+    d[13] = v - p[1 * TP - 3];
+    d[14] = v - p[2 * TP - 2];
+    d[15] = v - p[3 * TP - 1];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    }
+    int a_dark = -512, b_min = 512;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        a_dark = max(a_dark, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+        b_min = min(b_min, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+    }
+    return max(a_dark, -b_min);
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan *__restrict__ plan, FrameSrc fs,
+                                                    const OrbCell *__restrict__ cells,
+                                                    int32_t *__restrict__ cell_cnt,
+                                                    uint32_t *__restrict__ cell_keys)
+{
+    __shared__ uint8_t s_tile[TP * TP];
+    __shared__ uint8_t s_str[TP * TP];  // arc strength A clamped to [0,255]; 0 outside the interior
+    __shared__ int s_wave[17];
+
+    const int cell = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const OrbCell c = cells[cell];
+    const OrbLevel &L = plan->lv[c.level];
+    int pitch;
+    const uint8_t *img = level_ptr(fs, L, c.level, b, &pitch);
+    const int tw = c.tw, th = c.th;
+
+    for (int idx = tid; idx < tw * th; idx += 256) {
+        const int y = idx / tw, x = idx - y * tw;
+        s_tile[y * TP + x] = img[(int64_t)(c.y0 + y) * pitch + c.x0 + x];
+        s_str[y * TP + x] = 0;
+    }
+    __syncthreads();
+
+    const int iw = tw - 6, ih = th - 6;  // detectable interior [3,tw-3) x [3,th-3)
+    const int npix = (iw > 0 && ih > 0) ? iw * ih : 0;
+    for (int idx = tid; idx < npix; idx += 256) {
+        const int y = idx / iw, x = idx - y * iw;
+        const int a = fast_arc_strength(&s_tile[(y + 3) * TP + (x + 3)]);
+        s_str[(y + 3) * TP + (x + 3)] = (uint8_t)min(max(a, 0), 255);
+    }
+    __syncthreads();
+
+    // contiguous raster chunk per thread -> ordered emission with one block scan
+    const int per = (npix + 255) >> 8;  // <= 15 for 66x66 tiles
+    const int p0 = tid * per, p1 = min(p0 + per, npix);
+    uint32_t mask = 0;
+    int total = 0, base = 0, t = plan->ini_th;
+    for (int pass = 0; pass < 2; ++pass) {
+        mask = 0;
+        for (int p = p0; p < p1; ++p) {
+            const int y = p / iw + 3, x = p - (y - 3) * iw + 3;
+            const uint8_t *s = &s_str[y * TP + x];
+            const int a = s[0];
+            if (a <= t) continue;
+            const int sc = a - 1;
+            bool ok = true;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dx == 0 && dy == 0) continue;
+                    const int q = s[dy * TP + dx];
+                    const int qs = q > t ? q - 1 : 0;
+                    ok = ok && (sc > qs);
+                }
+            if (ok) mask |= 1u << (p - p0);
+        }
+        base = block_excl_scan(__popc(mask), s_wave, &total);
+        if (total > 0 || plan->min_th == t) break;
+        t = plan->min_th;  // src/ORBextractor.cc:821-825
+    }
+
+    const int64_t slot0 = ((int64_t)b * plan->ncells + cell) * plan->cell_cap;
+    if (tid == 0) cell_cnt[(int64_t)b * plan->ncells + cell] = total;
+    int k = base;
+    while (mask) {
+        const int bit = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const int p = p0 + bit;
+        const int y = p / iw + 3, x = p - (y - 3) * iw + 3;
+        const int sc = (int)s_str[y * TP + x] - 1;
+        cell_keys[slot0 + k] = orb_pack_key(x + c.ox, y + c.oy, sc);
+        ++k;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3  DistributeOctTree on the device.  One workgroup per (frame, level).
+//
+// The reference keeps a std::list of nodes: a pass visits nodes in some processing order, replaces each
+// visited node by its non-empty children (push_front in the order n1,n2,n3,n4) and may stop early once
+// the list holds >= N nodes.  Both of its loops are instances of one generic pass:
+//     breadth-first loop (:608-667)  processing order = list order,           never stops early
+//     largest-first loop (:678-739)  processing order = (size desc, creation desc), stops at >= N
+// and the list after a pass that processed ranks 0..R-1 is
+//     [children(P[R-1]) n4..n1] ... [children(P[0]) n4..n1]  ++  [unprocessed nodes in old order].
+// Positions therefore follow from prefix sums over the processing order, child membership from
+// per-node quadrant counters (LDS atomics), and the final "first strongest key" from an LDS atomicMax
+// on (response << 24 | ~original_index).  Keys never move: each key only carries its node index.
+// Equal-size ties in the largest-first order are broken by creation order (the reference compares heap
+// addresses there, :686 -- see DESIGN.md "quadtree contract").
+// ---------------------------------------------------------------------------------------------------
+#define QT 256
+#define KNODE_MASK 0x3FFFu
+
+struct QtShared {
+    int16_t *box[2][4];  // ulx, uly, urx, bry
+    int32_t *cnt[2];
+    int32_t *cc;      // [M*4] child counts, then child positions
+    int32_t *P;       // processing order -> node index
+    int32_t *rankOf;  // node index -> processing rank or -1
+    int32_t *acc;     // inclusive sums over ranks
+    int32_t *newIdx;  // new position of unprocessed nodes
+    unsigned long long *skey;
+    int32_t *misc;
+};
+
+__device__ __forceinline__ void qt_carve(char *base, int M, QtShared &q)
+{
+    char *p = base;
+    q.skey = (unsigned long long *)p; p += (size_t)M * 8;
+    q.cc = (int32_t *)p; p += (size_t)M * 16;
+    for (int i = 0; i < 2; ++i) { q.cnt[i] = (int32_t *)p; p += (size_t)M * 4; }
+    q.P = (int32_t *)p; p += (size_t)M * 4;
+    q.rankOf = (int32_t *)p; p += (size_t)M * 4;
+    q.acc = (int32_t *)p; p += (size_t)M * 4;
+    q.newIdx = (int32_t *)p; p += (size_t)M * 4;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) { q.box[i][j] = (int16_t *)p; p += (size_t)M * 2; }
+    q.misc = (int32_t *)p;
+}
+
+size_t orbk_octree_lds_bytes(int M) { return (size_t)M * (8 + 16 + 8 + 16 + 16) + 64 * 4; }
+
+// chunked block-wide inclusive scan over arr[0..n) in LDS (in place). Returns total.
+__device__ int qt_scan_inclusive(int32_t *arr, int n, int *s_wave)
+{
+    const int tid = threadIdx.x;
+    const int per = (n + QT - 1) / QT;
+    const int i0 = tid * per, i1 = min(i0 + per, n);
+    int sum = 0;
+    for (int i = i0; i < i1; ++i) sum += arr[i];
+    int total;
+    int base = block_excl_scan(sum, s_wave, &total);
+    for (int i = i0; i < i1; ++i) {
+        base += arr[i];
+        arr[i] = base;
+    }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(QT) void k_octree(const OrbPlan *__restrict__ plan,
+                                               const int32_t *__restrict__ cell_cnt,
+                                               const uint32_t *__restrict__ cell_keys,
+                                               int32_t *__restrict__ cell_off,   // [B][ncells] scratch
+                                               uint32_t *__restrict__ keys,      // [B][keys_per_frame] scratch
+                                               uint16_t *__restrict__ knode,     // [B][keys_per_frame] scratch
+                                               uint32_t *__restrict__ sel,       // [B][sel_per_frame] out
+                                               int32_t *__restrict__ nsel,       // [B][nlevels] out
+                                               int32_t *__restrict__ nkeys_out)  // [B][nlevels] out (taps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_wave[17];
+    const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const OrbLevel &L = plan->lv[level];
+    const int M = plan->node_cap;
+    const int N = L.nfeat;
+    QtShared q;
+    qt_carve(smem, M, q);
+    int32_t *misc = q.misc;
+
+    // ---- prologue: compact this level's per-cell key slots into the reference candidate order ----
+    const int32_t *ccnt = cell_cnt + (int64_t)b * plan->ncells + L.cell0;
+    int32_t *coff = cell_off + (int64_t)b * plan->ncells + L.cell0;
+    uint32_t *K = keys + (int64_t)b * plan->keys_per_frame + L.key_off;
+    uint16_t *KN = knode + (int64_t)b * plan->keys_per_frame + L.key_off;
+    int n = 0;
+    for (int c0 = 0; c0 < L.ncells; c0 += QT) {
+        const int c = c0 + tid;
+        const int v = c < L.ncells ? ccnt[c] : 0;
+        int tot;
+        const int ex = block_excl_scan(v, s_wave, &tot);
+        if (c < L.ncells) coff[c] = n + ex;
+        n += tot;
+    }
+    __syncthreads();
+    {
+        const int wid = tid >> 6, lane = tid & 63;
+        for (int c = wid; c < L.ncells; c += QT / 64) {
+            const int cn = ccnt[c], o = coff[c];
+            const uint32_t *src = cell_keys + ((int64_t)b * plan->ncells + L.cell0 + c) * plan->cell_cap;
+            for (int k = lane; k < cn; k += 64) K[o + k] = src[k];
+        }
+    }
+    if (tid == 0) nkeys_out[b * plan->nlevels + level] = n;
+    __syncthreads();
+
+    // ---- roots (:545-587): nini boxes, keys by (int)(x / hX), empty roots erased ----
+    int cur = 0;
+    const int nini = L.nini;
+    if (tid < 8) q.cc[tid] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += QT) {
+        const int x = orb_key_x(K[k]);
+        int r = (int)__fdiv_rn((float)x, L.hx);
+        r = min(max(r, 0), nini - 1);
+        KN[k] = (uint16_t)r;
+        atomicAdd(&q.cc[r], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int S0 = 0;
+        for (int r = 0; r < nini; ++r) {
+            const int cn = q.cc[r];
+            q.newIdx[r] = S0;
+            if (cn > 0) {
+                q.box[0][0][S0] = (int16_t)L.root_x[r];
+                q.box[0][1][S0] = 0;
+                q.box[0][2][S0] = (int16_t)L.root_x[r + 1];
+                q.box[0][3][S0] = (int16_t)(L.h - 2 * ORBFE_MINB);  // maxBorderY - minBorderY
+                q.cnt[0][S0] = cn;
+                ++S0;
+            }
+        }
+        // initial processing order: multi-key roots in list order
+        int m0 = 0;
+        for (int i = 0; i < S0; ++i) {
+            if (q.cnt[0][i] > 1) { q.P[m0] = i; q.rankOf[i] = m0; ++m0; }
+            else q.rankOf[i] = -1;
+        }
+        misc[0] = S0;
+        misc[1] = m0;
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += QT) KN[k] = (uint16_t)q.newIdx[KN[k]];
+    int S = misc[0], m = misc[1];
+    int modeB = 0;
+    __syncthreads();
+
+    // ---- passes ----
+    for (int guard = 0; guard < 64; ++guard) {
+        const int nx = cur ^ 1;
+        // 1. quadrant counts of every multi-key node
+        for (int i = tid; i < S * 4; i += QT) q.cc[i] = 0;
+        __syncthreads();
+        for (int k = tid; k < n; k += QT) {
+            const int i = KN[k] & KNODE_MASK;
+            if (q.cnt[cur][i] > 1) {
+                const uint32_t key = K[k];
+                const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
+                const int midx = ulx + ((q.box[cur][2][i] - ulx + 1) >> 1);  // UL.x + ceil(w/2)  (:480)
+                const int midy = uly + ((q.box[cur][3][i] - uly + 1) >> 1);
+                const int qd = (orb_key_x(key) < midx ? 0 : 1) + (orb_key_y(key) < midy ? 0 : 2);
+                atomicAdd(&q.cc[i * 4 + qd], 1);
+                KN[k] = (uint16_t)(i | (qd << 14));
+            }
+        }
+        __syncthreads();
+        // 2. non-empty children per processing rank, inclusive sums, stop rank R
+        for (int r = tid; r < m; r += QT) {
+            const int i = q.P[r];
+            q.acc[r] = (q.cc[i * 4] > 0) + (q.cc[i * 4 + 1] > 0) + (q.cc[i * 4 + 2] > 0) + (q.cc[i * 4 + 3] > 0);
+        }
+        if (tid == 0) misc[2] = m;
+        __syncthreads();
+        qt_scan_inclusive(q.acc, m, s_wave);
+        if (modeB) {
+            // first rank whose split brings the list to >= N nodes (:732)
+            for (int r = tid; r < m; r += QT)
+                if (S + q.acc[r] - (r + 1) >= N) atomicMin(&misc[2], r + 1);
+            __syncthreads();
+        }
+        const int R = misc[2];
+        const int totalChildren = R > 0 ? q.acc[R - 1] : 0;
+        // 3. unprocessed nodes keep their relative order behind the new children
+        for (int i = tid; i < S; i += QT) {
+            const int r = q.rankOf[i];
+            q.newIdx[i] = (r >= 0 && r < R) ? 0 : 1;
+        }
+        __syncthreads();
+        const int nUnproc = qt_scan_inclusive(q.newIdx, S, s_wave);
+        const int S2 = totalChildren + nUnproc;
+        // 4. write the next list
+        for (int i = tid; i < S; i += QT) {
+            const int r = q.rankOf[i];
+            if (r >= 0 && r < R) {
+                int pos = totalChildren - q.acc[r];
+                const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
+                const int urx = q.box[cur][2][i], bry = q.box[cur][3][i];
+                const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);
+                for (int qd = 3; qd >= 0; --qd) {  // list front holds n4, then n3, n2, n1 (:623-662)
+                    const int cn = q.cc[i * 4 + qd];
+                    if (cn > 0) {
+                        q.box[nx][0][pos] = (int16_t)((qd & 1) ? midx : ulx);
+                        q.box[nx][1][pos] = (int16_t)((qd & 2) ? midy : uly);
+                        q.box[nx][2][pos] = (int16_t)((qd & 1) ? urx : midx);
+                        q.box[nx][3][pos] = (int16_t)((qd & 2) ? bry : midy);
+                        q.cnt[nx][pos] = cn;
+                        q.cc[i * 4 + qd] = pos;
+                        ++pos;
+                    } else {
+                        q.cc[i * 4 + qd] = -1;
+                    }
+                }
+            } else {
+                const int pos = totalChildren + q.newIdx[i] - 1;
+                q.box[nx][0][pos] = q.box[cur][0][i];
+                q.box[nx][1][pos] = q.box[cur][1][i];
+                q.box[nx][2][pos] = q.box[cur][2][i];
+                q.box[nx][3][pos] = q.box[cur][3][i];
+                q.cnt[nx][pos] = q.cnt[cur][i];
+                q.newIdx[i] = pos;
+            }
+        }
+        __syncthreads();
+        // 5. keys follow their node
+        for (int k = tid; k < n; k += QT) {
+            const int kn = KN[k];
+            const int i = kn & KNODE_MASK, qd = kn >> 14;
+            const int r = q.rankOf[i];
+            KN[k] = (uint16_t)((r >= 0 && r < R) ? q.cc[i * 4 + qd] : q.newIdx[i]);
+        }
+        // 6. multi-key children in creation order (rank asc, n1..n4): counts per rank -> sequence numbers
+        for (int r = tid; r < R; r += QT) {
+            const int i = q.P[r];
+            int mc = 0;
+            for (int qd = 0; qd < 4; ++qd) {
+                const int pos = q.cc[i * 4 + qd];
+                if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
+            }
+            q.acc[r] = mc;
+        }
+        __syncthreads();
+        const int nToExpand = qt_scan_inclusive(q.acc, R, s_wave);
+        // 7. termination / next mode (:671-675, :736)
+        const bool finish = (S2 >= N) || (S2 == S);
+        if (!modeB && !finish && (S2 + 3 * nToExpand > N)) modeB = 1;
+        if (finish) {
+            S = S2;
+            cur = nx;
+            break;
+        }
+        // 8. next processing order
+        if (!modeB) {
+            // list order of the multi-key nodes of the new list
+            for (int i = tid; i < S2; i += QT) q.newIdx[i] = q.cnt[nx][i] > 1 ? 1 : 0;
+            __syncthreads();
+            const int m2 = qt_scan_inclusive(q.newIdx, S2, s_wave);
+            // rankOf must be rebuilt from newIdx before P is overwritten: use skey as staging for P
+            for (int i = tid; i < S2; i += QT) {
+                const bool multi = q.cnt[nx][i] > 1;
+                const int r = q.newIdx[i] - 1;
+                q.rankOf[i] = multi ? r : -1;
+                if (multi) ((int32_t *)q.skey)[r] = i;
+            }
+            __syncthreads();
+            for (int r = tid; r < m2; r += QT) q.P[r] = ((int32_t *)q.skey)[r];
+            m = m2;
+        } else {
+            // sort the new multi-key children by (size desc, creation seq desc) (:686-687)
+            int Mp = 2;
+            while (Mp < nToExpand) Mp <<= 1;
+            for (int i = tid; i < Mp; i += QT) q.skey[i] = 0ull;
+            __syncthreads();
+            for (int r = tid; r < R; r += QT) {
+                const int i = q.P[r];
+                int seq = q.acc[r];  // inclusive count -> sequence numbers of this rank end at acc[r]-1
+                int mc = 0;
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int pos = q.cc[i * 4 + qd];
+                    if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
+                }
+                seq -= mc;
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int pos = q.cc[i * 4 + qd];
+                    if (pos >= 0 && q.cnt[nx][pos] > 1) {
+                        q.skey[seq] = ((unsigned long long)(uint32_t)q.cnt[nx][pos] << 32) |
+                                      ((unsigned long long)(uint32_t)(seq + 1) << 16) | (unsigned long long)pos;
+                        ++seq;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int kk = 2; kk <= Mp; kk <<= 1)
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < Mp; i += QT) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = q.skey[i], c2 = q.skey[ixj];
+                            const bool desc = (i & kk) == 0;  // overall descending
+                            if (desc ? (a < c2) : (a > c2)) { q.skey[i] = c2; q.skey[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = tid; i < S2; i += QT) q.rankOf[i] = -1;
+            __syncthreads();
+            for (int r = tid; r < nToExpand; r += QT) {
+                const int pos = (int)(q.skey[r] & 0xFFFFull);
+                q.P[r] = pos;
+                q.rankOf[pos] = r;
+            }
+            m = nToExpand;
+        }
+        S = S2;
+        cur = nx;
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- keep the strongest key of every node, first in candidate order on ties (:746-762) ----
+    uint32_t *best = (uint32_t *)q.cc;
+    for (int i = tid; i < S; i += QT) best[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += QT) {
+        const int i = KN[k] & KNODE_MASK;
+        atomicMax(&best[i], ((uint32_t)orb_key_r(K[k]) << 24) | (0xFFFFFFu - (uint32_t)k));
+    }
+    __syncthreads();
+    uint32_t *out = sel + (int64_t)b * plan->sel_per_frame + L.sel_off;
+    const int nout = min(S, L.sel_cap);
+    for (int i = tid; i < nout; i += QT) {
+        const uint32_t key = K[0xFFFFFFu - (best[i] & 0xFFFFFFu)];
+        // + minBorderX / minBorderY (:853-854): level coordinates from here on
+        out[i] = orb_pack_key(orb_key_x(key) + ORBFE_MINB, orb_key_y(key) + ORBFE_MINB, orb_key_r(key));
+    }
+    if (tid == 0) nsel[b * plan->nlevels + level] = nout;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K4  7x7 Gaussian, sigma 2, 8-bit fixed-point kernel {18,34,49,55,49,34,18} (sum 257), REFLECT_101 at the
+// LEVEL edges.  64x16 output tile; the row pass lands in LDS as u16 (<= 255*257 = 65535).
+// ---------------------------------------------------------------------------------------------------
+#define BW 64
+#define BH 16
+__global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs, int level,
+                                               uint8_t *__restrict__ blur, int64_t blur_fstride)
+{
+    __shared__ uint8_t s_in[(BH + 6) * (BW + 8)];
+    __shared__ uint16_t s_row[(BH + 6) * BW];
+    const OrbLevel &L = plan->lv[level];
+    const int b = blockIdx.z, tid = threadIdx.x;
+    int pitch;
+    const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
+    uint8_t *dst = blur + (int64_t)b * blur_fstride + L.off;
+    const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
+    const int IW = BW + 6;
+    for (int idx = tid; idx < (BH + 6) * IW; idx += 256) {
+        const int y = idx / IW, x = idx - y * IW;
+        const int sy = reflect101(min(y0 + y - 3, L.h + 2), L.h);
+        const int sx = reflect101(min(x0 + x - 3, L.w + 2), L.w);
+        s_in[y * (BW + 8) + x] = src[(int64_t)sy * pitch + sx];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < (BH + 6) * BW; idx += 256) {
+        const int y = idx >> 6, x = idx & 63;
+        const uint8_t *p = &s_in[y * (BW + 8) + x];
+        const int r = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
+        s_row[y * BW + x] = (uint16_t)r;
+    }
+    __syncthreads();
+    const int vec_w = L.w & ~3;
+    for (int idx = tid; idx < BH * BW; idx += 256) {
+        const int y = idx >> 6, x = idx & 63;
+        if (x0 + x >= L.w || y0 + y >= L.h) continue;
+        const uint16_t *p = &s_row[y * BW + x];
+        const int acc = 18 * ((int)p[0] + p[6 * BW]) + 34 * ((int)p[BW] + p[5 * BW]) +
+                        49 * ((int)p[2 * BW] + p[4 * BW]) + 55 * (int)p[3 * BW];
+        int v = (acc + 32768) >> 16;
+        if (plan->blur_rounding == 1 && (acc & 0xFFFF) == 0x8000 && (x0 + x) < vec_w && (v & 1)) v -= 1;
+        dst[(int64_t)(y0 + y) * L.pitch + x0 + x] = (uint8_t)min(v, 255);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5  IC_Angle + steered BRIEF + keypoint assembly.  One wave per output slot.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    // cv::fastAtan2 (OpenCV 3.2 atan_f32), every operation rounded separately
+    const float s = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = __fmul_rn(0.9997878412794807f, s), p3 = __fmul_rn(-0.3258083974640975f, s);
+    const float p5 = __fmul_rn(0.1555786518463281f, s), p7 = __fmul_rn(-0.04432655554792128f, s);
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// canonical (float)cos / (float)sin of angle_deg * pi/180: fixed fp64 operation sequence
+__device__ __forceinline__ void canon_sincos(float angle_deg, float *ca, float *sb)
+{
+    const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float angle = __fmul_rn(angle_deg, factor_pi);
+    const double x = (double)angle;
+    const double kf = floor(__dadd_rn(__dmul_rn(x, 6.36619772367581382433e-01), 0.5));
+    const int k = (int)kf;
+    const double r = __dsub_rn(__dsub_rn(x, __dmul_rn(kf, 1.57079632673412561417e+00)),
+                               __dmul_rn(kf, 6.07710050650619224932e-11));
+    const double z = __dmul_rn(r, r);
+    double ps = __dadd_rn(-2.50507602534068634195e-08, __dmul_rn(z, 1.58969099521155010221e-10));
+    ps = __dadd_rn(2.75573137070700676789e-06, __dmul_rn(z, ps));
+    ps = __dadd_rn(-1.98412698298579493134e-04, __dmul_rn(z, ps));
+    ps = __dadd_rn(8.33333333332248946124e-03, __dmul_rn(z, ps));
+    ps = __dadd_rn(-1.66666666666666324348e-01, __dmul_rn(z, ps));
+    const double sn = __dadd_rn(r, __dmul_rn(__dmul_rn(z, r), ps));
+    double pc = __dadd_rn(2.08757232129817482790e-09, __dmul_rn(z, -1.13596475577881948265e-11));
+    pc = __dadd_rn(-2.75573143513906633035e-07, __dmul_rn(z, pc));
+    pc = __dadd_rn(2.48015872894767294178e-05, __dmul_rn(z, pc));
+    pc = __dadd_rn(-1.38888888888741095749e-03, __dmul_rn(z, pc));
+    pc = __dadd_rn(4.16666666666666019037e-02, __dmul_rn(z, pc));
+    const double cs = __dsub_rn(1.0, __dsub_rn(__dmul_rn(0.5, z), __dmul_rn(__dmul_rn(z, z), pc)));
+    double s, c;
+    switch (k & 3) {
+    case 0: s = sn; c = cs; break;
+    case 1: s = cs; c = -sn; break;
+    case 2: s = -sn; c = -cs; break;
+    default: s = -cs; c = sn; break;
+    }
+    *ca = __double2float_rn(c);
+    *sb = __double2float_rn(s);
+}
+
+__global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restrict__ plan, FrameSrc fs,
+                                                         const uint8_t *__restrict__ blur, int64_t blur_fstride,
+                                                         const uint32_t *__restrict__ sel,
+                                                         const int32_t *__restrict__ nsel,
+                                                         orbfe_keypoint *__restrict__ kps,
+                                                         uint8_t *__restrict__ desc, int32_t cap,
+                                                         int32_t *__restrict__ n_out)
+{
+    const int b = blockIdx.y;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (slot >= cap) return;
+    const int nl = plan->nlevels;
+    const int32_t *ns = nsel + b * nl;
+    int level = -1, idx = slot, total = 0;
+    for (int l = 0; l < nl; ++l) {
+        const int c = ns[l];
+        if (level < 0 && idx < c) level = l;
+        if (level < 0) idx -= c;
+        total += c;
+    }
+    if (slot == 0 && lane == 0) n_out[b] = total;
+    orbfe_keypoint *kp = kps + (int64_t)b * cap + slot;
+    uint8_t *dd = desc + ((int64_t)b * cap + slot) * 32;
+    if (level < 0) {  // zero-fill the padding so the buffers can be all-gathered as they are
+        if (lane < 7) ((uint32_t *)kp)[lane] = 0u;
+        if (lane < 8) ((uint32_t *)dd)[lane] = 0u;
+        return;
+    }
+    const OrbLevel &L = plan->lv[level];
+    const uint32_t key = sel[(int64_t)b * plan->sel_per_frame + L.sel_off + idx];
+    const int x = orb_key_x(key), y = orb_key_y(key);
+    int pitch;
+    const uint8_t *img = level_ptr(fs, L, level, b, &pitch);
+    const uint8_t *center = img + (int64_t)y * pitch + x;
+
+    // ---- IC_Angle: integer moments over the 749-px circular patch (any summation order is exact) ----
+    int m10 = 0, m01 = 0;
+    {
+        const int u = (lane & 31) - 15;  // lanes 31 and 63 idle
+        const int half = lane >> 5;
+        for (int v0 = -15; v0 <= 15; v0 += 2) {
+            const int v = v0 + half;
+            if (v <= 15 && (lane & 31) < 31) {
+                const int d = c_umax[v < 0 ? -v : v];
+                if (u >= -d && u <= d) {
+                    const int val = center[v * pitch + u];
+                    m10 += u * val;
+                    m01 += v * val;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o, 64);
+            m01 += __shfl_xor(m01, o, 64);
+        }
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- steered BRIEF on the blurred level ----
+    float a, bb;
+    canon_sincos(angle, &a, &bb);
+    const uint8_t *bc = blur + (int64_t)b * blur_fstride + L.off + (int64_t)y * L.pitch + x;
+    unsigned long long words[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const signed char *p = &c_pattern[(g * 64 + lane) * 4];
+        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, bb), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, bb)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, bb), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, bb)));
+        const int t0 = bc[r0 * L.pitch + c0], t1 = bc[r1 * L.pitch + c1];
+        words[g] = __ballot(t0 < t1);
+    }
+    if (lane < 4) ((unsigned long long *)dd)[lane] = words[lane];
+    if (lane == 0) {
+        float fx = (float)x, fy = (float)y;
+        if (level != 0) {  // pt *= mvScaleFactor[level] (:1104-1110)
+            fx = __fmul_rn(fx, L.scale);
+            fy = __fmul_rn(fy, L.scale);
+        }
+        kp->x = fx;
+        kp->y = fy;
+        kp->size = L.patch_size;
+        kp->angle = angle;
+        kp->response = (float)orb_key_r(key);
+        kp->octave = level;
+        kp->class_id = -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers (host)
+// ---------------------------------------------------------------------------------------------------
+static FrameSrc make_src(const OrbLaunch &a)
+{
+    FrameSrc fs;
+    fs.l0 = a.d_gray;
+    fs.l0_fstride = a.gray_fstride;
+    fs.l0_pitch = a.gray_pitch;
+    fs.pyr = a.d_pyr;
+    fs.pyr_fstride = a.pyr_fstride;
+    return fs;
+}
+
+hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
+{
+    const FrameSrc fs = make_src(a);
+    for (int l = 1; l < a.h_plan->nlevels; ++l) {
+        const OrbLevel &L = a.h_plan->lv[l];
+        dim3 grid((L.w + 63) / 64, (L.h + 3) / 4, a.nframes);
+        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, a.d_plan, fs, l, a.d_tabs);
+    }
+    return hipGetLastError();
+}
+
+hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
+{
+    const FrameSrc fs = make_src(a);
+    dim3 grid(a.h_plan->ncells, a.nframes);
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, st, a.d_plan, fs, a.d_cells, a.d_cell_cnt, a.d_cell_keys);
+    return hipGetLastError();
+}
+
+hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
+{
+    dim3 grid(a.h_plan->nlevels, a.nframes);
+    const size_t lds = orbk_octree_lds_bytes(a.h_plan->node_cap);
+    hipLaunchKernelGGL(k_octree, grid, dim3(QT), lds, st, a.d_plan, a.d_cell_cnt, a.d_cell_keys, a.d_cell_off,
+                       a.d_keys, a.d_knode, a.d_sel, a.d_nsel, a.d_nkeys);
+    return hipGetLastError();
+}
+
+hipError_t orbk_prepare_octree(int node_cap)
+{
+    const size_t lds = orbk_octree_lds_bytes(node_cap);
+    return hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st)
+{
+    const FrameSrc fs = make_src(a);
+    for (int l = 0; l < a.h_plan->nlevels; ++l) {
+        const OrbLevel &L = a.h_plan->lv[l];
+        dim3 grid((L.w + BW - 1) / BW, (L.h + BH - 1) / BH, a.nframes);
+        hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, a.d_plan, fs, l, a.d_blur, a.pyr_fstride);
+    }
+    return hipGetLastError();
+}
+
+hipError_t orbk_launch_describe(const OrbLaunch &a, hipStream_t st)
+{
+    const FrameSrc fs = make_src(a);
+    dim3 grid((a.cap + 3) / 4, a.nframes);
+    hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, st, a.d_plan, fs, a.d_blur, a.pyr_fstride, a.d_sel,
+                       a.d_nsel, a.d_kps, a.d_desc, a.cap, a.d_n_out);
+    return hipGetLastError();
+}

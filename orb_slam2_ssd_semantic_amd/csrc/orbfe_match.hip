@@ -1,0 +1,642 @@
+// orbfe_match.hip -- Hamming matcher kernels + C-ABI (include/orbfe.h "Matcher").
+//
+// Reference behaviour restated (paths relative to /root/reference):
+//   DescriptorDistance                 src/ORBmatcher.cc:1968-1984
+//   best / second-best update idiom    src/ORBmatcher.cc:280-289 (and :732-741)
+//   SearchByBoW (KF,F) / (KF,KF)       src/ORBmatcher.cc:217-363 / :665-812
+//   rotation histogram + prune         src/ORBmatcher.cc:308-316, :338-360
+//   ComputeThreeMaxima                 src/ORBmatcher.cc:1912-1957
+// Bit work on v_bcnt_u32_b32 (popcount-accumulate); no MFMA.  No CPU path.
+#include <algorithm>
+#include <new>
+
+#include "orbfe_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------
+struct Desc8 {
+    uint32_t w[8];
+};
+
+__device__ __forceinline__ int hamming8(const Desc8 &a, const uint32_t *__restrict__ b)
+{
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d += __popc(a.w[i] ^ b[i]);
+    return d;
+}
+
+struct Best2 {
+    int best, second, idx;
+};
+
+// merge of two partial results where `lo` covers the earlier iteration positions (first minimum wins)
+__device__ __forceinline__ Best2 merge_best2(const Best2 &lo, const Best2 &hi)
+{
+    Best2 r;
+    if (hi.best < lo.best) {
+        r.best = hi.best;
+        r.idx = hi.idx;
+        r.second = min(lo.best, hi.second);
+    } else {
+        r.best = lo.best;
+        r.idx = lo.idx;
+        r.second = min(lo.second, hi.best);
+    }
+    return r;
+}
+
+// ORBmatcher.cc:308-313: rot = a1 - a2 (+360 if < 0); bin = round(rot * (1/HISTO_LENGTH)) (sic)
+__device__ __forceinline__ int rot_bin(float a1, float a2)
+{
+    const float factor = 1.0f / ORBFE_HISTO_LENGTH;
+    float rot = __fsub_rn(a1, a2);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, factor));
+    if (bin == ORBFE_HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K8  brute force: 64 queries per workgroup, the train set split over the workgroup's waves.
+// A pair of frames is (q rows, t rows); blockIdx.y selects the pair in the batched form.
+// ---------------------------------------------------------------------------------------------------
+#define BF_WAVES 16
+
+struct BfPair {
+    const uint8_t *q;
+    const uint8_t *t;
+    int nq, nt;
+};
+
+__global__ __launch_bounds__(BF_WAVES * 64) void k_match_bf(const uint8_t *__restrict__ q_base,
+                                                            const uint8_t *__restrict__ t_base,
+                                                            const int32_t *__restrict__ n_arr,  // per-frame counts or NULL
+                                                            const int32_t *__restrict__ qframe,
+                                                            const int32_t *__restrict__ tframe, int cap, int nq_s,
+                                                            int nt_s, float nnratio, int th,
+                                                            int32_t *__restrict__ match, int32_t *__restrict__ best_o,
+                                                            int32_t *__restrict__ second_o)
+{
+    __shared__ int s_best[BF_WAVES][64], s_second[BF_WAVES][64], s_idx[BF_WAVES][64];
+    const int pair = blockIdx.y;
+    const uint8_t *q = q_base, *t = t_base;
+    int nq = nq_s, nt = nt_s;
+    int64_t out0 = 0;
+    if (n_arr) {  // batched-frames form
+        const int qf = qframe[pair], tf = tframe[pair];
+        q = q_base + (int64_t)qf * cap * 32;
+        t = t_base + (int64_t)tf * cap * 32;
+        nq = min(n_arr[qf], cap);
+        nt = min(n_arr[tf], cap);
+        out0 = (int64_t)pair * cap;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= (n_arr ? cap : nq)) return;
+    Desc8 dq;
+    {
+        const uint32_t *p = (const uint32_t *)(q + (int64_t)min(qi, max(nq - 1, 0)) * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dq.w[i] = nq > 0 ? p[i] : 0u;
+    }
+    // contiguous train slice per wave keeps "lowest index wins" a simple ordered merge
+    const int per = (nt + BF_WAVES - 1) / BF_WAVES;
+    const int j0 = min(wid * per, nt), j1 = min(j0 + per, nt);
+    Best2 r = {256, 256, -1};
+    for (int j = j0; j < j1; ++j) {
+        const uint32_t *tr = (const uint32_t *)(t + (int64_t)j * 32);  // wave-uniform address -> scalar loads
+        const int d = hamming8(dq, tr);
+        if (d < r.best) {
+            r.second = r.best;
+            r.best = d;
+            r.idx = j;
+        } else if (d < r.second) {
+            r.second = d;
+        }
+    }
+    s_best[wid][lane] = r.best;
+    s_second[wid][lane] = r.second;
+    s_idx[wid][lane] = r.idx;
+    __syncthreads();
+    if (wid == 0) {
+        for (int w = 1; w < BF_WAVES; ++w) {
+            Best2 hi = {s_best[w][lane], s_second[w][lane], s_idx[w][lane]};
+            r = merge_best2(r, hi);
+        }
+        const bool valid = qi < nq;
+        if (valid || (n_arr && qi < cap)) {
+            int m = -1;
+            if (valid && r.idx >= 0 && r.best <= th && (float)r.best < __fmul_rn(nnratio, (float)r.second)) m = r.idx;
+            match[out0 + qi] = m;
+            if (best_o) best_o[out0 + qi] = valid ? r.best : 256;
+            if (second_o) second_o[out0 + qi] = valid ? r.second : 256;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K10  rotation-consistency histogram over accepted matches, ComputeThreeMaxima, prune, count.
+// One workgroup per pair.  key i is kept when its bin is one of the three maxima.
+// angles: element i of side X is at X_ang[i * stride] (stride 1 for plain arrays, 7 for orbfe_keypoint).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rot_prune(int32_t *__restrict__ match, const float *__restrict__ a_ang,
+                                                   const float *__restrict__ b_ang, int ang_stride,
+                                                   const int32_t *__restrict__ n_arr,
+                                                   const int32_t *__restrict__ aframe,
+                                                   const int32_t *__restrict__ bframe, int cap, int n_s,
+                                                   int check_ori, int32_t *__restrict__ nmatches)
+{
+    __shared__ int s_hist[ORBFE_HISTO_LENGTH];
+    __shared__ int s_keep[3];
+    __shared__ int s_count;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    int n = n_s;
+    int32_t *mt = match;
+    const float *aa = a_ang, *ba = b_ang;
+    if (n_arr) {
+        const int af = aframe[pair], bf = bframe[pair];
+        n = min(n_arr[af], cap);
+        mt = match + (int64_t)pair * cap;
+        aa = a_ang + (int64_t)af * cap * ang_stride;
+        ba = b_ang + (int64_t)bf * cap * ang_stride;
+    }
+    if (tid < ORBFE_HISTO_LENGTH) s_hist[tid] = 0;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    if (check_ori) {
+        for (int i = tid; i < n; i += 256) {
+            const int j = mt[i];
+            if (j >= 0) atomicAdd(&s_hist[rot_bin(aa[(int64_t)i * ang_stride], ba[(int64_t)j * ang_stride])], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {  // ComputeThreeMaxima (:1912-1957)
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < ORBFE_HISTO_LENGTH; ++i) {
+                const int s = s_hist[i];
+                if (s > max1) {
+                    max3 = max2; max2 = max1; max1 = s;
+                    i3 = i2; i2 = i1; i1 = i;
+                } else if (s > max2) {
+                    max3 = max2; max2 = s;
+                    i3 = i2; i2 = i;
+                } else if (s > max3) {
+                    max3 = s; i3 = i;
+                }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+            s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+        }
+        __syncthreads();
+    }
+    int local = 0;
+    for (int i = tid; i < n; i += 256) {
+        const int j = mt[i];
+        if (j < 0) continue;
+        if (check_ori) {
+            const int bin = rot_bin(aa[(int64_t)i * ang_stride], ba[(int64_t)j * ang_stride]);
+            if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
+                mt[i] = -1;
+                continue;
+            }
+        }
+        ++local;
+    }
+    atomicAdd(&s_count, local);
+    __syncthreads();
+    if (tid == 0) nmatches[pair] = s_count;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K9  SearchByBoW: one thread per KeyFrame vocabulary node.  Nodes own disjoint feature sets, so the
+// greedy "F feature already claimed" rule (:273-274, :725) only couples features inside one node and
+// is replayed serially there, in the reference's iteration order.
+// matchF2KF[iF] = KF feature index, -1 none.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_search_by_bow(const uint8_t *__restrict__ descKF,
+                                                      const uint8_t *__restrict__ validKF,
+                                                      const uint32_t *__restrict__ nodeKF,
+                                                      const uint32_t *__restrict__ offKF,
+                                                      const uint32_t *__restrict__ idxKF, int nnodesKF,
+                                                      const uint8_t *__restrict__ descF,
+                                                      const uint8_t *__restrict__ validF,
+                                                      const uint32_t *__restrict__ nodeF,
+                                                      const uint32_t *__restrict__ offF,
+                                                      const uint32_t *__restrict__ idxF, int nnodesF, float nnratio,
+                                                      int th_low, int strict_lt, int32_t *__restrict__ matchF2KF)
+{
+    const int a = blockIdx.x * 64 + threadIdx.x;
+    if (a >= nnodesKF) return;
+    const uint32_t node = nodeKF[a];
+    int lo = 0, hi = nnodesF - 1, b = -1;  // lower_bound walk of :329-333 == binary search on sorted ids
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t v = nodeF[mid];
+        if (v == node) { b = mid; break; }
+        if (v < node) lo = mid + 1; else hi = mid - 1;
+    }
+    if (b < 0) return;
+    for (uint32_t ik = offKF[a]; ik < offKF[a + 1]; ++ik) {
+        const uint32_t rk = idxKF[ik];
+        if (validKF && !validKF[rk]) continue;
+        Desc8 dk;
+        const uint32_t *pk = (const uint32_t *)(descKF + (int64_t)rk * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dk.w[i] = pk[i];
+        int b1 = 256, b2 = 256, bi = -1;
+        for (uint32_t jf = offF[b]; jf < offF[b + 1]; ++jf) {
+            const uint32_t rf = idxF[jf];
+            if (matchF2KF[rf] >= 0) continue;
+            if (validF && !validF[rf]) continue;
+            const int d = hamming8(dk, (const uint32_t *)(descF + (int64_t)rf * 32));
+            if (d < b1) { b2 = b1; b1 = d; bi = (int)rf; }
+            else if (d < b2) { b2 = d; }
+        }
+        const bool pass = strict_lt ? (b1 < th_low) : (b1 <= th_low);
+        if (pass && bi >= 0 && (float)b1 < __fmul_rn(nnratio, (float)b2)) matchF2KF[bi] = (int32_t)rk;
+    }
+}
+
+// rotation prune for SearchByBoW: key = F feature i, rot = angKF[match[i]] - angF[i] (:308, :759)
+__global__ __launch_bounds__(256) void k_rot_prune_bow(int32_t *__restrict__ match, const float *__restrict__ angKF,
+                                                       const float *__restrict__ angF, int nF, int check_ori,
+                                                       int32_t *__restrict__ nmatches)
+{
+    __shared__ int s_hist[ORBFE_HISTO_LENGTH];
+    __shared__ int s_keep[3];
+    __shared__ int s_count;
+    const int tid = threadIdx.x;
+    if (tid < ORBFE_HISTO_LENGTH) s_hist[tid] = 0;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    if (check_ori) {
+        for (int i = tid; i < nF; i += 256) {
+            const int j = match[i];
+            if (j >= 0) atomicAdd(&s_hist[rot_bin(angKF[j], angF[i])], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < ORBFE_HISTO_LENGTH; ++i) {
+                const int s = s_hist[i];
+                if (s > max1) {
+                    max3 = max2; max2 = max1; max1 = s;
+                    i3 = i2; i2 = i1; i1 = i;
+                } else if (s > max2) {
+                    max3 = max2; max2 = s;
+                    i3 = i2; i2 = i;
+                } else if (s > max3) {
+                    max3 = s; i3 = i;
+                }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+            s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+        }
+        __syncthreads();
+    }
+    int local = 0;
+    for (int i = tid; i < nF; i += 256) {
+        const int j = match[i];
+        if (j < 0) continue;
+        if (check_ori) {
+            const int bin = rot_bin(angKF[j], angF[i]);
+            if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
+                match[i] = -1;
+                continue;
+            }
+        }
+        ++local;
+    }
+    atomicAdd(&s_count, local);
+    __syncthreads();
+    if (tid == 0) nmatches[0] = s_count;
+}
+
+// 8(f).1: best / second-best over a per-query candidate list
+__global__ __launch_bounds__(256) void k_hamming_csr(const uint8_t *__restrict__ q, int nq,
+                                                     const uint8_t *__restrict__ t, const uint32_t *__restrict__ off,
+                                                     const uint32_t *__restrict__ cand, int32_t *__restrict__ best_idx,
+                                                     int32_t *__restrict__ best, int32_t *__restrict__ second)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    Desc8 dq;
+    const uint32_t *p = (const uint32_t *)(q + (int64_t)i * 32);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dq.w[k] = p[k];
+    int b1 = 256, b2 = 256, bi = -1;
+    for (uint32_t j = off[i]; j < off[i + 1]; ++j) {
+        const uint32_t c = cand[j];
+        const int d = hamming8(dq, (const uint32_t *)(t + (int64_t)c * 32));
+        if (d < b1) { b2 = b1; b1 = d; bi = (int)c; }
+        else if (d < b2) { b2 = d; }
+    }
+    best_idx[i] = bi;
+    best[i] = b1;
+    second[i] = b2;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host API
+// ---------------------------------------------------------------------------------------------------
+struct MDevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need == 0) need = 4;
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        need = (need + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct orbfe_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    MDevBuf b[16];
+};
+
+struct MDeviceGuard {
+    int prev = -1, dev = -1;
+    explicit MDeviceGuard(int d) : dev(d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~MDeviceGuard()
+    {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+
+extern "C" int32_t orbfe_hamming(const uint8_t a[32], const uint8_t b[32])
+{
+    // src/ORBmatcher.cc:1968-1984 (the SWAR popcount there equals a hardware popcount)
+    int d = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t x, y;
+        memcpy(&x, a + 4 * i, 4);
+        memcpy(&y, b + 4 * i, 4);
+        d += __builtin_popcount(x ^ y);
+    }
+    return d;
+}
+
+extern "C" orbfe_status orbfe_matcher_create(int32_t device, orbfe_matcher **out)
+{
+    if (!out) return ORBFE_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        orbfe_set_error("no HIP device visible; liborbfe has no CPU fallback");
+        return ORBFE_ERR_NODEVICE;
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    if (device >= ndev) { orbfe_set_error("device out of range"); return ORBFE_ERR_ARG; }
+    orbfe_matcher *m = new (std::nothrow) orbfe_matcher();
+    if (!m) return ORBFE_ERR_NOMEM;
+    m->device = device;
+    MDeviceGuard g(device);
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+        orbfe_set_error("hipStreamCreate failed");
+        delete m;
+        return ORBFE_ERR_HIP;
+    }
+    *out = m;
+    return ORBFE_OK;
+}
+
+extern "C" void orbfe_matcher_destroy(orbfe_matcher *m)
+{
+    if (!m) return;
+    MDeviceGuard g(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (auto &b : m->b) b.release();
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+static orbfe_status launch_bf(const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, const float *d_qa,
+                              const float *d_ta, int ang_stride, float nnratio, int th, int check_ori,
+                              int32_t *d_match, int32_t *d_best, int32_t *d_second, int32_t *d_nm, hipStream_t st)
+{
+    if (nq > 0) {
+        dim3 grid((nq + 63) / 64, 1);
+        hipLaunchKernelGGL(k_match_bf, grid, dim3(BF_WAVES * 64), 0, st, d_q, d_t, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, 0, nq, nt, nnratio, th, d_match, d_best,
+                           d_second);
+        ORBFE_HIP(hipGetLastError());
+    }
+    const int ori = (check_ori && d_qa && d_ta) ? 1 : 0;
+    hipLaunchKernelGGL(k_rot_prune, dim3(1), dim3(256), 0, st, d_match, d_qa, d_ta, ang_stride,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0, nq, ori, d_nm);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_match_bf_device(orbfe_matcher *m, const uint8_t *d_q, int32_t nq, const uint8_t *d_t,
+                                              int32_t nt, const float *d_q_angle, const float *d_t_angle,
+                                              float nnratio, int32_t th, int32_t check_ori, int32_t *d_match_q2t,
+                                              int32_t *d_best, int32_t *d_second, int32_t *d_nmatches, void *stream)
+{
+    if (!m || nq < 0 || nt < 0 || !d_match_q2t || !d_nmatches || (nq > 0 && !d_q) || (nt > 0 && !d_t)) {
+        orbfe_set_error("bad argument to orbfe_match_bf_device");
+        return ORBFE_ERR_ARG;
+    }
+    MDeviceGuard g(m->device);
+    return launch_bf(d_q, nq, d_t, nt, d_q_angle, d_t_angle, 1, nnratio, th, check_ori, d_match_q2t, d_best, d_second,
+                     d_nmatches, stream ? (hipStream_t)stream : m->stream);
+}
+
+extern "C" orbfe_status orbfe_match_bf(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
+                                       const float *q_angle, const float *t_angle, float nnratio, int32_t th,
+                                       int32_t check_ori, int32_t *match_q2t, int32_t *best, int32_t *second,
+                                       int32_t *nmatches)
+{
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && (!q || !match_q2t)) || (nt > 0 && !t)) {
+        orbfe_set_error("bad argument to orbfe_match_bf");
+        return ORBFE_ERR_ARG;
+    }
+    if (nq == 0) {
+        if (nmatches) *nmatches = 0;
+        return ORBFE_OK;
+    }
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    const bool ori = check_ori && q_angle && t_angle;
+    ORBFE_HIP(m->b[0].ensure((size_t)nq * 32));
+    ORBFE_HIP(m->b[1].ensure((size_t)nt * 32));
+    ORBFE_HIP(m->b[2].ensure((size_t)nq * 4));
+    ORBFE_HIP(m->b[3].ensure((size_t)nt * 4));
+    ORBFE_HIP(m->b[4].ensure((size_t)nq * 4));
+    ORBFE_HIP(m->b[5].ensure((size_t)nq * 4));
+    ORBFE_HIP(m->b[6].ensure((size_t)nq * 4));
+    ORBFE_HIP(m->b[7].ensure(4));
+    ORBFE_HIP(hipMemcpyAsync(m->b[0].p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    if (nt > 0) ORBFE_HIP(hipMemcpyAsync(m->b[1].p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    if (ori) {
+        ORBFE_HIP(hipMemcpyAsync(m->b[2].p, q_angle, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+        if (nt > 0) ORBFE_HIP(hipMemcpyAsync(m->b[3].p, t_angle, (size_t)nt * 4, hipMemcpyHostToDevice, st));
+    }
+    orbfe_status s = launch_bf((const uint8_t *)m->b[0].p, nq, (const uint8_t *)m->b[1].p, nt,
+                               ori ? (const float *)m->b[2].p : nullptr, ori ? (const float *)m->b[3].p : nullptr, 1,
+                               nnratio, th, ori ? 1 : 0, (int32_t *)m->b[4].p, (int32_t *)m->b[5].p,
+                               (int32_t *)m->b[6].p, (int32_t *)m->b[7].p, st);
+    if (s != ORBFE_OK) return s;
+    int32_t nm = 0;
+    ORBFE_HIP(hipMemcpyAsync(match_q2t, m->b[4].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    if (best) ORBFE_HIP(hipMemcpyAsync(best, m->b[5].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    if (second) ORBFE_HIP(hipMemcpyAsync(second, m->b[6].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipMemcpyAsync(&nm, m->b[7].p, 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    if (nmatches) *nmatches = nm;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_match_bf_frames_device(orbfe_matcher *m, const orbfe_keypoint *d_kps,
+                                                     const uint8_t *d_desc, const int32_t *d_n, int32_t cap,
+                                                     const int32_t *d_qframe, const int32_t *d_tframe, int32_t npairs,
+                                                     float nnratio, int32_t th, int32_t check_ori,
+                                                     int32_t *d_match_q2t, int32_t *d_nmatches, void *stream)
+{
+    if (!m || !d_kps || !d_desc || !d_n || !d_qframe || !d_tframe || !d_match_q2t || !d_nmatches || cap < 1 ||
+        npairs < 0) {
+        orbfe_set_error("bad argument to orbfe_match_bf_frames_device");
+        return ORBFE_ERR_ARG;
+    }
+    if (npairs == 0) return ORBFE_OK;
+    MDeviceGuard g(m->device);
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    dim3 grid((cap + 63) / 64, npairs);
+    hipLaunchKernelGGL(k_match_bf, grid, dim3(BF_WAVES * 64), 0, st, d_desc, d_desc, d_n, d_qframe, d_tframe, cap, 0, 0,
+                       nnratio, th, d_match_q2t, (int32_t *)nullptr, (int32_t *)nullptr);
+    ORBFE_HIP(hipGetLastError());
+    const float *ang = &d_kps->angle;  // orbfe_keypoint.angle, stride 7 floats
+    hipLaunchKernelGGL(k_rot_prune, dim3(npairs), dim3(256), 0, st, d_match_q2t, ang, ang, 7, d_n, d_qframe, d_tframe,
+                       cap, 0, check_ori ? 1 : 0, d_nmatches);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+static bool csr_ok(const uint32_t *node, const uint32_t *off, const uint32_t *idx, int nn, int nfeat,
+                   std::vector<uint8_t> &seen)
+{
+    seen.assign((size_t)std::max(nfeat, 1), 0);
+    for (int a = 0; a < nn; ++a) {
+        if (a > 0 && node[a] <= node[a - 1]) return false;
+        if (off[a + 1] < off[a]) return false;
+        for (uint32_t k = off[a]; k < off[a + 1]; ++k) {
+            if (idx[k] >= (uint32_t)nfeat || seen[idx[k]]) return false;
+            seen[idx[k]] = 1;
+        }
+    }
+    return true;
+}
+
+extern "C" orbfe_status orbfe_search_by_bow(orbfe_matcher *m, const uint8_t *descKF, int32_t nKF,
+                                            const uint8_t *validKF, const float *angKF, const uint32_t *nodeKF,
+                                            const uint32_t *offKF, const uint32_t *idxKF, int32_t nnodesKF,
+                                            const uint8_t *descF, int32_t nF, const uint8_t *validF,
+                                            const float *angF, const uint32_t *nodeF, const uint32_t *offF,
+                                            const uint32_t *idxF, int32_t nnodesF, float nnratio, int32_t th_low,
+                                            int32_t strict_lt, int32_t check_ori, int32_t *matchF2KF,
+                                            int32_t *nmatches)
+{
+    if (!m || nKF < 0 || nF < 0 || nnodesKF < 0 || nnodesF < 0 || (nF > 0 && !matchF2KF) ||
+        (nnodesKF > 0 && (!nodeKF || !offKF || !descKF)) || (nnodesF > 0 && (!nodeF || !offF || !descF)) ||
+        (check_ori && (nKF > 0 && nF > 0) && (!angKF || !angF))) {
+        orbfe_set_error("bad argument to orbfe_search_by_bow");
+        return ORBFE_ERR_ARG;
+    }
+    for (int i = 0; i < nF; ++i) matchF2KF[i] = -1;
+    if (nmatches) *nmatches = 0;
+    if (nKF == 0 || nF == 0 || nnodesKF == 0 || nnodesF == 0) return ORBFE_OK;
+    std::vector<uint8_t> seen;
+    if (!csr_ok(nodeKF, offKF, idxKF, nnodesKF, nKF, seen) || !csr_ok(nodeF, offF, idxF, nnodesF, nF, seen)) {
+        orbfe_set_error("feature vector CSR invalid: node ids must ascend, indices in range and unique");
+        return ORBFE_ERR_ARG;
+    }
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    const size_t nikf = offKF[nnodesKF], nif = offF[nnodesF];
+    const size_t sz[14] = {(size_t)nKF * 32, (size_t)nKF, (size_t)nKF * 4, (size_t)nnodesKF * 4,
+                           (size_t)(nnodesKF + 1) * 4, nikf * 4, (size_t)nF * 32, (size_t)nF, (size_t)nF * 4,
+                           (size_t)nnodesF * 4, (size_t)(nnodesF + 1) * 4, nif * 4, (size_t)nF * 4, 4};
+    const void *src[12] = {descKF, validKF, angKF, nodeKF, offKF, idxKF, descF, validF, angF, nodeF, offF, idxF};
+    for (int i = 0; i < 14; ++i) ORBFE_HIP(m->b[i].ensure(sz[i]));
+    for (int i = 0; i < 12; ++i)
+        if (src[i] && sz[i]) ORBFE_HIP(hipMemcpyAsync(m->b[i].p, src[i], sz[i], hipMemcpyHostToDevice, st));
+    ORBFE_HIP(hipMemsetAsync(m->b[12].p, 0xFF, (size_t)nF * 4, st));
+    hipLaunchKernelGGL(k_search_by_bow, dim3((nnodesKF + 63) / 64), dim3(64), 0, st, (const uint8_t *)m->b[0].p,
+                       validKF ? (const uint8_t *)m->b[1].p : nullptr, (const uint32_t *)m->b[3].p,
+                       (const uint32_t *)m->b[4].p, (const uint32_t *)m->b[5].p, nnodesKF, (const uint8_t *)m->b[6].p,
+                       validF ? (const uint8_t *)m->b[7].p : nullptr, (const uint32_t *)m->b[9].p,
+                       (const uint32_t *)m->b[10].p, (const uint32_t *)m->b[11].p, nnodesF, nnratio, th_low,
+                       strict_lt ? 1 : 0, (int32_t *)m->b[12].p);
+    ORBFE_HIP(hipGetLastError());
+    // histogram key = F feature i, rot = angKF[match[i]] - angF[i] (:308, :759)
+    hipLaunchKernelGGL(k_rot_prune_bow, dim3(1), dim3(256), 0, st, (int32_t *)m->b[12].p, (const float *)m->b[2].p,
+                       (const float *)m->b[8].p, nF, check_ori ? 1 : 0, (int32_t *)m->b[13].p);
+    ORBFE_HIP(hipGetLastError());
+    int32_t nm = 0;
+    ORBFE_HIP(hipMemcpyAsync(matchF2KF, m->b[12].p, (size_t)nF * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipMemcpyAsync(&nm, m->b[13].p, 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    if (nmatches) *nmatches = nm;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_hamming_csr(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
+                                          const uint32_t *off, const uint32_t *cand, int32_t *best_idx, int32_t *best,
+                                          int32_t *second)
+{
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && (!q || !off || !best_idx || !best || !second))) {
+        orbfe_set_error("bad argument to orbfe_hamming_csr");
+        return ORBFE_ERR_ARG;
+    }
+    if (nq == 0) return ORBFE_OK;
+    const size_t nc = off[nq];
+    for (int i = 0; i < nq; ++i)
+        if (off[i + 1] < off[i]) { orbfe_set_error("CSR offsets must not decrease"); return ORBFE_ERR_ARG; }
+    for (size_t k = 0; k < nc; ++k)
+        if (cand[k] >= (uint32_t)nt) { orbfe_set_error("candidate index out of range"); return ORBFE_ERR_ARG; }
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    ORBFE_HIP(m->b[0].ensure((size_t)nq * 32));
+    ORBFE_HIP(m->b[1].ensure((size_t)nt * 32));
+    ORBFE_HIP(m->b[2].ensure((size_t)(nq + 1) * 4));
+    ORBFE_HIP(m->b[3].ensure(nc * 4));
+    ORBFE_HIP(m->b[4].ensure((size_t)nq * 4));
+    ORBFE_HIP(m->b[5].ensure((size_t)nq * 4));
+    ORBFE_HIP(m->b[6].ensure((size_t)nq * 4));
+    ORBFE_HIP(hipMemcpyAsync(m->b[0].p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    if (nt > 0) ORBFE_HIP(hipMemcpyAsync(m->b[1].p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    ORBFE_HIP(hipMemcpyAsync(m->b[2].p, off, (size_t)(nq + 1) * 4, hipMemcpyHostToDevice, st));
+    if (nc > 0) ORBFE_HIP(hipMemcpyAsync(m->b[3].p, cand, nc * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_hamming_csr, dim3((nq + 255) / 256), dim3(256), 0, st, (const uint8_t *)m->b[0].p, nq,
+                       (const uint8_t *)m->b[1].p, (const uint32_t *)m->b[2].p, (const uint32_t *)m->b[3].p,
+                       (int32_t *)m->b[4].p, (int32_t *)m->b[5].p, (int32_t *)m->b[6].p);
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpyAsync(best_idx, m->b[4].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipMemcpyAsync(best, m->b[5].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipMemcpyAsync(second, m->b[6].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    return ORBFE_OK;
+}

@@ -1,0 +1,116 @@
+"""Host-side mirror of the Hamming core of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:33-134).
+
+Same constructor `(nnratio=0.6, checkOri=True)`, same public constants, same method names for the
+part of the class that is on the hot path.  Map points / keyframes are passed
+as plain arrays: descriptors, "has a good MapPoint" flags, keypoint angles and the DBoW2
+FeatureVector as CSR (node ids ascending, offsets, feature indices).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, ptr
+
+
+def feature_vector_to_csr(fv):
+    """dict / mapping {node_id: [feature indices]} (DBoW2::FeatureVector) -> (node, off, idx) uint32 arrays."""
+    nodes = sorted(fv.keys())
+    node = np.asarray(nodes, np.uint32)
+    off = np.zeros(len(nodes) + 1, np.uint32)
+    idx = []
+    for i, k in enumerate(nodes):
+        idx.extend(int(v) for v in fv[k])
+        off[i + 1] = len(idx)
+    return node, off, np.asarray(idx, np.uint32)
+
+
+class ORBmatcher:
+    TH_HIGH = 100      # src/ORBmatcher.cc:39
+    TH_LOW = 50        # src/ORBmatcher.cc:40
+    HISTO_LENGTH = 30  # src/ORBmatcher.cc:41
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=-1):
+        self._L = _ffi.lib()
+        self._m = C.c_void_p()
+        check(self._L.orbfe_matcher_create(device, C.byref(self._m)), "orbfe_matcher_create")
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._L.orbfe_matcher_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._m
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """static int DescriptorDistance(const cv::Mat&, const cv::Mat&) (src/ORBmatcher.cc:1968-1984)."""
+        a = np.ascontiguousarray(a, np.uint8).reshape(32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(32)
+        return int(_ffi.lib().orbfe_hamming(ptr(a), ptr(b)))
+
+    def MatchBruteForce(self, descQ, descT, anglesQ=None, anglesT=None, th=None):
+        """BASELINE config 3: all-pairs best / second-best + ratio + rotation histogram.
+        Returns (match_q2t, best, second, nmatches)."""
+        q = np.ascontiguousarray(descQ, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(descT, np.uint8).reshape(-1, 32)
+        qa = None if anglesQ is None else np.ascontiguousarray(anglesQ, np.float32)
+        ta = None if anglesT is None else np.ascontiguousarray(anglesT, np.float32)
+        th = self.TH_HIGH if th is None else th
+        m = np.full(len(q), -1, np.int32)
+        b = np.full(len(q), 256, np.int32)
+        s = np.full(len(q), 256, np.int32)
+        n = C.c_int32(0)
+        st = self._L.orbfe_match_bf(self._m, ptr(q), len(q), ptr(t), len(t), ptr(qa), ptr(ta), self.mfNNratio, th,
+                                    int(self.mbCheckOrientation), ptr(m), ptr(b), ptr(s), C.byref(n))
+        check(st, "orbfe_match_bf")
+        return m, b, s, n.value
+
+    def SearchByBoW(self, descKF, validKF, anglesKF, fvKF, descF, validF, anglesF, fvF, strict_lt=None, th_low=None):
+        """SearchByBoW(KeyFrame*, Frame&, ...) when validF is None (src/ORBmatcher.cc:217-363),
+        SearchByBoW(KeyFrame*, KeyFrame*, ...) otherwise (src/ORBmatcher.cc:665-812).
+        fvKF / fvF: (node, off, idx) CSR or a {node: [indices]} mapping.  Returns (matchF2KF, nmatches)."""
+        if isinstance(fvKF, dict):
+            fvKF = feature_vector_to_csr(fvKF)
+        if isinstance(fvF, dict):
+            fvF = feature_vector_to_csr(fvF)
+        dk = np.ascontiguousarray(descKF, np.uint8).reshape(-1, 32)
+        df = np.ascontiguousarray(descF, np.uint8).reshape(-1, 32)
+        vk = None if validKF is None else np.ascontiguousarray(validKF, np.uint8)
+        vf = None if validF is None else np.ascontiguousarray(validF, np.uint8)
+        ak = np.ascontiguousarray(anglesKF, np.float32)
+        af = np.ascontiguousarray(anglesF, np.float32)
+        nk, ok, ik = [np.ascontiguousarray(a, np.uint32) for a in fvKF]
+        nf, of, if_ = [np.ascontiguousarray(a, np.uint32) for a in fvF]
+        if strict_lt is None:
+            strict_lt = validF is not None
+        th_low = self.TH_LOW if th_low is None else th_low
+        m = np.full(len(df), -1, np.int32)
+        n = C.c_int32(0)
+        st = self._L.orbfe_search_by_bow(self._m, ptr(dk), len(dk), ptr(vk), ptr(ak), ptr(nk), ptr(ok), ptr(ik),
+                                         len(nk), ptr(df), len(df), ptr(vf), ptr(af), ptr(nf), ptr(of), ptr(if_),
+                                         len(nf), self.mfNNratio, th_low, int(strict_lt),
+                                         int(self.mbCheckOrientation), ptr(m), C.byref(n))
+        check(st, "orbfe_search_by_bow")
+        return m, n.value
+
+    def HammingCSR(self, descQ, descT, off, cand):
+        """best / second-best over per-query candidate lists (SearchByProjection family)."""
+        q = np.ascontiguousarray(descQ, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(descT, np.uint8).reshape(-1, 32)
+        off = np.ascontiguousarray(off, np.uint32)
+        cand = np.ascontiguousarray(cand, np.uint32)
+        bi = np.full(len(q), -1, np.int32)
+        b = np.full(len(q), 256, np.int32)
+        s = np.full(len(q), 256, np.int32)
+        st = self._L.orbfe_hamming_csr(self._m, ptr(q), len(q), ptr(t), len(t), ptr(off), ptr(cand), ptr(bi), ptr(b),
+                                       ptr(s))
+        check(st, "orbfe_hamming_csr")
+        return bi, b, s
