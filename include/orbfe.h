@@ -146,9 +146,11 @@ enum {
     ORBFE_T_TOTAL = 5,   /* first launch -> last launch                          */
     ORBFE_T_COUNT = 6
 };
-/* enable != 0: record events around each stage of subsequent calls (adds a few us per call) */
+/* enable != 0: record events around each stage of subsequent calls (adds a few us per call) and reset
+ * the averaging window */
 orbfe_status orbfe_set_profiling(orbfe_handle *h, int32_t enable);
-/* milliseconds per stage of the last profiled call; synchronises the stream */
+/* milliseconds per stage, AVERAGED over the calls made since profiling was enabled (the 64 most recent at
+ * most); waits for those calls to finish */
 orbfe_status orbfe_get_stage_ms(orbfe_handle *h, float ms[ORBFE_T_COUNT]);
 
 /* ---------------------------------------------------------------------------------------------

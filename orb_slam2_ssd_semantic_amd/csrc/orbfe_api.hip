@@ -121,6 +121,8 @@ struct PinBuf {
 // ---------------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------------
+#define ORBFE_PROF_RING 64
+
 struct orbfe_handle {
     orbfe_params prm;
     int device = 0;
@@ -144,9 +146,10 @@ struct orbfe_handle {
     int64_t last_gray_fstride = 0;
     int32_t last_gray_pitch = 0;
     int32_t last_nframes = 0;
-    // profiling
-    bool profiling = false, have_times = false;
-    hipEvent_t ev[ORBFE_T_COUNT + 1];
+    // profiling: ring of event sets so a timed region of many asynchronous calls can be averaged afterwards
+    bool profiling = false;
+    hipEvent_t ev[ORBFE_PROF_RING][ORBFE_T_COUNT];
+    int prof_calls = 0;  // calls recorded since profiling was (re-)enabled
     bool ev_ok = false;
 };
 
@@ -399,9 +402,12 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
         orbfe_set_error("hipStreamCreate failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(ORBFE_ERR_HIP);
     }
-    for (int i = 0; i <= ORBFE_T_COUNT; ++i)
-        if (hipEventCreate(&h->ev[i]) != hipSuccess) { orbfe_set_error("hipEventCreate failed"); return fail(ORBFE_ERR_HIP); }
+    for (int r = 0; r < ORBFE_PROF_RING; ++r)
+        for (int i = 0; i < ORBFE_T_COUNT; ++i) h->ev[r][i] = nullptr;
     h->ev_ok = true;
+    for (int r = 0; r < ORBFE_PROF_RING; ++r)
+        for (int i = 0; i < ORBFE_T_COUNT; ++i)
+            if (hipEventCreate(&h->ev[r][i]) != hipSuccess) { orbfe_set_error("hipEventCreate failed"); return fail(ORBFE_ERR_HIP); }
     int umax[16];
     host_umax(umax);
     if (orbk_upload_constants(umax) != hipSuccess) {
@@ -428,7 +434,9 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
     for (PinBuf *b : pins) b->release();
     if (h->ev_ok)
-        for (int i = 0; i <= ORBFE_T_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
+        for (int r = 0; r < ORBFE_PROF_RING; ++r)
+            for (int i = 0; i < ORBFE_T_COUNT; ++i)
+                if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -465,18 +473,29 @@ extern "C" orbfe_status orbfe_set_profiling(orbfe_handle *h, int32_t enable)
 {
     if (!h) return ORBFE_ERR_ARG;
     h->profiling = enable != 0;
-    h->have_times = false;
+    h->prof_calls = 0;
     return ORBFE_OK;
 }
 
 extern "C" orbfe_status orbfe_get_stage_ms(orbfe_handle *h, float ms[ORBFE_T_COUNT])
 {
     if (!h || !ms) return ORBFE_ERR_ARG;
-    if (!h->have_times) { orbfe_set_error("no profiled call yet"); return ORBFE_ERR_STATE; }
+    if (h->prof_calls == 0) { orbfe_set_error("no profiled call yet"); return ORBFE_ERR_STATE; }
     DeviceGuard g(h->device);
-    ORBFE_HIP(hipEventSynchronize(h->ev[ORBFE_T_TOTAL]));
-    for (int i = 0; i < ORBFE_T_TOTAL; ++i) ORBFE_HIP(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
-    ORBFE_HIP(hipEventElapsedTime(&ms[ORBFE_T_TOTAL], h->ev[0], h->ev[ORBFE_T_TOTAL]));
+    const int ncalls = std::min(h->prof_calls, ORBFE_PROF_RING);
+    double acc[ORBFE_T_COUNT] = {0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < ncalls; ++c) {
+        hipEvent_t *e = h->ev[(h->prof_calls - 1 - c) % ORBFE_PROF_RING];
+        ORBFE_HIP(hipEventSynchronize(e[ORBFE_T_TOTAL]));
+        float t;
+        for (int i = 0; i < ORBFE_T_TOTAL; ++i) {
+            ORBFE_HIP(hipEventElapsedTime(&t, e[i], e[i + 1]));
+            acc[i] += t;
+        }
+        ORBFE_HIP(hipEventElapsedTime(&t, e[0], e[ORBFE_T_TOTAL]));
+        acc[ORBFE_T_TOTAL] += t;
+    }
+    for (int i = 0; i < ORBFE_T_COUNT; ++i) ms[i] = (float)(acc[i] / ncalls);
     return ORBFE_OK;
 }
 
@@ -527,20 +546,20 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_desc = d_desc;
     a.cap = cap;
     a.d_n_out = d_n_out;
-    const bool prof = h->profiling;
-    if (prof) ORBFE_HIP(hipEventRecord(h->ev[0], st));
+    hipEvent_t *ev = h->profiling ? h->ev[h->prof_calls % ORBFE_PROF_RING] : nullptr;
+    if (ev) ORBFE_HIP(hipEventRecord(ev[0], st));
     ORBFE_HIP(orbk_launch_pyramid(a, st));
-    if (prof) ORBFE_HIP(hipEventRecord(h->ev[1], st));
+    if (ev) ORBFE_HIP(hipEventRecord(ev[1], st));
     ORBFE_HIP(orbk_launch_fast(a, st));
-    if (prof) ORBFE_HIP(hipEventRecord(h->ev[2], st));
+    if (ev) ORBFE_HIP(hipEventRecord(ev[2], st));
     ORBFE_HIP(orbk_launch_octree(a, st));
-    if (prof) ORBFE_HIP(hipEventRecord(h->ev[3], st));
+    if (ev) ORBFE_HIP(hipEventRecord(ev[3], st));
     ORBFE_HIP(orbk_launch_blur(a, st));
-    if (prof) ORBFE_HIP(hipEventRecord(h->ev[4], st));
+    if (ev) ORBFE_HIP(hipEventRecord(ev[4], st));
     ORBFE_HIP(orbk_launch_describe(a, st));
-    if (prof) {
-        ORBFE_HIP(hipEventRecord(h->ev[5], st));
-        h->have_times = true;
+    if (ev) {
+        ORBFE_HIP(hipEventRecord(ev[5], st));
+        h->prof_calls++;
     }
     h->last_gray = d_gray;
     h->last_gray_fstride = (int64_t)frame_stride;

@@ -1,0 +1,193 @@
+"""Parity of the HIP extractor (through the C-ABI) against the CPU oracle and the golden fixtures.
+Bar: bit-exact keypoints (x, y, size, angle, response, octave, class_id), descriptors and ORDER."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from orb_slam2_ssd_semantic_amd.synth import synth_frame
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_golden.npz")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def assert_same_output(gk, gd, ok, od):
+    assert len(gk) == len(ok), (len(gk), len(ok))
+    for f in ok.dtype.names:
+        bad = np.nonzero(gk[f].view(np.uint32) != ok[f].view(np.uint32))[0]
+        assert len(bad) == 0, (f, bad[:5], gk[f][bad[:5]], ok[f][bad[:5]])
+    assert np.array_equal(gd, od)
+
+
+def cand_array(c):
+    return np.stack([c["x"], c["y"], c["response"]], 1) if len(c) else np.zeros((0, 3), np.float32)
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    return ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=8)
+
+
+@pytest.mark.parametrize("seed,sparse", [(0, False), (1, False), (2, True), (3, True), (11, False)])
+def test_stage_by_stage_parity(oracle, ext, seed, sparse):
+    img = synth_frame(seed, sparse=sparse)
+    oe = oracle.OracleExtractor()
+    ok, od = oe(img)
+    gk, gd = ext(img)
+    for l in range(8):
+        assert np.array_equal(ext.pyramid_level(l), oe.level(l)), f"pyramid level {l}"
+        assert np.array_equal(ext.blurred_level(l), oe.blurred(l)), f"blurred level {l}"
+        assert np.array_equal(ext.candidates(l), cand_array(oe.candidates(l))), f"FAST candidates level {l}"
+        assert np.array_equal(ext.selected(l), cand_array(oe.selected(l))), f"quadtree level {l}"
+    assert_same_output(gk, gd, ok, od)
+
+
+def test_golden_fixtures(ext):
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    g = np.load(GOLD)
+    cases = [("A_dense_s0", 0, 480, 640, False, 1000), ("A_dense_s1", 1, 480, 640, False, 1000),
+             ("A_sparse_s2", 2, 480, 640, True, 1000), ("B_dense_s10000", 10000, 480, 640, False, 2000),
+             ("odd_517x389_s7", 7, 389, 517, False, 500)]
+    for name, seed, h, w, sparse, nf in cases:
+        img = synth_frame(seed, h, w, sparse)
+        assert sha(img) == str(g[f"{name}/img_sha"])
+        e = ext if nf == 1000 else ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+        gk, gd = e(img)
+        assert_same_output(gk, gd, g[f"{name}/kps"], g[f"{name}/desc"])
+        assert [sha(e.pyramid_level(l)) for l in range(8)] == g[f"{name}/level_sha"].tolist()
+        assert [len(e.candidates(l)) for l in range(8)] == g[f"{name}/ncand"].tolist()
+
+
+@pytest.mark.parametrize("h,w,nf,nlev,sf,ini,mn", [
+    (480, 752, 1200, 8, 1.2, 20, 7),      # EuRoC-like aspect
+    (376, 1241, 2000, 8, 1.2, 20, 7),     # KITTI-like: 3 quadtree roots
+    (300, 300, 500, 8, 1.2, 20, 7),
+    (240, 320, 300, 4, 1.5, 15, 5),
+    (480, 640, 1000, 1, 1.2, 20, 7),      # single level
+    (480, 640, 60, 8, 1.2, 20, 7),        # tiny N: some levels ask for < 4 features
+    (480, 640, 3000, 8, 1.2, 40, 40),     # iniTh == minTh
+    (233, 311, 400, 6, 1.3, 12, 3),
+])
+def test_parameter_sweep(oracle, h, w, nf, nlev, sf, ini, mn):
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    img = synth_frame(100 + h + w, h, w)
+    oe = oracle.OracleExtractor(nf, sf, nlev, ini, mn)
+    ok, od = oe(img, cap=nf + 16 * nlev + 64)
+    e = ORBextractor(nf, sf, nlev, ini, mn, max_width=w, max_height=h)
+    gk, gd = e(img)
+    assert_same_output(gk, gd, ok, od)
+    assert np.array_equal(e.GetScaleFactors(), oe.scales()[0])
+    assert np.array_equal(e.GetInverseScaleSigmaSquares(), oe.scales()[3])
+    assert np.array_equal(e.mnFeaturesPerLevel, oe.features_per_level())
+
+
+def test_1080p_4000_features(oracle):
+    """BASELINE config 5 frame shape: 1920x1080, 4000 features (one frame against the oracle)."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    img = synth_frame(20000, 1080, 1920)
+    oe = oracle.OracleExtractor(4000, 1.2, 8, 20, 7)
+    ok, od = oe(img, cap=4200)
+    e = ORBextractor(4000, 1.2, 8, 20, 7, max_width=1920, max_height=1080)
+    gk, gd = e(img)
+    assert_same_output(gk, gd, ok, od)
+    for l in (0, 3, 7):
+        assert np.array_equal(e.candidates(l), cand_array(oe.candidates(l)))
+
+
+def test_edge_cases(oracle, ext):
+    from orb_slam2_ssd_semantic_amd import ORBextractor, OrbfeError, _ffi
+    # empty image: silent return, outputs untouched (src/ORBextractor.cc:1055-1056)
+    assert ext(np.zeros((0, 0), np.uint8)) == (None, None)
+    L = _ffi.lib()
+    n = C.c_int32(-5)
+    assert L.orbfe_extract(ext.handle, None, 0, 0, 0, None, None, 0, C.byref(n)) == 0 and n.value == -5
+    # flat image: zero keypoints (descriptors.release(), :1073-1074)
+    k, d = ext(np.full((480, 640), 90, np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    # non-contiguous rows (stride != width)
+    img = synth_frame(5)
+    wide = np.zeros((480, 800), np.uint8)
+    wide[:, :640] = img
+    k1, d1 = ext(img)
+    k2, d2 = ext(wide[:, :640])
+    assert np.array_equal(k1, k2) and np.array_equal(d1, d2)
+    # frame larger than planned / smaller than one FAST cell per level -> ORBFE_ERR_SIZE
+    with pytest.raises(OrbfeError) as ei:
+        ext(np.zeros((481, 640), np.uint8))
+    assert ei.value.status == _ffi.ORBFE_ERR_SIZE
+    with pytest.raises(OrbfeError) as ei:
+        ext(np.zeros((120, 160), np.uint8))
+    assert ei.value.status == _ffi.ORBFE_ERR_SIZE
+    # capacity too small -> ORBFE_ERR_CAP and n_out reports the need
+    kps = np.zeros(10, _ffi.KP_DTYPE)
+    desc = np.zeros((10, 32), np.uint8)
+    st = L.orbfe_extract(ext.handle, img.ctypes.data_as(C.c_void_p), 640, 480, 640, kps.ctypes.data_as(C.c_void_p),
+                         desc.ctypes.data_as(C.c_void_p), 10, C.byref(n))
+    assert st == _ffi.ORBFE_ERR_CAP and n.value == len(k1)
+    # smaller frame on the same handle re-plans; then back
+    small = synth_frame(6, 300, 400)
+    ks, ds = ext(small)
+    oks, ods = oracle.OracleExtractor()(small)
+    assert_same_output(ks, ds, oks, ods)
+    k3, d3 = ext(img)
+    assert np.array_equal(k1, k3) and np.array_equal(d1, d3)
+
+
+def test_padded_pyramid_is_reflect101(oracle, ext):
+    """mvImagePyramid with the 19-px BORDER_REFLECT_101 frame (src/ORBextractor.cc:1136-1142)."""
+    img = synth_frame(8)
+    ext(img)
+    oe = oracle.OracleExtractor()
+    oe(img)
+    for l in (0, 1, 7):
+        assert np.array_equal(ext.pyramid_level(l, with_border=True), oracle.copy_make_border101(oe.level(l), 19))
+
+
+def test_batch_equals_single_and_is_idempotent(oracle, ext):
+    imgs = [synth_frame(40 + i, sparse=(i % 3 == 0)) for i in range(11)]   # > max_batch: exercises chunking
+    res = ext.extract_batch(imgs)
+    oe = oracle.OracleExtractor()
+    for i, (k, d) in enumerate(res):
+        if i < 4:
+            ok, od = oe(imgs[i])
+            assert_same_output(k, d, ok, od)
+        ks, ds = ext(imgs[i])
+        assert np.array_equal(k, ks) and np.array_equal(d, ds)
+    res2 = ext.extract_batch(imgs[::-1])[::-1]                               # order of frames is irrelevant
+    for (k, d), (k2, d2) in zip(res, res2):
+        assert np.array_equal(k, k2) and np.array_equal(d, d2)
+
+
+def test_device_api_with_torch_tensors(oracle):
+    """HBM-resident batched mode (what bench.py times): torch only provides memory and the stream."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    B, cap = 6, 2112
+    e = ORBextractor(2000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=B)
+    assert cap >= e.capacity()
+    frames = np.stack([synth_frame(10000 + i) for i in range(B)])
+    d_gray = torch.from_numpy(frames).cuda()
+    d_kps = torch.full((B, cap, 7), -1, dtype=torch.int32, device="cuda")
+    d_desc = torch.full((B, cap, 32), 255, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    e.extract_batch_device(d_gray.data_ptr(), B, 640, 480, 640, 640 * 480, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                           d_n.data_ptr(), stream)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy()
+    desc = d_desc.cpu().numpy()
+    oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE
+    for i in range(B):
+        ok, od = oe(frames[i], cap=cap)
+        gk = kps[i, :n[i]].copy().view(KP_DTYPE).reshape(-1)
+        assert_same_output(gk, desc[i, :n[i]], ok, od)
+        assert not kps[i, n[i]:].any() and not desc[i, n[i]:].any()       # padding zero-filled for the all-gather
