@@ -107,13 +107,16 @@ orbfe_status orbfe_extract_batch(orbfe_handle *h, const uint8_t *const *grays, i
 /* Batched keyframe mode, DEVICE buffers (HBM-resident input, what bench.py times):
  *   d_gray   : nframes frames, frame i at d_gray + i*frame_stride, row pitch `stride`
  *   d_kps    : nframes*cap orbfe_keypoint      d_desc : nframes*cap*32 bytes     d_n_out : nframes int32
- * All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the handle's own stream)
- * and the call returns without synchronising.  Slots >= n_out[i] of a frame are zero-filled so the
+ * All work is enqueued on `stream`, a hipStream_t passed as void*.  NULL is HIP's (legacy) default stream
+ * -- the stream PyTorch uses unless told otherwise; pass orbfe_get_stream(h) for the handle's own
+ * non-blocking stream.  The call returns without synchronising.  Slots >= n_out[i] of a frame are zero-filled so the
  * padded buffers can be all-gathered as they are. */
 orbfe_status orbfe_extract_batch_device(orbfe_handle *h, const uint8_t *d_gray, int32_t nframes, int32_t w,
                                         int32_t ht, int32_t stride, size_t frame_stride,
                                         orbfe_keypoint *d_kps, uint8_t *d_desc, int32_t cap,
                                         int32_t *d_n_out, void *stream);
+/* the handle's own non-blocking stream (hipStream_t as void*): the host-buffer entry points run on it */
+void *orbfe_get_stream(orbfe_handle *h);
 /* block until everything enqueued by this handle on its own stream has finished */
 orbfe_status orbfe_synchronize(orbfe_handle *h);
 
@@ -176,7 +179,9 @@ orbfe_status orbfe_match_bf(orbfe_matcher *m, const uint8_t *q, int32_t nq, cons
                             const float *q_angle, const float *t_angle, float nnratio, int32_t th,
                             int32_t check_ori, int32_t *match_q2t, int32_t *best, int32_t *second,
                             int32_t *nmatches);
-/* same, DEVICE buffers, enqueued on `stream` (NULL = matcher's stream), no synchronisation;
+void *orbfe_matcher_get_stream(orbfe_matcher *m);
+/* same, DEVICE buffers, enqueued on `stream` (NULL = HIP's default stream, see orbfe_extract_batch_device;
+ * orbfe_matcher_get_stream(m) = the matcher's own stream), no synchronisation;
  * d_nmatches is one int32 in device memory */
 orbfe_status orbfe_match_bf_device(orbfe_matcher *m, const uint8_t *d_q, int32_t nq, const uint8_t *d_t,
                                    int32_t nt, const float *d_q_angle, const float *d_t_angle, float nnratio,

@@ -22,10 +22,10 @@ STAGES = ("pyramid", "fast", "octree", "blur", "describe", "total")
 SYMBOLS = (
     "orbfe_version", "orbfe_strerror", "orbfe_last_error", "orbfe_device_count", "orbfe_create", "orbfe_destroy",
     "orbfe_get_scales", "orbfe_get_features_per_level", "orbfe_keypoint_capacity", "orbfe_extract",
-    "orbfe_extract_batch", "orbfe_extract_batch_device", "orbfe_synchronize", "orbfe_get_level_size",
+    "orbfe_extract_batch", "orbfe_extract_batch_device", "orbfe_get_stream", "orbfe_synchronize", "orbfe_get_level_size",
     "orbfe_get_pyramid_level", "orbfe_tap_blurred_level", "orbfe_tap_candidates", "orbfe_tap_selected",
     "orbfe_set_profiling", "orbfe_get_stage_ms", "orbfe_hamming", "orbfe_matcher_create",
-    "orbfe_matcher_destroy", "orbfe_match_bf", "orbfe_match_bf_device", "orbfe_match_bf_frames_device",
+    "orbfe_matcher_destroy", "orbfe_matcher_get_stream", "orbfe_match_bf", "orbfe_match_bf_device", "orbfe_match_bf_frames_device",
     "orbfe_search_by_bow", "orbfe_hamming_csr",
 )
 
@@ -74,6 +74,10 @@ def lib():
     L.orbfe_extract_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     L.orbfe_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, sz, vp, vp, i32, vp, vp]
     L.orbfe_synchronize.argtypes = [vp]
+    L.orbfe_get_stream.argtypes = [vp]
+    L.orbfe_get_stream.restype = vp
+    L.orbfe_matcher_get_stream.argtypes = [vp]
+    L.orbfe_matcher_get_stream.restype = vp
     L.orbfe_get_level_size.argtypes = [vp, i32, vp, vp]
     L.orbfe_get_pyramid_level.argtypes = [vp, i32, i32, vp, i32, i32]
     L.orbfe_tap_blurred_level.argtypes = [vp, i32, i32, vp, i32]

@@ -499,6 +499,8 @@ extern "C" orbfe_status orbfe_get_stage_ms(orbfe_handle *h, float ms[ORBFE_T_COU
     return ORBFE_OK;
 }
 
+extern "C" void *orbfe_get_stream(orbfe_handle *h) { return h ? (void *)h->stream : nullptr; }
+
 extern "C" orbfe_status orbfe_synchronize(orbfe_handle *h)
 {
     if (!h) return ORBFE_ERR_ARG;
@@ -580,7 +582,7 @@ extern "C" orbfe_status orbfe_extract_batch_device(orbfe_handle *h, const uint8_
     }
     DeviceGuard g(h->device);
     return run_batch(h, d_gray, nframes, w, ht, stride, frame_stride, d_kps, d_desc, cap, d_n_out,
-                     stream ? (hipStream_t)stream : h->stream);
+                     (hipStream_t)stream);
 }
 
 // host buffers: stage through pinned memory in chunks of max_batch frames

@@ -423,6 +423,8 @@ extern "C" orbfe_status orbfe_matcher_create(int32_t device, orbfe_matcher **out
     return ORBFE_OK;
 }
 
+extern "C" void *orbfe_matcher_get_stream(orbfe_matcher *m) { return m ? (void *)m->stream : nullptr; }
+
 extern "C" void orbfe_matcher_destroy(orbfe_matcher *m)
 {
     if (!m) return;
@@ -462,7 +464,7 @@ extern "C" orbfe_status orbfe_match_bf_device(orbfe_matcher *m, const uint8_t *d
     }
     MDeviceGuard g(m->device);
     return launch_bf(d_q, nq, d_t, nt, d_q_angle, d_t_angle, 1, nnratio, th, check_ori, d_match_q2t, d_best, d_second,
-                     d_nmatches, stream ? (hipStream_t)stream : m->stream);
+                     d_nmatches, (hipStream_t)stream);
 }
 
 extern "C" orbfe_status orbfe_match_bf(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
@@ -523,7 +525,7 @@ extern "C" orbfe_status orbfe_match_bf_frames_device(orbfe_matcher *m, const orb
     }
     if (npairs == 0) return ORBFE_OK;
     MDeviceGuard g(m->device);
-    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    hipStream_t st = (hipStream_t)stream;
     dim3 grid((cap + 63) / 64, npairs);
     hipLaunchKernelGGL(k_match_bf, grid, dim3(BF_WAVES * 64), 0, st, d_desc, d_desc, d_n, d_qframe, d_tframe, cap, 0, 0,
                        nnratio, th, d_match_q2t, (int32_t *)nullptr, (int32_t *)nullptr);

@@ -1,0 +1,115 @@
+// ORBextractor.cc -- shim over the C-ABI.  Replaces the reference's src/ORBextractor.cc in libORB_SLAM2.
+#include "ORBextractor.h"
+
+#include <assert.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "orbfe.h"
+
+namespace ORB_SLAM2 {
+
+ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
+    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST)
+{
+    // scale tables are identical to the reference constructor (src/ORBextractor.cc:404-421); recomputed here so
+    // the getters work before the first frame fixes the device plan
+    mvScaleFactor.resize(nlevels);
+    mvLevelSigma2.resize(nlevels);
+    mvInvScaleFactor.resize(nlevels);
+    mvInvLevelSigma2.resize(nlevels);
+    mvScaleFactor[0] = 1.0f;
+    mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+        mvScaleFactor[i] = mvScaleFactor[i - 1] * _scaleFactor;
+        mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i];
+    }
+    for (int i = 0; i < nlevels; i++) {
+        mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i];
+        mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i];
+    }
+    mvImagePyramid.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels);
+}
+
+ORBextractor::~ORBextractor() { orbfe_destroy(mpHandle); }
+
+bool ORBextractor::EnsureHandle(int w, int h)
+{
+    if (mpHandle && w <= mPlanW && h <= mPlanH) return true;
+    orbfe_destroy(mpHandle);
+    mpHandle = nullptr;
+    orbfe_params p;
+    memset(&p, 0, sizeof(p));
+    p.nfeatures = nfeatures;
+    p.scale_factor = (float)scaleFactor;
+    p.nlevels = nlevels;
+    p.ini_th_fast = iniThFAST;
+    p.min_th_fast = minThFAST;
+    p.max_width = w > mPlanW ? w : mPlanW;
+    p.max_height = h > mPlanH ? h : mPlanH;
+    p.max_batch = 1;
+    p.device = -1;
+    mLastStatus = orbfe_create(&p, &mpHandle);
+    if (mLastStatus != ORBFE_OK) {
+        fprintf(stderr, "ORBextractor: orbfe_create failed: %s (%s)\n", orbfe_strerror(mLastStatus), orbfe_last_error());
+        return false;
+    }
+    mPlanW = p.max_width;
+    mPlanH = p.max_height;
+    orbfe_get_scales(mpHandle, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data());
+    orbfe_get_features_per_level(mpHandle, mnFeaturesPerLevel.data());
+    return true;
+}
+
+void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint> &_keypoints,
+                              cv::OutputArray _descriptors)
+{
+    if (_image.empty()) return;  // src/ORBextractor.cc:1055-1056
+    cv::Mat image = _image.getMat();
+    assert(image.type() == CV_8UC1);  // :1059
+    if (!EnsureHandle(image.cols, image.rows)) return;
+    const int cap = orbfe_keypoint_capacity(mpHandle);
+    static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_keypoint), "cv::KeyPoint layout");
+    _keypoints.resize(cap);
+    cv::Mat desc(cap, 32, CV_8U);
+    int n = 0;
+    mLastStatus = orbfe_extract(mpHandle, image.ptr<uint8_t>(0), image.cols, image.rows, (int)image.step,
+                                reinterpret_cast<orbfe_keypoint *>(_keypoints.data()), desc.ptr<uint8_t>(0), cap, &n);
+    if (mLastStatus != ORBFE_OK) {
+        fprintf(stderr, "ORBextractor: orbfe_extract failed: %s (%s)\n", orbfe_strerror(mLastStatus), orbfe_last_error());
+        _keypoints.clear();
+        _descriptors.release();
+        return;
+    }
+    _keypoints.resize(n);
+    if (n == 0) {
+        _descriptors.release();  // :1073-1074
+    } else {
+        _descriptors.create(n, 32, CV_8U);  // :1077
+        cv::Mat out = _descriptors.getMat();
+        for (int i = 0; i < n; ++i) memcpy(out.ptr<uint8_t>(i), desc.ptr<uint8_t>(i), 32);
+    }
+    if (mbKeepPyramid) SyncImagePyramid();
+}
+
+void ORBextractor::SyncImagePyramid()
+{
+    if (!mpHandle) return;
+    const int E = 19;  // EDGE_THRESHOLD
+    mvPadded.resize(nlevels);
+    for (int l = 0; l < nlevels; ++l) {
+        int w = 0, h = 0;
+        if (orbfe_get_level_size(mpHandle, l, &w, &h) != ORBFE_OK) return;
+        mvPadded[l].create(h + 2 * E, w + 2 * E, CV_8U);
+        mLastStatus = orbfe_get_pyramid_level(mpHandle, 0, l, mvPadded[l].ptr<uint8_t>(0), (int)mvPadded[l].step, 1);
+        if (mLastStatus != ORBFE_OK) return;
+#ifdef ORBFE_WITH_OPENCV
+        mvImagePyramid[l] = mvPadded[l](cv::Rect(E, E, w, h));  // ROI inside the padded buffer (:1128)
+#else
+        mvImagePyramid[l] = mvPadded[l].roi(E, E, w, h);
+#endif
+    }
+}
+
+}  // namespace ORB_SLAM2

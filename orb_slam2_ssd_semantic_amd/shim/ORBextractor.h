@@ -1,0 +1,63 @@
+// ORBextractor.h -- drop-in replacement for the reference's include/ORBextractor.h:35-116.
+// Same namespace, class name, constructor, operator() signature, getters and public mvImagePyramid, so
+// src/Frame.cc / src/Tracking.cc of the reference compile unchanged against it; all work is forwarded to the
+// C-ABI in include/orbfe.h (HIP kernels, no CPU path).
+#pragma once
+#include <vector>
+
+#ifdef ORBFE_WITH_OPENCV
+#include <opencv/cv.h>
+#else
+#include "cv_stub/orbfe_cv_stub.h"
+#endif
+
+struct orbfe_handle;
+
+namespace ORB_SLAM2 {
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+    ~ORBextractor();
+
+    // Compute the ORB features and descriptors on an image.  Mask is ignored (as in the reference).
+    void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint> &keypoints,
+                    cv::OutputArray descriptors);
+
+    int inline GetLevels() { return nlevels; }
+    float inline GetScaleFactor() { return scaleFactor; }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // The padded pyramid lives on the device.  Mono / RGB-D tracking never reads it; stereo does
+    // (Frame::ComputeStereoMatches, reference src/Frame.cc:649,761-778): set mbKeepPyramid = true there and every
+    // operator() refreshes mvImagePyramid[l] as an ROI of the (w+38)x(h+38) REFLECT_101-padded level.
+    std::vector<cv::Mat> mvImagePyramid;
+    bool mbKeepPyramid = false;
+    void SyncImagePyramid();
+
+    int LastStatus() const { return mLastStatus; }  // orbfe_status of the last call (the reference has no error path)
+
+protected:
+    int nfeatures;
+    double scaleFactor;
+    int nlevels;
+    int iniThFAST;
+    int minThFAST;
+    std::vector<int> mnFeaturesPerLevel;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+
+private:
+    bool EnsureHandle(int w, int h);
+    orbfe_handle *mpHandle = nullptr;
+    int mPlanW = 0, mPlanH = 0, mLastStatus = 0;
+    std::vector<cv::Mat> mvPadded;
+    ORBextractor(const ORBextractor &);
+    ORBextractor &operator=(const ORBextractor &);
+};
+
+}  // namespace ORB_SLAM2

@@ -1,0 +1,108 @@
+"""The C++ shim (orb_slam2_ssd_semantic_amd/shim) keeps the reference's class/call shapes and links against the
+C-ABI.  CPU: it compiles and links with g++.  GPU: the binary's outputs equal the oracle's."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from orb_slam2_ssd_semantic_amd.synth import synth_frame
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_shim")
+
+
+def build_shim():
+    from orb_slam2_ssd_semantic_amd import _build
+    _build.build()
+    srcs = [os.path.join(ROOT, "tests", "cpp", "test_shim.cpp"),
+            os.path.join(ROOT, "orb_slam2_ssd_semantic_amd", "shim", "ORBextractor.cc")]
+    deps = srcs + [os.path.join(ROOT, "orb_slam2_ssd_semantic_amd", "shim", f) for f in
+                   ("ORBextractor.h", "ORBmatcher.h", "cv_stub/orbfe_cv_stub.h")] + [_build.LIB]
+    if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
+        return EXE
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I",
+           os.path.join(ROOT, "orb_slam2_ssd_semantic_amd", "shim"), *srcs, "-L",
+           os.path.join(ROOT, "orb_slam2_ssd_semantic_amd"), "-lorbfe",
+           "-Wl,-rpath," + os.path.join(ROOT, "orb_slam2_ssd_semantic_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", EXE]
+    subprocess.check_call(cmd)
+    return EXE
+
+
+def test_shim_compiles_and_links():
+    exe = build_shim()
+    assert os.path.exists(exe)
+    hdr = open(os.path.join(ROOT, "orb_slam2_ssd_semantic_amd", "shim", "ORBextractor.h")).read()
+    # the reference's public surface (include/ORBextractor.h:35-116) is present verbatim
+    for s in ("namespace ORB_SLAM2", "class ORBextractor", "enum { HARRIS_SCORE = 0, FAST_SCORE = 1 }",
+              "ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)",
+              "void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint> &keypoints",
+              "GetLevels()", "GetScaleFactor()", "GetScaleFactors()", "GetInverseScaleFactors()",
+              "GetScaleSigmaSquares()", "GetInverseScaleSigmaSquares()", "std::vector<cv::Mat> mvImagePyramid"):
+        assert s in hdr, s
+    mh = open(os.path.join(ROOT, "orb_slam2_ssd_semantic_amd", "shim", "ORBmatcher.h")).read()
+    for s in ("ORBmatcher(float nnratio = 0.6, bool checkOri = true)", "static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)",
+              "TH_LOW = 50", "TH_HIGH = 100", "HISTO_LENGTH = 30", "int SearchByBoW("):
+        assert s in mh, s
+
+
+@pytest.mark.gpu
+def test_shim_outputs_equal_oracle(oracle, tmp_path):
+    exe = build_shim()
+    W, H, nf = 640, 480, 1000
+    frames = np.stack([synth_frame(70), synth_frame(71)])
+    raw = tmp_path / "in.raw"
+    out = tmp_path / "out.bin"
+    frames.tofile(raw)
+    r = subprocess.run([exe, str(raw), str(W), str(H), str(nf), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    blob = open(out, "rb").read()
+    pos = 0
+    oe = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    res = []
+    for k in range(2):
+        n = struct.unpack_from("<i", blob, pos)[0]
+        pos += 4
+        kps = np.frombuffer(blob, oracle.KP_DTYPE, n, pos)
+        pos += 28 * n
+        desc = np.frombuffer(blob, np.uint8, 32 * n, pos).reshape(n, 32)
+        pos += 32 * n
+        ok, od = oe(frames[k])
+        assert np.array_equal(kps, ok) and np.array_equal(desc, od)
+        res.append((ok, od))
+    lvl7 = oracle.copy_make_border101(oe.level(7), 19)   # pyramid of the last frame
+    n1, n2, n3, d01 = struct.unpack_from("<4i", blob, pos)
+    pos += 16
+    (k0, d0), (k1, d1) = res
+    mp1 = np.frombuffer(blob, np.int32, len(k1), pos); pos += 4 * len(k1)
+    mp2 = np.frombuffer(blob, np.int32, len(k0), pos); pos += 4 * len(k0)
+    bf = np.frombuffer(blob, np.int32, len(k1), pos); pos += 4 * len(k1)
+    lw, lh = struct.unpack_from("<2i", blob, pos); pos += 8
+    pyr = np.frombuffer(blob, np.uint8, (lw + 38) * (lh + 38), pos).reshape(lh + 38, lw + 38)
+    assert np.array_equal(pyr, lvl7)
+    assert d01 == oracle.hamming(d0[0], d0[1])
+
+    def fv(desc):
+        f = {}
+        for i in range(len(desc)):
+            f.setdefault(int(desc[i, 0] >> 2), []).append(i)
+        return f
+
+    def valid(n):
+        i = np.arange(n)
+        return ((i % 7 != 0) & (i % 11 != 0)).astype(np.uint8)
+
+    from orb_slam2_ssd_semantic_amd.matcher import feature_vector_to_csr as csr
+    # (KeyFrame*, Frame&): F features get the KF map point
+    m, n = oracle.search_by_bow(d0, valid(len(d0)), k0["angle"], csr(fv(d0)), d1, None, k1["angle"], csr(fv(d1)), 0.7, 50,
+                                False, True)
+    assert n == n1 and np.array_equal(m, mp1)
+    # (KeyFrame*, KeyFrame*): output indexed by KF1 feature, value = KF2 map point
+    m, n = oracle.search_by_bow(d0, valid(len(d0)), k0["angle"], csr(fv(d0)), d1, valid(len(d1)), k1["angle"], csr(fv(d1)),
+                                0.75, 50, True, True)
+    inv = np.full(len(d0), -1, np.int32)
+    inv[m[m >= 0]] = np.nonzero(m >= 0)[0]
+    assert n == n2 and np.array_equal(inv, mp2)
+    mb, _, _, nb = oracle.match_bf(d1, d0, k1["angle"], k0["angle"], 0.9, 100, True)
+    assert nb == n3 and np.array_equal(mb, bf)
