@@ -135,7 +135,7 @@ struct orbfe_handle {
     bool plan_valid = false;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
-    DevBuf d_plan, d_cells, d_tabs;
+    DevBuf d_plan, d_cells, d_tabs, d_btiles;
     // per-batch blocks
     DevBuf d_pyr, d_blur, d_cell_cnt, d_cell_keys, d_cell_off, d_keys, d_knode, d_sel, d_nsel, d_nkeys;
     // host-API staging
@@ -308,15 +308,29 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     P.node_cap = M;
     P.pyr_frame_bytes = off;
     if (tabs.empty()) tabs.resize(1);
+    std::vector<OrbTile> btiles;  // blur work list: 256-px x 32-row tiles, large levels first
+    for (int l = 0; l < nl; ++l)
+        for (int y0 = 0; y0 < P.lv[l].h; y0 += 32)
+            for (int x0 = 0; x0 < P.lv[l].w; x0 += 256) {
+                OrbTile t;
+                t.level = (uint16_t)l;
+                t.x0 = (uint16_t)x0;
+                t.y0 = (uint16_t)y0;
+                t.pad = 0;
+                btiles.push_back(t);
+            }
+    P.nbtiles = (int)btiles.size();
 
     ORBFE_HIP(h->d_plan.ensure(sizeof(OrbPlan)));
     ORBFE_HIP(h->d_cells.ensure(cells.size() * sizeof(OrbCell)));
     ORBFE_HIP(h->d_tabs.ensure(tabs.size() * sizeof(OrbTab)));
+    ORBFE_HIP(h->d_btiles.ensure(btiles.size() * sizeof(OrbTile)));
     // synchronous copies: plans change rarely (frame size change), never inside the timed region
     ORBFE_HIP(hipStreamSynchronize(h->stream));
     ORBFE_HIP(hipMemcpy(h->d_plan.p, &P, sizeof(OrbPlan), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_cells.p, cells.data(), cells.size() * sizeof(OrbCell), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_tabs.p, tabs.data(), tabs.size() * sizeof(OrbTab), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(h->d_btiles.p, btiles.data(), btiles.size() * sizeof(OrbTile), hipMemcpyHostToDevice));
     ORBFE_HIP(orbk_prepare_octree(M));
     h->plan = P;
     h->cells.swap(cells);
@@ -427,7 +441,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_pyr, &h->d_blur, &h->d_cell_cnt, &h->d_cell_keys,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_pyr, &h->d_blur, &h->d_cell_cnt, &h->d_cell_keys,
                       &h->d_cell_off, &h->d_keys, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
                       &h->d_okps, &h->d_odesc, &h->d_on};
     for (DevBuf *b : bufs) b->release();
@@ -529,6 +543,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_plan = (const OrbPlan *)h->d_plan.p;
     a.d_cells = (const OrbCell *)h->d_cells.p;
     a.d_tabs = (const OrbTab *)h->d_tabs.p;
+    a.d_btiles = (const OrbTile *)h->d_btiles.p;
     a.nframes = nframes;
     a.d_gray = d_gray;
     a.gray_fstride = (int64_t)frame_stride;

@@ -72,6 +72,11 @@ struct OrbTab {
     int16_t pad;
 };
 
+// work tile of a per-level image pass (blur): origin in level coordinates
+struct OrbTile {
+    uint16_t level, x0, y0, pad;
+};
+
 struct OrbPlan {
     int32_t nlevels;
     int32_t w, h;              // level-0 size this plan was built for
@@ -82,6 +87,7 @@ struct OrbPlan {
     int32_t node_cap;          // quadtree node capacity (power of two)
     int32_t ini_th, min_th;
     int32_t blur_rounding;
+    int32_t nbtiles;           // blur tiles per frame (256 px x 32 rows, one wave each)
     int64_t pyr_frame_bytes;   // bytes of one frame's pyramid slice (levels 1..n-1; level 0 kept too when owned)
     OrbLevel lv[ORBFE_MAX_LEVELS];
 };

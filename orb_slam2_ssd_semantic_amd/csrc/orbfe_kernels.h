@@ -8,6 +8,7 @@ struct OrbLaunch {
     const OrbPlan *d_plan;  // device copy
     const OrbCell *d_cells;
     const OrbTab *d_tabs;
+    const OrbTile *d_btiles;
     int32_t nframes;
     // input frames (level 0, read in place)
     const uint8_t *d_gray;

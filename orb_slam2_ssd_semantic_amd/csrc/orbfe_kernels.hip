@@ -580,46 +580,96 @@ __global__ __launch_bounds__(QT) void k_octree(const OrbPlan *__restrict__ plan,
 
 // ---------------------------------------------------------------------------------------------------
 // K4  7x7 Gaussian, sigma 2, 8-bit fixed-point kernel {18,34,49,55,49,34,18} (sum 257), REFLECT_101 at the
-// LEVEL edges.  64x16 output tile; the row pass lands in LDS as u16 (<= 255*257 = 65535).
+// LEVEL edges.  All levels of all frames in ONE launch.  One wave owns a 256-px wide, BL_RB-row tall
+// tile: every lane filters 4 adjacent pixels, walking down the rows with the last 7 row-sums in registers
+// (no LDS, no intermediate traffic): per row 3 aligned dword loads (12-byte window), 4 row sums, 4 outputs,
+// one dword store.  Reflected borders: rows by a wave-uniform index, columns by a per-byte path on edge lanes.
 // ---------------------------------------------------------------------------------------------------
-#define BW 64
-#define BH 16
-__global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs, int level,
+#define BL_RB 32
+
+__device__ __forceinline__ int blur_tap7(int a0, int a1, int a2, int a3, int a4, int a5, int a6)
+{
+    return 18 * (a0 + a6) + 34 * (a1 + a5) + 49 * (a2 + a4) + 55 * a3;
+}
+
+__global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
+                                               const OrbTile *__restrict__ tiles, int ntiles,
                                                uint8_t *__restrict__ blur, int64_t blur_fstride)
 {
-    __shared__ uint8_t s_in[(BH + 6) * (BW + 8)];
-    __shared__ uint16_t s_row[(BH + 6) * BW];
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    const OrbTile tl = tiles[t];
+    const int level = tl.level;
     const OrbLevel &L = plan->lv[level];
-    const int b = blockIdx.z, tid = threadIdx.x;
     int pitch;
     const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
     uint8_t *dst = blur + (int64_t)b * blur_fstride + L.off;
-    const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
-    const int IW = BW + 6;
-    for (int idx = tid; idx < (BH + 6) * IW; idx += 256) {
-        const int y = idx / IW, x = idx - y * IW;
-        const int sy = reflect101(min(y0 + y - 3, L.h + 2), L.h);
-        const int sx = reflect101(min(x0 + x - 3, L.w + 2), L.w);
-        s_in[y * (BW + 8) + x] = src[(int64_t)sy * pitch + sx];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < (BH + 6) * BW; idx += 256) {
-        const int y = idx >> 6, x = idx & 63;
-        const uint8_t *p = &s_in[y * (BW + 8) + x];
-        const int r = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-        s_row[y * BW + x] = (uint16_t)r;
-    }
-    __syncthreads();
-    const int vec_w = L.w & ~3;
-    for (int idx = tid; idx < BH * BW; idx += 256) {
-        const int y = idx >> 6, x = idx & 63;
-        if (x0 + x >= L.w || y0 + y >= L.h) continue;
-        const uint16_t *p = &s_row[y * BW + x];
-        const int acc = 18 * ((int)p[0] + p[6 * BW]) + 34 * ((int)p[BW] + p[5 * BW]) +
-                        49 * ((int)p[2 * BW] + p[4 * BW]) + 55 * (int)p[3 * BW];
-        int v = (acc + 32768) >> 16;
-        if (plan->blur_rounding == 1 && (acc & 0xFFFF) == 0x8000 && (x0 + x) < vec_w && (v & 1)) v -= 1;
-        dst[(int64_t)(y0 + y) * L.pitch + x0 + x] = (uint8_t)min(v, 255);
+    const int W = L.w, H = L.h, y0 = tl.y0;
+    const int x = tl.x0 + lane * 4;
+    const bool active = x < W;
+    const bool fast = x >= 4 && x + 8 <= W;
+    const int vec_w = W & ~3;
+    const int mode = plan->blur_rounding;
+    const int yend = min(y0 + BL_RB, H);
+    int S[7][4];
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[k][j] = 0;
+
+    for (int s0 = 0; s0 < BL_RB + 6; s0 += 7) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int s = s0 + k;
+            const int yin = y0 - 3 + s;
+            if (yin > yend + 2) break;  // wave-uniform
+            const int yy = reflect101(min(yin, H + 2), H);
+            const uint8_t *row = src + (int64_t)yy * pitch;
+            int px[12];  // pixels x-4 .. x+7
+            if (fast) {
+                const uint32_t w0 = *(const uint32_t *)(row + x - 4);
+                const uint32_t w1 = *(const uint32_t *)(row + x);
+                const uint32_t w2 = *(const uint32_t *)(row + x + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    px[i] = (w0 >> (8 * i)) & 0xFF;
+                    px[4 + i] = (w1 >> (8 * i)) & 0xFF;
+                    px[8 + i] = (w2 >> (8 * i)) & 0xFF;
+                }
+            } else if (active) {
+#pragma unroll
+                for (int i = 1; i < 11; ++i) px[i] = row[reflect101(min(x - 4 + i, W + 2), W)];
+                px[0] = px[11] = 0;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) px[i] = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                S[k][j] = blur_tap7(px[1 + j], px[2 + j], px[3 + j], px[4 + j], px[5 + j], px[6 + j], px[7 + j]);
+            if (s >= 6) {
+                const int y = yin - 3;
+                if (y < yend && active) {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // newest row sum is slot k (offset +3), oldest is slot (k+1)%7 (offset -3)
+                        const int acc = blur_tap7(S[(k + 1) % 7][j], S[(k + 2) % 7][j], S[(k + 3) % 7][j], S[(k + 4) % 7][j],
+                                                  S[(k + 5) % 7][j], S[(k + 6) % 7][j], S[k][j]);
+                        int v = (acc + 32768) >> 16;
+                        if (mode == 1 && (acc & 0xFFFF) == 0x8000 && (x + j) < vec_w && (v & 1)) v -= 1;
+                        packed |= (uint32_t)min(v, 255) << (8 * j);
+                    }
+                    uint8_t *o = dst + (int64_t)y * L.pitch + x;
+                    if (x + 4 <= W) {
+                        *(uint32_t *)o = packed;
+                    } else {
+                        for (int j = 0; j < 4 && x + j < W; ++j) o[j] = (uint8_t)(packed >> (8 * j));
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -827,11 +877,9 @@ hipError_t orbk_prepare_octree(int node_cap)
 hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st)
 {
     const FrameSrc fs = make_src(a);
-    for (int l = 0; l < a.h_plan->nlevels; ++l) {
-        const OrbLevel &L = a.h_plan->lv[l];
-        dim3 grid((L.w + BW - 1) / BW, (L.h + BH - 1) / BH, a.nframes);
-        hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, a.d_plan, fs, l, a.d_blur, a.pyr_fstride);
-    }
+    dim3 grid((a.h_plan->nbtiles + 3) / 4, a.nframes);
+    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, a.d_plan, fs, a.d_btiles, a.h_plan->nbtiles, a.d_blur,
+                       a.pyr_fstride);
     return hipGetLastError();
 }
 
