@@ -9,6 +9,7 @@
 //   cv::resize coefficient tables OpenCV 3.2 imgwarp.cpp
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -135,9 +136,9 @@ struct orbfe_handle {
     bool plan_valid = false;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
-    DevBuf d_plan, d_cells, d_tabs, d_btiles;
+    DevBuf d_plan, d_cells, d_tabs, d_btiles, d_supers, d_ftiles;
     // per-batch blocks
-    DevBuf d_pyr, d_blur, d_cell_cnt, d_cell_keys, d_cell_off, d_keys, d_knode, d_sel, d_nsel, d_nkeys;
+    DevBuf d_pyr, d_blur, d_fmap, d_cell_cnt, d_cell_keys, d_cell_off, d_keys, d_knode, d_sel, d_nsel, d_nkeys;
     // host-API staging
     DevBuf d_stage, d_okps, d_odesc, d_on;
     PinBuf h_stage, h_okps, h_odesc, h_on;
@@ -204,8 +205,11 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     P.ini_th = std::min(255, std::max(0, h->prm.ini_th_fast));
     P.min_th = std::min(255, std::max(0, h->prm.min_th_fast));
     P.blur_rounding = h->prm.blur_rounding;
+    P.dbg = getenv("ORBFE_DEBUG") ? atoi(getenv("ORBFE_DEBUG")) : 0;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
+    std::vector<OrbSuper> supers;
+    std::vector<OrbTile> ftiles;
     int64_t off = 0;
     int key_off = 0, sel_off = 0, cell_cap = 1, max_sel = 0;
     for (int l = 0; l < nl; ++l) {
@@ -263,6 +267,51 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             }
         }
         L.ncells = (int)cells.size() - L.cell0;
+        {
+            // non-skipped cells form a full (rows x cols) sub-grid (the skip rules depend on i or j alone);
+            // group it into blocks of cells whose union tile fits the LDS tile of k_fast_cells (141 x 140)
+            int ncc = 0;
+            for (int k = L.cell0; k < (int)cells.size() && cells[k].y0 == cells[L.cell0].y0; ++k) ++ncc;
+            const int nrr = ncc ? L.ncells / ncc : 0;
+            const int cbx = std::max(1, std::min(4, (141 - 6) / L.wcell));
+            const int cby = std::max(1, std::min(4, (140 - 6) / L.hcell));
+            for (int i0 = 0; i0 < nrr; i0 += cby)
+                for (int j0 = 0; j0 < ncc; j0 += cbx) {
+                    const int ny = std::min(cby, nrr - i0), nx = std::min(cbx, ncc - j0);
+                    const OrbCell &c0 = cells[L.cell0 + i0 * ncc + j0];
+                    const OrbCell &c1 = cells[L.cell0 + (i0 + ny - 1) * ncc + (j0 + nx - 1)];
+                    OrbSuper sp;
+                    sp.level = (uint16_t)l;
+                    sp.x0 = c0.x0;
+                    sp.y0 = c0.y0;
+                    sp.tw = (uint16_t)(c1.x0 + c1.tw - c0.x0);
+                    sp.th = (uint16_t)(c1.y0 + c1.th - c0.y0);
+                    sp.ncx = (uint16_t)nx;
+                    sp.ncy = (uint16_t)ny;
+                    sp.ncells = (uint16_t)(nx * ny);
+                    sp.cell0 = L.cell0 + i0 * ncc + j0;
+                    sp.cstride = ncc;
+                    if ((sp.x0 & 3) + sp.tw > 144 || sp.th > 140) {
+                        orbfe_set_error("FAST super-cell %dx%d exceeds the LDS tile", sp.tw, sp.th);
+                        return ORBFE_ERR_SIZE;
+                    }
+                    supers.push_back(sp);
+                }
+        }
+        {
+            const OrbCell &clast = cells.back();
+            L.ix1 = L.ncells ? clast.x0 + clast.tw - 3 : ORBFE_EDGE;
+            L.iy1 = L.ncells ? clast.y0 + clast.th - 3 : ORBFE_EDGE;
+            for (int y0 = ORBFE_EDGE; y0 < L.iy1; y0 += 64)
+                for (int x0 = 16; x0 < L.ix1; x0 += 248) {
+                    OrbTile t;
+                    t.level = (uint16_t)l;
+                    t.x0 = (uint16_t)x0;
+                    t.y0 = (uint16_t)y0;
+                    t.pad = 0;
+                    ftiles.push_back(t);
+                }
+        }
         L.nfeat = h->feat[l];
         // quadtree roots (src/ORBextractor.cc:545-559)
         L.nini = (int)roundf((float)(maxbx - minb) / (float)(maxby - minb));
@@ -320,17 +369,27 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
                 btiles.push_back(t);
             }
     P.nbtiles = (int)btiles.size();
+    P.nsupers = (int)supers.size();
+    P.nftiles = (int)ftiles.size();
+    if (P.ini_th < P.min_th) {
+        orbfe_set_error("iniThFAST (%d) must be >= minThFAST (%d)", P.ini_th, P.min_th);
+        return ORBFE_ERR_ARG;
+    }
 
     ORBFE_HIP(h->d_plan.ensure(sizeof(OrbPlan)));
     ORBFE_HIP(h->d_cells.ensure(cells.size() * sizeof(OrbCell)));
     ORBFE_HIP(h->d_tabs.ensure(tabs.size() * sizeof(OrbTab)));
     ORBFE_HIP(h->d_btiles.ensure(btiles.size() * sizeof(OrbTile)));
+    ORBFE_HIP(h->d_supers.ensure(supers.size() * sizeof(OrbSuper)));
+    ORBFE_HIP(h->d_ftiles.ensure(ftiles.size() * sizeof(OrbTile)));
     // synchronous copies: plans change rarely (frame size change), never inside the timed region
     ORBFE_HIP(hipStreamSynchronize(h->stream));
     ORBFE_HIP(hipMemcpy(h->d_plan.p, &P, sizeof(OrbPlan), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_cells.p, cells.data(), cells.size() * sizeof(OrbCell), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_tabs.p, tabs.data(), tabs.size() * sizeof(OrbTab), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_btiles.p, btiles.data(), btiles.size() * sizeof(OrbTile), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(h->d_supers.p, supers.data(), supers.size() * sizeof(OrbSuper), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(h->d_ftiles.p, ftiles.data(), ftiles.size() * sizeof(OrbTile), hipMemcpyHostToDevice));
     ORBFE_HIP(orbk_prepare_octree(M));
     h->plan = P;
     h->cells.swap(cells);
@@ -345,6 +404,7 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
     const size_t B = (size_t)nframes;
     ORBFE_HIP(h->d_pyr.ensure(B * (size_t)P.pyr_frame_bytes));
     ORBFE_HIP(h->d_blur.ensure(B * (size_t)P.pyr_frame_bytes));
+    ORBFE_HIP(h->d_fmap.ensure(B * (size_t)P.pyr_frame_bytes));
     ORBFE_HIP(h->d_cell_cnt.ensure(B * P.ncells * sizeof(int32_t)));
     ORBFE_HIP(h->d_cell_keys.ensure(B * P.ncells * (size_t)P.cell_cap * sizeof(uint32_t)));
     ORBFE_HIP(h->d_cell_off.ensure(B * P.ncells * sizeof(int32_t)));
@@ -441,7 +501,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_pyr, &h->d_blur, &h->d_cell_cnt, &h->d_cell_keys,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_supers, &h->d_ftiles, &h->d_fmap, &h->d_pyr, &h->d_blur, &h->d_cell_cnt, &h->d_cell_keys,
                       &h->d_cell_off, &h->d_keys, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
                       &h->d_okps, &h->d_odesc, &h->d_on};
     for (DevBuf *b : bufs) b->release();
@@ -544,12 +604,15 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_cells = (const OrbCell *)h->d_cells.p;
     a.d_tabs = (const OrbTab *)h->d_tabs.p;
     a.d_btiles = (const OrbTile *)h->d_btiles.p;
+    a.d_supers = (const OrbSuper *)h->d_supers.p;
+    a.d_ftiles = (const OrbTile *)h->d_ftiles.p;
     a.nframes = nframes;
     a.d_gray = d_gray;
     a.gray_fstride = (int64_t)frame_stride;
     a.gray_pitch = stride;
     a.d_pyr = (uint8_t *)h->d_pyr.p;
     a.d_blur = (uint8_t *)h->d_blur.p;
+    a.d_fmap = (uint8_t *)h->d_fmap.p;
     a.pyr_fstride = h->plan.pyr_frame_bytes;
     a.d_cell_cnt = (int32_t *)h->d_cell_cnt.p;
     a.d_cell_keys = (uint32_t *)h->d_cell_keys.p;

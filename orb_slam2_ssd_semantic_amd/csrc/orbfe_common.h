@@ -53,6 +53,7 @@ struct OrbLevel {
     float scale;           // mvScaleFactor[l]
     float patch_size;      // (float)(int)(PATCH_SIZE * scale)  (:846)
     int32_t root_x[5];     // root box x boundaries, nini+1 entries (nini <= 4)
+    int32_t ix1, iy1;      // end of the union of the cells' detectable interiors ([19,ix1) x [19,iy1))
 };
 
 // one FAST cell = one cv::FAST call of the reference (:798-838)
@@ -72,6 +73,17 @@ struct OrbTab {
     int16_t pad;
 };
 
+// a block of up to 4x4 FAST cells of one level handled by one workgroup (k_fast_cells)
+struct OrbSuper {
+    uint16_t level;
+    uint16_t x0, y0;    // tile origin (level coordinates) = origin of the first cell's cv::FAST tile
+    uint16_t tw, th;    // tile size incl. the 3-px apron on every side (<= 141 x 140)
+    uint16_t ncx, ncy;  // cells in the block
+    uint16_t ncells;    // ncx * ncy
+    int32_t cell0;      // frame cell-table index of the block's first cell
+    int32_t cstride;    // cell-table stride between cell rows of this level
+};
+
 // work tile of a per-level image pass (blur): origin in level coordinates
 struct OrbTile {
     uint16_t level, x0, y0, pad;
@@ -87,6 +99,9 @@ struct OrbPlan {
     int32_t node_cap;          // quadtree node capacity (power of two)
     int32_t ini_th, min_th;
     int32_t blur_rounding;
+    int32_t dbg;               // developer knob (ORBFE_DEBUG env): early-outs for phase timing, 0 in production
+    int32_t nsupers;           // FAST super-cells per frame (v2 kernel, unused by v3)
+    int32_t nftiles;           // FAST map tiles per frame (248 px x 64 rows, one wave each)
     int32_t nbtiles;           // blur tiles per frame (256 px x 32 rows, one wave each)
     int64_t pyr_frame_bytes;   // bytes of one frame's pyramid slice (levels 1..n-1; level 0 kept too when owned)
     OrbLevel lv[ORBFE_MAX_LEVELS];

@@ -9,6 +9,8 @@ struct OrbLaunch {
     const OrbCell *d_cells;
     const OrbTab *d_tabs;
     const OrbTile *d_btiles;
+    const OrbSuper *d_supers;
+    const OrbTile *d_ftiles;
     int32_t nframes;
     // input frames (level 0, read in place)
     const uint8_t *d_gray;
@@ -17,6 +19,7 @@ struct OrbLaunch {
     // handle-owned blocks, one slice per frame
     uint8_t *d_pyr;
     uint8_t *d_blur;
+    uint8_t *d_fmap;
     int64_t pyr_fstride;
     int32_t *d_cell_cnt;
     uint32_t *d_cell_keys;

@@ -158,80 +158,332 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *p /* LDS, pitch 
     return max(a_dark, -b_min);
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const OrbPlan *__restrict__ plan, FrameSrc fs,
-                                                    const OrbCell *__restrict__ cells,
-                                                    int32_t *__restrict__ cell_cnt,
-                                                    uint32_t *__restrict__ cell_keys)
-{
-    __shared__ uint8_t s_tile[TP * TP];
-    __shared__ uint8_t s_str[TP * TP];  // arc strength A clamped to [0,255]; 0 outside the interior
-    __shared__ int s_wave[17];
+// v3: dense streaming formulation.
+//
+// k_fast_map   one wave per (level, 248-px strip, 64-row block).  Every lane owns 4 adjacent pixels and walks down
+//              the rows with the last 7 image rows (3 dwords each) in registers -- no LDS, no byte loads.  With
+//              raw pixel values c[0..15] on the circle,  min over an arc of (v - c) = v - max(c)  and
+//              min over an arc of (c - v) = min(c) - v, so
+//                  A = max( v - min_k max(c[k..k+8]),  max_k min(c[k..k+8]) - v )
+//              needs no per-tap subtraction: two levels of min3/max3 give all 16 nine-arcs (2 ops per arc and
+//              polarity).  A is clamped to E = (A > max(minTh,1)) ? A : 0; the 3x3 strict NMS runs in registers on
+//              three rows of E (neighbour lanes via shuffles) with the reference's per-cv::FAST-call semantics:
+//              neighbours outside the own cell's detectable interior count as 0 (cell seams are per-lane column
+//              masks and wave-uniform row flags).  Because iniTh >= minTh, a corner with A > iniTh survives NMS at
+//              iniTh iff it survives at minTh, so ONE survivor map  M = survivor ? A : 0  encodes both of the
+//              reference's lists: {M > iniTh} and, for cells where that is empty, {M > 0}  (:818-825).
+// k_fast_emit  one wave per cell: counts {M > iniTh}, picks the threshold (fallback rule) and writes the cell's
+//              keypoints in raster order (ballot + prefix popcount) into its key slots.
+#define FM_RB 64      // output rows per tile
+#define FM_STRIP 248  // output columns per tile (lanes 1..62; lanes 0 and 63 are the NMS halo)
 
-    const int cell = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+// ---- packed 16-bit helpers: two pixels per VALU instruction --------------------------------------------
+// A pixel pair is held as two u16 halves (values 0..255).  Read as f16 bit patterns those are positive
+// denormals, whose order equals the integer order, so gfx950's 3-input packed min/max
+// (v_pk_minimum3_f16 / v_pk_maximum3_f16) give exact integer results at two pixels per instruction.
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_subsat_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// pixels (IDX, IDX+1) of a 12-byte row window as a u16 pair
+template <int IDX>
+__device__ __forceinline__ uint32_t rowpair(const uint32_t (&w)[3])
+{
+    static_assert(IDX >= 0 && IDX < 11, "window pair");
+    if ((IDX & 3) < 3)
+        return __builtin_amdgcn_perm(0u, w[IDX >> 2], 0x0c000c00u | ((uint32_t)((IDX & 3) + 1) << 16) | (uint32_t)(IDX & 3));
+    return __builtin_amdgcn_perm(w[(IDX >> 2) + 1 > 2 ? 2 : (IDX >> 2) + 1], w[IDX >> 2], 0x0c040c03u);
+}
+
+// arc strengths of the pixel pair (J, J+1) of the lane, as two i16 halves;
+// R[dy+3] = 12-byte window (pixels x-4 .. x+7) of image row y+dy
+template <int J>
+__device__ __forceinline__ uint32_t fast_strength_pair(const uint32_t (&rm3)[3], const uint32_t (&rm2)[3],
+                                                       const uint32_t (&rm1)[3], const uint32_t (&r0)[3],
+                                                       const uint32_t (&rp1)[3], const uint32_t (&rp2)[3],
+                                                       const uint32_t (&rp3)[3])
+{
+    uint32_t c[16];
+    c[0] = rowpair<4 + J>(rp3);
+    c[1] = rowpair<5 + J>(rp3);
+    c[2] = rowpair<6 + J>(rp2);
+    c[3] = rowpair<7 + J>(rp1);
+    c[4] = rowpair<7 + J>(r0);
+    c[5] = rowpair<7 + J>(rm1);
+    c[6] = rowpair<6 + J>(rm2);
+    c[7] = rowpair<5 + J>(rm3);
+    c[8] = rowpair<4 + J>(rm3);
+    c[9] = rowpair<3 + J>(rm3);
+    c[10] = rowpair<2 + J>(rm2);
+    c[11] = rowpair<1 + J>(rm1);
+    c[12] = rowpair<1 + J>(r0);
+    c[13] = rowpair<1 + J>(rp1);
+    c[14] = rowpair<2 + J>(rp2);
+    c[15] = rowpair<3 + J>(rp3);
+    const uint32_t v = rowpair<4 + J>(r0);
+    uint32_t lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        lo3[k] = pk_min3(c[k], c[(k + 1) & 15], c[(k + 2) & 15]);
+        hi3[k] = pk_max3(c[k], c[(k + 1) & 15], c[(k + 2) & 15]);
+    }
+    uint32_t lo9[16], hi9[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        lo9[k] = pk_min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);  // min of the nine-arc starting at k
+        hi9[k] = pk_max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);  // max of the nine-arc starting at k
+    }
+    uint32_t maxmin = pk_max3(lo9[0], lo9[1], lo9[2]);
+    uint32_t minmax = pk_min3(hi9[0], hi9[1], hi9[2]);
+#pragma unroll
+    for (int k = 3; k < 15; k += 2) {
+        maxmin = pk_max3(maxmin, lo9[k], lo9[k + 1]);
+        minmax = pk_min3(minmax, hi9[k], hi9[k + 1]);
+    }
+    maxmin = pk_max3(maxmin, lo9[15], lo9[15]);
+    minmax = pk_min3(minmax, hi9[15], hi9[15]);
+    // A = max(v - min_arcs(max), max_arcs(min) - v)
+    return pk_max_i16(pk_sub_i16(v, minmax), pk_sub_i16(maxmin, v));
+}
+
+__global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ plan, FrameSrc fs,
+                                                  const OrbTile *__restrict__ tiles, int ntiles,
+                                                  uint8_t *__restrict__ fmap, int64_t fmap_fstride)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    const OrbTile tl = tiles[t];
+    const int level = tl.level;
+    const OrbLevel &L = plan->lv[level];
+    int pitch;
+    const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
+    uint8_t *dst = fmap + (int64_t)b * fmap_fstride + L.off;
+    const int W = L.w;
+    const int ix0 = ORBFE_EDGE, iy0 = ORBFE_EDGE, ix1 = L.ix1, iy1 = L.iy1;
+    const int wcell = L.wcell, hcell = L.hcell;
+    const int x = tl.x0 - 4 + lane * 4;  // first pixel of this lane
+    const int ys = tl.y0;
+    const int yend = min(ys + FM_RB, iy1);  // output rows [ys, yend)
+    const bool loadable = x < W;
+    const int tz = max(plan->min_th, 1);
+
+    // per-lane column masks: bit j = pixel j inside the interior / has a valid left / right neighbour in its cell
+    int inside = 0, lvalid = 0, rvalid = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = x + j;
+        if (xx >= ix0 && xx < ix1) {
+            const int m = (xx - ix0) % wcell;
+            inside |= 1 << j;
+            if (m != 0) lvalid |= 1 << j;
+            if (m != wcell - 1 && xx + 1 < ix1) rvalid |= 1 << j;
+        }
+    }
+    const bool out_lane = lane >= 1 && lane <= 62 && inside != 0;
+    const uint32_t tzz = (uint32_t)tz * 0x00010001u;
+    const uint32_t in01 = ((inside & 1) ? 0xFFFFu : 0u) | ((inside & 2) ? 0xFFFF0000u : 0u);
+    const uint32_t in23 = ((inside & 4) ? 0xFFFFu : 0u) | ((inside & 8) ? 0xFFFF0000u : 0u);
+
+    uint32_t R[7][3];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) R[k][0] = R[k][1] = R[k][2] = 0u;
+    // E windows of the last three strength rows: lo = [E(x-1), E0, E1, E2], hi = [E3, E(x+4)]
+    uint32_t Ulo = 0, Uhi = 0, Mlo = 0, Mhi = 0, Dlo = 0, Dhi = 0;
+    int rmod = (ys - iy0) % hcell;  // (rn - iy0) % hcell of the next NMS row
+
+    for (int s0 = 0; s0 < FM_RB + 8; s0 += 7) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int s = s0 + k;
+            const int r = ys - 4 + s;  // image row loaded in this step
+            if (r > yend + 3) break;   // wave-uniform
+            if (loadable) {
+                const uint8_t *row = src + (int64_t)r * pitch + x;
+                R[k][0] = *(const uint32_t *)(row - 4);
+                R[k][1] = *(const uint32_t *)(row);
+                R[k][2] = *(const uint32_t *)(row + 4);
+            }
+            if (s < 6) continue;
+            // ---- strength row rc = r - 3 (newest ring slot k is row rc+3, slot (k+1)%7 is row rc-3) ----
+            const int rc = r - 3;
+            uint32_t e = 0;
+            if (rc >= iy0 && rc < iy1) {
+                const uint32_t(&rm3)[3] = R[(k + 1) % 7];
+                const uint32_t(&rm2)[3] = R[(k + 2) % 7];
+                const uint32_t(&rm1)[3] = R[(k + 3) % 7];
+                const uint32_t(&r0)[3] = R[(k + 4) % 7];
+                const uint32_t(&rp1)[3] = R[(k + 5) % 7];
+                const uint32_t(&rp2)[3] = R[(k + 6) % 7];
+                const uint32_t(&rp3)[3] = R[k];
+                // A > 0 half-words clamped, then S = max(A - tz, 0): zero for non-corners, order preserving for corners
+                const uint32_t a01 = pk_max_i16(fast_strength_pair<0>(rm3, rm2, rm1, r0, rp1, rp2, rp3), 0u);
+                const uint32_t a23 = pk_max_i16(fast_strength_pair<2>(rm3, rm2, rm1, r0, rp1, rp2, rp3), 0u);
+                const uint32_t s01 = pk_subsat_u16(a01, tzz) & in01;
+                const uint32_t s23 = pk_subsat_u16(a23, tzz) & in23;
+                e = __builtin_amdgcn_perm(s23, s01, 0x06040200u);  // bytes [S0, S1, S2, S3]
+            }
+            const uint32_t eL = (uint32_t)__shfl_up((int)e, 1, 64);
+            const uint32_t eR = (uint32_t)__shfl_down((int)e, 1, 64);
+            Ulo = Mlo; Uhi = Mhi;
+            Mlo = Dlo; Mhi = Dhi;
+            Dlo = (e << 8) | (eL >> 24);
+            Dhi = (e >> 24) | ((eR & 0xFFu) << 8);
+            if (s < 8) continue;
+            // ---- NMS row rn = rc - 1 ----
+            const int rn = rc - 1;
+            const bool up_ok = rmod != 0;
+            const bool dn_ok = (rmod != hcell - 1) && (rn + 1 < iy1);
+            if (++rmod == hcell) rmod = 0;
+            if (rn >= yend) continue;
+            const uint32_t ulo = up_ok ? Ulo : 0u, uhi = up_ok ? Uhi : 0u;
+            const uint32_t dlo = dn_ok ? Dlo : 0u, dhi = dn_ok ? Dhi : 0u;
+            int U[6], Mi[6], D[6];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                U[p] = (ulo >> (8 * p)) & 0xFF;
+                Mi[p] = (Mlo >> (8 * p)) & 0xFF;
+                D[p] = (dlo >> (8 * p)) & 0xFF;
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                U[4 + p] = (uhi >> (8 * p)) & 0xFF;
+                Mi[4 + p] = (Mhi >> (8 * p)) & 0xFF;
+                D[4 + p] = (dhi >> (8 * p)) & 0xFF;
+            }
+            int col[6];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) col[p] = max3i(U[p], Mi[p], D[p]);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lc = (lvalid >> j) & 1 ? col[j] : 0;
+                const int rc2 = (rvalid >> j) & 1 ? col[j + 2] : 0;
+                const int nb = max3i(lc, rc2, max(U[j + 1], D[j + 1]));
+                const int m = Mi[j + 1];
+                packed |= (uint32_t)(m > nb ? m + tz : 0) << (8 * j);
+            }
+            if (out_lane) *(uint32_t *)(dst + (int64_t)rn * L.pitch + x) = packed;
+        }
+    }
+}
+
+// One wave per cell.  The cell interior (iw x ih survivor bytes) is scanned with aligned dword loads: 16 lanes per
+// row (up to 64 px incl. misalignment), 4 rows per iteration, so lane order == raster order.  Non-zero bytes are
+// rare (strict 3x3 NMS): per lane 0..2 of them; their ranks come from two ballots of the count bits.
+__device__ __forceinline__ int lanes_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+
+__global__ __launch_bounds__(256) void k_fast_emit(const OrbPlan *__restrict__ plan, const OrbCell *__restrict__ cells,
+                                                   const uint8_t *__restrict__ fmap, int64_t fmap_fstride,
+                                                   int32_t *__restrict__ cell_cnt, uint32_t *__restrict__ cell_keys)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= plan->ncells) return;
     const OrbCell c = cells[cell];
     const OrbLevel &L = plan->lv[c.level];
-    int pitch;
-    const uint8_t *img = level_ptr(fs, L, c.level, b, &pitch);
-    const int tw = c.tw, th = c.th;
-
-    for (int idx = tid; idx < tw * th; idx += 256) {
-        const int y = idx / tw, x = idx - y * tw;
-        s_tile[y * TP + x] = img[(int64_t)(c.y0 + y) * pitch + c.x0 + x];
-        s_str[y * TP + x] = 0;
-    }
-    __syncthreads();
-
-    const int iw = tw - 6, ih = th - 6;  // detectable interior [3,tw-3) x [3,th-3)
-    const int npix = (iw > 0 && ih > 0) ? iw * ih : 0;
-    for (int idx = tid; idx < npix; idx += 256) {
-        const int y = idx / iw, x = idx - y * iw;
-        const int a = fast_arc_strength(&s_tile[(y + 3) * TP + (x + 3)]);
-        s_str[(y + 3) * TP + (x + 3)] = (uint8_t)min(max(a, 0), 255);
-    }
-    __syncthreads();
-
-    // contiguous raster chunk per thread -> ordered emission with one block scan
-    const int per = (npix + 255) >> 8;  // <= 15 for 66x66 tiles
-    const int p0 = tid * per, p1 = min(p0 + per, npix);
-    uint32_t mask = 0;
-    int total = 0, base = 0, t = plan->ini_th;
-    for (int pass = 0; pass < 2; ++pass) {
-        mask = 0;
-        for (int p = p0; p < p1; ++p) {
-            const int y = p / iw + 3, x = p - (y - 3) * iw + 3;
-            const uint8_t *s = &s_str[y * TP + x];
-            const int a = s[0];
-            if (a <= t) continue;
-            const int sc = a - 1;
-            bool ok = true;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    if (dx == 0 && dy == 0) continue;
-                    const int q = s[dy * TP + dx];
-                    const int qs = q > t ? q - 1 : 0;
-                    ok = ok && (sc > qs);
-                }
-            if (ok) mask |= 1u << (p - p0);
-        }
-        base = block_excl_scan(__popc(mask), s_wave, &total);
-        if (total > 0 || plan->min_th == t) break;
-        t = plan->min_th;  // src/ORBextractor.cc:821-825
-    }
-
+    const int iw = (int)c.tw - 6, ih = (int)c.th - 6;
     const int64_t slot0 = ((int64_t)b * plan->ncells + cell) * plan->cell_cap;
-    if (tid == 0) cell_cnt[(int64_t)b * plan->ncells + cell] = total;
-    int k = base;
-    while (mask) {
-        const int bit = __ffs(mask) - 1;
-        mask &= mask - 1;
-        const int p = p0 + bit;
-        const int y = p / iw + 3, x = p - (y - 3) * iw + 3;
-        const int sc = (int)s_str[y * TP + x] - 1;
-        cell_keys[slot0 + k] = orb_pack_key(x + c.ox, y + c.oy, sc);
-        ++k;
+    if (iw <= 0 || ih <= 0) {
+        if (lane == 0) cell_cnt[(int64_t)b * plan->ncells + cell] = 0;
+        return;
     }
+    const int cx0 = c.x0 + 3, cy0 = c.y0 + 3;  // interior origin (level coordinates)
+    const int xa = cx0 & ~3;                    // aligned start
+    const int sub = lane & 15, rsub = lane >> 4;
+    const int gx = xa + 4 * sub;                // level x of this lane's dword
+    // byte k of the dword is inside the cell iff cx0 <= gx + k < cx0 + iw
+    uint32_t bmask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (gx + k >= cx0 && gx + k < cx0 + iw) bmask |= 0xFFu << (8 * k);
+    const uint8_t *base = fmap + (int64_t)b * fmap_fstride + L.off + gx;
+    const int ini = plan->ini_th;
+
+    // all rows of the cell in flight at once (ih <= 60 -> at most 15 iterations of 4 rows).  Loads are
+    // unconditional (clamped addresses, results masked) so that they overlap instead of being waited on one by one.
+    uint32_t wv[15];
+    {
+        const int ndw = (cx0 + iw - xa + 3) >> 2;
+        const uint8_t *lbase = base - 4 * (sub - min(sub, ndw - 1));
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            const int y = min(4 * i + rsub, ih - 1);
+            wv[i] = *(const uint32_t *)(lbase + (int64_t)(cy0 + y) * L.pitch);
+        }
+#pragma unroll
+        for (int i = 0; i < 15; ++i)
+            if (4 * i + rsub >= ih) wv[i] = 0u;
+    }
+    // pass 1: does the iniTh list have any entry?  (src/ORBextractor.cc:821)
+    bool any_ini = false;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+        const uint32_t w = wv[i] & bmask;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) any_ini = any_ini || (int)((w >> (8 * k)) & 0xFF) > ini;
+    }
+    const int thr = __any(any_ini) ? ini : 0;
+
+    // pass 2: ordered emission
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+        if (4 * i >= ih) break;  // wave-uniform
+        const int y = 4 * i + rsub;
+        const uint32_t w = wv[i] & bmask;
+        int m[4], cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = (int)((w >> (8 * k)) & 0xFF);
+            if (m[k] <= thr) m[k] = 0;
+            cnt += m[k] != 0;
+        }
+        // cnt <= 2 (no two horizontally adjacent survivors); exclusive prefix over lanes from the two count bits
+        const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2);
+        if (b0 | b1) {
+            int k = total + lanes_below(b0) + 2 * lanes_below(b1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (m[j]) {
+                    // detection-window coordinates (level - 16) == tile-relative + j*wCell of the reference (:831-832)
+                    cell_keys[slot0 + k] = orb_pack_key(gx + j - ORBFE_MINB, cy0 + y - ORBFE_MINB, m[j] - 1);
+                    ++k;
+                }
+            total += __popcll(b0) + 2 * __popcll(b1);
+        }
+    }
+    if (lane == 0) cell_cnt[(int64_t)b * plan->ncells + cell] = total;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -854,8 +1106,12 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
 hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
 {
     const FrameSrc fs = make_src(a);
-    dim3 grid(a.h_plan->ncells, a.nframes);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, st, a.d_plan, fs, a.d_cells, a.d_cell_cnt, a.d_cell_keys);
+    dim3 grid((a.h_plan->nftiles + 3) / 4, a.nframes);
+    hipLaunchKernelGGL(k_fast_map, grid, dim3(256), 0, st, a.d_plan, fs, a.d_ftiles, a.h_plan->nftiles, a.d_fmap,
+                       a.pyr_fstride);
+    dim3 grid2((a.h_plan->ncells + 3) / 4, a.nframes);
+    hipLaunchKernelGGL(k_fast_emit, grid2, dim3(256), 0, st, a.d_plan, a.d_cells, a.d_fmap, a.pyr_fstride, a.d_cell_cnt,
+                       a.d_cell_keys);
     return hipGetLastError();
 }
 
