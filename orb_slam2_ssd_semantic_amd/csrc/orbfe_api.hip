@@ -412,7 +412,7 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
     ORBFE_HIP(h->d_knode.ensure(B * (size_t)P.keys_per_frame * sizeof(uint16_t)));
     ORBFE_HIP(h->d_sel.ensure(B * (size_t)P.sel_per_frame * sizeof(uint32_t)));
     ORBFE_HIP(h->d_nsel.ensure(B * P.nlevels * sizeof(int32_t)));
-    ORBFE_HIP(h->d_nkeys.ensure(B * P.nlevels * sizeof(int32_t)));
+    ORBFE_HIP(h->d_nkeys.ensure(B * P.nlevels * ORBFE_NK_STRIDE * sizeof(int32_t)));
     return ORBFE_OK;
 }
 
@@ -501,8 +501,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_supers, &h->d_ftiles, &h->d_fmap, &h->d_pyr, &h->d_blur, &h->d_cell_cnt, &h->d_cell_keys,
-                      &h->d_cell_off, &h->d_keys, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_supers, &h->d_ftiles, &h->d_fmap, &h->d_pyr, &h->d_blur, &h->d_cell_cnt, &h->d_cell_keys, &h->d_cell_off, &h->d_keys, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
                       &h->d_okps, &h->d_odesc, &h->d_on};
     for (DevBuf *b : bufs) b->release();
     PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
@@ -823,19 +822,19 @@ extern "C" orbfe_status orbfe_tap_candidates(orbfe_handle *h, int32_t frame, int
     const OrbLevel &L = P.lv[level];
     ORBFE_HIP(hipStreamSynchronize(h->stream));
     int32_t nk = 0;
-    ORBFE_HIP(hipMemcpy(&nk, (int32_t *)h->d_nkeys.p + (size_t)frame * P.nlevels + level, sizeof(int32_t),
+    ORBFE_HIP(hipMemcpy(&nk, (int32_t *)h->d_nkeys.p + ((size_t)frame * P.nlevels + level) * ORBFE_NK_STRIDE, sizeof(int32_t),
                         hipMemcpyDeviceToHost));
     *n = nk;
     if (nk > cap) return ORBFE_ERR_CAP;
     if (nk == 0) return ORBFE_OK;
     if (!xyr) return ORBFE_ERR_ARG;
-    std::vector<uint32_t> keys((size_t)nk);
-    ORBFE_HIP(hipMemcpy(keys.data(), (uint32_t *)h->d_keys.p + (size_t)frame * P.keys_per_frame + L.key_off,
+    std::vector<uint32_t> kv((size_t)nk);
+    ORBFE_HIP(hipMemcpy(kv.data(), (uint32_t *)h->d_keys.p + (size_t)frame * P.keys_per_frame + L.key_off,
                         sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost));
     for (int i = 0; i < nk; ++i) {
-        xyr[3 * i] = (float)orb_key_x(keys[i]);
-        xyr[3 * i + 1] = (float)orb_key_y(keys[i]);
-        xyr[3 * i + 2] = (float)orb_key_r(keys[i]);
+        xyr[3 * i] = (float)orb_key_x(kv[i]);
+        xyr[3 * i + 1] = (float)orb_key_y(kv[i]);
+        xyr[3 * i + 2] = (float)orb_key_r(kv[i]);
     }
     return ORBFE_OK;
 }

@@ -17,6 +17,7 @@
 #define ORBFE_HALF_PATCH 15  // HALF_PATCH_SIZE  (:53)
 #define ORBFE_PATCH 31       // PATCH_SIZE       (:52)
 #define ORBFE_MINB 16        // minBorderX/Y = EDGE_THRESHOLD-3 (:780)
+#define ORBFE_NK_STRIDE 32   // ints between per-(frame, level) key counters: one 128-B line each (atomic targets)
 #define ORBFE_TILE_MAX 72    // FAST cell tile edge upper bound (cell+6 <= 66 when nCols == 1)
 
 // ---- thread-local error text ---------------------------------------------------------------------

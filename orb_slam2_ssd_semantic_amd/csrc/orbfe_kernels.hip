@@ -9,6 +9,8 @@
 //
 // Integer / byte work bounded by HBM and LDS, no MFMA.  Float steps that decide an output bit use
 // explicitly rounded single operations (__fmul_rn/__fadd_rn/__fdiv_rn, no FMA contraction).
+#include <stdlib.h>
+
 #include "orbfe_common.h"
 #include "orbfe_kernels.h"
 #include "orbfe_pattern.inc"
@@ -403,21 +405,20 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 
-__global__ __launch_bounds__(256) void k_fast_emit(const OrbPlan *__restrict__ plan, const OrbCell *__restrict__ cells,
+#define EMIT_WAVES 4
+__global__ __launch_bounds__(EMIT_WAVES * 64) void k_fast_emit(const OrbPlan *__restrict__ plan, const OrbCell *__restrict__ cells,
                                                    const uint8_t *__restrict__ fmap, int64_t fmap_fstride,
-                                                   int32_t *__restrict__ cell_cnt, uint32_t *__restrict__ cell_keys)
+                                                   int32_t *__restrict__ cell_cnt,    // [B][ncells]
+                                                   uint32_t *__restrict__ cell_keys)  // [B][ncells][cell_cap]
 {
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cell >= plan->ncells) return;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int cell_raw = blockIdx.x * EMIT_WAVES + wid;
+    const bool have = cell_raw < plan->ncells;          // wave-uniform
+    const int cell = have ? cell_raw : plan->ncells - 1;
     const OrbCell c = cells[cell];
     const OrbLevel &L = plan->lv[c.level];
-    const int iw = (int)c.tw - 6, ih = (int)c.th - 6;
-    const int64_t slot0 = ((int64_t)b * plan->ncells + cell) * plan->cell_cap;
-    if (iw <= 0 || ih <= 0) {
-        if (lane == 0) cell_cnt[(int64_t)b * plan->ncells + cell] = 0;
-        return;
-    }
+    const int iw = have ? (int)c.tw - 6 : 0, ih = have ? (int)c.th - 6 : 0;
+    const bool live = iw > 0 && ih > 0;
     const int cx0 = c.x0 + 3, cy0 = c.y0 + 3;  // interior origin (level coordinates)
     const int xa = cx0 & ~3;                    // aligned start
     const int sub = lane & 15, rsub = lane >> 4;
@@ -434,26 +435,39 @@ __global__ __launch_bounds__(256) void k_fast_emit(const OrbPlan *__restrict__ p
     // unconditional (clamped addresses, results masked) so that they overlap instead of being waited on one by one.
     uint32_t wv[15];
     {
-        const int ndw = (cx0 + iw - xa + 3) >> 2;
+        const int ndw = max((cx0 + iw - xa + 3) >> 2, 1);
         const uint8_t *lbase = base - 4 * (sub - min(sub, ndw - 1));
 #pragma unroll
         for (int i = 0; i < 15; ++i) {
-            const int y = min(4 * i + rsub, ih - 1);
+            const int y = max(min(4 * i + rsub, ih - 1), 0);
             wv[i] = *(const uint32_t *)(lbase + (int64_t)(cy0 + y) * L.pitch);
         }
 #pragma unroll
         for (int i = 0; i < 15; ++i)
-            if (4 * i + rsub >= ih) wv[i] = 0u;
+            wv[i] = (4 * i + rsub < ih) ? (wv[i] & bmask) : 0u;
     }
-    // pass 1: does the iniTh list have any entry?  (src/ORBextractor.cc:821)
-    bool any_ini = false;
+    // pass 1: sizes of the iniTh list and of the minTh list (src/ORBextractor.cc:818-825)
+    int c_ini = 0, c_min = 0;
 #pragma unroll
     for (int i = 0; i < 15; ++i) {
-        const uint32_t w = wv[i] & bmask;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) any_ini = any_ini || (int)((w >> (8 * k)) & 0xFF) > ini;
+        for (int k = 0; k < 4; ++k) {
+            const int mv = (int)((wv[i] >> (8 * k)) & 0xFF);
+            c_ini += mv > ini;
+            c_min += mv > 0;
+        }
     }
-    const int thr = __any(any_ini) ? ini : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_ini += __shfl_xor(c_ini, o, 64);
+        c_min += __shfl_xor(c_min, o, 64);
+    }
+    const int thr = c_ini > 0 ? ini : 0;
+    const int ncell = live ? (c_ini > 0 ? c_ini : c_min) : 0;
+    if (!have) return;
+    if (lane == 0) cell_cnt[(int64_t)b * plan->ncells + cell] = ncell;
+    if (ncell == 0) return;
+    uint32_t *dstk = cell_keys + ((int64_t)b * plan->ncells + cell) * plan->cell_cap;
 
     // pass 2: ordered emission
     int total = 0;
@@ -461,11 +475,10 @@ __global__ __launch_bounds__(256) void k_fast_emit(const OrbPlan *__restrict__ p
     for (int i = 0; i < 15; ++i) {
         if (4 * i >= ih) break;  // wave-uniform
         const int y = 4 * i + rsub;
-        const uint32_t w = wv[i] & bmask;
         int m[4], cnt = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            m[k] = (int)((w >> (8 * k)) & 0xFF);
+            m[k] = (int)((wv[i] >> (8 * k)) & 0xFF);
             if (m[k] <= thr) m[k] = 0;
             cnt += m[k] != 0;
         }
@@ -477,17 +490,16 @@ __global__ __launch_bounds__(256) void k_fast_emit(const OrbPlan *__restrict__ p
             for (int j = 0; j < 4; ++j)
                 if (m[j]) {
                     // detection-window coordinates (level - 16) == tile-relative + j*wCell of the reference (:831-832)
-                    cell_keys[slot0 + k] = orb_pack_key(gx + j - ORBFE_MINB, cy0 + y - ORBFE_MINB, m[j] - 1);
+                    dstk[k] = orb_pack_key(gx + j - ORBFE_MINB, cy0 + y - ORBFE_MINB, m[j] - 1);
                     ++k;
                 }
             total += __popcll(b0) + 2 * __popcll(b1);
         }
     }
-    if (lane == 0) cell_cnt[(int64_t)b * plan->ncells + cell] = total;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K3  DistributeOctTree on the device.  One workgroup per (frame, level).
+// K3  DistributeOctTree on the device.  One workgroup (4 waves) per (frame, level).
 //
 // The reference keeps a std::list of nodes: a pass visits nodes in some processing order, replaces each
 // visited node by its non-empty children (push_front in the order n1,n2,n3,n4) and may stop early once
@@ -498,21 +510,28 @@ __global__ __launch_bounds__(256) void k_fast_emit(const OrbPlan *__restrict__ p
 //     [children(P[R-1]) n4..n1] ... [children(P[0]) n4..n1]  ++  [unprocessed nodes in old order].
 // Positions therefore follow from prefix sums over the processing order, child membership from
 // per-node quadrant counters (LDS atomics), and the final "first strongest key" from an LDS atomicMax
-// on (response << 24 | ~original_index).  Keys never move: each key only carries its node index.
+// on (response << 32 | ~candidate_order).  Keys never move: each key only carries its node index.
 // Equal-size ties in the largest-first order are broken by creation order (the reference compares heap
 // addresses there, :686 -- see DESIGN.md "quadtree contract").
+//
+// Structure of one pass:  [all waves] one streaming loop over the keys (map the key to its node of the current
+// list, classify into a quadrant, count)  ->  [wave 0 alone, wave-synchronous, no barriers] all node-level
+// bookkeeping (<= node_cap entries).  Keys arrive in arbitrary cell order from k_fast_emit; each carries `ord`,
+// its rank in the reference's candidate order, which is all the tie-break needs.
 // ---------------------------------------------------------------------------------------------------
-#define QT 256
+#define QT_MAX 1024
 #define KNODE_MASK 0x3FFFu
+#define KUNROLL 4
 
 struct QtShared {
     int16_t *box[2][4];  // ulx, uly, urx, bry
     int32_t *cnt[2];
-    int32_t *cc;      // [M*4] child counts, then child positions
-    int32_t *P;       // processing order -> node index
-    int32_t *rankOf;  // node index -> processing rank or -1
-    int32_t *acc;     // inclusive sums over ranks
-    int32_t *newIdx;  // new position of unprocessed nodes
+    int32_t *cc;        // [M*4] quadrant counts of the current pass
+    int32_t *childpos;  // [M*4] position of child (node, quadrant) in the next list, -1 if empty
+    int32_t *P;         // processing order -> node index
+    int32_t *rankOf;    // node index -> processing rank or -1
+    int32_t *acc;       // inclusive sums over ranks
+    int32_t *newIdx;    // next-list position of an unprocessed node, -1 for a processed one
     unsigned long long *skey;
     int32_t *misc;
 };
@@ -522,6 +541,7 @@ __device__ __forceinline__ void qt_carve(char *base, int M, QtShared &q)
     char *p = base;
     q.skey = (unsigned long long *)p; p += (size_t)M * 8;
     q.cc = (int32_t *)p; p += (size_t)M * 16;
+    q.childpos = (int32_t *)p; p += (size_t)M * 16;
     for (int i = 0; i < 2; ++i) { q.cnt[i] = (int32_t *)p; p += (size_t)M * 4; }
     q.P = (int32_t *)p; p += (size_t)M * 4;
     q.rankOf = (int32_t *)p; p += (size_t)M * 4;
@@ -532,51 +552,82 @@ __device__ __forceinline__ void qt_carve(char *base, int M, QtShared &q)
     q.misc = (int32_t *)p;
 }
 
-size_t orbk_octree_lds_bytes(int M) { return (size_t)M * (8 + 16 + 8 + 16 + 16) + 64 * 4; }
+size_t orbk_octree_lds_bytes(int M) { return (size_t)M * (8 + 16 + 16 + 8 + 16 + 16) + 64 * 4; }
 
-// chunked block-wide inclusive scan over arr[0..n) in LDS (in place). Returns total.
-__device__ int qt_scan_inclusive(int32_t *arr, int n, int *s_wave)
+// LDS ordering inside ONE wave: its DS operations execute in order, the fence only keeps the compiler honest
+#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
+
+// wave-synchronous inclusive scan of arr[0..n) in LDS, in place; returns the total
+__device__ __forceinline__ int wscan_inclusive(int32_t *arr, int n, int lane)
 {
-    const int tid = threadIdx.x;
-    const int per = (n + QT - 1) / QT;
-    const int i0 = tid * per, i1 = min(i0 + per, n);
-    int sum = 0;
-    for (int i = i0; i < i1; ++i) sum += arr[i];
-    int total;
-    int base = block_excl_scan(sum, s_wave, &total);
-    for (int i = i0; i < i1; ++i) {
-        base += arr[i];
-        arr[i] = base;
+    int carry = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const int v = i < n ? arr[i] : 0;
+        const int incl = wave_incl_scan(v);
+        if (i < n) arr[i] = carry + incl;
+        carry += __shfl(incl, 63, 64);
     }
-    __syncthreads();
-    return total;
+    WSYNC();
+    return carry;
 }
 
-__global__ __launch_bounds__(QT) void k_octree(const OrbPlan *__restrict__ plan,
-                                               const int32_t *__restrict__ cell_cnt,
-                                               const uint32_t *__restrict__ cell_keys,
-                                               int32_t *__restrict__ cell_off,   // [B][ncells] scratch
-                                               uint32_t *__restrict__ keys,      // [B][keys_per_frame] scratch
-                                               uint16_t *__restrict__ knode,     // [B][keys_per_frame] scratch
-                                               uint32_t *__restrict__ sel,       // [B][sel_per_frame] out
-                                               int32_t *__restrict__ nsel,       // [B][nlevels] out
-                                               int32_t *__restrict__ nkeys_out)  // [B][nlevels] out (taps)
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// counters[idx] += 1 for every active lane, with ONE LDS atomic per distinct idx in the wave: early quadtree passes
+// send thousands of keys to a handful of counters, where per-lane atomics serialise 64-way
+__device__ __forceinline__ void wave_agg_inc(int32_t *counters, int idx, bool active, int lane)
+{
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lidx = __shfl(idx, leader, 64);
+        const unsigned long long same = __ballot(active && idx == lidx);
+        if (lane == leader) atomicAdd(&counters[lidx], __popcll(same));
+        todo &= ~same;
+    }
+}
+
+// node of the current list a key belongs to, from its entry of the previous pass (node | quadrant << 14)
+__device__ __forceinline__ int qt_follow(const QtShared &q, uint32_t kn)
+{
+    const int i = (int)(kn & KNODE_MASK);
+    const int ni = q.newIdx[i];
+    return ni >= 0 ? ni : q.childpos[i * 4 + (int)(kn >> 14)];
+}
+
+__global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ plan,
+                                               const int32_t *__restrict__ cell_cnt,   // [B][ncells]
+                                               const uint32_t *__restrict__ cell_keys, // [B][ncells][cell_cap]
+                                               int32_t *__restrict__ cell_off,      // [B][ncells] scratch
+                                               uint32_t *__restrict__ keys,         // [B][keys_per_frame] scratch
+                                               uint16_t *__restrict__ knode,        // [B][keys_per_frame] scratch
+                                               int32_t *__restrict__ nkeys,         // [B][nlevels] out (taps)
+                                               uint32_t *__restrict__ sel,          // [B][sel_per_frame] out
+                                               int32_t *__restrict__ nsel)          // [B][nlevels] out
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_wave[17];
     const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int QT = blockDim.x;  // 256 .. 1024 (launch-time choice)
     const OrbLevel &L = plan->lv[level];
     const int M = plan->node_cap;
     const int N = L.nfeat;
     QtShared q;
     qt_carve(smem, M, q);
     int32_t *misc = q.misc;
-
-    // ---- prologue: compact this level's per-cell key slots into the reference candidate order ----
-    const int32_t *ccnt = cell_cnt + (int64_t)b * plan->ncells + L.cell0;
-    int32_t *coff = cell_off + (int64_t)b * plan->ncells + L.cell0;
     uint32_t *K = keys + (int64_t)b * plan->keys_per_frame + L.key_off;
     uint16_t *KN = knode + (int64_t)b * plan->keys_per_frame + L.key_off;
+
+    // ---- prologue: compact this level's per-cell key slots into the reference candidate order ----
+    __shared__ int s_wave[17];
+    const int32_t *ccnt = cell_cnt + (int64_t)b * plan->ncells + L.cell0;
+    int32_t *coff = cell_off + (int64_t)b * plan->ncells + L.cell0;
     int n = 0;
     for (int c0 = 0; c0 < L.ncells; c0 += QT) {
         const int c = c0 + tid;
@@ -587,35 +638,58 @@ __global__ __launch_bounds__(QT) void k_octree(const OrbPlan *__restrict__ plan,
         n += tot;
     }
     __syncthreads();
-    {
-        const int wid = tid >> 6, lane = tid & 63;
-        for (int c = wid; c < L.ncells; c += QT / 64) {
-            const int cn = ccnt[c], o = coff[c];
+    for (int c0 = wid; c0 < L.ncells; c0 += 4 * (QT / 64)) {  // 4 cells per wave in flight
+        int cn[4], co[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = min(c0 + u * (QT / 64), L.ncells - 1);
+            cn[u] = (c0 + u * (QT / 64) < L.ncells) ? ccnt[c] : 0;
+            co[u] = coff[c];
+        }
+        uint32_t v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = min(c0 + u * (QT / 64), L.ncells - 1);
             const uint32_t *src = cell_keys + ((int64_t)b * plan->ncells + L.cell0 + c) * plan->cell_cap;
-            for (int k = lane; k < cn; k += 64) K[o + k] = src[k];
+            v0[u] = lane < cn[u] ? src[lane] : 0u;
+            v1[u] = lane + 64 < cn[u] ? src[lane + 64] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (lane < cn[u]) K[co[u] + lane] = v0[u];
+            if (lane + 64 < cn[u]) K[co[u] + lane + 64] = v1[u];
+            if (cn[u] > 128) {
+                const int c = c0 + u * (QT / 64);
+                const uint32_t *src = cell_keys + ((int64_t)b * plan->ncells + L.cell0 + c) * plan->cell_cap;
+                for (int k = 128 + lane; k < cn[u]; k += 64) K[co[u] + k] = src[k];
+            }
         }
     }
-    if (tid == 0) nkeys_out[b * plan->nlevels + level] = n;
+    if (tid == 0) nkeys[(b * plan->nlevels + level) * ORBFE_NK_STRIDE] = n;
     __syncthreads();
+    if (plan->dbg == 10) return;
 
     // ---- roots (:545-587): nini boxes, keys by (int)(x / hX), empty roots erased ----
-    int cur = 0;
     const int nini = L.nini;
     if (tid < 8) q.cc[tid] = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += QT) {
-        const int x = orb_key_x(K[k]);
-        int r = (int)__fdiv_rn((float)x, L.hx);
-        r = min(max(r, 0), nini - 1);
-        KN[k] = (uint16_t)r;
-        atomicAdd(&q.cc[r], 1);
+    for (int k0 = 0; k0 < n; k0 += QT) {
+        const int k = k0 + tid;
+        int r = 0;
+        if (k < n) {
+            const int x = orb_key_x(K[k]);
+            r = (int)__fdiv_rn((float)x, L.hx);
+            r = min(max(r, 0), nini - 1);
+            KN[k] = (uint16_t)r;
+        }
+        wave_agg_inc(q.cc, r, k < n, lane);
     }
     __syncthreads();
     if (tid == 0) {
         int S0 = 0;
         for (int r = 0; r < nini; ++r) {
             const int cn = q.cc[r];
-            q.newIdx[r] = S0;
+            q.newIdx[r] = S0;  // root r -> list position (unused for empty roots)
             if (cn > 0) {
                 q.box[0][0][S0] = (int16_t)L.root_x[r];
                 q.box[0][1][S0] = 0;
@@ -625,205 +699,219 @@ __global__ __launch_bounds__(QT) void k_octree(const OrbPlan *__restrict__ plan,
                 ++S0;
             }
         }
-        // initial processing order: multi-key roots in list order
-        int m0 = 0;
+        int m0 = 0;  // initial processing order: multi-key roots in list order
         for (int i = 0; i < S0; ++i) {
             if (q.cnt[0][i] > 1) { q.P[m0] = i; q.rankOf[i] = m0; ++m0; }
             else q.rankOf[i] = -1;
         }
         misc[0] = S0;
         misc[1] = m0;
+        misc[3] = 0;  // finish
+        misc[4] = 0;  // modeB
     }
     __syncthreads();
-    for (int k = tid; k < n; k += QT) KN[k] = (uint16_t)q.newIdx[KN[k]];
     int S = misc[0], m = misc[1];
-    int modeB = 0;
-    __syncthreads();
+    int cur = 0;
+    if (plan->dbg == 11) return;
+    const int maxpass = plan->dbg >= 20 ? plan->dbg - 20 : 64;
 
     // ---- passes ----
-    for (int guard = 0; guard < 64; ++guard) {
+    for (int guard = 0; guard < maxpass; ++guard) {
         const int nx = cur ^ 1;
-        // 1. quadrant counts of every multi-key node
         for (int i = tid; i < S * 4; i += QT) q.cc[i] = 0;
         __syncthreads();
-        for (int k = tid; k < n; k += QT) {
-            const int i = KN[k] & KNODE_MASK;
-            if (q.cnt[cur][i] > 1) {
-                const uint32_t key = K[k];
-                const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
-                const int midx = ulx + ((q.box[cur][2][i] - ulx + 1) >> 1);  // UL.x + ceil(w/2)  (:480)
-                const int midy = uly + ((q.box[cur][3][i] - uly + 1) >> 1);
-                const int qd = (orb_key_x(key) < midx ? 0 : 1) + (orb_key_y(key) < midy ? 0 : 2);
-                atomicAdd(&q.cc[i * 4 + qd], 1);
-                KN[k] = (uint16_t)(i | (qd << 14));
+        // A. one streaming loop over the keys: follow to the current list, classify, count
+        for (int k0 = tid; k0 < n; k0 += QT * KUNROLL) {
+            uint32_t kn[KUNROLL], kv[KUNROLL];
+#pragma unroll
+            for (int u = 0; u < KUNROLL; ++u) {
+                const int k = k0 + u * QT;
+                kn[u] = k < n ? KN[k] : 0u;
+                kv[u] = k < n ? K[k] : 0u;
             }
-        }
-        __syncthreads();
-        // 2. non-empty children per processing rank, inclusive sums, stop rank R
-        for (int r = tid; r < m; r += QT) {
-            const int i = q.P[r];
-            q.acc[r] = (q.cc[i * 4] > 0) + (q.cc[i * 4 + 1] > 0) + (q.cc[i * 4 + 2] > 0) + (q.cc[i * 4 + 3] > 0);
-        }
-        if (tid == 0) misc[2] = m;
-        __syncthreads();
-        qt_scan_inclusive(q.acc, m, s_wave);
-        if (modeB) {
-            // first rank whose split brings the list to >= N nodes (:732)
-            for (int r = tid; r < m; r += QT)
-                if (S + q.acc[r] - (r + 1) >= N) atomicMin(&misc[2], r + 1);
-            __syncthreads();
-        }
-        const int R = misc[2];
-        const int totalChildren = R > 0 ? q.acc[R - 1] : 0;
-        // 3. unprocessed nodes keep their relative order behind the new children
-        for (int i = tid; i < S; i += QT) {
-            const int r = q.rankOf[i];
-            q.newIdx[i] = (r >= 0 && r < R) ? 0 : 1;
-        }
-        __syncthreads();
-        const int nUnproc = qt_scan_inclusive(q.newIdx, S, s_wave);
-        const int S2 = totalChildren + nUnproc;
-        // 4. write the next list
-        for (int i = tid; i < S; i += QT) {
-            const int r = q.rankOf[i];
-            if (r >= 0 && r < R) {
-                int pos = totalChildren - q.acc[r];
-                const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
-                const int urx = q.box[cur][2][i], bry = q.box[cur][3][i];
-                const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);
-                for (int qd = 3; qd >= 0; --qd) {  // list front holds n4, then n3, n2, n1 (:623-662)
-                    const int cn = q.cc[i * 4 + qd];
-                    if (cn > 0) {
-                        q.box[nx][0][pos] = (int16_t)((qd & 1) ? midx : ulx);
-                        q.box[nx][1][pos] = (int16_t)((qd & 2) ? midy : uly);
-                        q.box[nx][2][pos] = (int16_t)((qd & 1) ? urx : midx);
-                        q.box[nx][3][pos] = (int16_t)((qd & 2) ? bry : midy);
-                        q.cnt[nx][pos] = cn;
-                        q.cc[i * 4 + qd] = pos;
-                        ++pos;
-                    } else {
-                        q.cc[i * 4 + qd] = -1;
+#pragma unroll
+            for (int u = 0; u < KUNROLL; ++u) {
+                const int k = k0 + u * QT;
+                if (k < n) {
+                    const int i = qt_follow(q, kn[u]);
+                    uint32_t out = (uint32_t)i;
+                    if (q.cnt[cur][i] > 1) {
+                        const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
+                        const int midx = ulx + ((q.box[cur][2][i] - ulx + 1) >> 1);  // UL.x + ceil(w/2)  (:480)
+                        const int midy = uly + ((q.box[cur][3][i] - uly + 1) >> 1);
+                        const int qd = (orb_key_x(kv[u]) < midx ? 0 : 1) + (orb_key_y(kv[u]) < midy ? 0 : 2);
+                        atomicAdd(&q.cc[i * 4 + qd], 1);
+                        out |= (uint32_t)qd << 14;
                     }
+                    KN[k] = (uint16_t)out;
                 }
-            } else {
-                const int pos = totalChildren + q.newIdx[i] - 1;
-                q.box[nx][0][pos] = q.box[cur][0][i];
-                q.box[nx][1][pos] = q.box[cur][1][i];
-                q.box[nx][2][pos] = q.box[cur][2][i];
-                q.box[nx][3][pos] = q.box[cur][3][i];
-                q.cnt[nx][pos] = q.cnt[cur][i];
-                q.newIdx[i] = pos;
             }
         }
         __syncthreads();
-        // 5. keys follow their node
-        for (int k = tid; k < n; k += QT) {
-            const int kn = KN[k];
-            const int i = kn & KNODE_MASK, qd = kn >> 14;
-            const int r = q.rankOf[i];
-            KN[k] = (uint16_t)((r >= 0 && r < R) ? q.cc[i * 4 + qd] : q.newIdx[i]);
-        }
-        // 6. multi-key children in creation order (rank asc, n1..n4): counts per rank -> sequence numbers
-        for (int r = tid; r < R; r += QT) {
-            const int i = q.P[r];
-            int mc = 0;
-            for (int qd = 0; qd < 4; ++qd) {
-                const int pos = q.cc[i * 4 + qd];
-                if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
-            }
-            q.acc[r] = mc;
-        }
-        __syncthreads();
-        const int nToExpand = qt_scan_inclusive(q.acc, R, s_wave);
-        // 7. termination / next mode (:671-675, :736)
-        const bool finish = (S2 >= N) || (S2 == S);
-        if (!modeB && !finish && (S2 + 3 * nToExpand > N)) modeB = 1;
-        if (finish) {
-            S = S2;
-            cur = nx;
-            break;
-        }
-        // 8. next processing order
-        if (!modeB) {
-            // list order of the multi-key nodes of the new list
-            for (int i = tid; i < S2; i += QT) q.newIdx[i] = q.cnt[nx][i] > 1 ? 1 : 0;
-            __syncthreads();
-            const int m2 = qt_scan_inclusive(q.newIdx, S2, s_wave);
-            // rankOf must be rebuilt from newIdx before P is overwritten: use skey as staging for P
-            for (int i = tid; i < S2; i += QT) {
-                const bool multi = q.cnt[nx][i] > 1;
-                const int r = q.newIdx[i] - 1;
-                q.rankOf[i] = multi ? r : -1;
-                if (multi) ((int32_t *)q.skey)[r] = i;
-            }
-            __syncthreads();
-            for (int r = tid; r < m2; r += QT) q.P[r] = ((int32_t *)q.skey)[r];
-            m = m2;
-        } else {
-            // sort the new multi-key children by (size desc, creation seq desc) (:686-687)
-            int Mp = 2;
-            while (Mp < nToExpand) Mp <<= 1;
-            for (int i = tid; i < Mp; i += QT) q.skey[i] = 0ull;
-            __syncthreads();
-            for (int r = tid; r < R; r += QT) {
+        // B. node-level bookkeeping by wave 0 alone (wave-synchronous)
+        if (plan->dbg == 12) { cur = nx; break; }
+        if (wid == 0) {
+            const int modeB = misc[4];
+            // non-empty children per processing rank, inclusive sums, stop rank R
+            for (int r = lane; r < m; r += 64) {
                 const int i = q.P[r];
-                int seq = q.acc[r];  // inclusive count -> sequence numbers of this rank end at acc[r]-1
-                int mc = 0;
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int pos = q.cc[i * 4 + qd];
-                    if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
-                }
-                seq -= mc;
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int pos = q.cc[i * 4 + qd];
-                    if (pos >= 0 && q.cnt[nx][pos] > 1) {
-                        q.skey[seq] = ((unsigned long long)(uint32_t)q.cnt[nx][pos] << 32) |
-                                      ((unsigned long long)(uint32_t)(seq + 1) << 16) | (unsigned long long)pos;
-                        ++seq;
-                    }
-                }
+                q.acc[r] = (q.cc[i * 4] > 0) + (q.cc[i * 4 + 1] > 0) + (q.cc[i * 4 + 2] > 0) + (q.cc[i * 4 + 3] > 0);
             }
-            __syncthreads();
-            for (int kk = 2; kk <= Mp; kk <<= 1)
-                for (int j = kk >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < Mp; i += QT) {
-                        const int ixj = i ^ j;
-                        if (ixj > i) {
-                            const unsigned long long a = q.skey[i], c2 = q.skey[ixj];
-                            const bool desc = (i & kk) == 0;  // overall descending
-                            if (desc ? (a < c2) : (a > c2)) { q.skey[i] = c2; q.skey[ixj] = a; }
+            WSYNC();
+            wscan_inclusive(q.acc, m, lane);
+            int R = m;
+            if (modeB) {  // first rank whose split brings the list to >= N nodes (:732)
+                int rmin = m;
+                for (int r = lane; r < m; r += 64)
+                    if (S + q.acc[r] - (r + 1) >= N) rmin = min(rmin, r + 1);
+                R = wave_min_i(rmin);
+            }
+            const int totalChildren = R > 0 ? q.acc[R - 1] : 0;
+            // unprocessed nodes keep their relative order behind the new children
+            for (int i = lane; i < S; i += 64) {
+                const int r = q.rankOf[i];
+                q.newIdx[i] = (r >= 0 && r < R) ? 0 : 1;
+            }
+            WSYNC();
+            const int nUnproc = wscan_inclusive(q.newIdx, S, lane);
+            const int S2 = totalChildren + nUnproc;
+            // write the next list; leave the old->new map (newIdx / childpos) for the next key loop
+            for (int i = lane; i < S; i += 64) {
+                const int r = q.rankOf[i];
+                if (r >= 0 && r < R) {
+                    int pos = totalChildren - q.acc[r];
+                    const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
+                    const int urx = q.box[cur][2][i], bry = q.box[cur][3][i];
+                    const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);
+                    for (int qd = 3; qd >= 0; --qd) {  // list front holds n4, then n3, n2, n1 (:623-662)
+                        const int cn = q.cc[i * 4 + qd];
+                        if (cn > 0) {
+                            q.box[nx][0][pos] = (int16_t)((qd & 1) ? midx : ulx);
+                            q.box[nx][1][pos] = (int16_t)((qd & 2) ? midy : uly);
+                            q.box[nx][2][pos] = (int16_t)((qd & 1) ? urx : midx);
+                            q.box[nx][3][pos] = (int16_t)((qd & 2) ? bry : midy);
+                            q.cnt[nx][pos] = cn;
+                            q.childpos[i * 4 + qd] = pos;
+                            ++pos;
+                        } else {
+                            q.childpos[i * 4 + qd] = -1;
                         }
                     }
-                    __syncthreads();
+                    q.newIdx[i] = -1;
+                } else {
+                    const int pos = totalChildren + q.newIdx[i] - 1;
+                    q.box[nx][0][pos] = q.box[cur][0][i];
+                    q.box[nx][1][pos] = q.box[cur][1][i];
+                    q.box[nx][2][pos] = q.box[cur][2][i];
+                    q.box[nx][3][pos] = q.box[cur][3][i];
+                    q.cnt[nx][pos] = q.cnt[cur][i];
+                    q.newIdx[i] = pos;
                 }
-            for (int i = tid; i < S2; i += QT) q.rankOf[i] = -1;
-            __syncthreads();
-            for (int r = tid; r < nToExpand; r += QT) {
-                const int pos = (int)(q.skey[r] & 0xFFFFull);
-                q.P[r] = pos;
-                q.rankOf[pos] = r;
             }
-            m = nToExpand;
+            WSYNC();
+            // multi-key children in creation order (rank asc, n1..n4): counts per rank -> sequence numbers
+            for (int r = lane; r < R; r += 64) {
+                const int i = q.P[r];
+                int mc = 0;
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int pos = q.childpos[i * 4 + qd];
+                    if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
+                }
+                q.acc[r] = mc;
+            }
+            WSYNC();
+            const int nToExpand = wscan_inclusive(q.acc, R, lane);
+            // termination / next mode (:671-675, :736)
+            const bool finish = (S2 >= N) || (S2 == S);
+            int modeB2 = modeB;
+            if (!modeB && !finish && (S2 + 3 * nToExpand > N)) modeB2 = 1;
+            int m2 = 0;
+            if (!finish) {
+                if (!modeB2) {
+                    // list order of the multi-key nodes of the new list; P/rankOf of the OLD list are dead now
+                    for (int i = lane; i < S2; i += 64) ((int32_t *)q.skey)[i] = q.cnt[nx][i] > 1 ? 1 : 0;
+                    WSYNC();
+                    m2 = wscan_inclusive((int32_t *)q.skey, S2, lane);
+                    for (int i = lane; i < S2; i += 64) {
+                        const bool multi = q.cnt[nx][i] > 1;
+                        const int r = ((int32_t *)q.skey)[i] - 1;
+                        q.rankOf[i] = multi ? r : -1;
+                        if (multi) q.P[r] = i;
+                    }
+                } else {
+                    // sort the new multi-key children by (size desc, creation seq desc) (:686-687)
+                    int Mp = 2;
+                    while (Mp < nToExpand) Mp <<= 1;
+                    for (int i = lane; i < Mp; i += 64) q.skey[i] = 0ull;
+                    WSYNC();
+                    for (int r = lane; r < R; r += 64) {
+                        const int i = q.P[r];
+                        int mc = 0;
+                        for (int qd = 0; qd < 4; ++qd) {
+                            const int pos = q.childpos[i * 4 + qd];
+                            if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
+                        }
+                        int seq = q.acc[r] - mc;  // acc is inclusive
+                        for (int qd = 0; qd < 4; ++qd) {
+                            const int pos = q.childpos[i * 4 + qd];
+                            if (pos >= 0 && q.cnt[nx][pos] > 1) {
+                                q.skey[seq] = ((unsigned long long)(uint32_t)q.cnt[nx][pos] << 32) |
+                                              ((unsigned long long)(uint32_t)(seq + 1) << 16) | (unsigned long long)pos;
+                                ++seq;
+                            }
+                        }
+                    }
+                    WSYNC();
+                    for (int kk = 2; kk <= Mp; kk <<= 1)
+                        for (int j = kk >> 1; j > 0; j >>= 1) {
+                            for (int i = lane; i < Mp; i += 64) {
+                                const int ixj = i ^ j;
+                                if (ixj > i) {
+                                    const unsigned long long a = q.skey[i], c2 = q.skey[ixj];
+                                    const bool desc = (i & kk) == 0;  // overall descending
+                                    if (desc ? (a < c2) : (a > c2)) { q.skey[i] = c2; q.skey[ixj] = a; }
+                                }
+                            }
+                            WSYNC();
+                        }
+                    for (int i = lane; i < S2; i += 64) q.rankOf[i] = -1;
+                    WSYNC();
+                    for (int r = lane; r < nToExpand; r += 64) {
+                        const int pos = (int)(q.skey[r] & 0xFFFFull);
+                        q.P[r] = pos;
+                        q.rankOf[pos] = r;
+                    }
+                    m2 = nToExpand;
+                }
+            }
+            WSYNC();
+            if (lane == 0) {
+                misc[0] = S2;
+                misc[1] = m2;
+                misc[3] = finish ? 1 : 0;
+                misc[4] = modeB2;
+            }
         }
-        S = S2;
-        cur = nx;
         __syncthreads();
+        S = misc[0];
+        m = misc[1];
+        cur = nx;
+        if (misc[3]) break;
     }
-    __syncthreads();
 
     // ---- keep the strongest key of every node, first in candidate order on ties (:746-762) ----
-    uint32_t *best = (uint32_t *)q.cc;
-    for (int i = tid; i < S; i += QT) best[i] = 0;
+    unsigned long long *best = q.skey;
+    for (int i = tid; i < S; i += QT) best[i] = 0ull;
     __syncthreads();
     for (int k = tid; k < n; k += QT) {
-        const int i = KN[k] & KNODE_MASK;
-        atomicMax(&best[i], ((uint32_t)orb_key_r(K[k]) << 24) | (0xFFFFFFu - (uint32_t)k));
+        const int i = qt_follow(q, KN[k]);
+        atomicMax(&best[i], ((unsigned long long)orb_key_r(K[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)k));
     }
     __syncthreads();
     uint32_t *out = sel + (int64_t)b * plan->sel_per_frame + L.sel_off;
     const int nout = min(S, L.sel_cap);
     for (int i = tid; i < nout; i += QT) {
-        const uint32_t key = K[0xFFFFFFu - (best[i] & 0xFFFFFFu)];
+        const uint32_t key = K[0xFFFFFFFFu - (uint32_t)(best[i] & 0xFFFFFFFFull)];
         // + minBorderX / minBorderY (:853-854): level coordinates from here on
         out[i] = orb_pack_key(orb_key_x(key) + ORBFE_MINB, orb_key_y(key) + ORBFE_MINB, orb_key_r(key));
     }
@@ -1119,8 +1207,9 @@ hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
 {
     dim3 grid(a.h_plan->nlevels, a.nframes);
     const size_t lds = orbk_octree_lds_bytes(a.h_plan->node_cap);
-    hipLaunchKernelGGL(k_octree, grid, dim3(QT), lds, st, a.d_plan, a.d_cell_cnt, a.d_cell_keys, a.d_cell_off,
-                       a.d_keys, a.d_knode, a.d_sel, a.d_nsel, a.d_nkeys);
+    static const int qt = getenv("ORBFE_QT") ? atoi(getenv("ORBFE_QT")) : 512;
+    hipLaunchKernelGGL(k_octree, grid, dim3(qt), lds, st, a.d_plan, a.d_cell_cnt, a.d_cell_keys, a.d_cell_off, a.d_keys,
+                       a.d_knode, a.d_nkeys, a.d_sel, a.d_nsel);
     return hipGetLastError();
 }
 
