@@ -674,7 +674,7 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
     for (int f0 = 0; f0 < nframes; f0 += chunk_max) {
         const int nb = std::min(chunk_max, nframes - f0);
         ORBFE_HIP(h->h_stage.ensure(fbytes * nb));
-        ORBFE_HIP(h->d_stage.ensure(fbytes * nb));
+        ORBFE_HIP(h->d_stage.ensure(fbytes * nb + 64));  // + slack: kernels read whole dwords past the last pixel
         ORBFE_HIP(h->d_okps.ensure(sizeof(orbfe_keypoint) * (size_t)cap * nb));
         ORBFE_HIP(h->d_odesc.ensure((size_t)32 * cap * nb));
         ORBFE_HIP(h->d_on.ensure(sizeof(int32_t) * nb));

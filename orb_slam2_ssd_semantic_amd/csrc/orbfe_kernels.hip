@@ -87,30 +87,81 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 // ---------------------------------------------------------------------------------------------------
 // K1  bilinear pyramid level:  dst(level) = resize(src(level-1))      
-// One thread per destination pixel, 64x4 tiles; coefficient tables precomputed on the host in fp64/fp32
-// exactly as cv::resize does.  All arithmetic is int32.
+// One wave per 256 x 32 destination tile: every lane owns 4 adjacent destination pixels and walks down the rows.
+// Its horizontal taps (source column, the two 11-bit coefficients) are per-lane constants; per source row it
+// loads a 12-byte window (3 aligned dwords) and forms the four horizontal sums H = S[sx]*a0 + S[sx+1]*a1.
+// Consecutive destination rows share source rows (sy1 of one row is sy0 of the next ~5 times out of 6), so the
+// H row is carried in registers.  Vertical step: ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2, one dword store.
+// Coefficient tables are precomputed on the host in fp64/fp32 exactly as cv::resize does; all kernel math is int32.
 // ---------------------------------------------------------------------------------------------------
+#define PY_RB 8  // destination rows per wave: short waves, the per-launch parallelism comes from their number
+
 __global__ __launch_bounds__(256) void k_pyr_resize(const OrbPlan *__restrict__ plan, FrameSrc fs, int level,
                                                     const OrbTab *__restrict__ tabs)
 {
     const OrbLevel &D = plan->lv[level];
     const OrbLevel &S = plan->lv[level - 1];
-    const int b = blockIdx.z;
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dx >= D.w || dy >= D.h) return;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int W = D.w, H = D.h;
+    const int nstrips = (W + 255) >> 8;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ntiles = nstrips * ((H + PY_RB - 1) / PY_RB);
+    if (t >= ntiles) return;
+    const int strip = t % nstrips, rblk = t / nstrips;
+    const int dx0 = strip * 256 + lane * 4;
+    const int y0 = rblk * PY_RB;
+    const int nrows = min(PY_RB, H - y0);
     int sp;
     const uint8_t *src = level_ptr(fs, S, level - 1, b, &sp);
     uint8_t *dst = fs.pyr + (int64_t)b * fs.pyr_fstride + D.off;
-    const OrbTab tx = tabs[D.xtab + dx];
-    const OrbTab ty = tabs[D.ytab + dy];
-    const int sx0 = tx.s, sx1 = min(tx.s + 1, S.w - 1);
-    const int sy0 = min(max((int)ty.s, 0), S.h - 1), sy1 = min(max((int)ty.s + 1, 0), S.h - 1);
-    const uint8_t *r0 = src + (int64_t)sy0 * sp, *r1 = src + (int64_t)sy1 * sp;
-    const int h0 = r0[sx0] * tx.c0 + r0[sx1] * tx.c1;
-    const int h1 = r1[sx0] * tx.c0 + r1[sx1] * tx.c1;
-    const int v = ((((int)ty.c0 * (h0 >> 4)) >> 16) + (((int)ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
-    dst[(int64_t)dy * D.pitch + dx] = (uint8_t)v;
+    const bool active = dx0 < W;
+
+    // per-lane horizontal taps: source column and the two 11-bit coefficients of each of the 4 pixels
+    int sx[4], a0[4], a1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const OrbTab tx = tabs[D.xtab + min(dx0 + j, W - 1)];
+        sx[j] = tx.s;
+        a0[j] = tx.c0;
+        a1[j] = tx.c1;
+    }
+    // The pair (S[sx], S[sx+1]) of every tap is ONE unaligned 16-bit load.  It may touch the byte after the last
+    // source pixel (sx = S.w-1 has a1 = 0): inside the padded rows of the handle's own levels, and inside the
+    // caller's level-0 buffer thanks to the 16-byte slack orbfe.h asks for.
+    // straight-line: all source pairs of the tile in flight at once, then the arithmetic (no control flow)
+    uint32_t p0[PY_RB][4], p1[PY_RB][4];
+    int vb0[PY_RB], vb1[PY_RB];
+#pragma unroll
+    for (int d = 0; d < PY_RB; ++d) {
+        const OrbTab ty = tabs[D.ytab + min(y0 + d, H - 1)];
+        const int tys = (int)ty.s;
+        const int sy0 = min(max(tys, 0), S.h - 1), sy1 = min(max(tys + 1, 0), S.h - 1);
+        vb0[d] = ty.c0;
+        vb1[d] = ty.c1;
+        const uint8_t *r0 = src + (int64_t)sy0 * sp, *r1 = src + (int64_t)sy1 * sp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p0[d][j] = *(const uint16_t *)(r0 + sx[j]);
+            p1[d][j] = *(const uint16_t *)(r1 + sx[j]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < PY_RB; ++d) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ha = __mul24((int)(p0[d][j] & 0xFFu), a0[j]) + __mul24((int)(p0[d][j] >> 8), a1[j]);
+            const int hb = __mul24((int)(p1[d][j] & 0xFFu), a0[j]) + __mul24((int)(p1[d][j] >> 8), a1[j]);
+            const int v = ((__mul24(vb0[d], ha >> 4) >> 16) + (__mul24(vb1[d], hb >> 4) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xFF) << (8 * j);
+        }
+        if (active && d < nrows) {
+            uint8_t *o = dst + (int64_t)(y0 + d) * D.pitch + dx0;
+            if (dx0 + 4 <= W) *(uint32_t *)o = packed;
+            else
+                for (int j = 0; j < 4 && dx0 + j < W; ++j) o[j] = (uint8_t)(packed >> (8 * j));
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1185,7 +1236,8 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
     const FrameSrc fs = make_src(a);
     for (int l = 1; l < a.h_plan->nlevels; ++l) {
         const OrbLevel &L = a.h_plan->lv[l];
-        dim3 grid((L.w + 63) / 64, (L.h + 3) / 4, a.nframes);
+        const int ntiles = ((L.w + 255) / 256) * ((L.h + PY_RB - 1) / PY_RB);
+        dim3 grid((ntiles + 3) / 4, a.nframes);
         hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, a.d_plan, fs, l, a.d_tabs);
     }
     return hipGetLastError();
