@@ -19,11 +19,15 @@ __constant__ signed char c_pattern[1024];
 // umax[v] of the circular patch (src/ORBextractor.cc:449-465): {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}
 __constant__ int c_umax[16];
 
+hipError_t orbk_upload_moment_weights(const int *umax16);
+
 hipError_t orbk_upload_constants(const int *umax16)
 {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), orbfe_pattern31_host, 1024);
     if (e != hipSuccess) return e;
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int));
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int));
+    if (e != hipSuccess) return e;
+    return orbk_upload_moment_weights(umax16);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1124,6 +1128,39 @@ __device__ __forceinline__ void canon_sincos(float angle_deg, float *ca, float *
     *sb = __double2float_rn(s);
 }
 
+// 16 lanes per keypoint, 4 keypoints per wave, 4 waves per workgroup.
+//   A  IC_Angle moments: the 31 rows of the patch as 8 unaligned dwords each; a lane takes dword k = sub & 7 of rows
+//      (sub >> 3) + 2i.  m10 and the row sums come from v_dot4_u32_u8 against per-(row, dword) weight bytes
+//      ((u + 15) inside the circle, 1 inside the circle), reduced over the 16 lanes -- integer, any order is exact.
+//   B  fastAtan2 / canonical sincos per lane (16x redundant instead of 64x).
+//   C  rBRIEF: the 37 x 40 blurred patch is staged in LDS with coalesced dword loads; lane `sub` evaluates pairs
+//      16*sub .. 16*sub+15, i.e. descriptor bytes 2*sub and 2*sub+1, from LDS byte reads.
+#define DS_PP 40   // LDS patch pitch (bytes): columns x-18 .. x+21
+#define DS_PR 37   // patch rows y-18 .. y+18
+
+__constant__ uint2 c_momw[31 * 8];  // per (row v+15, dword k): .x = weights (u+15) or 0, .y = 1 or 0 per byte
+
+// circular patch of IC_Angle (src/ORBextractor.cc:59-88): row v covers u in [-umax[|v|], umax[|v|]]
+hipError_t orbk_upload_moment_weights(const int *umax16)
+{
+    uint2 h[31 * 8];
+    for (int row = 0; row < 31; ++row) {
+        const int v = row - 15, d = umax16[v < 0 ? -v : v];
+        for (int k = 0; k < 8; ++k) {
+            uint32_t w10 = 0, w1 = 0;
+            for (int i = 0; i < 4; ++i) {
+                const int u = 4 * k + i - 15;
+                if (u >= -d && u <= d) {
+                    w10 |= (uint32_t)(u + 15) << (8 * i);
+                    w1 |= 1u << (8 * i);
+                }
+            }
+            h[row * 8 + k] = make_uint2(w10, w1);
+        }
+    }
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_momw), h, sizeof(h));
+}
+
 __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restrict__ plan, FrameSrc fs,
                                                          const uint8_t *__restrict__ blur, int64_t blur_fstride,
                                                          const uint32_t *__restrict__ sel,
@@ -1132,10 +1169,16 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
                                                          uint8_t *__restrict__ desc, int32_t cap,
                                                          int32_t *__restrict__ n_out)
 {
-    const int b = blockIdx.y;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (slot >= cap) return;
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[16][DS_PR * DS_PP];
+    __shared__ uint2 s_momw[31 * 8];
+    __shared__ uint32_t s_pat[256];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int sub = lane & 15, quad = tid >> 4;  // quad 0..15 inside the workgroup = one keypoint
+    for (int i = tid; i < 31 * 8; i += 256) s_momw[i] = c_momw[i];
+    s_pat[tid] = ((const uint32_t *)c_pattern)[tid];
+    __syncthreads();
+
+    const int slot = blockIdx.x * 16 + quad;
     const int nl = plan->nlevels;
     const int32_t *ns = nsel + b * nl;
     int level = -1, idx = slot, total = 0;
@@ -1145,75 +1188,103 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
         if (level < 0) idx -= c;
         total += c;
     }
-    if (slot == 0 && lane == 0) n_out[b] = total;
+    if (slot == 0 && sub == 0) n_out[b] = total;
+    const bool in_cap = slot < cap;
     orbfe_keypoint *kp = kps + (int64_t)b * cap + slot;
     uint8_t *dd = desc + ((int64_t)b * cap + slot) * 32;
-    if (level < 0) {  // zero-fill the padding so the buffers can be all-gathered as they are
-        if (lane < 7) ((uint32_t *)kp)[lane] = 0u;
-        if (lane < 8) ((uint32_t *)dd)[lane] = 0u;
-        return;
+    const bool live = in_cap && level >= 0;
+    if (in_cap && level < 0) {  // zero-fill the padding so the buffers can be all-gathered as they are
+        if (sub < 7) ((uint32_t *)kp)[sub] = 0u;
+        if (sub < 8) ((uint32_t *)dd)[sub] = 0u;
     }
-    const OrbLevel &L = plan->lv[level];
-    const uint32_t key = sel[(int64_t)b * plan->sel_per_frame + L.sel_off + idx];
-    const int x = orb_key_x(key), y = orb_key_y(key);
+    const int lv = live ? level : 0;
+    const OrbLevel &L = plan->lv[lv];
+    uint32_t key = 0;
+    if (live) key = sel[(int64_t)b * plan->sel_per_frame + L.sel_off + idx];
+    // dead quads shadow a valid position so that every lane can run the same loads
+    const int x = live ? orb_key_x(key) : ORBFE_EDGE, y = live ? orb_key_y(key) : ORBFE_EDGE;
     int pitch;
-    const uint8_t *img = level_ptr(fs, L, level, b, &pitch);
-    const uint8_t *center = img + (int64_t)y * pitch + x;
+    const uint8_t *img = level_ptr(fs, L, lv, b, &pitch);
 
-    // ---- IC_Angle: integer moments over the 749-px circular patch (any summation order is exact) ----
-    int m10 = 0, m01 = 0;
+    // ---- A: moments ----
+    int m10 = 0, rs15 = 0, m01 = 0;
     {
-        const int u = (lane & 31) - 15;  // lanes 31 and 63 idle
-        const int half = lane >> 5;
-        for (int v0 = -15; v0 <= 15; v0 += 2) {
-            const int v = v0 + half;
-            if (v <= 15 && (lane & 31) < 31) {
-                const int d = c_umax[v < 0 ? -v : v];
-                if (u >= -d && u <= d) {
-                    const int val = center[v * pitch + u];
-                    m10 += u * val;
-                    m01 += v * val;
-                }
-            }
+        const int k = sub & 7, r0 = sub >> 3;
+        const uint8_t *p = img + (int64_t)(y - 15) * pitch + (x - 15) + 4 * k;
+        uint32_t w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = min(r0 + 2 * i, 30);
+            w[i] = *(const uint32_t *)(p + (int64_t)row * pitch);  // unaligned dword
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int i = 0; i < 16; ++i) {
+            const int row = r0 + 2 * i;
+            if (row <= 30) {
+                const uint2 wt = s_momw[row * 8 + k];
+                const uint32_t a = __builtin_amdgcn_udot4(w[i], wt.x, 0u, false);  // sum (u+15) * I
+                const uint32_t s1 = __builtin_amdgcn_udot4(w[i], wt.y, 0u, false); // sum I
+                m10 += (int)a;
+                rs15 += (int)s1;
+                m01 += (row - 15) * (int)s1;
+            }
+        }
+        m10 -= 15 * rs15;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
             m10 += __shfl_xor(m10, o, 64);
             m01 += __shfl_xor(m01, o, 64);
         }
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- steered BRIEF on the blurred level ----
+    // ---- C: blurred patch -> LDS ----
+    uint8_t *patch = s_patch[quad];
+    {
+        const uint8_t *bp = blur + (int64_t)b * blur_fstride + L.off + (int64_t)(y - 18) * L.pitch + (x - 18);
+#pragma unroll
+        for (int it = 0; it < 24; ++it) {
+            const int f = it * 16 + sub;            // dword index 0 .. 369
+            const int fr = min(f, DS_PR * 10 - 1);
+            const int row = (fr * 6554) >> 16;      // fr / 10 for fr < 16384
+            const int kk = fr - row * 10;
+            const uint32_t v = *(const uint32_t *)(bp + (int64_t)row * L.pitch + 4 * kk);  // unaligned dword
+            if (f < DS_PR * 10) *(uint32_t *)(patch + row * DS_PP + 4 * kk) = v;
+        }
+    }
     float a, bb;
     canon_sincos(angle, &a, &bb);
-    const uint8_t *bc = blur + (int64_t)b * blur_fstride + L.off + (int64_t)y * L.pitch + x;
-    unsigned long long words[4];
+    __syncthreads();
+    uint32_t bits = 0;
+    const uint8_t *pc = patch + 18 * DS_PP + 18;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const signed char *p = &c_pattern[(g * 64 + lane) * 4];
-        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t pt = s_pat[sub * 16 + i];
+        const float x0 = (float)(int8_t)(pt & 0xFF), y0 = (float)(int8_t)((pt >> 8) & 0xFF);
+        const float x1 = (float)(int8_t)((pt >> 16) & 0xFF), y1 = (float)(int8_t)(pt >> 24);
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, bb), __fmul_rn(y0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, bb)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, bb), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, bb)));
-        const int t0 = bc[r0 * L.pitch + c0], t1 = bc[r1 * L.pitch + c1];
-        words[g] = __ballot(t0 < t1);
+        const int t0 = pc[r0 * DS_PP + c0], t1 = pc[r1 * DS_PP + c1];
+        bits |= (uint32_t)(t0 < t1) << i;
     }
-    if (lane < 4) ((unsigned long long *)dd)[lane] = words[lane];
-    if (lane == 0) {
-        float fx = (float)x, fy = (float)y;
-        if (level != 0) {  // pt *= mvScaleFactor[level] (:1104-1110)
-            fx = __fmul_rn(fx, L.scale);
-            fy = __fmul_rn(fy, L.scale);
+    if (live) {
+        ((uint16_t *)dd)[sub] = (uint16_t)bits;
+        if (sub == 0) {
+            float fx = (float)x, fy = (float)y;
+            if (level != 0) {  // pt *= mvScaleFactor[level] (:1104-1110)
+                fx = __fmul_rn(fx, L.scale);
+                fy = __fmul_rn(fy, L.scale);
+            }
+            kp->x = fx;
+            kp->y = fy;
+            kp->size = L.patch_size;
+            kp->angle = angle;
+            kp->response = (float)orb_key_r(key);
+            kp->octave = level;
+            kp->class_id = -1;
         }
-        kp->x = fx;
-        kp->y = fy;
-        kp->size = L.patch_size;
-        kp->angle = angle;
-        kp->response = (float)orb_key_r(key);
-        kp->octave = level;
-        kp->class_id = -1;
     }
 }
 
@@ -1283,7 +1354,7 @@ hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st)
 hipError_t orbk_launch_describe(const OrbLaunch &a, hipStream_t st)
 {
     const FrameSrc fs = make_src(a);
-    dim3 grid((a.cap + 3) / 4, a.nframes);
+    dim3 grid((a.cap + 15) / 16, a.nframes);
     hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, st, a.d_plan, fs, a.d_blur, a.pyr_fstride, a.d_sel,
                        a.d_nsel, a.d_kps, a.d_desc, a.cap, a.d_n_out);
     return hipGetLastError();
