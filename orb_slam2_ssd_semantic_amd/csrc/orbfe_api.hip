@@ -138,7 +138,7 @@ struct orbfe_handle {
     std::vector<OrbTab> tabs;
     DevBuf d_plan, d_cells, d_tabs, d_btiles, d_supers, d_ftiles;
     // per-batch blocks
-    DevBuf d_pyr, d_blur, d_fmap, d_cell_cnt, d_cell_keys, d_cell_off, d_keys, d_knode, d_sel, d_nsel, d_nkeys;
+    DevBuf d_pyr, d_blur, d_skeys, d_scount, d_keys, d_kord, d_knode, d_sel, d_nsel, d_nkeys;
     // host-API staging
     DevBuf d_stage, d_okps, d_odesc, d_on;
     PinBuf h_stage, h_okps, h_odesc, h_on;
@@ -272,6 +272,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             // group it into blocks of cells whose union tile fits the LDS tile of k_fast_cells (141 x 140)
             int ncc = 0;
             for (int k = L.cell0; k < (int)cells.size() && cells[k].y0 == cells[L.cell0].y0; ++k) ++ncc;
+            L.ncc = ncc;
             const int nrr = ncc ? L.ncells / ncc : 0;
             const int cbx = std::max(1, std::min(4, (141 - 6) / L.wcell));
             const int cby = std::max(1, std::min(4, (140 - 6) / L.hcell));
@@ -355,6 +356,11 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         return ORBFE_ERR_ARG;
     }
     P.node_cap = M;
+    for (int l = 0; l < nl; ++l)
+        if (P.lv[l].ncells > M * 16 * 8 || P.lv[l].ncells >= (1 << 20) || P.lv[l].wcell > 63 || P.lv[l].hcell > 63) {
+            orbfe_set_error("level %d: %d FAST cells exceed the quadtree kernel's cell bitmap", l, P.lv[l].ncells);
+            return ORBFE_ERR_SIZE;
+        }
     P.pyr_frame_bytes = off;
     if (tabs.empty()) tabs.resize(1);
     std::vector<OrbTile> btiles;  // blur work list: 256-px x 32-row tiles, large levels first
@@ -404,11 +410,10 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
     const size_t B = (size_t)nframes;
     ORBFE_HIP(h->d_pyr.ensure(B * (size_t)P.pyr_frame_bytes));
     ORBFE_HIP(h->d_blur.ensure(B * (size_t)P.pyr_frame_bytes));
-    ORBFE_HIP(h->d_fmap.ensure(B * (size_t)P.pyr_frame_bytes));
-    ORBFE_HIP(h->d_cell_cnt.ensure(B * P.ncells * sizeof(int32_t)));
-    ORBFE_HIP(h->d_cell_keys.ensure(B * P.ncells * (size_t)P.cell_cap * sizeof(uint32_t)));
-    ORBFE_HIP(h->d_cell_off.ensure(B * P.ncells * sizeof(int32_t)));
+    ORBFE_HIP(h->d_skeys.ensure(B * (size_t)P.keys_per_frame * sizeof(uint2)));
+    ORBFE_HIP(h->d_scount.ensure(B * P.nlevels * ORBFE_NK_STRIDE * sizeof(int32_t)));
     ORBFE_HIP(h->d_keys.ensure(B * (size_t)P.keys_per_frame * sizeof(uint32_t)));
+    ORBFE_HIP(h->d_kord.ensure(B * (size_t)P.keys_per_frame * sizeof(uint32_t)));
     ORBFE_HIP(h->d_knode.ensure(B * (size_t)P.keys_per_frame * sizeof(uint16_t)));
     ORBFE_HIP(h->d_sel.ensure(B * (size_t)P.sel_per_frame * sizeof(uint32_t)));
     ORBFE_HIP(h->d_nsel.ensure(B * P.nlevels * sizeof(int32_t)));
@@ -501,7 +506,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_supers, &h->d_ftiles, &h->d_fmap, &h->d_pyr, &h->d_blur, &h->d_cell_cnt, &h->d_cell_keys, &h->d_cell_off, &h->d_keys, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_supers, &h->d_ftiles, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_keys, &h->d_kord, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
                       &h->d_okps, &h->d_odesc, &h->d_on};
     for (DevBuf *b : bufs) b->release();
     PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
@@ -611,12 +616,11 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.gray_pitch = stride;
     a.d_pyr = (uint8_t *)h->d_pyr.p;
     a.d_blur = (uint8_t *)h->d_blur.p;
-    a.d_fmap = (uint8_t *)h->d_fmap.p;
     a.pyr_fstride = h->plan.pyr_frame_bytes;
-    a.d_cell_cnt = (int32_t *)h->d_cell_cnt.p;
-    a.d_cell_keys = (uint32_t *)h->d_cell_keys.p;
-    a.d_cell_off = (int32_t *)h->d_cell_off.p;
+    a.d_skeys = (uint2 *)h->d_skeys.p;
+    a.d_scount = (int32_t *)h->d_scount.p;
     a.d_keys = (uint32_t *)h->d_keys.p;
+    a.d_kord = (uint32_t *)h->d_kord.p;
     a.d_knode = (uint16_t *)h->d_knode.p;
     a.d_sel = (uint32_t *)h->d_sel.p;
     a.d_nsel = (int32_t *)h->d_nsel.p;
@@ -828,13 +832,20 @@ extern "C" orbfe_status orbfe_tap_candidates(orbfe_handle *h, int32_t frame, int
     if (nk > cap) return ORBFE_ERR_CAP;
     if (nk == 0) return ORBFE_OK;
     if (!xyr) return ORBFE_ERR_ARG;
-    std::vector<uint32_t> kv((size_t)nk);
+    // filtered keys are in arbitrary order; their `ord` is the rank key of the reference's candidate order
+    std::vector<uint32_t> kv((size_t)nk), ko((size_t)nk);
     ORBFE_HIP(hipMemcpy(kv.data(), (uint32_t *)h->d_keys.p + (size_t)frame * P.keys_per_frame + L.key_off,
                         sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(ko.data(), (uint32_t *)h->d_kord.p + (size_t)frame * P.keys_per_frame + L.key_off,
+                        sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost));
+    std::vector<int> order((size_t)nk);
+    for (int i = 0; i < nk; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return ko[a] < ko[b]; });
     for (int i = 0; i < nk; ++i) {
-        xyr[3 * i] = (float)orb_key_x(kv[i]);
-        xyr[3 * i + 1] = (float)orb_key_y(kv[i]);
-        xyr[3 * i + 2] = (float)orb_key_r(kv[i]);
+        const uint32_t k = kv[order[i]];
+        xyr[3 * i] = (float)orb_key_x(k);
+        xyr[3 * i + 1] = (float)orb_key_y(k);
+        xyr[3 * i + 2] = (float)orb_key_r(k);
     }
     return ORBFE_OK;
 }

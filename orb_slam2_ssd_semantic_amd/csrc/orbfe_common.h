@@ -43,6 +43,7 @@ struct OrbLevel {
     int32_t ncols, nrows;  // FAST grid                        (:792-796)
     int32_t wcell, hcell;
     int32_t cell0, ncells; // this level's cells in the frame's cell table (skipped cells removed)
+    int32_t ncc;           // cell columns after the skip rule (cells form an ncells/ncc x ncc grid)
     int32_t nfeat;         // mnFeaturesPerLevel[l]            (:426-439)
     int32_t nini;          // quadtree roots                   (:545)
     float hx;              // root width                       (:547)

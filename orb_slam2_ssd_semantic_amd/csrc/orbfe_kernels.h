@@ -19,12 +19,11 @@ struct OrbLaunch {
     // handle-owned blocks, one slice per frame
     uint8_t *d_pyr;
     uint8_t *d_blur;
-    uint8_t *d_fmap;
     int64_t pyr_fstride;
-    int32_t *d_cell_cnt;
-    uint32_t *d_cell_keys;
-    int32_t *d_cell_off;
-    uint32_t *d_keys;
+    uint2 *d_skeys;      // unordered NMS survivors {key, ord} per level (k_fast_map)
+    int32_t *d_scount;
+    uint32_t *d_keys;    // per level: keys after the per-cell threshold fallback
+    uint32_t *d_kord;
     uint16_t *d_knode;
     uint32_t *d_sel;
     int32_t *d_nsel;

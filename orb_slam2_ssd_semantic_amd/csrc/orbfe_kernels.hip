@@ -229,8 +229,10 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *p /* LDS, pitch 
 //              masks and wave-uniform row flags).  Because iniTh >= minTh, a corner with A > iniTh survives NMS at
 //              iniTh iff it survives at minTh, so ONE survivor map  M = survivor ? A : 0  encodes both of the
 //              reference's lists: {M > iniTh} and, for cells where that is empty, {M > 0}  (:818-825).
-// k_fast_emit  one wave per cell: counts {M > iniTh}, picks the threshold (fallback rule) and writes the cell's
-//              keypoints in raster order (ballot + prefix popcount) into its key slots.
+//              Survivors are appended UNORDERED to the level's list {key, ord}; `ord` is computable from the pixel
+//              position alone and is a rank key of the reference's candidate order (cell-row-major, raster inside
+//              a cell), which is all DistributeOctTree's tie-break needs.  The fallback rule (a cell whose iniTh
+//              list is empty contributes its minTh list) is applied per cell in k_octree's prologue.
 #define FM_RB 64      // output rows per tile
 #define FM_STRIP 248  // output columns per tile (lanes 1..62; lanes 0 and 63 are the NMS halo)
 
@@ -330,19 +332,32 @@ __device__ __forceinline__ uint32_t fast_strength_pair(const uint32_t (&rm3)[3],
     return pk_max_i16(pk_sub_i16(v, minmax), pk_sub_i16(maxmin, v));
 }
 
+__device__ __forceinline__ int lanes_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+
+#define FM_BUF 256  // per-wave LDS staging of survivors before one atomic reserves their run in the level's list
+
 __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ plan, FrameSrc fs,
                                                   const OrbTile *__restrict__ tiles, int ntiles,
-                                                  uint8_t *__restrict__ fmap, int64_t fmap_fstride)
+                                                  uint2 *__restrict__ skeys,      // [B][keys_per_frame] {key, ord}
+                                                  int32_t *__restrict__ scount)   // [B][nlevels] * NK_STRIDE, zeroed
 {
+    __shared__ uint2 s_buf[4][FM_BUF];
     const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wv;
     if (t >= ntiles) return;
     const OrbTile tl = tiles[t];
     const int level = tl.level;
     const OrbLevel &L = plan->lv[level];
     int pitch;
     const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
-    uint8_t *dst = fmap + (int64_t)b * fmap_fstride + L.off;
+    uint2 *slist = skeys + (int64_t)b * plan->keys_per_frame + L.key_off;
+    int32_t *scnt = scount + (b * plan->nlevels + level) * ORBFE_NK_STRIDE;
+    uint2 *sbuf = s_buf[wv];
+    int nbuf = 0;  // wave-uniform fill of sbuf
     const int W = L.w;
     const int ix0 = ORBFE_EDGE, iy0 = ORBFE_EDGE, ix1 = L.ix1, iy1 = L.iy1;
     const int wcell = L.wcell, hcell = L.hcell;
@@ -365,6 +380,16 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
         }
     }
     const bool out_lane = lane >= 1 && lane <= 62 && inside != 0;
+    // per-pixel part of `ord`, the rank key of the reference's candidate order (cell-row-major, raster inside a cell):
+    // ord = (cell_row * ncc + cell_col) << 12 | y_in_cell << 6 | x_in_cell
+    uint32_t ordx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rel = max(x + j - ix0, 0);
+        const int cc = rel / wcell;
+        ordx[j] = ((uint32_t)cc << 12) | (uint32_t)(rel - cc * wcell);
+    }
+    int crow = (ys - iy0) / hcell;  // cell row of the next NMS row (wave-uniform)
     const uint32_t tzz = (uint32_t)tz * 0x00010001u;
     const uint32_t in01 = ((inside & 1) ? 0xFFFFu : 0u) | ((inside & 2) ? 0xFFFF0000u : 0u);
     const uint32_t in23 = ((inside & 4) ? 0xFFFFu : 0u) | ((inside & 8) ? 0xFFFF0000u : 0u);
@@ -418,7 +443,8 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
             const int rn = rc - 1;
             const bool up_ok = rmod != 0;
             const bool dn_ok = (rmod != hcell - 1) && (rn + 1 < iy1);
-            if (++rmod == hcell) rmod = 0;
+            const uint32_t ordy = ((uint32_t)(crow * L.ncc) << 12) | ((uint32_t)rmod << 6);
+            if (++rmod == hcell) { rmod = 0; ++crow; }
             if (rn >= yend) continue;
             const uint32_t ulo = up_ok ? Ulo : 0u, uhi = up_ok ? Uhi : 0u;
             const uint32_t dlo = dn_ok ? Dlo : 0u, dhi = dn_ok ? Dhi : 0u;
@@ -438,118 +464,46 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
             int col[6];
 #pragma unroll
             for (int p = 0; p < 6; ++p) col[p] = max3i(U[p], Mi[p], D[p]);
-            uint32_t packed = 0;
+            int surv[4], cnt = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int lc = (lvalid >> j) & 1 ? col[j] : 0;
                 const int rc2 = (rvalid >> j) & 1 ? col[j + 2] : 0;
                 const int nb = max3i(lc, rc2, max(U[j + 1], D[j + 1]));
                 const int m = Mi[j + 1];
-                packed |= (uint32_t)(m > nb ? m + tz : 0) << (8 * j);
+                surv[j] = (out_lane && m > nb) ? m + tz : 0;  // A of an NMS survivor (cv score = A - 1), else 0
+                cnt += surv[j] != 0;
             }
-            if (out_lane) *(uint32_t *)(dst + (int64_t)rn * L.pitch + x) = packed;
-        }
-    }
-}
-
-// One wave per cell.  The cell interior (iw x ih survivor bytes) is scanned with aligned dword loads: 16 lanes per
-// row (up to 64 px incl. misalignment), 4 rows per iteration, so lane order == raster order.  Non-zero bytes are
-// rare (strict 3x3 NMS): per lane 0..2 of them; their ranks come from two ballots of the count bits.
-__device__ __forceinline__ int lanes_below(unsigned long long m)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-}
-
-#define EMIT_WAVES 4
-__global__ __launch_bounds__(EMIT_WAVES * 64) void k_fast_emit(const OrbPlan *__restrict__ plan, const OrbCell *__restrict__ cells,
-                                                   const uint8_t *__restrict__ fmap, int64_t fmap_fstride,
-                                                   int32_t *__restrict__ cell_cnt,    // [B][ncells]
-                                                   uint32_t *__restrict__ cell_keys)  // [B][ncells][cell_cap]
-{
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int cell_raw = blockIdx.x * EMIT_WAVES + wid;
-    const bool have = cell_raw < plan->ncells;          // wave-uniform
-    const int cell = have ? cell_raw : plan->ncells - 1;
-    const OrbCell c = cells[cell];
-    const OrbLevel &L = plan->lv[c.level];
-    const int iw = have ? (int)c.tw - 6 : 0, ih = have ? (int)c.th - 6 : 0;
-    const bool live = iw > 0 && ih > 0;
-    const int cx0 = c.x0 + 3, cy0 = c.y0 + 3;  // interior origin (level coordinates)
-    const int xa = cx0 & ~3;                    // aligned start
-    const int sub = lane & 15, rsub = lane >> 4;
-    const int gx = xa + 4 * sub;                // level x of this lane's dword
-    // byte k of the dword is inside the cell iff cx0 <= gx + k < cx0 + iw
-    uint32_t bmask = 0;
+            // cnt <= 2 (no two horizontally adjacent survivors): wave prefix from the two count bits
+            const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2);
+            if (b0 | b1) {
+                int k = nbuf + lanes_below(b0) + 2 * lanes_below(b1);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (gx + k >= cx0 && gx + k < cx0 + iw) bmask |= 0xFFu << (8 * k);
-    const uint8_t *base = fmap + (int64_t)b * fmap_fstride + L.off + gx;
-    const int ini = plan->ini_th;
-
-    // all rows of the cell in flight at once (ih <= 60 -> at most 15 iterations of 4 rows).  Loads are
-    // unconditional (clamped addresses, results masked) so that they overlap instead of being waited on one by one.
-    uint32_t wv[15];
-    {
-        const int ndw = max((cx0 + iw - xa + 3) >> 2, 1);
-        const uint8_t *lbase = base - 4 * (sub - min(sub, ndw - 1));
-#pragma unroll
-        for (int i = 0; i < 15; ++i) {
-            const int y = max(min(4 * i + rsub, ih - 1), 0);
-            wv[i] = *(const uint32_t *)(lbase + (int64_t)(cy0 + y) * L.pitch);
-        }
-#pragma unroll
-        for (int i = 0; i < 15; ++i)
-            wv[i] = (4 * i + rsub < ih) ? (wv[i] & bmask) : 0u;
-    }
-    // pass 1: sizes of the iniTh list and of the minTh list (src/ORBextractor.cc:818-825)
-    int c_ini = 0, c_min = 0;
-#pragma unroll
-    for (int i = 0; i < 15; ++i) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int mv = (int)((wv[i] >> (8 * k)) & 0xFF);
-            c_ini += mv > ini;
-            c_min += mv > 0;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        c_ini += __shfl_xor(c_ini, o, 64);
-        c_min += __shfl_xor(c_min, o, 64);
-    }
-    const int thr = c_ini > 0 ? ini : 0;
-    const int ncell = live ? (c_ini > 0 ? c_ini : c_min) : 0;
-    if (!have) return;
-    if (lane == 0) cell_cnt[(int64_t)b * plan->ncells + cell] = ncell;
-    if (ncell == 0) return;
-    uint32_t *dstk = cell_keys + ((int64_t)b * plan->ncells + cell) * plan->cell_cap;
-
-    // pass 2: ordered emission
-    int total = 0;
-#pragma unroll
-    for (int i = 0; i < 15; ++i) {
-        if (4 * i >= ih) break;  // wave-uniform
-        const int y = 4 * i + rsub;
-        int m[4], cnt = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            m[k] = (int)((wv[i] >> (8 * k)) & 0xFF);
-            if (m[k] <= thr) m[k] = 0;
-            cnt += m[k] != 0;
-        }
-        // cnt <= 2 (no two horizontally adjacent survivors); exclusive prefix over lanes from the two count bits
-        const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2);
-        if (b0 | b1) {
-            int k = total + lanes_below(b0) + 2 * lanes_below(b1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (m[j]) {
-                    // detection-window coordinates (level - 16) == tile-relative + j*wCell of the reference (:831-832)
-                    dstk[k] = orb_pack_key(gx + j - ORBFE_MINB, cy0 + y - ORBFE_MINB, m[j] - 1);
-                    ++k;
+                for (int j = 0; j < 4; ++j)
+                    if (surv[j]) {
+                        // detection-window coordinates (level - 16) == tile-relative + j*wCell of the reference (:831-832)
+                        sbuf[k] = make_uint2(orb_pack_key(x + j - ORBFE_MINB, rn - ORBFE_MINB, surv[j] - 1),
+                                             ordy + ordx[j]);
+                        ++k;
+                    }
+                nbuf += __popcll(b0) + 2 * __popcll(b1);
+                if (nbuf > FM_BUF - 128) {  // a row adds at most 124: flush before the next one could overflow
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(scnt, nbuf);
+                    base = __shfl(base, 0, 64);
+                    for (int i = lane; i < nbuf; i += 64)
+                        if (base + i < L.key_cap) slist[base + i] = sbuf[i];
+                    nbuf = 0;
                 }
-            total += __popcll(b0) + 2 * __popcll(b1);
+            }
         }
+    }
+    if (nbuf > 0) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(scnt, nbuf);
+        base = __shfl(base, 0, 64);
+        for (int i = lane; i < nbuf; i += 64)
+            if (base + i < L.key_cap) slist[base + i] = sbuf[i];
     }
 }
 
@@ -571,10 +525,10 @@ __global__ __launch_bounds__(EMIT_WAVES * 64) void k_fast_emit(const OrbPlan *__
 //
 // Structure of one pass:  [all waves] one streaming loop over the keys (map the key to its node of the current
 // list, classify into a quadrant, count)  ->  [wave 0 alone, wave-synchronous, no barriers] all node-level
-// bookkeeping (<= node_cap entries).  Keys arrive in arbitrary cell order from k_fast_emit; each carries `ord`,
+// bookkeeping (<= node_cap entries).  Keys arrive in arbitrary order from k_fast_map; each carries `ord`,
 // its rank in the reference's candidate order, which is all the tie-break needs.
 // ---------------------------------------------------------------------------------------------------
-#define QT_MAX 1024
+#define QT_MAX 512
 #define KNODE_MASK 0x3FFFu
 #define KUNROLL 4
 
@@ -657,10 +611,10 @@ __device__ __forceinline__ int qt_follow(const QtShared &q, uint32_t kn)
 }
 
 __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ plan,
-                                               const int32_t *__restrict__ cell_cnt,   // [B][ncells]
-                                               const uint32_t *__restrict__ cell_keys, // [B][ncells][cell_cap]
-                                               int32_t *__restrict__ cell_off,      // [B][ncells] scratch
-                                               uint32_t *__restrict__ keys,         // [B][keys_per_frame] scratch
+                                               const uint2 *__restrict__ skeys,     // [B][keys_per_frame] {key, ord} from k_fast_map
+                                               const int32_t *__restrict__ scount,  // [B][nlevels] * NK_STRIDE
+                                               uint32_t *__restrict__ keys,         // [B][keys_per_frame] scratch: filtered keys
+                                               uint32_t *__restrict__ kord,         // [B][keys_per_frame] scratch: their ord
                                                uint16_t *__restrict__ knode,        // [B][keys_per_frame] scratch
                                                int32_t *__restrict__ nkeys,         // [B][nlevels] out (taps)
                                                uint32_t *__restrict__ sel,          // [B][sel_per_frame] out
@@ -669,60 +623,66 @@ __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ p
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int QT = blockDim.x;  // 256 .. 1024 (launch-time choice)
+    const int QT = blockDim.x;  // 256 .. 512 (launch-time choice)
     const OrbLevel &L = plan->lv[level];
     const int M = plan->node_cap;
     const int N = L.nfeat;
     QtShared q;
     qt_carve(smem, M, q);
     int32_t *misc = q.misc;
+    const uint2 *SK = skeys + (int64_t)b * plan->keys_per_frame + L.key_off;
     uint32_t *K = keys + (int64_t)b * plan->keys_per_frame + L.key_off;
+    uint32_t *KO = kord + (int64_t)b * plan->keys_per_frame + L.key_off;
     uint16_t *KN = knode + (int64_t)b * plan->keys_per_frame + L.key_off;
 
-    // ---- prologue: compact this level's per-cell key slots into the reference candidate order ----
-    __shared__ int s_wave[17];
-    const int32_t *ccnt = cell_cnt + (int64_t)b * plan->ncells + L.cell0;
-    int32_t *coff = cell_off + (int64_t)b * plan->ncells + L.cell0;
-    int n = 0;
-    for (int c0 = 0; c0 < L.ncells; c0 += QT) {
-        const int c = c0 + tid;
-        const int v = c < L.ncells ? ccnt[c] : 0;
-        int tot;
-        const int ex = block_excl_scan(v, s_wave, &tot);
-        if (c < L.ncells) coff[c] = n + ex;
-        n += tot;
+    // ---- prologue: the reference's per-cell threshold fallback (:818-825) on the unordered survivor list ----
+    // A cell contributes {A > iniTh} if that is non-empty, else all its NMS survivors ({A > minTh}).
+    const int ns = min(scount[(b * plan->nlevels + level) * ORBFE_NK_STRIDE], L.key_cap);
+    uint32_t *cflag = (uint32_t *)q.cc;  // bitmap over this level's cells (M*16 bytes >= ncells/8 checked on the host)
+    const int nwords = (L.ncells + 31) >> 5;
+    for (int i = tid; i < nwords; i += QT) cflag[i] = 0u;
+    if (tid == 0) misc[5] = 0;
+    __syncthreads();
+    const int ini = plan->ini_th;
+    for (int k0 = tid; k0 < ns; k0 += QT * KUNROLL) {
+        uint2 e[KUNROLL];
+#pragma unroll
+        for (int u = 0; u < KUNROLL; ++u) e[u] = SK[min(k0 + u * QT, ns - 1)];
+#pragma unroll
+        for (int u = 0; u < KUNROLL; ++u)
+            if (k0 + u * QT < ns && orb_key_r(e[u].x) >= ini) {  // cv score = A - 1 >= iniTh  <=>  A > iniTh
+                const uint32_t cell = e[u].y >> 12;
+                atomicOr(&cflag[cell >> 5], 1u << (cell & 31));
+            }
     }
     __syncthreads();
-    for (int c0 = wid; c0 < L.ncells; c0 += 4 * (QT / 64)) {  // 4 cells per wave in flight
-        int cn[4], co[4];
+    for (int k0 = 0; k0 < ns; k0 += QT * KUNROLL) {
+        uint2 e[KUNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = min(c0 + u * (QT / 64), L.ncells - 1);
-            cn[u] = (c0 + u * (QT / 64) < L.ncells) ? ccnt[c] : 0;
-            co[u] = coff[c];
-        }
-        uint32_t v0[4], v1[4];
+        for (int u = 0; u < KUNROLL; ++u) e[u] = SK[min(k0 + u * QT + tid, ns - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = min(c0 + u * (QT / 64), L.ncells - 1);
-            const uint32_t *src = cell_keys + ((int64_t)b * plan->ncells + L.cell0 + c) * plan->cell_cap;
-            v0[u] = lane < cn[u] ? src[lane] : 0u;
-            v1[u] = lane + 64 < cn[u] ? src[lane + 64] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (lane < cn[u]) K[co[u] + lane] = v0[u];
-            if (lane + 64 < cn[u]) K[co[u] + lane + 64] = v1[u];
-            if (cn[u] > 128) {
-                const int c = c0 + u * (QT / 64);
-                const uint32_t *src = cell_keys + ((int64_t)b * plan->ncells + L.cell0 + c) * plan->cell_cap;
-                for (int k = 128 + lane; k < cn[u]; k += 64) K[co[u] + k] = src[k];
+        for (int u = 0; u < KUNROLL; ++u) {
+            const int k = k0 + u * QT + tid;
+            bool keep = false;
+            if (k < ns) {
+                const uint32_t cell = e[u].y >> 12;
+                keep = orb_key_r(e[u].x) >= ini || !((cflag[cell >> 5] >> (cell & 31)) & 1u);
+            }
+            const unsigned long long bal = __ballot(keep);
+            int base = 0;
+            if (lane == 0 && bal) base = atomicAdd(&misc[5], __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (keep) {
+                const int o = base + lanes_below(bal);
+                K[o] = e[u].x;
+                KO[o] = e[u].y;
             }
         }
     }
+    __syncthreads();
+    const int n = misc[5];
     if (tid == 0) nkeys[(b * plan->nlevels + level) * ORBFE_NK_STRIDE] = n;
     __syncthreads();
-    if (plan->dbg == 10) return;
 
     // ---- roots (:545-587): nini boxes, keys by (int)(x / hX), empty roots erased ----
     const int nini = L.nini;
@@ -960,15 +920,18 @@ __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ p
     __syncthreads();
     for (int k = tid; k < n; k += QT) {
         const int i = qt_follow(q, KN[k]);
-        atomicMax(&best[i], ((unsigned long long)orb_key_r(K[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)k));
+        KN[k] = (uint16_t)i;
+        atomicMax(&best[i], ((unsigned long long)orb_key_r(K[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - KO[k]));
     }
     __syncthreads();
     uint32_t *out = sel + (int64_t)b * plan->sel_per_frame + L.sel_off;
     const int nout = min(S, L.sel_cap);
-    for (int i = tid; i < nout; i += QT) {
-        const uint32_t key = K[0xFFFFFFFFu - (uint32_t)(best[i] & 0xFFFFFFFFull)];
-        // + minBorderX / minBorderY (:853-854): level coordinates from here on
-        out[i] = orb_pack_key(orb_key_x(key) + ORBFE_MINB, orb_key_y(key) + ORBFE_MINB, orb_key_r(key));
+    for (int k = tid; k < n; k += QT) {
+        const int i = KN[k];
+        const uint32_t key = K[k];
+        if (i < nout && best[i] == (((unsigned long long)orb_key_r(key) << 32) | (unsigned long long)(0xFFFFFFFFu - KO[k])))
+            // + minBorderX / minBorderY (:853-854): level coordinates from here on
+            out[i] = orb_pack_key(orb_key_x(key) + ORBFE_MINB, orb_key_y(key) + ORBFE_MINB, orb_key_r(key));
     }
     if (tid == 0) nsel[b * plan->nlevels + level] = nout;
 }
@@ -1317,12 +1280,11 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
 hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
 {
     const FrameSrc fs = make_src(a);
+    hipError_t e = hipMemsetAsync(a.d_scount, 0, sizeof(int32_t) * (size_t)a.nframes * a.h_plan->nlevels * ORBFE_NK_STRIDE, st);
+    if (e != hipSuccess) return e;
     dim3 grid((a.h_plan->nftiles + 3) / 4, a.nframes);
-    hipLaunchKernelGGL(k_fast_map, grid, dim3(256), 0, st, a.d_plan, fs, a.d_ftiles, a.h_plan->nftiles, a.d_fmap,
-                       a.pyr_fstride);
-    dim3 grid2((a.h_plan->ncells + 3) / 4, a.nframes);
-    hipLaunchKernelGGL(k_fast_emit, grid2, dim3(256), 0, st, a.d_plan, a.d_cells, a.d_fmap, a.pyr_fstride, a.d_cell_cnt,
-                       a.d_cell_keys);
+    hipLaunchKernelGGL(k_fast_map, grid, dim3(256), 0, st, a.d_plan, fs, a.d_ftiles, a.h_plan->nftiles, a.d_skeys,
+                       a.d_scount);
     return hipGetLastError();
 }
 
@@ -1331,8 +1293,8 @@ hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
     dim3 grid(a.h_plan->nlevels, a.nframes);
     const size_t lds = orbk_octree_lds_bytes(a.h_plan->node_cap);
     static const int qt = getenv("ORBFE_QT") ? atoi(getenv("ORBFE_QT")) : 512;
-    hipLaunchKernelGGL(k_octree, grid, dim3(qt), lds, st, a.d_plan, a.d_cell_cnt, a.d_cell_keys, a.d_cell_off, a.d_keys,
-                       a.d_knode, a.d_nkeys, a.d_sel, a.d_nsel);
+    hipLaunchKernelGGL(k_octree, grid, dim3(qt), lds, st, a.d_plan, a.d_skeys, a.d_scount, a.d_keys, a.d_kord, a.d_knode,
+                       a.d_nkeys, a.d_sel, a.d_nsel);
     return hipGetLastError();
 }
 
