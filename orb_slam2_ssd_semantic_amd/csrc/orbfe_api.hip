@@ -136,7 +136,7 @@ struct orbfe_handle {
     bool plan_valid = false;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
-    DevBuf d_plan, d_cells, d_tabs, d_btiles, d_supers, d_ftiles;
+    DevBuf d_plan, d_cells, d_tabs, d_btiles, d_supers, d_ftiles, d_flanes;
     // per-batch blocks
     DevBuf d_pyr, d_blur, d_skeys, d_scount, d_keys, d_kord, d_knode, d_sel, d_nsel, d_nkeys;
     // host-API staging
@@ -377,6 +377,63 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     P.nbtiles = (int)btiles.size();
     P.nsupers = (int)supers.size();
     P.nftiles = (int)ftiles.size();
+    // FAST lane list: per level, per (balanced) row block of <= 64 rows, the 4-px columns x = 16, 20, ... < ix1 form a
+    // strip; strips are packed back to back into single-level waves of 64 lanes.  Where a wave boundary falls inside a
+    // strip, each side gets one halo lane (computes neighbour strengths, outputs nothing).
+    std::vector<OrbLane> flanes;
+    {
+        std::vector<OrbLane> stream;
+        for (int l = 0; l < nl; ++l) {
+            const OrbLevel &L = P.lv[l];
+            const int rows = L.iy1 - ORBFE_EDGE, ncol = (L.ix1 - 16 + 3) / 4;
+            if (rows <= 0 || ncol <= 0) continue;
+            const int nblk = (rows + 63) / 64, rb = (rows + nblk - 1) / nblk;
+            for (int k = 0; k < nblk; ++k) {
+                const int ys = ORBFE_EDGE + k * rb, nr = std::min(rb, L.iy1 - ys);
+                for (int c = 0; c < ncol && nr > 0; ++c) {
+                    OrbLane ln;
+                    ln.x = (uint16_t)(16 + 4 * c);
+                    ln.ys = (uint16_t)ys;
+                    ln.nrows = (uint16_t)nr;
+                    ln.flags = (uint16_t)(l << 8);
+                    stream.push_back(ln);
+                }
+            }
+        }
+        auto same_strip = [](const OrbLane &a, const OrbLane &b2) {
+            return (a.flags >> 8) == (b2.flags >> 8) && a.ys == b2.ys && b2.x == a.x + 4;
+        };
+        size_t i = 0;
+        while (i < stream.size()) {
+            const int lvl = stream[i].flags >> 8;
+            const size_t w0 = flanes.size();
+            if (i > 0 && same_strip(stream[i - 1], stream[i])) {  // continuing a cut strip: left halo first
+                OrbLane hl = stream[i - 1];
+                hl.flags |= 1;
+                flanes.push_back(hl);
+            }
+            while (i < stream.size() && (stream[i].flags >> 8) == lvl && flanes.size() - w0 < 64) {
+                const bool more = i + 1 < stream.size() && same_strip(stream[i], stream[i + 1]);
+                if (flanes.size() - w0 == 63 && more) {  // last slot and the strip goes on: right halo, lane moves on
+                    OrbLane hr = stream[i];
+                    hr.flags |= 1;
+                    flanes.push_back(hr);
+                    break;
+                }
+                flanes.push_back(stream[i]);
+                ++i;
+            }
+            while (flanes.size() - w0 < 64) {  // dead lanes
+                OrbLane d;
+                d.x = 16;
+                d.ys = ORBFE_EDGE;
+                d.nrows = 0;
+                d.flags = (uint16_t)((lvl << 8) | 1);
+                flanes.push_back(d);
+            }
+        }
+    }
+    P.nfwaves = (int)(flanes.size() / 64);
     if (P.ini_th < P.min_th) {
         orbfe_set_error("iniThFAST (%d) must be >= minThFAST (%d)", P.ini_th, P.min_th);
         return ORBFE_ERR_ARG;
@@ -388,6 +445,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(h->d_btiles.ensure(btiles.size() * sizeof(OrbTile)));
     ORBFE_HIP(h->d_supers.ensure(supers.size() * sizeof(OrbSuper)));
     ORBFE_HIP(h->d_ftiles.ensure(ftiles.size() * sizeof(OrbTile)));
+    ORBFE_HIP(h->d_flanes.ensure(std::max<size_t>(flanes.size(), 1) * sizeof(OrbLane)));
     // synchronous copies: plans change rarely (frame size change), never inside the timed region
     ORBFE_HIP(hipStreamSynchronize(h->stream));
     ORBFE_HIP(hipMemcpy(h->d_plan.p, &P, sizeof(OrbPlan), hipMemcpyHostToDevice));
@@ -396,6 +454,8 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(hipMemcpy(h->d_btiles.p, btiles.data(), btiles.size() * sizeof(OrbTile), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_supers.p, supers.data(), supers.size() * sizeof(OrbSuper), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_ftiles.p, ftiles.data(), ftiles.size() * sizeof(OrbTile), hipMemcpyHostToDevice));
+    if (!flanes.empty())
+        ORBFE_HIP(hipMemcpy(h->d_flanes.p, flanes.data(), flanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     ORBFE_HIP(orbk_prepare_octree(M));
     h->plan = P;
     h->cells.swap(cells);
@@ -506,7 +566,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_supers, &h->d_ftiles, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_keys, &h->d_kord, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_supers, &h->d_ftiles, &h->d_flanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_keys, &h->d_kord, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
                       &h->d_okps, &h->d_odesc, &h->d_on};
     for (DevBuf *b : bufs) b->release();
     PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
@@ -610,6 +670,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_btiles = (const OrbTile *)h->d_btiles.p;
     a.d_supers = (const OrbSuper *)h->d_supers.p;
     a.d_ftiles = (const OrbTile *)h->d_ftiles.p;
+    a.d_flanes = (const OrbLane *)h->d_flanes.p;
     a.nframes = nframes;
     a.d_gray = d_gray;
     a.gray_fstride = (int64_t)frame_stride;

@@ -86,6 +86,12 @@ struct OrbSuper {
     int32_t cstride;    // cell-table stride between cell rows of this level
 };
 
+// one lane of a streaming image pass: a 4-pixel column walked down `nrows` rows
+struct OrbLane {
+    uint16_t x, ys, nrows;
+    uint16_t flags;  // bit 0: halo (computes, does not output); bits 8..15: level
+};
+
 // work tile of a per-level image pass (blur): origin in level coordinates
 struct OrbTile {
     uint16_t level, x0, y0, pad;
@@ -103,7 +109,8 @@ struct OrbPlan {
     int32_t blur_rounding;
     int32_t dbg;               // developer knob (ORBFE_DEBUG env): early-outs for phase timing, 0 in production
     int32_t nsupers;           // FAST super-cells per frame (v2 kernel, unused by v3)
-    int32_t nftiles;           // FAST map tiles per frame (248 px x 64 rows, one wave each)
+    int32_t nftiles;           // (unused)
+    int32_t nfwaves;           // FAST waves per frame (64 lane descriptors each)
     int32_t nbtiles;           // blur tiles per frame (256 px x 32 rows, one wave each)
     int64_t pyr_frame_bytes;   // bytes of one frame's pyramid slice (levels 1..n-1; level 0 kept too when owned)
     OrbLevel lv[ORBFE_MAX_LEVELS];

@@ -11,6 +11,7 @@ struct OrbLaunch {
     const OrbTile *d_btiles;
     const OrbSuper *d_supers;
     const OrbTile *d_ftiles;
+    const OrbLane *d_flanes;
     int32_t nframes;
     // input frames (level 0, read in place)
     const uint8_t *d_gray;

@@ -340,7 +340,7 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
 #define FM_BUF 256  // per-wave LDS staging of survivors before one atomic reserves their run in the level's list
 
 __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ plan, FrameSrc fs,
-                                                  const OrbTile *__restrict__ tiles, int ntiles,
+                                                  const OrbLane *__restrict__ lanes, int nwaves,
                                                   uint2 *__restrict__ skeys,      // [B][keys_per_frame] {key, ord}
                                                   int32_t *__restrict__ scount)   // [B][nlevels] * NK_STRIDE, zeroed
 {
@@ -348,9 +348,12 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int t = blockIdx.x * 4 + wv;
-    if (t >= ntiles) return;
-    const OrbTile tl = tiles[t];
-    const int level = tl.level;
+    if (t >= nwaves) return;
+    // Work is described per LANE: a 4-pixel column, a run of rows, "halo" (contributes neighbour strengths only).
+    // The host packs the column strips of all row blocks of one level back to back into 64-lane waves, so narrow
+    // levels do not leave lanes idle; neighbouring lanes are neighbouring columns inside one strip.
+    const OrbLane ld = lanes[(int64_t)t * 64 + lane];
+    const int level = __builtin_amdgcn_readfirstlane((int)(ld.flags >> 8));
     const OrbLevel &L = plan->lv[level];
     int pitch;
     const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
@@ -358,12 +361,16 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
     int32_t *scnt = scount + (b * plan->nlevels + level) * ORBFE_NK_STRIDE;
     uint2 *sbuf = s_buf[wv];
     int nbuf = 0;  // wave-uniform fill of sbuf
-    const int W = L.w;
+    const int W = L.w, H = L.h;
     const int ix0 = ORBFE_EDGE, iy0 = ORBFE_EDGE, ix1 = L.ix1, iy1 = L.iy1;
     const int wcell = L.wcell, hcell = L.hcell;
-    const int x = tl.x0 - 4 + lane * 4;  // first pixel of this lane
-    const int ys = tl.y0;
-    const int yend = min(ys + FM_RB, iy1);  // output rows [ys, yend)
+    const int x = ld.x;                 // first pixel of this lane
+    const int ys = ld.ys;
+    const int yend = ys + ld.nrows;     // output rows [ys, yend) of this lane
+    int nsteps = ld.nrows;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
+    nsteps += 8;                        // wave-uniform
     const bool loadable = x < W;
     const int tz = max(plan->min_th, 1);
 
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
             if (m != wcell - 1 && xx + 1 < ix1) rvalid |= 1 << j;
         }
     }
-    const bool out_lane = lane >= 1 && lane <= 62 && inside != 0;
+    const bool out_lane = !(ld.flags & 1) && inside != 0;
     // per-pixel part of `ord`, the rank key of the reference's candidate order (cell-row-major, raster inside a cell):
     // ord = (cell_row * ncc + cell_col) << 12 | y_in_cell << 6 | x_in_cell
     uint32_t ordx[4];
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
         const int cc = rel / wcell;
         ordx[j] = ((uint32_t)cc << 12) | (uint32_t)(rel - cc * wcell);
     }
-    int crow = (ys - iy0) / hcell;  // cell row of the next NMS row (wave-uniform)
+    int crow = (ys - iy0) / hcell;  // cell row of the next NMS row (per lane)
     const uint32_t tzz = (uint32_t)tz * 0x00010001u;
     const uint32_t in01 = ((inside & 1) ? 0xFFFFu : 0u) | ((inside & 2) ? 0xFFFF0000u : 0u);
     const uint32_t in23 = ((inside & 4) ? 0xFFFFu : 0u) | ((inside & 8) ? 0xFFFF0000u : 0u);
@@ -399,16 +406,16 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
     for (int k = 0; k < 7; ++k) R[k][0] = R[k][1] = R[k][2] = 0u;
     // E windows of the last three strength rows: lo = [E(x-1), E0, E1, E2], hi = [E3, E(x+4)]
     uint32_t Ulo = 0, Uhi = 0, Mlo = 0, Mhi = 0, Dlo = 0, Dhi = 0;
-    int rmod = (ys - iy0) % hcell;  // (rn - iy0) % hcell of the next NMS row
+    int rmod = (ys - iy0) % hcell;  // (rn - iy0) % hcell of the next NMS row (per lane)
 
-    for (int s0 = 0; s0 < FM_RB + 8; s0 += 7) {
+    for (int s0 = 0; s0 < nsteps; s0 += 7) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int s = s0 + k;
-            const int r = ys - 4 + s;  // image row loaded in this step
-            if (r > yend + 3) break;   // wave-uniform
+            if (s >= nsteps) break;    // wave-uniform
+            const int r = ys - 4 + s;  // image row loaded in this step (lanes past their run re-read a valid row)
             if (loadable) {
-                const uint8_t *row = src + (int64_t)r * pitch + x;
+                const uint8_t *row = src + (int64_t)min(r, H - 1) * pitch + x;
                 R[k][0] = *(const uint32_t *)(row - 4);
                 R[k][1] = *(const uint32_t *)(row);
                 R[k][2] = *(const uint32_t *)(row + 4);
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
             // ---- strength row rc = r - 3 (newest ring slot k is row rc+3, slot (k+1)%7 is row rc-3) ----
             const int rc = r - 3;
             uint32_t e = 0;
-            if (rc >= iy0 && rc < iy1) {
+            {
                 const uint32_t(&rm3)[3] = R[(k + 1) % 7];
                 const uint32_t(&rm2)[3] = R[(k + 2) % 7];
                 const uint32_t(&rm1)[3] = R[(k + 3) % 7];
@@ -431,6 +438,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
                 const uint32_t s01 = pk_subsat_u16(a01, tzz) & in01;
                 const uint32_t s23 = pk_subsat_u16(a23, tzz) & in23;
                 e = __builtin_amdgcn_perm(s23, s01, 0x06040200u);  // bytes [S0, S1, S2, S3]
+                if (rc < iy0 || rc >= iy1) e = 0u;
             }
             const uint32_t eL = (uint32_t)__shfl_up((int)e, 1, 64);
             const uint32_t eR = (uint32_t)__shfl_down((int)e, 1, 64);
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
             const bool dn_ok = (rmod != hcell - 1) && (rn + 1 < iy1);
             const uint32_t ordy = ((uint32_t)(crow * L.ncc) << 12) | ((uint32_t)rmod << 6);
             if (++rmod == hcell) { rmod = 0; ++crow; }
-            if (rn >= yend) continue;
+            const bool row_out = rn < yend;  // per lane
             const uint32_t ulo = up_ok ? Ulo : 0u, uhi = up_ok ? Uhi : 0u;
             const uint32_t dlo = dn_ok ? Dlo : 0u, dhi = dn_ok ? Dhi : 0u;
             int U[6], Mi[6], D[6];
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
                 const int rc2 = (rvalid >> j) & 1 ? col[j + 2] : 0;
                 const int nb = max3i(lc, rc2, max(U[j + 1], D[j + 1]));
                 const int m = Mi[j + 1];
-                surv[j] = (out_lane && m > nb) ? m + tz : 0;  // A of an NMS survivor (cv score = A - 1), else 0
+                surv[j] = (out_lane && row_out && m > nb) ? m + tz : 0;  // A of an NMS survivor (cv score = A - 1), else 0
                 cnt += surv[j] != 0;
             }
             // cnt <= 2 (no two horizontally adjacent survivors): wave prefix from the two count bits
@@ -1282,8 +1290,8 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
     const FrameSrc fs = make_src(a);
     hipError_t e = hipMemsetAsync(a.d_scount, 0, sizeof(int32_t) * (size_t)a.nframes * a.h_plan->nlevels * ORBFE_NK_STRIDE, st);
     if (e != hipSuccess) return e;
-    dim3 grid((a.h_plan->nftiles + 3) / 4, a.nframes);
-    hipLaunchKernelGGL(k_fast_map, grid, dim3(256), 0, st, a.d_plan, fs, a.d_ftiles, a.h_plan->nftiles, a.d_skeys,
+    dim3 grid((a.h_plan->nfwaves + 3) / 4, a.nframes);
+    hipLaunchKernelGGL(k_fast_map, grid, dim3(256), 0, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
                        a.d_scount);
     return hipGetLastError();
 }
