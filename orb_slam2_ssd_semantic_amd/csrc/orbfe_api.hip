@@ -136,7 +136,7 @@ struct orbfe_handle {
     bool plan_valid = false;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
-    DevBuf d_plan, d_cells, d_tabs, d_btiles, d_supers, d_ftiles, d_flanes;
+    DevBuf d_plan, d_cells, d_tabs, d_btiles, d_supers, d_ftiles, d_flanes, d_blanes;
     // per-batch blocks
     DevBuf d_pyr, d_blur, d_skeys, d_scount, d_keys, d_kord, d_knode, d_sel, d_nsel, d_nkeys;
     // host-API staging
@@ -434,6 +434,33 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         }
     }
     P.nfwaves = (int)(flanes.size() / 64);
+    // blur lane list: every 4-px column of every (balanced, <= 64 rows) row block, single-level waves, no halos
+    std::vector<OrbLane> blanes;
+    for (int l = 0; l < nl; ++l) {
+        const OrbLevel &L = P.lv[l];
+        if (L.w < 16) { orbfe_set_error("level %d too narrow for the blur kernel", l); return ORBFE_ERR_SIZE; }
+        const int ncol = (L.w + 3) / 4, nblk = (L.h + 63) / 64, rb = (L.h + nblk - 1) / nblk;
+        for (int k = 0; k < nblk; ++k) {
+            const int ys = k * rb, nr = std::min(rb, L.h - ys);
+            for (int c = 0; c < ncol && nr > 0; ++c) {
+                OrbLane ln;
+                ln.x = (uint16_t)(4 * c);
+                ln.ys = (uint16_t)ys;
+                ln.nrows = (uint16_t)nr;
+                ln.flags = (uint16_t)(l << 8);
+                blanes.push_back(ln);
+            }
+        }
+        while (blanes.size() % 64) {  // dead lanes: shadow the level's first column, output nothing
+            OrbLane d;
+            d.x = 0;
+            d.ys = 0;
+            d.nrows = 0;
+            d.flags = (uint16_t)((l << 8) | 1);
+            blanes.push_back(d);
+        }
+    }
+    P.nbwaves = (int)(blanes.size() / 64);
     if (P.ini_th < P.min_th) {
         orbfe_set_error("iniThFAST (%d) must be >= minThFAST (%d)", P.ini_th, P.min_th);
         return ORBFE_ERR_ARG;
@@ -446,6 +473,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(h->d_supers.ensure(supers.size() * sizeof(OrbSuper)));
     ORBFE_HIP(h->d_ftiles.ensure(ftiles.size() * sizeof(OrbTile)));
     ORBFE_HIP(h->d_flanes.ensure(std::max<size_t>(flanes.size(), 1) * sizeof(OrbLane)));
+    ORBFE_HIP(h->d_blanes.ensure(std::max<size_t>(blanes.size(), 1) * sizeof(OrbLane)));
     // synchronous copies: plans change rarely (frame size change), never inside the timed region
     ORBFE_HIP(hipStreamSynchronize(h->stream));
     ORBFE_HIP(hipMemcpy(h->d_plan.p, &P, sizeof(OrbPlan), hipMemcpyHostToDevice));
@@ -456,6 +484,8 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(hipMemcpy(h->d_ftiles.p, ftiles.data(), ftiles.size() * sizeof(OrbTile), hipMemcpyHostToDevice));
     if (!flanes.empty())
         ORBFE_HIP(hipMemcpy(h->d_flanes.p, flanes.data(), flanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
+    if (!blanes.empty())
+        ORBFE_HIP(hipMemcpy(h->d_blanes.p, blanes.data(), blanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     ORBFE_HIP(orbk_prepare_octree(M));
     h->plan = P;
     h->cells.swap(cells);
@@ -566,7 +596,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_supers, &h->d_ftiles, &h->d_flanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_keys, &h->d_kord, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_supers, &h->d_ftiles, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_keys, &h->d_kord, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
                       &h->d_okps, &h->d_odesc, &h->d_on};
     for (DevBuf *b : bufs) b->release();
     PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
@@ -671,6 +701,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_supers = (const OrbSuper *)h->d_supers.p;
     a.d_ftiles = (const OrbTile *)h->d_ftiles.p;
     a.d_flanes = (const OrbLane *)h->d_flanes.p;
+    a.d_blanes = (const OrbLane *)h->d_blanes.p;
     a.nframes = nframes;
     a.d_gray = d_gray;
     a.gray_fstride = (int64_t)frame_stride;

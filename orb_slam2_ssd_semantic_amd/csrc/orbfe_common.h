@@ -111,7 +111,8 @@ struct OrbPlan {
     int32_t nsupers;           // FAST super-cells per frame (v2 kernel, unused by v3)
     int32_t nftiles;           // (unused)
     int32_t nfwaves;           // FAST waves per frame (64 lane descriptors each)
-    int32_t nbtiles;           // blur tiles per frame (256 px x 32 rows, one wave each)
+    int32_t nbwaves;           // blur waves per frame (64 lane descriptors each)
+    int32_t nbtiles;           // (unused) (256 px x 32 rows, one wave each)
     int64_t pyr_frame_bytes;   // bytes of one frame's pyramid slice (levels 1..n-1; level 0 kept too when owned)
     OrbLevel lv[ORBFE_MAX_LEVELS];
 };

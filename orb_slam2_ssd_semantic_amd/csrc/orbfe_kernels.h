@@ -12,6 +12,7 @@ struct OrbLaunch {
     const OrbSuper *d_supers;
     const OrbTile *d_ftiles;
     const OrbLane *d_flanes;
+    const OrbLane *d_blanes;
     int32_t nframes;
     // input frames (level 0, read in place)
     const uint8_t *d_gray;

@@ -951,82 +951,110 @@ __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ p
 // (no LDS, no intermediate traffic): per row 3 aligned dword loads (12-byte window), 4 row sums, 4 outputs,
 // one dword store.  Reflected borders: rows by a wave-uniform index, columns by a per-byte path on edge lanes.
 // ---------------------------------------------------------------------------------------------------
-#define BL_RB 32
-
 __device__ __forceinline__ int blur_tap7(int a0, int a1, int a2, int a3, int a4, int a5, int a6)
 {
     return 18 * (a0 + a6) + 34 * (a1 + a5) + 49 * (a2 + a4) + 55 * a3;
 }
 
+// Work is described per LANE (a 4-pixel column, a run of <= 64 rows), packed by the host into single-level waves, so
+// no lane idles on narrow levels.  Column borders are branch-free: every lane loads 3 dwords from a per-lane base that
+// covers all (reflected) source pixels of its 12-byte window and rearranges them with per-lane byte selectors
+// (identity for interior lanes); row borders are a per-lane reflected row index.
 __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
-                                               const OrbTile *__restrict__ tiles, int ntiles,
+                                               const OrbLane *__restrict__ lanes, int nwaves,
                                                uint8_t *__restrict__ blur, int64_t blur_fstride)
 {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= ntiles) return;
-    const OrbTile tl = tiles[t];
-    const int level = tl.level;
+    if (t >= nwaves) return;
+    const OrbLane ld = lanes[(int64_t)t * 64 + lane];
+    const int level = __builtin_amdgcn_readfirstlane((int)(ld.flags >> 8));
     const OrbLevel &L = plan->lv[level];
     int pitch;
     const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
     uint8_t *dst = blur + (int64_t)b * blur_fstride + L.off;
-    const int W = L.w, H = L.h, y0 = tl.y0;
-    const int x = tl.x0 + lane * 4;
-    const bool active = x < W;
-    const bool fast = x >= 4 && x + 8 <= W;
+    const int W = L.w, H = L.h;
+    const int x = ld.x, y0 = ld.ys, yend = y0 + ld.nrows;
+    const bool active = !(ld.flags & 1);
     const int vec_w = W & ~3;
     const int mode = plan->blur_rounding;
-    const int yend = min(y0 + BL_RB, H);
+    int nsteps = ld.nrows;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
+    nsteps += 6;  // wave-uniform
+
+    // window pixel i (0..11) is level column reflect101(x - 4 + i); i = 0 and 11 are never used
+    int srcx[12], lo = W;
+#pragma unroll
+    for (int i = 1; i < 11; ++i) {
+        srcx[i] = reflect101(min(x - 4 + i, W + 2), W);
+        lo = min(lo, srcx[i]);
+    }
+    srcx[0] = srcx[1];
+    srcx[11] = srcx[10];
+    const int base = lo & ~3;  // all ten sources lie in [base, base + 12) (checked on the host for every level width)
+    uint32_t selA[3], selB[3], mskB[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        selA[d] = selB[d] = mskB[d] = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int bi = min(max(srcx[4 * d + k] - base, 0), 11);  // loaded byte index
+            if (bi < 8) selA[d] |= (uint32_t)bi << (8 * k);           // from {w1:w0}
+            else {
+                selB[d] |= (uint32_t)(bi - 8) << (8 * k);             // from w2
+                mskB[d] |= 0xFFu << (8 * k);
+            }
+        }
+    }
+
     int S[7][4];
 #pragma unroll
     for (int k = 0; k < 7; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) S[k][j] = 0;
 
-    for (int s0 = 0; s0 < BL_RB + 6; s0 += 7) {
+    for (int s0 = 0; s0 < nsteps; s0 += 7) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int s = s0 + k;
+            if (s >= nsteps) break;  // wave-uniform
             const int yin = y0 - 3 + s;
-            if (yin > yend + 2) break;  // wave-uniform
             const int yy = reflect101(min(yin, H + 2), H);
-            const uint8_t *row = src + (int64_t)yy * pitch;
-            int px[12];  // pixels x-4 .. x+7
-            if (fast) {
-                const uint32_t w0 = *(const uint32_t *)(row + x - 4);
-                const uint32_t w1 = *(const uint32_t *)(row + x);
-                const uint32_t w2 = *(const uint32_t *)(row + x + 4);
+            const uint8_t *row = src + (int64_t)yy * pitch + base;
+            const uint32_t l0 = *(const uint32_t *)(row);
+            const uint32_t l1 = *(const uint32_t *)(row + 4);
+            const uint32_t l2 = *(const uint32_t *)(row + 8);
+            uint32_t w[3];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    px[i] = (w0 >> (8 * i)) & 0xFF;
-                    px[4 + i] = (w1 >> (8 * i)) & 0xFF;
-                    px[8 + i] = (w2 >> (8 * i)) & 0xFF;
-                }
-            } else if (active) {
+            for (int d = 0; d < 3; ++d) {
+                const uint32_t ta = __builtin_amdgcn_perm(l1, l0, selA[d]);
+                const uint32_t tb = __builtin_amdgcn_perm(l2, l2, selB[d]);
+                w[d] = (tb & mskB[d]) | (ta & ~mskB[d]);
+            }
+            int px[12];
 #pragma unroll
-                for (int i = 1; i < 11; ++i) px[i] = row[reflect101(min(x - 4 + i, W + 2), W)];
-                px[0] = px[11] = 0;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) px[i] = 0;
+            for (int i = 0; i < 4; ++i) {
+                px[i] = (w[0] >> (8 * i)) & 0xFF;
+                px[4 + i] = (w[1] >> (8 * i)) & 0xFF;
+                px[8 + i] = (w[2] >> (8 * i)) & 0xFF;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 S[k][j] = blur_tap7(px[1 + j], px[2 + j], px[3 + j], px[4 + j], px[5 + j], px[6 + j], px[7 + j]);
             if (s >= 6) {
                 const int y = yin - 3;
-                if (y < yend && active) {
-                    uint32_t packed = 0;
+                uint32_t packed = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // newest row sum is slot k (offset +3), oldest is slot (k+1)%7 (offset -3)
-                        const int acc = blur_tap7(S[(k + 1) % 7][j], S[(k + 2) % 7][j], S[(k + 3) % 7][j], S[(k + 4) % 7][j],
-                                                  S[(k + 5) % 7][j], S[(k + 6) % 7][j], S[k][j]);
-                        int v = (acc + 32768) >> 16;
-                        if (mode == 1 && (acc & 0xFFFF) == 0x8000 && (x + j) < vec_w && (v & 1)) v -= 1;
-                        packed |= (uint32_t)min(v, 255) << (8 * j);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    // newest row sum is slot k (offset +3), oldest is slot (k+1)%7 (offset -3)
+                    const int acc = blur_tap7(S[(k + 1) % 7][j], S[(k + 2) % 7][j], S[(k + 3) % 7][j], S[(k + 4) % 7][j],
+                                              S[(k + 5) % 7][j], S[(k + 6) % 7][j], S[k][j]);
+                    int v = (acc + 32768) >> 16;
+                    if (mode == 1 && (acc & 0xFFFF) == 0x8000 && (x + j) < vec_w && (v & 1)) v -= 1;
+                    packed |= (uint32_t)min(v, 255) << (8 * j);
+                }
+                if (active && y < yend) {
                     uint8_t *o = dst + (int64_t)y * L.pitch + x;
                     if (x + 4 <= W) {
                         *(uint32_t *)o = packed;
@@ -1315,8 +1343,8 @@ hipError_t orbk_prepare_octree(int node_cap)
 hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st)
 {
     const FrameSrc fs = make_src(a);
-    dim3 grid((a.h_plan->nbtiles + 3) / 4, a.nframes);
-    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, a.d_plan, fs, a.d_btiles, a.h_plan->nbtiles, a.d_blur,
+    dim3 grid((a.h_plan->nbwaves + 3) / 4, a.nframes);
+    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, a.d_plan, fs, a.d_blanes, a.h_plan->nbwaves, a.d_blur,
                        a.pyr_fstride);
     return hipGetLastError();
 }
