@@ -357,7 +357,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     }
     P.node_cap = M;
     for (int l = 0; l < nl; ++l)
-        if (P.lv[l].ncells > M * 16 * 8 || P.lv[l].ncells >= (1 << 20) || P.lv[l].wcell > 63 || P.lv[l].hcell > 63) {
+        if (P.lv[l].ncells > M * 16 * 8 || P.lv[l].ncells >= (1 << 16) || P.lv[l].wcell > 63 || P.lv[l].hcell > 63) {
             orbfe_set_error("level %d: %d FAST cells exceed the quadtree kernel's cell bitmap", l, P.lv[l].ncells);
             return ORBFE_ERR_SIZE;
         }

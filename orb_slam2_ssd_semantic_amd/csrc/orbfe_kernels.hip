@@ -649,7 +649,9 @@ __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ p
     uint32_t *cflag = (uint32_t *)q.cc;  // bitmap over this level's cells (M*16 bytes >= ncells/8 checked on the host)
     const int nwords = (L.ncells + 31) >> 5;
     for (int i = tid; i < nwords; i += QT) cflag[i] = 0u;
+    if (tid < 8) q.childpos[tid] = 0;
     if (tid == 0) misc[5] = 0;
+    const int nini = L.nini;
     __syncthreads();
     const int ini = plan->ini_th;
     for (int k0 = tid; k0 < ns; k0 += QT * KUNROLL) {
@@ -680,38 +682,27 @@ __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ p
             int base = 0;
             if (lane == 0 && bal) base = atomicAdd(&misc[5], __popcll(bal));
             base = __shfl(base, 0, 64);
+            int r = 0;
             if (keep) {
                 const int o = base + lanes_below(bal);
                 K[o] = e[u].x;
                 KO[o] = e[u].y;
+                // roots (:545-571): key -> root by (int)(x / hX)
+                r = (int)__fdiv_rn((float)orb_key_x(e[u].x), L.hx);
+                r = min(max(r, 0), nini - 1);
+                KN[o] = (uint16_t)r;
             }
+            wave_agg_inc(q.childpos, r, keep, lane);  // root sizes (childpos is free until the first node phase)
         }
     }
     __syncthreads();
     const int n = misc[5];
     if (tid == 0) nkeys[(b * plan->nlevels + level) * ORBFE_NK_STRIDE] = n;
-    __syncthreads();
-
-    // ---- roots (:545-587): nini boxes, keys by (int)(x / hX), empty roots erased ----
-    const int nini = L.nini;
-    if (tid < 8) q.cc[tid] = 0;
-    __syncthreads();
-    for (int k0 = 0; k0 < n; k0 += QT) {
-        const int k = k0 + tid;
-        int r = 0;
-        if (k < n) {
-            const int x = orb_key_x(K[k]);
-            r = (int)__fdiv_rn((float)x, L.hx);
-            r = min(max(r, 0), nini - 1);
-            KN[k] = (uint16_t)r;
-        }
-        wave_agg_inc(q.cc, r, k < n, lane);
-    }
-    __syncthreads();
+    // ---- roots (:545-587): nini boxes, empty roots erased ----
     if (tid == 0) {
         int S0 = 0;
         for (int r = 0; r < nini; ++r) {
-            const int cn = q.cc[r];
+            const int cn = q.childpos[r];
             q.newIdx[r] = S0;  // root r -> list position (unused for empty roots)
             if (cn > 0) {
                 q.box[0][0][S0] = (int16_t)L.root_x[r];
@@ -926,20 +917,33 @@ __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ p
     unsigned long long *best = q.skey;
     for (int i = tid; i < S; i += QT) best[i] = 0ull;
     __syncthreads();
-    for (int k = tid; k < n; k += QT) {
-        const int i = qt_follow(q, KN[k]);
-        KN[k] = (uint16_t)i;
-        atomicMax(&best[i], ((unsigned long long)orb_key_r(K[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - KO[k]));
+    // best = response (8 bit) | inverted ord (28 bit: first in candidate order wins ties) | key index (24 bit)
+    for (int k0 = tid; k0 < n; k0 += QT * KUNROLL) {
+        uint32_t kn[KUNROLL], kv[KUNROLL], ko[KUNROLL];
+#pragma unroll
+        for (int u = 0; u < KUNROLL; ++u) {
+            const int k = min(k0 + u * QT, n - 1);
+            kn[u] = KN[k];
+            kv[u] = K[k];
+            ko[u] = KO[k];
+        }
+#pragma unroll
+        for (int u = 0; u < KUNROLL; ++u) {
+            const int k = k0 + u * QT;
+            if (k < n) {
+                const int i = qt_follow(q, kn[u]);
+                atomicMax(&best[i], ((unsigned long long)orb_key_r(kv[u]) << 52) |
+                                        ((unsigned long long)(0x0FFFFFFFu - ko[u]) << 24) | (unsigned long long)k);
+            }
+        }
     }
     __syncthreads();
     uint32_t *out = sel + (int64_t)b * plan->sel_per_frame + L.sel_off;
     const int nout = min(S, L.sel_cap);
-    for (int k = tid; k < n; k += QT) {
-        const int i = KN[k];
-        const uint32_t key = K[k];
-        if (i < nout && best[i] == (((unsigned long long)orb_key_r(key) << 32) | (unsigned long long)(0xFFFFFFFFu - KO[k])))
-            // + minBorderX / minBorderY (:853-854): level coordinates from here on
-            out[i] = orb_pack_key(orb_key_x(key) + ORBFE_MINB, orb_key_y(key) + ORBFE_MINB, orb_key_r(key));
+    for (int i = tid; i < nout; i += QT) {
+        const uint32_t key = K[(uint32_t)(best[i] & 0xFFFFFFull)];
+        // + minBorderX / minBorderY (:853-854): level coordinates from here on
+        out[i] = orb_pack_key(orb_key_x(key) + ORBFE_MINB, orb_key_y(key) + ORBFE_MINB, orb_key_r(key));
     }
     if (tid == 0) nsel[b * plan->nlevels + level] = nout;
 }
