@@ -356,6 +356,12 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         return ORBFE_ERR_ARG;
     }
     P.node_cap = M;
+    if (orbk_octree_lds_bytes(M, 4) > 160 * 1024) {
+        orbfe_set_error("nfeatures too large: the quadtree of one level (%d nodes) does not fit the 160 KB LDS", max_sel);
+        return ORBFE_ERR_ARG;
+    }
+    P.max_nini = 1;
+    for (int l = 0; l < nl; ++l) P.max_nini = std::max(P.max_nini, P.lv[l].nini);
     for (int l = 0; l < nl; ++l)
         if (P.lv[l].ncells > M * 16 * 8 || P.lv[l].ncells >= (1 << 16) || P.lv[l].wcell > 63 || P.lv[l].hcell > 63) {
             orbfe_set_error("level %d: %d FAST cells exceed the quadtree kernel's cell bitmap", l, P.lv[l].ncells);
@@ -486,7 +492,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         ORBFE_HIP(hipMemcpy(h->d_flanes.p, flanes.data(), flanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     if (!blanes.empty())
         ORBFE_HIP(hipMemcpy(h->d_blanes.p, blanes.data(), blanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
-    ORBFE_HIP(orbk_prepare_octree(M));
+    ORBFE_HIP(orbk_prepare_octree(M, P.max_nini));
     h->plan = P;
     h->cells.swap(cells);
     h->tabs.swap(tabs);

@@ -105,6 +105,7 @@ struct OrbPlan {
     int32_t keys_per_frame;    // key scratch entries per frame
     int32_t sel_per_frame;     // selected-keypoint scratch entries per frame
     int32_t node_cap;          // quadtree node capacity (power of two)
+    int32_t max_nini;          // largest number of quadtree roots over the levels
     int32_t ini_th, min_th;
     int32_t blur_rounding;
     int32_t dbg;               // developer knob (ORBFE_DEBUG env): early-outs for phase timing, 0 in production

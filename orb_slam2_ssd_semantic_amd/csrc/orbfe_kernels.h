@@ -38,8 +38,8 @@ struct OrbLaunch {
 };
 
 hipError_t orbk_upload_constants(const int *umax16);
-size_t orbk_octree_lds_bytes(int node_cap);
-hipError_t orbk_prepare_octree(int node_cap);
+size_t orbk_octree_lds_bytes(int node_cap, int max_nini);
+hipError_t orbk_prepare_octree(int node_cap, int max_nini);
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st);

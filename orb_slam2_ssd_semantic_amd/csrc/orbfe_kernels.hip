@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K3  DistributeOctTree on the device.  One workgroup (4 waves) per (frame, level).
+// K3  DistributeOctTree on the device.  One workgroup per (frame, level).
 //
 // The reference keeps a std::list of nodes: a pass visits nodes in some processing order, replaces each
 // visited node by its non-empty children (push_front in the order n1,n2,n3,n4) and may stop early once
@@ -525,51 +525,63 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
 //     largest-first loop (:678-739)  processing order = (size desc, creation desc), stops at >= N
 // and the list after a pass that processed ranks 0..R-1 is
 //     [children(P[R-1]) n4..n1] ... [children(P[0]) n4..n1]  ++  [unprocessed nodes in old order].
-// Positions therefore follow from prefix sums over the processing order, child membership from
-// per-node quadrant counters (LDS atomics), and the final "first strongest key" from an LDS atomicMax
-// on (response << 32 | ~candidate_order).  Keys never move: each key only carries its node index.
+// Positions therefore follow from prefix sums over the processing order and the final "first strongest key" from an
+// LDS atomicMax on (response | ~candidate_order | key index).  Keys never move.
 // Equal-size ties in the largest-first order are broken by creation order (the reference compares heap
 // addresses there, :686 -- see DESIGN.md "quadtree contract").
 //
-// Structure of one pass:  [all waves] one streaming loop over the keys (map the key to its node of the current
-// list, classify into a quadrant, count)  ->  [wave 0 alone, wave-synchronous, no barriers] all node-level
-// bookkeeping (<= node_cap entries).  Keys arrive in arbitrary order from k_fast_map; each carries `ord`,
-// its rank in the reference's candidate order, which is all the tie-break needs.
+// What a pass needs from the keys is only the number of keys in each child quadrant.  The child boxes are a pure
+// function of the root box (DivideNode halves with ceil, :480-481), so every key's quadrant path is known up front:
+// the prologue computes a 5-level path code per key and a histogram over the 4^5 leaves of every root; quadrant
+// counts of any node down to depth 4 are sums of that histogram.  The first 5 passes -- normally all of them --
+// therefore run as node-level bookkeeping only, by ONE wave, without touching the keys and without barriers.
+// Only trees that must go deeper fall back to streaming key passes (keys then carry their node index).
+// Keys arrive in arbitrary order from k_fast_map; each carries `ord`, its rank in the reference's candidate order.
 // ---------------------------------------------------------------------------------------------------
 #define QT_MAX 512
 #define KNODE_MASK 0x3FFFu
-#define KUNROLL 4
+#define KUNROLL 8
+#define FFD 5               // histogram depth
+#define FF_PER_ROOT 1364    // 4 + 16 + 64 + 256 + 1024
+__host__ __device__ inline int ff_off(int d) { return ((1 << (2 * d)) - 4) / 3; }  // first entry of depth d (1..5)
 
 struct QtShared {
     int16_t *box[2][4];  // ulx, uly, urx, bry
     int32_t *cnt[2];
-    int32_t *cc;        // [M*4] quadrant counts of the current pass
-    int32_t *childpos;  // [M*4] position of child (node, quadrant) in the next list, -1 if empty
-    int32_t *P;         // processing order -> node index
-    int32_t *rankOf;    // node index -> processing rank or -1
-    int32_t *acc;       // inclusive sums over ranks
-    int32_t *newIdx;    // next-list position of an unprocessed node, -1 for a processed one
+    uint32_t *path[2];   // prefix | depth << 12 | root << 16
+    int32_t *cc;         // [M*4] quadrant counts of the current pass
+    int32_t *childpos;   // [M*4] position of child (node, quadrant) in the next list, -1 if empty
+    int32_t *P;          // processing order -> node index
+    int32_t *rankOf;     // node index -> processing rank or -1
+    int32_t *acc;        // inclusive sums over ranks
+    int32_t *newIdx;     // next-list position of an unprocessed node, -1 for a processed one
     unsigned long long *skey;
+    int32_t *hist;       // [nroots * FF_PER_ROOT] quadrant-path histogram, later the path -> node table
     int32_t *misc;
 };
 
-__device__ __forceinline__ void qt_carve(char *base, int M, QtShared &q)
+__device__ __forceinline__ void qt_carve(char *base, int M, int nroots, QtShared &q)
 {
     char *p = base;
     q.skey = (unsigned long long *)p; p += (size_t)M * 8;
     q.cc = (int32_t *)p; p += (size_t)M * 16;
     q.childpos = (int32_t *)p; p += (size_t)M * 16;
     for (int i = 0; i < 2; ++i) { q.cnt[i] = (int32_t *)p; p += (size_t)M * 4; }
+    for (int i = 0; i < 2; ++i) { q.path[i] = (uint32_t *)p; p += (size_t)M * 4; }
     q.P = (int32_t *)p; p += (size_t)M * 4;
     q.rankOf = (int32_t *)p; p += (size_t)M * 4;
     q.acc = (int32_t *)p; p += (size_t)M * 4;
     q.newIdx = (int32_t *)p; p += (size_t)M * 4;
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 4; ++j) { q.box[i][j] = (int16_t *)p; p += (size_t)M * 2; }
+    q.hist = (int32_t *)p; p += (size_t)nroots * FF_PER_ROOT * 4;
     q.misc = (int32_t *)p;
 }
 
-size_t orbk_octree_lds_bytes(int M) { return (size_t)M * (8 + 16 + 16 + 8 + 16 + 16) + 64 * 4; }
+size_t orbk_octree_lds_bytes(int M, int nroots)
+{
+    return (size_t)M * (8 + 16 + 16 + 8 + 8 + 16 + 16) + (size_t)nroots * FF_PER_ROOT * 4 + 64 * 4;
+}
 
 // LDS ordering inside ONE wave: its DS operations execute in order, the fence only keeps the compiler honest
 #define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
@@ -596,8 +608,7 @@ __device__ __forceinline__ int wave_min_i(int v)
     return v;
 }
 
-// counters[idx] += 1 for every active lane, with ONE LDS atomic per distinct idx in the wave: early quadtree passes
-// send thousands of keys to a handful of counters, where per-lane atomics serialise 64-way
+// counters[idx] += 1 for every active lane, with ONE LDS atomic per distinct idx in the wave
 __device__ __forceinline__ void wave_agg_inc(int32_t *counters, int idx, bool active, int lane)
 {
     unsigned long long todo = __ballot(active);
@@ -610,7 +621,7 @@ __device__ __forceinline__ void wave_agg_inc(int32_t *counters, int idx, bool ac
     }
 }
 
-// node of the current list a key belongs to, from its entry of the previous pass (node | quadrant << 14)
+// node of the current list a key belongs to, from its entry of the previous streaming pass (node | quadrant << 14)
 __device__ __forceinline__ int qt_follow(const QtShared &q, uint32_t kn)
 {
     const int i = (int)(kn & KNODE_MASK);
@@ -618,7 +629,156 @@ __device__ __forceinline__ int qt_follow(const QtShared &q, uint32_t kn)
     return ni >= 0 ? ni : q.childpos[i * 4 + (int)(kn >> 14)];
 }
 
-__global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ plan,
+// One generic pass at node level, executed by ONE wave (wave-synchronous, no barriers).
+// In:  q.cc[i*4+qd] for every node i in P (quadrant sizes), list `cur` of size S, processing order P[0..m), rankOf.
+// Out: list `cur^1` (boxes, sizes, paths), the old->new map (newIdx / childpos), next P / rankOf, S, m, modeB, finish.
+__device__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur, int &modeB, bool &finish, int lane)
+{
+    const int nx = cur ^ 1;
+    // non-empty children per processing rank, inclusive sums, stop rank R
+    for (int r = lane; r < m; r += 64) {
+        const int i = q.P[r];
+        q.acc[r] = (q.cc[i * 4] > 0) + (q.cc[i * 4 + 1] > 0) + (q.cc[i * 4 + 2] > 0) + (q.cc[i * 4 + 3] > 0);
+    }
+    WSYNC();
+    wscan_inclusive(q.acc, m, lane);
+    int R = m;
+    if (modeB) {  // first rank whose split brings the list to >= N nodes (:732)
+        int rmin = m;
+        for (int r = lane; r < m; r += 64)
+            if (S + q.acc[r] - (r + 1) >= N) rmin = min(rmin, r + 1);
+        R = wave_min_i(rmin);
+    }
+    const int totalChildren = R > 0 ? q.acc[R - 1] : 0;
+    // unprocessed nodes keep their relative order behind the new children
+    for (int i = lane; i < S; i += 64) {
+        const int r = q.rankOf[i];
+        q.newIdx[i] = (r >= 0 && r < R) ? 0 : 1;
+    }
+    WSYNC();
+    const int nUnproc = wscan_inclusive(q.newIdx, S, lane);
+    const int S2 = totalChildren + nUnproc;
+    // write the next list; leave the old->new map (newIdx / childpos) for whoever follows the keys
+    for (int i = lane; i < S; i += 64) {
+        const int r = q.rankOf[i];
+        const uint32_t pth = q.path[cur][i];
+        if (r >= 0 && r < R) {
+            int pos = totalChildren - q.acc[r];
+            const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
+            const int urx = q.box[cur][2][i], bry = q.box[cur][3][i];
+            const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);  // ceil(w/2) (:480-481)
+            const uint32_t cpath = (pth & 0xFFFF0000u) | ((((pth >> 12) & 0xFu) + 1u) << 12) | ((pth & 0xFFFu) << 2);
+            for (int qd = 3; qd >= 0; --qd) {  // list front holds n4, then n3, n2, n1 (:623-662)
+                const int cn = q.cc[i * 4 + qd];
+                if (cn > 0) {
+                    q.box[nx][0][pos] = (int16_t)((qd & 1) ? midx : ulx);
+                    q.box[nx][1][pos] = (int16_t)((qd & 2) ? midy : uly);
+                    q.box[nx][2][pos] = (int16_t)((qd & 1) ? urx : midx);
+                    q.box[nx][3][pos] = (int16_t)((qd & 2) ? bry : midy);
+                    q.cnt[nx][pos] = cn;
+                    q.path[nx][pos] = cpath | (uint32_t)qd;
+                    q.childpos[i * 4 + qd] = pos;
+                    ++pos;
+                } else {
+                    q.childpos[i * 4 + qd] = -1;
+                }
+            }
+            q.newIdx[i] = -1;
+        } else {
+            const int pos = totalChildren + q.newIdx[i] - 1;
+            q.box[nx][0][pos] = q.box[cur][0][i];
+            q.box[nx][1][pos] = q.box[cur][1][i];
+            q.box[nx][2][pos] = q.box[cur][2][i];
+            q.box[nx][3][pos] = q.box[cur][3][i];
+            q.cnt[nx][pos] = q.cnt[cur][i];
+            q.path[nx][pos] = pth;
+            q.newIdx[i] = pos;
+        }
+    }
+    WSYNC();
+    // multi-key children in creation order (rank asc, n1..n4): counts per rank -> sequence numbers
+    for (int r = lane; r < R; r += 64) {
+        const int i = q.P[r];
+        int mc = 0;
+        for (int qd = 0; qd < 4; ++qd) {
+            const int pos = q.childpos[i * 4 + qd];
+            if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
+        }
+        q.acc[r] = mc;
+    }
+    WSYNC();
+    const int nToExpand = wscan_inclusive(q.acc, R, lane);
+    // termination / next mode (:671-675, :736)
+    finish = (S2 >= N) || (S2 == S);
+    int modeB2 = modeB;
+    if (!modeB && !finish && (S2 + 3 * nToExpand > N)) modeB2 = 1;
+    int m2 = 0;
+    if (!finish) {
+        if (!modeB2) {
+            // list order of the multi-key nodes of the new list; P/rankOf of the OLD list are dead now
+            for (int i = lane; i < S2; i += 64) ((int32_t *)q.skey)[i] = q.cnt[nx][i] > 1 ? 1 : 0;
+            WSYNC();
+            m2 = wscan_inclusive((int32_t *)q.skey, S2, lane);
+            for (int i = lane; i < S2; i += 64) {
+                const bool multi = q.cnt[nx][i] > 1;
+                const int r = ((int32_t *)q.skey)[i] - 1;
+                q.rankOf[i] = multi ? r : -1;
+                if (multi) q.P[r] = i;
+            }
+        } else {
+            // sort the new multi-key children by (size desc, creation seq desc) (:686-687)
+            int Mp = 2;
+            while (Mp < nToExpand) Mp <<= 1;
+            for (int i = lane; i < Mp; i += 64) q.skey[i] = 0ull;
+            WSYNC();
+            for (int r = lane; r < R; r += 64) {
+                const int i = q.P[r];
+                int mc = 0;
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int pos = q.childpos[i * 4 + qd];
+                    if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
+                }
+                int seq = q.acc[r] - mc;  // acc is inclusive
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int pos = q.childpos[i * 4 + qd];
+                    if (pos >= 0 && q.cnt[nx][pos] > 1) {
+                        q.skey[seq] = ((unsigned long long)(uint32_t)q.cnt[nx][pos] << 32) |
+                                      ((unsigned long long)(uint32_t)(seq + 1) << 16) | (unsigned long long)pos;
+                        ++seq;
+                    }
+                }
+            }
+            WSYNC();
+            for (int kk = 2; kk <= Mp; kk <<= 1)
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    for (int i = lane; i < Mp; i += 64) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = q.skey[i], c2 = q.skey[ixj];
+                            const bool desc = (i & kk) == 0;  // overall descending
+                            if (desc ? (a < c2) : (a > c2)) { q.skey[i] = c2; q.skey[ixj] = a; }
+                        }
+                    }
+                    WSYNC();
+                }
+            for (int i = lane; i < S2; i += 64) q.rankOf[i] = -1;
+            WSYNC();
+            for (int r = lane; r < nToExpand; r += 64) {
+                const int pos = (int)(q.skey[r] & 0xFFFFull);
+                q.P[r] = pos;
+                q.rankOf[pos] = r;
+            }
+            m2 = nToExpand;
+        }
+    }
+    WSYNC();
+    S = S2;
+    m = m2;
+    cur = nx;
+    modeB = modeB2;
+}
+
+__global__ __launch_bounds__(QT_MAX, 4) void k_octree(const OrbPlan *__restrict__ plan,
                                                const uint2 *__restrict__ skeys,     // [B][keys_per_frame] {key, ord} from k_fast_map
                                                const int32_t *__restrict__ scount,  // [B][nlevels] * NK_STRIDE
                                                uint32_t *__restrict__ keys,         // [B][keys_per_frame] scratch: filtered keys
@@ -636,22 +796,23 @@ __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ p
     const int M = plan->node_cap;
     const int N = L.nfeat;
     QtShared q;
-    qt_carve(smem, M, q);
+    qt_carve(smem, M, plan->max_nini, q);
     int32_t *misc = q.misc;
     const uint2 *SK = skeys + (int64_t)b * plan->keys_per_frame + L.key_off;
     uint32_t *K = keys + (int64_t)b * plan->keys_per_frame + L.key_off;
     uint32_t *KO = kord + (int64_t)b * plan->keys_per_frame + L.key_off;
     uint16_t *KN = knode + (int64_t)b * plan->keys_per_frame + L.key_off;
+    const int nini = L.nini;
+    const int ybot = L.h - 2 * ORBFE_MINB;  // maxBorderY - minBorderY
 
-    // ---- prologue: the reference's per-cell threshold fallback (:818-825) on the unordered survivor list ----
+    // ---- prologue 1: the reference's per-cell threshold fallback (:818-825) on the unordered survivor list ----
     // A cell contributes {A > iniTh} if that is non-empty, else all its NMS survivors ({A > minTh}).
     const int ns = min(scount[(b * plan->nlevels + level) * ORBFE_NK_STRIDE], L.key_cap);
     uint32_t *cflag = (uint32_t *)q.cc;  // bitmap over this level's cells (M*16 bytes >= ncells/8 checked on the host)
     const int nwords = (L.ncells + 31) >> 5;
     for (int i = tid; i < nwords; i += QT) cflag[i] = 0u;
-    if (tid < 8) q.childpos[tid] = 0;
+    for (int i = tid; i < nini * FF_PER_ROOT; i += QT) q.hist[i] = 0;
     if (tid == 0) misc[5] = 0;
-    const int nini = L.nini;
     __syncthreads();
     const int ini = plan->ini_th;
     for (int k0 = tid; k0 < ns; k0 += QT * KUNROLL) {
@@ -666,6 +827,7 @@ __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ p
             }
     }
     __syncthreads();
+    // ---- prologue 2: keep / drop, compact, root + 5-level quadrant path of every kept key, leaf histogram ----
     for (int k0 = 0; k0 < ns; k0 += QT * KUNROLL) {
         uint2 e[KUNROLL];
 #pragma unroll
@@ -682,242 +844,183 @@ __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ p
             int base = 0;
             if (lane == 0 && bal) base = atomicAdd(&misc[5], __popcll(bal));
             base = __shfl(base, 0, 64);
-            int r = 0;
             if (keep) {
                 const int o = base + lanes_below(bal);
                 K[o] = e[u].x;
                 KO[o] = e[u].y;
+                const int kx = orb_key_x(e[u].x), ky = orb_key_y(e[u].x);
                 // roots (:545-571): key -> root by (int)(x / hX)
-                r = (int)__fdiv_rn((float)orb_key_x(e[u].x), L.hx);
+                int r = (int)__fdiv_rn((float)kx, L.hx);
                 r = min(max(r, 0), nini - 1);
-                KN[o] = (uint16_t)r;
+                int ulx = L.root_x[r], urx = L.root_x[r + 1], uly = 0, bry = ybot;
+                uint32_t code = 0;
+#pragma unroll
+                for (int d = 0; d < FFD; ++d) {  // DivideNode (:478-522) five times, in registers
+                    const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);
+                    const int qx = kx < midx ? 0 : 1, qy = ky < midy ? 0 : 1;
+                    code = (code << 2) | (uint32_t)(qx + 2 * qy);
+                    ulx = qx ? midx : ulx;
+                    urx = qx ? urx : midx;
+                    uly = qy ? midy : uly;
+                    bry = qy ? bry : midy;
+                }
+                KN[o] = (uint16_t)(((uint32_t)r << 10) | code);
+                atomicAdd(&q.hist[r * FF_PER_ROOT + ff_off(FFD) + (int)code], 1);
             }
-            wave_agg_inc(q.childpos, r, keep, lane);  // root sizes (childpos is free until the first node phase)
         }
     }
     __syncthreads();
     const int n = misc[5];
     if (tid == 0) nkeys[(b * plan->nlevels + level) * ORBFE_NK_STRIDE] = n;
-    // ---- roots (:545-587): nini boxes, empty roots erased ----
-    if (tid == 0) {
-        int S0 = 0;
-        for (int r = 0; r < nini; ++r) {
-            const int cn = q.childpos[r];
-            q.newIdx[r] = S0;  // root r -> list position (unused for empty roots)
-            if (cn > 0) {
-                q.box[0][0][S0] = (int16_t)L.root_x[r];
-                q.box[0][1][S0] = 0;
-                q.box[0][2][S0] = (int16_t)L.root_x[r + 1];
-                q.box[0][3][S0] = (int16_t)(L.h - 2 * ORBFE_MINB);  // maxBorderY - minBorderY
-                q.cnt[0][S0] = cn;
-                ++S0;
-            }
-        }
-        int m0 = 0;  // initial processing order: multi-key roots in list order
-        for (int i = 0; i < S0; ++i) {
-            if (q.cnt[0][i] > 1) { q.P[m0] = i; q.rankOf[i] = m0; ++m0; }
-            else q.rankOf[i] = -1;
-        }
-        misc[0] = S0;
-        misc[1] = m0;
-        misc[3] = 0;  // finish
-        misc[4] = 0;  // modeB
-    }
-    __syncthreads();
-    int S = misc[0], m = misc[1];
-    int cur = 0;
-    if (plan->dbg == 11) return;
-    const int maxpass = plan->dbg >= 20 ? plan->dbg - 20 : 64;
 
-    // ---- passes ----
-    for (int guard = 0; guard < maxpass; ++guard) {
-        const int nx = cur ^ 1;
-        for (int i = tid; i < S * 4; i += QT) q.cc[i] = 0;
-        __syncthreads();
-        // A. one streaming loop over the keys: follow to the current list, classify, count
-        for (int k0 = tid; k0 < n; k0 += QT * KUNROLL) {
-            uint32_t kn[KUNROLL], kv[KUNROLL];
-#pragma unroll
-            for (int u = 0; u < KUNROLL; ++u) {
-                const int k = k0 + u * QT;
-                kn[u] = k < n ? KN[k] : 0u;
-                kv[u] = k < n ? K[k] : 0u;
+    // ---- histogram passes: wave 0 alone, no key is touched ----
+    if (wid == 0) {
+        for (int d = FFD - 1; d >= 1; --d) {  // quadrant sizes of every possible node of depth d-1 .. 4
+            const int cntd = nini << (2 * d);
+            for (int e = lane; e < cntd; e += 64) {
+                const int r = e >> (2 * d), p = e & ((1 << (2 * d)) - 1);
+                const int32_t *src = &q.hist[r * FF_PER_ROOT + ff_off(d + 1) + (p << 2)];
+                q.hist[r * FF_PER_ROOT + ff_off(d) + p] = src[0] + src[1] + src[2] + src[3];
             }
-#pragma unroll
-            for (int u = 0; u < KUNROLL; ++u) {
-                const int k = k0 + u * QT;
-                if (k < n) {
-                    const int i = qt_follow(q, kn[u]);
-                    uint32_t out = (uint32_t)i;
-                    if (q.cnt[cur][i] > 1) {
-                        const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
-                        const int midx = ulx + ((q.box[cur][2][i] - ulx + 1) >> 1);  // UL.x + ceil(w/2)  (:480)
-                        const int midy = uly + ((q.box[cur][3][i] - uly + 1) >> 1);
-                        const int qd = (orb_key_x(kv[u]) < midx ? 0 : 1) + (orb_key_y(kv[u]) < midy ? 0 : 2);
-                        atomicAdd(&q.cc[i * 4 + qd], 1);
-                        out |= (uint32_t)qd << 14;
-                    }
-                    KN[k] = (uint16_t)out;
+            WSYNC();
+        }
+        int S = 0, m = 0, cur = 0, modeB = 0;
+        bool finish = false;
+        if (lane == 0) {  // roots (:545-587): nini boxes, empty roots erased
+            for (int r = 0; r < nini; ++r) {
+                const int32_t *h1 = &q.hist[r * FF_PER_ROOT];
+                const int cn = h1[0] + h1[1] + h1[2] + h1[3];
+                if (cn > 0) {
+                    q.box[0][0][S] = (int16_t)L.root_x[r];
+                    q.box[0][1][S] = 0;
+                    q.box[0][2][S] = (int16_t)L.root_x[r + 1];
+                    q.box[0][3][S] = (int16_t)ybot;
+                    q.cnt[0][S] = cn;
+                    q.path[0][S] = (uint32_t)r << 16;
+                    ++S;
                 }
             }
+            for (int i = 0; i < S; ++i) {  // initial processing order: multi-key roots in list order
+                if (q.cnt[0][i] > 1) { q.P[m] = i; q.rankOf[i] = m; ++m; }
+                else q.rankOf[i] = -1;
+            }
         }
-        __syncthreads();
-        // B. node-level bookkeeping by wave 0 alone (wave-synchronous)
-        if (plan->dbg == 12) { cur = nx; break; }
-        if (wid == 0) {
-            const int modeB = misc[4];
-            // non-empty children per processing rank, inclusive sums, stop rank R
+        S = __shfl(S, 0, 64);
+        m = __shfl(m, 0, 64);
+        WSYNC();
+        int npass = 0;
+        const int ffd = plan->dbg == 50 ? 0 : FFD;  // developer knob: 50 = streaming passes only
+        while (!finish && npass < ffd) {  // nodes processed in pass p have depth <= p-1 <= 4: sizes come from the histogram
             for (int r = lane; r < m; r += 64) {
                 const int i = q.P[r];
-                q.acc[r] = (q.cc[i * 4] > 0) + (q.cc[i * 4 + 1] > 0) + (q.cc[i * 4 + 2] > 0) + (q.cc[i * 4 + 3] > 0);
+                const uint32_t pth = q.path[cur][i];
+                const int d = (int)((pth >> 12) & 0xFu), root = (int)(pth >> 16);
+                const int32_t *src = &q.hist[root * FF_PER_ROOT + ff_off(d + 1) + (int)((pth & 0xFFFu) << 2)];
+                q.cc[i * 4] = src[0];
+                q.cc[i * 4 + 1] = src[1];
+                q.cc[i * 4 + 2] = src[2];
+                q.cc[i * 4 + 3] = src[3];
             }
             WSYNC();
-            wscan_inclusive(q.acc, m, lane);
-            int R = m;
-            if (modeB) {  // first rank whose split brings the list to >= N nodes (:732)
-                int rmin = m;
-                for (int r = lane; r < m; r += 64)
-                    if (S + q.acc[r] - (r + 1) >= N) rmin = min(rmin, r + 1);
-                R = wave_min_i(rmin);
-            }
-            const int totalChildren = R > 0 ? q.acc[R - 1] : 0;
-            // unprocessed nodes keep their relative order behind the new children
-            for (int i = lane; i < S; i += 64) {
-                const int r = q.rankOf[i];
-                q.newIdx[i] = (r >= 0 && r < R) ? 0 : 1;
-            }
-            WSYNC();
-            const int nUnproc = wscan_inclusive(q.newIdx, S, lane);
-            const int S2 = totalChildren + nUnproc;
-            // write the next list; leave the old->new map (newIdx / childpos) for the next key loop
-            for (int i = lane; i < S; i += 64) {
-                const int r = q.rankOf[i];
-                if (r >= 0 && r < R) {
-                    int pos = totalChildren - q.acc[r];
-                    const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
-                    const int urx = q.box[cur][2][i], bry = q.box[cur][3][i];
-                    const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);
-                    for (int qd = 3; qd >= 0; --qd) {  // list front holds n4, then n3, n2, n1 (:623-662)
-                        const int cn = q.cc[i * 4 + qd];
-                        if (cn > 0) {
-                            q.box[nx][0][pos] = (int16_t)((qd & 1) ? midx : ulx);
-                            q.box[nx][1][pos] = (int16_t)((qd & 2) ? midy : uly);
-                            q.box[nx][2][pos] = (int16_t)((qd & 1) ? urx : midx);
-                            q.box[nx][3][pos] = (int16_t)((qd & 2) ? bry : midy);
-                            q.cnt[nx][pos] = cn;
-                            q.childpos[i * 4 + qd] = pos;
-                            ++pos;
-                        } else {
-                            q.childpos[i * 4 + qd] = -1;
-                        }
-                    }
-                    q.newIdx[i] = -1;
-                } else {
-                    const int pos = totalChildren + q.newIdx[i] - 1;
-                    q.box[nx][0][pos] = q.box[cur][0][i];
-                    q.box[nx][1][pos] = q.box[cur][1][i];
-                    q.box[nx][2][pos] = q.box[cur][2][i];
-                    q.box[nx][3][pos] = q.box[cur][3][i];
-                    q.cnt[nx][pos] = q.cnt[cur][i];
-                    q.newIdx[i] = pos;
-                }
-            }
-            WSYNC();
-            // multi-key children in creation order (rank asc, n1..n4): counts per rank -> sequence numbers
-            for (int r = lane; r < R; r += 64) {
-                const int i = q.P[r];
-                int mc = 0;
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int pos = q.childpos[i * 4 + qd];
-                    if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
-                }
-                q.acc[r] = mc;
-            }
-            WSYNC();
-            const int nToExpand = wscan_inclusive(q.acc, R, lane);
-            // termination / next mode (:671-675, :736)
-            const bool finish = (S2 >= N) || (S2 == S);
-            int modeB2 = modeB;
-            if (!modeB && !finish && (S2 + 3 * nToExpand > N)) modeB2 = 1;
-            int m2 = 0;
-            if (!finish) {
-                if (!modeB2) {
-                    // list order of the multi-key nodes of the new list; P/rankOf of the OLD list are dead now
-                    for (int i = lane; i < S2; i += 64) ((int32_t *)q.skey)[i] = q.cnt[nx][i] > 1 ? 1 : 0;
-                    WSYNC();
-                    m2 = wscan_inclusive((int32_t *)q.skey, S2, lane);
-                    for (int i = lane; i < S2; i += 64) {
-                        const bool multi = q.cnt[nx][i] > 1;
-                        const int r = ((int32_t *)q.skey)[i] - 1;
-                        q.rankOf[i] = multi ? r : -1;
-                        if (multi) q.P[r] = i;
-                    }
-                } else {
-                    // sort the new multi-key children by (size desc, creation seq desc) (:686-687)
-                    int Mp = 2;
-                    while (Mp < nToExpand) Mp <<= 1;
-                    for (int i = lane; i < Mp; i += 64) q.skey[i] = 0ull;
-                    WSYNC();
-                    for (int r = lane; r < R; r += 64) {
-                        const int i = q.P[r];
-                        int mc = 0;
-                        for (int qd = 0; qd < 4; ++qd) {
-                            const int pos = q.childpos[i * 4 + qd];
-                            if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
-                        }
-                        int seq = q.acc[r] - mc;  // acc is inclusive
-                        for (int qd = 0; qd < 4; ++qd) {
-                            const int pos = q.childpos[i * 4 + qd];
-                            if (pos >= 0 && q.cnt[nx][pos] > 1) {
-                                q.skey[seq] = ((unsigned long long)(uint32_t)q.cnt[nx][pos] << 32) |
-                                              ((unsigned long long)(uint32_t)(seq + 1) << 16) | (unsigned long long)pos;
-                                ++seq;
-                            }
-                        }
-                    }
-                    WSYNC();
-                    for (int kk = 2; kk <= Mp; kk <<= 1)
-                        for (int j = kk >> 1; j > 0; j >>= 1) {
-                            for (int i = lane; i < Mp; i += 64) {
-                                const int ixj = i ^ j;
-                                if (ixj > i) {
-                                    const unsigned long long a = q.skey[i], c2 = q.skey[ixj];
-                                    const bool desc = (i & kk) == 0;  // overall descending
-                                    if (desc ? (a < c2) : (a > c2)) { q.skey[i] = c2; q.skey[ixj] = a; }
-                                }
-                            }
-                            WSYNC();
-                        }
-                    for (int i = lane; i < S2; i += 64) q.rankOf[i] = -1;
-                    WSYNC();
-                    for (int r = lane; r < nToExpand; r += 64) {
-                        const int pos = (int)(q.skey[r] & 0xFFFFull);
-                        q.P[r] = pos;
-                        q.rankOf[pos] = r;
-                    }
-                    m2 = nToExpand;
-                }
-            }
-            WSYNC();
-            if (lane == 0) {
-                misc[0] = S2;
-                misc[1] = m2;
-                misc[3] = finish ? 1 : 0;
-                misc[4] = modeB2;
-            }
+            qt_node_phase(q, N, S, m, cur, modeB, finish, lane);
+            ++npass;
         }
+        // path -> node table of the current list (overwrites the histogram): exactly one node of a key's path exists
+        for (int i = lane; i < nini * FF_PER_ROOT; i += 64) q.hist[i] = -1;
+        if (lane < 4) misc[8 + lane] = -1;
+        WSYNC();
+        for (int i = lane; i < S; i += 64) {
+            const uint32_t pth = q.path[cur][i];
+            const int d = (int)((pth >> 12) & 0xFu), root = (int)(pth >> 16);
+            if (d == 0) misc[8 + root] = i;
+            else q.hist[root * FF_PER_ROOT + ff_off(d) + (int)(pth & 0xFFFu)] = i;
+            q.newIdx[i] = i;  // identity map for keys that already carry a node index
+        }
+        WSYNC();
+        if (lane == 0) {
+            misc[0] = S;
+            misc[1] = m;
+            misc[2] = cur;
+            misc[3] = finish ? 1 : 0;
+            misc[4] = modeB;
+        }
+    }
+    __syncthreads();
+    int S = misc[0], m = misc[1], cur = misc[2];
+    const bool ff_done = misc[3] != 0;
+
+    // node of a key from its path code: the deepest table hit (only one node of the path exists)
+    auto node_of_code = [&](uint32_t kn) {
+        const int root = (int)(kn >> 10), code = (int)(kn & 0x3FFu);
+        int idx = misc[8 + root];
+#pragma unroll
+        for (int d = 1; d <= FFD; ++d) {
+            const int t = q.hist[root * FF_PER_ROOT + ff_off(d) + (code >> (2 * (FFD - d)))];
+            idx = t >= 0 ? t : idx;
+        }
+        return idx;
+    };
+
+    if (!ff_done) {
+        // ---- deeper trees: keys take their node index and the passes stream over the keys ----
+        for (int k = tid; k < n; k += QT) KN[k] = (uint16_t)node_of_code(KN[k]);
         __syncthreads();
-        S = misc[0];
-        m = misc[1];
-        cur = nx;
-        if (misc[3]) break;
+        for (int guard = 0; guard < 64; ++guard) {
+            for (int i = tid; i < S * 4; i += QT) q.cc[i] = 0;
+            __syncthreads();
+            for (int k0 = tid; k0 < n; k0 += QT * KUNROLL) {
+                uint32_t kn[KUNROLL], kv[KUNROLL];
+#pragma unroll
+                for (int u = 0; u < KUNROLL; ++u) {
+                    const int k = min(k0 + u * QT, n - 1);
+                    kn[u] = KN[k];
+                    kv[u] = K[k];
+                }
+#pragma unroll
+                for (int u = 0; u < KUNROLL; ++u) {
+                    const int k = k0 + u * QT;
+                    if (k < n) {
+                        const int i = qt_follow(q, kn[u]);
+                        uint32_t out = (uint32_t)i;
+                        if (q.cnt[cur][i] > 1) {
+                            const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
+                            const int midx = ulx + ((q.box[cur][2][i] - ulx + 1) >> 1);  // UL.x + ceil(w/2)  (:480)
+                            const int midy = uly + ((q.box[cur][3][i] - uly + 1) >> 1);
+                            const int qd = (orb_key_x(kv[u]) < midx ? 0 : 1) + (orb_key_y(kv[u]) < midy ? 0 : 2);
+                            atomicAdd(&q.cc[i * 4 + qd], 1);
+                            out |= (uint32_t)qd << 14;
+                        }
+                        KN[k] = (uint16_t)out;
+                    }
+                }
+            }
+            __syncthreads();
+            if (wid == 0) {
+                int modeB = misc[4];
+                bool finish = false;
+                int S1 = S, m1 = m, c1 = cur;
+                qt_node_phase(q, N, S1, m1, c1, modeB, finish, lane);
+                if (lane == 0) {
+                    misc[0] = S1;
+                    misc[1] = m1;
+                    misc[2] = c1;
+                    misc[3] = finish ? 1 : 0;
+                    misc[4] = modeB;
+                }
+            }
+            __syncthreads();
+            S = misc[0];
+            m = misc[1];
+            cur = misc[2];
+            if (misc[3]) break;
+        }
     }
 
     // ---- keep the strongest key of every node, first in candidate order on ties (:746-762) ----
+    // best = response (8 bit) | inverted ord (28 bit: first in candidate order wins ties) | key index (24 bit)
     unsigned long long *best = q.skey;
     for (int i = tid; i < S; i += QT) best[i] = 0ull;
     __syncthreads();
-    // best = response (8 bit) | inverted ord (28 bit: first in candidate order wins ties) | key index (24 bit)
     for (int k0 = tid; k0 < n; k0 += QT * KUNROLL) {
         uint32_t kn[KUNROLL], kv[KUNROLL], ko[KUNROLL];
 #pragma unroll
@@ -931,7 +1034,7 @@ __global__ __launch_bounds__(QT_MAX) void k_octree(const OrbPlan *__restrict__ p
         for (int u = 0; u < KUNROLL; ++u) {
             const int k = k0 + u * QT;
             if (k < n) {
-                const int i = qt_follow(q, kn[u]);
+                const int i = ff_done ? node_of_code(kn[u]) : qt_follow(q, kn[u]);
                 atomicMax(&best[i], ((unsigned long long)orb_key_r(kv[u]) << 52) |
                                         ((unsigned long long)(0x0FFFFFFFu - ko[u]) << 24) | (unsigned long long)k);
             }
@@ -1331,16 +1434,16 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
 hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
 {
     dim3 grid(a.h_plan->nlevels, a.nframes);
-    const size_t lds = orbk_octree_lds_bytes(a.h_plan->node_cap);
-    static const int qt = getenv("ORBFE_QT") ? atoi(getenv("ORBFE_QT")) : 512;
+    const size_t lds = orbk_octree_lds_bytes(a.h_plan->node_cap, a.h_plan->max_nini);
+    static const int qt = getenv("ORBFE_QT") ? atoi(getenv("ORBFE_QT")) : 512;  // must be <= QT_MAX
     hipLaunchKernelGGL(k_octree, grid, dim3(qt), lds, st, a.d_plan, a.d_skeys, a.d_scount, a.d_keys, a.d_kord, a.d_knode,
                        a.d_nkeys, a.d_sel, a.d_nsel);
     return hipGetLastError();
 }
 
-hipError_t orbk_prepare_octree(int node_cap)
+hipError_t orbk_prepare_octree(int node_cap, int max_nini)
 {
-    const size_t lds = orbk_octree_lds_bytes(node_cap);
+    const size_t lds = orbk_octree_lds_bytes(node_cap, max_nini);
     return hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 

@@ -101,6 +101,38 @@ def test_1080p_4000_features(oracle):
         assert np.array_equal(e.candidates(l), cand_array(oe.candidates(l)))
 
 
+@pytest.mark.parametrize("seed,box", [(0, (200, 150, 96, 96)), (1, (19, 19, 60, 60)), (2, (500, 380, 120, 80)), (3, (300, 30, 40, 400))])
+def test_clustered_corners_deep_quadtree(oracle, ext, seed, box):
+    """All corners inside a small box.  Boxes 0-2: the reference quadtree stops as soon as a pass leaves the node count
+    unchanged (one non-empty child), so only a couple of keypoints survive per level; box 3 (a tall strip) splits far
+    below depth 5, where the kernel's histogram passes end and its streaming key passes take over."""
+    x0, y0, bw, bh = box
+    img = np.full((480, 640), 128, np.uint8)
+    img[y0:y0 + bh, x0:x0 + bw] = synth_frame(900 + seed)[y0:y0 + bh, x0:x0 + bw]
+    oe = oracle.OracleExtractor()
+    ok, od = oe(img)
+    gk, gd = ext(img)
+    for l in range(8):
+        assert np.array_equal(ext.candidates(l), cand_array(oe.candidates(l))), f"FAST candidates level {l}"
+        assert np.array_equal(ext.selected(l), cand_array(oe.selected(l))), f"quadtree level {l}"
+    assert_same_output(gk, gd, ok, od)
+
+
+def test_streaming_quadtree_passes_only(oracle):
+    """ORBFE_DEBUG=50 disables the histogram passes: every pass streams over the keys (the deep-tree code path)."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    os.environ["ORBFE_DEBUG"] = "50"
+    try:
+        e = ORBextractor(1000, 1.2, 8, 20, 7)
+        for seed, sparse in ((0, False), (2, True)):
+            img = synth_frame(seed, sparse=sparse)
+            ok, od = oracle.OracleExtractor()(img)
+            gk, gd = e(img)
+            assert_same_output(gk, gd, ok, od)
+    finally:
+        del os.environ["ORBFE_DEBUG"]
+
+
 def test_edge_cases(oracle, ext):
     from orb_slam2_ssd_semantic_amd import ORBextractor, OrbfeError, _ffi
     # empty image: silent return, outputs untouched (src/ORBextractor.cc:1055-1056)
