@@ -206,7 +206,7 @@ def main():
         # reported as `roofline`, the per-stage table and the pyramid/FAST pass ride along in `stages`.
         def gbs(name):
             return ab[name] * B / (stage_k[name] * 1e-3) / 1e9 if stage_k[name] > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": {"pyramid": "k_pyr_resize (7 launches)", "fast": "k_fast_cells",
+        roof = {"bound": "hbm", "kernel": {"pyramid": "k_pyr_resize (7 launches)", "fast": "k_fast_map",
                                            "octree": "k_octree", "blur": "k_blur7 (8 launches)",
                                            "describe": "k_orient_describe"}[dom],
                 "achieved": round(gbs(dom), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
