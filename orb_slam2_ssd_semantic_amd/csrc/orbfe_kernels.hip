@@ -98,37 +98,56 @@ __device__ __forceinline__ int reflect101(int p, int len)
 // H row is carried in registers.  Vertical step: ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2, one dword store.
 // Coefficient tables are precomputed on the host in fp64/fp32 exactly as cv::resize does; all kernel math is int32.
 // ---------------------------------------------------------------------------------------------------
-#define PY_RB 8  // destination rows per wave: short waves, the per-launch parallelism comes from their number
+#define PY_RB 4  // destination rows per lane: short waves, the per-launch parallelism comes from their number
 
-__global__ __launch_bounds__(256) void k_pyr_resize(const OrbPlan *__restrict__ plan, FrameSrc fs, int level,
-                                                    const OrbTab *__restrict__ tabs)
+// Everything a level needs travels as kernel arguments and the bilinear taps are recomputed in the kernel with the
+// exact fp64 / fp32 operation sequence of cv::resize, so a wave's only memory round trip before its
+// stores is the pixel fetch itself.
+struct PyrArgs {
+    const uint8_t *src;  // level l-1, frame 0
+    uint8_t *dst;        // level l, frame 0
+    int64_t src_fstride, dst_fstride;
+    int32_t sw, sh, spitch;
+    int32_t dw, dh, dpitch;
+    double scale_x, scale_y;  // 1. / ((double)dst / src), computed on the host exactly as cv::resize does
+};
+
+// one axis tap: source index and the two 11-bit coefficients (x axis clamps like cv::resize's xofs/ialpha loop)
+__device__ __forceinline__ void pyr_tap(int d, double scale, int ssize, bool is_x, int &s, int &c0, int &c1)
 {
-    const OrbLevel &D = plan->lv[level];
-    const OrbLevel &S = plan->lv[level - 1];
+    float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+    int si = (int)floorf(f);
+    f = __fsub_rn(f, (float)si);
+    if (is_x) {
+        if (si < 0) { f = 0.f; si = 0; }
+        if (si >= ssize - 1) { f = 0.f; si = ssize - 1; }
+    }
+    s = si;
+    c0 = min(max(__float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f)), -32768), 32767);
+    c1 = min(max(__float2int_rn(__fmul_rn(f, 2048.f)), -32768), 32767);
+}
+
+__global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
+{
     const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int W = D.w, H = D.h;
-    const int nstrips = (W + 255) >> 8;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int ntiles = nstrips * ((H + PY_RB - 1) / PY_RB);
-    if (t >= ntiles) return;
-    const int strip = t % nstrips, rblk = t / nstrips;
-    const int dx0 = strip * 256 + lane * 4;
+    const int W = a.dw, H = a.dh;
+    // lanes are a flat index over (row block, 4-pixel column group): no lane idles on levels narrower than a strip
+    const int ncol4 = (W + 3) >> 2, nrblk = (H + PY_RB - 1) / PY_RB;
+    const int flat = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    const bool active = flat < ncol4 * nrblk;
+    const int fl = min(flat, ncol4 * nrblk - 1);
+    const int rblk = fl / ncol4;
+    const int dx0 = (fl - rblk * ncol4) * 4;
     const int y0 = rblk * PY_RB;
     const int nrows = min(PY_RB, H - y0);
-    int sp;
-    const uint8_t *src = level_ptr(fs, S, level - 1, b, &sp);
-    uint8_t *dst = fs.pyr + (int64_t)b * fs.pyr_fstride + D.off;
-    const bool active = dx0 < W;
+    const uint8_t *src = a.src + (int64_t)b * a.src_fstride;
+    uint8_t *dst = a.dst + (int64_t)b * a.dst_fstride;
+    const int sp = a.spitch;
 
     // per-lane horizontal taps: source column and the two 11-bit coefficients of each of the 4 pixels
     int sx[4], a0[4], a1[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const OrbTab tx = tabs[D.xtab + min(dx0 + j, W - 1)];
-        sx[j] = tx.s;
-        a0[j] = tx.c0;
-        a1[j] = tx.c1;
-    }
+    for (int j = 0; j < 4; ++j) pyr_tap(min(dx0 + j, W - 1), a.scale_x, a.sw, true, sx[j], a0[j], a1[j]);
     // The pair (S[sx], S[sx+1]) of every tap is ONE unaligned 16-bit load.  It may touch the byte after the last
     // source pixel (sx = S.w-1 has a1 = 0): inside the padded rows of the handle's own levels, and inside the
     // caller's level-0 buffer thanks to the 16-byte slack orbfe.h asks for.
@@ -137,11 +156,9 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const OrbPlan *__restrict__ 
     int vb0[PY_RB], vb1[PY_RB];
 #pragma unroll
     for (int d = 0; d < PY_RB; ++d) {
-        const OrbTab ty = tabs[D.ytab + min(y0 + d, H - 1)];
-        const int tys = (int)ty.s;
-        const int sy0 = min(max(tys, 0), S.h - 1), sy1 = min(max(tys + 1, 0), S.h - 1);
-        vb0[d] = ty.c0;
-        vb1[d] = ty.c1;
+        int tys;
+        pyr_tap(min(y0 + d, H - 1), a.scale_y, a.sh, false, tys, vb0[d], vb1[d]);
+        const int sy0 = min(max(tys, 0), a.sh - 1), sy1 = min(max(tys + 1, 0), a.sh - 1);
         const uint8_t *r0 = src + (int64_t)sy0 * sp, *r1 = src + (int64_t)sy1 * sp;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -160,7 +177,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const OrbPlan *__restrict__ 
             packed |= (uint32_t)(v & 0xFF) << (8 * j);
         }
         if (active && d < nrows) {
-            uint8_t *o = dst + (int64_t)(y0 + d) * D.pitch + dx0;
+            uint8_t *o = dst + (int64_t)(y0 + d) * a.dpitch + dx0;
             if (dx0 + 4 <= W) *(uint32_t *)o = packed;
             else
                 for (int j = 0; j < 4 && dx0 + j < W; ++j) o[j] = (uint8_t)(packed >> (8 * j));
@@ -1410,12 +1427,28 @@ static FrameSrc make_src(const OrbLaunch &a)
 
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
 {
-    const FrameSrc fs = make_src(a);
     for (int l = 1; l < a.h_plan->nlevels; ++l) {
-        const OrbLevel &L = a.h_plan->lv[l];
-        const int ntiles = ((L.w + 255) / 256) * ((L.h + PY_RB - 1) / PY_RB);
-        dim3 grid((ntiles + 3) / 4, a.nframes);
-        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, a.d_plan, fs, l, a.d_tabs);
+        const OrbLevel &D = a.h_plan->lv[l];
+        const OrbLevel &S = a.h_plan->lv[l - 1];
+        PyrArgs pa;
+        if (l == 1) {
+            pa.src = a.d_gray;
+            pa.src_fstride = a.gray_fstride;
+            pa.spitch = a.gray_pitch;
+        } else {
+            pa.src = a.d_pyr + S.off;
+            pa.src_fstride = a.pyr_fstride;
+            pa.spitch = S.pitch;
+        }
+        pa.dst = a.d_pyr + D.off;
+        pa.dst_fstride = a.pyr_fstride;
+        pa.sw = S.w; pa.sh = S.h;
+        pa.dw = D.w; pa.dh = D.h; pa.dpitch = D.pitch;
+        pa.scale_x = 1. / ((double)D.w / S.w);  // cv::resize: inv_scale = (double)dsize/ssize; scale = 1./inv_scale
+        pa.scale_y = 1. / ((double)D.h / S.h);
+        const int nlanes = ((D.w + 3) / 4) * ((D.h + PY_RB - 1) / PY_RB);
+        dim3 grid((nlanes + 255) / 256, a.nframes);
+        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, pa);
     }
     return hipGetLastError();
 }
