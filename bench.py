@@ -108,7 +108,8 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the CPU-oracle baseline and the single-frame latency probe (used for rocprof runs)")
     ap.add_argument("--include-h2d", action="store_true", help="also report the PCIe-inclusive rate (not `value`)")
     args = ap.parse_args()
 
@@ -252,6 +253,28 @@ def main():
                 hd.copy_(d_desc, non_blocking=True)
             torch.cuda.synchronize()
             result["pcie_inclusive_frames_per_s"] = round(3 * B / (time.perf_counter() - t1), 2)
+        if world == 1 and not args.no_cpu_baseline:
+            # online (single-frame, host buffers in / out) latency of ORBextractor::operator(): replicas-only path
+            e1 = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1, device=local_rank)
+            img = np.ascontiguousarray(frames[0])
+            for _ in range(5):
+                e1(img)
+            lat = []
+            for _ in range(50):
+                t2 = time.perf_counter()
+                e1(img)
+                lat.append(time.perf_counter() - t2)
+            result["single_frame_host_latency_ms"] = round(float(np.median(lat)) * 1e3, 4)
+            pm = os.path.join(ROOT, "profiles", "r01_v3_pmc_hbm.json")
+            if os.path.exists(pm):  # HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes
+                try:
+                    pj = json.load(open(pm))
+                    kn = roof["kernel"].split(" ")[0]
+                    tb = (pj["FETCH_SIZE_KB"][kn]["mean_per_launch"] + pj["WRITE_SIZE_KB"][kn]["mean_per_launch"]) * 1024
+                    roof["traffic"] = int(tb)
+                    roof["traffic_note"] = "FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_v3_pmc_hbm.json (separate --pmc passes, uncorrected)"
+                except Exception:
+                    pass
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(w, h, nf)
             result["cpu_baseline"] = cb
