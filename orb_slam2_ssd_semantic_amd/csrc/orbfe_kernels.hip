@@ -257,35 +257,31 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *p /* LDS, pitch 
 // A pixel pair is held as two u16 halves (values 0..255).  Read as f16 bit patterns those are positive
 // denormals, whose order equals the integer order, so gfx950's 3-input packed min/max
 // (v_pk_minimum3_f16 / v_pk_maximum3_f16) give exact integer results at two pixels per instruction.
+typedef _Float16 orb_h2 __attribute__((ext_vector_type(2)));
+typedef short orb_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short orb_u2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
 {
-    uint32_t r;
-    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    const orb_h2 x = __builtin_bit_cast(orb_h2, a), y = __builtin_bit_cast(orb_h2, b), z = __builtin_bit_cast(orb_h2, c);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_minimum(__builtin_elementwise_minimum(x, y), z));  // v_pk_minimum3_f16
 }
 __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
 {
-    uint32_t r;
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    const orb_h2 x = __builtin_bit_cast(orb_h2, a), y = __builtin_bit_cast(orb_h2, b), z = __builtin_bit_cast(orb_h2, c);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));  // v_pk_maximum3_f16
 }
 __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
 {
-    uint32_t r;
-    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_s2, a) - __builtin_bit_cast(orb_s2, b));
 }
 __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
 {
-    uint32_t r;
-    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(orb_s2, a), __builtin_bit_cast(orb_s2, b)));
 }
 __device__ __forceinline__ uint32_t pk_subsat_u16(uint32_t a, uint32_t b)
 {
-    uint32_t r;
-    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(orb_u2, a), __builtin_bit_cast(orb_u2, b)));
 }
 
 // pixels (IDX, IDX+1) of a 12-byte row window as a u16 pair
