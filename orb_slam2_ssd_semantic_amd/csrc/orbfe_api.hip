@@ -136,7 +136,7 @@ struct orbfe_handle {
     bool plan_valid = false;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
-    DevBuf d_plan, d_cells, d_tabs, d_btiles, d_supers, d_ftiles, d_flanes, d_blanes;
+    DevBuf d_plan, d_cells, d_tabs, d_flanes, d_blanes;
     // per-batch blocks
     DevBuf d_pyr, d_blur, d_skeys, d_scount, d_keys, d_kord, d_knode, d_sel, d_nsel, d_nkeys;
     // host-API staging
@@ -208,8 +208,6 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     P.dbg = getenv("ORBFE_DEBUG") ? atoi(getenv("ORBFE_DEBUG")) : 0;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
-    std::vector<OrbSuper> supers;
-    std::vector<OrbTile> ftiles;
     int64_t off = 0;
     int key_off = 0, sel_off = 0, cell_cap = 1, max_sel = 0;
     for (int l = 0; l < nl; ++l) {
@@ -268,50 +266,15 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         }
         L.ncells = (int)cells.size() - L.cell0;
         {
-            // non-skipped cells form a full (rows x cols) sub-grid (the skip rules depend on i or j alone);
-            // group it into blocks of cells whose union tile fits the LDS tile of k_fast_cells (141 x 140)
+            // non-skipped cells form a full (rows x cols) sub-grid (the skip rules depend on i or j alone)
             int ncc = 0;
             for (int k = L.cell0; k < (int)cells.size() && cells[k].y0 == cells[L.cell0].y0; ++k) ++ncc;
             L.ncc = ncc;
-            const int nrr = ncc ? L.ncells / ncc : 0;
-            const int cbx = std::max(1, std::min(4, (141 - 6) / L.wcell));
-            const int cby = std::max(1, std::min(4, (140 - 6) / L.hcell));
-            for (int i0 = 0; i0 < nrr; i0 += cby)
-                for (int j0 = 0; j0 < ncc; j0 += cbx) {
-                    const int ny = std::min(cby, nrr - i0), nx = std::min(cbx, ncc - j0);
-                    const OrbCell &c0 = cells[L.cell0 + i0 * ncc + j0];
-                    const OrbCell &c1 = cells[L.cell0 + (i0 + ny - 1) * ncc + (j0 + nx - 1)];
-                    OrbSuper sp;
-                    sp.level = (uint16_t)l;
-                    sp.x0 = c0.x0;
-                    sp.y0 = c0.y0;
-                    sp.tw = (uint16_t)(c1.x0 + c1.tw - c0.x0);
-                    sp.th = (uint16_t)(c1.y0 + c1.th - c0.y0);
-                    sp.ncx = (uint16_t)nx;
-                    sp.ncy = (uint16_t)ny;
-                    sp.ncells = (uint16_t)(nx * ny);
-                    sp.cell0 = L.cell0 + i0 * ncc + j0;
-                    sp.cstride = ncc;
-                    if ((sp.x0 & 3) + sp.tw > 144 || sp.th > 140) {
-                        orbfe_set_error("FAST super-cell %dx%d exceeds the LDS tile", sp.tw, sp.th);
-                        return ORBFE_ERR_SIZE;
-                    }
-                    supers.push_back(sp);
-                }
         }
         {
             const OrbCell &clast = cells.back();
             L.ix1 = L.ncells ? clast.x0 + clast.tw - 3 : ORBFE_EDGE;
             L.iy1 = L.ncells ? clast.y0 + clast.th - 3 : ORBFE_EDGE;
-            for (int y0 = ORBFE_EDGE; y0 < L.iy1; y0 += 64)
-                for (int x0 = 16; x0 < L.ix1; x0 += 248) {
-                    OrbTile t;
-                    t.level = (uint16_t)l;
-                    t.x0 = (uint16_t)x0;
-                    t.y0 = (uint16_t)y0;
-                    t.pad = 0;
-                    ftiles.push_back(t);
-                }
         }
         L.nfeat = h->feat[l];
         // quadtree roots (src/ORBextractor.cc:545-559)
@@ -369,20 +332,6 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         }
     P.pyr_frame_bytes = off;
     if (tabs.empty()) tabs.resize(1);
-    std::vector<OrbTile> btiles;  // blur work list: 256-px x 32-row tiles, large levels first
-    for (int l = 0; l < nl; ++l)
-        for (int y0 = 0; y0 < P.lv[l].h; y0 += 32)
-            for (int x0 = 0; x0 < P.lv[l].w; x0 += 256) {
-                OrbTile t;
-                t.level = (uint16_t)l;
-                t.x0 = (uint16_t)x0;
-                t.y0 = (uint16_t)y0;
-                t.pad = 0;
-                btiles.push_back(t);
-            }
-    P.nbtiles = (int)btiles.size();
-    P.nsupers = (int)supers.size();
-    P.nftiles = (int)ftiles.size();
     // FAST lane list: per level, per (balanced) row block of <= 64 rows, the 4-px columns x = 16, 20, ... < ix1 form a
     // strip; strips are packed back to back into single-level waves of 64 lanes.  Where a wave boundary falls inside a
     // strip, each side gets one halo lane (computes neighbour strengths, outputs nothing).
@@ -475,9 +424,6 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(h->d_plan.ensure(sizeof(OrbPlan)));
     ORBFE_HIP(h->d_cells.ensure(cells.size() * sizeof(OrbCell)));
     ORBFE_HIP(h->d_tabs.ensure(tabs.size() * sizeof(OrbTab)));
-    ORBFE_HIP(h->d_btiles.ensure(btiles.size() * sizeof(OrbTile)));
-    ORBFE_HIP(h->d_supers.ensure(supers.size() * sizeof(OrbSuper)));
-    ORBFE_HIP(h->d_ftiles.ensure(ftiles.size() * sizeof(OrbTile)));
     ORBFE_HIP(h->d_flanes.ensure(std::max<size_t>(flanes.size(), 1) * sizeof(OrbLane)));
     ORBFE_HIP(h->d_blanes.ensure(std::max<size_t>(blanes.size(), 1) * sizeof(OrbLane)));
     // synchronous copies: plans change rarely (frame size change), never inside the timed region
@@ -485,9 +431,6 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(hipMemcpy(h->d_plan.p, &P, sizeof(OrbPlan), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_cells.p, cells.data(), cells.size() * sizeof(OrbCell), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_tabs.p, tabs.data(), tabs.size() * sizeof(OrbTab), hipMemcpyHostToDevice));
-    ORBFE_HIP(hipMemcpy(h->d_btiles.p, btiles.data(), btiles.size() * sizeof(OrbTile), hipMemcpyHostToDevice));
-    ORBFE_HIP(hipMemcpy(h->d_supers.p, supers.data(), supers.size() * sizeof(OrbSuper), hipMemcpyHostToDevice));
-    ORBFE_HIP(hipMemcpy(h->d_ftiles.p, ftiles.data(), ftiles.size() * sizeof(OrbTile), hipMemcpyHostToDevice));
     if (!flanes.empty())
         ORBFE_HIP(hipMemcpy(h->d_flanes.p, flanes.data(), flanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     if (!blanes.empty())
@@ -602,7 +545,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_btiles, &h->d_supers, &h->d_ftiles, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_keys, &h->d_kord, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_keys, &h->d_kord, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
                       &h->d_okps, &h->d_odesc, &h->d_on};
     for (DevBuf *b : bufs) b->release();
     PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
@@ -703,9 +646,6 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_plan = (const OrbPlan *)h->d_plan.p;
     a.d_cells = (const OrbCell *)h->d_cells.p;
     a.d_tabs = (const OrbTab *)h->d_tabs.p;
-    a.d_btiles = (const OrbTile *)h->d_btiles.p;
-    a.d_supers = (const OrbSuper *)h->d_supers.p;
-    a.d_ftiles = (const OrbTile *)h->d_ftiles.p;
     a.d_flanes = (const OrbLane *)h->d_flanes.p;
     a.d_blanes = (const OrbLane *)h->d_blanes.p;
     a.nframes = nframes;

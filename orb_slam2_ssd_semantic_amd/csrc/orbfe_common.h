@@ -75,26 +75,10 @@ struct OrbTab {
     int16_t pad;
 };
 
-// a block of up to 4x4 FAST cells of one level handled by one workgroup (k_fast_cells)
-struct OrbSuper {
-    uint16_t level;
-    uint16_t x0, y0;    // tile origin (level coordinates) = origin of the first cell's cv::FAST tile
-    uint16_t tw, th;    // tile size incl. the 3-px apron on every side (<= 141 x 140)
-    uint16_t ncx, ncy;  // cells in the block
-    uint16_t ncells;    // ncx * ncy
-    int32_t cell0;      // frame cell-table index of the block's first cell
-    int32_t cstride;    // cell-table stride between cell rows of this level
-};
-
 // one lane of a streaming image pass: a 4-pixel column walked down `nrows` rows
 struct OrbLane {
     uint16_t x, ys, nrows;
     uint16_t flags;  // bit 0: halo (computes, does not output); bits 8..15: level
-};
-
-// work tile of a per-level image pass (blur): origin in level coordinates
-struct OrbTile {
-    uint16_t level, x0, y0, pad;
 };
 
 struct OrbPlan {
@@ -108,12 +92,9 @@ struct OrbPlan {
     int32_t max_nini;          // largest number of quadtree roots over the levels
     int32_t ini_th, min_th;
     int32_t blur_rounding;
-    int32_t dbg;               // developer knob (ORBFE_DEBUG env): early-outs for phase timing, 0 in production
-    int32_t nsupers;           // FAST super-cells per frame (v2 kernel, unused by v3)
-    int32_t nftiles;           // (unused)
+    int32_t dbg;               // developer knob (ORBFE_DEBUG env), 0 in production; 50 = quadtree streaming passes only
     int32_t nfwaves;           // FAST waves per frame (64 lane descriptors each)
     int32_t nbwaves;           // blur waves per frame (64 lane descriptors each)
-    int32_t nbtiles;           // (unused) (256 px x 32 rows, one wave each)
     int64_t pyr_frame_bytes;   // bytes of one frame's pyramid slice (levels 1..n-1; level 0 kept too when owned)
     OrbLevel lv[ORBFE_MAX_LEVELS];
 };

@@ -8,9 +8,6 @@ struct OrbLaunch {
     const OrbPlan *d_plan;  // device copy
     const OrbCell *d_cells;
     const OrbTab *d_tabs;
-    const OrbTile *d_btiles;
-    const OrbSuper *d_supers;
-    const OrbTile *d_ftiles;
     const OrbLane *d_flanes;
     const OrbLane *d_blanes;
     int32_t nframes;

@@ -186,53 +186,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2  FAST-9/16 per cell.  One workgroup = one cv::FAST call of the reference.
-//   tile -> LDS, arc strength A(x,y) = max(A_dark, A_bright) for every interior pixel -> LDS,
-//   corner at t <=> A > t, cv score = A-1; 3x3 strict NMS at iniTh; if the cell is empty, again at minTh
-//   (the strength map is threshold independent, so the fallback costs no second scoring pass);
-//   survivors are emitted in raster order through a block scan (output order is part of the contract).
+// K2  FAST-9/16 with the reference's per-cell semantics: corner at t <=> A > t for the arc strength
+//   A = max(A_dark, A_bright), cv score = A - 1, 3x3 strict NMS inside each cell's detectable interior, iniTh list
+//   or -- for a cell where that is empty -- minTh list.
 // ---------------------------------------------------------------------------------------------------
-#define TP ORBFE_TILE_MAX
-
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-__device__ __forceinline__ int fast_arc_strength(const uint8_t *p /* LDS, pitch TP */)
-{
-    const int v = p[0];
-    int d[16];
-    d[0] = v - p[3 * TP + 0];
-    d[1] = v - p[3 * TP + 1];
-    d[2] = v - p[2 * TP + 2];
-    d[3] = v - p[1 * TP + 3];
-    d[4] = v - p[0 * TP + 3];
-    d[5] = v - p[-1 * TP + 3];
-    d[6] = v - p[-2 * TP + 2];
-    d[7] = v - p[-3 * TP + 1];
-    d[8] = v - p[-3 * TP + 0];
-    d[9] = v - p[-3 * TP - 1];
-    d[10] = v - p[-2 * TP - 2];
-    d[11] = v - p[-1 * TP - 3];
-    d[12] = v - p[0 * TP - 3];
-    d[13] = v - p[1 * TP - 3];
-    d[14] = v - p[2 * TP - 2];
-    d[15] = v - p[3 * TP - 1];
-    int lo3[16], hi3[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        lo3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        hi3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-    }
-    int a_dark = -512, b_min = 512;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        a_dark = max(a_dark, min3i(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
-        b_min = min(b_min, max3i(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
-    }
-    return max(a_dark, -b_min);
-}
-
-// v3: dense streaming formulation.
+// Dense streaming formulation.
 //
 // k_fast_map   one wave per (level, 248-px strip, 64-row block).  Every lane owns 4 adjacent pixels and walks down
 //              the rows with the last 7 image rows (3 dwords each) in registers -- no LDS, no byte loads.  With
@@ -250,8 +211,6 @@ __device__ __forceinline__ int fast_arc_strength(const uint8_t *p /* LDS, pitch 
 //              position alone and is a rank key of the reference's candidate order (cell-row-major, raster inside
 //              a cell), which is all DistributeOctTree's tie-break needs.  The fallback rule (a cell whose iniTh
 //              list is empty contributes its minTh list) is applied per cell in k_octree's prologue.
-#define FM_RB 64      // output rows per tile
-#define FM_STRIP 248  // output columns per tile (lanes 1..62; lanes 0 and 63 are the NMS halo)
 
 // ---- packed 16-bit helpers: two pixels per VALU instruction --------------------------------------------
 // A pixel pair is held as two u16 halves (values 0..255).  Read as f16 bit patterns those are positive
