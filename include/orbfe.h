@@ -88,7 +88,8 @@ orbfe_status orbfe_get_scales(const orbfe_handle *h, float *scale, float *inv_sc
                               float *inv_sigma2);
 /* mnFeaturesPerLevel (src/ORBextractor.cc:426-439); nlevels ints */
 orbfe_status orbfe_get_features_per_level(const orbfe_handle *h, int32_t *out);
-/* upper bound of keypoints one frame can produce: nfeatures + 2*nlevels rounded up to 64 */
+/* upper bound of keypoints one frame can produce: sum over levels of max(N_l + 2, 4 * nIni_l) -- the quadtree may end
+ * a pass with up to 3 nodes more than asked, and never with fewer than the initial roots' children -- rounded up to 64 */
 int32_t orbfe_keypoint_capacity(const orbfe_handle *h);
 
 /* ORBextractor::operator()(image, mask, keypoints, descriptors) for one 8-bit gray frame in HOST
@@ -222,6 +223,26 @@ orbfe_status orbfe_search_by_bow(orbfe_matcher *m, const uint8_t *descKF, int32_
 orbfe_status orbfe_hamming_csr(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
                                const uint32_t *off, const uint32_t *cand, int32_t *best_idx, int32_t *best,
                                int32_t *second);
+
+/* the frame grid index that every projection-gated matcher walks.
+ * Frame::AssignFeaturesToGrid (src/Frame.cc:319-334) + Frame::PosInGrid (:522-531): 64 x 48 cells over the undistorted
+ * image bounds; keypoint i goes to cell (round((x-minx)*gw_inv), round((y-miny)*gh_inv)) if that is inside the grid.
+ *   xy[n*2]            undistorted keypoint positions (mvKeysUn[i].pt)
+ *   cell_off[64*48+1]  CSR offsets, cell c = ix*48 + iy (= mGrid[ix][iy]);  cell_idx[n]: keypoint indices, ascending per
+ *                      cell (push_back order);  *n_in_grid = number of keypoints inside the grid.  HOST buffers. */
+#define ORBFE_GRID_COLS 64 /* FRAME_GRID_COLS include/Frame.h:26 */
+#define ORBFE_GRID_ROWS 48 /* FRAME_GRID_ROWS include/Frame.h:25 */
+orbfe_status orbfe_assign_grid(orbfe_matcher *m, const float *xy, int32_t n, float minx, float miny, float gw_inv,
+                               float gh_inv, uint32_t *cell_off, uint32_t *cell_idx, int32_t *n_in_grid);
+/* Frame::GetFeaturesInArea (src/Frame.cc:465-518) for a batch of nq queries (x, y, r, minLevel, maxLevel):
+ *   qxyr[nq*3], qlevels[nq*2] (may be NULL = -1,-1);  octave[n] = mvKeysUn[i].octave
+ *   off[nq+1], cand[cap]: per query the keypoint indices in the reference's iteration order (ix, iy, cell order).
+ * Returns ORBFE_ERR_CAP (with off[nq] = required total) when cap is too small.  Feed (off, cand) to orbfe_hamming_csr
+ * to get SearchByProjection's best / second-best per query.  HOST buffers. */
+orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy, const int32_t *octave, int32_t n,
+                                    const uint32_t *cell_off, const uint32_t *cell_idx, float minx, float miny,
+                                    float gw_inv, float gh_inv, const float *qxyr, const int32_t *qlevels, int32_t nq,
+                                    uint32_t *off, uint32_t *cand, int32_t cap);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,9 @@ def lib():
     L.orc_search_by_bow.argtypes = ([vp, C.c_int, vp, vp, vp, vp, vp, C.c_int] * 2
                                     + [C.c_float, C.c_int, C.c_int, C.c_int, vp, vp])
     L.orc_hamming_csr.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.orc_assign_grid.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
+    L.orc_features_in_area.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_int, C.c_int, vp, C.c_int]
     _lib = L
     return L
 
@@ -347,3 +350,23 @@ def hamming_csr(q, t, off, cand):
     rc = lib().orc_hamming_csr(_p(q), len(q), _p(t), len(t), _p(off), _p(cand), _p(bi), _p(b), _p(s))
     assert rc == 0
     return bi, b, s
+
+
+def assign_grid(xy, minx, miny, gw_inv, gh_inv):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    off = np.zeros(64 * 48 + 1, np.uint32)
+    idx = np.zeros(max(len(xy), 1), np.uint32)
+    n = lib().orc_assign_grid(_p(xy), len(xy), minx, miny, gw_inv, gh_inv, _p(off), _p(idx))
+    return off, idx[:n].copy()
+
+
+def features_in_area(xy, octave, off, idx, minx, miny, gw_inv, gh_inv, x, y, r, min_level=-1, max_level=-1):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    octave = np.ascontiguousarray(octave, np.int32)
+    off = np.ascontiguousarray(off, np.uint32)
+    idx = np.ascontiguousarray(idx, np.uint32)
+    out = np.zeros(max(len(xy), 1), np.uint32)
+    n = lib().orc_features_in_area(_p(xy), _p(octave), _p(off), _p(idx), minx, miny, gw_inv, gh_inv, x, y, r, min_level,
+                                   max_level, _p(out), out.size)
+    assert n >= 0
+    return out[:n].copy()

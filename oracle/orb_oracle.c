@@ -1069,3 +1069,75 @@ int orc_hamming_csr(const uint8_t *q, int nq, const uint8_t *t, int nt, const ui
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * 8(f).2  Frame grid index (src/Frame.cc:319-334, 465-531)
+ * ---------------------------------------------------------------------------------------------- */
+static int pos_in_grid(float x, float y, float minx, float miny, float gw_inv, float gh_inv, int *px, int *py)
+{
+    *px = (int)roundf((x - minx) * gw_inv); /* :525 std::round(float) */
+    *py = (int)roundf((y - miny) * gh_inv);
+    return !(*px < 0 || *px >= ORC_GRID_COLS || *py < 0 || *py >= ORC_GRID_ROWS);
+}
+
+int orc_assign_grid(const float *xy, int n, float minx, float miny, float gw_inv, float gh_inv, uint32_t *cell_off,
+                    uint32_t *cell_idx)
+{
+    const int nc = ORC_GRID_COLS * ORC_GRID_ROWS;
+    uint32_t *cnt = (uint32_t *)calloc((size_t)nc + 1, sizeof(uint32_t));
+    int placed = 0;
+    for (int i = 0; i < n; i++) {
+        int px, py;
+        if (pos_in_grid(xy[2 * i], xy[2 * i + 1], minx, miny, gw_inv, gh_inv, &px, &py)) cnt[px * ORC_GRID_ROWS + py]++;
+    }
+    cell_off[0] = 0;
+    for (int c = 0; c < nc; c++) cell_off[c + 1] = cell_off[c] + cnt[c];
+    memset(cnt, 0, sizeof(uint32_t) * (size_t)nc);
+    for (int i = 0; i < n; i++) { /* push_back in keypoint order (:326-333) */
+        int px, py;
+        if (pos_in_grid(xy[2 * i], xy[2 * i + 1], minx, miny, gw_inv, gh_inv, &px, &py)) {
+            const int c = px * ORC_GRID_ROWS + py;
+            cell_idx[cell_off[c] + cnt[c]++] = (uint32_t)i;
+            placed++;
+        }
+    }
+    free(cnt);
+    return placed;
+}
+
+int orc_features_in_area(const float *xy, const int32_t *octave, const uint32_t *cell_off, const uint32_t *cell_idx,
+                         float minx, float miny, float gw_inv, float gh_inv, float x, float y, float r, int min_level,
+                         int max_level, uint32_t *out, int cap)
+{
+    int nmin_x = (int)floorf((x - minx - r) * gw_inv); /* :470 */
+    if (nmin_x < 0) nmin_x = 0;
+    if (nmin_x >= ORC_GRID_COLS) return 0;
+    int nmax_x = (int)ceilf((x - minx + r) * gw_inv);
+    if (nmax_x > ORC_GRID_COLS - 1) nmax_x = ORC_GRID_COLS - 1;
+    if (nmax_x < 0) return 0;
+    int nmin_y = (int)floorf((y - miny - r) * gh_inv);
+    if (nmin_y < 0) nmin_y = 0;
+    if (nmin_y >= ORC_GRID_ROWS) return 0;
+    int nmax_y = (int)ceilf((y - miny + r) * gh_inv);
+    if (nmax_y > ORC_GRID_ROWS - 1) nmax_y = ORC_GRID_ROWS - 1;
+    if (nmax_y < 0) return 0;
+    const int check = (min_level > 0) || (max_level >= 0); /* :486 */
+    int n = 0;
+    for (int ix = nmin_x; ix <= nmax_x; ix++)
+        for (int iy = nmin_y; iy <= nmax_y; iy++) {
+            const int c = ix * ORC_GRID_ROWS + iy;
+            for (uint32_t j = cell_off[c]; j < cell_off[c + 1]; j++) {
+                const uint32_t k = cell_idx[j];
+                if (check) {
+                    if (octave[k] < min_level) continue;
+                    if (max_level >= 0 && octave[k] > max_level) continue;
+                }
+                const float dx = xy[2 * k] - x, dy = xy[2 * k + 1] - y;
+                if (fabsf(dx) < r && fabsf(dy) < r) {
+                    if (n >= cap) return -1;
+                    out[n++] = k;
+                }
+            }
+        }
+    return n;
+}

@@ -140,6 +140,17 @@ int orc_search_by_bow(const uint8_t *descKF, int nKF, const uint8_t *validKF, co
 int orc_hamming_csr(const uint8_t *q, int nq, const uint8_t *t, int nt, const uint32_t *off /* nq+1 */,
                     const uint32_t *cand, int32_t *best_idx, int32_t *best, int32_t *second);
 
+/* ---- 8(f).2: Frame::AssignFeaturesToGrid (src/Frame.cc:319-334) + PosInGrid (:522-531) ----
+ * 64 x 48 grid; cell c = ix*48 + iy (mGrid[ix][iy]); cell_off has 64*48+1 entries, cell_idx ascending per cell. */
+#define ORC_GRID_COLS 64
+#define ORC_GRID_ROWS 48
+int orc_assign_grid(const float *xy /* n x 2 */, int n, float minx, float miny, float gw_inv, float gh_inv,
+                    uint32_t *cell_off, uint32_t *cell_idx);
+/* ---- 8(f).2: Frame::GetFeaturesInArea (src/Frame.cc:465-518) for one query; returns the count, -1 if cap too small */
+int orc_features_in_area(const float *xy, const int32_t *octave, const uint32_t *cell_off, const uint32_t *cell_idx,
+                         float minx, float miny, float gw_inv, float gh_inv, float x, float y, float r, int min_level,
+                         int max_level, uint32_t *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

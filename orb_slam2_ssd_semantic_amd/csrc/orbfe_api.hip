@@ -123,6 +123,9 @@ struct PinBuf {
 // handle
 // ---------------------------------------------------------------------------------------------------
 #define ORBFE_PROF_RING 64
+// event marks of one profiled call: 0 start, 1 pyramid done, 2 FAST done, 3 quadtree done, 4 describe start, 5 end (launch
+// stream); 6 / 7 around the blur (on whichever stream it ran)
+#define ORBFE_EV_N 8
 
 struct orbfe_handle {
     orbfe_params prm;
@@ -149,9 +152,14 @@ struct orbfe_handle {
     int32_t last_nframes = 0;
     // profiling: ring of event sets so a timed region of many asynchronous calls can be averaged afterwards
     bool profiling = false;
-    hipEvent_t ev[ORBFE_PROF_RING][ORBFE_T_COUNT];
+    hipEvent_t ev[ORBFE_PROF_RING][ORBFE_EV_N];
     int prof_calls = 0;  // calls recorded since profiling was (re-)enabled
     bool ev_ok = false;
+    // blur depends on the pyramid only, the quadtree on FAST only: the blur runs on a side stream next to the
+    // latency-bound quadtree (overlap 2), next to FAST + quadtree (1), or in line (0)
+    int overlap = 2;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }  // cvRound: half-to-even
@@ -521,11 +529,18 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
         return fail(ORBFE_ERR_HIP);
     }
     for (int r = 0; r < ORBFE_PROF_RING; ++r)
-        for (int i = 0; i < ORBFE_T_COUNT; ++i) h->ev[r][i] = nullptr;
+        for (int i = 0; i < ORBFE_EV_N; ++i) h->ev[r][i] = nullptr;
     h->ev_ok = true;
     for (int r = 0; r < ORBFE_PROF_RING; ++r)
-        for (int i = 0; i < ORBFE_T_COUNT; ++i)
+        for (int i = 0; i < ORBFE_EV_N; ++i)
             if (hipEventCreate(&h->ev[r][i]) != hipSuccess) { orbfe_set_error("hipEventCreate failed"); return fail(ORBFE_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        orbfe_set_error("side stream / event creation failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(ORBFE_ERR_HIP);
+    }
+    if (const char *e = getenv("ORBFE_OVERLAP")) h->overlap = std::max(0, std::min(2, atoi(e)));
     int umax[16];
     host_umax(umax);
     if (orbk_upload_constants(umax) != hipSuccess) {
@@ -552,8 +567,12 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     for (PinBuf *b : pins) b->release();
     if (h->ev_ok)
         for (int r = 0; r < ORBFE_PROF_RING; ++r)
-            for (int i = 0; i < ORBFE_T_COUNT; ++i)
+            for (int i = 0; i < ORBFE_EV_N; ++i)
                 if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
+    if (h->side) (void)hipStreamSynchronize(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -603,14 +622,14 @@ extern "C" orbfe_status orbfe_get_stage_ms(orbfe_handle *h, float ms[ORBFE_T_COU
     double acc[ORBFE_T_COUNT] = {0, 0, 0, 0, 0, 0};
     for (int c = 0; c < ncalls; ++c) {
         hipEvent_t *e = h->ev[(h->prof_calls - 1 - c) % ORBFE_PROF_RING];
-        ORBFE_HIP(hipEventSynchronize(e[ORBFE_T_TOTAL]));
-        float t;
-        for (int i = 0; i < ORBFE_T_TOTAL; ++i) {
-            ORBFE_HIP(hipEventElapsedTime(&t, e[i], e[i + 1]));
+        ORBFE_HIP(hipEventSynchronize(e[5]));
+        ORBFE_HIP(hipEventSynchronize(e[7]));
+        static const int from[ORBFE_T_COUNT] = {0, 1, 2, 6, 4, 0}, to[ORBFE_T_COUNT] = {1, 2, 3, 7, 5, 5};
+        for (int i = 0; i < ORBFE_T_COUNT; ++i) {
+            float t;
+            ORBFE_HIP(hipEventElapsedTime(&t, e[from[i]], e[to[i]]));
             acc[i] += t;
         }
-        ORBFE_HIP(hipEventElapsedTime(&t, e[0], e[ORBFE_T_TOTAL]));
-        acc[ORBFE_T_TOTAL] += t;
     }
     for (int i = 0; i < ORBFE_T_COUNT; ++i) ms[i] = (float)(acc[i] / ncalls);
     return ORBFE_OK;
@@ -671,11 +690,29 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     if (ev) ORBFE_HIP(hipEventRecord(ev[0], st));
     ORBFE_HIP(orbk_launch_pyramid(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[1], st));
+    const int ov = h->overlap;
+    auto fork_blur = [&]() -> hipError_t {
+        hipError_t e = hipEventRecord(h->ev_fork, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->ev_fork, 0);
+        if (e == hipSuccess && ev) e = hipEventRecord(ev[6], h->side);
+        if (e == hipSuccess) e = orbk_launch_blur(a, h->side);
+        if (e == hipSuccess && ev) e = hipEventRecord(ev[7], h->side);
+        if (e == hipSuccess) e = hipEventRecord(h->ev_join, h->side);
+        return e;
+    };
+    if (ov == 1) ORBFE_HIP(fork_blur());
     ORBFE_HIP(orbk_launch_fast(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[2], st));
+    if (ov == 2) ORBFE_HIP(fork_blur());
     ORBFE_HIP(orbk_launch_octree(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[3], st));
-    ORBFE_HIP(orbk_launch_blur(a, st));
+    if (ov == 0) {
+        if (ev) ORBFE_HIP(hipEventRecord(ev[6], st));
+        ORBFE_HIP(orbk_launch_blur(a, st));
+        if (ev) ORBFE_HIP(hipEventRecord(ev[7], st));
+    } else {
+        ORBFE_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    }
     if (ev) ORBFE_HIP(hipEventRecord(ev[4], st));
     ORBFE_HIP(orbk_launch_describe(a, st));
     if (ev) {

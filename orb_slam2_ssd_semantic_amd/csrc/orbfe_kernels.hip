@@ -238,6 +238,18 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(orb_s2, a), __builtin_bit_cast(orb_s2, b)));
 }
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, a) - __builtin_bit_cast(orb_u2, b));
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(orb_u2, a), __builtin_bit_cast(orb_u2, b)));
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(orb_u2, a), __builtin_bit_cast(orb_u2, b)));
+}
 __device__ __forceinline__ uint32_t pk_subsat_u16(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(orb_u2, a), __builtin_bit_cast(orb_u2, b)));
@@ -253,13 +265,13 @@ __device__ __forceinline__ uint32_t rowpair(const uint32_t (&w)[3])
     return __builtin_amdgcn_perm(w[(IDX >> 2) + 1 > 2 ? 2 : (IDX >> 2) + 1], w[IDX >> 2], 0x0c040c03u);
 }
 
-// arc strengths of the pixel pair (J, J+1) of the lane, as two i16 halves;
+// thresholded arc strengths S = max(A - t, 0) of the pixel pair (J, J+1) of the lane, as two u16 halves;
 // R[dy+3] = 12-byte window (pixels x-4 .. x+7) of image row y+dy
 template <int J>
 __device__ __forceinline__ uint32_t fast_strength_pair(const uint32_t (&rm3)[3], const uint32_t (&rm2)[3],
                                                        const uint32_t (&rm1)[3], const uint32_t (&r0)[3],
                                                        const uint32_t (&rp1)[3], const uint32_t (&rp2)[3],
-                                                       const uint32_t (&rp3)[3])
+                                                       const uint32_t (&rp3)[3], uint32_t t)
 {
     uint32_t c[16];
     c[0] = rowpair<4 + J>(rp3);
@@ -279,29 +291,29 @@ __device__ __forceinline__ uint32_t fast_strength_pair(const uint32_t (&rm3)[3],
     c[14] = rowpair<2 + J>(rp2);
     c[15] = rowpair<3 + J>(rp3);
     const uint32_t v = rowpair<4 + J>(r0);
-    uint32_t lo3[16], hi3[16];
+    // Nine-arcs k and k+1 (k even) share the eight pixels c[k+1..k+8], so
+    //   max(min arc_k, min arc_k+1) = min(c[k+1..k+8], max(c[k], c[k+9]))     (and dually for the dark polarity):
+    // odd-aligned pairs P/Q, one 3-way and one closing 3-way op per arc pair -- 36 ops per polarity for all 16 arcs.
+    uint32_t P[8], Q[8], ex[8], en[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        lo3[k] = pk_min3(c[k], c[(k + 1) & 15], c[(k + 2) & 15]);
-        hi3[k] = pk_max3(c[k], c[(k + 1) & 15], c[(k + 2) & 15]);
+    for (int i = 0; i < 8; ++i) {
+        P[i] = pk_min_u16(c[2 * i + 1], c[(2 * i + 2) & 15]);
+        Q[i] = pk_max_u16(c[2 * i + 1], c[(2 * i + 2) & 15]);
+        ex[i] = pk_max_u16(c[2 * i], c[(2 * i + 9) & 15]);
+        en[i] = pk_min_u16(c[2 * i], c[(2 * i + 9) & 15]);
     }
-    uint32_t lo9[16], hi9[16];
+    uint32_t Wb[8], Wd[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        lo9[k] = pk_min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);  // min of the nine-arc starting at k
-        hi9[k] = pk_max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);  // max of the nine-arc starting at k
+    for (int i = 0; i < 8; ++i) {
+        Wb[i] = pk_min3(pk_min3(P[i], P[(i + 1) & 7], P[(i + 2) & 7]), P[(i + 3) & 7], ex[i]);
+        Wd[i] = pk_max3(pk_max3(Q[i], Q[(i + 1) & 7], Q[(i + 2) & 7]), Q[(i + 3) & 7], en[i]);
     }
-    uint32_t maxmin = pk_max3(lo9[0], lo9[1], lo9[2]);
-    uint32_t minmax = pk_min3(hi9[0], hi9[1], hi9[2]);
-#pragma unroll
-    for (int k = 3; k < 15; k += 2) {
-        maxmin = pk_max3(maxmin, lo9[k], lo9[k + 1]);
-        minmax = pk_min3(minmax, hi9[k], hi9[k + 1]);
-    }
-    maxmin = pk_max3(maxmin, lo9[15], lo9[15]);
-    minmax = pk_min3(minmax, hi9[15], hi9[15]);
-    // A = max(v - min_arcs(max), max_arcs(min) - v)
-    return pk_max_i16(pk_sub_i16(v, minmax), pk_sub_i16(maxmin, v));
+    const uint32_t maxmin = pk_max_u16(pk_max3(pk_max3(pk_max3(Wb[0], Wb[1], Wb[2]), Wb[3], Wb[4]), Wb[5], Wb[6]), Wb[7]);
+    const uint32_t minmax = pk_min_u16(pk_min3(pk_min3(pk_min3(Wd[0], Wd[1], Wd[2]), Wd[3], Wd[4]), Wd[5], Wd[6]), Wd[7]);
+    // S = max(A, t) - t with A = max(v - min_arcs(max), max_arcs(min) - v, 0): zero for non-corners (A <= t), order
+    // preserving for corners; t = 0x3FF in a half switches the pixel off (A <= 255)
+    const uint32_t m = pk_max3(pk_subsat_u16(v, minmax), pk_subsat_u16(maxmin, v), t);
+    return pk_sub_u16(m, t);
 }
 
 __device__ __forceinline__ int lanes_below(unsigned long long m)
@@ -309,7 +321,17 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 
-#define FM_BUF 256  // per-wave LDS staging of survivors before one atomic reserves their run in the level's list
+#define FM_BUF 384       // per-wave LDS staging of survivors before one atomic reserves their run in the level's list
+#define FM_ROW_MAX 140   // a row adds at most 2 per lane + 1 per lane that straddles a cell seam (<= 9 of them)
+
+__device__ __forceinline__ void fm_flush(uint2 *slist, int32_t *scnt, const uint2 *sbuf, int nbuf, int key_cap, int lane)
+{
+    int base = 0;
+    if (lane == 0) base = atomicAdd(scnt, nbuf);
+    base = __shfl(base, 0, 64);
+    for (int i = lane; i < nbuf; i += 64)
+        if (base + i < key_cap) slist[base + i] = sbuf[i];
+}
 
 __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ plan, FrameSrc fs,
                                                   const OrbLane *__restrict__ lanes, int nwaves,
@@ -333,17 +355,15 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
     int32_t *scnt = scount + (b * plan->nlevels + level) * ORBFE_NK_STRIDE;
     uint2 *sbuf = s_buf[wv];
     int nbuf = 0;  // wave-uniform fill of sbuf
-    const int W = L.w, H = L.h;
+    const int H = L.h, key_cap = L.key_cap;
     const int ix0 = ORBFE_EDGE, iy0 = ORBFE_EDGE, ix1 = L.ix1, iy1 = L.iy1;
     const int wcell = L.wcell, hcell = L.hcell;
-    const int x = ld.x;                 // first pixel of this lane
+    const int x = ld.x;                 // first pixel of this lane (16 <= x < ix1: the 12-byte row window is in the image)
     const int ys = ld.ys;
-    const int yend = ys + ld.nrows;     // output rows [ys, yend) of this lane
     int nsteps = ld.nrows;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
-    nsteps += 8;                        // wave-uniform
-    const bool loadable = x < W;
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps) + 8;  // wave-uniform, and the compiler knows it
     const int tz = max(plan->min_th, 1);
 
     // per-lane column masks: bit j = pixel j inside the interior / has a valid left / right neighbour in its cell
@@ -358,7 +378,18 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
             if (m != wcell - 1 && xx + 1 < ix1) rvalid |= 1 << j;
         }
     }
+    auto halves = [](int bits, int j) -> uint32_t {
+        return (((bits >> j) & 1) ? 0xFFFFu : 0u) | (((bits >> (j + 1)) & 1) ? 0xFFFF0000u : 0u);
+    };
+    const uint32_t in01 = halves(inside, 0), in23 = halves(inside, 2);
+    const uint32_t lv01 = halves(lvalid, 0), lv23 = halves(lvalid, 2);
+    const uint32_t rv01 = halves(rvalid, 0), rv23 = halves(rvalid, 2);
+    // a cell seam between the two pixels of a pair lets BOTH be NMS survivors; at most one pair of a lane has one
+    const bool split01 = (inside & 3) == 3 && !(lvalid & 2), split23 = (inside & 12) == 12 && !(lvalid & 8);
+    const uint32_t sm01 = split01 ? 0xFFFFFFFFu : 0u, sm23 = split23 ? 0xFFFFFFFFu : 0u;
+    const bool wave_split = __ballot(split01 || split23) != 0ull;
     const bool out_lane = !(ld.flags & 1) && inside != 0;
+    const int nrows_out = out_lane ? (int)ld.nrows : 0;
     // per-pixel part of `ord`, the rank key of the reference's candidate order (cell-row-major, raster inside a cell):
     // ord = (cell_row * ncc + cell_col) << 12 | y_in_cell << 6 | x_in_cell
     uint32_t ordx[4];
@@ -368,34 +399,36 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
         const int cc = rel / wcell;
         ordx[j] = ((uint32_t)cc << 12) | (uint32_t)(rel - cc * wcell);
     }
-    int crow = (ys - iy0) / hcell;  // cell row of the next NMS row (per lane)
+    int rmod = (ys - iy0) % hcell;                                  // y_in_cell of the next NMS row (per lane)
+    uint32_t ordy = ((uint32_t)(((ys - iy0) / hcell) * L.ncc) << 12) | ((uint32_t)rmod << 6);
+    const uint32_t ord_wrap = ((uint32_t)L.ncc << 12) - ((uint32_t)hcell << 6);  // added when a new cell row starts
     const uint32_t tzz = (uint32_t)tz * 0x00010001u;
-    const uint32_t in01 = ((inside & 1) ? 0xFFFFu : 0u) | ((inside & 2) ? 0xFFFF0000u : 0u);
-    const uint32_t in23 = ((inside & 4) ? 0xFFFFu : 0u) | ((inside & 8) ? 0xFFFF0000u : 0u);
+    const uint32_t resp0 = (uint32_t)(tz - 1);
+    const int ysrel = ys - 7 - iy0;                                 // strength row of step s, relative to iy0, minus s
+    const uint32_t hrange = (uint32_t)(iy1 - iy0);
+    // key of pixel 0 in the NMS row of step 0 (detection-window coordinates = level - 16, reference :831-832)
+    const uint32_t key00 = (uint32_t)(x - ORBFE_MINB) + ((uint32_t)(ys - 8 - ORBFE_MINB) << 12);
+    const uint8_t *col = src + x;
 
     uint32_t R[7][3];
+    uint32_t S01[7], S23[7];  // S of the pixel pairs (0,1), (2,3) for the strength row computed in ring slot k
 #pragma unroll
-    for (int k = 0; k < 7; ++k) R[k][0] = R[k][1] = R[k][2] = 0u;
-    // E windows of the last three strength rows: lo = [E(x-1), E0, E1, E2], hi = [E3, E(x+4)]
-    uint32_t Ulo = 0, Uhi = 0, Mlo = 0, Mhi = 0, Dlo = 0, Dhi = 0;
-    int rmod = (ys - iy0) % hcell;  // (rn - iy0) % hcell of the next NMS row (per lane)
+    for (int k = 0; k < 7; ++k) R[k][0] = R[k][1] = R[k][2] = S01[k] = S23[k] = 0u;
 
     for (int s0 = 0; s0 < nsteps; s0 += 7) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int s = s0 + k;
             if (s >= nsteps) break;    // wave-uniform
-            const int r = ys - 4 + s;  // image row loaded in this step (lanes past their run re-read a valid row)
-            if (loadable) {
-                const uint8_t *row = src + (int64_t)min(r, H - 1) * pitch + x;
+            {
+                const int r = ys - 4 + s;  // image row loaded in this step (lanes past their run re-read a valid row)
+                const uint8_t *row = col + (int64_t)min(r, H - 1) * pitch;
                 R[k][0] = *(const uint32_t *)(row - 4);
                 R[k][1] = *(const uint32_t *)(row);
                 R[k][2] = *(const uint32_t *)(row + 4);
             }
             if (s < 6) continue;
             // ---- strength row rc = r - 3 (newest ring slot k is row rc+3, slot (k+1)%7 is row rc-3) ----
-            const int rc = r - 3;
-            uint32_t e = 0;
             {
                 const uint32_t(&rm3)[3] = R[(k + 1) % 7];
                 const uint32_t(&rm2)[3] = R[(k + 2) % 7];
@@ -404,87 +437,75 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
                 const uint32_t(&rp1)[3] = R[(k + 5) % 7];
                 const uint32_t(&rp2)[3] = R[(k + 6) % 7];
                 const uint32_t(&rp3)[3] = R[k];
-                // A > 0 half-words clamped, then S = max(A - tz, 0): zero for non-corners, order preserving for corners
-                const uint32_t a01 = pk_max_i16(fast_strength_pair<0>(rm3, rm2, rm1, r0, rp1, rp2, rp3), 0u);
-                const uint32_t a23 = pk_max_i16(fast_strength_pair<2>(rm3, rm2, rm1, r0, rp1, rp2, rp3), 0u);
-                const uint32_t s01 = pk_subsat_u16(a01, tzz) & in01;
-                const uint32_t s23 = pk_subsat_u16(a23, tzz) & in23;
-                e = __builtin_amdgcn_perm(s23, s01, 0x06040200u);  // bytes [S0, S1, S2, S3]
-                if (rc < iy0 || rc >= iy1) e = 0u;
+                const bool rowok = (uint32_t)(ysrel + s) < hrange;  // iy0 <= rc < iy1
+                const uint32_t tt = rowok ? tzz : 0x03FF03FFu;
+                S01[k] = fast_strength_pair<0>(rm3, rm2, rm1, r0, rp1, rp2, rp3, tt) & in01;
+                S23[k] = fast_strength_pair<2>(rm3, rm2, rm1, r0, rp1, rp2, rp3, tt) & in23;
             }
-            const uint32_t eL = (uint32_t)__shfl_up((int)e, 1, 64);
-            const uint32_t eR = (uint32_t)__shfl_down((int)e, 1, 64);
-            Ulo = Mlo; Uhi = Mhi;
-            Mlo = Dlo; Mhi = Dhi;
-            Dlo = (e << 8) | (eL >> 24);
-            Dhi = (e >> 24) | ((eR & 0xFFu) << 8);
             if (s < 8) continue;
-            // ---- NMS row rn = rc - 1 ----
-            const int rn = rc - 1;
-            const bool up_ok = rmod != 0;
-            const bool dn_ok = (rmod != hcell - 1) && (rn + 1 < iy1);
-            const uint32_t ordy = ((uint32_t)(crow * L.ncc) << 12) | ((uint32_t)rmod << 6);
-            if (++rmod == hcell) { rmod = 0; ++crow; }
-            const bool row_out = rn < yend;  // per lane
-            const uint32_t ulo = up_ok ? Ulo : 0u, uhi = up_ok ? Uhi : 0u;
-            const uint32_t dlo = dn_ok ? Dlo : 0u, dhi = dn_ok ? Dhi : 0u;
-            int U[6], Mi[6], D[6];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                U[p] = (ulo >> (8 * p)) & 0xFF;
-                Mi[p] = (Mlo >> (8 * p)) & 0xFF;
-                D[p] = (dlo >> (8 * p)) & 0xFF;
+            // ---- 3x3 strict NMS of row rn = rc - 1 on packed pairs: rows U = S[k-2], M = S[k-1], D = S[k] ----
+            const int ku = (k + 5) % 7, km = (k + 6) % 7;
+            const bool up_ok = rmod != 0;            // neighbours outside the own cell count as 0
+            const bool dn_ok = rmod != hcell - 1;    // (the row at iy1 is already all zero)
+            const uint32_t ord_row = ordy;
+            {
+                const bool wrap = rmod == hcell - 1;
+                rmod = wrap ? 0 : rmod + 1;
+                ordy += wrap ? 64u + ord_wrap : 64u;
             }
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                U[4 + p] = (uhi >> (8 * p)) & 0xFF;
-                Mi[4 + p] = (Mhi >> (8 * p)) & 0xFF;
-                D[4 + p] = (dhi >> (8 * p)) & 0xFF;
-            }
-            int col[6];
-#pragma unroll
-            for (int p = 0; p < 6; ++p) col[p] = max3i(U[p], Mi[p], D[p]);
-            int surv[4], cnt = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int lc = (lvalid >> j) & 1 ? col[j] : 0;
-                const int rc2 = (rvalid >> j) & 1 ? col[j + 2] : 0;
-                const int nb = max3i(lc, rc2, max(U[j + 1], D[j + 1]));
-                const int m = Mi[j + 1];
-                surv[j] = (out_lane && row_out && m > nb) ? m + tz : 0;  // A of an NMS survivor (cv score = A - 1), else 0
-                cnt += surv[j] != 0;
-            }
-            // cnt <= 2 (no two horizontally adjacent survivors): wave prefix from the two count bits
-            const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2);
-            if (b0 | b1) {
-                int k = nbuf + lanes_below(b0) + 2 * lanes_below(b1);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (surv[j]) {
-                        // detection-window coordinates (level - 16) == tile-relative + j*wCell of the reference (:831-832)
-                        sbuf[k] = make_uint2(orb_pack_key(x + j - ORBFE_MINB, rn - ORBFE_MINB, surv[j] - 1),
-                                             ordy + ordx[j]);
-                        ++k;
+            const uint32_t u01 = up_ok ? S01[ku] : 0u, u23 = up_ok ? S23[ku] : 0u;
+            const uint32_t d01 = dn_ok ? S01[k] : 0u, d23 = dn_ok ? S23[k] : 0u;
+            const uint32_t m01 = S01[km], m23 = S23[km];
+            const uint32_t v01 = pk_max_u16(u01, d01), v23 = pk_max_u16(u23, d23);   // vertical neighbours
+            const uint32_t c01 = pk_max_u16(v01, m01), c23 = pk_max_u16(v23, m23);   // column maxima
+            const uint32_t cL = (uint32_t)__shfl_up((int)c23, 1, 64);                // .hi = column x-1
+            const uint32_t cR = (uint32_t)__shfl_down((int)c01, 1, 64);              // .lo = column x+4
+            const uint32_t l01 = __builtin_amdgcn_alignbit(c01, cL, 16) & lv01;      // columns (x-1, x)
+            const uint32_t x12 = __builtin_amdgcn_alignbit(c23, c01, 16);            // columns (x+1, x+2)
+            const uint32_t r23 = __builtin_amdgcn_alignbit(cR, c23, 16) & rv23;      // columns (x+3, x+4)
+            const uint32_t n01 = pk_max3(l01, x12 & rv01, v01);
+            const uint32_t n23 = pk_max3(x12 & lv23, r23, v23);
+            const uint32_t g01 = pk_subsat_u16(m01, n01), g23 = pk_subsat_u16(m23, n23);  // != 0 <=> survivor
+            const bool row_out = s - 8 < nrows_out;  // per lane
+            const bool has01 = row_out && g01 != 0u, has23 = row_out && g23 != 0u;
+            const unsigned long long b01 = __ballot(has01), b23 = __ballot(has23);
+            if (b01 | b23) {
+                const uint32_t keyrow = key00 + ((uint32_t)s << 12);
+                const int p01 = __popcll(b01);
+                if (has01) {
+                    const bool hi = g01 > 0xFFFFu;
+                    const uint32_t a = hi ? m01 >> 16 : m01 & 0xFFFFu;
+                    sbuf[nbuf + lanes_below(b01)] = make_uint2(keyrow + (hi ? 1u : 0u) + ((a + resp0) << 24),
+                                                               ord_row + (hi ? ordx[1] : ordx[0]));
+                }
+                if (has23) {
+                    const bool hi = g23 > 0xFFFFu;
+                    const uint32_t a = hi ? m23 >> 16 : m23 & 0xFFFFu;
+                    sbuf[nbuf + p01 + lanes_below(b23)] = make_uint2(keyrow + (hi ? 3u : 2u) + ((a + resp0) << 24),
+                                                                     ord_row + (hi ? ordx[3] : ordx[2]));
+                }
+                nbuf += p01 + __popcll(b23);
+                if (wave_split) {  // both pixels of a seam pair survived: the low one is still to be written
+                    const uint32_t gs = (g01 & sm01) | (g23 & sm23);
+                    const bool dbl = row_out && (gs & 0xFFFFu) != 0u && gs > 0xFFFFu;
+                    const unsigned long long bd = __ballot(dbl);
+                    if (bd) {
+                        if (dbl) {
+                            const uint32_t a = (split23 ? m23 : m01) & 0xFFFFu;
+                            sbuf[nbuf + lanes_below(bd)] = make_uint2(keyrow + (split23 ? 2u : 0u) + ((a + resp0) << 24),
+                                                                      ord_row + (split23 ? ordx[2] : ordx[0]));
+                        }
+                        nbuf += __popcll(bd);
                     }
-                nbuf += __popcll(b0) + 2 * __popcll(b1);
-                if (nbuf > FM_BUF - 128) {  // a row adds at most 124: flush before the next one could overflow
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(scnt, nbuf);
-                    base = __shfl(base, 0, 64);
-                    for (int i = lane; i < nbuf; i += 64)
-                        if (base + i < L.key_cap) slist[base + i] = sbuf[i];
+                }
+                if (nbuf > FM_BUF - FM_ROW_MAX) {
+                    fm_flush(slist, scnt, sbuf, nbuf, key_cap, lane);
                     nbuf = 0;
                 }
             }
         }
     }
-    if (nbuf > 0) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(scnt, nbuf);
-        base = __shfl(base, 0, 64);
-        for (int i = lane; i < nbuf; i += 64)
-            if (base + i < L.key_cap) slist[base + i] = sbuf[i];
-    }
+    if (nbuf > 0) fm_flush(slist, scnt, sbuf, nbuf, key_cap, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -750,7 +771,7 @@ __device__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur
     modeB = modeB2;
 }
 
-__global__ __launch_bounds__(QT_MAX, 4) void k_octree(const OrbPlan *__restrict__ plan,
+__global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict__ plan,
                                                const uint2 *__restrict__ skeys,     // [B][keys_per_frame] {key, ord} from k_fast_map
                                                const int32_t *__restrict__ scount,  // [B][nlevels] * NK_STRIDE
                                                uint32_t *__restrict__ keys,         // [B][keys_per_frame] scratch: filtered keys

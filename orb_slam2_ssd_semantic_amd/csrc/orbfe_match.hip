@@ -642,3 +642,231 @@ extern "C" orbfe_status orbfe_hamming_csr(orbfe_matcher *m, const uint8_t *q, in
     ORBFE_HIP(hipStreamSynchronize(st));
     return ORBFE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// SURVEY 8(f).2  Frame grid index: AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea (src/Frame.cc:319-334, 465-531)
+// ---------------------------------------------------------------------------------------------------
+#define GRID_NC (ORBFE_GRID_COLS * ORBFE_GRID_ROWS)
+
+__device__ __forceinline__ int grid_cell_of(float x, float y, float minx, float miny, float gwi, float ghi)
+{
+    const int px = (int)roundf(__fmul_rn(__fsub_rn(x, minx), gwi));  // :525 std::round(float)
+    const int py = (int)roundf(__fmul_rn(__fsub_rn(y, miny), ghi));
+    if (px < 0 || px >= ORBFE_GRID_COLS || py < 0 || py >= ORBFE_GRID_ROWS) return -1;
+    return px * ORBFE_GRID_ROWS + py;
+}
+
+// one workgroup: histogram over the 3072 cells (LDS), scan, placement, then each cell's short list is put into
+// ascending keypoint order (the reference push_backs in keypoint order)
+__global__ __launch_bounds__(1024) void k_assign_grid(const float *__restrict__ xy, int n, float minx, float miny, float gwi,
+                                                      float ghi, uint32_t *__restrict__ cell_off,
+                                                      uint32_t *__restrict__ cell_idx, int32_t *__restrict__ n_in)
+{
+    __shared__ uint32_t s_cnt[GRID_NC], s_off[GRID_NC + 1];
+    __shared__ uint32_t s_part[1024];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < GRID_NC; c += 1024) s_cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int c = grid_cell_of(xy[2 * i], xy[2 * i + 1], minx, miny, gwi, ghi);
+        if (c >= 0) atomicAdd(&s_cnt[c], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of 3072 counters: 3 per thread
+    uint32_t loc[3], sum = 0;
+    for (int k = 0; k < 3; ++k) { loc[k] = s_cnt[tid * 3 + k]; sum += loc[k]; }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = tid >= d ? s_part[tid - d] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t base = s_part[tid] - sum;
+    for (int k = 0; k < 3; ++k) { s_off[tid * 3 + k] = base; base += loc[k]; }
+    if (tid == 1023) s_off[GRID_NC] = s_part[1023];
+    __syncthreads();
+    for (int c = tid; c <= GRID_NC; c += 1024) cell_off[c] = s_off[c];
+    if (tid == 0) *n_in = (int32_t)s_off[GRID_NC];
+    for (int c = tid; c < GRID_NC; c += 1024) s_cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int c = grid_cell_of(xy[2 * i], xy[2 * i + 1], minx, miny, gwi, ghi);
+        if (c >= 0) cell_idx[s_off[c] + atomicAdd(&s_cnt[c], 1u)] = (uint32_t)i;
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (int c = tid; c < GRID_NC; c += 1024) {  // insertion sort of the (short) cell lists
+        const uint32_t o = s_off[c], e = s_off[c + 1];
+        for (uint32_t a = o + 1; a < e; ++a) {
+            const uint32_t v = cell_idx[a];
+            uint32_t bpos = a;
+            while (bpos > o && cell_idx[bpos - 1] > v) { cell_idx[bpos] = cell_idx[bpos - 1]; --bpos; }
+            cell_idx[bpos] = v;
+        }
+    }
+}
+
+// GetFeaturesInArea for query i; write == false only counts.  Returns the count.
+__device__ int area_query(const float *__restrict__ xy, const int32_t *__restrict__ octave,
+                          const uint32_t *__restrict__ cell_off, const uint32_t *__restrict__ cell_idx, float minx,
+                          float miny, float gwi, float ghi, float x, float y, float r, int minL, int maxL,
+                          uint32_t *out, bool write)
+{
+    int nminx = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minx), r), gwi));  // :470
+    nminx = max(nminx, 0);
+    if (nminx >= ORBFE_GRID_COLS) return 0;
+    int nmaxx = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, minx), r), gwi));
+    nmaxx = min(nmaxx, ORBFE_GRID_COLS - 1);
+    if (nmaxx < 0) return 0;
+    int nminy = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, miny), r), ghi));
+    nminy = max(nminy, 0);
+    if (nminy >= ORBFE_GRID_ROWS) return 0;
+    int nmaxy = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, miny), r), ghi));
+    nmaxy = min(nmaxy, ORBFE_GRID_ROWS - 1);
+    if (nmaxy < 0) return 0;
+    const bool check = (minL > 0) || (maxL >= 0);  // :486
+    int cnt = 0;
+    for (int ix = nminx; ix <= nmaxx; ++ix)
+        for (int iy = nminy; iy <= nmaxy; ++iy) {
+            const int c = ix * ORBFE_GRID_ROWS + iy;
+            for (uint32_t j = cell_off[c]; j < cell_off[c + 1]; ++j) {
+                const uint32_t k = cell_idx[j];
+                if (check) {
+                    const int o = octave[k];
+                    if (o < minL) continue;
+                    if (maxL >= 0 && o > maxL) continue;
+                }
+                const float dx = __fsub_rn(xy[2 * k], x), dy = __fsub_rn(xy[2 * k + 1], y);
+                if (fabsf(dx) < r && fabsf(dy) < r) {
+                    if (write) out[cnt] = k;
+                    ++cnt;
+                }
+            }
+        }
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void k_area_count(const float *xy, const int32_t *octave, const uint32_t *cell_off,
+                                                    const uint32_t *cell_idx, float minx, float miny, float gwi,
+                                                    float ghi, const float *qxyr, const int32_t *qlv, int nq,
+                                                    uint32_t *cnt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    cnt[i] = (uint32_t)area_query(xy, octave, cell_off, cell_idx, minx, miny, gwi, ghi, qxyr[3 * i], qxyr[3 * i + 1],
+                                  qxyr[3 * i + 2], qlv ? qlv[2 * i] : -1, qlv ? qlv[2 * i + 1] : -1, nullptr, false);
+}
+
+// single-workgroup exclusive scan cnt[0..nq) -> off[0..nq]
+__global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ cnt, int nq, uint32_t *__restrict__ off)
+{
+    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nq; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = i < nq ? cnt[i] : 0u;
+        s_part[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const uint32_t t = tid >= d ? s_part[tid - d] : 0u;
+            __syncthreads();
+            s_part[tid] += t;
+            __syncthreads();
+        }
+        if (i < nq) off[i] = s_carry + s_part[tid] - v;
+        __syncthreads();
+        if (tid == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) off[nq] = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_area_write(const float *xy, const int32_t *octave, const uint32_t *cell_off,
+                                                    const uint32_t *cell_idx, float minx, float miny, float gwi,
+                                                    float ghi, const float *qxyr, const int32_t *qlv, int nq,
+                                                    const uint32_t *off, uint32_t *cand, uint32_t cap)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq || off[nq] > cap) return;
+    area_query(xy, octave, cell_off, cell_idx, minx, miny, gwi, ghi, qxyr[3 * i], qxyr[3 * i + 1], qxyr[3 * i + 2],
+               qlv ? qlv[2 * i] : -1, qlv ? qlv[2 * i + 1] : -1, cand + off[i], true);
+}
+
+extern "C" orbfe_status orbfe_assign_grid(orbfe_matcher *m, const float *xy, int32_t n, float minx, float miny,
+                                          float gw_inv, float gh_inv, uint32_t *cell_off, uint32_t *cell_idx,
+                                          int32_t *n_in_grid)
+{
+    if (!m || n < 0 || !cell_off || (n > 0 && (!xy || !cell_idx))) {
+        orbfe_set_error("bad argument to orbfe_assign_grid");
+        return ORBFE_ERR_ARG;
+    }
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    ORBFE_HIP(m->b[0].ensure((size_t)n * 8));
+    ORBFE_HIP(m->b[1].ensure((size_t)(GRID_NC + 1) * 4));
+    ORBFE_HIP(m->b[2].ensure((size_t)n * 4));
+    ORBFE_HIP(m->b[3].ensure(4));
+    if (n > 0) ORBFE_HIP(hipMemcpyAsync(m->b[0].p, xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_assign_grid, dim3(1), dim3(1024), 0, st, (const float *)m->b[0].p, n, minx, miny, gw_inv, gh_inv,
+                       (uint32_t *)m->b[1].p, (uint32_t *)m->b[2].p, (int32_t *)m->b[3].p);
+    ORBFE_HIP(hipGetLastError());
+    int32_t nin = 0;
+    ORBFE_HIP(hipMemcpyAsync(cell_off, m->b[1].p, (size_t)(GRID_NC + 1) * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipMemcpyAsync(&nin, m->b[3].p, 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    if (nin > 0) ORBFE_HIP(hipMemcpy(cell_idx, m->b[2].p, (size_t)nin * 4, hipMemcpyDeviceToHost));
+    if (n_in_grid) *n_in_grid = nin;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy, const int32_t *octave, int32_t n,
+                                               const uint32_t *cell_off, const uint32_t *cell_idx, float minx,
+                                               float miny, float gw_inv, float gh_inv, const float *qxyr,
+                                               const int32_t *qlevels, int32_t nq, uint32_t *off, uint32_t *cand,
+                                               int32_t cap)
+{
+    if (!m || n < 0 || nq < 0 || cap < 0 || !cell_off || !off || (nq > 0 && !qxyr) || (n > 0 && (!xy || !octave || !cell_idx))) {
+        orbfe_set_error("bad argument to orbfe_features_in_area");
+        return ORBFE_ERR_ARG;
+    }
+    const uint32_t nin = cell_off[GRID_NC];
+    if (nin > (uint32_t)n) { orbfe_set_error("cell_off inconsistent with n"); return ORBFE_ERR_ARG; }
+    for (int c = 0; c < GRID_NC; ++c)
+        if (cell_off[c + 1] < cell_off[c]) { orbfe_set_error("cell_off must not decrease"); return ORBFE_ERR_ARG; }
+    for (uint32_t k = 0; k < nin; ++k)
+        if (cell_idx[k] >= (uint32_t)n) { orbfe_set_error("cell_idx out of range"); return ORBFE_ERR_ARG; }
+    off[0] = 0;
+    if (nq == 0) return ORBFE_OK;
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    const size_t sz[8] = {(size_t)n * 8, (size_t)n * 4, (size_t)(GRID_NC + 1) * 4, (size_t)nin * 4, (size_t)nq * 12,
+                          (size_t)nq * 8, (size_t)(nq + 1) * 4, (size_t)nq * 4};
+    for (int i = 0; i < 8; ++i) ORBFE_HIP(m->b[i].ensure(sz[i]));
+    ORBFE_HIP(m->b[8].ensure((size_t)std::max(cap, 1) * 4));
+    const void *src[6] = {xy, octave, cell_off, cell_idx, qxyr, qlevels};
+    for (int i = 0; i < 6; ++i)
+        if (src[i] && sz[i]) ORBFE_HIP(hipMemcpyAsync(m->b[i].p, src[i], sz[i], hipMemcpyHostToDevice, st));
+    const int32_t *dql = qlevels ? (const int32_t *)m->b[5].p : nullptr;
+    hipLaunchKernelGGL(k_area_count, dim3((nq + 255) / 256), dim3(256), 0, st, (const float *)m->b[0].p,
+                       (const int32_t *)m->b[1].p, (const uint32_t *)m->b[2].p, (const uint32_t *)m->b[3].p, minx, miny,
+                       gw_inv, gh_inv, (const float *)m->b[4].p, dql, nq, (uint32_t *)m->b[7].p);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, (const uint32_t *)m->b[7].p, nq, (uint32_t *)m->b[6].p);
+    hipLaunchKernelGGL(k_area_write, dim3((nq + 255) / 256), dim3(256), 0, st, (const float *)m->b[0].p,
+                       (const int32_t *)m->b[1].p, (const uint32_t *)m->b[2].p, (const uint32_t *)m->b[3].p, minx, miny,
+                       gw_inv, gh_inv, (const float *)m->b[4].p, dql, nq, (const uint32_t *)m->b[6].p,
+                       (uint32_t *)m->b[8].p, (uint32_t)cap);
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpyAsync(off, m->b[6].p, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    if (off[nq] > (uint32_t)cap) {
+        orbfe_set_error("cap=%d too small for %u candidates", cap, off[nq]);
+        return ORBFE_ERR_CAP;
+    }
+    if (off[nq] > 0) ORBFE_HIP(hipMemcpy(cand, m->b[8].p, (size_t)off[nq] * 4, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}

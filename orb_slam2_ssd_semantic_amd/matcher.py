@@ -114,3 +114,52 @@ class ORBmatcher:
                                        ptr(s))
         check(st, "orbfe_hamming_csr")
         return bi, b, s
+
+
+class FrameGrid:
+    """Device-built mGrid of a Frame (reference src/Frame.cc:319-334) + batched GetFeaturesInArea (:465-518).
+
+    `FrameGrid(matcher, keysUn_xy, octaves, minX, minY, gridElementWidthInv, gridElementHeightInv)`; then
+    `GetFeaturesInArea(x, y, r, minLevel=-1, maxLevel=-1)` for one query or `query(qxyr, qlevels)` for a batch
+    (CSR result to feed `ORBmatcher.HammingCSR`)."""
+    COLS, ROWS = 64, 48
+
+    def __init__(self, matcher, xy, octave, minx, miny, gw_inv, gh_inv):
+        self._mt = matcher
+        self.xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        self.octave = np.ascontiguousarray(octave, np.int32)
+        self.p = (float(np.float32(minx)), float(np.float32(miny)), float(np.float32(gw_inv)), float(np.float32(gh_inv)))
+        n = len(self.xy)
+        self.cell_off = np.zeros(self.COLS * self.ROWS + 1, np.uint32)
+        self.cell_idx = np.zeros(max(n, 1), np.uint32)
+        nin = C.c_int32(0)
+        st = matcher._L.orbfe_assign_grid(matcher._m, ptr(self.xy), n, *self.p, ptr(self.cell_off), ptr(self.cell_idx),
+                                          C.byref(nin))
+        check(st, "orbfe_assign_grid")
+        self.cell_idx = self.cell_idx[:nin.value].copy()
+
+    def mGrid(self, ix, iy):
+        c = ix * self.ROWS + iy
+        return self.cell_idx[self.cell_off[c]:self.cell_off[c + 1]]
+
+    def query(self, qxyr, qlevels=None, cap=None):
+        q = np.ascontiguousarray(qxyr, np.float32).reshape(-1, 3)
+        ql = None if qlevels is None else np.ascontiguousarray(qlevels, np.int32).reshape(-1, 2)
+        nq = len(q)
+        off = np.zeros(nq + 1, np.uint32)
+        cap = cap or max(64 * nq, 1024)
+        while True:
+            cand = np.zeros(max(cap, 1), np.uint32)
+            st = self._mt._L.orbfe_features_in_area(self._mt._m, ptr(self.xy), ptr(self.octave), len(self.xy),
+                                                    ptr(self.cell_off), ptr(self.cell_idx if len(self.cell_idx) else
+                                                                            np.zeros(1, np.uint32)), *self.p,
+                                                    ptr(q), ptr(ql), nq, ptr(off), ptr(cand), cap)
+            if st == _ffi.ORBFE_ERR_CAP:
+                cap = int(off[nq])
+                continue
+            check(st, "orbfe_features_in_area")
+            return off, cand[:off[nq]].copy()
+
+    def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1):
+        off, cand = self.query([[x, y, r]], [[minLevel, maxLevel]])
+        return cand

@@ -1,0 +1,139 @@
+"""Frame grid index (AssignFeaturesToGrid / GetFeaturesInArea, reference src/Frame.cc:319-334, 465-531).
+
+CPU part: the C oracle against a definition-level Python twin.  GPU part: the HIP path (through the C-ABI) against the
+oracle, index-exact including candidate order."""
+import math
+
+import numpy as np
+import pytest
+
+F = np.float32
+
+
+def grid_case(seed, n, w=640.0, h=480.0, spill=20.0):
+    rng = np.random.default_rng(seed)
+    xy = np.stack([rng.uniform(-spill, w + spill, n), rng.uniform(-spill, h + spill, n)], 1).astype(F)
+    if n > 8:  # exact half-cell positions: round() ties away from zero
+        xy[:4, 0] = F(5.0) * np.arange(4, dtype=F)
+        xy[4:8, 1] = F(15.0) + F(10.0) * np.arange(4, dtype=F)
+    octave = rng.integers(0, 8, n).astype(np.int32)
+    minx, miny = F(0.0), F(0.0)
+    gwi = F(64) / F(w - 0.0)
+    ghi = F(48) / F(h - 0.0)
+    return xy, octave, float(minx), float(miny), float(gwi), float(ghi)
+
+
+def twin_assign(xy, minx, miny, gwi, ghi):
+    cells = [[] for _ in range(64 * 48)]
+    for i, (x, y) in enumerate(xy):
+        vx = F(F(x) - F(minx)) * F(gwi)
+        vy = F(F(y) - F(miny)) * F(ghi)
+        px = int(math.copysign(math.floor(abs(float(vx)) + 0.5), float(vx)))  # C round(): half away from zero
+        py = int(math.copysign(math.floor(abs(float(vy)) + 0.5), float(vy)))
+        if 0 <= px < 64 and 0 <= py < 48:
+            cells[px * 48 + py].append(i)
+    return cells
+
+
+def twin_area(xy, octave, cells, minx, miny, gwi, ghi, x, y, r, minL, maxL):
+    x, y, r = F(x), F(y), F(r)
+    out = []
+    a = max(0, int(math.floor(float(F(F(F(x - F(minx)) - r) * F(gwi))))))
+    if a >= 64:
+        return out
+    b = min(63, int(math.ceil(float(F(F(F(x - F(minx)) + r) * F(gwi))))))
+    if b < 0:
+        return out
+    c = max(0, int(math.floor(float(F(F(F(y - F(miny)) - r) * F(ghi))))))
+    if c >= 48:
+        return out
+    d = min(47, int(math.ceil(float(F(F(F(y - F(miny)) + r) * F(ghi))))))
+    if d < 0:
+        return out
+    chk = minL > 0 or maxL >= 0
+    for ix in range(a, b + 1):
+        for iy in range(c, d + 1):
+            for k in cells[ix * 48 + iy]:
+                if chk:
+                    if octave[k] < minL:
+                        continue
+                    if maxL >= 0 and octave[k] > maxL:
+                        continue
+                if abs(F(xy[k, 0] - x)) < r and abs(F(xy[k, 1] - y)) < r:
+                    out.append(k)
+    return out
+
+
+def queries(seed, nq):
+    rng = np.random.default_rng(1000 + seed)
+    q = np.stack([rng.uniform(-60, 700, nq), rng.uniform(-60, 540, nq), rng.uniform(1, 60, nq)], 1).astype(F)
+    lv = np.stack([rng.integers(-1, 4, nq), rng.integers(-1, 8, nq)], 1).astype(np.int32)
+    if nq > 4:
+        q[0] = (-500, 100, 10)   # entirely left of the grid
+        q[1] = (5000, 100, 10)   # entirely right
+        q[2] = (100, -900, 10)
+        q[3] = (100, 9000, 10)
+    return q, lv
+
+
+@pytest.mark.parametrize("seed,n", [(0, 1000), (1, 2000), (2, 9), (3, 0), (4, 1)])
+def test_oracle_grid_vs_twin(oracle, seed, n):
+    xy, octave, minx, miny, gwi, ghi = grid_case(seed, n)
+    off, idx = oracle.assign_grid(xy, minx, miny, gwi, ghi)
+    cells = twin_assign(xy, minx, miny, gwi, ghi)
+    assert off[0] == 0 and off[-1] == sum(len(c) for c in cells)
+    for c in range(64 * 48):
+        assert list(idx[off[c]:off[c + 1]]) == cells[c]
+    q, lv = queries(seed, 40)
+    for (x, y, r), (a, b) in zip(q, lv):
+        got = oracle.features_in_area(xy, octave, off, idx, minx, miny, gwi, ghi, float(x), float(y), float(r), int(a),
+                                      int(b))
+        assert list(got) == twin_area(xy, octave, cells, minx, miny, gwi, ghi, x, y, r, int(a), int(b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,nq", [(0, 1000, 1000), (1, 2000, 3000), (2, 9, 5), (3, 0, 7), (4, 1, 1), (5, 8000, 100),
+                                       (6, 500, 0)])
+def test_gpu_grid_parity(oracle, seed, n, nq):
+    from orb_slam2_ssd_semantic_amd import FrameGrid, ORBmatcher
+    mt = ORBmatcher(0.9, True)
+    xy, octave, minx, miny, gwi, ghi = grid_case(seed, n)
+    g = FrameGrid(mt, xy, octave, minx, miny, gwi, ghi)
+    off, idx = oracle.assign_grid(xy, minx, miny, gwi, ghi)
+    assert np.array_equal(g.cell_off, off)
+    assert np.array_equal(g.cell_idx, idx)
+    q, lv = queries(seed, nq)
+    for levels in (lv, None):
+        qoff, cand = g.query(q, levels, cap=16)  # small cap: exercises the ORBFE_ERR_CAP retry
+        assert qoff[0] == 0 and len(cand) == qoff[-1]
+        for i in range(nq):
+            a, b = (int(lv[i, 0]), int(lv[i, 1])) if levels is not None else (-1, -1)
+            ref = oracle.features_in_area(xy, octave, off, idx, minx, miny, gwi, ghi, float(q[i, 0]), float(q[i, 1]),
+                                          float(q[i, 2]), a, b)
+            assert np.array_equal(cand[qoff[i]:qoff[i + 1]], ref)
+
+
+@pytest.mark.gpu
+def test_gpu_projection_search_pipeline(oracle):
+    """grid query -> hamming_csr == the oracle's two stages chained (SearchByProjection inner loop)."""
+    from orb_slam2_ssd_semantic_amd import FrameGrid, ORBmatcher
+    rng = np.random.default_rng(7)
+    mt = ORBmatcher(0.9, True)
+    xy, octave, minx, miny, gwi, ghi = grid_case(11, 2000)
+    desc = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
+    qd = rng.integers(0, 256, (500, 32), dtype=np.uint8)
+    g = FrameGrid(mt, xy, octave, minx, miny, gwi, ghi)
+    q, lv = queries(11, 500)
+    off, cand = g.query(q, lv)
+    bi, b, s = mt.HammingCSR(qd, desc, off, cand)
+    rbi, rb, rs = oracle.hamming_csr(qd, desc, off, cand)
+    assert np.array_equal(bi, rbi) and np.array_equal(b, rb) and np.array_equal(s, rs)
+
+
+def test_grid_bad_args_cpu():
+    """argument validation happens before any device work"""
+    from orb_slam2_ssd_semantic_amd import _ffi
+    L = _ffi.lib()
+    assert L.orbfe_assign_grid(None, None, 0, 0.0, 0.0, 1.0, 1.0, None, None, None) == _ffi.ORBFE_ERR_ARG
+    assert L.orbfe_features_in_area(None, None, None, 0, None, None, 0.0, 0.0, 1.0, 1.0, None, None, 0, None, None,
+                                    0) == _ffi.ORBFE_ERR_ARG
