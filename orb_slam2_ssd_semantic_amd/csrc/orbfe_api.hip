@@ -157,7 +157,7 @@ struct orbfe_handle {
     bool ev_ok = false;
     // blur depends on the pyramid only, the quadtree on FAST only: the blur runs on a side stream next to the
     // latency-bound quadtree (overlap 2), next to FAST + quadtree (1), or in line (0)
-    int overlap = 2;
+    int overlap = 0;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };

@@ -386,7 +386,6 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
     const uint32_t rv01 = halves(rvalid, 0), rv23 = halves(rvalid, 2);
     // a cell seam between the two pixels of a pair lets BOTH be NMS survivors; at most one pair of a lane has one
     const bool split01 = (inside & 3) == 3 && !(lvalid & 2), split23 = (inside & 12) == 12 && !(lvalid & 8);
-    const uint32_t sm01 = split01 ? 0xFFFFFFFFu : 0u, sm23 = split23 ? 0xFFFFFFFFu : 0u;
     const bool wave_split = __ballot(split01 || split23) != 0ull;
     const bool out_lane = !(ld.flags & 1) && inside != 0;
     const int nrows_out = out_lane ? (int)ld.nrows : 0;
@@ -458,8 +457,9 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
             const uint32_t m01 = S01[km], m23 = S23[km];
             const uint32_t v01 = pk_max_u16(u01, d01), v23 = pk_max_u16(u23, d23);   // vertical neighbours
             const uint32_t c01 = pk_max_u16(v01, m01), c23 = pk_max_u16(v23, m23);   // column maxima
-            const uint32_t cL = (uint32_t)__shfl_up((int)c23, 1, 64);                // .hi = column x-1
-            const uint32_t cR = (uint32_t)__shfl_down((int)c01, 1, 64);              // .lo = column x+4
+            // neighbour lanes by DPP wave shifts (lane 0 / 63 read back 0: they have no such neighbour)
+            const uint32_t cL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c23, 0x138, 0xF, 0xF, false);  // wave_shr:1, .hi = column x-1
+            const uint32_t cR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c01, 0x130, 0xF, 0xF, false);  // wave_shl:1, .lo = column x+4
             const uint32_t l01 = __builtin_amdgcn_alignbit(c01, cL, 16) & lv01;      // columns (x-1, x)
             const uint32_t x12 = __builtin_amdgcn_alignbit(c23, c01, 16);            // columns (x+1, x+2)
             const uint32_t r23 = __builtin_amdgcn_alignbit(cR, c23, 16) & rv23;      // columns (x+3, x+4)
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
                 }
                 nbuf += p01 + __popcll(b23);
                 if (wave_split) {  // both pixels of a seam pair survived: the low one is still to be written
-                    const uint32_t gs = (g01 & sm01) | (g23 & sm23);
+                    const uint32_t gs = split01 ? g01 : (split23 ? g23 : 0u);
                     const bool dbl = row_out && (gs & 0xFFFFu) != 0u && gs > 0xFFFFu;
                     const unsigned long long bd = __ballot(dbl);
                     if (bd) {
@@ -1051,15 +1051,24 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
 // (no LDS, no intermediate traffic): per row 3 aligned dword loads (12-byte window), 4 row sums, 4 outputs,
 // one dword store.  Reflected borders: rows by a wave-uniform index, columns by a per-byte path on edge lanes.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int blur_tap7(int a0, int a1, int a2, int a3, int a4, int a5, int a6)
+// weights of window dword d (pixels x-4+4d .. x-1+4d) for the output pixel x+j: its taps are window bytes j+1 .. j+7
+__host__ __device__ constexpr uint32_t blur_hw(int j, int d)
 {
-    return 18 * (a0 + a6) + 34 * (a1 + a5) + 49 * (a2 + a4) + 55 * a3;
+    const int kern[7] = {18, 34, 49, 55, 49, 34, 18};
+    uint32_t w = 0u;
+    for (int b = 0; b < 4; ++b) {
+        const int t = 4 * d + b - j - 1;
+        if (t >= 0 && t <= 6) w |= (uint32_t)kern[t] << (8 * b);
+    }
+    return w;
 }
 
 // Work is described per LANE (a 4-pixel column, a run of <= 64 rows), packed by the host into single-level waves, so
 // no lane idles on narrow levels.  Column borders are branch-free: every lane loads 3 dwords from a per-lane base that
 // covers all (reflected) source pixels of its 12-byte window and rearranges them with per-lane byte selectors
 // (identity for interior lanes); row borders are a per-lane reflected row index.
+#define BL_PF 2  // prefetch distance in rows
+template <int MODE>
 __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
                                                const OrbLane *__restrict__ lanes, int nwaves,
                                                uint8_t *__restrict__ blur, int64_t blur_fstride)
@@ -1077,11 +1086,10 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
     const int x = ld.x, y0 = ld.ys, yend = y0 + ld.nrows;
     const bool active = !(ld.flags & 1);
     const int vec_w = W & ~3;
-    const int mode = plan->blur_rounding;
     int nsteps = ld.nrows;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
-    nsteps += 6;  // wave-uniform
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps) + 6;  // wave-uniform
 
     // window pixel i (0..11) is level column reflect101(x - 4 + i); i = 0 and 11 are never used
     int srcx[12], lo = W;
@@ -1107,12 +1115,26 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
             }
         }
     }
+    const bool full = x + 4 <= W;
+    const int dpitch = L.pitch;
 
-    int S[7][4];
+    uint32_t S[7][4];  // row sums (<= 255 * 257) of the last seven rows
 #pragma unroll
     for (int k = 0; k < 7; ++k)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) S[k][j] = 0;
+        for (int j = 0; j < 4; ++j) S[k][j] = 0u;
+
+    // raw rows are fetched BL_PF steps ahead into the same 7-slot ring, so a wave keeps several rows in flight
+    uint32_t Lr[7][3];
+    auto fetch = [&](int s, uint32_t (&dst3)[3]) {
+        const int yy = reflect101(min(y0 - 3 + s, H + 2), H);
+        const uint8_t *row = src + (__umul24((uint32_t)yy, (uint32_t)pitch) + (uint32_t)base);
+        dst3[0] = *(const uint32_t *)(row);
+        dst3[1] = *(const uint32_t *)(row + 4);
+        dst3[2] = *(const uint32_t *)(row + 8);
+    };
+#pragma unroll
+    for (int k = 0; k < BL_PF; ++k) fetch(k, Lr[k]);
 
     for (int s0 = 0; s0 < nsteps; s0 += 7) {
 #pragma unroll
@@ -1120,11 +1142,8 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
             const int s = s0 + k;
             if (s >= nsteps) break;  // wave-uniform
             const int yin = y0 - 3 + s;
-            const int yy = reflect101(min(yin, H + 2), H);
-            const uint8_t *row = src + (int64_t)yy * pitch + base;
-            const uint32_t l0 = *(const uint32_t *)(row);
-            const uint32_t l1 = *(const uint32_t *)(row + 4);
-            const uint32_t l2 = *(const uint32_t *)(row + 8);
+            fetch(s + BL_PF, Lr[(k + BL_PF) % 7]);  // rows past the run re-read a valid (reflected / clamped) row
+            const uint32_t l0 = Lr[k][0], l1 = Lr[k][1], l2 = Lr[k][2];
             uint32_t w[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -1132,31 +1151,34 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
                 const uint32_t tb = __builtin_amdgcn_perm(l2, l2, selB[d]);
                 w[d] = (tb & mskB[d]) | (ta & ~mskB[d]);
             }
-            int px[12];
+            // horizontal taps as byte dot products against per-(pixel, dword) weight constants
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                px[i] = (w[0] >> (8 * i)) & 0xFF;
-                px[4 + i] = (w[1] >> (8 * i)) & 0xFF;
-                px[8 + i] = (w[2] >> (8 * i)) & 0xFF;
+            for (int j = 0; j < 4; ++j) {
+                uint32_t h = 0u;
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    if (blur_hw(j, d) != 0u) h = __builtin_amdgcn_udot4(w[d], blur_hw(j, d), h, false);
+                S[k][j] = h;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                S[k][j] = blur_tap7(px[1 + j], px[2 + j], px[3 + j], px[4 + j], px[5 + j], px[6 + j], px[7 + j]);
             if (s >= 6) {
                 const int y = yin - 3;
-                uint32_t packed = 0;
+                uint32_t tq[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     // newest row sum is slot k (offset +3), oldest is slot (k+1)%7 (offset -3)
-                    const int acc = blur_tap7(S[(k + 1) % 7][j], S[(k + 2) % 7][j], S[(k + 3) % 7][j], S[(k + 4) % 7][j],
-                                              S[(k + 5) % 7][j], S[(k + 6) % 7][j], S[k][j]);
-                    int v = (acc + 32768) >> 16;
-                    if (mode == 1 && (acc & 0xFFFF) == 0x8000 && (x + j) < vec_w && (v & 1)) v -= 1;
-                    packed |= (uint32_t)min(v, 255) << (8 * j);
+                    // 24-bit multiplies (operands < 2^18): v_mad_u32_u24, not the quarter-rate 32-bit multiply
+                    const uint32_t acc = __umul24(18u, S[(k + 1) % 7][j] + S[k][j]) + __umul24(34u, S[(k + 2) % 7][j] + S[(k + 6) % 7][j]) +
+                                         __umul24(49u, S[(k + 3) % 7][j] + S[(k + 5) % 7][j]) + __umul24(55u, S[(k + 4) % 7][j]) + 32768u;
+                    uint32_t q = acc;  // (q >> 16) = value rounded half-up, <= 257
+                    if (MODE == 1 && (acc & 0xFFFFu) == 0u && (x + j) < vec_w && (q & 0x10000u)) q -= 0x10000u;  // SSE2 half-even
+                    tq[j] = min(q, 0x00FFFFFFu);  // byte 2 = saturate_cast<uchar>
                 }
+                const uint32_t p01 = __builtin_amdgcn_perm(tq[1], tq[0], 0x0c0c0602u);
+                const uint32_t p23 = __builtin_amdgcn_perm(tq[3], tq[2], 0x0c0c0602u);
+                const uint32_t packed = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
                 if (active && y < yend) {
-                    uint8_t *o = dst + (int64_t)y * L.pitch + x;
-                    if (x + 4 <= W) {
+                    uint8_t *o = dst + (__umul24((uint32_t)y, (uint32_t)dpitch) + (uint32_t)x);
+                    if (full) {
                         *(uint32_t *)o = packed;
                     } else {
                         for (int j = 0; j < 4 && x + j < W; ++j) o[j] = (uint8_t)(packed >> (8 * j));
@@ -1460,8 +1482,12 @@ hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st)
 {
     const FrameSrc fs = make_src(a);
     dim3 grid((a.h_plan->nbwaves + 3) / 4, a.nframes);
-    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, a.d_plan, fs, a.d_blanes, a.h_plan->nbwaves, a.d_blur,
-                       a.pyr_fstride);
+    if (a.h_plan->blur_rounding == 1)
+        hipLaunchKernelGGL(k_blur7<1>, grid, dim3(256), 0, st, a.d_plan, fs, a.d_blanes, a.h_plan->nbwaves, a.d_blur,
+                           a.pyr_fstride);
+    else
+        hipLaunchKernelGGL(k_blur7<0>, grid, dim3(256), 0, st, a.d_plan, fs, a.d_blanes, a.h_plan->nbwaves, a.d_blur,
+                           a.pyr_fstride);
     return hipGetLastError();
 }
 

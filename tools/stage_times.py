@@ -13,3 +13,10 @@ torch.cuda.synchronize(); ext.set_profiling(True)
 for i in range(10): ext.extract_batch_device(fr.data_ptr(),B,w,h,w,w*h,dk.data_ptr(),dd.data_ptr(),cap,dn.data_ptr(),None)
 torch.cuda.synchronize()
 print(os.environ.get("ORBFE_DEBUG","0"), {k:round(v,4) for k,v in ext.stage_ms().items()})
+ext.set_profiling(False)
+e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+for i in range(3): ext.extract_batch_device(fr.data_ptr(),B,w,h,w,w*h,dk.data_ptr(),dd.data_ptr(),cap,dn.data_ptr(),None)
+torch.cuda.synchronize(); e0.record()
+for i in range(20): ext.extract_batch_device(fr.data_ptr(),B,w,h,w,w*h,dk.data_ptr(),dd.data_ptr(),cap,dn.data_ptr(),None)
+e1.record(); torch.cuda.synchronize()
+print("split", os.environ.get("ORBFE_SPLIT","1"), "total_ms_unprofiled", round(e0.elapsed_time(e1)/20,4))
