@@ -304,6 +304,10 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         L.patch_size = (float)(int)(ORBFE_PATCH * h->scale[l]);  // :846
         if (l >= 1) {
             const OrbLevel &S = P.lv[l - 1];
+            if (S.w >= 2 * L.w) {  // k_pyr_resize: the 4 source pairs of a lane must fit one 8-byte window
+                orbfe_set_error("scale factor too large: level %d is less than half as wide as level %d", l, l - 1);
+                return ORBFE_ERR_ARG;
+            }
             L.xtab = (int)tabs.size();
             tabs.resize(tabs.size() + L.w);
             resize_axis(S.w, L.w, true, &tabs[L.xtab]);

@@ -33,6 +33,10 @@ hipError_t orbk_upload_constants(const int *umax16)
 // ---------------------------------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------------------------------
+typedef _Float16 orb_h2 __attribute__((ext_vector_type(2)));
+typedef short orb_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short orb_u2 __attribute__((ext_vector_type(2)));
+
 struct FrameSrc {
     const uint8_t *l0;   // level-0 frames (caller's buffer)
     int64_t l0_fstride;  // bytes between frames
@@ -142,43 +146,52 @@ __global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
     const int nrows = min(PY_RB, H - y0);
     const uint8_t *src = a.src + (int64_t)b * a.src_fstride;
     uint8_t *dst = a.dst + (int64_t)b * a.dst_fstride;
-    const int sp = a.spitch;
 
-    // per-lane horizontal taps: source column and the two 11-bit coefficients of each of the 4 pixels
-    int sx[4], a0[4], a1[4];
+    // per-lane horizontal taps.  The four source pairs (S[sx], S[sx+1]) of a lane lie inside the 8 bytes starting at
+    // its first source column (level-to-level scale < 2, checked by the host), so ONE unaligned 8-byte load per
+    // source row feeds all four pixels: pixel j picks its pair with a per-lane v_perm selector (-> two u16 halves)
+    // and the horizontal sum S[sx]*a0 + S[sx+1]*a1 is one v_dot2_u32_u16 against the packed coefficients.
+    // The window may reach 7 bytes past the last source pixel of a row: inside the handle's own levels (a later
+    // level follows), and inside the caller's level-0 buffer thanks to the 16-byte slack orbfe.h asks for.
+    int sx0 = 0;
+    uint32_t sel[4];
+    orb_u2 coef[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pyr_tap(min(dx0 + j, W - 1), a.scale_x, a.sw, true, sx[j], a0[j], a1[j]);
-    // The pair (S[sx], S[sx+1]) of every tap is ONE unaligned 16-bit load.  It may touch the byte after the last
-    // source pixel (sx = S.w-1 has a1 = 0): inside the padded rows of the handle's own levels, and inside the
-    // caller's level-0 buffer thanks to the 16-byte slack orbfe.h asks for.
-    // straight-line: all source pairs of the tile in flight at once, then the arithmetic (no control flow)
-    uint32_t p0[PY_RB][4], p1[PY_RB][4];
+    for (int j = 0; j < 4; ++j) {
+        int sxj, c0, c1;
+        pyr_tap(min(dx0 + j, W - 1), a.scale_x, a.sw, true, sxj, c0, c1);
+        if (j == 0) sx0 = sxj;
+        const uint32_t o = (uint32_t)min(sxj - sx0, 6);
+        sel[j] = 0x0c000c00u | ((o + 1u) << 16) | o;
+        coef[j] = orb_u2{(unsigned short)c0, (unsigned short)c1};
+    }
+    // straight-line: all source windows of the tile in flight at once, then the arithmetic (no control flow)
+    uint2 q0[PY_RB], q1[PY_RB];
     int vb0[PY_RB], vb1[PY_RB];
+    const uint32_t sp = (uint32_t)a.spitch;
 #pragma unroll
     for (int d = 0; d < PY_RB; ++d) {
         int tys;
         pyr_tap(min(y0 + d, H - 1), a.scale_y, a.sh, false, tys, vb0[d], vb1[d]);
         const int sy0 = min(max(tys, 0), a.sh - 1), sy1 = min(max(tys + 1, 0), a.sh - 1);
-        const uint8_t *r0 = src + (int64_t)sy0 * sp, *r1 = src + (int64_t)sy1 * sp;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            p0[d][j] = *(const uint16_t *)(r0 + sx[j]);
-            p1[d][j] = *(const uint16_t *)(r1 + sx[j]);
-        }
+        q0[d] = *(const uint2 *)(src + (__umul24((uint32_t)sy0, sp) + (uint32_t)sx0));
+        q1[d] = *(const uint2 *)(src + (__umul24((uint32_t)sy1, sp) + (uint32_t)sx0));
     }
+    const bool full = dx0 + 4 <= W;
 #pragma unroll
     for (int d = 0; d < PY_RB; ++d) {
-        uint32_t packed = 0;
+        uint32_t v4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ha = __mul24((int)(p0[d][j] & 0xFFu), a0[j]) + __mul24((int)(p0[d][j] >> 8), a1[j]);
-            const int hb = __mul24((int)(p1[d][j] & 0xFFu), a0[j]) + __mul24((int)(p1[d][j] >> 8), a1[j]);
-            const int v = ((__mul24(vb0[d], ha >> 4) >> 16) + (__mul24(vb1[d], hb >> 4) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xFF) << (8 * j);
+            const uint32_t ha = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, __builtin_amdgcn_perm(q0[d].y, q0[d].x, sel[j])), coef[j], 0u, false);
+            const uint32_t hb = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, __builtin_amdgcn_perm(q1[d].y, q1[d].x, sel[j])), coef[j], 0u, false);
+            v4[j] = ((__umul24((uint32_t)vb0[d], ha >> 4) >> 16) + (__umul24((uint32_t)vb1[d], hb >> 4) >> 16) + 2u) >> 2;
         }
+        const uint32_t packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v4[3], v4[2], 0x0c0c0400u),
+                                                      __builtin_amdgcn_perm(v4[1], v4[0], 0x0c0c0400u), 0x05040100u);
         if (active && d < nrows) {
-            uint8_t *o = dst + (int64_t)(y0 + d) * a.dpitch + dx0;
-            if (dx0 + 4 <= W) *(uint32_t *)o = packed;
+            uint8_t *o = dst + (__umul24((uint32_t)(y0 + d), (uint32_t)a.dpitch) + (uint32_t)dx0);
+            if (full) *(uint32_t *)o = packed;
             else
                 for (int j = 0; j < 4 && dx0 + j < W; ++j) o[j] = (uint8_t)(packed >> (8 * j));
         }
@@ -216,9 +229,6 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 // A pixel pair is held as two u16 halves (values 0..255).  Read as f16 bit patterns those are positive
 // denormals, whose order equals the integer order, so gfx950's 3-input packed min/max
 // (v_pk_minimum3_f16 / v_pk_maximum3_f16) give exact integer results at two pixels per instruction.
-typedef _Float16 orb_h2 __attribute__((ext_vector_type(2)));
-typedef short orb_s2 __attribute__((ext_vector_type(2)));
-typedef unsigned short orb_u2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -407,34 +417,36 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
     const uint32_t hrange = (uint32_t)(iy1 - iy0);
     // key of pixel 0 in the NMS row of step 0 (detection-window coordinates = level - 16, reference :831-832)
     const uint32_t key00 = (uint32_t)(x - ORBFE_MINB) + ((uint32_t)(ys - 8 - ORBFE_MINB) << 12);
-    const uint8_t *col = src + x;
 
-    uint32_t R[7][3];
-    uint32_t S01[7], S23[7];  // S of the pixel pairs (0,1), (2,3) for the strength row computed in ring slot k
+    // 8-slot rings (7 live rows + the row being fetched one step ahead), statically indexed under the 8-fold unroll
+    uint32_t R[8][3];
+    uint32_t S01[8], S23[8];  // S of the pixel pairs (0,1), (2,3) for the strength row computed in ring slot k
 #pragma unroll
-    for (int k = 0; k < 7; ++k) R[k][0] = R[k][1] = R[k][2] = S01[k] = S23[k] = 0u;
+    for (int k = 0; k < 8; ++k) R[k][0] = R[k][1] = R[k][2] = S01[k] = S23[k] = 0u;
+    auto fetch = [&](int s, uint32_t (&dst3)[3]) {
+        const int r = ys - 4 + s;  // image row of step s (lanes past their run re-read a valid row)
+        const uint8_t *row = src + (__umul24((uint32_t)min(r, H - 1), (uint32_t)pitch) + (uint32_t)x);
+        dst3[0] = *(const uint32_t *)(row - 4);
+        dst3[1] = *(const uint32_t *)(row);
+        dst3[2] = *(const uint32_t *)(row + 4);
+    };
+    fetch(0, R[0]);
 
-    for (int s0 = 0; s0 < nsteps; s0 += 7) {
+    for (int s0 = 0; s0 < nsteps; s0 += 8) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < 8; ++k) {
             const int s = s0 + k;
             if (s >= nsteps) break;    // wave-uniform
-            {
-                const int r = ys - 4 + s;  // image row loaded in this step (lanes past their run re-read a valid row)
-                const uint8_t *row = col + (int64_t)min(r, H - 1) * pitch;
-                R[k][0] = *(const uint32_t *)(row - 4);
-                R[k][1] = *(const uint32_t *)(row);
-                R[k][2] = *(const uint32_t *)(row + 4);
-            }
+            fetch(s + 1, R[(k + 1) % 8]);
             if (s < 6) continue;
-            // ---- strength row rc = r - 3 (newest ring slot k is row rc+3, slot (k+1)%7 is row rc-3) ----
+            // ---- strength row rc = r - 3 (newest ring slot k is row rc+3, slot (k+2)%8 is row rc-3) ----
             {
-                const uint32_t(&rm3)[3] = R[(k + 1) % 7];
-                const uint32_t(&rm2)[3] = R[(k + 2) % 7];
-                const uint32_t(&rm1)[3] = R[(k + 3) % 7];
-                const uint32_t(&r0)[3] = R[(k + 4) % 7];
-                const uint32_t(&rp1)[3] = R[(k + 5) % 7];
-                const uint32_t(&rp2)[3] = R[(k + 6) % 7];
+                const uint32_t(&rm3)[3] = R[(k + 2) % 8];
+                const uint32_t(&rm2)[3] = R[(k + 3) % 8];
+                const uint32_t(&rm1)[3] = R[(k + 4) % 8];
+                const uint32_t(&r0)[3] = R[(k + 5) % 8];
+                const uint32_t(&rp1)[3] = R[(k + 6) % 8];
+                const uint32_t(&rp2)[3] = R[(k + 7) % 8];
                 const uint32_t(&rp3)[3] = R[k];
                 const bool rowok = (uint32_t)(ysrel + s) < hrange;  // iy0 <= rc < iy1
                 const uint32_t tt = rowok ? tzz : 0x03FF03FFu;
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
             }
             if (s < 8) continue;
             // ---- 3x3 strict NMS of row rn = rc - 1 on packed pairs: rows U = S[k-2], M = S[k-1], D = S[k] ----
-            const int ku = (k + 5) % 7, km = (k + 6) % 7;
+            const int ku = (k + 6) % 8, km = (k + 7) % 8;
             const bool up_ok = rmod != 0;            // neighbours outside the own cell count as 0
             const bool dn_ok = rmod != hcell - 1;    // (the row at iy1 is already all zero)
             const uint32_t ord_row = ordy;
