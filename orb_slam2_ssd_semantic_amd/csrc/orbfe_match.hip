@@ -59,27 +59,62 @@ __device__ __forceinline__ int rot_bin(float a1, float a2)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K8  brute force: 64 queries per workgroup, the train set split over the workgroup's waves.
-// A pair of frames is (q rows, t rows); blockIdx.y selects the pair in the batched form.
+// K8  brute force on the matrix cores.
+//
+// All-pairs Hamming is a GEMM in disguise: with every query bit mapped to the int8 value 2b-1 and every train bit
+// to 64(2b-1),
+//     dot(t', q') = 64 * (256 - 2 * hamming(q, t)) = 128 * (128 - d),
+// exact in int32.  v_mfma_i32_32x32x32_i8 evaluates a 32 x 32 tile of such dots over 32 bit positions per
+// instruction; 8 of them cover the 256 bits.  The accumulators do not start at zero but at a 7-bit "field"
+// 32 - (train row inside the tile), so an accumulator IS the ranking key
+//     key = 128 * (128 - d) + field                      (larger = closer, earlier row wins ties)
+// and all that is left for the VALU is to keep, per query, the two largest keys: 2.5 instructions per distance
+// instead of the 20 of an xor/popcount loop.  The best key gives (distance, lowest index) and the second key the
+// second-smallest distance with multiplicity, which is exactly what the reference's sequential
+//     if (d < best) {second = best; best = d; idx = j;} else if (d < second) second = d;
+// produces.  Between train tiles the field of the running keys is forced to 127 (an older row beats any newer
+// one on equal distance) and the global index of the best is latched whenever the best key changed in a tile.
+//
+// Workgroup = 4 waves x BM_Q query tiles of 32 = 512 queries; the train descriptors stream through LDS in tiles of
+// 32 rows, expanded bit -> +-64 byte on the way in (8-byte table look-up per source byte) and laid out so that the
+// A operand of lane (row r, k-half h) at k-step s is one conflict-free ds_read_b128 at ((2s + h) * 32 + r) * 16.
+// The query tiles (B operands, 32 VGPRs each) are expanded once and stay in registers.  The bit -> k assignment is
+// the same on both sides, which is all a dot product needs.
+// The wave is software-pipelined: the MFMA chain of the next query tile (at the end of a train tile: of query tile 0
+// of the next train tile) is issued between the ranking instructions of the current one.
 // ---------------------------------------------------------------------------------------------------
-#define BF_WAVES 16
+#define BM_WAVES 4
+#define BM_Q 4
+#define BM_QW (BM_WAVES * BM_Q * 32)
+#define BM_NEG (-(1 << 30))
+#define BM_MAX_NT (1 << 22)  // the index is latched as a plain int; only nt * 32 bytes must be addressable in 32 bits
 
-struct BfPair {
-    const uint8_t *q;
-    const uint8_t *t;
-    int nq, nt;
-};
+typedef int bm_v4i __attribute__((ext_vector_type(4)));
+typedef int bm_v16i __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(BF_WAVES * 64) void k_match_bf(const uint8_t *__restrict__ q_base,
-                                                            const uint8_t *__restrict__ t_base,
-                                                            const int32_t *__restrict__ n_arr,  // per-frame counts or NULL
-                                                            const int32_t *__restrict__ qframe,
-                                                            const int32_t *__restrict__ tframe, int cap, int nq_s,
-                                                            int nt_s, float nnratio, int th,
-                                                            int32_t *__restrict__ match, int32_t *__restrict__ best_o,
-                                                            int32_t *__restrict__ second_o)
+// bit b of v -> byte b: +mag if set, -mag if clear (two dwords for the 8 bits)
+__device__ __forceinline__ uint2 bm_expand_byte(uint32_t v, uint32_t mag)
 {
-    __shared__ int s_best[BF_WAVES][64], s_second[BF_WAVES][64], s_idx[BF_WAVES][64];
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        lo |= (((v >> b) & 1u) ? mag : (0x100u - mag)) << (8 * b);
+        hi |= (((v >> (4 + b)) & 1u) ? mag : (0x100u - mag)) << (8 * b);
+    }
+    return make_uint2(lo, hi);
+}
+
+__global__ __launch_bounds__(BM_WAVES * 64, 2) void k_match_bf(const uint8_t *__restrict__ q_base,
+                                                               const uint8_t *__restrict__ t_base,
+                                                               const int32_t *__restrict__ n_arr,  // per-frame counts or NULL
+                                                               const int32_t *__restrict__ qframe,
+                                                               const int32_t *__restrict__ tframe, int cap, int nq_s,
+                                                               int nt_s, float nnratio, int th,
+                                                               int32_t *__restrict__ match, int32_t *__restrict__ best_o,
+                                                               int32_t *__restrict__ second_o)
+{
+    __shared__ uint2 s_tabq[256], s_tabt[256];  // query bits -> +-1, train bits -> +-64
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[2][32 * 256];
     const int pair = blockIdx.y;
     const uint8_t *q = q_base, *t = t_base;
     int nq = nq_s, nt = nt_s;
@@ -92,47 +127,153 @@ __global__ __launch_bounds__(BF_WAVES * 64) void k_match_bf(const uint8_t *__res
         nt = min(n_arr[tf], cap);
         out0 = (int64_t)pair * cap;
     }
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int qi = blockIdx.x * 64 + lane;
-    if (blockIdx.x * 64 >= (n_arr ? cap : nq)) return;
-    Desc8 dq;
-    {
-        const uint32_t *p = (const uint32_t *)(q + (int64_t)min(qi, max(nq - 1, 0)) * 32);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dq.w[i] = nq > 0 ? p[i] : 0u;
-    }
-    // contiguous train slice per wave keeps "lowest index wins" a simple ordered merge
-    const int per = (nt + BF_WAVES - 1) / BF_WAVES;
-    const int j0 = min(wid * per, nt), j1 = min(j0 + per, nt);
-    Best2 r = {256, 256, -1};
-    for (int j = j0; j < j1; ++j) {
-        const uint32_t *tr = (const uint32_t *)(t + (int64_t)j * 32);  // wave-uniform address -> scalar loads
-        const int d = hamming8(dq, tr);
-        if (d < r.best) {
-            r.second = r.best;
-            r.best = d;
-            r.idx = j;
-        } else if (d < r.second) {
-            r.second = d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0 = blockIdx.x * BM_QW;
+    const int nslots = n_arr ? cap : nq;  // output slots of this pair
+    if (q0 >= nslots) return;
+    if (q0 >= nq) {  // only padding slots of the batched form: no match, no compute
+        for (int i = q0 + tid; i < min(q0 + BM_QW, nslots); i += BM_WAVES * 64) {
+            match[out0 + i] = -1;
+            if (best_o) best_o[out0 + i] = 256;
+            if (second_o) second_o[out0 + i] = 256;
         }
+        return;
     }
-    s_best[wid][lane] = r.best;
-    s_second[wid][lane] = r.second;
-    s_idx[wid][lane] = r.idx;
+    s_tabq[tid] = bm_expand_byte((uint32_t)tid, 1u);
+    s_tabt[tid] = bm_expand_byte((uint32_t)tid, 64u);
     __syncthreads();
-    if (wid == 0) {
-        for (int w = 1; w < BF_WAVES; ++w) {
-            Best2 hi = {s_best[w][lane], s_second[w][lane], s_idx[w][lane]};
-            r = merge_best2(r, hi);
+
+    const int c = lane & 31, h = lane >> 5;
+    // ---- B operands: BM_Q query tiles, lane (c, h) holds bits [128h, 128h + 128) of query c as 8 x 16 bytes ----
+    bm_v4i B[BM_Q][8];
+#pragma unroll
+    for (int u = 0; u < BM_Q; ++u) {
+        const int qi = q0 + (wid * BM_Q + u) * 32 + c;
+        const uint4 raw = *(const uint4 *)(q + (int64_t)min(qi, nq - 1) * 32 + h * 16);
+        const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int sstep = 0; sstep < 8; ++sstep) {
+            const uint32_t b0 = (rw[sstep >> 1] >> (16 * (sstep & 1))) & 0xFFu;
+            const uint32_t b1 = (rw[sstep >> 1] >> (16 * (sstep & 1) + 8)) & 0xFFu;
+            const uint2 e0 = s_tabq[b0], e1 = s_tabq[b1];
+            B[u][sstep] = bm_v4i{(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
         }
-        const bool valid = qi < nq;
-        if (valid || (n_arr && qi < cap)) {
+    }
+    int kb[BM_Q], ks[BM_Q], bi[BM_Q];
+#pragma unroll
+    for (int u = 0; u < BM_Q; ++u) {
+        kb[u] = ks[u] = BM_NEG;
+        bi[u] = -1;
+    }
+    if (nt > 0) {
+        // ---- train tile staging: thread (r = tid & 31, w = tid >> 5) expands source dword w of row r ----
+        const int sr = tid & 31, sw = tid >> 5;
+        const uint32_t *t32 = (const uint32_t *)t;
+        // rows past the end re-read the last row: their keys are masked in the last tile
+        auto stage_load = [&](int T) -> uint32_t { return t32[(uint32_t)(min(T + sr, nt - 1) * 8 + sw)]; };
+        auto stage_store = [&](uint32_t dw, int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int beta = 4 * sw + i, hh = beta >> 4, bp = beta & 15;
+                const int off = (((bp >> 1) * 2 + hh) * 32 + sr) * 16 + (bp & 1) * 8;
+                *(uint2 *)(s_tile[buf] + off) = s_tabt[(dw >> (8 * i)) & 0xFFu];
+            }
+        };
+        auto load_a = [&](bm_v4i (&A)[8], int buf) {
+#pragma unroll
+            for (int sstep = 0; sstep < 8; ++sstep)
+                A[sstep] = *(const bm_v4i *)(s_tile[buf] + ((sstep * 2 + h) * 32 + c) * 16);
+        };
+        // accumulator start values = key fields: 32 - (train row of the accumulator inside the tile)
+        bm_v16i cfull;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) cfull[reg] = 32 - ((reg & 3) + 8 * (reg >> 2) + 4 * h);
+        auto chain = [&](const bm_v4i (&A)[8], const bm_v4i (&Bu)[8]) -> bm_v16i {
+            bm_v16i acc = cfull;
+#pragma unroll
+            for (int sstep = 0; sstep < 8; ++sstep) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[sstep], Bu[sstep], acc, 0, 0, 0);
+            return acc;
+        };
+        auto interleave = [&]() {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // five VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // two largest keys of query tile u over the 16 rows in `acc`; latch the index when the best changed
+        auto rank = [&](const bm_v16i &acc, int u, int T, bool mask_tail) {
+            const int bprev = kb[u] | 127;
+            int b = bprev, s2 = ks[u] | 127;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int key = acc[reg];
+                if (mask_tail && T + (reg & 3) + 8 * (reg >> 2) + 4 * h >= nt) key = BM_NEG;
+                const int lo = min(b, key);
+                b = max(b, key);
+                s2 = max(s2, lo);
+            }
+            if (b != bprev) bi[u] = T + 32 - (b & 127);
+            kb[u] = b;
+            ks[u] = s2;
+        };
+
+        stage_store(stage_load(0), 0);
+        uint32_t g1 = stage_load(32);  // source dword of the tile after next, fetched two tiles before it is consumed
+        __syncthreads();
+        bm_v4i A[8];
+        load_a(A, 0);
+        bm_v16i acc = chain(A, B[0]);
+        int buf = 0, T = 0;
+        for (; T + 32 < nt; T += 32) {  // all tiles but the last one
+            const uint32_t g2 = stage_load(T + 64);
+            stage_store(g1, buf ^ 1);  // tile T + 32 (not read before the barrier below)
+            g1 = g2;
+#pragma unroll
+            for (int u = 0; u < BM_Q; ++u) {
+                bm_v16i nacc;
+                if (u + 1 < BM_Q) {
+                    nacc = chain(A, B[u + 1]);
+                } else {  // next train tile
+                    __syncthreads();
+                    buf ^= 1;
+                    load_a(A, buf);
+                    nacc = chain(A, B[0]);
+                }
+                rank(acc, u, T, false);
+                interleave();
+                acc = nacc;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BM_Q; ++u) {  // last tile: rows past the end of the train set are masked
+            bm_v16i nacc = acc;
+            if (u + 1 < BM_Q) nacc = chain(A, B[u + 1]);
+            rank(acc, u, T, true);
+            acc = nacc;
+        }
+    }
+    // ---- lanes c and c + 32 hold different train rows of the same query: merge the two halves, decode ----
+#pragma unroll
+    for (int u = 0; u < BM_Q; ++u) {
+        const int ob = __shfl_xor(kb[u], 32, 64), os = __shfl_xor(ks[u], 32, 64), oi = __shfl_xor(bi[u], 32, 64);
+        // distance part of a key: m = 128 - d (sentinels stay far below)
+        const int mb = kb[u] >> 7, mo = ob >> 7;
+        const bool take_o = mo > mb || (mo == mb && oi >= 0 && (bi[u] < 0 || oi < bi[u]));
+        const int m1 = take_o ? mo : mb, idx = take_o ? oi : bi[u];
+        const int m2 = max(min(mb, mo), max(ks[u] >> 7, os >> 7));
+        const int qi = q0 + (wid * BM_Q + u) * 32 + c;
+        if (h == 0 && qi < nslots) {
+            const int best = idx >= 0 ? 128 - m1 : 256;
+            const int second = m2 > (BM_NEG >> 8) ? 128 - m2 : 256;
+            const bool valid = qi < nq;
             int m = -1;
-            if (valid && r.idx >= 0 && r.best <= th && (float)r.best < __fmul_rn(nnratio, (float)r.second)) m = r.idx;
+            if (valid && idx >= 0 && best <= th && (float)best < __fmul_rn(nnratio, (float)second)) m = idx;
             match[out0 + qi] = m;
-            if (best_o) best_o[out0 + qi] = valid ? r.best : 256;
-            if (second_o) second_o[out0 + qi] = valid ? r.second : 256;
+            if (best_o) best_o[out0 + qi] = valid ? best : 256;
+            if (second_o) second_o[out0 + qi] = valid ? second : 256;
         }
     }
 }
@@ -440,8 +581,8 @@ static orbfe_status launch_bf(const uint8_t *d_q, int nq, const uint8_t *d_t, in
                               int32_t *d_match, int32_t *d_best, int32_t *d_second, int32_t *d_nm, hipStream_t st)
 {
     if (nq > 0) {
-        dim3 grid((nq + 63) / 64, 1);
-        hipLaunchKernelGGL(k_match_bf, grid, dim3(BF_WAVES * 64), 0, st, d_q, d_t, (const int32_t *)nullptr,
+        dim3 grid((nq + BM_QW - 1) / BM_QW, 1);
+        hipLaunchKernelGGL(k_match_bf, grid, dim3(BM_WAVES * 64), 0, st, d_q, d_t, (const int32_t *)nullptr,
                            (const int32_t *)nullptr, (const int32_t *)nullptr, 0, nq, nt, nnratio, th, d_match, d_best,
                            d_second);
         ORBFE_HIP(hipGetLastError());
@@ -458,8 +599,8 @@ extern "C" orbfe_status orbfe_match_bf_device(orbfe_matcher *m, const uint8_t *d
                                               float nnratio, int32_t th, int32_t check_ori, int32_t *d_match_q2t,
                                               int32_t *d_best, int32_t *d_second, int32_t *d_nmatches, void *stream)
 {
-    if (!m || nq < 0 || nt < 0 || !d_match_q2t || !d_nmatches || (nq > 0 && !d_q) || (nt > 0 && !d_t)) {
-        orbfe_set_error("bad argument to orbfe_match_bf_device");
+    if (!m || nq < 0 || nt < 0 || nt > BM_MAX_NT || !d_match_q2t || !d_nmatches || (nq > 0 && !d_q) || (nt > 0 && !d_t)) {
+        orbfe_set_error("bad argument to orbfe_match_bf_device (train set limited to %d descriptors)", BM_MAX_NT);
         return ORBFE_ERR_ARG;
     }
     MDeviceGuard g(m->device);
@@ -472,8 +613,8 @@ extern "C" orbfe_status orbfe_match_bf(orbfe_matcher *m, const uint8_t *q, int32
                                        int32_t check_ori, int32_t *match_q2t, int32_t *best, int32_t *second,
                                        int32_t *nmatches)
 {
-    if (!m || nq < 0 || nt < 0 || (nq > 0 && (!q || !match_q2t)) || (nt > 0 && !t)) {
-        orbfe_set_error("bad argument to orbfe_match_bf");
+    if (!m || nq < 0 || nt < 0 || nt > BM_MAX_NT || (nq > 0 && (!q || !match_q2t)) || (nt > 0 && !t)) {
+        orbfe_set_error("bad argument to orbfe_match_bf (train set limited to %d descriptors)", BM_MAX_NT);
         return ORBFE_ERR_ARG;
     }
     if (nq == 0) {
@@ -519,15 +660,15 @@ extern "C" orbfe_status orbfe_match_bf_frames_device(orbfe_matcher *m, const orb
                                                      int32_t *d_match_q2t, int32_t *d_nmatches, void *stream)
 {
     if (!m || !d_kps || !d_desc || !d_n || !d_qframe || !d_tframe || !d_match_q2t || !d_nmatches || cap < 1 ||
-        npairs < 0) {
-        orbfe_set_error("bad argument to orbfe_match_bf_frames_device");
+        cap > BM_MAX_NT || npairs < 0) {
+        orbfe_set_error("bad argument to orbfe_match_bf_frames_device (cap 1..%d)", BM_MAX_NT);
         return ORBFE_ERR_ARG;
     }
     if (npairs == 0) return ORBFE_OK;
     MDeviceGuard g(m->device);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((cap + 63) / 64, npairs);
-    hipLaunchKernelGGL(k_match_bf, grid, dim3(BF_WAVES * 64), 0, st, d_desc, d_desc, d_n, d_qframe, d_tframe, cap, 0, 0,
+    dim3 grid((cap + BM_QW - 1) / BM_QW, npairs);
+    hipLaunchKernelGGL(k_match_bf, grid, dim3(BM_WAVES * 64), 0, st, d_desc, d_desc, d_n, d_qframe, d_tframe, cap, 0, 0,
                        nnratio, th, d_match_q2t, (int32_t *)nullptr, (int32_t *)nullptr);
     ORBFE_HIP(hipGetLastError());
     const float *ang = &d_kps->angle;  // orbfe_keypoint.angle, stride 7 floats
