@@ -141,7 +141,7 @@ struct orbfe_handle {
     std::vector<OrbTab> tabs;
     DevBuf d_plan, d_cells, d_tabs, d_flanes, d_blanes;
     // per-batch blocks
-    DevBuf d_pyr, d_blur, d_skeys, d_scount, d_keys, d_kord, d_knode, d_sel, d_nsel, d_nkeys;
+    DevBuf d_pyr, d_blur, d_skeys, d_scount, d_knode, d_sel, d_nsel, d_nkeys;
     // host-API staging
     DevBuf d_stage, d_okps, d_odesc, d_on;
     PinBuf h_stage, h_okps, h_odesc, h_on;
@@ -322,6 +322,8 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     }
     P.ncells = (int)cells.size();
     P.cell_cap = cell_cap;
+    P.max_ncells = 1;
+    for (int l = 0; l < nl; ++l) P.max_ncells = std::max(P.max_ncells, P.lv[l].ncells);
     P.keys_per_frame = key_off;
     P.sel_per_frame = sel_off;
     int M = 64;
@@ -331,15 +333,15 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         return ORBFE_ERR_ARG;
     }
     P.node_cap = M;
-    if (orbk_octree_lds_bytes(M, 4) > 160 * 1024) {
+    if (orbk_octree_lds_bytes(M, 4, w, ht, P.max_ncells) > 160 * 1024) {
         orbfe_set_error("nfeatures too large: the quadtree of one level (%d nodes) does not fit the 160 KB LDS", max_sel);
         return ORBFE_ERR_ARG;
     }
     P.max_nini = 1;
     for (int l = 0; l < nl; ++l) P.max_nini = std::max(P.max_nini, P.lv[l].nini);
     for (int l = 0; l < nl; ++l)
-        if (P.lv[l].ncells > M * 16 * 8 || P.lv[l].ncells >= (1 << 16) || P.lv[l].wcell > 63 || P.lv[l].hcell > 63) {
-            orbfe_set_error("level %d: %d FAST cells exceed the quadtree kernel's cell bitmap", l, P.lv[l].ncells);
+        if (P.lv[l].ncells >= (1 << 16) || P.lv[l].wcell > 63 || P.lv[l].hcell > 63) {
+            orbfe_set_error("level %d: %d FAST cells / cell size exceed the 16 + 6 + 6 bit candidate-order key", l, P.lv[l].ncells);
             return ORBFE_ERR_SIZE;
         }
     P.pyr_frame_bytes = off;
@@ -447,7 +449,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         ORBFE_HIP(hipMemcpy(h->d_flanes.p, flanes.data(), flanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     if (!blanes.empty())
         ORBFE_HIP(hipMemcpy(h->d_blanes.p, blanes.data(), blanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
-    ORBFE_HIP(orbk_prepare_octree(M, P.max_nini));
+    ORBFE_HIP(orbk_prepare_octree(M, P.max_nini, P.w, P.h, P.max_ncells));
     h->plan = P;
     h->cells.swap(cells);
     h->tabs.swap(tabs);
@@ -463,8 +465,6 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
     ORBFE_HIP(h->d_blur.ensure(B * (size_t)P.pyr_frame_bytes));
     ORBFE_HIP(h->d_skeys.ensure(B * (size_t)P.keys_per_frame * sizeof(uint2)));
     ORBFE_HIP(h->d_scount.ensure(B * P.nlevels * ORBFE_NK_STRIDE * sizeof(int32_t)));
-    ORBFE_HIP(h->d_keys.ensure(B * (size_t)P.keys_per_frame * sizeof(uint32_t)));
-    ORBFE_HIP(h->d_kord.ensure(B * (size_t)P.keys_per_frame * sizeof(uint32_t)));
     ORBFE_HIP(h->d_knode.ensure(B * (size_t)P.keys_per_frame * sizeof(uint16_t)));
     ORBFE_HIP(h->d_sel.ensure(B * (size_t)P.sel_per_frame * sizeof(uint32_t)));
     ORBFE_HIP(h->d_nsel.ensure(B * P.nlevels * sizeof(int32_t)));
@@ -564,7 +564,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_keys, &h->d_kord, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
                       &h->d_okps, &h->d_odesc, &h->d_on};
     for (DevBuf *b : bufs) b->release();
     PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
@@ -680,8 +680,6 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.pyr_fstride = h->plan.pyr_frame_bytes;
     a.d_skeys = (uint2 *)h->d_skeys.p;
     a.d_scount = (int32_t *)h->d_scount.p;
-    a.d_keys = (uint32_t *)h->d_keys.p;
-    a.d_kord = (uint32_t *)h->d_kord.p;
     a.d_knode = (uint16_t *)h->d_knode.p;
     a.d_sel = (uint32_t *)h->d_sel.p;
     a.d_nsel = (int32_t *)h->d_nsel.p;
@@ -904,19 +902,35 @@ extern "C" orbfe_status orbfe_tap_candidates(orbfe_handle *h, int32_t frame, int
     const OrbPlan &P = h->plan;
     const OrbLevel &L = P.lv[level];
     ORBFE_HIP(hipStreamSynchronize(h->stream));
-    int32_t nk = 0;
+    int32_t nk = 0, nsv = 0;
     ORBFE_HIP(hipMemcpy(&nk, (int32_t *)h->d_nkeys.p + ((size_t)frame * P.nlevels + level) * ORBFE_NK_STRIDE, sizeof(int32_t),
                         hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(&nsv, (int32_t *)h->d_scount.p + ((size_t)frame * P.nlevels + level) * ORBFE_NK_STRIDE, sizeof(int32_t),
+                        hipMemcpyDeviceToHost));
+    nsv = std::min(nsv, L.key_cap);
     *n = nk;
     if (nk > cap) return ORBFE_ERR_CAP;
     if (nk == 0) return ORBFE_OK;
     if (!xyr) return ORBFE_ERR_ARG;
-    // filtered keys are in arbitrary order; their `ord` is the rank key of the reference's candidate order
-    std::vector<uint32_t> kv((size_t)nk), ko((size_t)nk);
-    ORBFE_HIP(hipMemcpy(kv.data(), (uint32_t *)h->d_keys.p + (size_t)frame * P.keys_per_frame + L.key_off,
-                        sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost));
-    ORBFE_HIP(hipMemcpy(ko.data(), (uint32_t *)h->d_kord.p + (size_t)frame * P.keys_per_frame + L.key_off,
-                        sizeof(uint32_t) * (size_t)nk, hipMemcpyDeviceToHost));
+    // The device keeps the NMS survivors {key, ord} unordered and in place; the per-cell threshold fallback (:818-825) is
+    // the same rule k_octree applies: a survivor counts if it is above iniTh or its cell has no survivor above iniTh.
+    // `ord` is the rank key of the reference's candidate order.
+    std::vector<uint2> sv((size_t)nsv);
+    ORBFE_HIP(hipMemcpy(sv.data(), (uint2 *)h->d_skeys.p + (size_t)frame * P.keys_per_frame + L.key_off,
+                        sizeof(uint2) * (size_t)nsv, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> strong((size_t)L.ncells, 0);
+    for (const uint2 &e : sv)
+        if ((int)orb_key_r(e.x) >= P.ini_th && (e.y >> 12) < (uint32_t)L.ncells) strong[e.y >> 12] = 1;
+    std::vector<uint32_t> kv, ko;
+    for (const uint2 &e : sv)
+        if ((int)orb_key_r(e.x) >= P.ini_th || ((e.y >> 12) < (uint32_t)L.ncells && !strong[e.y >> 12])) {
+            kv.push_back(e.x);
+            ko.push_back(e.y);
+        }
+    if ((int)kv.size() != nk) {
+        orbfe_set_error("candidate tap: host filter found %d keys, device counted %d", (int)kv.size(), nk);
+        return ORBFE_ERR_STATE;
+    }
     std::vector<int> order((size_t)nk);
     for (int i = 0; i < nk; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](int a, int b) { return ko[a] < ko[b]; });

@@ -86,6 +86,7 @@ struct OrbPlan {
     int32_t w, h;              // level-0 size this plan was built for
     int32_t ncells;            // cells per frame (all levels)
     int32_t cell_cap;          // key slots per cell
+    int32_t max_ncells;        // largest FAST cell count of a level (quadtree cell-flag bitmap)
     int32_t keys_per_frame;    // key scratch entries per frame
     int32_t sel_per_frame;     // selected-keypoint scratch entries per frame
     int32_t node_cap;          // quadtree node capacity (power of two)

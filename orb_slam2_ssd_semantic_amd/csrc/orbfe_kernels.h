@@ -21,8 +21,6 @@ struct OrbLaunch {
     int64_t pyr_fstride;
     uint2 *d_skeys;      // unordered NMS survivors {key, ord} per level (k_fast_map)
     int32_t *d_scount;
-    uint32_t *d_keys;    // per level: keys after the per-cell threshold fallback
-    uint32_t *d_kord;
     uint16_t *d_knode;
     uint32_t *d_sel;
     int32_t *d_nsel;
@@ -35,8 +33,8 @@ struct OrbLaunch {
 };
 
 hipError_t orbk_upload_constants(const int *umax16);
-size_t orbk_octree_lds_bytes(int node_cap, int max_nini);
-hipError_t orbk_prepare_octree(int node_cap, int max_nini);
+size_t orbk_octree_lds_bytes(int node_cap, int max_nini, int w, int h, int ncells);
+hipError_t orbk_prepare_octree(int node_cap, int max_nini, int w, int h, int ncells);
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st);

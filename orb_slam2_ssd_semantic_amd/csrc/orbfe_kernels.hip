@@ -551,9 +551,15 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
 __host__ __device__ inline int ff_off(int d) { return ((1 << (2 * d)) - 4) / 3; }  // first entry of depth d (1..5)
 
 struct QtShared {
-    int16_t *box[2][4];  // ulx, uly, urx, bry
-    int32_t *cnt[2];
-    uint32_t *path[2];   // prefix | depth << 12 | root << 16
+    // two generations of the node list (current / next), addressed arithmetically -- an array of pointers indexed by
+    // a run-time generation would live in scratch memory
+    int M;
+    int16_t *box0;       // [2][4][M] ulx, uly, urx, bry
+    int32_t *cnt0;       // [2][M]
+    uint32_t *path0;     // [2][M] prefix | depth << 12 | root << 16
+    __device__ __forceinline__ int16_t *box(int g, int j) const { return box0 + (g * 4 + j) * M; }
+    __device__ __forceinline__ int32_t *cnt(int g) const { return cnt0 + g * M; }
+    __device__ __forceinline__ uint32_t *path(int g) const { return path0 + g * M; }
     int32_t *cc;         // [M*4] quadrant counts of the current pass
     int32_t *childpos;   // [M*4] position of child (node, quadrant) in the next list, -1 if empty
     int32_t *P;          // processing order -> node index
@@ -562,30 +568,37 @@ struct QtShared {
     int32_t *newIdx;     // next-list position of an unprocessed node, -1 for a processed one
     unsigned long long *skey;
     int32_t *hist;       // [nroots * FF_PER_ROOT] quadrant-path histogram, later the path -> node table
+    uint16_t *xtab;      // [w] window column -> root << 10 | x half of the 5-level path code (bits 8,6,4,2,0)
+    uint16_t *ytab;      // [h] window row    -> y half of the path code (bits 9,7,5,3,1)
+    uint32_t *cflag;     // [ncells / 32] bit = the FAST cell has a survivor above iniTh
     int32_t *misc;
 };
 
-__device__ __forceinline__ void qt_carve(char *base, int M, int nroots, QtShared &q)
+__device__ __forceinline__ void qt_carve(char *base, int M, int nroots, int w, int h, int ncells, QtShared &q)
 {
     char *p = base;
     q.skey = (unsigned long long *)p; p += (size_t)M * 8;
     q.cc = (int32_t *)p; p += (size_t)M * 16;
     q.childpos = (int32_t *)p; p += (size_t)M * 16;
-    for (int i = 0; i < 2; ++i) { q.cnt[i] = (int32_t *)p; p += (size_t)M * 4; }
-    for (int i = 0; i < 2; ++i) { q.path[i] = (uint32_t *)p; p += (size_t)M * 4; }
+    q.M = M;
+    q.cnt0 = (int32_t *)p; p += (size_t)M * 8;
+    q.path0 = (uint32_t *)p; p += (size_t)M * 8;
     q.P = (int32_t *)p; p += (size_t)M * 4;
     q.rankOf = (int32_t *)p; p += (size_t)M * 4;
     q.acc = (int32_t *)p; p += (size_t)M * 4;
     q.newIdx = (int32_t *)p; p += (size_t)M * 4;
-    for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 4; ++j) { q.box[i][j] = (int16_t *)p; p += (size_t)M * 2; }
+    q.box0 = (int16_t *)p; p += (size_t)M * 16;
     q.hist = (int32_t *)p; p += (size_t)nroots * FF_PER_ROOT * 4;
-    q.misc = (int32_t *)p;
+    q.misc = (int32_t *)p; p += 64 * 4;
+    q.xtab = (uint16_t *)p; p += (size_t)((w + 1) & ~1) * 2;
+    q.ytab = (uint16_t *)p; p += (size_t)((h + 1) & ~1) * 2;
+    q.cflag = (uint32_t *)p;
 }
 
-size_t orbk_octree_lds_bytes(int M, int nroots)
+size_t orbk_octree_lds_bytes(int M, int nroots, int w, int h, int ncells)
 {
-    return (size_t)M * (8 + 16 + 16 + 8 + 8 + 16 + 16) + (size_t)nroots * FF_PER_ROOT * 4 + 64 * 4;
+    return (size_t)M * (8 + 16 + 16 + 8 + 8 + 16 + 16) + (size_t)nroots * FF_PER_ROOT * 4 + 64 * 4 +
+           (size_t)(((w + 1) & ~1) + ((h + 1) & ~1)) * 2 + (size_t)((ncells + 31) / 32) * 4;
 }
 
 // LDS ordering inside ONE wave: its DS operations execute in order, the fence only keeps the compiler honest
@@ -637,7 +650,7 @@ __device__ __forceinline__ int qt_follow(const QtShared &q, uint32_t kn)
 // One generic pass at node level, executed by ONE wave (wave-synchronous, no barriers).
 // In:  q.cc[i*4+qd] for every node i in P (quadrant sizes), list `cur` of size S, processing order P[0..m), rankOf.
 // Out: list `cur^1` (boxes, sizes, paths), the old->new map (newIdx / childpos), next P / rankOf, S, m, modeB, finish.
-__device__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur, int &modeB, bool &finish, int lane)
+__device__ __forceinline__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur, int &modeB, bool &finish, int lane)
 {
     const int nx = cur ^ 1;
     // non-empty children per processing rank, inclusive sums, stop rank R
@@ -666,22 +679,22 @@ __device__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur
     // write the next list; leave the old->new map (newIdx / childpos) for whoever follows the keys
     for (int i = lane; i < S; i += 64) {
         const int r = q.rankOf[i];
-        const uint32_t pth = q.path[cur][i];
+        const uint32_t pth = q.path(cur)[i];
         if (r >= 0 && r < R) {
             int pos = totalChildren - q.acc[r];
-            const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
-            const int urx = q.box[cur][2][i], bry = q.box[cur][3][i];
+            const int ulx = q.box(cur, 0)[i], uly = q.box(cur, 1)[i];
+            const int urx = q.box(cur, 2)[i], bry = q.box(cur, 3)[i];
             const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);  // ceil(w/2) (:480-481)
             const uint32_t cpath = (pth & 0xFFFF0000u) | ((((pth >> 12) & 0xFu) + 1u) << 12) | ((pth & 0xFFFu) << 2);
             for (int qd = 3; qd >= 0; --qd) {  // list front holds n4, then n3, n2, n1 (:623-662)
                 const int cn = q.cc[i * 4 + qd];
                 if (cn > 0) {
-                    q.box[nx][0][pos] = (int16_t)((qd & 1) ? midx : ulx);
-                    q.box[nx][1][pos] = (int16_t)((qd & 2) ? midy : uly);
-                    q.box[nx][2][pos] = (int16_t)((qd & 1) ? urx : midx);
-                    q.box[nx][3][pos] = (int16_t)((qd & 2) ? bry : midy);
-                    q.cnt[nx][pos] = cn;
-                    q.path[nx][pos] = cpath | (uint32_t)qd;
+                    q.box(nx, 0)[pos] = (int16_t)((qd & 1) ? midx : ulx);
+                    q.box(nx, 1)[pos] = (int16_t)((qd & 2) ? midy : uly);
+                    q.box(nx, 2)[pos] = (int16_t)((qd & 1) ? urx : midx);
+                    q.box(nx, 3)[pos] = (int16_t)((qd & 2) ? bry : midy);
+                    q.cnt(nx)[pos] = cn;
+                    q.path(nx)[pos] = cpath | (uint32_t)qd;
                     q.childpos[i * 4 + qd] = pos;
                     ++pos;
                 } else {
@@ -691,12 +704,12 @@ __device__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur
             q.newIdx[i] = -1;
         } else {
             const int pos = totalChildren + q.newIdx[i] - 1;
-            q.box[nx][0][pos] = q.box[cur][0][i];
-            q.box[nx][1][pos] = q.box[cur][1][i];
-            q.box[nx][2][pos] = q.box[cur][2][i];
-            q.box[nx][3][pos] = q.box[cur][3][i];
-            q.cnt[nx][pos] = q.cnt[cur][i];
-            q.path[nx][pos] = pth;
+            q.box(nx, 0)[pos] = q.box(cur, 0)[i];
+            q.box(nx, 1)[pos] = q.box(cur, 1)[i];
+            q.box(nx, 2)[pos] = q.box(cur, 2)[i];
+            q.box(nx, 3)[pos] = q.box(cur, 3)[i];
+            q.cnt(nx)[pos] = q.cnt(cur)[i];
+            q.path(nx)[pos] = pth;
             q.newIdx[i] = pos;
         }
     }
@@ -707,7 +720,7 @@ __device__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur
         int mc = 0;
         for (int qd = 0; qd < 4; ++qd) {
             const int pos = q.childpos[i * 4 + qd];
-            if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
+            if (pos >= 0 && q.cnt(nx)[pos] > 1) ++mc;
         }
         q.acc[r] = mc;
     }
@@ -721,11 +734,11 @@ __device__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur
     if (!finish) {
         if (!modeB2) {
             // list order of the multi-key nodes of the new list; P/rankOf of the OLD list are dead now
-            for (int i = lane; i < S2; i += 64) ((int32_t *)q.skey)[i] = q.cnt[nx][i] > 1 ? 1 : 0;
+            for (int i = lane; i < S2; i += 64) ((int32_t *)q.skey)[i] = q.cnt(nx)[i] > 1 ? 1 : 0;
             WSYNC();
             m2 = wscan_inclusive((int32_t *)q.skey, S2, lane);
             for (int i = lane; i < S2; i += 64) {
-                const bool multi = q.cnt[nx][i] > 1;
+                const bool multi = q.cnt(nx)[i] > 1;
                 const int r = ((int32_t *)q.skey)[i] - 1;
                 q.rankOf[i] = multi ? r : -1;
                 if (multi) q.P[r] = i;
@@ -741,13 +754,13 @@ __device__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur
                 int mc = 0;
                 for (int qd = 0; qd < 4; ++qd) {
                     const int pos = q.childpos[i * 4 + qd];
-                    if (pos >= 0 && q.cnt[nx][pos] > 1) ++mc;
+                    if (pos >= 0 && q.cnt(nx)[pos] > 1) ++mc;
                 }
                 int seq = q.acc[r] - mc;  // acc is inclusive
                 for (int qd = 0; qd < 4; ++qd) {
                     const int pos = q.childpos[i * 4 + qd];
-                    if (pos >= 0 && q.cnt[nx][pos] > 1) {
-                        q.skey[seq] = ((unsigned long long)(uint32_t)q.cnt[nx][pos] << 32) |
+                    if (pos >= 0 && q.cnt(nx)[pos] > 1) {
+                        q.skey[seq] = ((unsigned long long)(uint32_t)q.cnt(nx)[pos] << 32) |
                                       ((unsigned long long)(uint32_t)(seq + 1) << 16) | (unsigned long long)pos;
                         ++seq;
                     }
@@ -786,9 +799,7 @@ __device__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur
 __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict__ plan,
                                                const uint2 *__restrict__ skeys,     // [B][keys_per_frame] {key, ord} from k_fast_map
                                                const int32_t *__restrict__ scount,  // [B][nlevels] * NK_STRIDE
-                                               uint32_t *__restrict__ keys,         // [B][keys_per_frame] scratch: filtered keys
-                                               uint32_t *__restrict__ kord,         // [B][keys_per_frame] scratch: their ord
-                                               uint16_t *__restrict__ knode,        // [B][keys_per_frame] scratch
+                                               uint16_t *__restrict__ knode,        // [B][keys_per_frame] scratch (deep trees only)
                                                int32_t *__restrict__ nkeys,         // [B][nlevels] out (taps)
                                                uint32_t *__restrict__ sel,          // [B][sel_per_frame] out
                                                int32_t *__restrict__ nsel)          // [B][nlevels] out
@@ -797,15 +808,14 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int QT = blockDim.x;  // 256 .. 512 (launch-time choice)
+    if (plan->dbg == 60) return;  // XDBG
     const OrbLevel &L = plan->lv[level];
     const int M = plan->node_cap;
     const int N = L.nfeat;
     QtShared q;
-    qt_carve(smem, M, plan->max_nini, q);
+    qt_carve(smem, M, plan->max_nini, plan->w, plan->h, plan->max_ncells, q);
     int32_t *misc = q.misc;
     const uint2 *SK = skeys + (int64_t)b * plan->keys_per_frame + L.key_off;
-    uint32_t *K = keys + (int64_t)b * plan->keys_per_frame + L.key_off;
-    uint32_t *KO = kord + (int64_t)b * plan->keys_per_frame + L.key_off;
     uint16_t *KN = knode + (int64_t)b * plan->keys_per_frame + L.key_off;
     const int nini = L.nini;
     const int ybot = L.h - 2 * ORBFE_MINB;  // maxBorderY - minBorderY
@@ -813,12 +823,40 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     // ---- prologue 1: the reference's per-cell threshold fallback (:818-825) on the unordered survivor list ----
     // A cell contributes {A > iniTh} if that is non-empty, else all its NMS survivors ({A > minTh}).
     const int ns = min(scount[(b * plan->nlevels + level) * ORBFE_NK_STRIDE], L.key_cap);
-    uint32_t *cflag = (uint32_t *)q.cc;  // bitmap over this level's cells (M*16 bytes >= ncells/8 checked on the host)
+    uint32_t *cflag = q.cflag;  // bitmap over this level's cells; stays valid to the end of the kernel
     const int nwords = (L.ncells + 31) >> 5;
     for (int i = tid; i < nwords; i += QT) cflag[i] = 0u;
     for (int i = tid; i < nini * FF_PER_ROOT; i += QT) q.hist[i] = 0;
     if (tid == 0) misc[5] = 0;
+    if (plan->dbg == 65) { if (ns == 123456789) misc[0] = 1; __syncthreads(); return; }  // XDBG
+    // DivideNode (:478-522) halves x and y independently (mid = UL + ceil(extent / 2)), so a key's 5-level quadrant
+    // path is the bit-interleave of a 5-level x path (a function of the key's column and root) and a 5-level y path
+    // (a function of its row): two small tables replace five DivideNode steps per key.
+    const int winw = L.w - 2 * ORBFE_MINB;
+    for (int i = tid; i < winw + ybot; i += QT) {
+        const bool isx = i < winw;
+        const int v = isx ? i : i - winw;
+        int lo = 0, hi = ybot, r = 0;
+        if (isx) {  // roots (:545-571): key -> root by (int)(x / hX)
+            r = (int)__fdiv_rn((float)v, L.hx);
+            r = min(max(r, 0), nini - 1);
+            lo = L.root_x[r];
+            hi = L.root_x[r + 1];
+        }
+        uint32_t code = 0;
+#pragma unroll
+        for (int d = 0; d < FFD; ++d) {
+            const int mid = lo + ((hi - lo + 1) >> 1);
+            const int hb = v < mid ? 0 : 1;
+            code = (code << 2) | (uint32_t)hb;
+            lo = hb ? mid : lo;
+            hi = hb ? hi : mid;
+        }
+        if (isx) q.xtab[v] = (uint16_t)(((uint32_t)r << 10) | code);
+        else q.ytab[v] = (uint16_t)(code << 1);
+    }
     __syncthreads();
+    if (plan->dbg == 64) return;  // XDBG
     const int ini = plan->ini_th;
     for (int k0 = tid; k0 < ns; k0 += QT * KUNROLL) {
         uint2 e[KUNROLL];
@@ -828,55 +866,41 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
         for (int u = 0; u < KUNROLL; ++u)
             if (k0 + u * QT < ns && orb_key_r(e[u].x) >= ini) {  // cv score = A - 1 >= iniTh  <=>  A > iniTh
                 const uint32_t cell = e[u].y >> 12;
-                atomicOr(&cflag[cell >> 5], 1u << (cell & 31));
+                // neighbouring keys share cells (and flag words): test first, the atomics would serialise
+                if (!((cflag[cell >> 5] >> (cell & 31)) & 1u)) atomicOr(&cflag[cell >> 5], 1u << (cell & 31));
             }
     }
     __syncthreads();
-    // ---- prologue 2: keep / drop, compact, root + 5-level quadrant path of every kept key, leaf histogram ----
-    for (int k0 = 0; k0 < ns; k0 += QT * KUNROLL) {
+    if (plan->dbg == 61) return;  // XDBG
+    // ---- prologue 2: leaf histogram of the kept keys (a key is kept if it is above iniTh or its cell has no such key).
+    // Keys are never moved or copied: whoever needs a key later re-derives "kept" and its path code from the key.
+    auto key_kept = [&](const uint2 &e) {
+        const uint32_t cell = e.y >> 12;
+        return (int)orb_key_r(e.x) >= ini || !((cflag[cell >> 5] >> (cell & 31)) & 1u);
+    };
+    auto key_code = [&](const uint2 &e) {  // root << 10 | 5-level path code
+        return (uint32_t)q.xtab[orb_key_x(e.x)] | (uint32_t)q.ytab[orb_key_y(e.x)];
+    };
+    int nkept = 0;
+    for (int k0 = tid; k0 < ns; k0 += QT * KUNROLL) {
         uint2 e[KUNROLL];
 #pragma unroll
-        for (int u = 0; u < KUNROLL; ++u) e[u] = SK[min(k0 + u * QT + tid, ns - 1)];
+        for (int u = 0; u < KUNROLL; ++u) e[u] = SK[min(k0 + u * QT, ns - 1)];
 #pragma unroll
-        for (int u = 0; u < KUNROLL; ++u) {
-            const int k = k0 + u * QT + tid;
-            bool keep = false;
-            if (k < ns) {
-                const uint32_t cell = e[u].y >> 12;
-                keep = orb_key_r(e[u].x) >= ini || !((cflag[cell >> 5] >> (cell & 31)) & 1u);
+        for (int u = 0; u < KUNROLL; ++u)
+            if (k0 + u * QT < ns && key_kept(e[u])) {
+                const uint32_t rc = key_code(e[u]);
+                atomicAdd(&q.hist[(int)(rc >> 10) * FF_PER_ROOT + ff_off(FFD) + (int)(rc & 0x3FFu)], 1);
+                ++nkept;
             }
-            const unsigned long long bal = __ballot(keep);
-            int base = 0;
-            if (lane == 0 && bal) base = atomicAdd(&misc[5], __popcll(bal));
-            base = __shfl(base, 0, 64);
-            if (keep) {
-                const int o = base + lanes_below(bal);
-                K[o] = e[u].x;
-                KO[o] = e[u].y;
-                const int kx = orb_key_x(e[u].x), ky = orb_key_y(e[u].x);
-                // roots (:545-571): key -> root by (int)(x / hX)
-                int r = (int)__fdiv_rn((float)kx, L.hx);
-                r = min(max(r, 0), nini - 1);
-                int ulx = L.root_x[r], urx = L.root_x[r + 1], uly = 0, bry = ybot;
-                uint32_t code = 0;
-#pragma unroll
-                for (int d = 0; d < FFD; ++d) {  // DivideNode (:478-522) five times, in registers
-                    const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);
-                    const int qx = kx < midx ? 0 : 1, qy = ky < midy ? 0 : 1;
-                    code = (code << 2) | (uint32_t)(qx + 2 * qy);
-                    ulx = qx ? midx : ulx;
-                    urx = qx ? urx : midx;
-                    uly = qy ? midy : uly;
-                    bry = qy ? bry : midy;
-                }
-                KN[o] = (uint16_t)(((uint32_t)r << 10) | code);
-                atomicAdd(&q.hist[r * FF_PER_ROOT + ff_off(FFD) + (int)code], 1);
-            }
-        }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nkept += __shfl_xor(nkept, o, 64);
+    if (lane == 0 && nkept) atomicAdd(&misc[5], nkept);
     __syncthreads();
     const int n = misc[5];
     if (tid == 0) nkeys[(b * plan->nlevels + level) * ORBFE_NK_STRIDE] = n;
+    if (plan->dbg == 62) return;  // XDBG
 
     // ---- histogram passes: wave 0 alone, no key is touched ----
     if (wid == 0) {
@@ -896,17 +920,17 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
                 const int32_t *h1 = &q.hist[r * FF_PER_ROOT];
                 const int cn = h1[0] + h1[1] + h1[2] + h1[3];
                 if (cn > 0) {
-                    q.box[0][0][S] = (int16_t)L.root_x[r];
-                    q.box[0][1][S] = 0;
-                    q.box[0][2][S] = (int16_t)L.root_x[r + 1];
-                    q.box[0][3][S] = (int16_t)ybot;
-                    q.cnt[0][S] = cn;
-                    q.path[0][S] = (uint32_t)r << 16;
+                    q.box(0, 0)[S] = (int16_t)L.root_x[r];
+                    q.box(0, 1)[S] = 0;
+                    q.box(0, 2)[S] = (int16_t)L.root_x[r + 1];
+                    q.box(0, 3)[S] = (int16_t)ybot;
+                    q.cnt(0)[S] = cn;
+                    q.path(0)[S] = (uint32_t)r << 16;
                     ++S;
                 }
             }
             for (int i = 0; i < S; ++i) {  // initial processing order: multi-key roots in list order
-                if (q.cnt[0][i] > 1) { q.P[m] = i; q.rankOf[i] = m; ++m; }
+                if (q.cnt(0)[i] > 1) { q.P[m] = i; q.rankOf[i] = m; ++m; }
                 else q.rankOf[i] = -1;
             }
         }
@@ -918,7 +942,7 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
         while (!finish && npass < ffd) {  // nodes processed in pass p have depth <= p-1 <= 4: sizes come from the histogram
             for (int r = lane; r < m; r += 64) {
                 const int i = q.P[r];
-                const uint32_t pth = q.path[cur][i];
+                const uint32_t pth = q.path(cur)[i];
                 const int d = (int)((pth >> 12) & 0xFu), root = (int)(pth >> 16);
                 const int32_t *src = &q.hist[root * FF_PER_ROOT + ff_off(d + 1) + (int)((pth & 0xFFFu) << 2)];
                 q.cc[i * 4] = src[0];
@@ -935,7 +959,7 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
         if (lane < 4) misc[8 + lane] = -1;
         WSYNC();
         for (int i = lane; i < S; i += 64) {
-            const uint32_t pth = q.path[cur][i];
+            const uint32_t pth = q.path(cur)[i];
             const int d = (int)((pth >> 12) & 0xFu), root = (int)(pth >> 16);
             if (d == 0) misc[8 + root] = i;
             else q.hist[root * FF_PER_ROOT + ff_off(d) + (int)(pth & 0xFFFu)] = i;
@@ -953,44 +977,53 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     __syncthreads();
     int S = misc[0], m = misc[1], cur = misc[2];
     const bool ff_done = misc[3] != 0;
+    if (plan->dbg == 63) return;  // XDBG
 
-    // node of a key from its path code: the deepest table hit (only one node of the path exists)
-    auto node_of_code = [&](uint32_t kn) {
-        const int root = (int)(kn >> 10), code = (int)(kn & 0x3FFu);
+    // flatten the path -> node table: every leaf learns the one node of its path that exists (the deepest table hit),
+    // in place -- a leaf entry is read and written by its own thread only, the shallower levels are read-only here
+    for (int i = tid; i < nini << (2 * FFD); i += QT) {
+        const int root = i >> (2 * FFD), code = i & ((1 << (2 * FFD)) - 1);
         int idx = misc[8 + root];
 #pragma unroll
-        for (int d = 1; d <= FFD; ++d) {
+        for (int d = 1; d < FFD; ++d) {
             const int t = q.hist[root * FF_PER_ROOT + ff_off(d) + (code >> (2 * (FFD - d)))];
             idx = t >= 0 ? t : idx;
         }
-        return idx;
-    };
+        int32_t *leaf = &q.hist[root * FF_PER_ROOT + ff_off(FFD) + code];
+        const int t = *leaf;
+        *leaf = t >= 0 ? t : idx;
+    }
+    __syncthreads();
+    auto node_of_code = [&](uint32_t kn) { return q.hist[(int)(kn >> 10) * FF_PER_ROOT + ff_off(FFD) + (int)(kn & 0x3FFu)]; };
 
     if (!ff_done) {
         // ---- deeper trees: keys take their node index and the passes stream over the keys ----
-        for (int k = tid; k < n; k += QT) KN[k] = (uint16_t)node_of_code(KN[k]);
+        for (int k = tid; k < ns; k += QT) {
+            const uint2 e = SK[k];
+            KN[k] = key_kept(e) ? (uint16_t)node_of_code(key_code(e)) : (uint16_t)0xFFFFu;  // 0xFFFF = dropped key
+        }
         __syncthreads();
         for (int guard = 0; guard < 64; ++guard) {
             for (int i = tid; i < S * 4; i += QT) q.cc[i] = 0;
             __syncthreads();
-            for (int k0 = tid; k0 < n; k0 += QT * KUNROLL) {
+            for (int k0 = tid; k0 < ns; k0 += QT * KUNROLL) {
                 uint32_t kn[KUNROLL], kv[KUNROLL];
 #pragma unroll
                 for (int u = 0; u < KUNROLL; ++u) {
-                    const int k = min(k0 + u * QT, n - 1);
+                    const int k = min(k0 + u * QT, ns - 1);
                     kn[u] = KN[k];
-                    kv[u] = K[k];
+                    kv[u] = SK[k].x;
                 }
 #pragma unroll
                 for (int u = 0; u < KUNROLL; ++u) {
                     const int k = k0 + u * QT;
-                    if (k < n) {
+                    if (k < ns && kn[u] != 0xFFFFu) {
                         const int i = qt_follow(q, kn[u]);
                         uint32_t out = (uint32_t)i;
-                        if (q.cnt[cur][i] > 1) {
-                            const int ulx = q.box[cur][0][i], uly = q.box[cur][1][i];
-                            const int midx = ulx + ((q.box[cur][2][i] - ulx + 1) >> 1);  // UL.x + ceil(w/2)  (:480)
-                            const int midy = uly + ((q.box[cur][3][i] - uly + 1) >> 1);
+                        if (q.cnt(cur)[i] > 1) {
+                            const int ulx = q.box(cur, 0)[i], uly = q.box(cur, 1)[i];
+                            const int midx = ulx + ((q.box(cur, 2)[i] - ulx + 1) >> 1);  // UL.x + ceil(w/2)  (:480)
+                            const int midy = uly + ((q.box(cur, 3)[i] - uly + 1) >> 1);
                             const int qd = (orb_key_x(kv[u]) < midx ? 0 : 1) + (orb_key_y(kv[u]) < midy ? 0 : 2);
                             atomicAdd(&q.cc[i * 4 + qd], 1);
                             out |= (uint32_t)qd << 14;
@@ -1026,22 +1059,24 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     unsigned long long *best = q.skey;
     for (int i = tid; i < S; i += QT) best[i] = 0ull;
     __syncthreads();
-    for (int k0 = tid; k0 < n; k0 += QT * KUNROLL) {
-        uint32_t kn[KUNROLL], kv[KUNROLL], ko[KUNROLL];
+    for (int k0 = tid; k0 < ns; k0 += QT * KUNROLL) {
+        uint2 e[KUNROLL];
+        uint32_t kn[KUNROLL];
 #pragma unroll
         for (int u = 0; u < KUNROLL; ++u) {
-            const int k = min(k0 + u * QT, n - 1);
-            kn[u] = KN[k];
-            kv[u] = K[k];
-            ko[u] = KO[k];
+            const int k = min(k0 + u * QT, ns - 1);
+            e[u] = SK[k];
+            kn[u] = ff_done ? 0u : (uint32_t)KN[k];
         }
 #pragma unroll
         for (int u = 0; u < KUNROLL; ++u) {
             const int k = k0 + u * QT;
-            if (k < n) {
-                const int i = ff_done ? node_of_code(kn[u]) : qt_follow(q, kn[u]);
-                atomicMax(&best[i], ((unsigned long long)orb_key_r(kv[u]) << 52) |
-                                        ((unsigned long long)(0x0FFFFFFFu - ko[u]) << 24) | (unsigned long long)k);
+            if (k < ns && (ff_done ? key_kept(e[u]) : kn[u] != 0xFFFFu)) {
+                const int i = ff_done ? node_of_code(key_code(e[u])) : qt_follow(q, kn[u]);
+                const unsigned long long cand = ((unsigned long long)orb_key_r(e[u].x) << 52) |
+                                                ((unsigned long long)(0x0FFFFFFFu - e[u].y) << 24) | (unsigned long long)k;
+                // neighbouring keys share nodes: a plain read filters most of them before the (serialising) atomic
+                if (cand > best[i]) atomicMax(&best[i], cand);
             }
         }
     }
@@ -1049,7 +1084,7 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     uint32_t *out = sel + (int64_t)b * plan->sel_per_frame + L.sel_off;
     const int nout = min(S, L.sel_cap);
     for (int i = tid; i < nout; i += QT) {
-        const uint32_t key = K[(uint32_t)(best[i] & 0xFFFFFFull)];
+        const uint32_t key = SK[(uint32_t)(best[i] & 0xFFFFFFull)].x;
         // + minBorderX / minBorderY (:853-854): level coordinates from here on
         out[i] = orb_pack_key(orb_key_x(key) + ORBFE_MINB, orb_key_y(key) + ORBFE_MINB, orb_key_r(key));
     }
@@ -1477,16 +1512,16 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
 hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
 {
     dim3 grid(a.h_plan->nlevels, a.nframes);
-    const size_t lds = orbk_octree_lds_bytes(a.h_plan->node_cap, a.h_plan->max_nini);
+    const size_t lds = orbk_octree_lds_bytes(a.h_plan->node_cap, a.h_plan->max_nini, a.h_plan->w, a.h_plan->h, a.h_plan->max_ncells);
     static const int qt = getenv("ORBFE_QT") ? atoi(getenv("ORBFE_QT")) : 512;  // must be <= QT_MAX
-    hipLaunchKernelGGL(k_octree, grid, dim3(qt), lds, st, a.d_plan, a.d_skeys, a.d_scount, a.d_keys, a.d_kord, a.d_knode,
+    hipLaunchKernelGGL(k_octree, grid, dim3(qt), lds, st, a.d_plan, a.d_skeys, a.d_scount, a.d_knode,
                        a.d_nkeys, a.d_sel, a.d_nsel);
     return hipGetLastError();
 }
 
-hipError_t orbk_prepare_octree(int node_cap, int max_nini)
+hipError_t orbk_prepare_octree(int node_cap, int max_nini, int w, int h, int ncells)
 {
-    const size_t lds = orbk_octree_lds_bytes(node_cap, max_nini);
+    const size_t lds = orbk_octree_lds_bytes(node_cap, max_nini, w, h, ncells);
     return hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
