@@ -123,6 +123,9 @@ struct PinBuf {
 // handle
 // ---------------------------------------------------------------------------------------------------
 #define ORBFE_PROF_RING 64
+// rows a FAST / blur wave walks down.  Measured on MI355X (256 x 640x480): 24..48 rows are equally fast and ~5 % faster
+// than 64+ -- the 6..8 warm-up rows of a block are nearly free, while shorter waves balance the CUs better.
+#define ORBFE_ROWS_PER_WAVE 40
 // event marks of one profiled call: 0 start, 1 pyramid done, 2 FAST done, 3 quadtree done, 4 describe start, 5 end (launch
 // stream); 6 / 7 around the blur (on whichever stream it ran)
 #define ORBFE_EV_N 8
@@ -346,7 +349,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         }
     P.pyr_frame_bytes = off;
     if (tabs.empty()) tabs.resize(1);
-    // FAST lane list: per level, per (balanced) row block of <= 64 rows, the 4-px columns x = 16, 20, ... < ix1 form a
+    // FAST lane list: per level, per (balanced) row block of <= ORBFE_ROWS_PER_WAVE rows, the 4-px columns x = 16, 20, ... < ix1 form a
     // strip; strips are packed back to back into single-level waves of 64 lanes.  Where a wave boundary falls inside a
     // strip, each side gets one halo lane (computes neighbour strengths, outputs nothing).
     std::vector<OrbLane> flanes;
@@ -356,7 +359,8 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             const OrbLevel &L = P.lv[l];
             const int rows = L.iy1 - ORBFE_EDGE, ncol = (L.ix1 - 16 + 3) / 4;
             if (rows <= 0 || ncol <= 0) continue;
-            const int nblk = (rows + 63) / 64, rb = (rows + nblk - 1) / nblk;
+            const int frb = ORBFE_ROWS_PER_WAVE;
+            const int nblk = (rows + frb - 1) / frb, rb = (rows + nblk - 1) / nblk;
             for (int k = 0; k < nblk; ++k) {
                 const int ys = ORBFE_EDGE + k * rb, nr = std::min(rb, L.iy1 - ys);
                 for (int c = 0; c < ncol && nr > 0; ++c) {
@@ -403,12 +407,13 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         }
     }
     P.nfwaves = (int)(flanes.size() / 64);
-    // blur lane list: every 4-px column of every (balanced, <= 64 rows) row block, single-level waves, no halos
+    // blur lane list: every 4-px column of every (balanced, <= ORBFE_ROWS_PER_WAVE rows) row block, single-level waves, no halos
     std::vector<OrbLane> blanes;
     for (int l = 0; l < nl; ++l) {
         const OrbLevel &L = P.lv[l];
         if (L.w < 16) { orbfe_set_error("level %d too narrow for the blur kernel", l); return ORBFE_ERR_SIZE; }
-        const int ncol = (L.w + 3) / 4, nblk = (L.h + 63) / 64, rb = (L.h + nblk - 1) / nblk;
+        const int brb = ORBFE_ROWS_PER_WAVE;
+        const int ncol = (L.w + 3) / 4, nblk = (L.h + brb - 1) / brb, rb = (L.h + nblk - 1) / nblk;
         for (int k = 0; k < nblk; ++k) {
             const int ys = k * rb, nr = std::min(rb, L.h - ys);
             for (int c = 0; c < ncol && nr > 0; ++c) {

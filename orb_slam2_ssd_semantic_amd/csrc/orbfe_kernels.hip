@@ -208,7 +208,7 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 
 // Dense streaming formulation.
 //
-// k_fast_map   one wave per (level, 248-px strip, 64-row block).  Every lane owns 4 adjacent pixels and walks down
+// k_fast_map   one wave per (level, 256-px strip piece, row block).  Every lane owns 4 adjacent pixels and walks down
 //              the rows with the last 7 image rows (3 dwords each) in registers -- no LDS, no byte loads.  With
 //              raw pixel values c[0..15] on the circle,  min over an arc of (v - c) = v - max(c)  and
 //              min over an arc of (c - v) = min(c) - v, so
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
     __shared__ uint2 s_buf[4][FM_BUF];
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int t = blockIdx.x * 4 + wv;
+    const int t = blockIdx.x * (blockDim.x >> 6) + wv;
     if (t >= nwaves) return;
     // Work is described per LANE: a 4-pixel column, a run of rows, "halo" (contributes neighbour strengths only).
     // The host packs the column strips of all row blocks of one level back to back into 64-lane waves, so narrow
@@ -808,7 +808,6 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int QT = blockDim.x;  // 256 .. 512 (launch-time choice)
-    if (plan->dbg == 60) return;  // XDBG
     const OrbLevel &L = plan->lv[level];
     const int M = plan->node_cap;
     const int N = L.nfeat;
@@ -828,7 +827,6 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     for (int i = tid; i < nwords; i += QT) cflag[i] = 0u;
     for (int i = tid; i < nini * FF_PER_ROOT; i += QT) q.hist[i] = 0;
     if (tid == 0) misc[5] = 0;
-    if (plan->dbg == 65) { if (ns == 123456789) misc[0] = 1; __syncthreads(); return; }  // XDBG
     // DivideNode (:478-522) halves x and y independently (mid = UL + ceil(extent / 2)), so a key's 5-level quadrant
     // path is the bit-interleave of a 5-level x path (a function of the key's column and root) and a 5-level y path
     // (a function of its row): two small tables replace five DivideNode steps per key.
@@ -856,7 +854,6 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
         else q.ytab[v] = (uint16_t)(code << 1);
     }
     __syncthreads();
-    if (plan->dbg == 64) return;  // XDBG
     const int ini = plan->ini_th;
     for (int k0 = tid; k0 < ns; k0 += QT * KUNROLL) {
         uint2 e[KUNROLL];
@@ -871,7 +868,6 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
             }
     }
     __syncthreads();
-    if (plan->dbg == 61) return;  // XDBG
     // ---- prologue 2: leaf histogram of the kept keys (a key is kept if it is above iniTh or its cell has no such key).
     // Keys are never moved or copied: whoever needs a key later re-derives "kept" and its path code from the key.
     auto key_kept = [&](const uint2 &e) {
@@ -900,7 +896,6 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     __syncthreads();
     const int n = misc[5];
     if (tid == 0) nkeys[(b * plan->nlevels + level) * ORBFE_NK_STRIDE] = n;
-    if (plan->dbg == 62) return;  // XDBG
 
     // ---- histogram passes: wave 0 alone, no key is touched ----
     if (wid == 0) {
@@ -977,7 +972,6 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     __syncthreads();
     int S = misc[0], m = misc[1], cur = misc[2];
     const bool ff_done = misc[3] != 0;
-    if (plan->dbg == 63) return;  // XDBG
 
     // flatten the path -> node table: every leaf learns the one node of its path that exists (the deepest table hit),
     // in place -- a leaf entry is read and written by its own thread only, the shallower levels are read-only here
@@ -1110,7 +1104,7 @@ __host__ __device__ constexpr uint32_t blur_hw(int j, int d)
     return w;
 }
 
-// Work is described per LANE (a 4-pixel column, a run of <= 64 rows), packed by the host into single-level waves, so
+// Work is described per LANE (a 4-pixel column, a short run of rows), packed by the host into single-level waves, so
 // no lane idles on narrow levels.  Column borders are branch-free: every lane loads 3 dwords from a per-lane base that
 // covers all (reflected) source pixels of its 12-byte window and rearranges them with per-lane byte selectors
 // (identity for interior lanes); row borders are a per-lane reflected row index.
