@@ -265,14 +265,14 @@ def main():
                 e1(img)
                 lat.append(time.perf_counter() - t2)
             result["single_frame_host_latency_ms"] = round(float(np.median(lat)) * 1e3, 4)
-            pm = os.path.join(ROOT, "profiles", "r01_v3_pmc_hbm.json")
+            pm = os.path.join(ROOT, "profiles", "r01_v5_pmc_hbm.json")
             if os.path.exists(pm):  # HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes
                 try:
                     pj = json.load(open(pm))
                     kn = roof["kernel"].split(" ")[0]
                     tb = (pj["FETCH_SIZE_KB"][kn]["mean_per_launch"] + pj["WRITE_SIZE_KB"][kn]["mean_per_launch"]) * 1024
                     roof["traffic"] = int(tb)
-                    roof["traffic_note"] = "FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_v3_pmc_hbm.json (separate --pmc passes, uncorrected)"
+                    roof["traffic_note"] = "FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_v5_pmc_hbm.json (separate --pmc passes, uncorrected)"
                 except Exception:
                     pass
         if world == 1 and not args.no_cpu_baseline:
