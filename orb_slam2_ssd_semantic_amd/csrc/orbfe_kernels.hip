@@ -1333,14 +1333,28 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[16][DS_PR * DS_PP];
     __shared__ uint2 s_momw[31 * 8];
-    __shared__ uint32_t s_pat[256];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    __shared__ float4 s_pat[256];  // (x0, y0, x1, y1) of every test pair as floats
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, each XCD has its own 4 MB
+    // L2 and a frame's two pyramids are ~2 MB.  With a multiple of 8 frames, all workgroups of frame f run on XCD
+    // f % 8, so overlapping patches of a frame are fetched from HBM once instead of once per XCD.
+    int b = blockIdx.y, bx = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, j = lin >> 3;
+        b = xcd + 8 * (j / (int)gridDim.x);
+        bx = j % (int)gridDim.x;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
     const int sub = lane & 15, quad = tid >> 4;  // quad 0..15 inside the workgroup = one keypoint
     for (int i = tid; i < 31 * 8; i += 256) s_momw[i] = c_momw[i];
-    s_pat[tid] = ((const uint32_t *)c_pattern)[tid];
+    {
+        const uint32_t pt = ((const uint32_t *)c_pattern)[tid];
+        // pair p = 16 * sub + i is stored at [i][sub]: the 16 lanes of a keypoint read consecutive float4s
+        s_pat[(tid & 15) * 16 + (tid >> 4)] = make_float4((float)(int8_t)(pt & 0xFF), (float)(int8_t)((pt >> 8) & 0xFF),
+                                                         (float)(int8_t)((pt >> 16) & 0xFF), (float)(int8_t)(pt >> 24));
+    }
     __syncthreads();
 
-    const int slot = blockIdx.x * 16 + quad;
+    const int slot = bx * 16 + quad;
     const int nl = plan->nlevels;
     const int32_t *ns = nsel + b * nl;
     int level = -1, idx = slot, total = 0;
@@ -1403,31 +1417,43 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     // ---- C: blurred patch -> LDS ----
     uint8_t *patch = s_patch[quad];
     {
-        const uint8_t *bp = blur + (int64_t)b * blur_fstride + L.off + (int64_t)(y - 18) * L.pitch + (x - 18);
+        const int bpitch = L.pitch;
+        const uint8_t *bp = blur + (int64_t)b * blur_fstride + L.off + (int64_t)(y - 18) * bpitch + (x - 18);
+        // dword f = it * 16 + sub of the 37 x 10 dword patch: (row, k) advance by (1, 6) per iteration, with carry
+        int row = sub >= 10 ? 1 : 0, kk = sub >= 10 ? sub - 10 : sub;
+        uint32_t v[24];
+        int lofs[24];
 #pragma unroll
         for (int it = 0; it < 24; ++it) {
-            const int f = it * 16 + sub;            // dword index 0 .. 369
-            const int fr = min(f, DS_PR * 10 - 1);
-            const int row = (fr * 6554) >> 16;      // fr / 10 for fr < 16384
-            const int kk = fr - row * 10;
-            const uint32_t v = *(const uint32_t *)(bp + (int64_t)row * L.pitch + 4 * kk);  // unaligned dword
-            if (f < DS_PR * 10) *(uint32_t *)(patch + row * DS_PP + 4 * kk) = v;
+            const int rr = min(row, DS_PR - 1);
+            v[it] = *(const uint32_t *)(bp + (uint32_t)(rr * bpitch + 4 * kk));  // unaligned dword
+            lofs[it] = row < DS_PR ? row * DS_PP + 4 * kk : -1;
+            kk += 6;
+            row += 1;
+            if (kk >= 10) { kk -= 10; row += 1; }
         }
+#pragma unroll
+        for (int it = 0; it < 24; ++it)
+            if (lofs[it] >= 0) *(uint32_t *)(patch + lofs[it]) = v[it];
     }
     float a, bb;
     canon_sincos(angle, &a, &bb);
     __syncthreads();
     uint32_t bits = 0;
     const uint8_t *pc = patch + 18 * DS_PP + 18;
+    // rotated sample positions (:100-106): row = cvRound(x*b + y*a), col = cvRound(x*a - y*b), every product and sum
+    // rounded separately.  Two coordinates per packed-fp32 instruction; x*a - y*b == x*a + y*(-b) exactly.
+    // cvRound by the 1.5 * 2^23 trick: the fp32 add rounds to the nearest integer, ties to even, and leaves it in
+    // the low mantissa bits.
+    typedef float orb_f2 __attribute__((ext_vector_type(2)));
+    const orb_f2 ba = {bb, a}, anb = {a, -bb}, magic = {12582912.f, 12582912.f};
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const uint32_t pt = s_pat[sub * 16 + i];
-        const float x0 = (float)(int8_t)(pt & 0xFF), y0 = (float)(int8_t)((pt >> 8) & 0xFF);
-        const float x1 = (float)(int8_t)((pt >> 16) & 0xFF), y1 = (float)(int8_t)(pt >> 24);
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, bb), __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, bb)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, bb), __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, bb)));
+        const float4 pt = s_pat[i * 16 + sub];
+        const orb_f2 p0 = orb_f2{pt.x, pt.x} * ba + orb_f2{pt.y, pt.y} * anb + magic;  // (row0, col0) + magic
+        const orb_f2 p1 = orb_f2{pt.z, pt.z} * ba + orb_f2{pt.w, pt.w} * anb + magic;
+        const int r0 = (int)(short)__float_as_int(p0.x), c0 = __float_as_int(p0.y) - 0x4B400000;
+        const int r1 = (int)(short)__float_as_int(p1.x), c1 = __float_as_int(p1.y) - 0x4B400000;
         const int t0 = pc[r0 * DS_PP + c0], t1 = pc[r1 * DS_PP + c1];
         bits |= (uint32_t)(t0 < t1) << i;
     }
