@@ -244,6 +244,15 @@ orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy, const int
                                     float gw_inv, float gh_inv, const float *qxyr, const int32_t *qlevels, int32_t nq,
                                     uint32_t *off, uint32_t *cand, int32_t cap);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) for a batch of map points.
+ *   pool[npool*32]      descriptors (rows of the observing keyframes' mDescriptors)
+ *   off[npoints+1], idx map point p observes pool[idx[off[p] .. off[p+1])]  (at most 1024 observations per point)
+ *   best_idx[npoints]   position inside the point's list of the descriptor with the least median Hamming distance to
+ *                       the others (self distance 0 included, element (int)(0.5*(N-1)) of the sorted row; first on
+ *                       ties); median[npoints] that median; both -1 for a point without observations.  HOST buffers. */
+orbfe_status orbfe_distinctive_descriptors(orbfe_matcher *m, const uint8_t *pool, int32_t npool, const uint32_t *off,
+                                           const uint32_t *idx, int32_t npoints, int32_t *best_idx, int32_t *median);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,7 @@ def lib():
     L.orc_assign_grid.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
     L.orc_features_in_area.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_int, C.c_int, vp, C.c_int]
+    L.orc_distinctive.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp]
     _lib = L
     return L
 
@@ -370,3 +371,15 @@ def features_in_area(xy, octave, off, idx, minx, miny, gw_inv, gh_inv, x, y, r, 
                                    max_level, _p(out), out.size)
     assert n >= 0
     return out[:n].copy()
+
+
+def distinctive(pool, off, idx):
+    pool = np.ascontiguousarray(pool, np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(off, np.uint32)
+    idx = np.ascontiguousarray(idx, np.uint32)
+    npts = len(off) - 1
+    best = np.zeros(max(npts, 1), np.int32)
+    med = np.zeros(max(npts, 1), np.int32)
+    rc = lib().orc_distinctive(_p(pool), len(pool), _p(off), _p(idx), npts, _p(best), _p(med))
+    assert rc == 0
+    return best[:npts].copy(), med[:npts].copy()

@@ -1141,3 +1141,46 @@ int orc_features_in_area(const float *xy, const int32_t *octave, const uint32_t 
         }
     return n;
 }
+
+/* ---- 8(f).4: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) ---- */
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+
+int orc_distinctive(const uint8_t *pool, int npool, const uint32_t *off, const uint32_t *idx, int npoints,
+                    int32_t *best_idx, int32_t *median)
+{
+    for (int p = 0; p < npoints; ++p) {
+        const int n = (int)(off[p + 1] - off[p]);
+        best_idx[p] = -1;
+        median[p] = -1;
+        if (n <= 0) continue; /* :308-309 */
+        const uint32_t *ob = idx + off[p];
+        for (int i = 0; i < n; ++i)
+            if ((int)ob[i] >= npool) return -1;
+        int *dist = (int *)malloc(sizeof(int) * (size_t)n * (size_t)n);
+        int *row = (int *)malloc(sizeof(int) * (size_t)n);
+        if (!dist || !row) { free(dist); free(row); return -2; }
+        for (int i = 0; i < n; ++i) { /* :314-323 */
+            dist[i * n + i] = 0;
+            for (int j = i + 1; j < n; ++j) {
+                const int d = orc_hamming(pool + (size_t)ob[i] * 32, pool + (size_t)ob[j] * 32);
+                dist[i * n + j] = d;
+                dist[j * n + i] = d;
+            }
+        }
+        int bestm = 0x7fffffff, besti = 0; /* :328-341 */
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < n; ++j) row[j] = dist[i * n + j];
+            qsort(row, (size_t)n, sizeof(int), cmp_int);
+            const int med = row[(int)(0.5 * (n - 1))];
+            if (med < bestm) {
+                bestm = med;
+                besti = i;
+            }
+        }
+        best_idx[p] = besti;
+        median[p] = bestm;
+        free(dist);
+        free(row);
+    }
+    return 0;
+}

@@ -151,6 +151,12 @@ int orc_features_in_area(const float *xy, const int32_t *octave, const uint32_t 
                          float minx, float miny, float gw_inv, float gh_inv, float x, float y, float r, int min_level,
                          int max_level, uint32_t *out, int cap);
 
+/* ---- 8(f).4: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) for a batch of map points ----
+ * point p observes descriptors pool[idx[off[p] .. off[p+1])]; best_idx[p] = position (inside the point's list) of the
+ * descriptor with the least median distance to the others (first on ties), median[p] that median; -1 / -1 if empty. */
+int orc_distinctive(const uint8_t *pool, int npool, const uint32_t *off, const uint32_t *idx, int npoints,
+                    int32_t *best_idx, int32_t *median);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1011,3 +1011,98 @@ extern "C" orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy
     if (off[nq] > 0) ORBFE_HIP(hipMemcpy(cand, m->b[8].p, (size_t)off[nq] * 4, hipMemcpyDeviceToHost));
     return ORBFE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// SURVEY 8(f).4  MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345), batched over map points.
+// One wave per map point: its observed descriptors are staged in LDS, lane i owns row i of the distance matrix and
+// finds that row's median -- element (int)(0.5 * (N - 1)) of the sorted row, self distance 0 included (:332-334) --
+// by bisection on the value range [0, 256] with the row recomputed from LDS (no N x N matrix, any N); the point's
+// descriptor is the row with the least median, first on ties (:335-339).
+// ---------------------------------------------------------------------------------------------------
+#define DD_MAX_OBS 1024
+
+__global__ __launch_bounds__(64) void k_distinctive(const uint8_t *__restrict__ pool, const uint32_t *__restrict__ off,
+                                                    const uint32_t *__restrict__ idx, int32_t *__restrict__ best_idx,
+                                                    int32_t *__restrict__ median)
+{
+    extern __shared__ uint4 s_obs[];  // [n][2]
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const uint32_t o0 = off[p];
+    const int n = (int)(off[p + 1] - o0);
+    if (n <= 0) {
+        if (lane == 0) { best_idx[p] = -1; median[p] = -1; }
+        return;
+    }
+    for (int t = lane; t < 2 * n; t += 64) s_obs[t] = ((const uint4 *)pool)[(size_t)idx[o0 + (t >> 1)] * 2 + (t & 1)];
+    __syncthreads();
+    const int k = (int)(0.5 * (n - 1));
+    uint32_t bestkey = 0xFFFFFFFFu;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane, ic = min(i, n - 1);
+        const uint4 a0 = s_obs[2 * ic], a1 = s_obs[2 * ic + 1];
+        int lo = 0, hi = 256;
+        for (int it = 0; it < 9; ++it) {  // 257 values: 9 halvings; lanes whose interval closed early idle harmlessly
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < n; ++j) {
+                const uint4 b0 = s_obs[2 * j], b1 = s_obs[2 * j + 1];  // same address in every lane: LDS broadcast
+                const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                              __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+                cnt += d <= mid ? 1 : 0;
+            }
+            if (lo < hi) {
+                if (cnt >= k + 1) hi = mid;
+                else lo = mid + 1;
+            }
+        }
+        if (i < n) bestkey = min(bestkey, ((uint32_t)lo << 16) | (uint32_t)i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bestkey = min(bestkey, (uint32_t)__shfl_xor((int)bestkey, o, 64));
+    if (lane == 0) {
+        best_idx[p] = (int32_t)(bestkey & 0xFFFFu);
+        median[p] = (int32_t)(bestkey >> 16);
+    }
+}
+
+extern "C" orbfe_status orbfe_distinctive_descriptors(orbfe_matcher *m, const uint8_t *pool, int32_t npool,
+                                                      const uint32_t *off, const uint32_t *idx, int32_t npoints,
+                                                      int32_t *best_idx, int32_t *median)
+{
+    if (!m || npool < 0 || npoints < 0 || (npoints > 0 && (!off || !best_idx || !median))) {
+        orbfe_set_error("bad argument to orbfe_distinctive_descriptors");
+        return ORBFE_ERR_ARG;
+    }
+    if (npoints == 0) return ORBFE_OK;
+    uint32_t maxn = 0;
+    for (int i = 0; i < npoints; ++i) {
+        if (off[i + 1] < off[i]) { orbfe_set_error("CSR offsets must not decrease"); return ORBFE_ERR_ARG; }
+        maxn = std::max(maxn, off[i + 1] - off[i]);
+    }
+    if (maxn > DD_MAX_OBS) {
+        orbfe_set_error("a map point with %u observations exceeds the supported %d", maxn, DD_MAX_OBS);
+        return ORBFE_ERR_ARG;
+    }
+    const size_t nc = off[npoints];
+    if (nc > 0 && (!idx || !pool)) { orbfe_set_error("null pool / idx"); return ORBFE_ERR_ARG; }
+    for (size_t k = 0; k < nc; ++k)
+        if (idx[k] >= (uint32_t)npool) { orbfe_set_error("observation index out of range"); return ORBFE_ERR_ARG; }
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    ORBFE_HIP(m->b[0].ensure((size_t)std::max(npool, 1) * 32));
+    ORBFE_HIP(m->b[2].ensure((size_t)(npoints + 1) * 4));
+    ORBFE_HIP(m->b[3].ensure(std::max(nc, (size_t)1) * 4));
+    ORBFE_HIP(m->b[4].ensure((size_t)npoints * 4));
+    ORBFE_HIP(m->b[5].ensure((size_t)npoints * 4));
+    if (npool > 0) ORBFE_HIP(hipMemcpyAsync(m->b[0].p, pool, (size_t)npool * 32, hipMemcpyHostToDevice, st));
+    ORBFE_HIP(hipMemcpyAsync(m->b[2].p, off, (size_t)(npoints + 1) * 4, hipMemcpyHostToDevice, st));
+    if (nc > 0) ORBFE_HIP(hipMemcpyAsync(m->b[3].p, idx, nc * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_distinctive, dim3(npoints), dim3(64), (size_t)std::max(maxn, 1u) * 32, st,
+                       (const uint8_t *)m->b[0].p, (const uint32_t *)m->b[2].p, (const uint32_t *)m->b[3].p,
+                       (int32_t *)m->b[4].p, (int32_t *)m->b[5].p);
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpyAsync(best_idx, m->b[4].p, (size_t)npoints * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipMemcpyAsync(median, m->b[5].p, (size_t)npoints * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    return ORBFE_OK;
+}

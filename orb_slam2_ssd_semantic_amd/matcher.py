@@ -115,6 +115,21 @@ class ORBmatcher:
         check(st, "orbfe_hamming_csr")
         return bi, b, s
 
+    def ComputeDistinctiveDescriptors(self, pool, off, idx):
+        """SURVEY 8(f).4: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) for a batch of map points.
+        pool: descriptors; map point p observes pool[idx[off[p]:off[p+1]]].  Returns (best position inside the
+        point's list, its median distance), -1 / -1 for points without observations."""
+        pool = np.ascontiguousarray(pool, np.uint8).reshape(-1, 32)
+        off = np.ascontiguousarray(off, np.uint32)
+        idx = np.ascontiguousarray(idx, np.uint32)
+        npts = len(off) - 1
+        best = np.full(max(npts, 1), -1, np.int32)
+        med = np.full(max(npts, 1), -1, np.int32)
+        st = self._L.orbfe_distinctive_descriptors(self._m, ptr(pool), len(pool), ptr(off), ptr(idx), npts, ptr(best),
+                                                   ptr(med))
+        check(st, "orbfe_distinctive_descriptors")
+        return best[:npts].copy(), med[:npts].copy()
+
 
 class FrameGrid:
     """Device-built mGrid of a Frame (reference src/Frame.cc:319-334) + batched GetFeaturesInArea (:465-518).
