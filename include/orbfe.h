@@ -244,6 +244,17 @@ orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy, const int
                                     float gw_inv, float gh_inv, const float *qxyr, const int32_t *qlevels, int32_t nq,
                                     uint32_t *off, uint32_t *cand, int32_t cap);
 
+/* Frame::ComputeStereoMatches (src/Frame.cc:642-846): row-band descriptor search in the right image,
+ * 11 x 11 SAD refinement over 11 shifts on the two extractors' device-resident pyramids (mvImagePyramid of the LAST
+ * call of `left` / `right`, frame 0), parabola fit, disparity -> depth, and the median-based outlier rejection.
+ *   kpsL/descL/nL, kpsR/descR/nR  what those two calls returned (mvKeys / mDescriptors, mvKeysRight / mDescriptorsRight)
+ *   mbf, mb                       baseline * fx and the baseline; the reference reads mb before assigning it (:682,
+ *                                 undefined) -- here minZ = mb is an explicit argument
+ *   uRight[nL], depth[nL]         mvuRight / mvDepth, -1 where no match.  HOST buffers. */
+orbfe_status orbfe_stereo_matches(orbfe_matcher *m, orbfe_handle *left, orbfe_handle *right, const orbfe_keypoint *kpsL,
+                                  const uint8_t *descL, int32_t nL, const orbfe_keypoint *kpsR, const uint8_t *descR,
+                                  int32_t nR, float mbf, float mb, float *uRight, float *depth);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) for a batch of map points.
  *   pool[npool*32]      descriptors (rows of the observing keyframes' mDescriptors)
  *   off[npoints+1], idx map point p observes pool[idx[off[p] .. off[p+1])]  (at most 1024 observations per point)

@@ -86,6 +86,7 @@ def lib():
     L.orc_assign_grid.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
     L.orc_features_in_area.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_int, C.c_int, vp, C.c_int]
+    L.orc_stereo_matches.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
     L.orc_distinctive.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp]
     _lib = L
     return L
@@ -383,3 +384,19 @@ def distinctive(pool, off, idx):
     rc = lib().orc_distinctive(_p(pool), len(pool), _p(off), _p(idx), npts, _p(best), _p(med))
     assert rc == 0
     return best[:npts].copy(), med[:npts].copy()
+
+
+def stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mbf, mb):
+    """Frame::ComputeStereoMatches; exL / exR are OracleExtractors whose last call saw the left / right image."""
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE)
+    kpsR = np.ascontiguousarray(kpsR, KP_DTYPE)
+    descL = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+    descR = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+    n = len(kpsL)
+    u = np.zeros(max(n, 1), np.float32)
+    d = np.zeros(max(n, 1), np.float32)
+    sad = np.zeros(max(n, 1), np.int32)
+    rc = lib().orc_stereo_matches(exL.h, exR.h, _p(kpsL), _p(descL), n, _p(kpsR), _p(descR), len(kpsR), mbf, mb, _p(u),
+                                  _p(d), _p(sad))
+    assert rc == 0
+    return u[:n].copy(), d[:n].copy(), sad[:n].copy()

@@ -1184,3 +1184,114 @@ int orc_distinctive(const uint8_t *pool, int npool, const uint32_t *off, const u
     }
     return 0;
 }
+
+/* ---- 8(f).2b: Frame::ComputeStereoMatches (src/Frame.cc:642-846) ---- */
+typedef struct { int d, i; } orc_di;
+static int cmp_di(const void *a, const void *b)
+{
+    const orc_di *x = (const orc_di *)a, *y = (const orc_di *)b;
+    if (x->d != y->d) return x->d < y->d ? -1 : 1;
+    return x->i < y->i ? -1 : (x->i > y->i ? 1 : 0);
+}
+
+int orc_stereo_matches(const orc_extractor *eL, const orc_extractor *eR, const orc_keypoint *kpsL, const uint8_t *descL,
+                       int nL, const orc_keypoint *kpsR, const uint8_t *descR, int nR, float mbf, float mb,
+                       float *uRight, float *depth, int32_t *sad)
+{
+    const int thOrbDist = (100 + 50) / 2; /* (TH_HIGH + TH_LOW) / 2, :647 */
+    const float minZ = mb, minD = 0.f;
+    const float maxD = mbf / minZ;
+    orc_di *vd = (orc_di *)malloc(sizeof(orc_di) * (size_t)(nL > 0 ? nL : 1));
+    int nvd = 0;
+    if (!vd) return -2;
+    for (int i = 0; i < nL; ++i) {
+        uRight[i] = -1.0f;
+        depth[i] = -1.0f;
+        if (sad) sad[i] = -1;
+    }
+    for (int iL = 0; iL < nL; ++iL) {
+        const orc_keypoint *kL = &kpsL[iL];
+        const int levelL = kL->octave;
+        const float vL = kL->y, uL = kL->x;
+        const int rowL = (int)vL; /* vRowIndices[vL]: float -> size_t */
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = 100; /* TH_HIGH */
+        int bestIdxR = -1;
+        for (int iR = 0; iR < nR; ++iR) { /* candidates of row rowL in push_back order = ascending iR (:665-679) */
+            const orc_keypoint *kR = &kpsR[iR];
+            const float r = 2.0f * eR->scale[kR->octave];
+            const int maxr = (int)ceilf(kR->y + r), minr = (int)floorf(kR->y - r);
+            if (rowL < minr || rowL > maxr) continue;
+            if (kR->octave < levelL - 1 || kR->octave > levelL + 1) continue;
+            const float uR = kR->x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc_hamming(descL + (size_t)iL * 32, descR + (size_t)iR * 32);
+                if (dist < bestDist) {
+                    bestDist = dist;
+                    bestIdxR = iR;
+                }
+            }
+        }
+        if (bestIdxR < 0 || !(bestDist < thOrbDist)) continue;
+        /* sub-pixel refinement by SAD over 11 x 11 windows, 11 shifts (:752-827) */
+        const float uR0 = kpsR[bestIdxR].x;
+        const float sf = eL->inv_scale[levelL];
+        const float scaleduL = roundf(kL->x * sf), scaledvL = roundf(kL->y * sf), scaleduR0 = roundf(uR0 * sf);
+        const int w = 5, L = 5;
+        const uint8_t *imL = eL->level[levelL], *imR = eR->level[levelL];
+        const int wl = eL->lw[levelL], wr = eR->lw[levelL];
+        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+        if (iniu < 0 || endu >= (float)wr) continue;
+        const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
+        int bestSad = 0x7fffffff, bestinc = 0;
+        float vDists[11];
+        const int cl = imL[cv * wl + cu];
+        for (int inc = -L; inc <= L; ++inc) {
+            const int crc = imR[cv * wr + cr + inc];
+            int acc = 0; /* exact: |(l - cl) - (r - crc)| summed over 121 pixels */
+            for (int dy = -w; dy <= w; ++dy)
+                for (int dx = -w; dx <= w; ++dx) {
+                    const int a = imL[(cv + dy) * wl + cu + dx] - cl;
+                    const int b = imR[(cv + dy) * wr + cr + inc + dx] - crc;
+                    acc += a > b ? a - b : b - a;
+                }
+            const float dist = (float)acc;
+            if (dist < (float)bestSad) {
+                bestSad = (int)dist;
+                bestinc = inc;
+            }
+            vDists[L + inc] = dist;
+        }
+        if (bestinc == -L || bestinc == L) continue;
+        const float d1 = vDists[L + bestinc - 1], d2 = vDists[L + bestinc], d3 = vDists[L + bestinc + 1];
+        const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+        if (deltaR < -1 || deltaR > 1) continue;
+        float bestuR = eL->scale[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
+        float disparity = uL - bestuR;
+        if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) {
+                disparity = 0.01;
+                bestuR = uL - 0.01; /* double arithmetic, then float */
+            }
+            depth[iL] = mbf / disparity;
+            uRight[iL] = bestuR;
+            if (sad) sad[iL] = bestSad;
+            vd[nvd].d = bestSad;
+            vd[nvd].i = iL;
+            ++nvd;
+        }
+    }
+    if (nvd > 0) { /* :831-845; with no match the reference indexes an empty vector (undefined): nothing to do */
+        qsort(vd, (size_t)nvd, sizeof(orc_di), cmp_di);
+        const float median = (float)vd[nvd / 2].d;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nvd - 1; i >= 0; --i) {
+            if ((float)vd[i].d < thDist) break;
+            uRight[vd[i].i] = -1;
+            depth[vd[i].i] = -1;
+        }
+    }
+    free(vd);
+    return 0;
+}

@@ -157,6 +157,15 @@ int orc_features_in_area(const float *xy, const int32_t *octave, const uint32_t 
 int orc_distinctive(const uint8_t *pool, int npool, const uint32_t *off, const uint32_t *idx, int npoints,
                     int32_t *best_idx, int32_t *median);
 
+/* ---- 8(f).2b: Frame::ComputeStereoMatches (src/Frame.cc:642-846) ----
+ * eL / eR: extractors whose LAST orc_extract call saw the left / right image (their pyramids are read);
+ * kps / desc: what those calls returned.  uRight[nL], depth[nL] = mvuRight / mvDepth (-1 where no match);
+ * sad[nL] (optional) = the SAD distance kept for the outlier filter, -1 where none.
+ * The reference reads `mb` before it is assigned (:682, undefined); here the caller passes it (minZ = mb). */
+int orc_stereo_matches(const orc_extractor *eL, const orc_extractor *eR, const orc_keypoint *kpsL, const uint8_t *descL,
+                       int nL, const orc_keypoint *kpsR, const uint8_t *descR, int nR, float mbf, float mb,
+                       float *uRight, float *depth, int32_t *sad);
+
 #ifdef __cplusplus
 }
 #endif

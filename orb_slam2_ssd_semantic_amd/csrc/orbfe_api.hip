@@ -884,6 +884,27 @@ extern "C" orbfe_status orbfe_get_pyramid_level(orbfe_handle *h, int32_t frame, 
                        dst, dst_stride, border);
 }
 
+int32_t orbfe_internal_pyramid_view(orbfe_handle *h, int frame, OrbPyrView *v)
+{
+    orbfe_status s = check_tap(h, frame, 0);
+    if (s != ORBFE_OK) return s;
+    DeviceGuard g(h->device);
+    ORBFE_HIP(hipStreamSynchronize(h->stream));
+    v->nlevels = h->plan.nlevels;
+    v->device = h->device;
+    for (int l = 0; l < h->plan.nlevels; ++l) {
+        const OrbLevel &L = h->plan.lv[l];
+        v->ptr[l] = l == 0 ? h->last_gray + (int64_t)frame * h->last_gray_fstride
+                           : (const uint8_t *)h->d_pyr.p + (int64_t)frame * h->plan.pyr_frame_bytes + L.off;
+        v->pitch[l] = l == 0 ? h->last_gray_pitch : L.pitch;
+        v->w[l] = L.w;
+        v->h[l] = L.h;
+        v->scale[l] = h->scale[l];
+        v->inv_scale[l] = h->inv_scale[l];
+    }
+    return ORBFE_OK;
+}
+
 extern "C" orbfe_status orbfe_tap_blurred_level(orbfe_handle *h, int32_t frame, int32_t level, uint8_t *dst,
                                                 int32_t dst_stride)
 {

@@ -40,3 +40,14 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_describe(const OrbLaunch &a, hipStream_t st);
+
+// device view of the pyramid the handle built in its last call (orbfe_api.hip), for kernels outside the extractor
+struct OrbPyrView {
+    int32_t nlevels, device;
+    const uint8_t *ptr[ORBFE_MAX_LEVELS];
+    int32_t pitch[ORBFE_MAX_LEVELS], w[ORBFE_MAX_LEVELS], h[ORBFE_MAX_LEVELS];
+    float scale[ORBFE_MAX_LEVELS], inv_scale[ORBFE_MAX_LEVELS];
+};
+struct orbfe_handle;
+// fills `v` for frame `frame` of the last batch and waits for the handle's own stream; ORBFE_ERR_STATE before any call
+int32_t orbfe_internal_pyramid_view(orbfe_handle *h, int frame, OrbPyrView *v);

@@ -11,6 +11,7 @@
 #include <new>
 
 #include "orbfe_common.h"
+#include "orbfe_kernels.h"
 
 // ---------------------------------------------------------------------------------------------------
 // device helpers
@@ -1103,6 +1104,213 @@ extern "C" orbfe_status orbfe_distinctive_descriptors(orbfe_matcher *m, const ui
     ORBFE_HIP(hipGetLastError());
     ORBFE_HIP(hipMemcpyAsync(best_idx, m->b[4].p, (size_t)npoints * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipMemcpyAsync(median, m->b[5].p, (size_t)npoints * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    return ORBFE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SURVEY 8(f).2  Frame::ComputeStereoMatches (src/Frame.cc:642-846).
+// k_stereo_match: one wave per left keypoint.  Phase A scans the right keypoints in index order -- the reference's
+//   per-row candidate lists are the right keypoints whose band [floor(y - r), ceil(y + r)], r = 2 * scale[octave],
+//   holds the left keypoint's row, in push_back (= index) order, so the band test replaces the row table -- and keeps
+//   the first smallest Hamming distance below TH_HIGH.  Phase B is the 11 x 11 SAD search over 11 shifts on the
+//   device-resident pyramids of the two extractors (integer sums: |(l - cl) - (r - cr)| is exact in the reference's
+//   float arithmetic), the parabola fit and the disparity / depth bookkeeping, every float operation rounded as there.
+// k_stereo_filter: the final outlier rejection (:831-845): median of the kept SAD distances by rank counting.
+// ---------------------------------------------------------------------------------------------------
+struct StereoArgs {
+    OrbPyrView L, R;
+    float mbf, mb;
+};
+
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a, const orbfe_keypoint *__restrict__ kpsL,
+                                                      const uint8_t *__restrict__ descL, int nL,
+                                                      const orbfe_keypoint *__restrict__ kpsR,
+                                                      const uint8_t *__restrict__ descR, int nR,
+                                                      float *__restrict__ uRight, float *__restrict__ depth,
+                                                      int32_t *__restrict__ sad)
+{
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= nL) return;
+    const orbfe_keypoint kL = kpsL[iL];
+    const int levelL = kL.octave;
+    const float uL = kL.x, vL = kL.y;
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_sad = -1;
+    const float minD = 0.f, maxD = __fdiv_rn(a.mbf, a.mb);
+    const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+    const int rowL = (int)vL;
+    uint32_t best = 0xFFFFFFFFu;  // dist << 20 | iR
+    if (!(maxU < 0)) {
+        Desc8 dl;
+        {
+            const uint32_t *p = (const uint32_t *)(descL + (int64_t)iL * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dl.w[i] = p[i];
+        }
+        for (int iR = lane; iR < nR; iR += 64) {
+            const orbfe_keypoint kR = kpsR[iR];
+            const float r = __fmul_rn(2.0f, a.R.scale[kR.octave]);
+            const int maxr = (int)ceilf(__fadd_rn(kR.y, r)), minr = (int)floorf(__fsub_rn(kR.y, r));
+            if (rowL < minr || rowL > maxr) continue;
+            if (kR.octave < levelL - 1 || kR.octave > levelL + 1) continue;
+            if (kR.x >= minU && kR.x <= maxU) {
+                const int d = hamming8(dl, (const uint32_t *)(descR + (int64_t)iR * 32));
+                if (d < ORBFE_TH_HIGH) best = min(best, ((uint32_t)d << 20) | (uint32_t)iR);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
+    const int bestDist = (int)(best >> 20), bestIdxR = (int)(best & 0xFFFFFu);
+    if (best != 0xFFFFFFFFu && bestDist < (ORBFE_TH_HIGH + ORBFE_TH_LOW) / 2) {
+        const float uR0 = kpsR[bestIdxR].x;
+        const float sf = a.L.inv_scale[levelL];
+        const float scaleduL = roundf(__fmul_rn(kL.x, sf)), scaledvL = roundf(__fmul_rn(kL.y, sf));
+        const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        const int w = 5, Ls = 5;
+        const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)Ls), (float)w);
+        const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)Ls), (float)w), 1.0f);
+        if (!(iniu < 0 || endu >= (float)a.R.w[levelL])) {
+            const uint8_t *imL = a.L.ptr[levelL], *imR = a.R.ptr[levelL];
+            const int pl = a.L.pitch[levelL], pr = a.R.pitch[levelL];
+            const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
+            const int cl = imL[cv * pl + cu];
+            // the lane's two window pixels (121 = 64 + 57)
+            const int p0 = lane, p1 = lane + 64;
+            const int dy0 = p0 / 11 - w, dx0 = p0 % 11 - w, dy1 = min(p1, 120) / 11 - w, dx1 = min(p1, 120) % 11 - w;
+            const int l0 = imL[(cv + dy0) * pl + cu + dx0] - cl, l1 = imL[(cv + dy1) * pl + cu + dx1] - cl;
+            int bestSad = 0x7fffffff, bestinc = 0;
+            float vDists[11];
+#pragma unroll
+            for (int inc = -5; inc <= 5; ++inc) {
+                const int crc = imR[cv * pr + cr + inc];
+                const int r0 = imR[(cv + dy0) * pr + cr + inc + dx0] - crc, r1 = imR[(cv + dy1) * pr + cr + inc + dx1] - crc;
+                int acc = abs(l0 - r0) + (p1 < 121 ? abs(l1 - r1) : 0);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                const float dist = (float)acc;
+                if (dist < (float)bestSad) {  // float against int, as :783
+                    bestSad = (int)dist;
+                    bestinc = inc;
+                }
+                vDists[inc + 5] = dist;
+            }
+            if (bestinc != -Ls && bestinc != Ls) {
+                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int t = 1; t < 10; ++t)
+                    if (t == bestinc + 5) { d1 = vDists[t - 1]; d2 = vDists[t]; d3 = vDists[t + 1]; }
+                const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
+                                               __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = __fmul_rn(a.L.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+                    float disparity = __fsub_rn(uL, bestuR);
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) {
+                            disparity = 0.01f;                                           // float(0.01)
+                            bestuR = __double2float_rn(__dsub_rn((double)uL, 0.01));    // double arithmetic, :821
+                        }
+                        out_d = __fdiv_rn(a.mbf, disparity);
+                        out_u = bestuR;
+                        out_sad = bestSad;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        uRight[iL] = out_u;
+        depth[iL] = out_d;
+        sad[iL] = out_sad;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_stereo_filter(int nL, float *__restrict__ uRight, float *__restrict__ depth,
+                                                        const int32_t *__restrict__ sad)
+{
+    __shared__ int s_n, s_median;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_n = 0; s_median = -1; }
+    __syncthreads();
+    int cnt = 0;
+    for (int i = tid; i < nL; i += 1024) cnt += sad[i] >= 0;
+    if (cnt) atomicAdd(&s_n, cnt);
+    __syncthreads();
+    const int nv = s_n;
+    if (nv == 0) return;  // the reference indexes an empty vector here (undefined): nothing to do
+    const int target = nv / 2;  // position in the (distance, index)-sorted list
+    for (int i = tid; i < nL; i += 1024) {
+        const int di = sad[i];
+        if (di < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < nL; ++j) {
+            const int dj = sad[j];
+            rank += (dj >= 0 && (dj < di || (dj == di && j < i))) ? 1 : 0;
+        }
+        if (rank == target) s_median = di;
+    }
+    __syncthreads();
+    const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), (float)s_median);
+    for (int i = tid; i < nL; i += 1024) {
+        const int di = sad[i];
+        if (di >= 0 && !((float)di < thDist)) {
+            uRight[i] = -1.0f;
+            depth[i] = -1.0f;
+        }
+    }
+}
+
+extern "C" orbfe_status orbfe_stereo_matches(orbfe_matcher *m, orbfe_handle *left, orbfe_handle *right,
+                                             const orbfe_keypoint *kpsL, const uint8_t *descL, int32_t nL,
+                                             const orbfe_keypoint *kpsR, const uint8_t *descR, int32_t nR, float mbf,
+                                             float mb, float *uRight, float *depth)
+{
+    if (!m || !left || !right || nL < 0 || nR < 0 || nR >= (1 << 20) || (nL > 0 && (!kpsL || !descL || !uRight || !depth)) ||
+        (nR > 0 && (!kpsR || !descR))) {
+        orbfe_set_error("bad argument to orbfe_stereo_matches");
+        return ORBFE_ERR_ARG;
+    }
+    if (nL == 0) return ORBFE_OK;
+    StereoArgs a;
+    orbfe_status s = (orbfe_status)orbfe_internal_pyramid_view(left, 0, &a.L);
+    if (s != ORBFE_OK) return s;
+    s = (orbfe_status)orbfe_internal_pyramid_view(right, 0, &a.R);
+    if (s != ORBFE_OK) return s;
+    if (a.L.device != m->device || a.R.device != m->device || a.L.nlevels != a.R.nlevels) {
+        orbfe_set_error("stereo: the two extractors and the matcher must share a device and a pyramid shape");
+        return ORBFE_ERR_ARG;
+    }
+    for (int i = 0; i < nL; ++i)
+        if (kpsL[i].octave < 0 || kpsL[i].octave >= a.L.nlevels) { orbfe_set_error("left octave out of range"); return ORBFE_ERR_ARG; }
+    for (int i = 0; i < nR; ++i)
+        if (kpsR[i].octave < 0 || kpsR[i].octave >= a.R.nlevels) { orbfe_set_error("right octave out of range"); return ORBFE_ERR_ARG; }
+    a.mbf = mbf;
+    a.mb = mb;
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    ORBFE_HIP(m->b[0].ensure((size_t)nL * sizeof(orbfe_keypoint)));
+    ORBFE_HIP(m->b[1].ensure((size_t)nL * 32));
+    ORBFE_HIP(m->b[2].ensure((size_t)std::max(nR, 1) * sizeof(orbfe_keypoint)));
+    ORBFE_HIP(m->b[3].ensure((size_t)std::max(nR, 1) * 32));
+    ORBFE_HIP(m->b[4].ensure((size_t)nL * 4));
+    ORBFE_HIP(m->b[5].ensure((size_t)nL * 4));
+    ORBFE_HIP(m->b[6].ensure((size_t)nL * 4));
+    ORBFE_HIP(hipMemcpyAsync(m->b[0].p, kpsL, (size_t)nL * sizeof(orbfe_keypoint), hipMemcpyHostToDevice, st));
+    ORBFE_HIP(hipMemcpyAsync(m->b[1].p, descL, (size_t)nL * 32, hipMemcpyHostToDevice, st));
+    if (nR > 0) {
+        ORBFE_HIP(hipMemcpyAsync(m->b[2].p, kpsR, (size_t)nR * sizeof(orbfe_keypoint), hipMemcpyHostToDevice, st));
+        ORBFE_HIP(hipMemcpyAsync(m->b[3].p, descR, (size_t)nR * 32, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_stereo_match, dim3((nL + 3) / 4), dim3(256), 0, st, a, (const orbfe_keypoint *)m->b[0].p,
+                       (const uint8_t *)m->b[1].p, nL, (const orbfe_keypoint *)m->b[2].p, (const uint8_t *)m->b[3].p, nR,
+                       (float *)m->b[4].p, (float *)m->b[5].p, (int32_t *)m->b[6].p);
+    hipLaunchKernelGGL(k_stereo_filter, dim3(1), dim3(1024), 0, st, nL, (float *)m->b[4].p, (float *)m->b[5].p,
+                       (const int32_t *)m->b[6].p);
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpyAsync(uRight, m->b[4].p, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipMemcpyAsync(depth, m->b[5].p, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipStreamSynchronize(st));
     return ORBFE_OK;
 }

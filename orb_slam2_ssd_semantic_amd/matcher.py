@@ -115,6 +115,22 @@ class ORBmatcher:
         check(st, "orbfe_hamming_csr")
         return bi, b, s
 
+    def ComputeStereoMatches(self, extractorLeft, extractorRight, keysL, descL, keysR, descR, mbf, mb):
+        """SURVEY 8(f).2: Frame::ComputeStereoMatches (src/Frame.cc:642-846).  The two ORBextractor mirrors must have
+        just processed the left / right image (their device-resident pyramids are read).  Returns (mvuRight, mvDepth)."""
+        from ._ffi import KP_DTYPE
+        kl = np.ascontiguousarray(keysL, KP_DTYPE)
+        kr = np.ascontiguousarray(keysR, KP_DTYPE)
+        dl = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+        dr = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+        n = len(kl)
+        u = np.full(max(n, 1), -1, np.float32)
+        d = np.full(max(n, 1), -1, np.float32)
+        st = self._L.orbfe_stereo_matches(self._m, extractorLeft.handle, extractorRight.handle, ptr(kl), ptr(dl), n,
+                                          ptr(kr), ptr(dr), len(kr), float(mbf), float(mb), ptr(u), ptr(d))
+        check(st, "orbfe_stereo_matches")
+        return u[:n].copy(), d[:n].copy()
+
     def ComputeDistinctiveDescriptors(self, pool, off, idx):
         """SURVEY 8(f).4: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) for a batch of map points.
         pool: descriptors; map point p observes pool[idx[off[p]:off[p+1]]].  Returns (best position inside the
