@@ -41,6 +41,8 @@ public:
     void SyncImagePyramid();
 
     int LastStatus() const { return mLastStatus; }  // orbfe_status of the last call (the reference has no error path)
+    // the C handle, for calls that keep the pyramid on the device (orbfe_stereo_matches); null before the first operator()
+    orbfe_handle *handle() const { return mpHandle; }
 
 protected:
     int nfeatures;
