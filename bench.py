@@ -270,9 +270,12 @@ def main():
                 try:
                     pj = json.load(open(pm))
                     kn = roof["kernel"].split(" ")[0]
-                    tb = (pj["FETCH_SIZE_KB"][kn]["mean_per_launch"] + pj["WRITE_SIZE_KB"][kn]["mean_per_launch"]) * 1024
+                    # gfx950: FETCH_SIZE reports half of the read bytes (calibrated on this repo's access shapes,
+                    # profiles/r01_fetch_calibration.txt), WRITE_SIZE is exact
+                    tb = (2 * pj["FETCH_SIZE_KB"][kn]["mean_per_launch"] + pj["WRITE_SIZE_KB"][kn]["mean_per_launch"]) * 1024
                     roof["traffic"] = int(tb)
-                    roof["traffic_note"] = "FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_v5_pmc_hbm.json (separate --pmc passes, uncorrected)"
+                    roof["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_v5_pmc_hbm.json "
+                                            "(separate --pmc passes; x2 read correction per profiles/r01_fetch_calibration.txt)")
                 except Exception:
                     pass
         if world == 1 and not args.no_cpu_baseline:
