@@ -93,6 +93,19 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// XCD-aware placement for grids of (work item, frame): workgroups are dealt round-robin to the 8 XCDs in launch order
+// and every XCD has its own 4 MB L2, while one frame's pyramids are ~2 MB.  With a multiple of 8 frames, all workgroups
+// of frame f are steered to XCD f % 8, so rows shared by neighbouring waves / overlapping patches of a frame are
+// fetched from HBM once instead of once per XCD.
+__device__ __forceinline__ void xcd_frame_remap(int &bx, int &b)
+{
+    if ((gridDim.y & 7) == 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, j = lin >> 3;
+        b = xcd + 8 * (j / (int)gridDim.x);
+        bx = j % (int)gridDim.x;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K1  bilinear pyramid level:  dst(level) = resize(src(level-1))      
 // One wave per 256 x 32 destination tile: every lane owns 4 adjacent destination pixels and walks down the rows.
@@ -349,9 +362,11 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
                                                   int32_t *__restrict__ scount)   // [B][nlevels] * NK_STRIDE, zeroed
 {
     __shared__ uint2 s_buf[4][FM_BUF];
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    int b = blockIdx.y, bx = blockIdx.x;
+    xcd_frame_remap(bx, b);
+    const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int t = blockIdx.x * (blockDim.x >> 6) + wv;
+    const int t = bx * (blockDim.x >> 6) + wv;
     if (t >= nwaves) return;
     // Work is described per LANE: a 4-pixel column, a run of rows, "halo" (contributes neighbour strengths only).
     // The host packs the column strips of all row blocks of one level back to back into 64-lane waves, so narrow
@@ -1114,8 +1129,10 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
                                                const OrbLane *__restrict__ lanes, int nwaves,
                                                uint8_t *__restrict__ blur, int64_t blur_fstride)
 {
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int b = blockIdx.y, bx = blockIdx.x;
+    xcd_frame_remap(bx, b);
+    const int lane = threadIdx.x & 63;
+    const int t = bx * 4 + (threadIdx.x >> 6);
     if (t >= nwaves) return;
     const OrbLane ld = lanes[(int64_t)t * 64 + lane];
     const int level = __builtin_amdgcn_readfirstlane((int)(ld.flags >> 8));
@@ -1334,15 +1351,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[16][DS_PR * DS_PP];
     __shared__ uint2 s_momw[31 * 8];
     __shared__ float4 s_pat[256];  // (x0, y0, x1, y1) of every test pair as floats
-    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in launch order, each XCD has its own 4 MB
-    // L2 and a frame's two pyramids are ~2 MB.  With a multiple of 8 frames, all workgroups of frame f run on XCD
-    // f % 8, so overlapping patches of a frame are fetched from HBM once instead of once per XCD.
     int b = blockIdx.y, bx = blockIdx.x;
-    if ((gridDim.y & 7) == 0) {
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, j = lin >> 3;
-        b = xcd + 8 * (j / (int)gridDim.x);
-        bx = j % (int)gridDim.x;
-    }
+    xcd_frame_remap(bx, b);
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = lane & 15, quad = tid >> 4;  // quad 0..15 inside the workgroup = one keypoint
     for (int i = tid; i < 31 * 8; i += 256) s_momw[i] = c_momw[i];
