@@ -820,7 +820,10 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
                                                int32_t *__restrict__ nsel)          // [B][nlevels] out
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    // Workgroups go round-robin to the 8 XCDs in launch order; with level = blockIdx.x every XCD would own ONE pyramid
+    // level of all frames, and level 0 carries ~10x the keys of level 7.  Rotating the level by the frame index gives
+    // every XCD the same mix of levels.
+    const int b = blockIdx.y, level = (int)((blockIdx.x + blockIdx.y) % gridDim.x), tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int QT = blockDim.x;  // 256 .. 512 (launch-time choice)
     const OrbLevel &L = plan->lv[level];
