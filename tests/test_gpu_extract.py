@@ -223,3 +223,28 @@ def test_device_api_with_torch_tensors(oracle):
         gk = kps[i, :n[i]].copy().view(KP_DTYPE).reshape(-1)
         assert_same_output(gk, desc[i, :n[i]], ok, od)
         assert not kps[i, n[i]:].any() and not desc[i, n[i]:].any()       # padding zero-filled for the all-gather
+
+
+def test_batch_multiple_of_eight_xcd_placement(oracle):
+    """16 distinct frames in one launch: the XCD-aware frame placement (batches that are a multiple of 8) and the
+    level rotation of the quadtree grid must not change any frame's result."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    B = 16
+    e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=B)
+    imgs = [synth_frame(300 + i, sparse=(i % 4 == 1)) for i in range(B)]
+    res = e.extract_batch(imgs)
+    oe = oracle.OracleExtractor()
+    for i, (k, d) in enumerate(res):
+        ok, od = oe(imgs[i])
+        assert_same_output(k, d, ok, od)
+
+
+def test_scale_factor_limits(oracle):
+    from orb_slam2_ssd_semantic_amd import ORBextractor, OrbfeError
+    img = synth_frame(77, 480, 640)
+    oe = oracle.OracleExtractor(500, 1.9, 3, 20, 7)          # just below the kernel's level-ratio limit of 2
+    ok, od = oe(img, cap=700)
+    gk, gd = ORBextractor(500, 1.9, 3, 20, 7, max_width=640, max_height=480)(img)
+    assert_same_output(gk, gd, ok, od)
+    with pytest.raises(OrbfeError):                          # a level less than half as wide as its parent
+        ORBextractor(500, 2.5, 3, 20, 7, max_width=640, max_height=480)(img)
