@@ -311,12 +311,18 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
                 orbfe_set_error("scale factor too large: level %d is less than half as wide as level %d", l, l - 1);
                 return ORBFE_ERR_ARG;
             }
-            L.xtab = (int)tabs.size();
-            tabs.resize(tabs.size() + L.w);
-            resize_axis(S.w, L.w, true, &tabs[L.xtab]);
-            L.ytab = (int)tabs.size();
-            tabs.resize(tabs.size() + L.h);
-            resize_axis(S.h, L.h, false, &tabs[L.ytab]);
+            // tap tables, 4-entry aligned and padded by 8 (a lane reads the taps of its 4 pixels / 8 rows as
+            // 16-byte loads; entries past the end repeat the last one)
+            auto add_axis = [&](int ssize, int dsize, bool is_x) {
+                while (tabs.size() % 4) tabs.push_back(OrbTab{0, 0, 0, 0});
+                const int at = (int)tabs.size();
+                tabs.resize(tabs.size() + dsize + 8);
+                resize_axis(ssize, dsize, is_x, &tabs[at]);
+                for (int i = 0; i < 8; ++i) tabs[at + dsize + i] = tabs[at + dsize - 1];
+                return at;
+            };
+            L.xtab = add_axis(S.w, L.w, true);
+            L.ytab = add_axis(S.h, L.h, false);
         }
         if (L.w > 4095 + 2 * ORBFE_MINB || L.h > 4095 + 2 * ORBFE_MINB) {
             orbfe_set_error("level %d exceeds the 12-bit key coordinate range", l);

@@ -68,10 +68,10 @@ struct OrbCell {
 };
 
 // bilinear resize table entry: source index + the two 11-bit coefficients
-struct OrbTab {
-    int16_t s;   // sx / sy (un-clamped for y)
+struct OrbTab {  // one cv::resize tap of one axis: dword 0 = the coefficient pair, dword 1 = the source index
     int16_t c0;  // (1-f)*2048 rounded half-even
     int16_t c1;  // f*2048
+    int16_t s;   // sx / sy (un-clamped for y)
     int16_t pad;
 };
 

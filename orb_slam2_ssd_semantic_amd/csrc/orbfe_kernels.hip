@@ -115,34 +115,19 @@ __device__ __forceinline__ void xcd_frame_remap(int &bx, int &b)
 // H row is carried in registers.  Vertical step: ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2, one dword store.
 // Coefficient tables are precomputed on the host in fp64/fp32 exactly as cv::resize does; all kernel math is int32.
 // ---------------------------------------------------------------------------------------------------
-#define PY_RB 4  // destination rows per lane: short waves, the per-launch parallelism comes from their number
+#define PY_RB 4  // destination rows per lane (2 and 8 measured slower)
 
-// Everything a level needs travels as kernel arguments and the bilinear taps are recomputed in the kernel with the
-// exact fp64 / fp32 operation sequence of cv::resize, so a wave's only memory round trip before its
-// stores is the pixel fetch itself.
+// The level's geometry travels as kernel arguments; the bilinear taps (source index + two 11-bit coefficients per
+// destination column / row) come from host-built tables computed with the exact fp64 / fp32 operation sequence of
+// cv::resize: a lane fetches the taps of its 4 pixels and PY_RB rows with 16-byte loads.
 struct PyrArgs {
     const uint8_t *src;  // level l-1, frame 0
     uint8_t *dst;        // level l, frame 0
     int64_t src_fstride, dst_fstride;
     int32_t sw, sh, spitch;
     int32_t dw, dh, dpitch;
-    double scale_x, scale_y;  // 1. / ((double)dst / src), computed on the host exactly as cv::resize does
+    const OrbTab *xtab, *ytab;  // cv::resize taps of the two axes (host-built, 4-entry aligned, padded by 4 entries)
 };
-
-// one axis tap: source index and the two 11-bit coefficients (x axis clamps like cv::resize's xofs/ialpha loop)
-__device__ __forceinline__ void pyr_tap(int d, double scale, int ssize, bool is_x, int &s, int &c0, int &c1)
-{
-    float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
-    int si = (int)floorf(f);
-    f = __fsub_rn(f, (float)si);
-    if (is_x) {
-        if (si < 0) { f = 0.f; si = 0; }
-        if (si >= ssize - 1) { f = 0.f; si = ssize - 1; }
-    }
-    s = si;
-    c0 = min(max(__float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f)), -32768), 32767);
-    c1 = min(max(__float2int_rn(__fmul_rn(f, 2048.f)), -32768), 32767);
-}
 
 __global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
 {
@@ -166,17 +151,28 @@ __global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
     // and the horizontal sum S[sx]*a0 + S[sx+1]*a1 is one v_dot2_u32_u16 against the packed coefficients.
     // The window may reach 7 bytes past the last source pixel of a row: inside the handle's own levels (a later
     // level follows), and inside the caller's level-0 buffer thanks to the 16-byte slack orbfe.h asks for.
-    int sx0 = 0;
+    // taps of the lane's 4 pixels and 4 rows: four 16-byte loads from the host-built tables (exact cv::resize taps)
+    const uint4 tx01 = *(const uint4 *)(a.xtab + dx0), tx23 = *(const uint4 *)(a.xtab + dx0 + 2);
+    const uint32_t xc[4] = {tx01.x, tx01.z, tx23.x, tx23.z};  // coefficient pairs c0 | c1 << 16
+    const int xs[4] = {(int)(short)tx01.y, (int)(short)tx01.w, (int)(short)tx23.y, (int)(short)tx23.w};
+    uint32_t yc[PY_RB];
+    int ys4[PY_RB];
+#pragma unroll
+    for (int d = 0; d < PY_RB; d += 2) {
+        const uint4 ty = *(const uint4 *)(a.ytab + y0 + d);
+        yc[d] = ty.x;
+        yc[d + 1] = ty.z;
+        ys4[d] = (int)(short)ty.y;
+        ys4[d + 1] = (int)(short)ty.w;
+    }
+    const int sx0 = xs[0];
     uint32_t sel[4];
     orb_u2 coef[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        int sxj, c0, c1;
-        pyr_tap(min(dx0 + j, W - 1), a.scale_x, a.sw, true, sxj, c0, c1);
-        if (j == 0) sx0 = sxj;
-        const uint32_t o = (uint32_t)min(sxj - sx0, 6);
+        const uint32_t o = (uint32_t)min(max(xs[j] - sx0, 0), 6);
         sel[j] = 0x0c000c00u | ((o + 1u) << 16) | o;
-        coef[j] = orb_u2{(unsigned short)c0, (unsigned short)c1};
+        coef[j] = __builtin_bit_cast(orb_u2, xc[j]);
     }
     // straight-line: all source windows of the tile in flight at once, then the arithmetic (no control flow)
     uint2 q0[PY_RB], q1[PY_RB];
@@ -184,8 +180,9 @@ __global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
     const uint32_t sp = (uint32_t)a.spitch;
 #pragma unroll
     for (int d = 0; d < PY_RB; ++d) {
-        int tys;
-        pyr_tap(min(y0 + d, H - 1), a.scale_y, a.sh, false, tys, vb0[d], vb1[d]);
+        const int tys = ys4[d];
+        vb0[d] = (int)(yc[d] & 0xFFFFu);
+        vb1[d] = (int)(yc[d] >> 16);
         const int sy0 = min(max(tys, 0), a.sh - 1), sy1 = min(max(tys + 1, 0), a.sh - 1);
         q0[d] = *(const uint2 *)(src + (__umul24((uint32_t)sy0, sp) + (uint32_t)sx0));
         q1[d] = *(const uint2 *)(src + (__umul24((uint32_t)sy1, sp) + (uint32_t)sx0));
@@ -1522,8 +1519,8 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
         pa.dst_fstride = a.pyr_fstride;
         pa.sw = S.w; pa.sh = S.h;
         pa.dw = D.w; pa.dh = D.h; pa.dpitch = D.pitch;
-        pa.scale_x = 1. / ((double)D.w / S.w);  // cv::resize: inv_scale = (double)dsize/ssize; scale = 1./inv_scale
-        pa.scale_y = 1. / ((double)D.h / S.h);
+        pa.xtab = a.d_tabs + D.xtab;
+        pa.ytab = a.d_tabs + D.ytab;
         const int nlanes = ((D.w + 3) / 4) * ((D.h + PY_RB - 1) / PY_RB);
         dim3 grid((nlanes + 255) / 256, a.nframes);
         hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, pa);
