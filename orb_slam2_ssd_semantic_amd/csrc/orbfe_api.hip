@@ -142,7 +142,7 @@ struct orbfe_handle {
     bool plan_valid = false;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
-    DevBuf d_plan, d_cells, d_tabs, d_flanes, d_blanes;
+    DevBuf d_plan, d_tabs, d_flanes, d_blanes;
     // per-batch blocks
     DevBuf d_pyr, d_blur, d_skeys, d_scount, d_knode, d_sel, d_nsel, d_nkeys;
     // host-API staging
@@ -447,14 +447,12 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     }
 
     ORBFE_HIP(h->d_plan.ensure(sizeof(OrbPlan)));
-    ORBFE_HIP(h->d_cells.ensure(cells.size() * sizeof(OrbCell)));
     ORBFE_HIP(h->d_tabs.ensure(tabs.size() * sizeof(OrbTab)));
     ORBFE_HIP(h->d_flanes.ensure(std::max<size_t>(flanes.size(), 1) * sizeof(OrbLane)));
     ORBFE_HIP(h->d_blanes.ensure(std::max<size_t>(blanes.size(), 1) * sizeof(OrbLane)));
     // synchronous copies: plans change rarely (frame size change), never inside the timed region
     ORBFE_HIP(hipStreamSynchronize(h->stream));
     ORBFE_HIP(hipMemcpy(h->d_plan.p, &P, sizeof(OrbPlan), hipMemcpyHostToDevice));
-    ORBFE_HIP(hipMemcpy(h->d_cells.p, cells.data(), cells.size() * sizeof(OrbCell), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_tabs.p, tabs.data(), tabs.size() * sizeof(OrbTab), hipMemcpyHostToDevice));
     if (!flanes.empty())
         ORBFE_HIP(hipMemcpy(h->d_flanes.p, flanes.data(), flanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
@@ -575,7 +573,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_cells, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
                       &h->d_okps, &h->d_odesc, &h->d_on};
     for (DevBuf *b : bufs) b->release();
     PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
@@ -678,7 +676,6 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     OrbLaunch a;
     a.h_plan = &h->plan;
     a.d_plan = (const OrbPlan *)h->d_plan.p;
-    a.d_cells = (const OrbCell *)h->d_cells.p;
     a.d_tabs = (const OrbTab *)h->d_tabs.p;
     a.d_flanes = (const OrbLane *)h->d_flanes.p;
     a.d_blanes = (const OrbLane *)h->d_blanes.p;

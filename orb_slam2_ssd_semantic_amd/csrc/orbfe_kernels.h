@@ -6,7 +6,6 @@
 struct OrbLaunch {
     const OrbPlan *h_plan;  // host copy
     const OrbPlan *d_plan;  // device copy
-    const OrbCell *d_cells;
     const OrbTab *d_tabs;
     const OrbLane *d_flanes;
     const OrbLane *d_blanes;
