@@ -28,8 +28,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from orb_slam2_ssd_semantic_amd.distributed import OverlappedKeyframeGather  # noqa: E402
 from orb_slam2_ssd_semantic_amd import ORBextractor, ORBmatcher, _ffi  # noqa: E402
-from orb_slam2_ssd_semantic_amd.distributed import all_gather_keyframes  # noqa: E402
 from orb_slam2_ssd_semantic_amd.synth import synth_frame  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -133,25 +133,38 @@ def main():
 
     frames = make_frames(B, w, h, 10000 + rank * B)
     d_gray = torch.from_numpy(frames).cuda()
-    d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
-    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
-    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    # two output sets: with N > 1 the all-gather of step k overlaps the kernels of step k+1, so the set being gathered
+    # must not be overwritten (N = 1 just alternates)
+    outs = [(torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda"),
+             torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+             torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(2)]
+    d_kps, d_desc, d_n = outs[0]
     qf = torch.arange(0, B, dtype=torch.int32, device="cuda")
     tf = (torch.arange(0, B, dtype=torch.int32, device="cuda") + (B - 1)) % B  # predecessor (wraps at frame 0)
     d_match = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
     d_nm = torch.zeros(B, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    # (n, kps, desc) order of distributed.all_gather_keyframes
+    gather = OverlappedKeyframeGather([(o[2], o[0], o[1]) for o in outs]) if world > 1 else None
+    counter = [0]
 
     def step():
-        ext.extract_batch_device(d_gray.data_ptr(), B, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), cap,
-                                 d_n.data_ptr(), stream)
+        k = counter[0] & 1
+        counter[0] += 1
+        kps, desc, n = outs[k]
+        if gather:
+            gather.acquire(k)  # set k is free again once its previous gather (two steps ago) has read it (stream-level wait)
+        ext.extract_batch_device(d_gray.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap,
+                                 n.data_ptr(), stream)
         if not args.no_match:
-            rc = L.orbfe_match_bf_frames_device(mat.handle, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+            rc = L.orbfe_match_bf_frames_device(mat.handle, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), cap,
                                                 qf.data_ptr(), tf.data_ptr(), B, 0.9, 100, 1, d_match.data_ptr(),
                                                 d_nm.data_ptr(), stream)
             _ffi.check(rc, "orbfe_match_bf_frames_device")
         if world > 1:
-            return all_gather_keyframes(d_n, d_kps, d_desc)
+            # the one exchange step of the batched keyframe mode (distributed.all_gather_keyframes, asynchronous here):
+            # RCCL runs on its own stream after the kernels above and overlaps the next step's kernels
+            gather.launch(k)
         return None
 
     def fence():

@@ -49,3 +49,38 @@ def all_gather_keyframes(n, kps, desc, nframes_total=None, group=None):
         idx.extend(range(r * S, r * S + (hi - lo)))
     idx = torch.as_tensor(idx, dtype=torch.long, device=n.device)
     return tuple(t.index_select(0, idx) for t in out)
+
+
+class OverlappedKeyframeGather:
+    """Double-buffered, asynchronous form of `all_gather_keyframes` for a steady stream of batches.
+
+    The producer alternates between two output sets (n, kps, desc).  `acquire(k)` makes the current stream wait until
+    the gather that last read set k has finished (stream-level on RCCL, host-level on gloo), `launch(k)` starts the
+    all-gather of set k after the work already enqueued on the current stream; it then overlaps whatever is enqueued
+    next.  `result(k)` waits for and returns the gathered (n, kps, desc) of set k in rank-major order.
+    """
+
+    def __init__(self, sets, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.sets = sets
+        self.pending = [[] for _ in sets]
+        self.gathered = [tuple(torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
+                                           device=t.device) for t in s) for s in sets]
+
+    def acquire(self, k):
+        for w in self.pending[k]:
+            w.wait()
+        self.pending[k] = []
+
+    def launch(self, k):
+        if self.world == 1:
+            for dst, src in zip(self.gathered[k], self.sets[k]):
+                dst.copy_(src)
+            return
+        for dst, src in zip(self.gathered[k], self.sets[k]):
+            self.pending[k].append(dist.all_gather_into_tensor(dst, src.contiguous(), group=self.group, async_op=True))
+
+    def result(self, k):
+        self.acquire(k)
+        return self.gathered[k]

@@ -77,3 +77,44 @@ def test_all_gather_world2(oracle, nframes):
             assert np.array_equal(d_all[f, :len(k)], d)
             assert not d_all[f, len(k):].any()
     assert np.array_equal(ret[0][2], ret[1][2])
+
+
+def _overlap_worker(rank, world, port, steps, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from orb_slam2_ssd_semantic_amd.distributed import OverlappedKeyframeGather
+        S, cap = 3, 5
+        sets = [(torch.zeros(S, dtype=torch.int32), torch.zeros(S, cap, 7, dtype=torch.int32),
+                 torch.zeros(S, cap, 32, dtype=torch.uint8)) for _ in range(2)]
+        g = OverlappedKeyframeGather(sets)
+        seen = []
+        for i in range(steps):  # exactly the loop of bench.py's step(): acquire set k, produce into it, launch its gather
+            k = i & 1
+            g.acquire(k)
+            n, kps, desc = sets[k]
+            n.fill_(100 * i + rank)
+            kps.fill_(1000 * i + rank)
+            desc.fill_((7 * i + rank) % 256)
+            g.launch(k)
+            if i >= 1:  # the gather of the previous step completes while this one is produced
+                pn, pk, pd = g.result((i - 1) & 1)
+                seen.append((pn.clone(), pk[:, 0, 0].clone(), pd[:, 0, 0].clone()))
+        ret[rank] = [(a.numpy(), b.numpy(), c.numpy()) for a, b, c in seen]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gather_world2():
+    world, steps = 2, 6
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, port, steps, ret), nprocs=world, join=True)
+    for rank in range(world):
+        for j, (n, k, d) in enumerate(ret[rank]):   # j = index of the step whose gather this is
+            for r in range(world):
+                assert (n[r * 3:(r + 1) * 3] == 100 * j + r).all()
+                assert (k[r * 3:(r + 1) * 3] == 1000 * j + r).all()
+                assert (d[r * 3:(r + 1) * 3] == (7 * j + r) % 256).all()
