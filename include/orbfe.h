@@ -255,6 +255,24 @@ orbfe_status orbfe_stereo_matches(orbfe_matcher *m, orbfe_handle *left, orbfe_ha
                                   const uint8_t *descL, int32_t nL, const orbfe_keypoint *kpsR, const uint8_t *descR,
                                   int32_t nR, float mbf, float mb, float *uRight, float *depth);
 
+/* DBoW2 TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) as called by
+ * Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:553, src/KeyFrame.cc:82; levelsup = 4).  DBoW2 is not vendored
+ * by the reference; the algorithm is restated from the published one.  The tree is handed over as arrays:
+ * children of node i = child_idx[child_off[i] .. child_off[i+1]) in stored order (node 0 = root; child ids must exceed
+ * their parent's id), node_desc[nnodes*32], word_id / weight (TF-IDF) meaningful for leaves, L = tree depth. */
+typedef struct orbfe_vocabulary orbfe_vocabulary;
+orbfe_status orbfe_vocabulary_create(int32_t device, int32_t nnodes, const uint32_t *child_off, const uint32_t *child_idx,
+                                     const uint8_t *node_desc, const uint32_t *word_id, const double *weight, int32_t L,
+                                     orbfe_vocabulary **out);
+void orbfe_vocabulary_destroy(orbfe_vocabulary *v);
+/* desc[n*32] (n <= 8192).  Per feature (any may be NULL): f_word / f_node (-1 when the word's weight is 0 and the feature
+ * is skipped) / f_weight.  BowVector: bow_id[<= n] ascending, bow_val L1-normalised doubles, *nbow.  FeatureVector as the
+ * CSR orbfe_search_by_bow takes: fv_node[<= n] ascending, fv_off[*nfv + 1], fv_idx[<= n].  HOST buffers. */
+orbfe_status orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocabulary *v, const uint8_t *desc, int32_t n,
+                                 int32_t levelsup, int32_t *f_word, int32_t *f_node, double *f_weight, uint32_t *bow_id,
+                                 double *bow_val, int32_t *nbow, uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx,
+                                 int32_t *nfv);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) for a batch of map points.
  *   pool[npool*32]      descriptors (rows of the observing keyframes' mDescriptors)
  *   off[npoints+1], idx map point p observes pool[idx[off[p] .. off[p+1])]  (at most 1024 observations per point)

@@ -87,6 +87,7 @@ def lib():
     L.orc_features_in_area.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_int, C.c_int, vp, C.c_int]
     L.orc_stereo_matches.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
+    L.orc_bow_transform.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int] + [vp] * 6 + [vp] * 4
     L.orc_distinctive.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp]
     _lib = L
     return L
@@ -400,3 +401,26 @@ def stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mbf, mb):
                                   _p(d), _p(sad))
     assert rc == 0
     return u[:n].copy(), d[:n].copy(), sad[:n].copy()
+
+
+def bow_transform(voc, desc, levelsup=4):
+    """voc: dict(child_off, child_idx, node_desc, word_id, weight, L).  Returns dict of per-feature word/node/weight,
+    the BowVector (ids, values) and the FeatureVector CSR (node, off, idx)."""
+    co = np.ascontiguousarray(voc["child_off"], np.uint32)
+    ci = np.ascontiguousarray(voc["child_idx"], np.uint32)
+    nd = np.ascontiguousarray(voc["node_desc"], np.uint8).reshape(-1, 32)
+    wi = np.ascontiguousarray(voc["word_id"], np.uint32)
+    ww = np.ascontiguousarray(voc["weight"], np.float64)
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(desc)
+    m = max(n, 1)
+    fw, fn, fwt = np.zeros(m, np.int32), np.zeros(m, np.int32), np.zeros(m, np.float64)
+    bid, bval, nb = np.zeros(m, np.uint32), np.zeros(m, np.float64), C.c_int(0)
+    fvn, fvo, fvi, nf = np.zeros(m, np.uint32), np.zeros(m + 1, np.uint32), np.zeros(m, np.uint32), C.c_int(0)
+    rc = lib().orc_bow_transform(len(nd), _p(co), _p(ci), _p(nd), _p(wi), _p(ww), int(voc["L"]), levelsup, _p(desc), n,
+                                 _p(fw), _p(fn), _p(fwt), _p(bid), _p(bval), C.byref(nb), _p(fvn), _p(fvo), _p(fvi),
+                                 C.byref(nf))
+    assert rc == 0
+    return dict(word=fw[:n].copy(), node=fn[:n].copy(), weight=fwt[:n].copy(), bow_id=bid[:nb.value].copy(),
+                bow_val=bval[:nb.value].copy(), fv_node=fvn[:nf.value].copy(), fv_off=fvo[:nf.value + 1].copy(),
+                fv_idx=fvi[:int(fvo[nf.value])].copy())

@@ -1295,3 +1295,92 @@ int orc_stereo_matches(const orc_extractor *eL, const orc_extractor *eR, const o
     free(vd);
     return 0;
 }
+
+/* ---- 8(f).3: DBoW2 TemplatedVocabulary::transform ---- */
+typedef struct { uint32_t key; int i; } orc_ki;
+static int cmp_ki(const void *a, const void *b)
+{
+    const orc_ki *x = (const orc_ki *)a, *y = (const orc_ki *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->i < y->i ? -1 : (x->i > y->i ? 1 : 0);
+}
+
+int orc_bow_transform(int nnodes, const uint32_t *child_off, const uint32_t *child_idx, const uint8_t *node_desc,
+                      const uint32_t *word_id, const double *weight, int L, int levelsup, const uint8_t *desc, int n,
+                      int32_t *f_word, int32_t *f_node, double *f_weight, uint32_t *bow_id, double *bow_val, int *nbow,
+                      uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx, int *nfv)
+{
+    *nbow = 0;
+    *nfv = 0;
+    fv_off[0] = 0;
+    if (nnodes <= 0 || child_off[1] == child_off[0]) { /* empty vocabulary */
+        for (int i = 0; i < n; ++i) { f_word[i] = -1; f_node[i] = -1; f_weight[i] = 0.0; }
+        return 0;
+    }
+    const int nid_level = L - levelsup;
+    orc_ki *kw = (orc_ki *)malloc(sizeof(orc_ki) * (size_t)(n > 0 ? n : 1));
+    orc_ki *kn = (orc_ki *)malloc(sizeof(orc_ki) * (size_t)(n > 0 ? n : 1));
+    int m = 0;
+    if (!kw || !kn) { free(kw); free(kn); return -2; }
+    for (int i = 0; i < n; ++i) {
+        uint32_t nid = 0; /* nid_level <= 0 -> root */
+        uint32_t fin = 0;
+        int level = 0;
+        do {
+            ++level;
+            const uint32_t c0 = child_off[fin], c1 = child_off[fin + 1];
+            fin = child_idx[c0];
+            int best = orc_hamming(desc + (size_t)i * 32, node_desc + (size_t)fin * 32);
+            for (uint32_t c = c0 + 1; c < c1; ++c) {
+                const uint32_t id = child_idx[c];
+                const int d = orc_hamming(desc + (size_t)i * 32, node_desc + (size_t)id * 32);
+                if (d < best) { best = d; fin = id; }
+            }
+            if (level == nid_level) nid = fin;
+        } while (child_off[fin + 1] != child_off[fin]);
+        const double w = weight[fin];
+        if (w > 0) {
+            f_word[i] = (int32_t)word_id[fin];
+            f_node[i] = (int32_t)nid;
+            f_weight[i] = w;
+            kw[m].key = word_id[fin]; kw[m].i = i;
+            kn[m].key = nid; kn[m].i = i;
+            ++m;
+        } else {
+            f_word[i] = -1;
+            f_node[i] = -1;
+            f_weight[i] = 0.0;
+        }
+    }
+    qsort(kw, (size_t)m, sizeof(orc_ki), cmp_ki);
+    qsort(kn, (size_t)m, sizeof(orc_ki), cmp_ki);
+    int nb = 0;
+    for (int j = 0; j < m;) { /* std::map<WordId, double>: += in feature order */
+        int e = j;
+        double v = 0.0;
+        while (e < m && kw[e].key == kw[j].key) { v += f_weight[kw[e].i]; ++e; }
+        bow_id[nb] = kw[j].key;
+        bow_val[nb] = v;
+        ++nb;
+        j = e;
+    }
+    double norm = 0.0; /* BowVector::normalize(L1) */
+    for (int j = 0; j < nb; ++j) norm += fabs(bow_val[j]);
+    if (norm > 0.0)
+        for (int j = 0; j < nb; ++j) bow_val[j] /= norm;
+    int nf = 0;
+    for (int j = 0; j < m;) {
+        int e = j;
+        while (e < m && kn[e].key == kn[j].key) { fv_idx[e] = (uint32_t)kn[e].i; ++e; }
+        fv_node[nf] = kn[j].key;
+        fv_off[nf] = (uint32_t)j;
+        ++nf;
+        j = e;
+    }
+    fv_off[nf] = (uint32_t)m;
+    *nbow = nb;
+    *nfv = nf;
+    free(kw);
+    free(kn);
+    return 0;
+}

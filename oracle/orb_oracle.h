@@ -166,6 +166,21 @@ int orc_stereo_matches(const orc_extractor *eL, const orc_extractor *eR, const o
                        int nL, const orc_keypoint *kpsR, const uint8_t *descR, int nR, float mbf, float mb,
                        float *uRight, float *depth, int32_t *sad);
 
+/* ---- 8(f).3: DBoW2 TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) ----
+ * DBoW2 is a third-party dependency the reference does not vendor (perfect/Thirdparty/DBoW2 holds a readme only;
+ * ORB-SLAM2 ships its own modified copy, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h).  Restated from the published
+ * algorithm as used at src/Frame.cc:553 / src/KeyFrame.cc:82 (levelsup = 4, ORBvoc: k = 10, L = 6, TF-IDF, L1):
+ * every feature descends the tree taking the child with the smallest Hamming distance (first on ties); word weight 0
+ * -> feature skipped; BowVector = per word the sum of the weights in feature order, then L1-normalised in ascending
+ * word order (doubles); FeatureVector = per node at level L - levelsup the feature indices in feature order.
+ * Tree as arrays: children of node i are child_idx[child_off[i] .. child_off[i+1]) (node 0 = root), node_desc
+ * [nnodes][32], word_id / weight meaningful for leaves.  Outputs: per feature word / node (-1 if skipped) / weight;
+ * bow_id/bow_val[<= n] ascending; fv_node[<= n] ascending, fv_off[nfv+1], fv_idx[<= n]. */
+int orc_bow_transform(int nnodes, const uint32_t *child_off, const uint32_t *child_idx, const uint8_t *node_desc,
+                      const uint32_t *word_id, const double *weight, int L, int levelsup, const uint8_t *desc, int n,
+                      int32_t *f_word, int32_t *f_node, double *f_weight, uint32_t *bow_id, double *bow_val, int *nbow,
+                      uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx, int *nfv);
+
 #ifdef __cplusplus
 }
 #endif

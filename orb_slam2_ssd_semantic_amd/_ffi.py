@@ -27,7 +27,8 @@ SYMBOLS = (
     "orbfe_set_profiling", "orbfe_get_stage_ms", "orbfe_hamming", "orbfe_matcher_create",
     "orbfe_matcher_destroy", "orbfe_matcher_get_stream", "orbfe_match_bf", "orbfe_match_bf_device", "orbfe_match_bf_frames_device",
     "orbfe_search_by_bow", "orbfe_hamming_csr", "orbfe_assign_grid", "orbfe_features_in_area",
-    "orbfe_distinctive_descriptors", "orbfe_stereo_matches",
+    "orbfe_distinctive_descriptors", "orbfe_stereo_matches", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
+    "orbfe_bow_transform",
 )
 
 
@@ -96,6 +97,10 @@ def lib():
     L.orbfe_search_by_bow.argtypes = ([vp] + [vp, i32, vp, vp, vp, vp, vp, i32] * 2 + [f32, i32, i32, i32, vp, vp])
     L.orbfe_hamming_csr.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]
     L.orbfe_assign_grid.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp]
+    L.orbfe_vocabulary_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32, vp]
+    L.orbfe_vocabulary_destroy.argtypes = [vp]
+    L.orbfe_vocabulary_destroy.restype = None
+    L.orbfe_bow_transform.argtypes = [vp, vp, vp, i32, i32] + [vp] * 10
     L.orbfe_stereo_matches.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp]
     L.orbfe_distinctive_descriptors.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]
     L.orbfe_features_in_area.argtypes = [vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, i32, vp, vp, i32]

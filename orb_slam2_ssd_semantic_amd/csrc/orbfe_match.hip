@@ -1314,3 +1314,288 @@ extern "C" orbfe_status orbfe_stereo_matches(orbfe_matcher *m, orbfe_handle *lef
     ORBFE_HIP(hipStreamSynchronize(st));
     return ORBFE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// SURVEY 8(f).3  DBoW2 TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) as called at
+// src/Frame.cc:553 and src/KeyFrame.cc:82.  DBoW2 is not vendored by the reference; the algorithm is restated from the
+// published one.
+// k_bow_descend: thread per feature walks the tree, per level the child with the smallest Hamming distance (first on
+//   ties); remembers the node at level L - levelsup; features whose word has weight 0 are dropped.
+// k_bow_aggregate: one workgroup turns the per-feature (word, node, weight) into the two containers of the reference:
+//   an LDS bitonic sort by (word, feature) gives std::map order, every first-of-its-word thread adds its weights in
+//   feature order (doubles, the order `+=` ran in the reference), thread 0 forms the L1 norm in ascending word order,
+//   then the same sort by (node, feature) gives the FeatureVector as the CSR orbfe_search_by_bow consumes.
+// ---------------------------------------------------------------------------------------------------
+#define BOW_MAX_FEATURES 8192
+
+struct orbfe_vocabulary {
+    int device = 0, nnodes = 0, L = 0;
+    MDevBuf child_off, child_idx, node_desc, word_id, weight;
+};
+
+__global__ __launch_bounds__(256) void k_bow_descend(const uint32_t *__restrict__ child_off,
+                                                     const uint32_t *__restrict__ child_idx,
+                                                     const uint8_t *__restrict__ node_desc,
+                                                     const uint32_t *__restrict__ word_id,
+                                                     const double *__restrict__ weight, int nid_level,
+                                                     const uint8_t *__restrict__ desc, int n,
+                                                     int32_t *__restrict__ f_word, int32_t *__restrict__ f_node,
+                                                     double *__restrict__ f_weight)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Desc8 q;
+    {
+        const uint32_t *p = (const uint32_t *)(desc + (int64_t)i * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q.w[k] = p[k];
+    }
+    uint32_t fin = 0, nid = 0;
+    int level = 0;
+    uint32_t c0 = child_off[0], c1 = child_off[1];
+    do {  // child ids are larger than their parent's (checked at creation): the walk ends
+        ++level;
+        fin = child_idx[c0];
+        int best = hamming8(q, (const uint32_t *)(node_desc + (int64_t)fin * 32));
+        for (uint32_t c = c0 + 1; c < c1; ++c) {
+            const uint32_t id = child_idx[c];
+            const int d = hamming8(q, (const uint32_t *)(node_desc + (int64_t)id * 32));
+            if (d < best) { best = d; fin = id; }
+        }
+        if (level == nid_level) nid = fin;
+        c0 = child_off[fin];
+        c1 = child_off[fin + 1];
+    } while (c1 != c0);
+    const double w = weight[fin];
+    const bool keep = w > 0;
+    f_word[i] = keep ? (int32_t)word_id[fin] : -1;
+    f_node[i] = keep ? (int32_t)nid : -1;
+    f_weight[i] = keep ? w : 0.0;
+}
+
+__device__ void bow_bitonic_sort(unsigned long long *key, int P, int tid)
+{
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < P; t += 1024) {
+                const int ixj = t ^ j;
+                if (ixj > t) {
+                    const unsigned long long a = key[t], b = key[ixj];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { key[t] = b; key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// exclusive position of every flagged element among P (each thread owns a contiguous chunk); returns the total
+__device__ int bow_positions(const unsigned long long *key, int P, int tid, int *s_scan, int *pos_of_first_in_chunk)
+{
+    const int chunk = (P + 1023) / 1024, j0 = tid * chunk, j1 = min(j0 + chunk, P);
+    int cnt = 0;
+    for (int j = j0; j < j1; ++j) {
+        const unsigned long long kj = key[j];
+        if (kj != ~0ull && (j == 0 || (key[j - 1] >> 32) != (kj >> 32))) ++cnt;
+    }
+    s_scan[tid] = cnt;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = tid >= d ? s_scan[tid - d] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    *pos_of_first_in_chunk = s_scan[tid] - cnt;
+    const int total = s_scan[1023];
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void k_bow_aggregate(int n, int P, const int32_t *__restrict__ f_word,
+                                                        const int32_t *__restrict__ f_node,
+                                                        const double *__restrict__ f_weight,
+                                                        uint32_t *__restrict__ bow_id, double *__restrict__ bow_val,
+                                                        uint32_t *__restrict__ fv_node, uint32_t *__restrict__ fv_off,
+                                                        uint32_t *__restrict__ fv_idx, int32_t *__restrict__ counts)
+{
+    extern __shared__ unsigned long long s_key[];  // [P] keys, then [P] doubles
+    double *s_val = (double *)(s_key + P);
+    __shared__ int s_scan[1024];
+    __shared__ double s_norm;
+    const int tid = threadIdx.x;
+    const int chunk = (P + 1023) / 1024, j0 = tid * chunk, j1 = min(j0 + chunk, P);
+    // ---- BowVector ----
+    for (int i = tid; i < P; i += 1024)
+        s_key[i] = (i < n && f_word[i] >= 0) ? (((unsigned long long)(uint32_t)f_word[i] << 32) | (uint32_t)i) : ~0ull;
+    __syncthreads();
+    bow_bitonic_sort(s_key, P, tid);
+    int pos;
+    const int nbow = bow_positions(s_key, P, tid, s_scan, &pos);
+    for (int j = j0; j < j1; ++j) {
+        const unsigned long long kj = s_key[j];
+        if (kj != ~0ull && (j == 0 || (s_key[j - 1] >> 32) != (kj >> 32))) {
+            double v = 0.0;  // map[word] += weight, in feature order
+            for (int e = j; e < P && (s_key[e] >> 32) == (kj >> 32); ++e) v = __dadd_rn(v, f_weight[(uint32_t)s_key[e]]);
+            bow_id[pos] = (uint32_t)(kj >> 32);
+            s_val[pos] = v;
+            ++pos;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {  // BowVector::normalize(L1): ascending word order
+        double norm = 0.0;
+        for (int o = 0; o < nbow; ++o) norm = __dadd_rn(norm, fabs(s_val[o]));
+        s_norm = norm;
+    }
+    __syncthreads();
+    for (int o = tid; o < nbow; o += 1024) bow_val[o] = s_norm > 0.0 ? __ddiv_rn(s_val[o], s_norm) : s_val[o];
+    __syncthreads();
+    // ---- FeatureVector ----
+    for (int i = tid; i < P; i += 1024)
+        s_key[i] = (i < n && f_node[i] >= 0) ? (((unsigned long long)(uint32_t)f_node[i] << 32) | (uint32_t)i) : ~0ull;
+    __syncthreads();
+    bow_bitonic_sort(s_key, P, tid);
+    const int nfv = bow_positions(s_key, P, tid, s_scan, &pos);
+    int m = 0;
+    for (int j = j0; j < j1; ++j) {
+        const unsigned long long kj = s_key[j];
+        if (kj == ~0ull) continue;
+        fv_idx[j] = (uint32_t)kj;
+        if (j == 0 || (s_key[j - 1] >> 32) != (kj >> 32)) {
+            fv_node[pos] = (uint32_t)(kj >> 32);
+            fv_off[pos] = (uint32_t)j;
+            ++pos;
+        }
+        ++m;
+    }
+    s_scan[tid] = m;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int t = 0; t < 1024; ++t) tot += s_scan[t];
+        fv_off[nfv] = (uint32_t)tot;
+        counts[0] = nbow;
+        counts[1] = nfv;
+        counts[2] = tot;
+    }
+}
+
+extern "C" orbfe_status orbfe_vocabulary_create(int32_t device, int32_t nnodes, const uint32_t *child_off,
+                                                const uint32_t *child_idx, const uint8_t *node_desc,
+                                                const uint32_t *word_id, const double *weight, int32_t L,
+                                                orbfe_vocabulary **out)
+{
+    if (!out || nnodes < 1 || !child_off || !node_desc || !word_id || !weight || L < 1) {
+        orbfe_set_error("bad argument to orbfe_vocabulary_create");
+        return ORBFE_ERR_ARG;
+    }
+    *out = nullptr;
+    const uint32_t nc = child_off[nnodes];
+    if (child_off[0] != 0 || (nc > 0 && !child_idx)) { orbfe_set_error("vocabulary: bad child CSR"); return ORBFE_ERR_ARG; }
+    for (int i = 0; i < nnodes; ++i) {
+        if (child_off[i + 1] < child_off[i]) { orbfe_set_error("vocabulary: child offsets must not decrease"); return ORBFE_ERR_ARG; }
+        for (uint32_t c = child_off[i]; c < child_off[i + 1]; ++c)
+            if (child_idx[c] <= (uint32_t)i || child_idx[c] >= (uint32_t)nnodes) {
+                orbfe_set_error("vocabulary: child ids must be larger than their parent's id and < nnodes");
+                return ORBFE_ERR_ARG;
+            }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        orbfe_set_error("no HIP device visible; liborbfe has no CPU fallback");
+        return ORBFE_ERR_NODEVICE;
+    }
+    if (device < 0) device = 0;
+    if (device >= ndev) { orbfe_set_error("device %d out of range", device); return ORBFE_ERR_ARG; }
+    orbfe_vocabulary *v = new (std::nothrow) orbfe_vocabulary();
+    if (!v) return ORBFE_ERR_NOMEM;
+    v->device = device;
+    v->nnodes = nnodes;
+    v->L = L;
+    MDeviceGuard g(device);
+    auto up = [&](MDevBuf &b, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(std::max(bytes, (size_t)4));
+        if (e == hipSuccess && bytes) e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(v->child_off, child_off, (size_t)(nnodes + 1) * 4);
+    if (e == hipSuccess) e = up(v->child_idx, child_idx, (size_t)nc * 4);
+    if (e == hipSuccess) e = up(v->node_desc, node_desc, (size_t)nnodes * 32);
+    if (e == hipSuccess) e = up(v->word_id, word_id, (size_t)nnodes * 4);
+    if (e == hipSuccess) e = up(v->weight, weight, (size_t)nnodes * 8);
+    if (e != hipSuccess) {
+        orbfe_set_error("vocabulary upload failed: %s", hipGetErrorString(e));
+        orbfe_vocabulary_destroy(v);
+        return ORBFE_ERR_HIP;
+    }
+    *out = v;
+    return ORBFE_OK;
+}
+
+extern "C" void orbfe_vocabulary_destroy(orbfe_vocabulary *v)
+{
+    if (!v) return;
+    MDeviceGuard g(v->device);
+    MDevBuf *bufs[] = {&v->child_off, &v->child_idx, &v->node_desc, &v->word_id, &v->weight};
+    for (MDevBuf *b : bufs) b->release();
+    delete v;
+}
+
+extern "C" orbfe_status orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocabulary *v, const uint8_t *desc, int32_t n,
+                                            int32_t levelsup, int32_t *f_word, int32_t *f_node, double *f_weight,
+                                            uint32_t *bow_id, double *bow_val, int32_t *nbow, uint32_t *fv_node,
+                                            uint32_t *fv_off, uint32_t *fv_idx, int32_t *nfv)
+{
+    if (!m || !v || n < 0 || n > BOW_MAX_FEATURES || !nbow || !nfv || !fv_off ||
+        (n > 0 && (!desc || !bow_id || !bow_val || !fv_node || !fv_idx))) {
+        orbfe_set_error("bad argument to orbfe_bow_transform (at most %d features per call)", BOW_MAX_FEATURES);
+        return ORBFE_ERR_ARG;
+    }
+    if (v->device != m->device) { orbfe_set_error("vocabulary and matcher are on different devices"); return ORBFE_ERR_ARG; }
+    *nbow = 0;
+    *nfv = 0;
+    fv_off[0] = 0;
+    if (n == 0) return ORBFE_OK;
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    int P = 2;
+    while (P < n) P <<= 1;
+    ORBFE_HIP(m->b[0].ensure((size_t)n * 32));
+    ORBFE_HIP(m->b[1].ensure((size_t)n * 4));   // f_word
+    ORBFE_HIP(m->b[2].ensure((size_t)n * 4));   // f_node
+    ORBFE_HIP(m->b[3].ensure((size_t)n * 8));   // f_weight
+    ORBFE_HIP(m->b[4].ensure((size_t)n * 4));   // bow_id
+    ORBFE_HIP(m->b[5].ensure((size_t)n * 8));   // bow_val
+    ORBFE_HIP(m->b[6].ensure((size_t)n * 4));   // fv_node
+    ORBFE_HIP(m->b[7].ensure((size_t)(n + 1) * 4));
+    ORBFE_HIP(m->b[8].ensure((size_t)n * 4));   // fv_idx
+    ORBFE_HIP(m->b[9].ensure(16));
+    ORBFE_HIP(hipMemcpyAsync(m->b[0].p, desc, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bow_descend, dim3((n + 255) / 256), dim3(256), 0, st, (const uint32_t *)v->child_off.p,
+                       (const uint32_t *)v->child_idx.p, (const uint8_t *)v->node_desc.p, (const uint32_t *)v->word_id.p,
+                       (const double *)v->weight.p, v->L - levelsup, (const uint8_t *)m->b[0].p, n, (int32_t *)m->b[1].p,
+                       (int32_t *)m->b[2].p, (double *)m->b[3].p);
+    const size_t lds = (size_t)P * 16;
+    ORBFE_HIP(hipFuncSetAttribute((const void *)k_bow_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_bow_aggregate, dim3(1), dim3(1024), lds, st, n, P, (const int32_t *)m->b[1].p,
+                       (const int32_t *)m->b[2].p, (const double *)m->b[3].p, (uint32_t *)m->b[4].p, (double *)m->b[5].p,
+                       (uint32_t *)m->b[6].p, (uint32_t *)m->b[7].p, (uint32_t *)m->b[8].p, (int32_t *)m->b[9].p);
+    ORBFE_HIP(hipGetLastError());
+    int32_t counts[3] = {0, 0, 0};
+    ORBFE_HIP(hipMemcpyAsync(counts, m->b[9].p, 12, hipMemcpyDeviceToHost, st));
+    if (f_word) ORBFE_HIP(hipMemcpyAsync(f_word, m->b[1].p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (f_node) ORBFE_HIP(hipMemcpyAsync(f_node, m->b[2].p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (f_weight) ORBFE_HIP(hipMemcpyAsync(f_weight, m->b[3].p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    *nbow = counts[0];
+    *nfv = counts[1];
+    if (counts[0] > 0) {
+        ORBFE_HIP(hipMemcpy(bow_id, m->b[4].p, (size_t)counts[0] * 4, hipMemcpyDeviceToHost));
+        ORBFE_HIP(hipMemcpy(bow_val, m->b[5].p, (size_t)counts[0] * 8, hipMemcpyDeviceToHost));
+    }
+    ORBFE_HIP(hipMemcpy(fv_off, m->b[7].p, (size_t)(counts[1] + 1) * 4, hipMemcpyDeviceToHost));
+    if (counts[1] > 0) ORBFE_HIP(hipMemcpy(fv_node, m->b[6].p, (size_t)counts[1] * 4, hipMemcpyDeviceToHost));
+    if (counts[2] > 0) ORBFE_HIP(hipMemcpy(fv_idx, m->b[8].p, (size_t)counts[2] * 4, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}

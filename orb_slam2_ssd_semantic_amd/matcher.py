@@ -194,3 +194,47 @@ class FrameGrid:
     def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1):
         off, cand = self.query([[x, y, r]], [[minLevel, maxLevel]])
         return cand
+
+
+class ORBVocabulary:
+    """DBoW2 vocabulary tree on the device (reference include/ORBVocabulary.h).
+
+    `ORBVocabulary(matcher, child_off, child_idx, node_desc, word_id, weight, L)`; `transform(descriptors, levelsup=4)`
+    mirrors `mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)` (src/Frame.cc:553) and returns
+    (BowVector as (ids, values), FeatureVector as the (node, off, idx) CSR `ORBmatcher.SearchByBoW` takes)."""
+
+    def __init__(self, matcher, child_off, child_idx, node_desc, word_id, weight, L, device=-1):
+        self._mt = matcher
+        self._L = _ffi.lib()
+        self._v = C.c_void_p()
+        co = np.ascontiguousarray(child_off, np.uint32)
+        ci = np.ascontiguousarray(child_idx, np.uint32)
+        nd = np.ascontiguousarray(node_desc, np.uint8).reshape(-1, 32)
+        wi = np.ascontiguousarray(word_id, np.uint32)
+        ww = np.ascontiguousarray(weight, np.float64)
+        check(self._L.orbfe_vocabulary_create(device, len(nd), ptr(co), ptr(ci), ptr(nd), ptr(wi), ptr(ww), int(L),
+                                              C.byref(self._v)), "orbfe_vocabulary_create")
+
+    def close(self):
+        if getattr(self, "_v", None):
+            self._L.orbfe_vocabulary_destroy(self._v)
+            self._v = None
+
+    def __del__(self):
+        self.close()
+
+    def transform(self, desc, levelsup=4, per_feature=False):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        m = max(n, 1)
+        fw, fn, fwt = np.zeros(m, np.int32), np.zeros(m, np.int32), np.zeros(m, np.float64)
+        bid, bval, nb = np.zeros(m, np.uint32), np.zeros(m, np.float64), C.c_int32(0)
+        fvn, fvo, fvi, nf = np.zeros(m, np.uint32), np.zeros(m + 1, np.uint32), np.zeros(m, np.uint32), C.c_int32(0)
+        st = self._L.orbfe_bow_transform(self._mt._m, self._v, ptr(d), n, levelsup, ptr(fw), ptr(fn), ptr(fwt), ptr(bid),
+                                         ptr(bval), C.byref(nb), ptr(fvn), ptr(fvo), ptr(fvi), C.byref(nf))
+        check(st, "orbfe_bow_transform")
+        bow = (bid[:nb.value].copy(), bval[:nb.value].copy())
+        fv = (fvn[:nf.value].copy(), fvo[:nf.value + 1].copy(), fvi[:int(fvo[nf.value])].copy())
+        if per_feature:
+            return bow, fv, (fw[:n].copy(), fn[:n].copy(), fwt[:n].copy())
+        return bow, fv
