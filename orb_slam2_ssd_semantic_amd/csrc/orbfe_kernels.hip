@@ -1346,8 +1346,13 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
                                                          const int32_t *__restrict__ nsel,
                                                          orbfe_keypoint *__restrict__ kps,
                                                          uint8_t *__restrict__ desc, int32_t cap,
-                                                         int32_t *__restrict__ n_out)
+                                                         int32_t *__restrict__ n_out, int32_t nl,
+                                                         int32_t sel_per_frame)
 {
+    // Everything the keypoint look-up needs is requested in ONE round trip (level counts, per-level constants into
+    // LDS, pattern and moment weights), so the dependent chain of a workgroup is: this, the key, the pixels.
+    struct DescLevel { int32_t sel_off, off, pitch; float scale, patch_size; };
+    __shared__ DescLevel s_lv[ORBFE_MAX_LEVELS];
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[16][DS_PR * DS_PP];
     __shared__ uint2 s_momw[31 * 8];
     __shared__ float4 s_pat[256];  // (x0, y0, x1, y1) of every test pair as floats
@@ -1355,6 +1360,16 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     xcd_frame_remap(bx, b);
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = lane & 15, quad = tid >> 4;  // quad 0..15 inside the workgroup = one keypoint
+    int32_t cnt[ORBFE_MAX_LEVELS];
+    {
+        const int32_t *ns = nsel + b * nl;
+#pragma unroll
+        for (int l = 0; l < ORBFE_MAX_LEVELS; ++l) cnt[l] = l < nl ? ns[l] : 0;
+    }
+    if (tid < nl) {
+        const OrbLevel &Lt = plan->lv[tid];
+        s_lv[tid] = DescLevel{Lt.sel_off, Lt.off, Lt.pitch, Lt.scale, Lt.patch_size};
+    }
     for (int i = tid; i < 31 * 8; i += 256) s_momw[i] = c_momw[i];
     {
         const uint32_t pt = ((const uint32_t *)c_pattern)[tid];
@@ -1365,11 +1380,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     __syncthreads();
 
     const int slot = bx * 16 + quad;
-    const int nl = plan->nlevels;
-    const int32_t *ns = nsel + b * nl;
     int level = -1, idx = slot, total = 0;
-    for (int l = 0; l < nl; ++l) {
-        const int c = ns[l];
+#pragma unroll
+    for (int l = 0; l < ORBFE_MAX_LEVELS; ++l) {
+        const int c = cnt[l];
         if (level < 0 && idx < c) level = l;
         if (level < 0) idx -= c;
         total += c;
@@ -1384,13 +1398,13 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
         if (sub < 8) ((uint32_t *)dd)[sub] = 0u;
     }
     const int lv = live ? level : 0;
-    const OrbLevel &L = plan->lv[lv];
+    const DescLevel L = s_lv[lv];
     uint32_t key = 0;
-    if (live) key = sel[(int64_t)b * plan->sel_per_frame + L.sel_off + idx];
+    if (live) key = sel[(int64_t)b * sel_per_frame + L.sel_off + idx];
     // dead quads shadow a valid position so that every lane can run the same loads
     const int x = live ? orb_key_x(key) : ORBFE_EDGE, y = live ? orb_key_y(key) : ORBFE_EDGE;
-    int pitch;
-    const uint8_t *img = level_ptr(fs, L, lv, b, &pitch);
+    const int pitch = lv == 0 ? fs.l0_pitch : L.pitch;
+    const uint8_t *img = lv == 0 ? fs.l0 + (int64_t)b * fs.l0_fstride : fs.pyr + (int64_t)b * fs.pyr_fstride + L.off;
 
     // ---- A: moments ----
     int m10 = 0, rs15 = 0, m01 = 0;
@@ -1573,6 +1587,6 @@ hipError_t orbk_launch_describe(const OrbLaunch &a, hipStream_t st)
     const FrameSrc fs = make_src(a);
     dim3 grid((a.cap + 15) / 16, a.nframes);
     hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, st, a.d_plan, fs, a.d_blur, a.pyr_fstride, a.d_sel,
-                       a.d_nsel, a.d_kps, a.d_desc, a.cap, a.d_n_out);
+                       a.d_nsel, a.d_kps, a.d_desc, a.cap, a.d_n_out, a.h_plan->nlevels, a.h_plan->sel_per_frame);
     return hipGetLastError();
 }
