@@ -185,6 +185,9 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if gather:  # retire the work handles of the last two gathers (already complete: fence() synchronised the device)
+        gather.acquire(0)
+        gather.acquire(1)
     stage = ext.stage_ms()
     ext.set_profiling(False)
     if world > 1:
