@@ -204,18 +204,32 @@ __global__ __launch_bounds__(BM_WAVES * 64, 2) void k_match_bf(const uint8_t *__
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        // two largest keys of query tile u over the 16 rows in `acc`; latch the index when the best changed
+        // two largest keys of query tile u over the 16 rows in `acc`; latch the index when the best changed.
+        // A tournament instead of a running (best, second) pair: same instruction count, but depth 5 instead of 16 --
+        // with two waves per SIMD a 16-long dependent chain leaves the VALU idle most of the time.
         auto rank = [&](const bm_v16i &acc, int u, int T, bool mask_tail) {
-            const int bprev = kb[u] | 127;
-            int b = bprev, s2 = ks[u] | 127;
+            int hi[8], lo[8];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                int key = acc[reg];
-                if (mask_tail && T + (reg & 3) + 8 * (reg >> 2) + 4 * h >= nt) key = BM_NEG;
-                const int lo = min(b, key);
-                b = max(b, key);
-                s2 = max(s2, lo);
+            for (int p = 0; p < 8; ++p) {
+                int k0 = acc[2 * p], k1 = acc[2 * p + 1];
+                if (mask_tail) {
+                    if (T + ((2 * p) & 3) + 8 * ((2 * p) >> 2) + 4 * h >= nt) k0 = BM_NEG;
+                    if (T + ((2 * p + 1) & 3) + 8 * ((2 * p + 1) >> 2) + 4 * h >= nt) k1 = BM_NEG;
+                }
+                hi[p] = max(k0, k1);
+                lo[p] = min(k0, k1);
             }
+#pragma unroll
+            for (int w = 4; w >= 1; w >>= 1)
+#pragma unroll
+                for (int p = 0; p < w; ++p) {  // merge the (largest, second) pairs p and p + w
+                    const int h2 = max(hi[p], hi[p + w]);
+                    lo[p] = max(min(hi[p], hi[p + w]), max(lo[p], lo[p + w]));
+                    hi[p] = h2;
+                }
+            const int bprev = kb[u] | 127, sprev = ks[u] | 127;
+            const int b = max(bprev, hi[0]);
+            const int s2 = max(min(bprev, hi[0]), max(sprev, lo[0]));
             if (b != bprev) bi[u] = T + 32 - (b & 127);
             kb[u] = b;
             ks[u] = s2;
