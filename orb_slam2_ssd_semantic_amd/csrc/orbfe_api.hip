@@ -335,15 +335,12 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     for (int l = 0; l < nl; ++l) P.max_ncells = std::max(P.max_ncells, P.lv[l].ncells);
     P.keys_per_frame = key_off;
     P.sel_per_frame = sel_off;
-    int M = 64;
-    while (M < max_sel + 1) M <<= 1;
-    if (M > 4096) {
-        orbfe_set_error("nfeatures too large: %d quadtree nodes per level exceed 4096", max_sel);
-        return ORBFE_ERR_ARG;
-    }
+    // node arrays: one slot more than the largest list, rounded to 64 (only the sort buffer inside is a power of two)
+    const int M = orb_align_up(std::max(max_sel + 1, 64), 64);
     P.node_cap = M;
     if (orbk_octree_lds_bytes(M, 4, w, ht, P.max_ncells) > 160 * 1024) {
-        orbfe_set_error("nfeatures too large: the quadtree of one level (%d nodes) does not fit the 160 KB LDS", max_sel);
+        orbfe_set_error("nfeatures too large: the quadtree of one level (%d nodes) does not fit the 160 KB LDS "
+                        "(about 1700 features asked of a single level)", max_sel);
         return ORBFE_ERR_ARG;
     }
     P.max_nini = 1;

@@ -89,7 +89,7 @@ struct OrbPlan {
     int32_t max_ncells;        // largest FAST cell count of a level (quadtree cell-flag bitmap)
     int32_t keys_per_frame;    // key scratch entries per frame
     int32_t sel_per_frame;     // selected-keypoint scratch entries per frame
-    int32_t node_cap;          // quadtree node capacity (power of two)
+    int32_t node_cap;          // quadtree node capacity (multiple of 64)
     int32_t max_nini;          // largest number of quadtree roots over the levels
     int32_t ini_th, min_th;
     int32_t blur_rounding;

@@ -586,10 +586,17 @@ struct QtShared {
     int32_t *misc;
 };
 
+__host__ __device__ inline int qt_pow2(int v)
+{
+    int p = 2;
+    while (p < v) p <<= 1;
+    return p;
+}
+
 __device__ __forceinline__ void qt_carve(char *base, int M, int nroots, int w, int h, int ncells, QtShared &q)
 {
     char *p = base;
-    q.skey = (unsigned long long *)p; p += (size_t)M * 8;
+    q.skey = (unsigned long long *)p; p += (size_t)qt_pow2(M) * 8;  // the largest-first sort is bitonic: power of two
     q.cc = (int32_t *)p; p += (size_t)M * 16;
     q.childpos = (int32_t *)p; p += (size_t)M * 16;
     q.M = M;
@@ -609,7 +616,7 @@ __device__ __forceinline__ void qt_carve(char *base, int M, int nroots, int w, i
 
 size_t orbk_octree_lds_bytes(int M, int nroots, int w, int h, int ncells)
 {
-    return (size_t)M * (8 + 16 + 16 + 8 + 8 + 16 + 16) + (size_t)nroots * FF_PER_ROOT * 4 + 64 * 4 +
+    return (size_t)qt_pow2(M) * 8 + (size_t)M * (16 + 16 + 8 + 8 + 16 + 16) + (size_t)nroots * FF_PER_ROOT * 4 + 64 * 4 +
            (size_t)(((w + 1) & ~1) + ((h + 1) & ~1)) * 2 + (size_t)((ncells + 31) / 32) * 4;
 }
 
