@@ -106,8 +106,8 @@ orbfe_status orbfe_extract_batch(orbfe_handle *h, const uint8_t *const *grays, i
                                  int32_t *n_out);
 
 /* Batched keyframe mode, DEVICE buffers (HBM-resident input, what bench.py times):
- *   d_gray   : nframes frames, frame i at d_gray + i*frame_stride, row pitch `stride`; the buffer must stay
- *              readable for 16 bytes past the last frame's last pixel (kernels read whole dwords)
+ *   d_gray   : nframes frames, frame i at d_gray + i*frame_stride, row pitch `stride`; nothing outside
+ *              [d_gray, last pixel of the last frame] is read (row windows are pulled back at the right edge)
  *   d_kps    : nframes*cap orbfe_keypoint      d_desc : nframes*cap*32 bytes     d_n_out : nframes int32
  * All work is enqueued on `stream`, a hipStream_t passed as void*.  NULL is HIP's (legacy) default stream
  * -- the stream PyTorch uses unless told otherwise; pass orbfe_get_stream(h) for the handle's own

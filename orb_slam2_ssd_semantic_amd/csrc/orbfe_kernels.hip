@@ -149,8 +149,6 @@ __global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
     // its first source column (level-to-level scale < 2, checked by the host), so ONE unaligned 8-byte load per
     // source row feeds all four pixels: pixel j picks its pair with a per-lane v_perm selector (-> two u16 halves)
     // and the horizontal sum S[sx]*a0 + S[sx+1]*a1 is one v_dot2_u32_u16 against the packed coefficients.
-    // The window may reach 7 bytes past the last source pixel of a row: inside the handle's own levels (a later
-    // level follows), and inside the caller's level-0 buffer thanks to the 16-byte slack orbfe.h asks for.
     // taps of the lane's 4 pixels and 4 rows: four 16-byte loads from the host-built tables (exact cv::resize taps)
     const uint4 tx01 = *(const uint4 *)(a.xtab + dx0), tx23 = *(const uint4 *)(a.xtab + dx0 + 2);
     const uint32_t xc[4] = {tx01.x, tx01.z, tx23.x, tx23.z};  // coefficient pairs c0 | c1 << 16
@@ -165,13 +163,15 @@ __global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
         ys4[d] = (int)(short)ty.y;
         ys4[d + 1] = (int)(short)ty.w;
     }
-    const int sx0 = xs[0];
+    // the window never leaves the source row: at the right edge it is pulled back to end at the last pixel (the
+    // second byte of a pair at the last column has coefficient 0, any byte serves)
+    const int sx0 = min(xs[0], a.sw - 8);
     uint32_t sel[4];
     orb_u2 coef[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t o = (uint32_t)min(max(xs[j] - sx0, 0), 6);
-        sel[j] = 0x0c000c00u | ((o + 1u) << 16) | o;
+        const uint32_t o = (uint32_t)min(max(xs[j] - sx0, 0), 7);
+        sel[j] = 0x0c000c00u | (min(o + 1u, 7u) << 16) | o;
         coef[j] = __builtin_bit_cast(orb_u2, xc[j]);
     }
     // straight-line: all source windows of the tile in flight at once, then the arithmetic (no control flow)
@@ -1165,7 +1165,9 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
     }
     srcx[0] = srcx[1];
     srcx[11] = srcx[10];
-    const int base = lo & ~3;  // all ten sources lie in [base, base + 12) (checked on the host for every level width)
+    // all ten sources lie in [base, base + 12) (checked on the host for every level width); at the right edge the
+    // window is pulled back so that it ends at the last pixel of the row
+    const int base = min(lo & ~3, W - 12);
     uint32_t selA[3], selB[3], mskB[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {

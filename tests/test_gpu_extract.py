@@ -248,3 +248,29 @@ def test_scale_factor_limits(oracle):
     assert_same_output(gk, gd, ok, od)
     with pytest.raises(OrbfeError):                          # a level less than half as wide as its parent
         ORBextractor(500, 2.5, 3, 20, 7, max_width=640, max_height=480)(img)
+
+
+def test_exact_sized_input_buffer_is_never_overrun(oracle):
+    """512 frames of 640x480 are exactly 150 MiB, so the allocation ends on a 2 MiB page boundary and any read past the
+    last pixel faults (it did: an 8-byte row window of the pyramid kernel reached 7 bytes past the last row)."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE, ORBextractor
+    B, cap = 512, 1088
+    e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=B)
+    assert cap >= e.capacity()
+    base = np.stack([synth_frame(900 + i) for i in range(4)])
+    frames = np.ascontiguousarray(np.tile(base, (B // 4, 1, 1)))
+    assert frames.nbytes % (2 << 20) == 0
+    d_gray = torch.from_numpy(frames).cuda()
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_gray.data_ptr(), B, 640, 480, 640, 640 * 480, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                           d_n.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    oe = oracle.OracleExtractor()
+    for i in (0, 1, B - 2, B - 1):
+        ok, od = oe(frames[i])
+        gk = d_kps[i, :n[i]].cpu().numpy().copy().view(KP_DTYPE).reshape(-1)
+        assert_same_output(gk, d_desc[i, :n[i]].cpu().numpy(), ok, od)
