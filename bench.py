@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=1024, help="frames per step per GPU (HBM-resident batch)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
@@ -281,7 +281,7 @@ def main():
                 e1(img)
                 lat.append(time.perf_counter() - t2)
             result["single_frame_host_latency_ms"] = round(float(np.median(lat)) * 1e3, 4)
-            pm = os.path.join(ROOT, "profiles", "r01_v6_pmc_hbm.json")
+            pm = os.path.join(ROOT, "profiles", "r01_v8_pmc_hbm.json")
             if os.path.exists(pm):  # HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes
                 try:
                     pj = json.load(open(pm))
@@ -290,7 +290,7 @@ def main():
                     # profiles/r01_fetch_calibration.txt), WRITE_SIZE is exact
                     tb = (2 * pj["FETCH_SIZE_KB"][kn]["mean_per_launch"] + pj["WRITE_SIZE_KB"][kn]["mean_per_launch"]) * 1024
                     roof["traffic"] = int(tb)
-                    roof["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_v6_pmc_hbm.json "
+                    roof["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_v8_pmc_hbm.json "
                                             "(separate --pmc passes; x2 read correction per profiles/r01_fetch_calibration.txt)")
                 except Exception:
                     pass
