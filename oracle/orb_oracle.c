@@ -667,10 +667,17 @@ void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *
  * correctly rounded, CPU-ifunc dependent).  Contract: evaluate in fp64 with the FIXED operation
  * sequence below (Cody-Waite reduction by pi/2, fdlibm kernel polynomials, separate mul/add, no
  * FMA) and round once to fp32.  The HIP kernel executes the identical sequence. */
+void orc_sincos_rad(float angle, float *cos_a, float *sin_b);
 void orc_sincos(float angle_deg, float *cos_a, float *sin_b)
 {
     const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f); /* :91 */
     const float angle = angle_deg * factor_pi;                                   /* :96 */
+    orc_sincos_rad(angle, cos_a, sin_b);
+}
+
+/* the canonical (float)cos / (float)sin of a float argument in radians (what :97 computes) */
+void orc_sincos_rad(float angle, float *cos_a, float *sin_b)
+{
     const double x = (double)angle;
     const double two_over_pi = 6.36619772367581382433e-01;
     const double pio2_hi = 1.57079632673412561417e+00; /* first 33 bits of pi/2 */

@@ -9,12 +9,18 @@
  * restated from the published algorithms because OpenCV is a non-vendored,
  * un-pinned third-party dependency.
  *
- * PARITY STATUS: **parity unpinned** by the reference -- the reference ships no
- * tests, no golden vectors and cannot be built here (no OpenCV / DBoW2).  The
- * oracle is pinned instead by (a) known-answer tables derived from the reference
- * source itself (umax, features-per-level, level sizes, grid geometry, pattern
- * checksum, DescriptorDistance, ComputeThreeMaxima) and (b) independent
- * definition-level twins (tests/twins.py).  See DESIGN.md "Oracle".
+ * PARITY STATUS: pinned to code compiled from the reference for everything that IS the reference's code;
+ * "restated, unpinned by real OpenCV" for the five OpenCV algorithms.
+ *   - oracle/_ref/libref_orb.so (recipe: oracle/refbuild/Makefile) is the UNMODIFIED reference
+ *     src/ORBextractor.cc and src/ORBmatcher.cc compiled against a cv stub.  tests/test_ref_pin.py checks
+ *     oracle == _ref bit for bit, stage by stage, on the golden cases + 200 seeded frames + 300 quadtree sets +
+ *     480 SearchByBoW cases: constructor tables, pyramid orchestration, the cell loop and threshold fallback,
+ *     DistributeOctTree / DivideNode, IC_Angle, computeOrbDescriptor, rescale + order, DescriptorDistance,
+ *     SearchByBoW x2, ComputeThreeMaxima.  tests/golden/orb_golden.npz is generated from _ref.
+ *   - cv::resize, copyMakeBorder, cv::FAST, GaussianBlur, fastAtan2 are NOT in /root/reference (OpenCV is a
+ *     non-vendored, un-pinned dependency and is not installed): inside _ref they are THIS file's restatements
+ *     of the OpenCV 3.2 generic path, pinned only by known-answer tables and definition-level twins
+ *     (tests/test_oracle_kat.py, tests/twins.py).  For those five stages parity remains "unpinned".
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * link or call this library.  The product (orb_slam2_ssd_semantic_amd/csrc)
@@ -100,6 +106,7 @@ void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *
 
 /* ---- E8: steered BRIEF (ORBextractor.cc:92-131) ---- */
 void orc_sincos(float angle_deg, float *cos_a, float *sin_b); /* canonical (float)cos/(float)sin of angle*pi/180 */
+void orc_sincos_rad(float angle_rad, float *cos_a, float *sin_b); /* the same sequence entered after the *factorPI step */
 void orc_descriptor(const uint8_t *blurred, int stride, int x, int y, float angle_deg, uint8_t desc[32]);
 
 /* ---- E1: operator() (ORBextractor.cc:1052-1114) ---- */

@@ -1,0 +1,247 @@
+"""ctypes binding of oracle/_ref/libref_orb.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+libref_orb.so is the UNMODIFIED /root/reference/src/ORBextractor.cc and src/ORBmatcher.cc compiled by
+oracle/refbuild/Makefile against a cv stub (types) whose five OpenCV algorithms are the oracle's restatements.
+It exists to pin oracle/orb_oracle.c to code compiled from the reference.  Only tests/ (and, as a CPU baseline,
+bench.py's cpu_baseline leg) may import this module; the product package never does.
+
+/root/reference exists only in the build container: there build() runs the Makefile; on the GPU box the
+prebuilt library travels with the snapshot and build() only checks that it is present.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_OUT = os.path.join(_HERE, "_ref")
+_LIB = os.path.join(_OUT, "libref_orb.so")
+REFERENCE = os.environ.get("ORBFE_REFERENCE", "/root/reference")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4")])
+
+
+def have_reference():
+    return os.path.exists(os.path.join(REFERENCE, "src", "ORBextractor.cc"))
+
+
+def available():
+    return os.path.exists(_LIB) or have_reference()
+
+
+def build():
+    """make -C oracle/refbuild when the reference sources are present; otherwise require the prebuilt library."""
+    if have_reference():
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "refbuild"), f"REF={REFERENCE}"])
+    if not os.path.exists(_LIB):
+        raise RuntimeError("oracle/_ref/libref_orb.so is missing and /root/reference is not available to build it")
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.ref_ext_create.restype = vp
+    L.ref_ext_create.argtypes = [ci, cf, ci, ci, ci]
+    L.ref_ext_destroy.argtypes = [vp]
+    L.ref_ext_tables.argtypes = [vp] * 8
+    L.ref_ext_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp]
+    L.ref_ext_keypoints_octtree.argtypes = [vp, vp, ci, ci, ci, vp, ci, vp]
+    L.ref_ext_level.argtypes = [vp, ci, ci, vp, ci, vp, vp]
+    L.ref_ext_num_candidates.argtypes = [vp, ci]
+    L.ref_ext_candidates.argtypes = [vp, ci, vp]
+    L.ref_ext_num_blur.argtypes = [vp]
+    L.ref_ext_blur.argtypes = [vp, ci, vp, ci, vp, vp]
+    L.ref_ext_fast_calls.restype = C.c_long
+    L.ref_ext_fast_calls.argtypes = [vp]
+    L.ref_ext_blur_ties.restype = C.c_long
+    L.ref_ext_blur_ties.argtypes = [vp]
+    L.ref_distribute_octtree.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci]
+    L.ref_config_bump.argtypes = [ci]
+    L.ref_set_trig_mode.argtypes = [ci]
+    L.ref_set_blur_mode.argtypes = [ci]
+    L.ref_glibc_sincosf.argtypes = [cf, vp, vp]
+    L.ref_descriptor_distance.argtypes = [vp, vp]
+    L.ref_three_maxima.argtypes = [vp, ci, vp, vp, vp]
+    L.ref_search_by_bow_kf_f.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, cf, ci, vp]
+    L.ref_search_by_bow_kf_kf.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci] * 2 + [cf, ci, vp]
+    L.ref_matcher_constants.argtypes = [vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def configure(bump=True, canonical_trig=True, blur_mode=0):
+    """The two machine-dependent spots of the reference binary and the blur column-rounding variant:
+    bump=True           operator new from a bump arena -> the :686 pointer sort breaks ties by creation order
+    bump=False          glibc malloc -> tie order depends on the heap's history (what a real build does)
+    canonical_trig=True cos/sin at :97 = the canonical orc_sincos sequence; False = this machine's glibc cosf/sinf
+    blur_mode           0 integer half-up, 1 emulate the SSE2 column kernel (SURVEY 9.4 ambiguity A)"""
+    L = lib()
+    L.ref_config_bump(int(bump))
+    L.ref_set_trig_mode(int(canonical_trig))
+    L.ref_set_blur_mode(int(blur_mode))
+
+
+class RefExtractor:
+    """The reference's ORB_SLAM2::ORBextractor itself (src/ORBextractor.cc), behind flat buffers."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.h = self.L.ref_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ref_ext_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        fpl, um, pat = np.zeros(n, np.int32), np.zeros(16, np.int32), np.zeros(1024, np.int32)
+        self.L.ref_ext_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(fpl), _p(um), _p(pat))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, features_per_level=fpl, umax=um, pattern=pat)
+
+    def __call__(self, image, cap=None):
+        """operator(): (keypoints[KP_DTYPE], descriptors[N,32])."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = image.shape if image.ndim == 2 else (0, 0)
+        cap = cap or (self.nfeatures + 4 * self.nlevels + 64)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(-1)
+        rc = self.L.ref_ext_extract(self.h, _p(image), w, h, image.strides[0] if image.ndim == 2 else 0, _p(kps),
+                                    _p(desc), cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"ref_ext_extract rc={rc} n={n.value}")
+        if n.value < 0:  # empty image: the reference returned without touching its outputs
+            return None, None
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def keypoints_octtree(self, image, cap=None):
+        """ComputePyramid + ComputeKeyPointsOctTree: list of per-level keypoint arrays (level coordinates)."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = image.shape
+        cap = cap or (self.nfeatures + 4 * self.nlevels + 64)
+        kps = np.zeros(cap, KP_DTYPE)
+        nl = np.zeros(self.nlevels, np.int32)
+        rc = self.L.ref_ext_keypoints_octtree(self.h, _p(image), w, h, image.strides[0], _p(kps), cap, _p(nl))
+        if rc != 0:
+            raise RuntimeError(f"ref_ext_keypoints_octtree rc={rc}")
+        o = np.concatenate([[0], np.cumsum(nl)])
+        return [kps[o[i]:o[i + 1]].copy() for i in range(self.nlevels)]
+
+    def level(self, level, with_border=False, cap=1 << 24):
+        buf = np.zeros(cap, np.uint8)
+        w, h = C.c_int(), C.c_int()
+        rc = self.L.ref_ext_level(self.h, level, int(with_border), _p(buf), cap, C.byref(w), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"ref_ext_level rc={rc}")
+        return buf[:w.value * h.value].reshape(h.value, w.value).copy()
+
+    def candidates(self, level):
+        n = self.L.ref_ext_num_candidates(self.h, level)
+        out = np.zeros(n, CAND_DTYPE)
+        if n:
+            self.L.ref_ext_candidates(self.h, level, _p(out))
+        return out
+
+    def blurred(self):
+        """GaussianBlur results of the last operator() in call order (levels with >= 1 keypoint)."""
+        out = []
+        for i in range(self.L.ref_ext_num_blur(self.h)):
+            buf = np.zeros(1 << 24, np.uint8)
+            w, h = C.c_int(), C.c_int()
+            assert self.L.ref_ext_blur(self.h, i, _p(buf), buf.size, C.byref(w), C.byref(h)) == 0
+            out.append(buf[:w.value * h.value].reshape(h.value, w.value).copy())
+        return out
+
+    def fast_calls(self):
+        return self.L.ref_ext_fast_calls(self.h)
+
+    def distribute_octtree(self, cands, minx, maxx, miny, maxy, N, level=0):
+        cands = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        out = np.zeros(max(1, cands.size), CAND_DTYPE)
+        n = self.L.ref_distribute_octtree(self.h, _p(cands), cands.size, minx, maxx, miny, maxy, N, level, _p(out),
+                                          out.size)
+        if n < 0:
+            raise RuntimeError(f"ref_distribute_octtree rc={n}")
+        return out[:n].copy()
+
+
+def glibc_sincosf(x):
+    s, c = C.c_float(), C.c_float()
+    lib().ref_glibc_sincosf(float(x), C.byref(s), C.byref(c))
+    return np.float32(c.value), np.float32(s.value)
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().ref_descriptor_distance(_p(a), _p(b))
+
+
+def three_maxima(counts):
+    counts = np.ascontiguousarray(counts, np.int32)
+    v = [C.c_int() for _ in range(3)]
+    lib().ref_three_maxima(_p(counts), counts.size, *[C.byref(x) for x in v])
+    return tuple(x.value for x in v)
+
+
+def matcher_constants():
+    v = [C.c_int() for _ in range(3)]
+    lib().ref_matcher_constants(*[C.byref(x) for x in v])
+    return dict(TH_LOW=v[0].value, TH_HIGH=v[1].value, HISTO_LENGTH=v[2].value)
+
+
+def _csr(fv):
+    node, off, idx = fv
+    return (np.ascontiguousarray(node, np.uint32), np.ascontiguousarray(off, np.uint32),
+            np.ascontiguousarray(idx, np.uint32))
+
+
+def search_by_bow_kf_f(descKF, validKF, angKF, fvKF, descF, angF, fvF, nnratio, check_ori):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...): (matchF2KF[nF], return value)."""
+    descKF = np.ascontiguousarray(descKF, np.uint8).reshape(-1, 32)
+    descF = np.ascontiguousarray(descF, np.uint8).reshape(-1, 32)
+    validKF = np.ascontiguousarray(validKF, np.uint8)
+    angKF = np.ascontiguousarray(angKF, np.float32)
+    angF = np.ascontiguousarray(angF, np.float32)
+    nk, ok, ik = _csr(fvKF)
+    nf, of, if_ = _csr(fvF)
+    out = np.full(descF.shape[0], -1, np.int32)
+    n = lib().ref_search_by_bow_kf_f(_p(descKF), descKF.shape[0], _p(validKF), _p(angKF), _p(nk), _p(ok), _p(ik),
+                                     nk.size, _p(descF), descF.shape[0], _p(angF), _p(nf), _p(of), _p(if_), nf.size,
+                                     float(nnratio), int(check_ori), _p(out))
+    return out, n
+
+
+def search_by_bow_kf_kf(desc1, valid1, ang1, fv1, desc2, valid2, ang2, fv2, nnratio, check_ori):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...): (match12[n1], return value)."""
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    valid1 = np.ascontiguousarray(valid1, np.uint8)
+    valid2 = np.ascontiguousarray(valid2, np.uint8)
+    ang1 = np.ascontiguousarray(ang1, np.float32)
+    ang2 = np.ascontiguousarray(ang2, np.float32)
+    n1_, o1, i1 = _csr(fv1)
+    n2_, o2, i2 = _csr(fv2)
+    out = np.full(desc1.shape[0], -1, np.int32)
+    n = lib().ref_search_by_bow_kf_kf(_p(desc1), desc1.shape[0], _p(valid1), _p(ang1), _p(n1_), _p(o1), _p(i1),
+                                      n1_.size, _p(desc2), desc2.shape[0], _p(valid2), _p(ang2), _p(n2_), _p(o2),
+                                      _p(i2), n2_.size, float(nnratio), int(check_ori), _p(out))
+    return out, n

@@ -1,0 +1,2 @@
+/* cv stub (oracle/refbuild): everything lives in opencv2/core/core.hpp */
+#include "../core/core.hpp"

@@ -1,0 +1,171 @@
+/*
+ * ref_matcher_api.cpp -- C entry points around the UNMODIFIED reference class ORB_SLAM2::ORBmatcher
+ * (/root/reference/src/ORBmatcher.cc, compiled whole as its own translation unit against ref_mocks.h).
+ * TEST INFRASTRUCTURE, NOT PRODUCT CODE: lives in oracle/_ref/libref_orb.so, used by tests/ to pin the matcher
+ * part of oracle/orb_oracle.c (M0 DescriptorDistance :1968-1984, M1 SearchByBoW(KF,F) :217-363,
+ * M2 SearchByBoW(KF,KF) :665-812, M5 ComputeThreeMaxima :1912-1957).
+ *
+ * This file only builds the mock KeyFrame / Frame / MapPoint objects from flat arrays, calls the reference
+ * members and flattens what they return (MapPoint* -> feature index).
+ */
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ORBmatcher.h" /* the reference's own header; its MapPoint.h / KeyFrame.h / Frame.h are ref_mocks.h */
+
+namespace ORB_SLAM2
+{
+float Frame::mnMinX = 0, Frame::mnMaxX = 640, Frame::mnMinY = 0, Frame::mnMaxY = 480;
+
+/* The projection family (M4) is compiled from the reference but not exercised by oracle/_ref: its grid queries
+ * belong to Frame.cc / KeyFrame.cc, which are outside this library. */
+static void not_wired(const char *what)
+{
+    fprintf(stderr, "oracle/_ref: %s is not wired (M4 family is compiled, not exercised)\n", what);
+    abort();
+}
+vector<size_t> Frame::GetFeaturesInArea(const float &, const float &, const float &, const int, const int) const
+{
+    not_wired("Frame::GetFeaturesInArea");
+    return vector<size_t>();
+}
+std::vector<size_t> KeyFrame::GetFeaturesInArea(const float &, const float &, const float &) const
+{
+    not_wired("KeyFrame::GetFeaturesInArea");
+    return std::vector<size_t>();
+}
+int MapPoint::PredictScale(const float &, KeyFrame *)
+{
+    not_wired("MapPoint::PredictScale");
+    return 0;
+}
+int MapPoint::PredictScale(const float &, Frame *)
+{
+    not_wired("MapPoint::PredictScale");
+    return 0;
+}
+} // namespace ORB_SLAM2
+
+namespace
+{
+using namespace ORB_SLAM2;
+
+struct MatcherTap : public ORBmatcher {
+    MatcherTap(float r, bool o) : ORBmatcher(r, o) {}
+    using ORBmatcher::ComputeThreeMaxima;
+};
+
+void fill_featvec(DBoW2::FeatureVector &fv, const uint32_t *node, const uint32_t *off, const uint32_t *idx, int nnodes)
+{
+    for (int a = 0; a < nnodes; a++)
+        for (uint32_t k = off[a]; k < off[a + 1]; k++) fv.addFeature(node[a], idx[k]);
+}
+void fill_keys(std::vector<cv::KeyPoint> &keys, const float *ang, int n)
+{
+    keys.assign((size_t)n, cv::KeyPoint());
+    for (int i = 0; i < n; i++) keys[(size_t)i].angle = ang ? ang[i] : 0.f;
+}
+/* valid[i]: 0 = no MapPoint (NULL), 1 = good MapPoint, 2 = MapPoint with isBad() */
+void fill_mappoints(std::vector<MapPoint> &pool, std::vector<MapPoint *> &ptr, const uint8_t *valid, int n)
+{
+    pool.assign((size_t)n, MapPoint());
+    ptr.assign((size_t)n, (MapPoint *)0);
+    for (int i = 0; i < n; i++) {
+        const int v = valid ? valid[i] : 1;
+        if (v == 0) continue;
+        pool[(size_t)i].bad = (v == 2);
+        ptr[(size_t)i] = &pool[(size_t)i];
+    }
+}
+} // namespace
+
+extern "C" {
+
+int ref_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    /* 4-byte aligned copies: the reference reads the rows through int32_t pointers (:1970-1971) */
+    int32_t ta[8], tb[8];
+    memcpy(ta, a, 32);
+    memcpy(tb, b, 32);
+    cv::Mat ma(1, 32, CV_8UC1, ta), mb(1, 32, CV_8UC1, tb);
+    return ORBmatcher::DescriptorDistance(ma, mb);
+}
+
+void ref_three_maxima(const int *counts, int L, int *ind1, int *ind2, int *ind3)
+{
+    std::vector<std::vector<int> > histo((size_t)L);
+    for (int i = 0; i < L; i++) histo[(size_t)i].assign((size_t)counts[i], 0);
+    MatcherTap m(0.6f, true);
+    int a = -1, b = -1, c = -1;
+    m.ComputeThreeMaxima(histo.data(), L, a, b, c);
+    *ind1 = a;
+    *ind2 = b;
+    *ind3 = c;
+}
+
+/* M1: SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&).  matchF2KF[iF] = KF feature whose MapPoint was
+ * assigned to F feature iF (-1 = NULL); returns the reference's return value. */
+int ref_search_by_bow_kf_f(const uint8_t *descKF, int nKF, const uint8_t *validKF, const float *angKF,
+                           const uint32_t *nodeKF, const uint32_t *offKF, const uint32_t *idxKF, int nnodesKF,
+                           const uint8_t *descF, int nF, const float *angF, const uint32_t *nodeF,
+                           const uint32_t *offF, const uint32_t *idxF, int nnodesF, float nnratio, int check_ori,
+                           int32_t *matchF2KF)
+{
+    KeyFrame kf;
+    Frame f;
+    std::vector<MapPoint> pool;
+    kf.N = nKF;
+    kf.mDescriptors = cv::Mat(nKF, 32, CV_8UC1, (void *)descKF);
+    fill_keys(kf.mvKeysUn, angKF, nKF);
+    kf.mvKeys = kf.mvKeysUn;
+    fill_mappoints(pool, kf.mvpMapPoints, validKF, nKF);
+    fill_featvec(kf.mFeatVec, nodeKF, offKF, idxKF, nnodesKF);
+    f.N = nF;
+    f.mDescriptors = cv::Mat(nF, 32, CV_8UC1, (void *)descF);
+    fill_keys(f.mvKeys, angF, nF);
+    f.mvKeysUn = f.mvKeys;
+    fill_featvec(f.mFeatVec, nodeF, offF, idxF, nnodesF);
+    ORBmatcher m(nnratio, check_ori != 0);
+    std::vector<MapPoint *> out;
+    const int n = m.SearchByBoW(&kf, f, out);
+    for (int i = 0; i < nF; i++) matchF2KF[i] = out[(size_t)i] ? (int32_t)(out[(size_t)i] - pool.data()) : -1;
+    return n;
+}
+
+/* M2: SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&).  match12[i1] = KF2 feature whose MapPoint was
+ * assigned to KF1 feature i1 (-1 = NULL). */
+int ref_search_by_bow_kf_kf(const uint8_t *desc1, int n1, const uint8_t *valid1, const float *ang1,
+                            const uint32_t *node1, const uint32_t *off1, const uint32_t *idx1, int nnodes1,
+                            const uint8_t *desc2, int n2, const uint8_t *valid2, const float *ang2,
+                            const uint32_t *node2, const uint32_t *off2, const uint32_t *idx2, int nnodes2,
+                            float nnratio, int check_ori, int32_t *match12)
+{
+    KeyFrame k1, k2;
+    std::vector<MapPoint> pool1, pool2;
+    k1.N = n1;
+    k1.mDescriptors = cv::Mat(n1, 32, CV_8UC1, (void *)desc1);
+    fill_keys(k1.mvKeysUn, ang1, n1);
+    fill_mappoints(pool1, k1.mvpMapPoints, valid1, n1);
+    fill_featvec(k1.mFeatVec, node1, off1, idx1, nnodes1);
+    k2.N = n2;
+    k2.mDescriptors = cv::Mat(n2, 32, CV_8UC1, (void *)desc2);
+    fill_keys(k2.mvKeysUn, ang2, n2);
+    fill_mappoints(pool2, k2.mvpMapPoints, valid2, n2);
+    fill_featvec(k2.mFeatVec, node2, off2, idx2, nnodes2);
+    ORBmatcher m(nnratio, check_ori != 0);
+    std::vector<MapPoint *> out;
+    const int n = m.SearchByBoW(&k1, &k2, out);
+    for (int i = 0; i < n1; i++) match12[i] = out[(size_t)i] ? (int32_t)(out[(size_t)i] - pool2.data()) : -1;
+    return n;
+}
+
+void ref_matcher_constants(int *th_low, int *th_high, int *histo_length)
+{
+    *th_low = ORBmatcher::TH_LOW;
+    *th_high = ORBmatcher::TH_HIGH;
+    *histo_length = ORBmatcher::HISTO_LENGTH;
+}
+}

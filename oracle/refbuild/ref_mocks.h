@@ -1,0 +1,141 @@
+/*
+ * ref_mocks.h -- mock MapPoint / KeyFrame / Frame for compiling the UNMODIFIED /root/reference/src/ORBmatcher.cc
+ * (TEST INFRASTRUCTURE for oracle/_ref, NOT PRODUCT CODE).
+ *
+ * The reference's own MapPoint.h / KeyFrame.h / Frame.h pull in Map, KeyFrameDatabase, ORBVocabulary (DBoW2
+ * templates), g2o and Eigen, none of which exist here.  This header is force-included (-include) with the
+ * reference's include guards pre-defined (-DMAPPOINT_H -DKEYFRAME_H -DFRAME_H), so `#include "MapPoint.h"` etc.
+ * in include/ORBmatcher.h become empty and the matcher sees these plain data holders instead.  They declare the
+ * members ORBmatcher.cc touches, with the reference's names, types and signatures (include/Frame.h:63-190,
+ * include/KeyFrame.h:43-197, include/MapPoint.h:46-108); no behaviour of the matcher is restated here.
+ */
+#ifndef ORBFE_REF_MOCKS_H
+#define ORBFE_REF_MOCKS_H
+
+#include <map>
+#include <set>
+#include <vector>
+
+#include <opencv2/core/core.hpp>
+
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+
+#define FRAME_GRID_ROWS 48
+#define FRAME_GRID_COLS 64
+
+using std::pair; /* include/ORBmatcher.h:82 writes std::vector<pair<size_t,size_t> > without std:: */
+using std::vector;
+
+namespace ORB_SLAM2
+{
+class KeyFrame;
+class Frame;
+
+class MapPoint
+{
+  public:
+    MapPoint()
+        : mTrackProjX(0), mTrackProjY(0), mTrackProjXR(0), mbTrackInView(false), mnTrackScaleLevel(0),
+          mTrackViewCos(0), mnLastFrameSeen(0), mnFuseCandidateForKF(0), bad(false), nobs(0), min_dist(0),
+          max_dist(1e9f), replaced(0)
+    {
+    }
+    cv::Mat GetWorldPos() { return world_pos.clone(); }
+    cv::Mat GetNormal() { return normal.clone(); }
+    int Observations() { return nobs; }
+    void AddObservation(KeyFrame *pKF, size_t idx)
+    {
+        if (!observations.count(pKF)) nobs++;
+        observations[pKF] = idx;
+    }
+    int GetIndexInKeyFrame(KeyFrame *pKF) { return observations.count(pKF) ? (int)observations[pKF] : -1; }
+    bool IsInKeyFrame(KeyFrame *pKF) { return observations.count(pKF) != 0; }
+    bool isBad() { return bad; }
+    void Replace(MapPoint *pMP) { replaced = pMP; bad = true; }
+    cv::Mat GetDescriptor() { return descriptor.clone(); }
+    float GetMinDistanceInvariance() { return 0.8f * min_dist; }
+    float GetMaxDistanceInvariance() { return 1.2f * max_dist; }
+    int PredictScale(const float &currentDist, KeyFrame *pKF);
+    int PredictScale(const float &currentDist, Frame *pF);
+
+    float mTrackProjX, mTrackProjY, mTrackProjXR;
+    bool mbTrackInView;
+    int mnTrackScaleLevel;
+    float mTrackViewCos;
+    long unsigned int mnLastFrameSeen;
+    long unsigned int mnFuseCandidateForKF;
+
+    /* mock state */
+    bool bad;
+    int nobs;
+    float min_dist, max_dist;
+    MapPoint *replaced;
+    cv::Mat world_pos, normal, descriptor;
+    std::map<KeyFrame *, size_t> observations;
+};
+
+class Frame
+{
+  public:
+    Frame() : fx(1), fy(1), cx(0), cy(0), mbf(0), mb(0), N(0), mnScaleLevels(8), mfLogScaleFactor(0.18232156f) {}
+    vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1,
+                                     const int maxLevel = -1) const;
+    float fx, fy, cx, cy;
+    float mbf, mb;
+    int N;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    std::vector<float> mvuRight, mvDepth;
+    DBoW2::FeatureVector mFeatVec;
+    cv::Mat mDescriptors;
+    std::vector<MapPoint *> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    cv::Mat mTcw;
+    int mnScaleLevels;
+    float mfLogScaleFactor;
+    vector<float> mvScaleFactors, mvInvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY;
+};
+
+class KeyFrame
+{
+  public:
+    KeyFrame()
+        : fx(1), fy(1), cx(0), cy(0), mbf(0), mb(0), N(0), mnScaleLevels(8), mfLogScaleFactor(0.18232156f), mnMinX(0),
+          mnMinY(0), mnMaxX(640), mnMaxY(480), mnId(0)
+    {
+    }
+    cv::Mat GetCameraCenter() { return Ow.clone(); }
+    cv::Mat GetRotation() { return Rcw.clone(); }
+    cv::Mat GetTranslation() { return tcw.clone(); }
+    void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
+    std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
+    MapPoint *GetMapPoint(const size_t &idx) { return mvpMapPoints[idx]; }
+    std::set<MapPoint *> GetMapPoints()
+    {
+        std::set<MapPoint *> s;
+        for (size_t i = 0; i < mvpMapPoints.size(); i++)
+            if (mvpMapPoints[i] && !mvpMapPoints[i]->isBad()) s.insert(mvpMapPoints[i]);
+        return s;
+    }
+    std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r) const;
+    bool IsInImage(const float &x, const float &y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }
+
+    float fx, fy, cx, cy, mbf, mb;
+    int N;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    std::vector<float> mvuRight, mvDepth;
+    cv::Mat mDescriptors;
+    DBoW2::FeatureVector mFeatVec;
+    int mnScaleLevels;
+    float mfLogScaleFactor;
+    std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
+    int mnMinX, mnMinY, mnMaxX, mnMaxY;
+    long unsigned int mnId;
+
+    /* mock state */
+    std::vector<MapPoint *> mvpMapPoints;
+    cv::Mat Ow, Rcw, tcw;
+};
+
+} // namespace ORB_SLAM2
+#endif

@@ -89,6 +89,24 @@ def test_search_by_bow_parity(oracle, seed, strict, with_valid_f, nK, nF, nn):
         assert np.array_equal(got[0], ref[0]) and got[1] == ref[1]
 
 
+def test_search_by_bow_reference_golden():
+    """HIP SearchByBoW x2 against vectors produced by the reference's own compiled ORBmatcher
+    (tests/golden/make_golden.py, oracle/_ref): M1 :217-363 and M2 :665-812."""
+    import os
+    from orb_slam2_ssd_semantic_amd import ORBmatcher
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "orb_golden.npz"))
+    k0, d0, k1, d1 = g["A_dense_s0/kps"], g["A_dense_s0/desc"], g["bow/k1"], g["bow/d1"]
+    fv0 = tuple(g[f"bow/fv0_{k}"] for k in ("node", "off", "idx"))
+    fv1 = tuple(g[f"bow/fv1_{k}"] for k in ("node", "off", "idx"))
+    v0, v1 = g["bow/valid0"], g["bow/valid1"]
+    m, n = ORBmatcher(0.7, True).SearchByBoW(d0, v0, k0["angle"], fv0, d1, None, k1["angle"], fv1)
+    assert n == int(g["bow_kf_f/n"]) and np.array_equal(m, g["bow_kf_f/match"])
+    m21, n = ORBmatcher(0.75, True).SearchByBoW(d0, v0, k0["angle"], fv0, d1, v1, k1["angle"], fv1)
+    m12 = np.full(len(d0), -1, np.int32)
+    m12[m21[m21 >= 0]] = np.flatnonzero(m21 >= 0)
+    assert n == int(g["bow_kf_kf/n"]) and np.array_equal(m12, g["bow_kf_kf/match12"])
+
+
 def test_search_by_bow_rejects_bad_csr(mt):
     from orb_slam2_ssd_semantic_amd import OrbfeError, _ffi
     d = np.zeros((4, 32), np.uint8)
