@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- ORB extract + match frames/sec on 640x480 TUM-shaped frames (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one HBM-resident batch of synthetic frames on every rank:
-    orbfe_extract_batch_device  (pyramid -> FAST -> quadtree -> blur -> IC-angle + rBRIEF)
-    orbfe_match_bf_frames_device (every frame against its predecessor in the batch; config 3 parameters
+One "step" = one pass of the hot path over one HBM-resident batch of synthetic frames on every rank, issued as
+`--launches` back-to-back sub-batches of `--frames` frames:
+    orbfe_extract_batch_device   (pyramid -> FAST -> quadtree -> blur -> IC-angle + rBRIEF)
+    orbfe_match_bf_frames_device (every frame against its predecessor in the sub-batch; config 3 parameters
                                   nnratio 0.9, TH_HIGH 100, rotation histogram on)
-    [N > 1] one all-gather (RCCL over xGMI) of counts + keypoints + descriptors (config 4's exchange step)
-Frames are independent, so ranks shard by construction (weak scaling: every rank owns --frames frames);
-there is no collective on the data path itself.
+    [N > 1] one asynchronous all-gather (RCCL over xGMI) of counts + keypoints + descriptors of the whole step
+Frames are independent, so ranks shard by construction (weak scaling: every rank owns its own batch); there is no
+collective on the data path itself.
 
-    python bench.py --gpus 1 --steps K --warmup W
+`value` is the HBM-resident rate (inputs in HBM when the timed region starts).  The same JSON line also carries
+  pcie_inclusive        the contract's config 3 as SURVEY 8(d) words it: pinned host frames -> H2D -> kernels -> D2H of
+                        counts / keypoints / descriptors / matches, double-buffered on three streams (never `value`)
+  workloads             S(seed) (corner-saturated) and S_tum(seed) (camera-like corner statistics), both FAST variants
+  config4               the batched-keyframe configuration: 2000 features, a 1024-frame batch sharded over the ranks,
+                        all-gather bytes and bus bandwidth, strong and weak figures
+  roofline / cpu_baseline / cpu_baseline_all_cores
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1 re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  The CPU oracle is used only for the `cpu_baseline` leg (rank 0, N = 1).
+Rank 0 prints ONE JSON line.  oracle/ is used only for the cpu_baseline legs (rank 0, N = 1).
+`--fake` replaces the extractor by a CPU stand-in over gloo: it exists so that tests/ can drive the spawn /
+rendezvous / gather / reporting path on a box without GPUs; its line is marked "fake": true.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,11 +41,15 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from orb_slam2_ssd_semantic_amd.distributed import OverlappedKeyframeGather  # noqa: E402
-from orb_slam2_ssd_semantic_amd import ORBextractor, ORBmatcher, _ffi  # noqa: E402
-from orb_slam2_ssd_semantic_amd.synth import synth_frame  # noqa: E402
+from orb_slam2_ssd_semantic_amd.distributed import OverlappedKeyframeGather, all_gather_keyframes, shard_range  # noqa: E402
+from orb_slam2_ssd_semantic_amd.synth import synth_frame, synth_tum_like  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# VALU model of k_fast_map (tools/valu_count.py on the shipped kernel: VALU instructions of one row step of one wave;
+# tools/ubench/valu_rate.hip: one wave64 VALU instruction of this min/max/perm/packed-16 mix issues every ~4.2 clk per
+# SIMD).  256 CUs x 4 SIMDs; the clock is read from the device.
+VALU_MODEL = {"k_fast_map": {"valu_per_row_step": 286.0, "issue_clk": 4.2}}
+N_SIMD = 1024
 
 
 def level_sizes(w, h, nlevels=8, sf=1.2):
@@ -58,28 +75,49 @@ def algorithmic_bytes(w, h, nfeat, ncand):
     }
 
 
-def make_frames(nframes, w, h, seed0):
-    """Distinct synthetic frames S(seed).  A base set comes from the canonical generator; the rest
-    are derived by cheap lossless transforms (roll + flip) so that every frame is a different image."""
-    nbase = min(nframes, 32)
-    base = [synth_frame(seed0 + i, h, w) for i in range(nbase)]
-    out = np.empty((nframes, h, w), np.uint8)
-    for i in range(nframes):
-        b = base[i % nbase]
-        k = i // nbase
+def expand_frames(base, total):
+    """`total` distinct frames from a base set [nb, h, w] by lossless transforms (roll + flip), on whatever device
+    `base` lives on.  Every frame is a different image with the statistics of its generator."""
+    nb, h, w = base.shape
+    out = torch.empty((total, h, w), dtype=torch.uint8, device=base.device)
+    k = 0
+    while k * nb < total:
+        blk = base
         if k:
-            b = np.roll(b, (37 * k) % h, axis=0)
-            b = np.roll(b, (101 * k) % w, axis=1)
+            blk = torch.roll(blk, shifts=((37 * k) % h, (101 * k) % w), dims=(1, 2))
             if k & 1:
-                b = b[:, ::-1]
-        out[i] = b
+                blk = blk.flip(2)
+        n = min(nb, total - k * nb)
+        out[k * nb:k * nb + n] = blk[:n]
+        k += 1
     return out
 
 
-def cpu_baseline(w, h, nfeat, budget_s=12.0, max_frames=200):
-    """Oracle restatement ('port') of ORBextractor::operator() + BF match, 1 thread, bounded sample."""
+def base_frames(gen, n, w, h, seed0):
+    make = synth_frame if gen == "S" else synth_tum_like
+    return np.stack([make(seed0 + i, h, w) for i in range(n)])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only).  oracle/ is test infrastructure: it is timed here, never used by the product.
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_baseline(w, h, nfeat, budget_s=10.0, max_frames=200):
+    """ORBextractor::operator() + BF match to the previous frame, 1 thread, bounded sample.  kind "reference": the
+    extractor is oracle/_ref/libref_orb.so = the UNMODIFIED reference src/ORBextractor.cc compiled against a cv stub
+    whose five OpenCV primitives are scalar C restatements (so slower than a real OpenCV build); the brute-force match
+    (not a reference function) is the oracle's.  Falls back to kind "port" (oracle/orb_oracle.c) without the library."""
     from oracle import oracle_ffi as O
-    e = O.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+    kind, e = "port", None
+    try:
+        from oracle import ref_ffi as R
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_orb.so")):
+            R.configure(bump=True, canonical_trig=True, blur_mode=0)
+            e = R.RefExtractor(nfeat, 1.2, 8, 20, 7)
+            kind = "reference"
+    except Exception:
+        e = None
+    if e is None:
+        e = O.OracleExtractor(nfeat, 1.2, 8, 20, 7)
     frames = [synth_frame(10000 + i, h, w) for i in range(8)]
     prev = None
     e(frames[0])  # warm-up
@@ -92,10 +130,109 @@ def cpu_baseline(w, h, nfeat, budget_s=12.0, max_frames=200):
         prev = (k, d)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} synthetic {w}x{h} frames, {nfeat} features, extract + BF match to previous frame, "
-                      f"oracle/orb_oracle.c single thread ({dt:.1f} s)",
+    what = ("oracle/_ref (unmodified reference ORBextractor.cc, cv stub with scalar OpenCV primitives) + oracle BF match"
+            if kind == "reference" else "oracle/orb_oracle.c")
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": f"{n} synthetic {w}x{h} frames S(seed), {nfeat} features, extract + BF match to previous frame, "
+                      f"{what}, single thread ({dt:.1f} s)",
             "host_cpus": os.cpu_count()}
+
+
+def cpu_baseline_all_cores(w, h, nfeat, duration_s=6.0, max_procs=64):
+    """One frame stream per core (the reference extractor is serial per call): independent worker processes
+    (oracle/cpu_worker.py, oracle restatement = kind "port"), all started on a common wall-clock tick."""
+    procs = min(os.cpu_count() or 1, max_procs)
+    t_go = time.time() + 8.0
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), str(w), str(h), str(nfeat), repr(t_go),
+           repr(duration_s)]
+    ps = [subprocess.Popen(cmd + [str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
+    frames = 0
+    for p in ps:
+        out, _ = p.communicate(timeout=duration_s + 120)
+        try:
+            frames += int(out.strip().split()[-1])
+        except Exception:
+            pass
+    return {"value": round(frames / duration_s, 2), "unit": "frames/s", "cores": procs, "kind": "port",
+            "sample": f"{procs} processes x {duration_s:.0f} s, each its own stream of 640x480 S(seed) frames, extract + BF "
+                      f"match to previous frame, oracle/orb_oracle.c", "host_cpus": os.cpu_count()}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the engines: HIP (the product) and the CPU stand-in used by the spawn-path test
+# ----------------------------------------------------------------------------------------------------------------
+class HipEngine:
+    """Owns the extractor / matcher handles, the output sets and the launch sequence of one step."""
+
+    def __init__(self, args, local_rank, nfeatures, frames_per_launch, launches, world):
+        from orb_slam2_ssd_semantic_amd import ORBextractor, ORBmatcher, _ffi
+        self.ffi = _ffi
+        self.L = _ffi.lib()
+        self.w, self.h, self.F, self.nl = args.width, args.height, frames_per_launch, launches
+        self.match = not args.no_match
+        self.ext = ORBextractor(nfeatures, 1.2, 8, 20, 7, max_width=self.w, max_height=self.h, max_batch=self.F,
+                                device=local_rank)
+        self.mat = ORBmatcher(0.9, True, device=local_rank)
+        self.cap = self.ext.capacity()
+        B = self.F * self.nl
+        self.B = B
+        nsets = 2 if world > 1 else 1   # with N > 1 the gather of step k overlaps the kernels of step k+1
+        self.outs = [(torch.zeros((B, self.cap, 7), dtype=torch.int32, device="cuda"),
+                      torch.zeros((B, self.cap, 32), dtype=torch.uint8, device="cuda"),
+                      torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(nsets)]
+        self.qf = torch.arange(0, self.F, dtype=torch.int32, device="cuda")
+        self.tf = (torch.arange(0, self.F, dtype=torch.int32, device="cuda") + (self.F - 1)) % self.F  # predecessor
+        self.d_match = torch.zeros((B, self.cap), dtype=torch.int32, device="cuda")
+        self.d_nm = torch.zeros(B, dtype=torch.int32, device="cuda")
+
+    def launch(self, d_gray, j, out_set, stream):
+        """sub-batch j of the resident batch d_gray [B, h, w] -> slices j of the output set"""
+        kps, desc, n = self.outs[out_set]
+        F, w, h = self.F, self.w, self.h
+        lo = j * F
+        self.ext.extract_batch_device(d_gray[lo].data_ptr(), F, w, h, w, w * h, kps[lo].data_ptr(), desc[lo].data_ptr(),
+                                      self.cap, n[lo:].data_ptr(), stream)
+        if self.match:
+            rc = self.L.orbfe_match_bf_frames_device(self.mat.handle, kps[lo].data_ptr(), desc[lo].data_ptr(),
+                                                     n[lo:].data_ptr(), self.cap, self.qf.data_ptr(), self.tf.data_ptr(), F,
+                                                     0.9, 100, 1, self.d_match[lo].data_ptr(), self.d_nm[lo:].data_ptr(), stream)
+            self.ffi.check(rc, "orbfe_match_bf_frames_device")
+
+
+class FakeEngine:
+    """CPU stand-in with the same launch interface: fills the padded outputs with deterministic numbers.  No kernels,
+    no oracle -- it only lets the distributed plumbing of this file run where there is no GPU."""
+
+    def __init__(self, args, local_rank, nfeatures, frames_per_launch, launches, world):
+        self.w, self.h, self.F, self.nl = args.width, args.height, frames_per_launch, launches
+        self.cap = 64
+        self.B = self.F * self.nl
+        nsets = 2 if world > 1 else 1
+        self.outs = [(torch.zeros((self.B, self.cap, 7), dtype=torch.int32), torch.zeros((self.B, self.cap, 32), dtype=torch.uint8),
+                      torch.zeros(self.B, dtype=torch.int32)) for _ in range(nsets)]
+
+    def launch(self, d_gray, j, out_set, stream):
+        kps, desc, n = self.outs[out_set]
+        lo = j * self.F
+        s = d_gray[lo:lo + self.F].reshape(self.F, -1)[:, :self.cap].to(torch.int32)
+        n[lo:lo + self.F] = 1 + (s[:, 0] % (self.cap - 1))
+        kps[lo:lo + self.F, :, 0] = s
+        desc[lo:lo + self.F, :, 0] = s.to(torch.uint8)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def respawn(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -103,205 +240,424 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per step per GPU (HBM-resident batch)")
+    ap.add_argument("--frames", type=int, default=1024, help="frames per launch (sub-batch) per GPU")
+    ap.add_argument("--launches", type=int, default=24, help="sub-batches per step: a step covers frames x launches "
+                    "resident frames per GPU (default 24 576: twenty steps are > 2 s of GPU work)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--workload", choices=["S", "S_tum"], default="S", help="generator of the frames `value` is timed on")
+    ap.add_argument("--fast-mode", type=int, default=0, help="FAST variant of the timed region (0 dense, 1 sparse shortcuts)")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
-    ap.add_argument("--no-cpu-baseline", action="store_true",
-                    help="skip the CPU-oracle baseline and the single-frame latency probe (used for rocprof runs)")
-    ap.add_argument("--include-h2d", action="store_true", help="also report the PCIe-inclusive rate (not `value`)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the latency probe")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (rocprof runs): no PCIe leg, no "
+                    "S_tum leg, no config 4, no CPU baselines")
+    ap.add_argument("--fake", action="store_true", help="CPU stand-in over gloo (spawn-path test only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(respawn(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        print(f"WORLD_SIZE={world} does not match --gpus {args.gpus}", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+        print(f"bench.py: WORLD_SIZE={world} does not match --gpus {args.gpus}: refusing to report a line for the "
+              f"wrong number of GPUs", file=sys.stderr)
+        sys.exit(2)
+    fake = args.fake
+    if not fake:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if fake:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = "cpu" if fake else "cuda"
 
-    w, h, B, nf = args.width, args.height, args.frames, args.nfeatures
-    ext = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, device=local_rank)
-    mat = ORBmatcher(0.9, True, device=local_rank)
-    cap = ext.capacity()
-    L = _ffi.lib()
+    def fence():
+        if not fake:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        if not fake:
+            torch.cuda.synchronize()
 
-    frames = make_frames(B, w, h, 10000 + rank * B)
-    d_gray = torch.from_numpy(frames).cuda()
-    # two output sets: with N > 1 the all-gather of step k overlaps the kernels of step k+1, so the set being gathered
-    # must not be overwritten (N = 1 just alternates)
-    outs = [(torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda"),
-             torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
-             torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(2)]
-    d_kps, d_desc, d_n = outs[0]
-    qf = torch.arange(0, B, dtype=torch.int32, device="cuda")
-    tf = (torch.arange(0, B, dtype=torch.int32, device="cuda") + (B - 1)) % B  # predecessor (wraps at frame 0)
-    d_match = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
-    d_nm = torch.zeros(B, dtype=torch.int32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    w, h, F, NL, nf = args.width, args.height, args.frames, args.launches, args.nfeatures
+    B = F * NL
+    Engine = FakeEngine if fake else HipEngine
+    eng = Engine(args, local_rank, nf, F, NL, world)
+    if not fake:
+        eng.ext.set_fast_mode(args.fast_mode)
+    nbase = min(B, 32)
+    base = torch.from_numpy(base_frames(args.workload, nbase, w, h, 10000 + rank * 1000)).to(dev)
+    d_gray = expand_frames(base, B)
+    stream = None if fake else torch.cuda.current_stream().cuda_stream
     # (n, kps, desc) order of distributed.all_gather_keyframes
-    gather = OverlappedKeyframeGather([(o[2], o[0], o[1]) for o in outs]) if world > 1 else None
+    gather = OverlappedKeyframeGather([(o[2], o[0], o[1]) for o in eng.outs]) if world > 1 else None
     counter = [0]
 
     def step():
-        k = counter[0] & 1
+        k = counter[0] % len(eng.outs)
         counter[0] += 1
-        kps, desc, n = outs[k]
         if gather:
-            gather.acquire(k)  # set k is free again once its previous gather (two steps ago) has read it (stream-level wait)
-        ext.extract_batch_device(d_gray.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap,
-                                 n.data_ptr(), stream)
-        if not args.no_match:
-            rc = L.orbfe_match_bf_frames_device(mat.handle, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), cap,
-                                                qf.data_ptr(), tf.data_ptr(), B, 0.9, 100, 1, d_match.data_ptr(),
-                                                d_nm.data_ptr(), stream)
-            _ffi.check(rc, "orbfe_match_bf_frames_device")
-        if world > 1:
-            # the one exchange step of the batched keyframe mode (distributed.all_gather_keyframes, asynchronous here):
-            # RCCL runs on its own stream after the kernels above and overlaps the next step's kernels
+            gather.acquire(k)  # set k is free once its previous gather (two steps ago) has read it (stream-level wait)
+        for j in range(NL):
+            eng.launch(d_gray, j, k, stream)
+        if gather:
+            # the one exchange step of the batched keyframe mode, asynchronous: RCCL runs on its own stream after the
+            # kernels above and overlaps the next step's kernels
             gather.launch(k)
-        return None
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
-    ext.set_profiling(True)  # HIP events on the launch stream around every stage of every timed call
-    m0 = torch.cuda.Event(enable_timing=True)
-    m1 = torch.cuda.Event(enable_timing=True)
-    match_ms = 0.0
+    if not fake:
+        eng.ext.set_profiling(True)  # HIP events on the launch stream around every stage of the timed calls
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if gather:  # retire the work handles of the last two gathers (already complete: fence() synchronised the device)
-        gather.acquire(0)
-        gather.acquire(1)
-    stage = ext.stage_ms()
-    ext.set_profiling(False)
+    if gather:  # retire the work handles of the last gathers (already complete: fence() synchronised the device)
+        for k in range(len(eng.outs)):
+            gather.acquire(k)
+    stage = None
+    if not fake:
+        stage = eng.ext.stage_ms()
+        eng.ext.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # matcher kernel time (same stream as torch's current stream, so torch events bracket it correctly)
-    if not args.no_match:
-        torch.cuda.synchronize()
-        m0.record()
-        for _ in range(5):
-            L.orbfe_match_bf_frames_device(mat.handle, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
-                                           qf.data_ptr(), tf.data_ptr(), B, 0.9, 100, 1, d_match.data_ptr(),
-                                           d_nm.data_ptr(), stream)
-        m1.record()
-        torch.cuda.synchronize()
-        match_ms = m0.elapsed_time(m1) / 5
-
-    n_host = d_n.cpu().numpy()
-    ncand = 0
-    if rank == 0:
-        ncand = int(sum(len(ext.candidates(l, frame=0)) for l in range(8)))
-
     total_frames = B * world * args.steps
     value = total_frames / elapsed
+
     result = None
     if rank == 0:
-        ab = algorithmic_bytes(w, h, float(n_host.mean()), ncand)
-        stage_k = {k: stage[k] for k in ("pyramid", "fast", "octree", "blur", "describe")}
-        dom = max(stage_k, key=stage_k.get)
-        # the pass the north star prices against the HBM roofline is pyramid + FAST; the dominant stage is
-        # reported as `roofline`, the per-stage table and the pyramid/FAST pass ride along in `stages`.
-        def gbs(name):
-            return ab[name] * B / (stage_k[name] * 1e-3) / 1e9 if stage_k[name] > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": {"pyramid": "k_pyr_resize (7 launches)", "fast": "k_fast_map",
-                                           "octree": "k_octree", "blur": "k_blur7 (8 launches)",
-                                           "describe": "k_orient_describe"}[dom],
-                "achieved": round(gbs(dom), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs(dom) / HBM_PEAK_GBS, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": int(ab[dom] * B), "launch_ms": round(stage_k[dom], 4)}
-        pf_ms = stage_k["pyramid"] + stage_k["fast"]
-        pf_gbs = (ab["pyramid"] + ab["fast"]) * B / (pf_ms * 1e-3) / 1e9
-        stages = {k: {"ms": round(v, 4), "GBps": round(gbs(k), 2), "frac": round(gbs(k) / HBM_PEAK_GBS, 5)}
-                  for k, v in stage_k.items()}
-        stages["pyramid+fast"] = {"ms": round(pf_ms, 4), "GBps": round(pf_gbs, 2), "frac": round(pf_gbs / HBM_PEAK_GBS, 5)}
-        stages["extract_total_ms"] = round(stage["total"], 4)
-        stages["match_ms"] = round(match_ms, 4)
-        if match_ms > 0:
-            nn = n_host.astype(np.float64)
-            evals = float((nn * np.roll(nn, 1)).sum())
-            stages["match_Gdist_per_s"] = round(evals / (match_ms * 1e-3) / 1e9, 2)
         result = {
             "metric": "ORB extract+match frames/sec on 640x480 TUM RGB-D; bit-exact kp/desc",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("BASELINE config 3 shape: %dx%d synthetic TUM-shaped frames S(seed), %d features, "
-                                    "8 levels, %s, HBM-resident batch of %d frames per GPU%s") %
-                                   (w, h, nf, "extract only" if args.no_match else
+            "config": {"workload": ("BASELINE config 3 shape, HBM-RESIDENT inputs (the PCIe-inclusive rate of the same pipeline "
+                                    "is `pcie_inclusive`): %dx%d synthetic frames %s(seed) (no TUM data on the box), %d "
+                                    "features, 8 levels, %s; %d frames per GPU per step in %d launches of %d%s; exactness is "
+                                    "checked against the in-repo oracle, which is pinned to the compiled reference "
+                                    "(tests/test_ref_pin.py)") %
+                                   (w, h, args.workload, nf, "extract only" if args.no_match else
                                     "extract + brute-force Hamming match to previous frame (nnratio 0.9, TH_HIGH 100, rot. hist.)",
-                                    B, ", all-gather of counts/keypoints/descriptors" if world > 1 else ""),
-                       "frames_per_gpu_per_step": B, "width": w, "height": h, "nfeatures": nf,
-                       "parallelism": f"frames sharded over {world} GPU(s), one process per GPU",
-                       "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
-                       "fast_candidates_frame0": ncand},
-            "roofline": roof, "stages": stages,
+                                    B, NL, F, ", asynchronous all-gather of counts/keypoints/descriptors per step" if world > 1 else ""),
+                       "frames_per_gpu_per_step": B, "frames_per_launch": F, "width": w, "height": h, "nfeatures": nf,
+                       "parallelism": f"frames sharded over {world} GPU(s), one process per GPU"},
         }
-        if args.include_h2d:
-            pin = torch.from_numpy(frames).pin_memory()
-            hk = torch.empty((B, cap, 7), dtype=torch.int32).pin_memory()
-            hd = torch.empty((B, cap, 32), dtype=torch.uint8).pin_memory()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                d_gray.copy_(pin, non_blocking=True)
-                step()
-                hk.copy_(d_kps, non_blocking=True)
-                hd.copy_(d_desc, non_blocking=True)
-            torch.cuda.synchronize()
-            result["pcie_inclusive_frames_per_s"] = round(3 * B / (time.perf_counter() - t1), 2)
-        if world == 1 and not args.no_cpu_baseline:
-            # online (single-frame, host buffers in / out) latency of ORBextractor::operator(): replicas-only path
-            e1 = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1, device=local_rank)
-            img = np.ascontiguousarray(frames[0])
-            for _ in range(5):
-                e1(img)
-            lat = []
-            for _ in range(50):
-                t2 = time.perf_counter()
-                e1(img)
-                lat.append(time.perf_counter() - t2)
-            result["single_frame_host_latency_ms"] = round(float(np.median(lat)) * 1e3, 4)
-            pm = os.path.join(ROOT, "profiles", "r01_v8_pmc_hbm.json")
-            if os.path.exists(pm):  # HBM bytes of the dominant kernel from the committed rocprofv3 --pmc passes
-                try:
-                    pj = json.load(open(pm))
-                    kn = roof["kernel"].split(" ")[0]
-                    # gfx950: FETCH_SIZE reports half of the read bytes (calibrated on this repo's access shapes,
-                    # profiles/r01_fetch_calibration.txt), WRITE_SIZE is exact
-                    tb = (2 * pj["FETCH_SIZE_KB"][kn]["mean_per_launch"] + pj["WRITE_SIZE_KB"][kn]["mean_per_launch"]) * 1024
-                    roof["traffic"] = int(tb)
-                    roof["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_v8_pmc_hbm.json "
-                                            "(separate --pmc passes; x2 read correction per profiles/r01_fetch_calibration.txt)")
-                except Exception:
-                    pass
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(w, h, nf)
-            result["cpu_baseline"] = cb
-            result["speedup_vs_cpu_1thread"] = round(value / cb["value"], 1)
+        if fake:
+            result["fake"] = True
+            result["config"]["workload"] = "FAKE CPU stand-in (spawn-path test), not a measurement"
+            result["gathered_frames"] = int(gather.result(0)[0].shape[0]) if gather else B
+
+    if not fake:
+        extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fence)
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fence):
+    """Everything besides the timed region: stage table + roofline, PCIe-inclusive leg, S_tum leg, config 4, CPU legs."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    w, h, F, NL, nf = args.width, args.height, args.frames, args.launches, args.nfeatures
+    stream = torch.cuda.current_stream().cuda_stream
+    ext = eng.ext
+    n_host = eng.outs[0][2].cpu().numpy()
+
+    # matcher kernel time (torch's current stream = the launch stream, so torch events bracket it correctly)
+    match_ms = 0.0
+    if eng.match:
+        kps, desc, n = eng.outs[0]
+        m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        m0.record()
+        for _ in range(5):
+            eng.L.orbfe_match_bf_frames_device(eng.mat.handle, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), eng.cap,
+                                               eng.qf.data_ptr(), eng.tf.data_ptr(), F, 0.9, 100, 1, eng.d_match.data_ptr(),
+                                               eng.d_nm.data_ptr(), stream)
+        m1.record()
+        torch.cuda.synchronize()
+        match_ms = m0.elapsed_time(m1) / 5
+
+    if rank == 0:
+        # one more launch so the taps (candidate lists) belong to frame 0 of sub-batch 0
+        eng.launch(d_gray, 0, 0, stream)
+        torch.cuda.synchronize()
+        ncand = int(sum(len(ext.candidates(l, frame=0)) for l in range(8)))
+        assert ext.overflow() == 0, "device-side capacity overflow during the timed region"
+        ab = algorithmic_bytes(w, h, float(n_host.mean()), ncand)
+        stage_k = {k: stage[k] for k in ("pyramid", "fast", "octree", "blur", "describe")}
+        dom = max(stage_k, key=stage_k.get)
+
+        def gbs(name):
+            return ab[name] * F / (stage_k[name] * 1e-3) / 1e9 if stage_k[name] > 0 else 0.0
+        kname = {"pyramid": "k_pyr_resize (7 launches)", "fast": "k_fast_map", "octree": "k_octree",
+                 "blur": "k_blur7", "describe": "k_orient_describe"}
+        roof = {"bound": "hbm", "kernel": kname[dom], "achieved": round(gbs(dom), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs(dom) / HBM_PEAK_GBS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": int(ab[dom] * F), "launch_ms": round(stage_k[dom], 4),
+                "frames_per_launch": F}
+        # the FAST pass is bound by VALU issue, not by HBM: print that ceiling next to the HBM one
+        wc = ext.work_counts()
+        clk = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3 if hasattr(
+            torch.cuda.get_device_properties(local_rank), "clock_rate") else 2.4e9
+        vm = VALU_MODEL["k_fast_map"]
+        valu_min_ms = wc["fast_row_steps_per_frame"] * F * vm["valu_per_row_step"] * vm["issue_clk"] / (N_SIMD * clk) * 1e3
+        roof["valu_ceiling"] = {"kernel": "k_fast_map", "min_ms": round(valu_min_ms, 4), "measured_ms": round(stage_k["fast"], 4),
+                                "frac": round(valu_min_ms / stage_k["fast"], 4) if stage_k["fast"] > 0 else None,
+                                "model": "wave row steps/frame %d x %d frames x %.0f VALU instr x %.1f clk / (%d SIMDs x %.2f GHz)" %
+                                         (wc["fast_row_steps_per_frame"], F, vm["valu_per_row_step"], vm["issue_clk"], N_SIMD, clk / 1e9)}
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if name.endswith("_pmc_hbm.json") and name.startswith("r02"):
+                try:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    kn = roof["kernel"].split(" ")[0]
+                    # gfx950: FETCH_SIZE reports half of the read bytes (calibrated on this repo's access shapes,
+                    # profiles/r01_fetch_calibration.txt), WRITE_SIZE is exact
+                    tb = (2 * pj["FETCH_SIZE_KB"][kn]["mean_per_launch"] + pj["WRITE_SIZE_KB"][kn]["mean_per_launch"]) * 1024
+                    roof["traffic"] = int(tb * F / pj.get("frames_per_launch", F))
+                    roof["traffic_source"] = (f"profiles/{name}: 2 x FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 "
+                                              "--pmc passes of this command (committed file, not measured in this run)")
+                    break
+                except Exception:
+                    pass
+        pf_ms = stage_k["pyramid"] + stage_k["fast"]
+        pf_gbs = (ab["pyramid"] + ab["fast"]) * F / (pf_ms * 1e-3) / 1e9
+        stages = {k: {"ms": round(v, 4), "GBps": round(gbs(k), 2), "frac": round(gbs(k) / HBM_PEAK_GBS, 5)}
+                  for k, v in stage_k.items()}
+        stages["pyramid+fast"] = {"ms": round(pf_ms, 4), "GBps": round(pf_gbs, 2), "frac": round(pf_gbs / HBM_PEAK_GBS, 5)}
+        stages["extract_total_ms"] = round(stage["total"], 4)
+        stages["match_ms"] = round(match_ms, 4)
+        stages["per"] = f"launch of {F} frames"
+        if match_ms > 0:
+            nn = n_host[:F].astype(np.float64)
+            stages["match_Gdist_per_s"] = round(float((nn * np.roll(nn, 1)).sum()) / (match_ms * 1e-3) / 1e9, 2)
+        result["roofline"] = roof
+        result["stages"] = stages
+        result["config"]["mean_keypoints_per_frame"] = round(float(n_host.mean()), 1)
+        result["config"]["fast_candidates_frame0"] = ncand
+
+    if args.no_extras:
+        return
+
+    # ---- PCIe-inclusive leg (SURVEY 8(d) config 3 as worded): three streams, double buffering ---------------------
+    if world == 1:
+        result["pcie_inclusive"] = pcie_leg(eng, d_gray[:F], w, h, F)
+        result["pcie_inclusive_frames_per_s"] = result["pcie_inclusive"]["frames_per_s"]
+
+    # ---- the other workload, both FAST variants --------------------------------------------------------------------
+    if world == 1:
+        result["workloads"] = workload_legs(args, eng, d_gray[:F], local_rank)
+
+    # ---- config 4: 2000 features, a 1024-frame batch sharded over the ranks + all-gather ---------------------------
+    c4 = config4_leg(args, rank, local_rank, world, fence)
+    if rank == 0:
+        result["config4"] = c4
+
+    if world == 1 and not args.no_cpu_baseline:
+        # online (single-frame, host buffers in / out) latency of ORBextractor::operator(): replicas-only path
+        e1 = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1, device=local_rank)
+        img = d_gray[0].cpu().numpy().copy()
+        for _ in range(5):
+            e1(img)
+        lat = []
+        for _ in range(50):
+            t2 = time.perf_counter()
+            e1(img)
+            lat.append(time.perf_counter() - t2)
+        result["single_frame_host_latency_ms"] = round(float(np.median(lat)) * 1e3, 4)
+        del e1
+        cb = cpu_baseline(w, h, nf)
+        result["cpu_baseline"] = cb
+        result["speedup_vs_cpu_1thread"] = round(value / cb["value"], 1)
+        result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(w, h, nf)
+
+
+def pcie_leg(eng, d_src, w, h, F, nbatches=48):
+    """Host frames in, host results out: pinned buffers, H2D / kernels / D2H on three streams, two buffer sets."""
+    pin_in = d_src.cpu().pin_memory()
+    cap = eng.cap
+    d_in = [torch.empty_like(d_src) for _ in range(2)]
+    kps, desc, n = eng.outs[0]
+    d_out = [(kps[i * F:(i + 1) * F], desc[i * F:(i + 1) * F], n[i * F:(i + 1) * F], eng.d_match[i * F:(i + 1) * F],
+              eng.d_nm[i * F:(i + 1) * F]) for i in range(2)]
+    h_out = [tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in d_out[i]) for i in range(2)]
+    s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
+    s_cmp = torch.cuda.current_stream()
+    ev_in = [torch.cuda.Event() for _ in range(2)]
+    ev_cmp = [torch.cuda.Event() for _ in range(2)]
+    ev_out = [torch.cuda.Event() for _ in range(2)]
+
+    def link_rate(fn, nbytes, reps=6):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return nbytes * reps / (time.perf_counter() - t) / 1e9
+
+    h2d = link_rate(lambda: d_in[0].copy_(pin_in, non_blocking=True), pin_in.numel())
+    out_bytes = sum(t.numel() * t.element_size() for t in d_out[0])
+    d2h = link_rate(lambda: [hh.copy_(dd, non_blocking=True) for hh, dd in zip(h_out[0], d_out[0])], out_bytes)
+
+    def run(nb):
+        for i in range(nb):
+            k = i & 1
+            with torch.cuda.stream(s_in):
+                if i >= 2:
+                    s_in.wait_event(ev_cmp[k])      # the kernels of batch i-2 have consumed input buffer k
+                d_in[k].copy_(pin_in, non_blocking=True)
+                ev_in[k].record(s_in)
+            s_cmp.wait_event(ev_in[k])
+            if i >= 2:
+                s_cmp.wait_event(ev_out[k])         # the results of batch i-2 have left output set k
+            kk, dd, nn, mm, nm = d_out[k]
+            eng.ext.extract_batch_device(d_in[k].data_ptr(), F, w, h, w, w * h, kk.data_ptr(), dd.data_ptr(), cap,
+                                         nn.data_ptr(), s_cmp.cuda_stream)
+            if eng.match:
+                eng.L.orbfe_match_bf_frames_device(eng.mat.handle, kk.data_ptr(), dd.data_ptr(), nn.data_ptr(), cap,
+                                                   eng.qf.data_ptr(), eng.tf.data_ptr(), F, 0.9, 100, 1, mm.data_ptr(),
+                                                   nm.data_ptr(), s_cmp.cuda_stream)
+            ev_cmp[k].record(s_cmp)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_cmp[k])
+                for hh, dv in zip(h_out[k], d_out[k]):
+                    hh.copy_(dv, non_blocking=True)
+                ev_out[k].record(s_out)
+        torch.cuda.synchronize()
+
+    run(4)
+    t = time.perf_counter()
+    run(nbatches)
+    dt = time.perf_counter() - t
+    fps = nbatches * F / dt
+    link_fps = h2d * 1e9 / (w * h)
+    return {"frames_per_s": round(fps, 2), "h2d_GBps_measured": round(h2d, 2), "d2h_GBps_measured": round(d2h, 2),
+            "bytes_in_per_frame": w * h, "bytes_out_per_frame": int(out_bytes // F),
+            "link_bound_frames_per_s": round(link_fps, 1), "frac_of_link_bound": round(fps / link_fps, 4),
+            "sample": f"{nbatches} batches of {F} frames: pinned host frames -> H2D -> extract + match -> D2H of counts, "
+                      f"padded keypoints / descriptors / matches; H2D, kernels and D2H on three streams, two buffer sets"}
+
+
+def workload_legs(args, eng, d_S, local_rank):
+    """Stage times and rate of one launch of F frames on S and on S_tum, dense and sparse FAST variants."""
+    w, h, F = args.width, args.height, args.frames
+    stream = torch.cuda.current_stream().cuda_stream
+    base_t = torch.from_numpy(base_frames("S_tum" if args.workload == "S" else "S", min(F, 32), w, h, 10000)).cuda()
+    other = expand_frames(base_t, F)
+    sets = {args.workload: d_S, ("S_tum" if args.workload == "S" else "S"): other}
+    out = {}
+    kps, desc, n = eng.outs[0]
+    for name in ("S", "S_tum"):
+        g = sets[name]
+        row = {}
+        for mode, label in ((0, "dense"), (1, "sparse")):
+            eng.ext.set_fast_mode(mode, collect_stats=(mode == 1))
+            if mode == 1:
+                eng.ext.fast_stats(reset=True)
+            for _ in range(2):
+                eng.ext.extract_batch_device(g.data_ptr(), F, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), eng.cap,
+                                             n.data_ptr(), stream)
+            torch.cuda.synchronize()
+            if mode == 1:
+                st = eng.ext.fast_stats(reset=True)
+                row["sparse_arc_skip_frac"] = round(st["arc_skips"] / max(st["row_steps"], 1), 4)
+                row["sparse_nms_skip_frac"] = round(st["nms_skips"] / max(st["row_steps"], 1), 4)
+                eng.ext.set_fast_mode(1, collect_stats=False)
+            eng.ext.set_profiling(True)
+            t = time.perf_counter()
+            reps = 8
+            for _ in range(reps):
+                eng.ext.extract_batch_device(g.data_ptr(), F, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), eng.cap,
+                                             n.data_ptr(), stream)
+                if eng.match:
+                    eng.L.orbfe_match_bf_frames_device(eng.mat.handle, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), eng.cap,
+                                                       eng.qf.data_ptr(), eng.tf.data_ptr(), F, 0.9, 100, 1,
+                                                       eng.d_match.data_ptr(), eng.d_nm.data_ptr(), stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            sm = eng.ext.stage_ms()
+            eng.ext.set_profiling(False)
+            row[f"fps_{label}"] = round(reps * F / dt, 1)
+            row[f"stage_ms_{label}"] = {k: round(sm[k], 4) for k in ("pyramid", "fast", "octree", "blur", "describe")}
+        row["fast_candidates_frame0"] = int(sum(len(eng.ext.candidates(l, frame=0)) for l in range(8)))
+        row["mean_keypoints_per_frame"] = round(float(n[:F].float().mean().item()), 1)
+        out[name] = row
+    eng.ext.set_fast_mode(args.fast_mode)
+    return out
+
+
+def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2000, steps=10):
+    """BASELINE config 4: a 1024-frame keyframe batch S(10000+i), 2000 features, contiguous shards, one all-gather of
+    counts + padded keypoints + descriptors.  Strong figure: the fixed global batch; weak: 1024 frames on every rank."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    w, h = args.width, args.height
+    lo, hi = shard_range(global_batch, rank, world)
+    S = -(-global_batch // world)
+    ext = ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=global_batch, device=local_rank)
+    cap = ext.capacity()
+    stream = torch.cuda.current_stream().cuda_stream
+    base = torch.from_numpy(base_frames("S", 32, w, h, 10000)).cuda()
+    allf = expand_frames(base, global_batch)   # every rank builds the same global batch and takes its shard
+    out = {}
+
+    def run(frames, nfr, tag):
+        kps = torch.zeros((max(nfr, S), cap, 7), dtype=torch.int32, device="cuda")
+        desc = torch.zeros((max(nfr, S), cap, 32), dtype=torch.uint8, device="cuda")
+        n = torch.zeros(max(nfr, S), dtype=torch.int32, device="cuda")
+
+        def one():
+            ext.extract_batch_device(frames.data_ptr(), nfr, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap,
+                                     n.data_ptr(), stream)
+            return all_gather_keyframes(n[:S] if tag == "strong" else n, kps[:S] if tag == "strong" else kps,
+                                        desc[:S] if tag == "strong" else desc)
+        for _ in range(3):
+            one()
+        fence()
+        t = time.perf_counter()
+        for _ in range(steps):
+            g = one()
+        fence()
+        dt = time.perf_counter() - t
+        # the exchange step alone
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(steps):
+            all_gather_keyframes(n[:S] if tag == "strong" else n, kps[:S] if tag == "strong" else kps,
+                                 desc[:S] if tag == "strong" else desc)
+        fence()
+        dtg = (time.perf_counter() - t2) / steps
+        if world > 1:
+            tt = torch.tensor([dt, dtg], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt, dtg = float(tt[0]), float(tt[1])
+        rows = S if tag == "strong" else nfr
+        per_rank = rows * (4 + cap * 28 + cap * 32)
+        frames_total = global_batch if tag == "strong" else nfr * world
+        out[tag] = {"frames_per_s": round(frames_total * steps / dt, 1), "frames_per_gpu": nfr,
+                    "allgather_ms": round(dtg * 1e3, 4), "allgather_bytes_per_rank": int(per_rank),
+                    "allgather_bus_GBps": round(per_rank * (world - 1) / dtg / 1e9, 2) if world > 1 else None,
+                    "gathered_frames": int(g[0].shape[0])}
+        del kps, desc, n
+
+    run(allf[lo:hi].contiguous(), hi - lo, "strong")
+    run(allf, global_batch, "weak")
+    out["nfeatures"], out["global_batch"], out["cap"], out["n_gpus"] = nfeat, global_batch, cap, world
+    out["note"] = ("strong: the 1024-frame batch sharded in contiguous blocks (SURVEY 8(d) row 4); weak: 1024 frames on every "
+                   "rank.  The all-gather is synchronous here (its cost is visible); the main timed region overlaps it.")
+    assert ext.overflow() == 0
+    return out
 
 
 if __name__ == "__main__":

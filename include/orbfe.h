@@ -112,11 +112,29 @@ orbfe_status orbfe_extract_batch(orbfe_handle *h, const uint8_t *const *grays, i
  * All work is enqueued on `stream`, a hipStream_t passed as void*.  NULL is HIP's (legacy) default stream
  * -- the stream PyTorch uses unless told otherwise; pass orbfe_get_stream(h) for the handle's own
  * non-blocking stream.  The call returns without synchronising.  Slots >= n_out[i] of a frame are zero-filled so the
- * padded buffers can be all-gathered as they are. */
+ * padded buffers can be all-gathered as they are.
+ * Lifetime: level 0 of the pyramid is read IN PLACE from d_gray, also by later orbfe_get_pyramid_level /
+ * orbfe_tap_* / orbfe_stereo_matches calls on this handle -- keep d_gray alive and unchanged until the next extract
+ * call (or until you are done with those calls).  With the host entry points only the frames of the last chunk of
+ * max_batch frames stay addressable. */
 orbfe_status orbfe_extract_batch_device(orbfe_handle *h, const uint8_t *d_gray, int32_t nframes, int32_t w,
                                         int32_t ht, int32_t stride, size_t frame_stride,
                                         orbfe_keypoint *d_kps, uint8_t *d_desc, int32_t cap,
                                         int32_t *d_n_out, void *stream);
+/* Capacity check for the DEVICE entry point (the host entry points do it themselves and return ORBFE_ERR_CAP):
+ * every internal list is sized for its worst case, and the kernels raise a sticky device-side word instead of
+ * silently dropping data if a size is ever exceeded.  Waits for the stream of the last batched call, returns and
+ * clears the word: bit 0 = a level's FAST survivor list overflowed, bit 1 = a level's quadtree selection overflowed,
+ * bit 2 = a frame produced more keypoints than `cap` (d_n_out holds the required count). */
+orbfe_status orbfe_get_overflow(orbfe_handle *h, int32_t *flags);
+/* FAST kernel variant: 0 = dense (default), 1 = wave-uniform shortcuts for frames with sparse corners (skips the arc
+ * evaluation of 256-pixel row pieces that fail a 4-point necessary test, and the suppression of rows without
+ * strength).  Results are identical in both modes.  collect_stats != 0 counts {row steps, arc skips, NMS skips}. */
+orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32_t collect_stats);
+orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[3], int32_t reset);
+/* work model of the FAST kernel for the current frame size: out[0] = wave row steps per frame (one step = 64 lanes x 4
+ * pixels of one row, halo rows included), out[1] = waves per frame.  bench.py prices its VALU ceiling with it. */
+orbfe_status orbfe_get_work_counts(const orbfe_handle *h, int64_t out[2]);
 /* the handle's own non-blocking stream (hipStream_t as void*): the host-buffer entry points run on it */
 void *orbfe_get_stream(orbfe_handle *h);
 /* block until everything enqueued by this handle on its own stream has finished */

@@ -28,7 +28,7 @@ SYMBOLS = (
     "orbfe_matcher_destroy", "orbfe_matcher_get_stream", "orbfe_match_bf", "orbfe_match_bf_device", "orbfe_match_bf_frames_device",
     "orbfe_search_by_bow", "orbfe_hamming_csr", "orbfe_assign_grid", "orbfe_features_in_area",
     "orbfe_distinctive_descriptors", "orbfe_stereo_matches", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
-    "orbfe_bow_transform",
+    "orbfe_bow_transform", "orbfe_get_overflow", "orbfe_set_fast_mode", "orbfe_get_fast_stats", "orbfe_get_work_counts",
 )
 
 
@@ -85,6 +85,10 @@ def lib():
     L.orbfe_tap_blurred_level.argtypes = [vp, i32, i32, vp, i32]
     L.orbfe_tap_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
     L.orbfe_tap_selected.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.orbfe_get_work_counts.argtypes = [vp, vp]
+    L.orbfe_get_overflow.argtypes = [vp, vp]
+    L.orbfe_set_fast_mode.argtypes = [vp, i32, i32]
+    L.orbfe_get_fast_stats.argtypes = [vp, vp, i32]
     L.orbfe_set_profiling.argtypes = [vp, i32]
     L.orbfe_get_stage_ms.argtypes = [vp, vp]
     L.orbfe_hamming.argtypes = [vp, vp]

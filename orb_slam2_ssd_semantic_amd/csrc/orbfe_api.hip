@@ -145,6 +145,13 @@ struct orbfe_handle {
     DevBuf d_plan, d_tabs, d_flanes, d_blanes;
     // per-batch blocks
     DevBuf d_pyr, d_blur, d_skeys, d_scount, d_knode, d_sel, d_nsel, d_nkeys;
+    // sticky overflow word + FAST sparse-variant statistics: [0] int32 overflow bits, [2..7] 3 x uint64 counters
+    DevBuf d_misc;
+    int fast_mode = 0;            // 0 dense, 1 sparse shortcuts (orbfe_set_fast_mode)
+    bool fast_stats = false;
+    int64_t fast_row_steps = 0;
+    hipStream_t last_stream = nullptr;  // stream of the most recent batched call (synchronised before re-planning)
+    bool last_stream_valid = false;
     // host-API staging
     DevBuf d_stage, d_okps, d_odesc, d_on;
     PinBuf h_stage, h_okps, h_odesc, h_on;
@@ -410,6 +417,12 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         }
     }
     P.nfwaves = (int)(flanes.size() / 64);
+    int64_t fast_row_steps = 0;  // wave row steps one frame costs k_fast_map (VALU model of bench.py's roofline)
+    for (int wv = 0; wv < P.nfwaves; ++wv) {
+        int mx = 0;
+        for (int i = 0; i < 64; ++i) mx = std::max(mx, (int)flanes[(size_t)wv * 64 + i].nrows);
+        fast_row_steps += mx + 8;
+    }
     // blur lane list: every 4-px column of every (balanced, <= ORBFE_ROWS_PER_WAVE rows) row block, single-level waves, no halos
     std::vector<OrbLane> blanes;
     for (int l = 0; l < nl; ++l) {
@@ -447,8 +460,11 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(h->d_tabs.ensure(tabs.size() * sizeof(OrbTab)));
     ORBFE_HIP(h->d_flanes.ensure(std::max<size_t>(flanes.size(), 1) * sizeof(OrbLane)));
     ORBFE_HIP(h->d_blanes.ensure(std::max<size_t>(blanes.size(), 1) * sizeof(OrbLane)));
-    // synchronous copies: plans change rarely (frame size change), never inside the timed region
+    // synchronous copies: plans change rarely (frame size change), never inside the timed region.  Earlier batches may
+    // still be in flight on the handle's stream or on the caller's stream of the previous device call: both are drained
+    // before the plan tables they read are overwritten.
     ORBFE_HIP(hipStreamSynchronize(h->stream));
+    if (h->last_stream_valid && h->last_stream != h->stream) ORBFE_HIP(hipStreamSynchronize(h->last_stream));
     ORBFE_HIP(hipMemcpy(h->d_plan.p, &P, sizeof(OrbPlan), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_tabs.p, tabs.data(), tabs.size() * sizeof(OrbTab), hipMemcpyHostToDevice));
     if (!flanes.empty())
@@ -457,6 +473,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         ORBFE_HIP(hipMemcpy(h->d_blanes.p, blanes.data(), blanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     ORBFE_HIP(orbk_prepare_octree(M, P.max_nini, P.w, P.h, P.max_ncells));
     h->plan = P;
+    h->fast_row_steps = fast_row_steps;
     h->cells.swap(cells);
     h->tabs.swap(tabs);
     h->plan_valid = true;
@@ -467,6 +484,11 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
 {
     const OrbPlan &P = h->plan;
     const size_t B = (size_t)nframes;
+    if (B * (size_t)P.pyr_frame_bytes > h->d_pyr.bytes || B * (size_t)P.keys_per_frame * sizeof(uint2) > h->d_skeys.bytes) {
+        // a block is about to be re-allocated: nothing may still be reading the old one
+        ORBFE_HIP(hipStreamSynchronize(h->stream));
+        if (h->last_stream_valid && h->last_stream != h->stream) ORBFE_HIP(hipStreamSynchronize(h->last_stream));
+    }
     ORBFE_HIP(h->d_pyr.ensure(B * (size_t)P.pyr_frame_bytes));
     ORBFE_HIP(h->d_blur.ensure(B * (size_t)P.pyr_frame_bytes));
     ORBFE_HIP(h->d_skeys.ensure(B * (size_t)P.keys_per_frame * sizeof(uint2)));
@@ -475,6 +497,21 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
     ORBFE_HIP(h->d_sel.ensure(B * (size_t)P.sel_per_frame * sizeof(uint32_t)));
     ORBFE_HIP(h->d_nsel.ensure(B * P.nlevels * sizeof(int32_t)));
     ORBFE_HIP(h->d_nkeys.ensure(B * P.nlevels * ORBFE_NK_STRIDE * sizeof(int32_t)));
+    if (!h->d_misc.p) {
+        ORBFE_HIP(h->d_misc.ensure(64));
+        ORBFE_HIP(hipMemset(h->d_misc.p, 0, 64));
+    }
+    return ORBFE_OK;
+}
+
+// reads and clears the sticky overflow word; the stream of the last batched call is drained first
+static orbfe_status read_overflow(orbfe_handle *h, int32_t *flags)
+{
+    *flags = 0;
+    if (!h->d_misc.p) return ORBFE_OK;
+    if (h->last_stream_valid) ORBFE_HIP(hipStreamSynchronize(h->last_stream));
+    ORBFE_HIP(hipMemcpy(flags, h->d_misc.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (*flags) ORBFE_HIP(hipMemset(h->d_misc.p, 0, sizeof(int32_t)));
     return ORBFE_OK;
 }
 
@@ -573,6 +610,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
                       &h->d_okps, &h->d_odesc, &h->d_on};
     for (DevBuf *b : bufs) b->release();
+    h->d_misc.release();
     PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
     for (PinBuf *b : pins) b->release();
     if (h->ev_ok)
@@ -655,6 +693,41 @@ extern "C" orbfe_status orbfe_synchronize(orbfe_handle *h)
     return ORBFE_OK;
 }
 
+extern "C" orbfe_status orbfe_get_work_counts(const orbfe_handle *h, int64_t out[2])
+{
+    if (!h || !out) return ORBFE_ERR_ARG;
+    out[0] = h->fast_row_steps;
+    out[1] = h->plan.nfwaves;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_get_overflow(orbfe_handle *h, int32_t *flags)
+{
+    if (!h || !flags) return ORBFE_ERR_ARG;
+    DeviceGuard g(h->device);
+    return read_overflow(h, flags);
+}
+
+extern "C" orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32_t collect_stats)
+{
+    if (!h || mode < 0 || mode > 1) return ORBFE_ERR_ARG;
+    h->fast_mode = mode;
+    h->fast_stats = collect_stats != 0;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[3], int32_t reset)
+{
+    if (!h || !out) return ORBFE_ERR_ARG;
+    out[0] = out[1] = out[2] = 0;
+    if (!h->d_misc.p) return ORBFE_OK;
+    DeviceGuard g(h->device);
+    if (h->last_stream_valid) ORBFE_HIP(hipStreamSynchronize(h->last_stream));
+    ORBFE_HIP(hipMemcpy(out, (char *)h->d_misc.p + 16, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) ORBFE_HIP(hipMemset((char *)h->d_misc.p + 16, 0, 3 * sizeof(uint64_t)));
+    return ORBFE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the batched device path (everything else funnels into this)
 // ---------------------------------------------------------------------------------------------------
@@ -693,6 +766,11 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_desc = d_desc;
     a.cap = cap;
     a.d_n_out = d_n_out;
+    a.d_ovf = (int32_t *)h->d_misc.p;
+    a.fast_sparse = h->fast_mode;
+    a.d_fstat = h->fast_stats ? (unsigned long long *)((char *)h->d_misc.p + 16) : nullptr;
+    h->last_stream = st;
+    h->last_stream_valid = true;
     hipEvent_t *ev = h->profiling ? h->ev[h->prof_calls % ORBFE_PROF_RING] : nullptr;
     if (ev) ORBFE_HIP(hipEventRecord(ev[0], st));
     ORBFE_HIP(orbk_launch_pyramid(a, st));
@@ -782,6 +860,16 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
                                  hipMemcpyDeviceToHost, h->stream));
         ORBFE_HIP(hipMemcpyAsync(h->h_odesc.p, h->d_odesc.p, (size_t)32 * cap * nb, hipMemcpyDeviceToHost, h->stream));
         ORBFE_HIP(hipStreamSynchronize(h->stream));
+        {
+            int32_t ovf = 0;
+            orbfe_status so = read_overflow(h, &ovf);
+            if (so != ORBFE_OK) return so;
+            if (ovf & 3) {
+                orbfe_set_error("internal capacity exceeded (flags %d: 1 = FAST survivor list, 2 = quadtree selection); "
+                                "results of this batch are incomplete", ovf);
+                return ORBFE_ERR_CAP;
+            }
+        }
         for (int f = 0; f < nb; ++f) {
             const int n = ((int32_t *)h->h_on.p)[f];
             n_out[f0 + f] = n;

@@ -18,6 +18,7 @@
 #define ORBFE_PATCH 31       // PATCH_SIZE       (:52)
 #define ORBFE_MINB 16        // minBorderX/Y = EDGE_THRESHOLD-3 (:780)
 #define ORBFE_NK_STRIDE 32   // ints between per-(frame, level) key counters: one 128-B line each (atomic targets)
+#define ORBFE_LDS_MAX (160 * 1024)  // LDS of one gfx950 CU: the dynamic-LDS attribute of every kernel is set to this
 #define ORBFE_TILE_MAX 72    // FAST cell tile edge upper bound (cell+6 <= 66 when nCols == 1)
 
 // ---- thread-local error text ---------------------------------------------------------------------

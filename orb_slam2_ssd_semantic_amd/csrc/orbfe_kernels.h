@@ -29,6 +29,12 @@ struct OrbLaunch {
     uint8_t *d_desc;
     int32_t cap;
     int32_t *d_n_out;
+    // sticky overflow word: bit 0 a level's survivor list exceeded key_cap, bit 1 a level's selection exceeded sel_cap,
+    // bit 2 a frame's keypoints exceeded `cap`
+    int32_t *d_ovf;
+    // FAST variant: 1 = wave-uniform shortcuts for sparse-corner frames; d_fstat (optional) counts their effect
+    int32_t fast_sparse;
+    unsigned long long *d_fstat;
 };
 
 hipError_t orbk_upload_constants(const int *umax16);

@@ -336,6 +336,21 @@ __device__ __forceinline__ uint32_t fast_strength_pair(const uint32_t (&rm3)[3],
     return pk_sub_u16(m, t);
 }
 
+// Exact NECESSARY condition for A > t on the pixel pair (J, J+1): every nine-arc of the 16-pixel circle contains at
+// least one pixel of each opposite pair, so a bright corner needs max(c0, c8) > v + t AND max(c4, c12) > v + t (and
+// dually for dark).  Non-zero half <=> that pixel may be a corner.  15 packed ops against 92 for the strength.
+template <int J>
+__device__ __forceinline__ uint32_t fast_compass_pair(const uint32_t (&rm3)[3], const uint32_t (&r0)[3],
+                                                      const uint32_t (&rp3)[3], uint32_t t)
+{
+    const uint32_t c0 = rowpair<4 + J>(rp3), c8 = rowpair<4 + J>(rm3);
+    const uint32_t c4 = rowpair<7 + J>(r0), c12 = rowpair<1 + J>(r0);
+    const uint32_t v = rowpair<4 + J>(r0);
+    const uint32_t mb = pk_min_u16(pk_max_u16(c0, c8), pk_max_u16(c4, c12));
+    const uint32_t md = pk_max_u16(pk_min_u16(c0, c8), pk_min_u16(c4, c12));
+    return pk_subsat_u16(pk_max_u16(pk_subsat_u16(mb, v), pk_subsat_u16(v, md)), t);
+}
+
 __device__ __forceinline__ int lanes_below(unsigned long long m)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -353,10 +368,15 @@ __device__ __forceinline__ void fm_flush(uint2 *slist, int32_t *scnt, const uint
         if (base + i < key_cap) slist[base + i] = sbuf[i];
 }
 
+// SPARSE = 1: wave-uniform shortcuts for frames whose corners are sparse (real camera images): a row step whose 256
+// pixels all fail the compass test skips the arc evaluation, and an NMS row with no strength in its 3-row
+// neighbourhood skips the NMS / emission block.  Results are identical; on corner-saturated frames the tests only cost.
+template <int SPARSE>
 __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ plan, FrameSrc fs,
                                                   const OrbLane *__restrict__ lanes, int nwaves,
                                                   uint2 *__restrict__ skeys,      // [B][keys_per_frame] {key, ord}
-                                                  int32_t *__restrict__ scount)   // [B][nlevels] * NK_STRIDE, zeroed
+                                                  int32_t *__restrict__ scount,   // [B][nlevels] * NK_STRIDE, zeroed
+                                                  unsigned long long *__restrict__ fstat)  // {row steps, arc skips, nms skips} or null
 {
     __shared__ uint2 s_buf[4][FM_BUF];
     int b = blockIdx.y, bx = blockIdx.x;
@@ -377,6 +397,7 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
     int32_t *scnt = scount + (b * plan->nlevels + level) * ORBFE_NK_STRIDE;
     uint2 *sbuf = s_buf[wv];
     int nbuf = 0;  // wave-uniform fill of sbuf
+    int st_rows = 0, st_arc = 0, st_nms = 0;  // SPARSE statistics (wave-uniform)
     const int H = L.h, key_cap = L.key_cap;
     const int ix0 = ORBFE_EDGE, iy0 = ORBFE_EDGE, ix1 = L.ix1, iy1 = L.iy1;
     const int wcell = L.wcell, hcell = L.hcell;
@@ -462,8 +483,19 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
                 const uint32_t(&rp3)[3] = R[k];
                 const bool rowok = (uint32_t)(ysrel + s) < hrange;  // iy0 <= rc < iy1
                 const uint32_t tt = rowok ? tzz : 0x03FF03FFu;
-                S01[k] = fast_strength_pair<0>(rm3, rm2, rm1, r0, rp1, rp2, rp3, tt) & in01;
-                S23[k] = fast_strength_pair<2>(rm3, rm2, rm1, r0, rp1, rp2, rp3, tt) & in23;
+                bool arcs = true;
+                if (SPARSE) {
+                    const uint32_t p = (fast_compass_pair<0>(rm3, r0, rp3, tt) & in01) |
+                                       (fast_compass_pair<2>(rm3, r0, rp3, tt) & in23);
+                    arcs = __ballot(p != 0u) != 0ull;  // wave-uniform
+                    if (fstat) { st_rows++; st_arc += arcs ? 0 : 1; }
+                }
+                if (arcs) {
+                    S01[k] = fast_strength_pair<0>(rm3, rm2, rm1, r0, rp1, rp2, rp3, tt) & in01;
+                    S23[k] = fast_strength_pair<2>(rm3, rm2, rm1, r0, rp1, rp2, rp3, tt) & in23;
+                } else {
+                    S01[k] = S23[k] = 0u;
+                }
             }
             if (s < 8) continue;
             // ---- 3x3 strict NMS of row rn = rc - 1 on packed pairs: rows U = S[k-2], M = S[k-1], D = S[k] ----
@@ -475,6 +507,12 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
                 const bool wrap = rmod == hcell - 1;
                 rmod = wrap ? 0 : rmod + 1;
                 ordy += wrap ? 64u + ord_wrap : 64u;
+            }
+            if (SPARSE) {  // no strength in the row being suppressed -> nothing can survive (wave-uniform)
+                if (__ballot((S01[km] | S23[km]) != 0u) == 0ull) {
+                    if (fstat) st_nms++;
+                    continue;
+                }
             }
             const uint32_t u01 = up_ok ? S01[ku] : 0u, u23 = up_ok ? S23[ku] : 0u;
             const uint32_t d01 = dn_ok ? S01[k] : 0u, d23 = dn_ok ? S23[k] : 0u;
@@ -530,6 +568,11 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
         }
     }
     if (nbuf > 0) fm_flush(slist, scnt, sbuf, nbuf, key_cap, lane);
+    if (SPARSE && fstat && lane == 0) {
+        atomicAdd(&fstat[0], (unsigned long long)st_rows);
+        atomicAdd(&fstat[1], (unsigned long long)st_arc);
+        atomicAdd(&fstat[2], (unsigned long long)st_nms);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -821,7 +864,8 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
                                                uint16_t *__restrict__ knode,        // [B][keys_per_frame] scratch (deep trees only)
                                                int32_t *__restrict__ nkeys,         // [B][nlevels] out (taps)
                                                uint32_t *__restrict__ sel,          // [B][sel_per_frame] out
-                                               int32_t *__restrict__ nsel)          // [B][nlevels] out
+                                               int32_t *__restrict__ nsel,          // [B][nlevels] out
+                                               int32_t *__restrict__ ovf)           // sticky overflow word
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Workgroups go round-robin to the 8 XCDs in launch order; with level = blockIdx.x every XCD would own ONE pyramid
@@ -843,7 +887,9 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
 
     // ---- prologue 1: the reference's per-cell threshold fallback (:818-825) on the unordered survivor list ----
     // A cell contributes {A > iniTh} if that is non-empty, else all its NMS survivors ({A > minTh}).
-    const int ns = min(scount[(b * plan->nlevels + level) * ORBFE_NK_STRIDE], L.key_cap);
+    const int ns_all = scount[(b * plan->nlevels + level) * ORBFE_NK_STRIDE];
+    const int ns = min(ns_all, L.key_cap);
+    if (tid == 0 && ns_all > L.key_cap) atomicOr(ovf, 1);  // k_fast_map dropped survivors: results would be truncated
     uint32_t *cflag = q.cflag;  // bitmap over this level's cells; stays valid to the end of the kernel
     const int nwords = (L.ncells + 31) >> 5;
     for (int i = tid; i < nwords; i += QT) cflag[i] = 0u;
@@ -1104,7 +1150,10 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
         // + minBorderX / minBorderY (:853-854): level coordinates from here on
         out[i] = orb_pack_key(orb_key_x(key) + ORBFE_MINB, orb_key_y(key) + ORBFE_MINB, orb_key_r(key));
     }
-    if (tid == 0) nsel[b * plan->nlevels + level] = nout;
+    if (tid == 0) {
+        nsel[b * plan->nlevels + level] = nout;
+        if (S > L.sel_cap) atomicOr(ovf, 2);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1356,7 +1405,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
                                                          orbfe_keypoint *__restrict__ kps,
                                                          uint8_t *__restrict__ desc, int32_t cap,
                                                          int32_t *__restrict__ n_out, int32_t nl,
-                                                         int32_t sel_per_frame)
+                                                         int32_t sel_per_frame, int32_t *__restrict__ ovf)
 {
     // Everything the keypoint look-up needs is requested in ONE round trip (level counts, per-level constants into
     // LDS, pattern and moment weights), so the dependent chain of a workgroup is: this, the key, the pixels.
@@ -1397,7 +1446,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
         if (level < 0) idx -= c;
         total += c;
     }
-    if (slot == 0 && sub == 0) n_out[b] = total;
+    if (slot == 0 && sub == 0) {
+        n_out[b] = total;
+        if (total > cap) atomicOr(ovf, 4);  // n_out holds the required count; slots >= cap are not written
+    }
     const bool in_cap = slot < cap;
     orbfe_keypoint *kp = kps + (int64_t)b * cap + slot;
     uint8_t *dd = desc + ((int64_t)b * cap + slot) * 32;
@@ -1557,8 +1609,12 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
     hipError_t e = hipMemsetAsync(a.d_scount, 0, sizeof(int32_t) * (size_t)a.nframes * a.h_plan->nlevels * ORBFE_NK_STRIDE, st);
     if (e != hipSuccess) return e;
     dim3 grid((a.h_plan->nfwaves + 3) / 4, a.nframes);
-    hipLaunchKernelGGL(k_fast_map, grid, dim3(256), 0, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
-                       a.d_scount);
+    if (a.fast_sparse)
+        hipLaunchKernelGGL(k_fast_map<1>, grid, dim3(256), 0, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
+                           a.d_scount, a.d_fstat);
+    else
+        hipLaunchKernelGGL(k_fast_map<0>, grid, dim3(256), 0, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
+                           a.d_scount, (unsigned long long *)nullptr);
     return hipGetLastError();
 }
 
@@ -1568,14 +1624,17 @@ hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
     const size_t lds = orbk_octree_lds_bytes(a.h_plan->node_cap, a.h_plan->max_nini, a.h_plan->w, a.h_plan->h, a.h_plan->max_ncells);
     static const int qt = getenv("ORBFE_QT") ? atoi(getenv("ORBFE_QT")) : 512;  // must be <= QT_MAX
     hipLaunchKernelGGL(k_octree, grid, dim3(qt), lds, st, a.d_plan, a.d_skeys, a.d_scount, a.d_knode,
-                       a.d_nkeys, a.d_sel, a.d_nsel);
+                       a.d_nkeys, a.d_sel, a.d_nsel, a.d_ovf);
     return hipGetLastError();
 }
 
 hipError_t orbk_prepare_octree(int node_cap, int max_nini, int w, int h, int ncells)
 {
+    // The attribute is per kernel and process-wide: every handle sets it to the SAME value, the most the code can ever
+    // request (the CU's 160 KB), so a later, smaller handle can never lower the limit under an earlier, larger one.
     const size_t lds = orbk_octree_lds_bytes(node_cap, max_nini, w, h, ncells);
-    return hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > ORBFE_LDS_MAX) return hipErrorInvalidValue;
+    return hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORBFE_LDS_MAX);
 }
 
 hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st)
@@ -1596,6 +1655,7 @@ hipError_t orbk_launch_describe(const OrbLaunch &a, hipStream_t st)
     const FrameSrc fs = make_src(a);
     dim3 grid((a.cap + 15) / 16, a.nframes);
     hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, st, a.d_plan, fs, a.d_blur, a.pyr_fstride, a.d_sel,
-                       a.d_nsel, a.d_kps, a.d_desc, a.cap, a.d_n_out, a.h_plan->nlevels, a.h_plan->sel_per_frame);
+                       a.d_nsel, a.d_kps, a.d_desc, a.cap, a.d_n_out, a.h_plan->nlevels, a.h_plan->sel_per_frame,
+                       a.d_ovf);
     return hipGetLastError();
 }

@@ -108,6 +108,25 @@ class ORBextractor:
                                                 cap, d_n, stream)
         check(st, "orbfe_extract_batch_device")
 
+    def work_counts(self):
+        out = np.zeros(2, np.int64)
+        check(self._L.orbfe_get_work_counts(self._h, ptr(out)), "orbfe_get_work_counts")
+        return dict(fast_row_steps_per_frame=int(out[0]), fast_waves_per_frame=int(out[1]))
+
+    def overflow(self):
+        """Sticky device-side capacity flags since the last query (0 = every list fitted); waits for the last call."""
+        f = C.c_int32(0)
+        check(self._L.orbfe_get_overflow(self._h, C.byref(f)), "orbfe_get_overflow")
+        return f.value
+
+    def set_fast_mode(self, mode, collect_stats=False):
+        check(self._L.orbfe_set_fast_mode(self._h, int(mode), int(collect_stats)), "orbfe_set_fast_mode")
+
+    def fast_stats(self, reset=True):
+        out = np.zeros(3, np.uint64)
+        check(self._L.orbfe_get_fast_stats(self._h, ptr(out), int(reset)), "orbfe_get_fast_stats")
+        return dict(row_steps=int(out[0]), arc_skips=int(out[1]), nms_skips=int(out[2]))
+
     def synchronize(self):
         check(self._L.orbfe_synchronize(self._h), "orbfe_synchronize")
 

@@ -23,3 +23,70 @@ def synth_frame(seed, h=480, w=640, sparse=False):
 
 def synth_batch(seed0, n, h=480, w=640, sparse=False):
     return np.stack([synth_frame(seed0 + i, h, w, sparse) for i in range(n)])
+
+
+# rational rotations (exact cos / sin): no libm in the generator, so frames are bit-reproducible across machines
+_ROT = ((1.0, 0.0), (0.0, 1.0), (0.6, 0.8), (0.8, 0.6), (5 / 13, 12 / 13), (12 / 13, 5 / 13), (8 / 17, 15 / 17),
+        (-0.6, 0.8), (-0.8, 0.6), (-5 / 13, 12 / 13))
+
+
+def _value_noise(rng, h, w, s):
+    """Gaussian lattice noise of period s, bilinearly interpolated to h x w (only mul/add: reproducible)."""
+    gh, gw = h // s + 2, w // s + 2
+    g = rng.normal(0.0, 1.0, (gh, gw))
+    y = np.arange(h) / s
+    x = np.arange(w) / s
+    y0 = y.astype(np.int64)
+    x0 = x.astype(np.int64)
+    fy = (y - y0)[:, None]
+    fx = (x - x0)[None, :]
+    a = g[y0][:, x0]
+    b = g[y0][:, x0 + 1]
+    c = g[y0 + 1][:, x0]
+    d = g[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def _binomial5(img):
+    """[1 4 6 4 1] / 16 separable smoothing (sigma 1.0; dyadic weights, edge-replicated): lens + demosaic blur."""
+    p = np.pad(img, 2, mode="edge")
+    r = (p[:, :-4] + 4 * p[:, 1:-3] + 6 * p[:, 2:-2] + 4 * p[:, 3:-1] + p[:, 4:]) / 16.0
+    return (r[:-4] + 4 * r[1:-3] + 6 * r[2:-2] + 4 * r[3:-1] + r[4:]) / 16.0
+
+
+def synth_tum_like(seed, h=480, w=640):
+    """S_tum(seed): frames with the corner statistics of indoor camera images (TUM RGB-D is not in the container).
+
+    Multi-octave (1/f-like) texture at natural contrast, 10-20 piecewise-smooth "objects" (rotated boxes / ellipses
+    with their own albedo, mostly flat), a few fine-print patches, optics blur and sensor noise (sigma 1.6).  The
+    reference's FAST stage finds a few thousand NMS candidates per frame on these (3-10 k on TUM)
+    instead of the ~37 k of the corner-saturated S(seed); about 2.5 % of the pixels are FAST corners at minThFAST.
+    """
+    rng = np.random.default_rng(1_000_000 + seed)
+    tex = np.zeros((h, w), np.float64)
+    for s, amp in ((2, 0.7), (4, 1.0), (8, 1.3), (16, 1.7), (32, 2.4), (64, 3.4), (128, 4.6)):
+        tex += amp * _value_noise(rng, h, w, s)
+    tex /= 7.0
+    img = 118.0 + 34.0 * tex
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    for _ in range(int(rng.integers(10, 22))):
+        cy, cx = float(rng.integers(0, h)), float(rng.integers(0, w))
+        a, b = float(rng.integers(12, 140)), float(rng.integers(12, 140))
+        co, si = _ROT[int(rng.integers(0, len(_ROT)))]
+        u = (xx - cx) * co + (yy - cy) * si
+        v = (yy - cy) * co - (xx - cx) * si
+        if rng.random() < 0.7:
+            m = (np.abs(u) < a) & (np.abs(v) < b)
+        else:
+            m = u * u * (b * b) + v * v * (a * a) < a * a * b * b
+        alb = float(rng.integers(30, 221))
+        k = float(rng.integers(1, 11)) / 20.0
+        img = np.where(m, alb + k * (img - 118.0), img)
+    for _ in range(int(rng.integers(2, 6))):   # fine print / keyboards
+        y0, x0 = int(rng.integers(0, h - 60)), int(rng.integers(0, w - 90))
+        ph, pw, s = int(rng.integers(30, 60)), int(rng.integers(40, 90)), int(rng.integers(3, 7))
+        g = rng.integers(0, 2, (-(-ph // s), -(-pw // s))) * float(rng.integers(40, 121))
+        patch = np.repeat(np.repeat(g, s, 0), s, 1)[:ph, :pw]
+        img[y0:y0 + ph, x0:x0 + pw] = img[y0:y0 + ph, x0:x0 + pw] * 0.25 + patch + 40.0
+    img = _binomial5(img) + rng.normal(0.0, 1.6, (h, w))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

@@ -1,0 +1,206 @@
+"""Randomised parity sweeps and the sequence-scale check (BASELINE config 2), HIP path vs the CPU oracle.  GPU only.
+
+Fixed seeds, bounded counts: 100 extractor + 100 matcher + 30 caller (grid / distinctive / BoW / stereo) + 30
+device-API cases, then one batched device call over 200 frames S(seed) and 96 frames S_tum(seed) in BOTH FAST
+variants.  Integer / bit-pattern work: everything must be identical.  ORBFE_FUZZ_SCALE scales the counts
+(tools/fuzz_parity.py runs this file with a larger scale)."""
+import os
+
+import numpy as np
+import pytest
+
+from orb_slam2_ssd_semantic_amd.synth import synth_frame, synth_tum_like
+
+pytestmark = pytest.mark.gpu
+SCALE = float(os.environ.get("ORBFE_FUZZ_SCALE", "1"))
+
+
+def _n(base):
+    return max(1, int(round(base * SCALE)))
+
+
+def _same(gk, gd, ok, od):
+    return (len(gk) == len(ok) and np.array_equal(gd, od)
+            and all(np.array_equal(gk[f].view(np.uint32), ok[f].view(np.uint32)) for f in ok.dtype.names))
+
+
+def test_fuzz_extractor(oracle):
+    from orb_slam2_ssd_semantic_amd import ORBextractor, OrbfeError
+    rng = np.random.default_rng(1)
+    ran = 0
+    for c in range(_n(100)):
+        w, h = int(rng.integers(180, 1000)), int(rng.integers(160, 760))
+        nlev = int(rng.integers(1, 9))
+        sf = float(np.float32(rng.choice([1.1, 1.2, 1.25, 1.3, 1.4, 1.5, 1.7])))
+        nf = int(rng.integers(50, 3000))
+        ini = int(rng.integers(8, 40))
+        mn = int(rng.integers(1, ini + 1))
+        kind = int(rng.integers(0, 3))
+        seed = int(rng.integers(0, 1 << 30))
+        img = synth_tum_like(seed, h, w) if kind == 2 else synth_frame(seed, h, w, sparse=bool(kind))
+        if rng.random() < 0.2:  # flat regions: empty cells exercise the minTh fallback and tiny trees
+            y0, x0 = int(rng.integers(0, h // 2)), int(rng.integers(0, w // 2))
+            img[y0:y0 + h // 3, x0:x0 + w // 3] = 128
+        tag = f"case {c}: {w}x{h} nf={nf} nlev={nlev} sf={sf:.2f} th={ini}/{mn} kind={kind}"
+        try:
+            e = ORBextractor(nf, sf, nlev, ini, mn, max_width=w, max_height=h)
+            e.set_fast_mode(c & 1)
+            gk, gd = e(img)
+        except OrbfeError:
+            continue  # sizes the boundary rejects (level too small for one cell, > 4 quadtree roots, per-level cap)
+        ok, od = oracle.OracleExtractor(nf, sf, nlev, ini, mn)(img, cap=nf + 16 * nlev + 256)
+        assert _same(gk, gd, ok, od), tag
+        assert e.overflow() == 0, tag
+        ran += 1
+    assert ran >= 0.6 * _n(100)
+
+
+def test_fuzz_matcher(oracle):
+    from orb_slam2_ssd_semantic_amd import ORBmatcher
+    rng = np.random.default_rng(2)
+    for c in range(_n(100)):
+        nq, nt = int(rng.integers(0, 2500)), int(rng.integers(0, 2500))
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        if nt and nq:
+            q = t[rng.integers(0, nt, nq)].copy()
+            flips = int(rng.integers(0, 70))
+            if flips:
+                bits = rng.integers(0, 256, (nq, flips))
+                for j in range(flips):
+                    q[np.arange(nq), bits[:, j] >> 3] ^= (1 << (bits[:, j] & 7)).astype(np.uint8)
+            if rng.random() < 0.5:  # duplicate train rows: first index must win, second == best
+                t[rng.integers(0, nt, nt // 4)] = t[rng.integers(0, nt, nt // 4)]
+        qa = rng.uniform(0, 360, nq).astype(np.float32)
+        ta = rng.uniform(0, 360, nt).astype(np.float32)
+        ratio, th, ori = float(rng.choice([0.6, 0.75, 0.9])), int(rng.choice([50, 100])), bool(rng.integers(0, 2))
+        got = ORBmatcher(ratio, ori).MatchBruteForce(q, t, qa, ta, th)
+        ref = oracle.match_bf(q, t, qa, ta, ratio, th, ori)
+        assert all(np.array_equal(g, r) for g, r in zip(got[:3], ref[:3])) and got[3] == ref[3], (c, nq, nt)
+
+
+def test_fuzz_callers(oracle):
+    """The callers either side of the path: generators of the unit tests, fresh seeds."""
+    from test_bow import make_voc
+    from test_distinctive import make_case
+    from test_grid import grid_case, queries
+    from test_stereo import stereo_pair
+    from orb_slam2_ssd_semantic_amd import FrameGrid, ORBextractor, ORBmatcher, ORBVocabulary
+    rng = np.random.default_rng(4)
+    mt = ORBmatcher(0.9, True)
+    for c in range(_n(30)):
+        sd = int(rng.integers(0, 1 << 20))
+        xy, octave, minx, miny, gwi, ghi = grid_case(sd, int(rng.integers(0, 3000)))
+        g = FrameGrid(mt, xy, octave, minx, miny, gwi, ghi)
+        off, idx = oracle.assign_grid(xy, minx, miny, gwi, ghi)
+        assert np.array_equal(g.cell_off, off) and np.array_equal(g.cell_idx, idx), (c, sd)
+        q, lv = queries(sd, int(rng.integers(0, 400)))
+        qoff, cand = g.query(q, lv)
+        for i in range(len(q)):
+            ref = oracle.features_in_area(xy, octave, off, idx, minx, miny, gwi, ghi, float(q[i, 0]), float(q[i, 1]),
+                                          float(q[i, 2]), int(lv[i, 0]), int(lv[i, 1]))
+            assert np.array_equal(cand[qoff[i]:qoff[i + 1]], ref), (c, sd, i)
+        pool, doff, didx = make_case(sd, int(rng.integers(0, 400)), int(rng.integers(1, 90)))
+        b, m = mt.ComputeDistinctiveDescriptors(pool, doff, didx)
+        rb, rm = oracle.distinctive(pool, doff, didx)
+        assert np.array_equal(b, rb) and np.array_equal(m, rm), (c, sd)
+        voc = make_voc(sd, int(rng.integers(2, 11)), int(rng.integers(1, 5)))
+        desc = rng.integers(0, 256, (int(rng.integers(0, 3000)), 32), dtype=np.uint8)
+        lu = int(rng.integers(0, 5))
+        r = oracle.bow_transform(voc, desc, lu)
+        (bid, bval), (fvn, fvo, fvi) = ORBVocabulary(mt, **voc).transform(desc, lu)
+        assert np.array_equal(bid, r["bow_id"]) and np.array_equal(bval.view(np.uint64), r["bow_val"].view(np.uint64))
+        assert np.array_equal(fvn, r["fv_node"]) and np.array_equal(fvo, r["fv_off"]) and np.array_equal(fvi, r["fv_idx"])
+        if c < 3:
+            left, right = stereo_pair(sd % 1000)
+            exL, exR = oracle.OracleExtractor(), oracle.OracleExtractor()
+            kL, dL = exL(left)
+            kR, dR = exR(right)
+            mbf, mb = float(rng.uniform(20, 400)), float(rng.uniform(0.05, 2.0))
+            ru, rd, _ = oracle.stereo_matches(exL, exR, kL, dL, kR, dR, mbf, mb)
+            gl = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480)
+            gr = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480)
+            gkL, gdL = gl(left)
+            gkR, gdR = gr(right)
+            u, d = mt.ComputeStereoMatches(gl, gr, gkL, gdL, gkR, gdR, mbf, mb)
+            assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)), (c, sd)
+            assert np.array_equal(d.view(np.uint32), rd.view(np.uint32)), (c, sd)
+
+
+def _device_batch(e, buf, B, w, h, stride, fstride):
+    import torch
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE
+    cap = e.capacity()
+    d_gray = torch.from_numpy(buf).cuda()
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_gray.data_ptr(), B, w, h, stride, fstride, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                           d_n.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy()
+    desc = d_desc.cpu().numpy()
+    assert e.overflow() == 0
+    return [(kps[i, :n[i]].copy().view(KP_DTYPE).reshape(-1), desc[i, :n[i]]) for i in range(B)], (kps, desc, n)
+
+
+def test_fuzz_device_api(oracle):
+    """Odd widths, row strides, frame strides, batch sizes, exactly sized input buffers."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    rng = np.random.default_rng(3)
+    ran = 0
+    for c in range(_n(30)):
+        w, h = int(rng.integers(200, 900)), int(rng.integers(180, 700))
+        B = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 24]))
+        nf = int(rng.integers(100, 1500))
+        stride = w + int(rng.choice([0, 0, 1, 3, 4, 7, 64]))
+        fstride = stride * (h - 1) + w + int(rng.choice([0, 0, 1, 5, 64, 4096]))
+        buf = np.zeros(fstride * (B - 1) + stride * (h - 1) + w, np.uint8)  # exactly sized: not one byte of slack
+        imgs = []
+        for i in range(B):
+            img = synth_frame(int(rng.integers(0, 1 << 30)), h, w, sparse=bool(rng.integers(0, 2)))
+            imgs.append(img)
+            rows = np.lib.stride_tricks.as_strided(buf[i * fstride:], (h, w), (stride, 1))
+            rows[...] = img
+        try:
+            e = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+        except Exception:
+            continue
+        e.set_fast_mode(c & 1)
+        res, _ = _device_batch(e, buf, B, w, h, stride, fstride)
+        oe = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+        for i in sorted(set([0, B - 1, int(rng.integers(0, B))])):
+            ok, od = oe(imgs[i], cap=e.capacity() + 64)
+            assert _same(res[i][0], res[i][1], ok, od), (c, w, h, stride, fstride, B, nf, i)
+        ran += 1
+    assert ran >= 0.6 * _n(30)
+
+
+@pytest.mark.parametrize("gen,nframes", [("S", 200), ("S_tum", 96)])
+def test_sequence_batched_device_call(oracle, gen, nframes):
+    """BASELINE config 2 on the synthetic stand-in for the TUM sequence: N frames through ONE batched device call, every
+    frame's count, keypoint bit patterns, descriptor bytes and order against the oracle -- in both FAST variants, whose
+    padded output buffers must also be identical byte for byte."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    B = _n(nframes)
+    w, h = 640, 480
+    make = synth_frame if gen == "S" else synth_tum_like
+    frames = np.stack([make(s, h, w) for s in range(B)])
+    e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    expect = [oe(f) for f in frames]
+    raws = []
+    for mode in (0, 1):
+        e.set_fast_mode(mode, collect_stats=True)
+        res, raw = _device_batch(e, frames.reshape(-1), B, w, h, w, w * h)
+        for i in range(B):
+            assert _same(res[i][0], res[i][1], expect[i][0], expect[i][1]), (gen, mode, i)
+        raws.append(raw)
+        st = e.fast_stats()
+        if mode == 1:
+            assert st["row_steps"] > 0
+    for a, b in zip(raws[0], raws[1]):
+        assert np.array_equal(a, b)
+    ncand = [sum(len(oe.candidates(l)) for l in range(8))]
+    assert (ncand[0] > 20000) if gen == "S" else (1000 < ncand[0] < 12000)
