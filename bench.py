@@ -499,7 +499,9 @@ def pcie_leg(eng, d_src, w, h, F, nbatches=48):
     ev_cmp = [torch.cuda.Event() for _ in range(2)]
     ev_out = [torch.cuda.Event() for _ in range(2)]
 
-    def link_rate(fn, nbytes, reps=6):
+    def link_rate(fn, nbytes, reps=12):
+        for _ in range(3):   # first touches of the pinned pages / warm-up of the copy engines
+            fn()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(reps):

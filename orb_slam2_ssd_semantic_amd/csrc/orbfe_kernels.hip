@@ -1633,8 +1633,12 @@ hipError_t orbk_prepare_octree(int node_cap, int max_nini, int w, int h, int nce
     // The attribute is per kernel and process-wide: every handle sets it to the SAME value, the most the code can ever
     // request (the CU's 160 KB), so a later, smaller handle can never lower the limit under an earlier, larger one.
     const size_t lds = orbk_octree_lds_bytes(node_cap, max_nini, w, h, ncells);
-    if (lds > ORBFE_LDS_MAX) return hipErrorInvalidValue;
-    return hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORBFE_LDS_MAX);
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, (const void *)k_octree);
+    if (e != hipSuccess) return e;
+    const size_t lds_max = (size_t)ORBFE_LDS_MAX - fa.sharedSizeBytes;
+    if (lds > lds_max) return hipErrorInvalidValue;
+    return hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
 }
 
 hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st)

@@ -1591,9 +1591,14 @@ extern "C" orbfe_status orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocabu
                        (const double *)v->weight.p, v->L - levelsup, (const uint8_t *)m->b[0].p, n, (int32_t *)m->b[1].p,
                        (int32_t *)m->b[2].p, (double *)m->b[3].p);
     const size_t lds = (size_t)P * 16;
-    if (lds > ORBFE_LDS_MAX) { orbfe_set_error("orbfe_bow_transform: %d features need more than 160 KB of LDS", n); return ORBFE_ERR_SIZE; }
-    // process-wide per-kernel attribute: always the same value (the CU's 160 KB), so concurrent matchers cannot lower it
-    ORBFE_HIP(hipFuncSetAttribute((const void *)k_bow_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORBFE_LDS_MAX));
+    // The dynamic-LDS limit is a process-wide, per-kernel attribute: every caller sets it to the SAME value -- all of the
+    // CU's LDS that the kernel's static allocation leaves -- so concurrent matchers can never lower it under one another.
+    hipFuncAttributes fa;
+    ORBFE_HIP(hipFuncGetAttributes(&fa, (const void *)k_bow_aggregate));
+    const size_t lds_max = (size_t)ORBFE_LDS_MAX - fa.sharedSizeBytes;
+    if (lds > lds_max) { orbfe_set_error("orbfe_bow_transform: %d features need more than the CU's LDS", n); return ORBFE_ERR_SIZE; }
+    if (lds > 64 * 1024)
+        ORBFE_HIP(hipFuncSetAttribute((const void *)k_bow_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     hipLaunchKernelGGL(k_bow_aggregate, dim3(1), dim3(1024), lds, st, n, P, (const int32_t *)m->b[1].p,
                        (const int32_t *)m->b[2].p, (const double *)m->b[3].p, (uint32_t *)m->b[4].p, (double *)m->b[5].p,
                        (uint32_t *)m->b[6].p, (uint32_t *)m->b[7].p, (uint32_t *)m->b[8].p, (int32_t *)m->b[9].p);

@@ -1,0 +1,85 @@
+"""Round profile on the GPU box: rocprofv3 kernel statistics and PMC passes of the bench command, summarised into
+gpurun_out/<tag>_* (copy what should be judged into profiles/).
+
+usage (GPU box):  python tools/profile_round.py <tag> [bench args...]
+passes (each its own rocprofv3 run, as the microarchitecture guide prescribes: counters never share a run with a trace
+domain other than the kernel trace):
+   1. --kernel-trace --stats                  -> <tag>_kernel_stats.csv
+   2. --kernel-trace --pmc FETCH_SIZE         \
+   3. --kernel-trace --pmc WRITE_SIZE         /  -> <tag>_pmc_hbm.json (per kernel, per launch; 2 x FETCH + WRITE corrected bytes)
+   4. --kernel-trace --pmc VALUBusy           -> <tag>_pmc_valubusy.json
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+tag = sys.argv[1]
+bench_args = sys.argv[2:] or ["--no-extras", "--launches", "2", "--steps", "4", "--warmup", "2"]
+cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
+env = dict(os.environ, TMPDIR="/tmp")
+
+
+def kname(n):
+    return n.replace("void ", "").split("(")[0].split("<")[0]
+
+
+def rocprof(args, sub):
+    d = os.path.join(OUT, f"{tag}_{sub}")
+    shutil.rmtree(d, ignore_errors=True)
+    r = subprocess.run(["rocprofv3"] + args + ["--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return d, (json.loads(line[-1]) if line else None), r.returncode
+
+
+d, bench_line, rc = rocprof(["--kernel-trace", "--stats"], "trace")
+stats = glob.glob(os.path.join(d, "*", "*kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(OUT, f"{tag}_kernel_stats.csv"))
+    for r in csv.DictReader(open(stats[0])):
+        if r["Name"].startswith(("k_", "void k_")):
+            print("%-22s calls %5s avg_us %9.1f min %9.1f max %9.1f pct %5s" % (kname(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                                         float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+if bench_line:
+    json.dump(bench_line, open(os.path.join(OUT, f"{tag}_bench_under_rocprof.json"), "w"), indent=1)
+
+frames = bench_line["config"]["frames_per_launch"] if bench_line else None
+
+
+def pmc(counter):
+    d, _, _ = rocprof(["--kernel-trace", "--pmc", counter], "pmc_" + counter)
+    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    acc = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            k = kname(r["Kernel_Name"])
+            if k.startswith("k_") and r["Counter_Name"] == counter:
+                acc[k].append(float(r["Counter_Value"]))
+    shutil.rmtree(d, ignore_errors=True)
+    return {k: {"launches": len(v), "mean_per_launch": round(sum(v) / len(v), 1)} for k, v in acc.items()}
+
+
+fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
+hbm = {"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "frames_per_launch": frames,
+       "command": " ".join(["python", "bench.py"] + bench_args),
+       "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB per launch as reported. "
+               "gfx950 correction calibrated on this repo's access shapes (profiles/r01_fetch_calibration.txt): HBM read "
+               "bytes = 2 x FETCH_SIZE, HBM write bytes = WRITE_SIZE.",
+       "corrected_hbm_bytes_per_launch": {k: int((2 * fetch[k]["mean_per_launch"] + write.get(k, {"mean_per_launch": 0})["mean_per_launch"]) * 1024)
+                                          for k in fetch}}
+json.dump(hbm, open(os.path.join(OUT, f"{tag}_pmc_hbm.json"), "w"), indent=1)
+vb = pmc("VALUBusy")
+json.dump({"VALUBusy_percent": {k: v["mean_per_launch"] for k, v in vb.items()}, "frames_per_launch": frames,
+           "command": " ".join(["python", "bench.py"] + bench_args),
+           "note": "rocprofv3 --kernel-trace --pmc VALUBusy (derived metric), mean over the launches of each kernel"},
+          open(os.path.join(OUT, f"{tag}_pmc_valubusy.json"), "w"), indent=1)
+print(json.dumps(hbm["corrected_hbm_bytes_per_launch"]))
+print(json.dumps({k: v["mean_per_launch"] for k, v in vb.items()}))
+shutil.rmtree(os.path.join(OUT, f"{tag}_trace"), ignore_errors=True)
