@@ -42,14 +42,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from orb_slam2_ssd_semantic_amd.distributed import OverlappedKeyframeGather, all_gather_keyframes, shard_range  # noqa: E402
-from orb_slam2_ssd_semantic_amd.synth import synth_frame, synth_tum_like  # noqa: E402
+from orb_slam2_ssd_semantic_amd.synth import regular_vocabulary, synth_frame, synth_tum_like  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# VALU model of k_fast_map (tools/valu_count.py on the shipped kernel: VALU instructions of one row step of one wave;
-# tools/ubench/valu_rate.hip: one wave64 VALU instruction of this min/max/perm/packed-16 mix issues every ~4.2 clk per
-# SIMD).  256 CUs x 4 SIMDs; the clock is read from the device.
-VALU_MODEL = {"k_fast_map": {"valu_per_row_step": 286.0, "issue_clk": 4.2}}
-N_SIMD = 1024
+N_SIMD = 1024            # 256 CUs x 4 SIMDs
 
 
 def level_sizes(w, h, nlevels=8, sf=1.2):
@@ -252,6 +248,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the latency probe")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (rocprof runs): no PCIe leg, no "
                     "S_tum leg, no config 4, no CPU baselines")
+    ap.add_argument("--path", choices=["extract_match", "bow"], default="extract_match",
+                    help="bow: print the line of the device-resident ComputeBoW -> SearchByBoW chain instead")
     ap.add_argument("--fake", action="store_true", help="CPU stand-in over gloo (spawn-path test only)")
     args = ap.parse_args()
 
@@ -285,6 +283,11 @@ def main():
         if not fake:
             torch.cuda.synchronize()
 
+    if args.path == "bow":
+        if world != 1 or fake:
+            raise SystemExit("--path bow is a single-GPU line")
+        print(json.dumps(bow_leg(args, local_rank, steps=args.steps, warmup=args.warmup, standalone=True)), flush=True)
+        return
     w, h, F, NL, nf = args.width, args.height, args.frames, args.launches, args.nfeatures
     B = F * NL
     Engine = FakeEngine if fake else HipEngine
@@ -408,16 +411,30 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
                 "frac": round(gbs(dom) / HBM_PEAK_GBS, 5), "traffic": None,
                 "algorithmic_bytes_per_launch": int(ab[dom] * F), "launch_ms": round(stage_k[dom], 4),
                 "frames_per_launch": F}
-        # the FAST pass is bound by VALU issue, not by HBM: print that ceiling next to the HBM one
-        wc = ext.work_counts()
-        clk = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3 if hasattr(
-            torch.cuda.get_device_properties(local_rank), "clock_rate") else 2.4e9
-        vm = VALU_MODEL["k_fast_map"]
-        valu_min_ms = wc["fast_row_steps_per_frame"] * F * vm["valu_per_row_step"] * vm["issue_clk"] / (N_SIMD * clk) * 1e3
-        roof["valu_ceiling"] = {"kernel": "k_fast_map", "min_ms": round(valu_min_ms, 4), "measured_ms": round(stage_k["fast"], 4),
-                                "frac": round(valu_min_ms / stage_k["fast"], 4) if stage_k["fast"] > 0 else None,
-                                "model": "wave row steps/frame %d x %d frames x %.0f VALU instr x %.1f clk / (%d SIMDs x %.2f GHz)" %
-                                         (wc["fast_row_steps_per_frame"], F, vm["valu_per_row_step"], vm["issue_clk"], N_SIMD, clk / 1e9)}
+        # The FAST pass is bound by VALU issue, not by HBM: print that ceiling next to the HBM one.  Measured, not
+        # modelled: VALUBusy = share of the kernel's cycles in which the VALU was issuing, SQ_INSTS_VALU = wave
+        # instructions executed (rocprofv3 --pmc passes of this command, committed under profiles/).
+        clk = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3
+        P = [a * b for a, b in level_sizes(w, h)]
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if name.endswith("_pmc_valubusy.json") and name.startswith("r02"):
+                try:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    kn = roof["kernel"].split(" ")[0]
+                    vbusy = pj["VALUBusy_percent"][kn] / 100.0
+                    vc = {"kernel": kn, "valu_busy_frac": round(vbusy, 4), "frac": round(vbusy, 4),
+                          "min_ms_at_this_instruction_count": round(stage_k[dom] * vbusy, 4), "measured_ms": round(stage_k[dom], 4),
+                          "source": f"profiles/{name} (rocprofv3 --pmc VALUBusy / SQ_INSTS_VALU of this command; committed "
+                                    "file, not measured in this run)"}
+                    if "SQ_INSTS_VALU_per_launch" in pj and kn in pj["SQ_INSTS_VALU_per_launch"]:
+                        nv = pj["SQ_INSTS_VALU_per_launch"][kn] * F / pj.get("frames_per_launch", F)
+                        vc["wave_valu_insts_per_launch"] = int(nv)
+                        vc["lane_valu_insts_per_pixel"] = round(nv * 64 / (F * sum(P)), 2)
+                        vc["clk_per_wave_valu_inst_per_simd"] = round(stage_k[dom] * 1e-3 * clk * N_SIMD / nv, 3)
+                    roof["valu_ceiling"] = vc
+                    break
+                except Exception:
+                    pass
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             if name.endswith("_pmc_hbm.json") and name.startswith("r02"):
                 try:
@@ -464,6 +481,9 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
     c4 = config4_leg(args, rank, local_rank, world, fence)
     if rank == 0:
         result["config4"] = c4
+
+    if world == 1:
+        result["bow_chain"] = bow_leg(args, local_rank)
 
     if world == 1 and not args.no_cpu_baseline:
         # online (single-frame, host buffers in / out) latency of ORBextractor::operator(): replicas-only path
@@ -597,6 +617,94 @@ def workload_legs(args, eng, d_S, local_rank):
         row["mean_keypoints_per_frame"] = round(float(n[:F].float().mean().item()), 1)
         out[name] = row
     eng.ext.set_fast_mode(args.fast_mode)
+    return out
+
+
+def bow_leg(args, local_rank, npairs=256, steps=10, warmup=3, standalone=False):
+    """The device-resident chain behind Tracking / LoopClosing's BoW matching: extractor output block -> ComputeBoW for
+    every frame -> SearchByBoW(KeyFrame, Frame) for a batch of pairs, one stream, nothing leaves HBM in between.
+    256 pairs of 1000 x 1000 features (each frame against a shifted, re-noised view of itself), ORBvoc-shaped tree
+    (k = 10, L = 6, levelsup = 4 -> 100 FeatureVector nodes).  CPU side: the oracle's SearchByBoW / transform on one pair."""
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE, ORBextractor, ORBmatcher, ORBVocabulary
+    w, h, nf = args.width, args.height, args.nfeatures
+    B = 2 * npairs
+    stream = torch.cuda.current_stream().cuda_stream
+    ext = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, device=local_rank)
+    mat = ORBmatcher(0.7, True, device=local_rank)
+    voc = regular_vocabulary(10, 6, seed=3)
+    V = ORBVocabulary(mat, **voc)
+    cap = ext.capacity()
+    a = expand_frames(torch.from_numpy(base_frames("S", 32, w, h, 30000)).cuda(), npairs)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    b = torch.roll(a, shifts=(2, 3), dims=(1, 2)).to(torch.float32) + 2.5 * torch.randn(a.shape, device="cuda", generator=g)
+    frames = torch.cat([a, b.round().clamp(0, 255).to(torch.uint8)])
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")  # noqa: E731
+    d_kps, d_desc, d_n = z((B, cap, 7), torch.int32), z((B, cap, 32), torch.uint8), z(B, torch.int32)
+    bl = dict(f_word=z((B, cap), torch.int32), f_node=z((B, cap), torch.int32), f_weight=z((B, cap), torch.float64),
+              bow_id=z((B, cap), torch.int32), bow_val=z((B, cap), torch.float64), fv_node=z((B, cap), torch.int32),
+              fv_off=z((B, cap + 1), torch.int32), fv_idx=z((B, cap), torch.int32), counts=z((B, 4), torch.int32))
+    d_kf = torch.arange(0, npairs, dtype=torch.int32, device="cuda")
+    d_f = d_kf + npairs
+    d_match, d_nm = z((npairs, cap), torch.int32), z(npairs, torch.int32)
+    ext.extract_batch_device(frames.data_ptr(), B, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), stream)
+
+    def transform():
+        V.transform_batch_device(d_desc.data_ptr(), d_n.data_ptr(), B, cap, 4, bl["f_word"].data_ptr(), bl["f_node"].data_ptr(),
+                                 bl["f_weight"].data_ptr(), bl["bow_id"].data_ptr(), bl["bow_val"].data_ptr(),
+                                 bl["fv_node"].data_ptr(), bl["fv_off"].data_ptr(), bl["fv_idx"].data_ptr(), bl["counts"].data_ptr(), stream)
+
+    def search():
+        mat.SearchByBoW_batch_device(d_kps.data_ptr(), d_desc.data_ptr(), cap, None, bl["fv_node"].data_ptr(), bl["fv_off"].data_ptr(),
+                                     bl["fv_idx"].data_ptr(), bl["counts"].data_ptr(), d_kf.data_ptr(), d_f.data_ptr(), npairs,
+                                     d_match.data_ptr(), d_nm.data_ptr(), kf_kf=False, stream=stream)
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    t_tr = timed(transform)
+    t_se = timed(search)
+    n = d_n.cpu().numpy()
+    nm = d_nm.cpu().numpy()
+    counts = bl["counts"].cpu().numpy()
+    out = {"pairs": npairs, "features_per_frame": round(float(n.mean()), 1), "vocabulary": "k=10 L=6 (1 111 111 nodes), levelsup 4",
+           "fv_nodes_per_frame": round(float(counts[:, 1].mean()), 1), "mean_matches_per_pair": round(float(nm.mean()), 1),
+           "bow_transform_ms_per_batch": round(t_tr, 4), "bow_transform_us_per_frame": round(t_tr * 1e3 / B, 3),
+           "search_by_bow_ms_per_batch": round(t_se, 4), "search_by_bow_us_per_pair": round(t_se * 1e3 / npairs, 3)}
+    if not args.no_cpu_baseline:
+        from oracle import oracle_ffi as O
+        desc = d_desc.cpu().numpy()
+        kps = d_kps.cpu().numpy().view(KP_DTYPE).reshape(B, cap)
+        fvs, t0 = [], time.perf_counter()
+        for fidx in (0, npairs):
+            r = O.bow_transform(voc, desc[fidx, :n[fidx]], 4)
+            fvs.append((r["fv_node"], r["fv_off"], r["fv_idx"]))
+        t_cpu_tr = (time.perf_counter() - t0) / 2
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            om, on = O.search_by_bow(desc[0, :n[0]], None, kps["angle"][0, :n[0]], fvs[0], desc[npairs, :n[npairs]], None,
+                                     kps["angle"][npairs, :n[npairs]], fvs[1], 0.7, 50, False, True)
+        t_cpu_se = (time.perf_counter() - t0) / reps
+        assert np.array_equal(d_match[0, :n[npairs]].cpu().numpy(), om) and int(nm[0]) == on, "bow chain differs from the oracle"
+        out["cpu_oracle_search_by_bow_us_per_pair"] = round(t_cpu_se * 1e6, 1)
+        out["cpu_oracle_bow_transform_us_per_frame"] = round(t_cpu_tr * 1e6, 1)
+        out["search_speedup_vs_cpu_1thread"] = round(t_cpu_se * 1e6 / (t_se * 1e3 / npairs), 1)
+    if standalone:
+        return {"metric": "SearchByBoW (KeyFrame, Frame) pairs/sec, device-resident after ComputeBoW", "unit": "pairs/s",
+                "value": round(npairs / (t_se * 1e-3), 1), "n_gpus": 1, "steps": steps, "warmup": warmup,
+                "ms_per_step": round(t_se, 4), "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": "256 (KeyFrame, Frame) pairs of 1000 x 1000 ORB features, ~100 vocabulary nodes each"},
+                "bow_chain": out}
     return out
 
 

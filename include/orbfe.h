@@ -300,6 +300,33 @@ orbfe_status orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocabulary *v, co
 orbfe_status orbfe_distinctive_descriptors(orbfe_matcher *m, const uint8_t *pool, int32_t npool, const uint32_t *off,
                                            const uint32_t *idx, int32_t npoints, int32_t *best_idx, int32_t *median);
 
+/* ---- the same chain DEVICE-RESIDENT and BATCHED: extractor output block -> BoW -> SearchByBoW, one stream, no host
+ * round trip (Frame::ComputeBoW src/Frame.cc:546-555 / KeyFrame::ComputeBoW src/KeyFrame.cc:74-84, then
+ * ORBmatcher::SearchByBoW src/ORBmatcher.cc:217-363 / :665-812 for a batch of (KeyFrame, Frame) pairs).
+ *
+ * orbfe_bow_transform_batch_device: frame b owns `cap` slots of every array (cap + 1 of d_fv_off, 4 of d_counts):
+ *   in : d_desc [B][cap][32], d_n [B]               (what orbfe_extract_batch_device wrote; cap <= 8192)
+ *   out: d_f_word / d_f_node [B][cap] (-1 = no word / padding), d_f_weight [B][cap] doubles,
+ *        d_bow_id / d_bow_val [B][cap]  BowVector, ascending ids, L1-normalised,
+ *        d_fv_node [B][cap], d_fv_off [B][cap+1], d_fv_idx [B][cap]  FeatureVector CSR,
+ *        d_counts [B][4] = {nbow, nfv, number of indexed features, 0}
+ * orbfe_search_by_bow_batch_device: pair p = (KeyFrame d_kf[p], Frame d_f[p]), frame indices into the same blocks;
+ *   d_valid [B][cap] (1 = good MapPoint) or NULL = all; kf_kf = 0: SearchByBoW(KeyFrame*, Frame&) (`<= th_low`, d_valid
+ *   applies to the KeyFrame side only), kf_kf = 1: SearchByBoW(KeyFrame*, KeyFrame*) (`< th_low`, both sides);
+ *   d_match [P][cap]: KF feature index assigned to F feature i (-1 none; for kf_kf invert to get vpMatches12),
+ *   d_nmatches [P].  Both calls only enqueue on `stream` (NULL = HIP's default stream). */
+orbfe_status orbfe_bow_transform_batch_device(orbfe_matcher *m, const orbfe_vocabulary *v, const uint8_t *d_desc,
+                                              const int32_t *d_n, int32_t nframes, int32_t cap, int32_t levelsup,
+                                              int32_t *d_f_word, int32_t *d_f_node, double *d_f_weight,
+                                              uint32_t *d_bow_id, double *d_bow_val, uint32_t *d_fv_node,
+                                              uint32_t *d_fv_off, uint32_t *d_fv_idx, int32_t *d_counts, void *stream);
+orbfe_status orbfe_search_by_bow_batch_device(orbfe_matcher *m, const orbfe_keypoint *d_kps, const uint8_t *d_desc,
+                                              int32_t cap, const uint8_t *d_valid, const uint32_t *d_fv_node,
+                                              const uint32_t *d_fv_off, const uint32_t *d_fv_idx, const int32_t *d_counts,
+                                              const int32_t *d_kf, const int32_t *d_f, int32_t npairs, float nnratio,
+                                              int32_t th_low, int32_t kf_kf, int32_t check_ori, int32_t *d_match,
+                                              int32_t *d_nmatches, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1354,9 +1354,24 @@ __global__ __launch_bounds__(256) void k_bow_descend(const uint32_t *__restrict_
                                                      const double *__restrict__ weight, int nid_level,
                                                      const uint8_t *__restrict__ desc, int n,
                                                      int32_t *__restrict__ f_word, int32_t *__restrict__ f_node,
-                                                     double *__restrict__ f_weight)
+                                                     double *__restrict__ f_weight,
+                                                     const int32_t *__restrict__ n_arr, int stride)
 {
+    // batched form: frame blockIdx.y owns `stride` slots of every array and holds n_arr[frame] features
+    if (n_arr) {
+        const int b = blockIdx.y;
+        n = min(n_arr[b], stride);
+        desc += (int64_t)b * stride * 32;
+        f_word += (int64_t)b * stride;
+        f_node += (int64_t)b * stride;
+        f_weight += (int64_t)b * stride;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (n_arr && i >= n && i < stride) {  // padding slots carry "no word" so the buffers can be used as they are
+        f_word[i] = -1;
+        f_node[i] = -1;
+        f_weight[i] = 0.0;
+    }
     if (i >= n) return;
     Desc8 q;
     {
@@ -1431,8 +1446,22 @@ __global__ __launch_bounds__(1024) void k_bow_aggregate(int n, int P, const int3
                                                         const double *__restrict__ f_weight,
                                                         uint32_t *__restrict__ bow_id, double *__restrict__ bow_val,
                                                         uint32_t *__restrict__ fv_node, uint32_t *__restrict__ fv_off,
-                                                        uint32_t *__restrict__ fv_idx, int32_t *__restrict__ counts)
+                                                        uint32_t *__restrict__ fv_idx, int32_t *__restrict__ counts,
+                                                        const int32_t *__restrict__ n_arr, int stride)
 {
+    if (n_arr) {  // batched form: one workgroup per frame, `stride` slots per array (stride + 1 for fv_off, 4 counts)
+        const int b = blockIdx.x;
+        n = min(n_arr[b], stride);
+        f_word += (int64_t)b * stride;
+        f_node += (int64_t)b * stride;
+        f_weight += (int64_t)b * stride;
+        bow_id += (int64_t)b * stride;
+        bow_val += (int64_t)b * stride;
+        fv_node += (int64_t)b * stride;
+        fv_off += (int64_t)b * (stride + 1);
+        fv_idx += (int64_t)b * stride;
+        counts += (int64_t)b * 4;
+    }
     extern __shared__ unsigned long long s_key[];  // [P] keys, then [P] doubles
     double *s_val = (double *)(s_key + P);
     __shared__ int s_scan[1024];
@@ -1589,7 +1618,7 @@ extern "C" orbfe_status orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocabu
     hipLaunchKernelGGL(k_bow_descend, dim3((n + 255) / 256), dim3(256), 0, st, (const uint32_t *)v->child_off.p,
                        (const uint32_t *)v->child_idx.p, (const uint8_t *)v->node_desc.p, (const uint32_t *)v->word_id.p,
                        (const double *)v->weight.p, v->L - levelsup, (const uint8_t *)m->b[0].p, n, (int32_t *)m->b[1].p,
-                       (int32_t *)m->b[2].p, (double *)m->b[3].p);
+                       (int32_t *)m->b[2].p, (double *)m->b[3].p, (const int32_t *)nullptr, 0);
     const size_t lds = (size_t)P * 16;
     // The dynamic-LDS limit is a process-wide, per-kernel attribute: every caller sets it to the SAME value -- all of the
     // CU's LDS that the kernel's static allocation leaves -- so concurrent matchers can never lower it under one another.
@@ -1601,7 +1630,8 @@ extern "C" orbfe_status orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocabu
         ORBFE_HIP(hipFuncSetAttribute((const void *)k_bow_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     hipLaunchKernelGGL(k_bow_aggregate, dim3(1), dim3(1024), lds, st, n, P, (const int32_t *)m->b[1].p,
                        (const int32_t *)m->b[2].p, (const double *)m->b[3].p, (uint32_t *)m->b[4].p, (double *)m->b[5].p,
-                       (uint32_t *)m->b[6].p, (uint32_t *)m->b[7].p, (uint32_t *)m->b[8].p, (int32_t *)m->b[9].p);
+                       (uint32_t *)m->b[6].p, (uint32_t *)m->b[7].p, (uint32_t *)m->b[8].p, (int32_t *)m->b[9].p,
+                       (const int32_t *)nullptr, 0);
     ORBFE_HIP(hipGetLastError());
     int32_t counts[3] = {0, 0, 0};
     ORBFE_HIP(hipMemcpyAsync(counts, m->b[9].p, 12, hipMemcpyDeviceToHost, st));
@@ -1618,5 +1648,240 @@ extern "C" orbfe_status orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocabu
     ORBFE_HIP(hipMemcpy(fv_off, m->b[7].p, (size_t)(counts[1] + 1) * 4, hipMemcpyDeviceToHost));
     if (counts[1] > 0) ORBFE_HIP(hipMemcpy(fv_node, m->b[6].p, (size_t)counts[1] * 4, hipMemcpyDeviceToHost));
     if (counts[2] > 0) ORBFE_HIP(hipMemcpy(fv_idx, m->b[8].p, (size_t)counts[2] * 4, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Device-resident, batched chain behind Frame::ComputeBoW -> ORBmatcher::SearchByBoW: no host round trip between the
+// extractor's output block and the matches.
+//
+// K9b  k_search_by_bow_rows: SIXTEEN LANES (one DPP row) per KeyFrame vocabulary node, four nodes per wave.  The F
+// features of the matching node sit on the lanes; for every KF feature of the node (serial: the greedy "F feature already
+// claimed" rule, :273-274 / :725, couples them) all lanes evaluate their xor / popcount distance at once and two row
+// reductions (v_min over row_ror DPP moves) give best / first position / second.  Lists longer than a row are walked in
+// chunks of 16 in list order, merged with the reference's "earlier position wins" rule.  Claim flags of the first chunk
+// live in a register, later chunks re-read the match row (written by this very row only: nodes own disjoint features).
+// ---------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ uint32_t row_ror_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v)  // minimum over the 16 lanes of the DPP row, in every lane
+{
+    v = min(v, row_ror_u32<0x128>(v));  // row_ror:8
+    v = min(v, row_ror_u32<0x124>(v));  // row_ror:4
+    v = min(v, row_ror_u32<0x122>(v));  // row_ror:2
+    v = min(v, row_ror_u32<0x121>(v));  // row_ror:1
+    return v;
+}
+
+struct BowBatch {
+    const uint8_t *desc;        // [B][cap][32]
+    const orbfe_keypoint *kps;  // [B][cap]   (angles)
+    const uint8_t *valid;       // [B][cap] or null: 1 = the feature has a good MapPoint
+    const uint32_t *fv_node, *fv_off, *fv_idx;  // [B][cap], [B][cap+1], [B][cap]
+    const int32_t *counts;      // [B][4] {nbow, nfv, nidx, -}
+    const int32_t *kf, *f;      // [P] frame indices of the pairs
+    int32_t cap, npairs, th_low, strict_lt, use_valid_f, check_ori;
+    float nnratio;
+    int32_t *match;             // [P][cap] F feature -> KF feature, -1 none
+    int32_t *nmatches;          // [P]
+};
+
+__global__ __launch_bounds__(256) void k_search_by_bow_rows(BowBatch a)
+{
+    const int p = blockIdx.y;
+    const int kf = a.kf[p], f = a.f[p];
+    const int lane16 = threadIdx.x & 15;
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
+    const int nnK = a.counts[kf * 4 + 1], nnF = a.counts[f * 4 + 1];
+    const uint32_t *nodeK = a.fv_node + (int64_t)kf * a.cap, *offK = a.fv_off + (int64_t)kf * (a.cap + 1),
+                   *idxK = a.fv_idx + (int64_t)kf * a.cap;
+    const uint32_t *nodeF = a.fv_node + (int64_t)f * a.cap, *offF = a.fv_off + (int64_t)f * (a.cap + 1),
+                   *idxF = a.fv_idx + (int64_t)f * a.cap;
+    const uint8_t *descK = a.desc + (int64_t)kf * a.cap * 32, *descF = a.desc + (int64_t)f * a.cap * 32;
+    const uint8_t *validK = a.valid ? a.valid + (int64_t)kf * a.cap : nullptr;
+    const uint8_t *validF = (a.valid && a.use_valid_f) ? a.valid + (int64_t)f * a.cap : nullptr;
+    int32_t *match = a.match + (int64_t)p * a.cap;
+    for (int an = row; an < nnK; an += nrows) {  // row-uniform
+        const uint32_t node = nodeK[an];
+        int lo = 0, hi = nnF - 1, b = -1;  // lower_bound walk of :329-333 == binary search on sorted ids
+        while (lo <= hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t v = nodeF[mid];
+            if (v == node) { b = mid; break; }
+            if (v < node) lo = mid + 1; else hi = mid - 1;
+        }
+        if (b < 0) continue;
+        const uint32_t f0 = offF[b], nFb = offF[b + 1] - f0;
+        const uint32_t k0 = offK[an], nKa = offK[an + 1] - k0;
+        // chunk 0 of the F list stays in registers
+        Desc8 d0;
+        uint32_t rf0 = 0;
+        bool ok0 = lane16 < nFb;
+        if (ok0) {
+            rf0 = idxF[f0 + lane16];
+            if (validF && !validF[rf0]) ok0 = false;
+        }
+        {
+            const uint32_t *pf = (const uint32_t *)(descF + (int64_t)(ok0 ? rf0 : 0) * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d0.w[i] = pf[i];
+        }
+        for (uint32_t t = 0; t < nKa; ++t) {
+            const uint32_t rk = idxK[k0 + t];
+            if (validK && !validK[rk]) continue;  // !pMP || pMP->isBad() (:256-259)
+            Desc8 dk;
+            {
+                const uint32_t *pk = (const uint32_t *)(descK + (int64_t)rk * 32);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dk.w[i] = pk[i];
+            }
+            uint32_t b1 = 256, b2 = 256, bpos = 0xFFFFFu;  // running result over the chunks seen so far
+            for (uint32_t c0 = 0; c0 < nFb; c0 += 16) {
+                uint32_t dist = 0x3FFu;  // "no candidate"
+                if (c0 == 0) {
+                    if (ok0) {
+                        int d = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) d += __popc(dk.w[i] ^ d0.w[i]);
+                        dist = (uint32_t)d;
+                    }
+                } else if (c0 + lane16 < nFb) {
+                    const uint32_t rf = idxF[f0 + c0 + lane16];
+                    const bool free = __hip_atomic_load(&match[rf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0;
+                    if (free && !(validF && !validF[rf])) dist = (uint32_t)hamming8(dk, (const uint32_t *)(descF + (int64_t)rf * 32));
+                }
+                const uint32_t key = (dist << 20) | (c0 + lane16);        // smaller = closer, earlier position wins ties
+                const uint32_t k1 = row_min_u32(key);
+                const uint32_t k2 = row_min_u32(key == k1 ? 0xFFFFFFFFu : key);  // best of the OTHER candidates of the chunk
+                const uint32_t c1 = k1 >> 20, cs = min(k2 >> 20, 256u), cpos = k1 & 0xFFFFFu;
+                if (c1 < 0x3FFu) {   // merge: the running result covers earlier positions (first minimum wins)
+                    if (c1 < b1) { b2 = min(b1, cs); b1 = c1; bpos = cpos; }
+                    else { b2 = min(b2, c1); }
+                }
+            }
+            const bool pass = a.strict_lt ? ((int)b1 < a.th_low) : ((int)b1 <= a.th_low);
+            if (pass && bpos != 0xFFFFFu && (float)b1 < __fmul_rn(a.nnratio, (float)b2)) {
+                const uint32_t rf = bpos < 16 ? __shfl(rf0, (threadIdx.x & 48) + (int)bpos, 64) : idxF[f0 + bpos];
+                if (lane16 == 0) __hip_atomic_store(&match[rf], (int32_t)rk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // later chunk re-reads of this row see the claim
+                if (bpos == (uint32_t)lane16) ok0 = false;  // claimed (:273 vpMapPointMatches / :725 vbMatched2)
+            }
+        }
+    }
+}
+
+// rotation prune for the batched form: angles come from the keypoint records
+__global__ __launch_bounds__(256) void k_rot_prune_bow_batch(BowBatch a)
+{
+    __shared__ int s_hist[ORBFE_HISTO_LENGTH];
+    __shared__ int s_keep[3];
+    __shared__ int s_count;
+    const int tid = threadIdx.x, p = blockIdx.x;
+    const int kf = a.kf[p], f = a.f[p];
+    const orbfe_keypoint *kK = a.kps + (int64_t)kf * a.cap, *kF = a.kps + (int64_t)f * a.cap;
+    int32_t *match = a.match + (int64_t)p * a.cap;
+    if (tid < ORBFE_HISTO_LENGTH) s_hist[tid] = 0;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    if (a.check_ori) {
+        for (int i = tid; i < a.cap; i += 256) {
+            const int j = match[i];
+            if (j >= 0) atomicAdd(&s_hist[rot_bin(kK[j].angle, kF[i].angle)], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < ORBFE_HISTO_LENGTH; ++i) {
+                const int s = s_hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+            s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+        }
+        __syncthreads();
+    }
+    int local = 0;
+    for (int i = tid; i < a.cap; i += 256) {
+        const int j = match[i];
+        if (j < 0) continue;
+        if (a.check_ori) {
+            const int bin = rot_bin(kK[j].angle, kF[i].angle);
+            if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) { match[i] = -1; continue; }
+        }
+        ++local;
+    }
+    atomicAdd(&s_count, local);
+    __syncthreads();
+    if (tid == 0) a.nmatches[p] = s_count;
+}
+
+extern "C" orbfe_status orbfe_bow_transform_batch_device(orbfe_matcher *m, const orbfe_vocabulary *v, const uint8_t *d_desc,
+                                                         const int32_t *d_n, int32_t nframes, int32_t cap, int32_t levelsup,
+                                                         int32_t *d_f_word, int32_t *d_f_node, double *d_f_weight,
+                                                         uint32_t *d_bow_id, double *d_bow_val, uint32_t *d_fv_node,
+                                                         uint32_t *d_fv_off, uint32_t *d_fv_idx, int32_t *d_counts,
+                                                         void *stream)
+{
+    if (!m || !v || !d_desc || !d_n || nframes < 1 || cap < 1 || cap > BOW_MAX_FEATURES || !d_f_word || !d_f_node ||
+        !d_f_weight || !d_bow_id || !d_bow_val || !d_fv_node || !d_fv_off || !d_fv_idx || !d_counts) {
+        orbfe_set_error("bad argument to orbfe_bow_transform_batch_device (cap <= %d)", BOW_MAX_FEATURES);
+        return ORBFE_ERR_ARG;
+    }
+    if (v->device != m->device) { orbfe_set_error("vocabulary and matcher are on different devices"); return ORBFE_ERR_ARG; }
+    MDeviceGuard g(m->device);
+    hipStream_t st = (hipStream_t)stream;
+    int P = 2;
+    while (P < cap) P <<= 1;
+    const size_t lds = (size_t)P * 16;
+    hipFuncAttributes fa;
+    ORBFE_HIP(hipFuncGetAttributes(&fa, (const void *)k_bow_aggregate));
+    const size_t lds_max = (size_t)ORBFE_LDS_MAX - fa.sharedSizeBytes;
+    if (lds > lds_max) { orbfe_set_error("orbfe_bow_transform_batch_device: cap %d needs more than the CU's LDS", cap); return ORBFE_ERR_SIZE; }
+    if (lds > 64 * 1024)
+        ORBFE_HIP(hipFuncSetAttribute((const void *)k_bow_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    hipLaunchKernelGGL(k_bow_descend, dim3((cap + 255) / 256, nframes), dim3(256), 0, st, (const uint32_t *)v->child_off.p,
+                       (const uint32_t *)v->child_idx.p, (const uint8_t *)v->node_desc.p, (const uint32_t *)v->word_id.p,
+                       (const double *)v->weight.p, v->L - levelsup, d_desc, 0, d_f_word, d_f_node, d_f_weight, d_n, cap);
+    hipLaunchKernelGGL(k_bow_aggregate, dim3(nframes), dim3(1024), lds, st, 0, P, (const int32_t *)d_f_word,
+                       (const int32_t *)d_f_node, (const double *)d_f_weight, d_bow_id, d_bow_val, d_fv_node, d_fv_off,
+                       d_fv_idx, d_counts, d_n, cap);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_search_by_bow_batch_device(orbfe_matcher *m, const orbfe_keypoint *d_kps, const uint8_t *d_desc,
+                                                         int32_t cap, const uint8_t *d_valid, const uint32_t *d_fv_node,
+                                                         const uint32_t *d_fv_off, const uint32_t *d_fv_idx,
+                                                         const int32_t *d_counts, const int32_t *d_kf, const int32_t *d_f,
+                                                         int32_t npairs, float nnratio, int32_t th_low, int32_t kf_kf,
+                                                         int32_t check_ori, int32_t *d_match, int32_t *d_nmatches,
+                                                         void *stream)
+{
+    if (!m || !d_kps || !d_desc || cap < 1 || !d_fv_node || !d_fv_off || !d_fv_idx || !d_counts || !d_kf || !d_f ||
+        npairs < 0 || !d_match || !d_nmatches) {
+        orbfe_set_error("bad argument to orbfe_search_by_bow_batch_device");
+        return ORBFE_ERR_ARG;
+    }
+    if (npairs == 0) return ORBFE_OK;
+    MDeviceGuard g(m->device);
+    hipStream_t st = (hipStream_t)stream;
+    BowBatch a;
+    a.desc = d_desc; a.kps = d_kps; a.valid = d_valid;
+    a.fv_node = d_fv_node; a.fv_off = d_fv_off; a.fv_idx = d_fv_idx; a.counts = d_counts;
+    a.kf = d_kf; a.f = d_f;
+    a.cap = cap; a.npairs = npairs; a.th_low = th_low; a.strict_lt = kf_kf ? 1 : 0; a.use_valid_f = kf_kf ? 1 : 0;
+    a.check_ori = check_ori; a.nnratio = nnratio;
+    a.match = d_match; a.nmatches = d_nmatches;
+    ORBFE_HIP(hipMemsetAsync(d_match, 0xFF, sizeof(int32_t) * (size_t)npairs * cap, st));
+    hipLaunchKernelGGL(k_search_by_bow_rows, dim3(8, npairs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_rot_prune_bow_batch, dim3(npairs), dim3(256), 0, st, a);
+    ORBFE_HIP(hipGetLastError());
     return ORBFE_OK;
 }

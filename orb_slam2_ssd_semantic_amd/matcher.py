@@ -101,6 +101,16 @@ class ORBmatcher:
         check(st, "orbfe_search_by_bow")
         return m, n.value
 
+    def SearchByBoW_batch_device(self, d_kps, d_desc, cap, d_valid, d_fv_node, d_fv_off, d_fv_idx, d_counts, d_kf, d_f,
+                                 npairs, d_match, d_nmatches, kf_kf=False, th_low=None, stream=None):
+        """SearchByBoW for a batch of (KeyFrame, Frame) pairs taken from device-resident extractor / BoW blocks
+        (orbfe_search_by_bow_batch_device); device pointers (ints), asynchronous on `stream`."""
+        th_low = self.TH_LOW if th_low is None else th_low
+        check(self._L.orbfe_search_by_bow_batch_device(self._m, d_kps, d_desc, cap, d_valid, d_fv_node, d_fv_off, d_fv_idx,
+                                                       d_counts, d_kf, d_f, npairs, self.mfNNratio, th_low, int(kf_kf),
+                                                       int(self.mbCheckOrientation), d_match, d_nmatches, stream),
+              "orbfe_search_by_bow_batch_device")
+
     def HammingCSR(self, descQ, descT, off, cand):
         """best / second-best over per-query candidate lists (SearchByProjection family)."""
         q = np.ascontiguousarray(descQ, np.uint8).reshape(-1, 32)
@@ -222,6 +232,18 @@ class ORBVocabulary:
 
     def __del__(self):
         self.close()
+
+    @property
+    def handle(self):
+        return self._v
+
+    def transform_batch_device(self, d_desc, d_n, nframes, cap, levelsup, d_f_word, d_f_node, d_f_weight, d_bow_id,
+                               d_bow_val, d_fv_node, d_fv_off, d_fv_idx, d_counts, stream=None):
+        """Frame::ComputeBoW for every frame of an extractor output block, device pointers (ints), asynchronous on
+        `stream`: see orbfe_bow_transform_batch_device in include/orbfe.h for the layouts."""
+        check(self._L.orbfe_bow_transform_batch_device(self._mt._m, self._v, d_desc, d_n, nframes, cap, levelsup, d_f_word,
+                                                       d_f_node, d_f_weight, d_bow_id, d_bow_val, d_fv_node, d_fv_off,
+                                                       d_fv_idx, d_counts, stream), "orbfe_bow_transform_batch_device")
 
     def transform(self, desc, levelsup=4, per_feature=False):
         d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)

@@ -90,3 +90,24 @@ def synth_tum_like(seed, h=480, w=640):
         img[y0:y0 + ph, x0:x0 + pw] = img[y0:y0 + ph, x0:x0 + pw] * 0.25 + patch + 40.0
     img = _binomial5(img) + rng.normal(0.0, 1.6, (h, w))
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def regular_vocabulary(k=10, L=6, seed=0, zero_frac=0.0):
+    """Random DBoW2-shaped vocabulary tree (regular k-ary, depth L, breadth-first ids: children after parents) as the
+    arrays orbfe_vocabulary_create takes.  ORBvoc has k = 10, L = 6 (1 111 111 nodes, 10^6 words); the real file is
+    not in the container, so node descriptors are random and weights uniform -- the work per descriptor (L x k
+    Hamming distances) and the FeatureVector shape (k^(L - levelsup) nodes) are the real ones."""
+    rng = np.random.default_rng(seed)
+    level_start = np.concatenate([[0], np.cumsum([k ** l for l in range(L + 1)])])
+    nodes = int(level_start[-1])
+    inner = int(level_start[L])                      # nodes that have children
+    child_off = np.concatenate([np.arange(inner + 1, dtype=np.int64) * k, np.full(nodes - inner, inner * k, np.int64)])
+    child_idx = np.arange(1, nodes, dtype=np.uint32)  # children of node i are 1 + i*k .. 1 + i*k + k - 1
+    node_desc = rng.integers(0, 256, (nodes, 32), dtype=np.uint8)
+    word_id = np.zeros(nodes, np.uint32)
+    word_id[inner:] = np.arange(nodes - inner, dtype=np.uint32)
+    weight = rng.uniform(0.1, 9.0, nodes)
+    if zero_frac > 0:
+        weight[rng.random(nodes) < zero_frac] = 0.0
+    return dict(child_off=child_off.astype(np.uint32), child_idx=child_idx, node_desc=node_desc, word_id=word_id,
+                weight=weight, L=L)

@@ -53,17 +53,21 @@ if bench_line:
 frames = bench_line["config"]["frames_per_launch"] if bench_line else None
 
 
-def pmc(counter):
-    d, _, _ = rocprof(["--kernel-trace", "--pmc", counter], "pmc_" + counter)
+def pmc_multi(counters):
+    d, _, _ = rocprof(["--kernel-trace", "--pmc"] + counters, "pmc_" + counters[0])
     f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
-    acc = collections.defaultdict(list)
+    acc = {c: collections.defaultdict(list) for c in counters}
     if f:
         for r in csv.DictReader(open(f[0])):
             k = kname(r["Kernel_Name"])
-            if k.startswith("k_") and r["Counter_Name"] == counter:
-                acc[k].append(float(r["Counter_Value"]))
+            if k.startswith("k_") and r["Counter_Name"] in acc:
+                acc[r["Counter_Name"]][k].append(float(r["Counter_Value"]))
     shutil.rmtree(d, ignore_errors=True)
-    return {k: {"launches": len(v), "mean_per_launch": round(sum(v) / len(v), 1)} for k, v in acc.items()}
+    return {c: {k: {"launches": len(v), "mean_per_launch": round(sum(v) / len(v), 1)} for k, v in a.items()} for c, a in acc.items()}
+
+
+def pmc(counter):
+    return pmc_multi([counter])[counter]
 
 
 fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
@@ -76,10 +80,16 @@ hbm = {"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "frames_per_launch": fram
                                           for k in fetch}}
 json.dump(hbm, open(os.path.join(OUT, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 vb = pmc("VALUBusy")
+sq = pmc_multi(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"])
 json.dump({"VALUBusy_percent": {k: v["mean_per_launch"] for k, v in vb.items()}, "frames_per_launch": frames,
+           "SQ_INSTS_VALU_per_launch": {k: v["mean_per_launch"] for k, v in sq["SQ_INSTS_VALU"].items()},
+           "SQ_INSTS_SALU_per_launch": {k: v["mean_per_launch"] for k, v in sq["SQ_INSTS_SALU"].items()},
+           "SQ_WAVES_per_launch": {k: v["mean_per_launch"] for k, v in sq["SQ_WAVES"].items()},
            "command": " ".join(["python", "bench.py"] + bench_args),
-           "note": "rocprofv3 --kernel-trace --pmc VALUBusy (derived metric), mean over the launches of each kernel"},
+           "note": "rocprofv3 --kernel-trace --pmc VALUBusy (derived metric) and, in another pass, SQ_INSTS_VALU / SQ_INSTS_SALU / "
+                   "SQ_WAVES (wave-level instruction counts); mean over the launches of each kernel"},
           open(os.path.join(OUT, f"{tag}_pmc_valubusy.json"), "w"), indent=1)
 print(json.dumps(hbm["corrected_hbm_bytes_per_launch"]))
 print(json.dumps({k: v["mean_per_launch"] for k, v in vb.items()}))
+print(json.dumps({k: v["mean_per_launch"] for k, v in sq["SQ_INSTS_VALU"].items()}))
 shutil.rmtree(os.path.join(OUT, f"{tag}_trace"), ignore_errors=True)
