@@ -414,7 +414,7 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
         # The FAST pass is bound by VALU issue, not by HBM: print that ceiling next to the HBM one.  Measured, not
         # modelled: VALUBusy = share of the kernel's cycles in which the VALU was issuing, SQ_INSTS_VALU = wave
         # instructions executed (rocprofv3 --pmc passes of this command, committed under profiles/).
-        clk = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3
+        clk = getattr(torch.cuda.get_device_properties(local_rank), "clock_rate", 2.4e6) * 1e3  # kHz -> Hz (2.4 GHz: profiles/r02_valu_mix.json)
         P = [a * b for a, b in level_sizes(w, h)]
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             if name.endswith("_pmc_valubusy.json") and name.startswith("r02"):
@@ -427,7 +427,7 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
                           "source": f"profiles/{name} (rocprofv3 --pmc VALUBusy / SQ_INSTS_VALU of this command; committed "
                                     "file, not measured in this run)"}
                     if "SQ_INSTS_VALU_per_launch" in pj and kn in pj["SQ_INSTS_VALU_per_launch"]:
-                        nv = pj["SQ_INSTS_VALU_per_launch"][kn] * F / pj.get("frames_per_launch", F)
+                        nv = pj["SQ_INSTS_VALU_per_launch"][kn] * F / (pj.get("frames_per_launch") or F)
                         vc["wave_valu_insts_per_launch"] = int(nv)
                         vc["lane_valu_insts_per_pixel"] = round(nv * 64 / (F * sum(P)), 2)
                         vc["clk_per_wave_valu_inst_per_simd"] = round(stage_k[dom] * 1e-3 * clk * N_SIMD / nv, 3)
@@ -443,7 +443,7 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
                     # gfx950: FETCH_SIZE reports half of the read bytes (calibrated on this repo's access shapes,
                     # profiles/r01_fetch_calibration.txt), WRITE_SIZE is exact
                     tb = (2 * pj["FETCH_SIZE_KB"][kn]["mean_per_launch"] + pj["WRITE_SIZE_KB"][kn]["mean_per_launch"]) * 1024
-                    roof["traffic"] = int(tb * F / pj.get("frames_per_launch", F))
+                    roof["traffic"] = int(tb * F / (pj.get("frames_per_launch") or F))
                     roof["traffic_source"] = (f"profiles/{name}: 2 x FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 "
                                               "--pmc passes of this command (committed file, not measured in this run)")
                     break

@@ -50,7 +50,7 @@ if stats:
 if bench_line:
     json.dump(bench_line, open(os.path.join(OUT, f"{tag}_bench_under_rocprof.json"), "w"), indent=1)
 
-frames = bench_line["config"]["frames_per_launch"] if bench_line else None
+frames = bench_line["config"]["frames_per_launch"] if bench_line else 1024
 
 
 def pmc_multi(counters):
