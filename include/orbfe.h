@@ -200,6 +200,9 @@ orbfe_status orbfe_match_bf(orbfe_matcher *m, const uint8_t *q, int32_t nq, cons
                             int32_t check_ori, int32_t *match_q2t, int32_t *best, int32_t *second,
                             int32_t *nmatches);
 void *orbfe_matcher_get_stream(orbfe_matcher *m);
+/* all-pairs kernel behind the three orbfe_match_bf* calls: 0 (default) = exact int8 dot product on the matrix cores
+ * (dot = 128 * (128 - hamming)), 1 = xor / popcount.  Results are identical; see DESIGN.md for the measured A/B. */
+orbfe_status orbfe_matcher_set_bf_kernel(orbfe_matcher *m, int32_t kernel);
 /* same, DEVICE buffers, enqueued on `stream` (NULL = HIP's default stream, see orbfe_extract_batch_device;
  * orbfe_matcher_get_stream(m) = the matcher's own stream), no synchronisation;
  * d_nmatches is one int32 in device memory */

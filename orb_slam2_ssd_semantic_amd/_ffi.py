@@ -29,7 +29,7 @@ SYMBOLS = (
     "orbfe_search_by_bow", "orbfe_hamming_csr", "orbfe_assign_grid", "orbfe_features_in_area",
     "orbfe_distinctive_descriptors", "orbfe_stereo_matches", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
     "orbfe_bow_transform", "orbfe_get_overflow", "orbfe_set_fast_mode", "orbfe_get_fast_stats", "orbfe_get_work_counts",
-    "orbfe_bow_transform_batch_device", "orbfe_search_by_bow_batch_device",
+    "orbfe_bow_transform_batch_device", "orbfe_search_by_bow_batch_device", "orbfe_matcher_set_bf_kernel",
 )
 
 
@@ -87,6 +87,7 @@ def lib():
     L.orbfe_tap_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
     L.orbfe_tap_selected.argtypes = [vp, i32, i32, vp, i32, vp]
     L.orbfe_get_work_counts.argtypes = [vp, vp]
+    L.orbfe_matcher_set_bf_kernel.argtypes = [vp, i32]
     L.orbfe_bow_transform_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32] + [vp] * 10
     L.orbfe_search_by_bow_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, i32, vp, vp, vp]
     L.orbfe_get_overflow.argtypes = [vp, vp]

@@ -6,7 +6,10 @@
 //   SearchByBoW (KF,F) / (KF,KF)       src/ORBmatcher.cc:217-363 / :665-812
 //   rotation histogram + prune         src/ORBmatcher.cc:308-316, :338-360
 //   ComputeThreeMaxima                 src/ORBmatcher.cc:1912-1957
-// Bit work on v_bcnt_u32_b32 (popcount-accumulate); no MFMA.  No CPU path.
+// Candidate-list matchers (SearchByBoW, CSR Hamming, stereo, BoW descent, distinctive descriptors): xor + v_bcnt_u32_b32.
+// All-pairs brute force (M3): by default an EXACT int8 dot product on the matrix cores (k_match_bf); the xor / popcount
+// all-pairs kernel the north star names is kept as k_match_popc (orbfe_matcher_set_bf_kernel), bit-identical, slower
+// (profiles/r02_match_variants.json).  No CPU path.
 #include <algorithm>
 #include <new>
 
@@ -294,6 +297,81 @@ __global__ __launch_bounds__(BM_WAVES * 64, 2) void k_match_bf(const uint8_t *__
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K8b  brute force by xor / popcount (the all-pairs formulation BASELINE.json's north star names; kept for the A/B).
+// One lane per query (descriptor in 8 VGPRs), the train rows stream through LDS in tiles of 128 and are read as
+// broadcasts; per distance 8 v_xor + 8 v_bcnt_u32_b32 (accumulating) + 4 ranking ops on the unique key
+// (distance << 22 | train index): b2 = min(b2, max(b1, k)); b1 = min(b1, k) keeps the two smallest keys, i.e. best
+// distance with the lowest index and the second-smallest distance with multiplicity -- the reference's update idiom.
+// Same arguments, same outputs as k_match_bf.
+// ---------------------------------------------------------------------------------------------------
+#define BP_TILE 128
+__global__ __launch_bounds__(256) void k_match_popc(const uint8_t *__restrict__ q_base, const uint8_t *__restrict__ t_base,
+                                                    const int32_t *__restrict__ n_arr, const int32_t *__restrict__ qframe,
+                                                    const int32_t *__restrict__ tframe, int cap, int nq_s, int nt_s,
+                                                    float nnratio, int th, int32_t *__restrict__ match,
+                                                    int32_t *__restrict__ best_o, int32_t *__restrict__ second_o)
+{
+    __shared__ uint4 s_t[BP_TILE][2];
+    const int pair = blockIdx.y;
+    const uint8_t *q = q_base, *t = t_base;
+    int nq = nq_s, nt = nt_s;
+    int64_t out0 = 0;
+    if (n_arr) {
+        const int qf = qframe[pair], tf = tframe[pair];
+        q = q_base + (int64_t)qf * cap * 32;
+        t = t_base + (int64_t)tf * cap * 32;
+        nq = min(n_arr[qf], cap);
+        nt = min(n_arr[tf], cap);
+        out0 = (int64_t)pair * cap;
+    }
+    const int tid = threadIdx.x;
+    const int qi = blockIdx.x * 256 + tid;
+    const int nslots = n_arr ? cap : nq;
+    if (blockIdx.x * 256 >= nslots) return;
+    uint32_t qw[8];
+    {
+        const uint4 *pq = (const uint4 *)(q + (int64_t)min(qi, max(nq - 1, 0)) * 32);
+        const uint4 a = nq > 0 ? pq[0] : make_uint4(0, 0, 0, 0), b = nq > 0 ? pq[1] : make_uint4(0, 0, 0, 0);
+        qw[0] = a.x; qw[1] = a.y; qw[2] = a.z; qw[3] = a.w; qw[4] = b.x; qw[5] = b.y; qw[6] = b.z; qw[7] = b.w;
+    }
+    uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+    for (int T = 0; T < nt; T += BP_TILE) {
+        __syncthreads();
+        {
+            const int r = tid >> 1, hf = tid & 1;   // 256 threads stage 128 rows x 2 halves
+            s_t[r][hf] = ((const uint4 *)(t + (int64_t)min(T + r, nt - 1) * 32))[hf];
+        }
+        __syncthreads();
+        const int rows = min(BP_TILE, nt - T);
+        for (int r = 0; r < rows; ++r) {
+            const uint4 a = s_t[r][0], b = s_t[r][1];
+            uint32_t d = __popc(qw[0] ^ a.x);
+            d += __popc(qw[1] ^ a.y);
+            d += __popc(qw[2] ^ a.z);
+            d += __popc(qw[3] ^ a.w);
+            d += __popc(qw[4] ^ b.x);
+            d += __popc(qw[5] ^ b.y);
+            d += __popc(qw[6] ^ b.z);
+            d += __popc(qw[7] ^ b.w);
+            const uint32_t k = (d << 22) | (uint32_t)(T + r);
+            k2 = min(k2, max(k1, k));
+            k1 = min(k1, k);
+        }
+    }
+    if (qi < nslots) {
+        const bool valid = qi < nq;
+        const int best = k1 != 0xFFFFFFFFu ? (int)(k1 >> 22) : 256;
+        const int second = k2 != 0xFFFFFFFFu ? (int)(k2 >> 22) : 256;
+        const int idx = k1 != 0xFFFFFFFFu ? (int)(k1 & 0x3FFFFFu) : -1;
+        int m = -1;
+        if (valid && idx >= 0 && best <= th && (float)best < __fmul_rn(nnratio, (float)second)) m = idx;
+        match[out0 + qi] = m;
+        if (best_o) best_o[out0 + qi] = valid ? best : 256;
+        if (second_o) second_o[out0 + qi] = valid ? second : 256;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K10  rotation-consistency histogram over accepted matches, ComputeThreeMaxima, prune, count.
 // One workgroup per pair.  key i is kept when its bin is one of the three maxima.
 // angles: element i of side X is at X_ang[i * stride] (stride 1 for plain arrays, 7 for orbfe_keypoint).
@@ -526,6 +604,7 @@ struct orbfe_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
     MDevBuf b[16];
+    int bf_kernel = 0;  // 0 = k_match_bf (int8 dot product on the matrix cores), 1 = k_match_popc (xor / popcount)
 };
 
 struct MDeviceGuard {
@@ -581,6 +660,13 @@ extern "C" orbfe_status orbfe_matcher_create(int32_t device, orbfe_matcher **out
 
 extern "C" void *orbfe_matcher_get_stream(orbfe_matcher *m) { return m ? (void *)m->stream : nullptr; }
 
+extern "C" orbfe_status orbfe_matcher_set_bf_kernel(orbfe_matcher *m, int32_t kernel)
+{
+    if (!m || kernel < 0 || kernel > 1) return ORBFE_ERR_ARG;
+    m->bf_kernel = kernel;
+    return ORBFE_OK;
+}
+
 extern "C" void orbfe_matcher_destroy(orbfe_matcher *m)
 {
     if (!m) return;
@@ -591,15 +677,19 @@ extern "C" void orbfe_matcher_destroy(orbfe_matcher *m)
     delete m;
 }
 
-static orbfe_status launch_bf(const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, const float *d_qa,
+static orbfe_status launch_bf(int kernel, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, const float *d_qa,
                               const float *d_ta, int ang_stride, float nnratio, int th, int check_ori,
                               int32_t *d_match, int32_t *d_best, int32_t *d_second, int32_t *d_nm, hipStream_t st)
 {
     if (nq > 0) {
-        dim3 grid((nq + BM_QW - 1) / BM_QW, 1);
-        hipLaunchKernelGGL(k_match_bf, grid, dim3(BM_WAVES * 64), 0, st, d_q, d_t, (const int32_t *)nullptr,
-                           (const int32_t *)nullptr, (const int32_t *)nullptr, 0, nq, nt, nnratio, th, d_match, d_best,
-                           d_second);
+        if (kernel == 1)
+            hipLaunchKernelGGL(k_match_popc, dim3((nq + 255) / 256, 1), dim3(256), 0, st, d_q, d_t, (const int32_t *)nullptr,
+                               (const int32_t *)nullptr, (const int32_t *)nullptr, 0, nq, nt, nnratio, th, d_match, d_best,
+                               d_second);
+        else
+            hipLaunchKernelGGL(k_match_bf, dim3((nq + BM_QW - 1) / BM_QW, 1), dim3(BM_WAVES * 64), 0, st, d_q, d_t,
+                               (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0, nq, nt,
+                               nnratio, th, d_match, d_best, d_second);
         ORBFE_HIP(hipGetLastError());
     }
     const int ori = (check_ori && d_qa && d_ta) ? 1 : 0;
@@ -619,7 +709,7 @@ extern "C" orbfe_status orbfe_match_bf_device(orbfe_matcher *m, const uint8_t *d
         return ORBFE_ERR_ARG;
     }
     MDeviceGuard g(m->device);
-    return launch_bf(d_q, nq, d_t, nt, d_q_angle, d_t_angle, 1, nnratio, th, check_ori, d_match_q2t, d_best, d_second,
+    return launch_bf(m->bf_kernel, d_q, nq, d_t, nt, d_q_angle, d_t_angle, 1, nnratio, th, check_ori, d_match_q2t, d_best, d_second,
                      d_nmatches, (hipStream_t)stream);
 }
 
@@ -653,7 +743,7 @@ extern "C" orbfe_status orbfe_match_bf(orbfe_matcher *m, const uint8_t *q, int32
         ORBFE_HIP(hipMemcpyAsync(m->b[2].p, q_angle, (size_t)nq * 4, hipMemcpyHostToDevice, st));
         if (nt > 0) ORBFE_HIP(hipMemcpyAsync(m->b[3].p, t_angle, (size_t)nt * 4, hipMemcpyHostToDevice, st));
     }
-    orbfe_status s = launch_bf((const uint8_t *)m->b[0].p, nq, (const uint8_t *)m->b[1].p, nt,
+    orbfe_status s = launch_bf(m->bf_kernel, (const uint8_t *)m->b[0].p, nq, (const uint8_t *)m->b[1].p, nt,
                                ori ? (const float *)m->b[2].p : nullptr, ori ? (const float *)m->b[3].p : nullptr, 1,
                                nnratio, th, ori ? 1 : 0, (int32_t *)m->b[4].p, (int32_t *)m->b[5].p,
                                (int32_t *)m->b[6].p, (int32_t *)m->b[7].p, st);
@@ -682,9 +772,13 @@ extern "C" orbfe_status orbfe_match_bf_frames_device(orbfe_matcher *m, const orb
     if (npairs == 0) return ORBFE_OK;
     MDeviceGuard g(m->device);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((cap + BM_QW - 1) / BM_QW, npairs);
-    hipLaunchKernelGGL(k_match_bf, grid, dim3(BM_WAVES * 64), 0, st, d_desc, d_desc, d_n, d_qframe, d_tframe, cap, 0, 0,
-                       nnratio, th, d_match_q2t, (int32_t *)nullptr, (int32_t *)nullptr);
+    if (m->bf_kernel == 1)
+        hipLaunchKernelGGL(k_match_popc, dim3((cap + 255) / 256, npairs), dim3(256), 0, st, d_desc, d_desc, d_n, d_qframe,
+                           d_tframe, cap, 0, 0, nnratio, th, d_match_q2t, (int32_t *)nullptr, (int32_t *)nullptr);
+    else
+        hipLaunchKernelGGL(k_match_bf, dim3((cap + BM_QW - 1) / BM_QW, npairs), dim3(BM_WAVES * 64), 0, st, d_desc, d_desc,
+                           d_n, d_qframe, d_tframe, cap, 0, 0, nnratio, th, d_match_q2t, (int32_t *)nullptr,
+                           (int32_t *)nullptr);
     ORBFE_HIP(hipGetLastError());
     const float *ang = &d_kps->angle;  // orbfe_keypoint.angle, stride 7 floats
     hipLaunchKernelGGL(k_rot_prune, dim3(npairs), dim3(256), 0, st, d_match_q2t, ang, ang, 7, d_n, d_qframe, d_tframe,
@@ -1692,9 +1786,11 @@ struct BowBatch {
 
 __global__ __launch_bounds__(256) void k_search_by_bow_rows(BowBatch a)
 {
+    __shared__ uint4 s_dk[16][16][2];
+    __shared__ uint32_t s_rk[16][16];
     const int p = blockIdx.y;
     const int kf = a.kf[p], f = a.f[p];
-    const int lane16 = threadIdx.x & 15;
+    const int lane16 = threadIdx.x & 15, rowb = threadIdx.x >> 4;
     const int row = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
     const int nnK = a.counts[kf * 4 + 1], nnF = a.counts[f * 4 + 1];
     const uint32_t *nodeK = a.fv_node + (int64_t)kf * a.cap, *offK = a.fv_off + (int64_t)kf * (a.cap + 1),
@@ -1731,13 +1827,28 @@ __global__ __launch_bounds__(256) void k_search_by_bow_rows(BowBatch a)
             for (int i = 0; i < 8; ++i) d0.w[i] = pf[i];
         }
         for (uint32_t t = 0; t < nKa; ++t) {
-            const uint32_t rk = idxK[k0 + t];
-            if (validK && !validK[rk]) continue;  // !pMP || pMP->isBad() (:256-259)
+            // the KF features of the node are staged 16 at a time in LDS (index, MapPoint flag, descriptor): the serial
+            // loop below then depends on LDS latency only, not on two dependent global loads per feature
+            if ((t & 15u) == 0u) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // earlier reads of the staging area are done
+                uint32_t rk_l = 0xFFFFFFFFu;
+                if (t + lane16 < nKa) {
+                    rk_l = idxK[k0 + t + lane16];
+                    if (validK && !validK[rk_l]) rk_l = 0xFFFFFFFFu;  // !pMP || pMP->isBad() (:256-259)
+                }
+                s_rk[rowb][lane16] = rk_l;
+                const uint4 *pk = (const uint4 *)(descK + (int64_t)(rk_l == 0xFFFFFFFFu ? 0u : rk_l) * 32);
+                s_dk[rowb][lane16][0] = pk[0];
+                s_dk[rowb][lane16][1] = pk[1];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            const uint32_t rk = s_rk[rowb][t & 15u];
+            if (rk == 0xFFFFFFFFu) continue;
             Desc8 dk;
             {
-                const uint32_t *pk = (const uint32_t *)(descK + (int64_t)rk * 32);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) dk.w[i] = pk[i];
+                const uint4 q0 = s_dk[rowb][t & 15u][0], q1 = s_dk[rowb][t & 15u][1];
+                dk.w[0] = q0.x; dk.w[1] = q0.y; dk.w[2] = q0.z; dk.w[3] = q0.w;
+                dk.w[4] = q1.x; dk.w[5] = q1.y; dk.w[6] = q1.z; dk.w[7] = q1.w;
             }
             uint32_t b1 = 256, b2 = 256, bpos = 0xFFFFFu;  // running result over the chunks seen so far
             for (uint32_t c0 = 0; c0 < nFb; c0 += 16) {

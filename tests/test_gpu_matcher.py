@@ -162,3 +162,47 @@ def test_batched_frame_pairs_device(oracle):
         got = dm[p].cpu().numpy()
         assert np.array_equal(got[:n[p + 1]], ref[0]) and (got[n[p + 1]:] == -1).all()
         assert int(dnm[p]) == ref[3]
+
+
+@pytest.mark.parametrize("seed,nq,nt", [(0, 1000, 1004), (1, 37, 2100), (2, 1, 5), (3, 300, 1), (4, 257, 129), (5, 0, 10),
+                                        (6, 10, 0), (7, 4000, 4030)])
+def test_popcount_all_pairs_kernel_equals_mfma_kernel_and_oracle(oracle, seed, nq, nt):
+    """The xor / popcount all-pairs kernel the north star names (kept for the A/B against the matrix-core kernel) returns
+    the same matches, best and second distances, on host buffers and in the batched device form."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import ORBmatcher, _ffi
+    rng = np.random.default_rng(900 + seed)
+    t = make_desc(rng, nt)
+    q = make_desc(rng, nq, base=t[rng.integers(0, nt, nq)], flips=40) if nt and nq else make_desc(rng, nq)
+    if nt > 8:
+        t[rng.integers(0, nt, nt // 5)] = t[rng.integers(0, nt, nt // 5)]   # duplicate rows: lowest index wins, second == best
+    qa = rng.uniform(0, 360, nq).astype(np.float32)
+    ta = rng.uniform(0, 360, nt).astype(np.float32)
+    ref = oracle.match_bf(q, t, qa, ta, 0.9, 100, True)
+    outs = []
+    for kern in (0, 1):
+        m = ORBmatcher(0.9, True)
+        m.set_bf_kernel(kern)
+        got = m.MatchBruteForce(q, t, qa, ta, 100)
+        assert all(np.array_equal(g, r) for g, r in zip(got[:3], ref[:3])) and got[3] == ref[3], kern
+        outs.append(got)
+    if nq and nt:   # batched device form: two "frames" (q, t) padded to cap
+        cap = max(nq, nt) + 5
+        desc = np.zeros((2, cap, 32), np.uint8)
+        desc[0, :nq], desc[1, :nt] = q, t
+        kps = np.zeros((2, cap, 7), np.float32)
+        kps[0, :nq, 3], kps[1, :nt, 3] = qa, ta
+        dd, dk = torch.from_numpy(desc).cuda(), torch.from_numpy(kps).cuda()
+        dn = torch.tensor([nq, nt], dtype=torch.int32, device="cuda")
+        qf, tf = torch.tensor([0], dtype=torch.int32, device="cuda"), torch.tensor([1], dtype=torch.int32, device="cuda")
+        for kern in (0, 1):
+            m = ORBmatcher(0.9, True)
+            m.set_bf_kernel(kern)
+            dm = torch.full((1, cap), -7, dtype=torch.int32, device="cuda")
+            dnm = torch.zeros(1, dtype=torch.int32, device="cuda")
+            rc = _ffi.lib().orbfe_match_bf_frames_device(m.handle, dk.data_ptr(), dd.data_ptr(), dn.data_ptr(), cap, qf.data_ptr(),
+                                                         tf.data_ptr(), 1, 0.9, 100, 1, dm.data_ptr(), dnm.data_ptr(), None)
+            assert rc == 0
+            torch.cuda.synchronize()
+            got = dm[0].cpu().numpy()
+            assert np.array_equal(got[:nq], ref[0]) and (got[nq:] == -1).all() and int(dnm[0]) == ref[3], kern
