@@ -129,13 +129,12 @@ struct PyrArgs {
     const OrbTab *xtab, *ytab;  // cv::resize taps of the two axes (host-built, 4-entry aligned, padded by 4 entries)
 };
 
-__global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
+// one lane's work: 4 adjacent destination pixels x PY_RB rows of frame b; `flat` indexes (row block, 4-pixel column group)
+__device__ __forceinline__ void pyr_lane(const PyrArgs &a, int b, int flat)
 {
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int W = a.dw, H = a.dh;
     // lanes are a flat index over (row block, 4-pixel column group): no lane idles on levels narrower than a strip
     const int ncol4 = (W + 3) >> 2, nrblk = (H + PY_RB - 1) / PY_RB;
-    const int flat = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
     const bool active = flat < ncol4 * nrblk;
     const int fl = min(flat, ncol4 * nrblk - 1);
     const int rblk = fl / ncol4;
@@ -205,6 +204,31 @@ __global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
             else
                 for (int j = 0; j < 4 && dx0 + j < W; ++j) o[j] = (uint8_t)(packed >> (8 * j));
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
+{
+    pyr_lane(a, blockIdx.y, (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63));
+}
+
+// All levels of one frame in ONE launch: a workgroup of 1024 owns a frame and walks the levels 1 .. nl-1 in order; the
+// chained dependency (level l reads level l-1, :1134) is a workgroup barrier + device-scope fence instead of a launch
+// boundary, so different frames are at different levels at the same time (no per-level tail) and a level is re-read
+// from the XCD's L2 / the Infinity Cache right after it was written.  Same lane routine, same arithmetic.
+struct PyrAll {
+    PyrArgs lv[ORBFE_MAX_LEVELS - 1];
+    int32_t nl;  // number of destination levels
+};
+__global__ __launch_bounds__(1024) void k_pyr_all(PyrAll a)
+{
+    const int b = blockIdx.x;
+    for (int l = 0; l < a.nl; ++l) {
+        const PyrArgs &L = a.lv[l];
+        const int ntasks = ((L.dw + 3) >> 2) * ((L.dh + PY_RB - 1) / PY_RB);
+        for (int base = 0; base < ntasks; base += 1024) pyr_lane(L, b, base + (int)threadIdx.x);
+        __threadfence();
+        __syncthreads();
     }
 }
 
@@ -1577,6 +1601,8 @@ static FrameSrc make_src(const OrbLaunch &a)
 
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
 {
+    PyrAll all;
+    all.nl = a.h_plan->nlevels - 1;
     for (int l = 1; l < a.h_plan->nlevels; ++l) {
         const OrbLevel &D = a.h_plan->lv[l];
         const OrbLevel &S = a.h_plan->lv[l - 1];
@@ -1596,10 +1622,14 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
         pa.dw = D.w; pa.dh = D.h; pa.dpitch = D.pitch;
         pa.xtab = a.d_tabs + D.xtab;
         pa.ytab = a.d_tabs + D.ytab;
-        const int nlanes = ((D.w + 3) / 4) * ((D.h + PY_RB - 1) / PY_RB);
-        dim3 grid((nlanes + 255) / 256, a.nframes);
-        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, pa);
+        all.lv[l - 1] = pa;
+        if (!a.pyr_fused) {
+            const int nlanes = ((D.w + 3) / 4) * ((D.h + PY_RB - 1) / PY_RB);
+            dim3 grid((nlanes + 255) / 256, a.nframes);
+            hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, pa);
+        }
     }
+    if (a.pyr_fused && all.nl > 0) hipLaunchKernelGGL(k_pyr_all, dim3(a.nframes), dim3(1024), 0, st, all);
     return hipGetLastError();
 }
 
