@@ -148,7 +148,6 @@ struct orbfe_handle {
     // sticky overflow word + FAST sparse-variant statistics: [0] int32 overflow bits, [2..7] 3 x uint64 counters
     DevBuf d_misc;
     int fast_mode = 0;            // 0 dense, 1 sparse shortcuts (orbfe_set_fast_mode)
-    int pyr_fused = 0;            // ORBFE_PYR: 1 = all pyramid levels of a frame in one launch
     bool fast_stats = false;
     int64_t fast_row_steps = 0;
     hipStream_t last_stream = nullptr;  // stream of the most recent batched call (synchronised before re-planning)
@@ -589,7 +588,6 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
         return fail(ORBFE_ERR_HIP);
     }
     if (const char *e = getenv("ORBFE_OVERLAP")) h->overlap = std::max(0, std::min(2, atoi(e)));
-    if (const char *e = getenv("ORBFE_PYR")) h->pyr_fused = atoi(e) != 0;
     int umax[16];
     host_umax(umax);
     if (orbk_upload_constants(umax) != hipSuccess) {
@@ -770,7 +768,6 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_n_out = d_n_out;
     a.d_ovf = (int32_t *)h->d_misc.p;
     a.fast_sparse = h->fast_mode;
-    a.pyr_fused = h->pyr_fused;
     a.d_fstat = h->fast_stats ? (unsigned long long *)((char *)h->d_misc.p + 16) : nullptr;
     h->last_stream = st;
     h->last_stream_valid = true;

@@ -34,7 +34,6 @@ struct OrbLaunch {
     int32_t *d_ovf;
     // FAST variant: 1 = wave-uniform shortcuts for sparse-corner frames; d_fstat (optional) counts their effect
     int32_t fast_sparse;
-    int32_t pyr_fused;   // 1: all pyramid levels of a frame in one launch (k_pyr_all), 0: one launch per level
     unsigned long long *d_fstat;
 };
 

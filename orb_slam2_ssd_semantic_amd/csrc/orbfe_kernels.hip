@@ -212,26 +212,6 @@ __global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
     pyr_lane(a, blockIdx.y, (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63));
 }
 
-// All levels of one frame in ONE launch: a workgroup of 1024 owns a frame and walks the levels 1 .. nl-1 in order; the
-// chained dependency (level l reads level l-1, :1134) is a workgroup barrier + device-scope fence instead of a launch
-// boundary, so different frames are at different levels at the same time (no per-level tail) and a level is re-read
-// from the XCD's L2 / the Infinity Cache right after it was written.  Same lane routine, same arithmetic.
-struct PyrAll {
-    PyrArgs lv[ORBFE_MAX_LEVELS - 1];
-    int32_t nl;  // number of destination levels
-};
-__global__ __launch_bounds__(1024) void k_pyr_all(PyrAll a)
-{
-    const int b = blockIdx.x;
-    for (int l = 0; l < a.nl; ++l) {
-        const PyrArgs &L = a.lv[l];
-        const int ntasks = ((L.dw + 3) >> 2) * ((L.dh + PY_RB - 1) / PY_RB);
-        for (int base = 0; base < ntasks; base += 1024) pyr_lane(L, b, base + (int)threadIdx.x);
-        __threadfence();
-        __syncthreads();
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // K2  FAST-9/16 with the reference's per-cell semantics: corner at t <=> A > t for the arc strength
 //   A = max(A_dark, A_bright), cv score = A - 1, 3x3 strict NMS inside each cell's detectable interior, iniTh list
@@ -1601,8 +1581,9 @@ static FrameSrc make_src(const OrbLaunch &a)
 
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
 {
-    PyrAll all;
-    all.nl = a.h_plan->nlevels - 1;
+    // One launch per level (level l reads level l-1, :1134).  Measured alternative, not kept: all levels of a frame in one
+    // launch (a 1024-thread workgroup per frame, workgroup barriers between levels) -- 0.66 ms against 0.63 ms per 1024
+    // frames; with an agent-scope fence between the levels (an L2 write-back on this part) 4.8 ms.
     for (int l = 1; l < a.h_plan->nlevels; ++l) {
         const OrbLevel &D = a.h_plan->lv[l];
         const OrbLevel &S = a.h_plan->lv[l - 1];
@@ -1622,14 +1603,10 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
         pa.dw = D.w; pa.dh = D.h; pa.dpitch = D.pitch;
         pa.xtab = a.d_tabs + D.xtab;
         pa.ytab = a.d_tabs + D.ytab;
-        all.lv[l - 1] = pa;
-        if (!a.pyr_fused) {
-            const int nlanes = ((D.w + 3) / 4) * ((D.h + PY_RB - 1) / PY_RB);
-            dim3 grid((nlanes + 255) / 256, a.nframes);
-            hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, pa);
-        }
+        const int nlanes = ((D.w + 3) / 4) * ((D.h + PY_RB - 1) / PY_RB);
+        dim3 grid((nlanes + 255) / 256, a.nframes);
+        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, pa);
     }
-    if (a.pyr_fused && all.nl > 0) hipLaunchKernelGGL(k_pyr_all, dim3(a.nframes), dim3(1024), 0, st, all);
     return hipGetLastError();
 }
 
