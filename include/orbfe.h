@@ -330,6 +330,42 @@ orbfe_status orbfe_search_by_bow_batch_device(orbfe_matcher *m, const orbfe_keyp
                                               int32_t th_low, int32_t kf_kf, int32_t check_ori, int32_t *d_match,
                                               int32_t *d_nmatches, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Formats: the on-disk keyframe records of Map::Save / Map::Load and the ORB vocabulary files
+ * ------------------------------------------------------------------------------------------- */
+/* Keyframe block of Map::Save (perfect/src/Map.cc:330-381 _WriteKeyFrame, read back by _ReadKeyFrame :143-187):
+ *   u64 mnId | f64 mTimeStamp | f32 t_cw[3] | f32 q_cw[4] (x y z w) | i32 N |
+ *   N x { f32 pt.x pt.y size angle response | i32 octave | u8 descriptor[32] | u64 map-point index (ULONG_MAX = none) }
+ * = 48 + 64 * N bytes; class_id is not stored (the reader leaves -1).  HOST buffers; *written / *consumed = block size. */
+size_t orbfe_mapio_keyframe_bytes(int32_t n);
+orbfe_status orbfe_mapio_write_keyframe(uint8_t *dst, size_t cap, uint64_t id, double timestamp, const float t_cw[3],
+                                        const float q_cw[4], const orbfe_keypoint *kps, const uint8_t *desc,
+                                        const uint64_t *mp_index /* NULL = none */, int32_t n, size_t *written);
+orbfe_status orbfe_mapio_read_keyframe(const uint8_t *src, size_t len, uint64_t *id, double *timestamp, float t_cw[3],
+                                       float q_cw[4], orbfe_keypoint *kps, uint8_t *desc, uint64_t *mp_index, int32_t cap,
+                                       int32_t *n, size_t *consumed);
+/* the 64-byte feature records straight from an extractor output block in HBM (also what an all-gathered block is turned
+ * into before it is written): frame b -> d_out + b*cap*64, slots >= d_n[b] zero; d_mp_index [nframes][cap] or NULL */
+orbfe_status orbfe_mapio_pack_records_device(const orbfe_keypoint *d_kps, const uint8_t *d_desc, const int32_t *d_n,
+                                             const uint64_t *d_mp_index, int32_t nframes, int32_t cap, uint8_t *d_out,
+                                             void *stream);
+
+/* ORB vocabulary files as the reference loads them (src/System.cc:123-129; tool/text2binary.cc converts one into the
+ * other).  DBoW2 is not vendored by the reference; the two layouts are ORB-SLAM2's TemplatedVocabulary
+ * loadFromTextFile / saveToBinaryFile, restated (csrc/orbfe_io.hip).  Host only: no device is touched before
+ * orbfe_vocabulary_create_from_file. */
+typedef struct orbfe_vocfile orbfe_vocfile;
+orbfe_status orbfe_vocfile_load(const char *path /* ORBvoc.txt or ORBvoc.bin */, orbfe_vocfile **out);
+void orbfe_vocfile_free(orbfe_vocfile *v);
+orbfe_status orbfe_vocfile_info(const orbfe_vocfile *v, int32_t *k, int32_t *L, int32_t *nnodes, int32_t *nwords,
+                                int32_t *scoring, int32_t *weighting);
+/* pointers into the parsed file (valid until orbfe_vocfile_free); any may be NULL */
+orbfe_status orbfe_vocfile_arrays(const orbfe_vocfile *v, const uint32_t **child_off, const uint32_t **child_idx,
+                                  const uint8_t **node_desc, const uint32_t **word_id, const double **weight,
+                                  const uint32_t **parent, const uint8_t **is_leaf);
+orbfe_status orbfe_vocfile_save_binary(const orbfe_vocfile *v, const char *path);
+orbfe_status orbfe_vocabulary_create_from_file(int32_t device, const orbfe_vocfile *v, orbfe_vocabulary **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,5 +6,8 @@ package imports the CPU oracle under oracle/ -- that is test infrastructure.
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import FrameGrid, ORBVocabulary, ORBmatcher, feature_vector_to_csr  # noqa: F401
 from ._ffi import KP_DTYPE, OrbfeError  # noqa: F401
+from . import mapio  # noqa: F401
+from .mapio import VocabularyFile  # noqa: F401
 
-__all__ = ["ORBextractor", "ORBmatcher", "FrameGrid", "ORBVocabulary", "feature_vector_to_csr", "KP_DTYPE", "OrbfeError"]
+__all__ = ["ORBextractor", "ORBmatcher", "FrameGrid", "ORBVocabulary", "VocabularyFile", "mapio", "feature_vector_to_csr",
+           "KP_DTYPE", "OrbfeError"]

@@ -30,6 +30,9 @@ SYMBOLS = (
     "orbfe_distinctive_descriptors", "orbfe_stereo_matches", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
     "orbfe_bow_transform", "orbfe_get_overflow", "orbfe_set_fast_mode", "orbfe_get_fast_stats", "orbfe_get_work_counts",
     "orbfe_bow_transform_batch_device", "orbfe_search_by_bow_batch_device", "orbfe_matcher_set_bf_kernel",
+    "orbfe_mapio_keyframe_bytes", "orbfe_mapio_write_keyframe", "orbfe_mapio_read_keyframe", "orbfe_mapio_pack_records_device",
+    "orbfe_vocfile_load", "orbfe_vocfile_free", "orbfe_vocfile_info", "orbfe_vocfile_arrays", "orbfe_vocfile_save_binary",
+    "orbfe_vocabulary_create_from_file",
 )
 
 
@@ -88,6 +91,18 @@ def lib():
     L.orbfe_tap_selected.argtypes = [vp, i32, i32, vp, i32, vp]
     L.orbfe_get_work_counts.argtypes = [vp, vp]
     L.orbfe_matcher_set_bf_kernel.argtypes = [vp, i32]
+    L.orbfe_mapio_keyframe_bytes.restype = sz
+    L.orbfe_mapio_keyframe_bytes.argtypes = [i32]
+    L.orbfe_mapio_write_keyframe.argtypes = [vp, sz, C.c_uint64, C.c_double, vp, vp, vp, vp, vp, i32, vp]
+    L.orbfe_mapio_read_keyframe.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+    L.orbfe_mapio_pack_records_device.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    L.orbfe_vocfile_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.orbfe_vocfile_free.argtypes = [vp]
+    L.orbfe_vocfile_free.restype = None
+    L.orbfe_vocfile_info.argtypes = [vp] + [vp] * 6
+    L.orbfe_vocfile_arrays.argtypes = [vp] + [vp] * 7
+    L.orbfe_vocfile_save_binary.argtypes = [vp, C.c_char_p]
+    L.orbfe_vocabulary_create_from_file.argtypes = [i32, vp, C.POINTER(vp)]
     L.orbfe_bow_transform_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32] + [vp] * 10
     L.orbfe_search_by_bow_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, i32, vp, vp, vp]
     L.orbfe_get_overflow.argtypes = [vp, vp]
