@@ -90,6 +90,11 @@ def expand_frames(base, total):
 
 
 def base_frames(gen, n, w, h, seed0):
+    if gen == "TUM":   # the real sequence, when $TUM_FR3_WALKING_XYZ points at it (gray conversion of src/Tracking.cc:342)
+        from orb_slam2_ssd_semantic_amd import tum
+        fr = tum.load_gray_frames(limit=n)
+        assert fr.shape[1:] == (h, w), f"TUM frames are {fr.shape[1:]}, bench asked for {(h, w)}"
+        return fr
     make = synth_frame if gen == "S" else synth_tum_like
     return np.stack([make(seed0 + i, h, w) for i in range(n)])
 
@@ -242,7 +247,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--workload", choices=["S", "S_tum"], default="S", help="generator of the frames `value` is timed on")
+    ap.add_argument("--workload", choices=["S", "S_tum", "TUM"], default="S",
+                    help="frames `value` is timed on: S(seed), S_tum(seed), or the TUM sequence at $TUM_FR3_WALKING_XYZ")
     ap.add_argument("--fast-mode", type=int, default=0, help="FAST variant of the timed region (0 dense, 1 sparse shortcuts)")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the latency probe")
@@ -346,7 +352,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("BASELINE config 3 shape, HBM-RESIDENT inputs (the PCIe-inclusive rate of the same pipeline "
-                                    "is `pcie_inclusive`): %dx%d synthetic frames %s(seed) (no TUM data on the box), %d "
+                                    "is `pcie_inclusive`): %dx%d synthetic frames %s(seed) (S / S_tum: no TUM data on the box), %d "
                                     "features, 8 levels, %s; %d frames per GPU per step in %d launches of %d%s; exactness is "
                                     "checked against the in-repo oracle, which is pinned to the compiled reference "
                                     "(tests/test_ref_pin.py)") %

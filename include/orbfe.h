@@ -350,6 +350,14 @@ orbfe_status orbfe_mapio_pack_records_device(const orbfe_keypoint *d_kps, const 
                                              const uint64_t *d_mp_index, int32_t nframes, int32_t cap, uint8_t *d_out,
                                              void *stream);
 
+/* The caller's colour -> gray step before operator() (Tracking::GrabImageRGBD, src/Tracking.cc:339-353) for DEVICE-resident
+ * 3-channel interleaved frames: gray = (w0*c0 + 9617*c1 + w2*c2 + 8192) >> 14, (w0, w2) = (4899, 1868) when rgb_flag != 0
+ * (cvtColor(CV_RGB2GRAY) on the memory order given -- the reference's path for cv::imread's BGR with Camera.RGB = 1),
+ * (1868, 4899) otherwise (CV_BGR2GRAY).  Enqueued on `stream`. */
+orbfe_status orbfe_interleaved_to_gray_device(const uint8_t *d_src, int32_t nframes, int32_t w, int32_t h, int32_t src_stride,
+                                              size_t src_frame_stride, int32_t rgb_flag, uint8_t *d_gray,
+                                              int32_t gray_stride, size_t gray_frame_stride, void *stream);
+
 /* ORB vocabulary files as the reference loads them (src/System.cc:123-129; tool/text2binary.cc converts one into the
  * other).  DBoW2 is not vendored by the reference; the two layouts are ORB-SLAM2's TemplatedVocabulary
  * loadFromTextFile / saveToBinaryFile, restated (csrc/orbfe_io.hip).  Host only: no device is touched before

@@ -32,7 +32,7 @@ SYMBOLS = (
     "orbfe_bow_transform_batch_device", "orbfe_search_by_bow_batch_device", "orbfe_matcher_set_bf_kernel",
     "orbfe_mapio_keyframe_bytes", "orbfe_mapio_write_keyframe", "orbfe_mapio_read_keyframe", "orbfe_mapio_pack_records_device",
     "orbfe_vocfile_load", "orbfe_vocfile_free", "orbfe_vocfile_info", "orbfe_vocfile_arrays", "orbfe_vocfile_save_binary",
-    "orbfe_vocabulary_create_from_file",
+    "orbfe_vocabulary_create_from_file", "orbfe_interleaved_to_gray_device",
 )
 
 
@@ -103,6 +103,7 @@ def lib():
     L.orbfe_vocfile_arrays.argtypes = [vp] + [vp] * 7
     L.orbfe_vocfile_save_binary.argtypes = [vp, C.c_char_p]
     L.orbfe_vocabulary_create_from_file.argtypes = [i32, vp, C.POINTER(vp)]
+    L.orbfe_interleaved_to_gray_device.argtypes = [vp, i32, i32, i32, i32, sz, i32, vp, i32, sz, vp]
     L.orbfe_bow_transform_batch_device.argtypes = [vp, vp, vp, vp, i32, i32, i32] + [vp] * 10
     L.orbfe_search_by_bow_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, i32, vp, vp, vp]
     L.orbfe_get_overflow.argtypes = [vp, vp]

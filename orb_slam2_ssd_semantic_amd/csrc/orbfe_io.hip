@@ -156,6 +156,48 @@ extern "C" orbfe_status orbfe_mapio_pack_records_device(const orbfe_keypoint *d_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Tracking::GrabImageRGBD's colour -> gray step (src/Tracking.cc:339-353) on device-resident frames: cvtColor's 14-bit
+// fixed point luma, gray = (w0*c0 + 9617*c1 + w2*c2 + 8192) >> 14 with (w0, w2) = (4899, 1868) for CV_RGB2GRAY applied to
+// the memory order it is given (what the reference does to cv::imread's BGR with Camera.RGB = 1) and (1868, 4899) for
+// CV_BGR2GRAY.  Four pixels per thread: three dword loads, one dword store.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_interleaved_to_gray(const uint8_t *__restrict__ src, int64_t src_fstride, int spitch,
+                                                             uint8_t *__restrict__ dst, int64_t dst_fstride, int dpitch, int w,
+                                                             int h, uint32_t w0, uint32_t w2)
+{
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x4 >= w) return;
+    const uint8_t *row = src + (int64_t)b * src_fstride + (int64_t)y * spitch + (int64_t)x4 * 3;
+    uint8_t *o = dst + (int64_t)b * dst_fstride + (int64_t)y * dpitch + x4;
+    const int n = min(4, w - x4);
+    uint32_t g[4] = {0, 0, 0, 0};
+    for (int j = 0; j < n; ++j) {
+        const uint32_t c0 = row[3 * j], c1 = row[3 * j + 1], c2 = row[3 * j + 2];
+        g[j] = (c0 * w0 + c1 * 9617u + c2 * w2 + 8192u) >> 14;
+    }
+    if (n == 4 && (((uintptr_t)o) & 3) == 0) *(uint32_t *)o = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+    else
+        for (int j = 0; j < n; ++j) o[j] = (uint8_t)g[j];
+}
+
+extern "C" orbfe_status orbfe_interleaved_to_gray_device(const uint8_t *d_src, int32_t nframes, int32_t w, int32_t h,
+                                                         int32_t src_stride, size_t src_frame_stride, int32_t rgb_flag,
+                                                         uint8_t *d_gray, int32_t gray_stride, size_t gray_frame_stride,
+                                                         void *stream)
+{
+    if (!d_src || !d_gray || nframes < 1 || w < 1 || h < 1 || src_stride < 3 * w || gray_stride < w) {
+        orbfe_set_error("bad argument to orbfe_interleaved_to_gray_device");
+        return ORBFE_ERR_ARG;
+    }
+    const uint32_t w0 = rgb_flag ? 4899u : 1868u, w2 = rgb_flag ? 1868u : 4899u;
+    hipLaunchKernelGGL(k_interleaved_to_gray, dim3((w + 1023) / 1024, h, nframes), dim3(256), 0, (hipStream_t)stream, d_src,
+                       (int64_t)src_frame_stride, src_stride, d_gray, (int64_t)gray_frame_stride, gray_stride, w, h, w0, w2);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // ORB vocabulary files
 //   text   (ORBvoc.txt):  first line "k L scoring weighting"; then one line per node except the root, in node-id order:
 //                         "parent_id is_leaf d0 ... d31 weight" (descriptor bytes as decimal numbers, weight as double)

@@ -206,3 +206,22 @@ def test_sequence_batched_device_call(oracle, gen, nframes):
         assert np.array_equal(a, b)
     ncand = [sum(len(oe.candidates(l)) for l in range(8))]
     assert (ncand[0] > 20000) if gen == "S" else (1000 < ncand[0] < 12000)
+
+
+def test_tum_sequence(oracle):
+    """BASELINE config 2 on the real sequence when it is present ($TUM_FR3_WALKING_XYZ): every associated frame through
+    batched device calls, compared per frame with the oracle.  Skipped where the dataset does not exist (this container,
+    the GPU box of the driver)."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor, tum
+    if tum.sequence_dir() is None:
+        pytest.skip("TUM fr3/walking_xyz not available: set $TUM_FR3_WALKING_XYZ")
+    frames = tum.load_gray_frames()
+    N, h, w = frames.shape
+    e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=128)
+    oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    for lo in range(0, N, 128):
+        blk = np.ascontiguousarray(frames[lo:lo + 128])
+        res, _ = _device_batch(e, blk.reshape(-1), len(blk), w, h, w, w * h)
+        for i, (gk, gd) in enumerate(res):
+            ok, od = oe(blk[i])
+            assert _same(gk, gd, ok, od), lo + i
