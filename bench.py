@@ -587,7 +587,7 @@ def workload_legs(args, eng, d_S, local_rank):
     sets = {args.workload: d_S, ("S_tum" if args.workload == "S" else "S"): other}
     out = {}
     kps, desc, n = eng.outs[0]
-    for name in ("S", "S_tum"):
+    for name in sets:
         g = sets[name]
         row = {}
         for mode, label in ((0, "dense"), (1, "sparse")):

@@ -80,6 +80,35 @@ def lib():
     return L
 
 
+_SHIM = os.path.join(_OUT, "libshim_ref.so")
+_shim = None
+
+
+def shim_available():
+    return os.path.exists(_SHIM) or have_reference()
+
+
+def shim_lib():
+    """oracle/_ref/libshim_ref.so: the PRODUCT's link-level matcher shim (shim/ORBmatcher_orbfe.cc) compiled against the
+    reference's unmodified include/ORBmatcher.h and linked with the reference's own ORBmatcher.cc for every other member.
+    Same flat entry points as the ref_* ones, exported as shim_*; the SearchByBoW calls need a GPU."""
+    global _shim
+    if _shim is not None:
+        return _shim
+    build()
+    if not os.path.exists(_SHIM):
+        raise RuntimeError("oracle/_ref/libshim_ref.so is missing")
+    L = C.CDLL(_SHIM)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.shim_descriptor_distance.argtypes = [vp, vp]
+    L.shim_three_maxima.argtypes = [vp, ci, vp, vp, vp]
+    L.shim_search_by_bow_kf_f.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, cf, ci, vp]
+    L.shim_search_by_bow_kf_kf.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci] * 2 + [cf, ci, vp]
+    L.shim_matcher_constants.argtypes = [vp, vp, vp]
+    _shim = L
+    return L
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -189,10 +218,10 @@ def glibc_sincosf(x):
     return np.float32(c.value), np.float32(s.value)
 
 
-def descriptor_distance(a, b):
+def descriptor_distance(a, b, shim=False):
     a = np.ascontiguousarray(a, np.uint8)
     b = np.ascontiguousarray(b, np.uint8)
-    return lib().ref_descriptor_distance(_p(a), _p(b))
+    return (shim_lib().shim_descriptor_distance if shim else lib().ref_descriptor_distance)(_p(a), _p(b))
 
 
 def three_maxima(counts):
@@ -214,8 +243,9 @@ def _csr(fv):
             np.ascontiguousarray(idx, np.uint32))
 
 
-def search_by_bow_kf_f(descKF, validKF, angKF, fvKF, descF, angF, fvF, nnratio, check_ori):
-    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...): (matchF2KF[nF], return value)."""
+def search_by_bow_kf_f(descKF, validKF, angKF, fvKF, descF, angF, fvF, nnratio, check_ori, shim=False):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...): (matchF2KF[nF], return value).  shim=True: through the product's
+    link-level shim (HIP) instead of the reference's own body."""
     descKF = np.ascontiguousarray(descKF, np.uint8).reshape(-1, 32)
     descF = np.ascontiguousarray(descF, np.uint8).reshape(-1, 32)
     validKF = np.ascontiguousarray(validKF, np.uint8)
@@ -224,13 +254,14 @@ def search_by_bow_kf_f(descKF, validKF, angKF, fvKF, descF, angF, fvF, nnratio, 
     nk, ok, ik = _csr(fvKF)
     nf, of, if_ = _csr(fvF)
     out = np.full(descF.shape[0], -1, np.int32)
-    n = lib().ref_search_by_bow_kf_f(_p(descKF), descKF.shape[0], _p(validKF), _p(angKF), _p(nk), _p(ok), _p(ik),
+    fn = shim_lib().shim_search_by_bow_kf_f if shim else lib().ref_search_by_bow_kf_f
+    n = fn(_p(descKF), descKF.shape[0], _p(validKF), _p(angKF), _p(nk), _p(ok), _p(ik),
                                      nk.size, _p(descF), descF.shape[0], _p(angF), _p(nf), _p(of), _p(if_), nf.size,
                                      float(nnratio), int(check_ori), _p(out))
     return out, n
 
 
-def search_by_bow_kf_kf(desc1, valid1, ang1, fv1, desc2, valid2, ang2, fv2, nnratio, check_ori):
+def search_by_bow_kf_kf(desc1, valid1, ang1, fv1, desc2, valid2, ang2, fv2, nnratio, check_ori, shim=False):
     """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...): (match12[n1], return value)."""
     desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
     desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
@@ -241,7 +272,8 @@ def search_by_bow_kf_kf(desc1, valid1, ang1, fv1, desc2, valid2, ang2, fv2, nnra
     n1_, o1, i1 = _csr(fv1)
     n2_, o2, i2 = _csr(fv2)
     out = np.full(desc1.shape[0], -1, np.int32)
-    n = lib().ref_search_by_bow_kf_kf(_p(desc1), desc1.shape[0], _p(valid1), _p(ang1), _p(n1_), _p(o1), _p(i1),
+    fn = shim_lib().shim_search_by_bow_kf_kf if shim else lib().ref_search_by_bow_kf_kf
+    n = fn(_p(desc1), desc1.shape[0], _p(valid1), _p(ang1), _p(n1_), _p(o1), _p(i1),
                                       n1_.size, _p(desc2), desc2.shape[0], _p(valid2), _p(ang2), _p(n2_), _p(o2),
                                       _p(i2), n2_.size, float(nnratio), int(check_ori), _p(out))
     return out, n

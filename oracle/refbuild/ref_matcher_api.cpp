@@ -16,6 +16,18 @@
 
 #include "ORBmatcher.h" /* the reference's own header; its MapPoint.h / KeyFrame.h / Frame.h are ref_mocks.h */
 
+/* The same glue is compiled a second time for libshim_ref.so (Makefile): there the three members with the Hamming work come
+ * from orb_slam2_ssd_semantic_amd/shim/ORBmatcher_orbfe.cc (HIP path) and the entry points are exported as shim_*, while a
+ * reference translation unit compiled with -DSearchByBoW=RefSearchByBoW -DDescriptorDistance=RefDescriptorDistance supplies
+ * every other member of the class. */
+#ifndef REF_API_PREFIX
+#define REF_API_PREFIX ref_
+#endif
+#define REF_CAT2(a, b) a##b
+#define REF_CAT(a, b) REF_CAT2(a, b)
+#define REF_NAME(n) REF_CAT(REF_API_PREFIX, n)
+
+#ifndef REF_API_NO_MOCK_DEFS
 namespace ORB_SLAM2
 {
 float Frame::mnMinX = 0, Frame::mnMaxX = 640, Frame::mnMinY = 0, Frame::mnMaxY = 480;
@@ -48,6 +60,7 @@ int MapPoint::PredictScale(const float &, Frame *)
     return 0;
 }
 } // namespace ORB_SLAM2
+#endif
 
 namespace
 {
@@ -84,7 +97,7 @@ void fill_mappoints(std::vector<MapPoint> &pool, std::vector<MapPoint *> &ptr, c
 
 extern "C" {
 
-int ref_descriptor_distance(const uint8_t *a, const uint8_t *b)
+int REF_NAME(descriptor_distance)(const uint8_t *a, const uint8_t *b)
 {
     /* 4-byte aligned copies: the reference reads the rows through int32_t pointers (:1970-1971) */
     int32_t ta[8], tb[8];
@@ -94,7 +107,7 @@ int ref_descriptor_distance(const uint8_t *a, const uint8_t *b)
     return ORBmatcher::DescriptorDistance(ma, mb);
 }
 
-void ref_three_maxima(const int *counts, int L, int *ind1, int *ind2, int *ind3)
+void REF_NAME(three_maxima)(const int *counts, int L, int *ind1, int *ind2, int *ind3)
 {
     std::vector<std::vector<int> > histo((size_t)L);
     for (int i = 0; i < L; i++) histo[(size_t)i].assign((size_t)counts[i], 0);
@@ -108,7 +121,7 @@ void ref_three_maxima(const int *counts, int L, int *ind1, int *ind2, int *ind3)
 
 /* M1: SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&).  matchF2KF[iF] = KF feature whose MapPoint was
  * assigned to F feature iF (-1 = NULL); returns the reference's return value. */
-int ref_search_by_bow_kf_f(const uint8_t *descKF, int nKF, const uint8_t *validKF, const float *angKF,
+int REF_NAME(search_by_bow_kf_f)(const uint8_t *descKF, int nKF, const uint8_t *validKF, const float *angKF,
                            const uint32_t *nodeKF, const uint32_t *offKF, const uint32_t *idxKF, int nnodesKF,
                            const uint8_t *descF, int nF, const float *angF, const uint32_t *nodeF,
                            const uint32_t *offF, const uint32_t *idxF, int nnodesF, float nnratio, int check_ori,
@@ -137,7 +150,7 @@ int ref_search_by_bow_kf_f(const uint8_t *descKF, int nKF, const uint8_t *validK
 
 /* M2: SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&).  match12[i1] = KF2 feature whose MapPoint was
  * assigned to KF1 feature i1 (-1 = NULL). */
-int ref_search_by_bow_kf_kf(const uint8_t *desc1, int n1, const uint8_t *valid1, const float *ang1,
+int REF_NAME(search_by_bow_kf_kf)(const uint8_t *desc1, int n1, const uint8_t *valid1, const float *ang1,
                             const uint32_t *node1, const uint32_t *off1, const uint32_t *idx1, int nnodes1,
                             const uint8_t *desc2, int n2, const uint8_t *valid2, const float *ang2,
                             const uint32_t *node2, const uint32_t *off2, const uint32_t *idx2, int nnodes2,
@@ -162,7 +175,7 @@ int ref_search_by_bow_kf_kf(const uint8_t *desc1, int n1, const uint8_t *valid1,
     return n;
 }
 
-void ref_matcher_constants(int *th_low, int *th_high, int *histo_length)
+void REF_NAME(matcher_constants)(int *th_low, int *th_high, int *histo_length)
 {
     *th_low = ORBmatcher::TH_LOW;
     *th_high = ORBmatcher::TH_HIGH;
