@@ -268,14 +268,15 @@ def test_three_maxima_equals_reference(ref, oracle):
 def _bow_case(rng, n1, n2, nnodes, pvalid, dup):
     """Two feature sets with correlated descriptors spread over `nnodes` vocabulary nodes."""
     base = rng.integers(0, 256, (max(n1, n2), 32), dtype=np.uint8)
+    base_node = rng.integers(0, nnodes, max(n1, n2))      # both views put most features into the same node
 
     def side(n):
         d = base[:n].copy()
-        flip = rng.random((n, 256)) < rng.choice([0.02, 0.08, 0.2])
+        flip = rng.random((n, 256)) < rng.choice([0.01, 0.03, 0.08])
         d ^= np.packbits(flip, axis=1)
         if dup and n > 4:
             d[rng.integers(0, n, n // 3)] = d[rng.integers(0, n, n // 3)]     # exact duplicates -> distance ties
-        node_of = rng.integers(0, nnodes, n) * 3 + 1
+        node_of = np.where(rng.random(n) < 0.8, base_node[:n], rng.integers(0, nnodes, n)) * 3 + 1
         ids = np.unique(node_of)
         idx = [np.flatnonzero(node_of == v) for v in ids]
         off = np.concatenate([[0], np.cumsum([len(i) for i in idx])]).astype(np.uint32)
