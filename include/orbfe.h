@@ -244,6 +244,17 @@ orbfe_status orbfe_search_by_bow(orbfe_matcher *m, const uint8_t *descKF, int32_
 orbfe_status orbfe_hamming_csr(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
                                const uint32_t *off, const uint32_t *cand, int32_t *best_idx, int32_t *best,
                                int32_t *second);
+/* same, plus second_idx[nq] (may be NULL): the candidate that last set the runner-up distance in the reference's update
+ * idiom -- what SearchByProjection(Frame&, vector<MapPoint*>&) keeps as bestLevel2 (src/ORBmatcher.cc:128-147): the
+ * previous best when a new best arrives, else the first candidate below the runner-up; -1 if fewer than two */
+orbfe_status orbfe_hamming_csr_ex(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
+                                  const uint32_t *off, const uint32_t *cand, int32_t *best_idx, int32_t *best,
+                                  int32_t *second, int32_t *second_idx);
+/* DEVICE buffers (queries / train rows e.g. straight out of an extractor output block), enqueued on `stream`, no
+ * validation of the candidate indices (they must be < the number of train rows); d_second_idx may be NULL */
+orbfe_status orbfe_hamming_csr_device(orbfe_matcher *m, const uint8_t *d_q, int32_t nq, const uint8_t *d_t,
+                                      const uint32_t *d_off, const uint32_t *d_cand, int32_t *d_best_idx, int32_t *d_best,
+                                      int32_t *d_second, int32_t *d_second_idx, void *stream);
 
 /* the frame grid index that every projection-gated matcher walks.
  * Frame::AssignFeaturesToGrid (src/Frame.cc:319-334) + Frame::PosInGrid (:522-531): 64 x 48 cells over the undistorted

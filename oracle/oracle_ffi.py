@@ -83,6 +83,7 @@ def lib():
     L.orc_search_by_bow.argtypes = ([vp, C.c_int, vp, vp, vp, vp, vp, C.c_int] * 2
                                     + [C.c_float, C.c_int, C.c_int, C.c_int, vp, vp])
     L.orc_hamming_csr.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.orc_hamming_csr2.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.orc_assign_grid.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
     L.orc_features_in_area.argtypes = [vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_int, C.c_int, vp, C.c_int]
@@ -353,6 +354,18 @@ def hamming_csr(q, t, off, cand):
     rc = lib().orc_hamming_csr(_p(q), len(q), _p(t), len(t), _p(off), _p(cand), _p(bi), _p(b), _p(s))
     assert rc == 0
     return bi, b, s
+
+
+def hamming_csr2(q, t, off, cand):
+    """hamming_csr plus the candidate that owns the runner-up distance (bestLevel2's owner at ORBmatcher.cc:128-140)"""
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(off, np.uint32)
+    cand = np.ascontiguousarray(cand, np.uint32)
+    bi, b, s, si = (np.zeros(len(q), np.int32) for _ in range(4))
+    rc = lib().orc_hamming_csr2(_p(q), len(q), _p(t), len(t), _p(off), _p(cand), _p(bi), _p(b), _p(s), _p(si))
+    assert rc == 0
+    return bi, b, s, si
 
 
 def assign_grid(xy, minx, miny, gw_inv, gh_inv):

@@ -1058,23 +1058,30 @@ int orc_search_by_bow(const uint8_t *descKF, int nKF, const uint8_t *validKF, co
     return 0;
 }
 
-/* 8(f).1: per query i, candidates cand[off[i]..off[i+1]) -> best/2nd-best with the :280-289 idiom */
-int orc_hamming_csr(const uint8_t *q, int nq, const uint8_t *t, int nt, const uint32_t *off,
-                    const uint32_t *cand, int32_t *best_idx, int32_t *best, int32_t *second)
+/* 8(f).1: per query i, candidates cand[off[i]..off[i+1]) -> best/2nd-best with the :280-289 idiom; second_idx (optional)
+ * = the candidate that last set the runner-up, i.e. what ORBmatcher.cc:128-140 tracks as bestLevel2's owner */
+int orc_hamming_csr2(const uint8_t *q, int nq, const uint8_t *t, int nt, const uint32_t *off, const uint32_t *cand,
+                     int32_t *best_idx, int32_t *best, int32_t *second, int32_t *second_idx)
 {
     for (int i = 0; i < nq; i++) {
-        int b1 = 256, b2 = 256, bi = -1;
+        int b1 = 256, b2 = 256, bi = -1, si = -1;
         for (uint32_t j = off[i]; j < off[i + 1]; j++) {
             if ((int)cand[j] >= nt) return -1;
             int d = orc_hamming(q + (size_t)i * 32, t + (size_t)cand[j] * 32);
-            if (d < b1) { b2 = b1; b1 = d; bi = (int)cand[j]; }
-            else if (d < b2) { b2 = d; }
+            if (d < b1) { b2 = b1; si = bi; b1 = d; bi = (int)cand[j]; }
+            else if (d < b2) { b2 = d; si = (int)cand[j]; }
         }
         best_idx[i] = bi;
         best[i] = b1;
         second[i] = b2;
+        if (second_idx) second_idx[i] = si;
     }
     return 0;
+}
+int orc_hamming_csr(const uint8_t *q, int nq, const uint8_t *t, int nt, const uint32_t *off,
+                    const uint32_t *cand, int32_t *best_idx, int32_t *best, int32_t *second)
+{
+    return orc_hamming_csr2(q, nq, t, nt, off, cand, best_idx, best, second, 0);
 }
 
 /* ------------------------------------------------------------------------------------------------

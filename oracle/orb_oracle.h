@@ -146,6 +146,8 @@ int orc_search_by_bow(const uint8_t *descKF, int nKF, const uint8_t *validKF, co
 /* ---- 8(f).1: CSR batched Hamming best/2nd-best (core of the SearchByProjection family) ---- */
 int orc_hamming_csr(const uint8_t *q, int nq, const uint8_t *t, int nt, const uint32_t *off /* nq+1 */,
                     const uint32_t *cand, int32_t *best_idx, int32_t *best, int32_t *second);
+int orc_hamming_csr2(const uint8_t *q, int nq, const uint8_t *t, int nt, const uint32_t *off, const uint32_t *cand,
+                     int32_t *best_idx, int32_t *best, int32_t *second, int32_t *second_idx /* may be NULL */);
 
 /* ---- 8(f).2: Frame::AssignFeaturesToGrid (src/Frame.cc:319-334) + PosInGrid (:522-531) ----
  * 64 x 48 grid; cell c = ix*48 + iy (mGrid[ix][iy]); cell_off has 64*48+1 entries, cell_idx ascending per cell. */

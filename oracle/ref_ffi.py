@@ -76,6 +76,10 @@ def lib():
     L.ref_search_by_bow_kf_f.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, cf, ci, vp]
     L.ref_search_by_bow_kf_kf.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci] * 2 + [cf, ci, vp]
     L.ref_matcher_constants.argtypes = [vp, vp, vp]
+    L.ref_assign_grid.argtypes = [vp, ci, cf, cf, cf, cf, vp, vp]
+    L.ref_features_in_area.argtypes = [vp, vp, ci, vp, vp, cf, cf, cf, cf, cf, cf, cf, ci, ci, vp, ci]
+    L.ref_distinctive.argtypes = [vp, ci, vp, vp, ci, vp, vp]
+    L.ref_predict_scale.argtypes = [cf, cf, cf, ci]
     _lib = L
     return L
 
@@ -277,3 +281,42 @@ def search_by_bow_kf_kf(desc1, valid1, ang1, fv1, desc2, valid2, ang2, fv2, nnra
                                       n1_.size, _p(desc2), desc2.shape[0], _p(valid2), _p(ang2), _p(n2_), _p(o2),
                                       _p(i2), n2_.size, float(nnratio), int(check_ori), _p(out))
     return out, n
+
+
+# ---- reference bodies sliced out of Frame.cc / KeyFrame.cc / MapPoint.cc (oracle/refbuild/ref_slices.cpp) ----
+def assign_grid(xy, minx, miny, gw_inv, gh_inv):
+    """Frame::AssignFeaturesToGrid + PosInGrid -> (cell_off[64*48+1], cell_idx[n_in_grid])"""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    off = np.zeros(64 * 48 + 1, np.uint32)
+    idx = np.zeros(max(len(xy), 1), np.uint32)
+    n = lib().ref_assign_grid(_p(xy), len(xy), float(minx), float(miny), float(gw_inv), float(gh_inv), _p(off), _p(idx))
+    return off, idx[:n].copy()
+
+
+def features_in_area(xy, octave, off, idx, minx, miny, gw_inv, gh_inv, x, y, r, min_level=-1, max_level=-1):
+    """Frame::GetFeaturesInArea on a frame whose grid is the given CSR"""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    octave = np.ascontiguousarray(octave, np.int32)
+    off = np.ascontiguousarray(off, np.uint32)
+    idx = np.ascontiguousarray(idx, np.uint32)
+    out = np.zeros(max(len(xy), 1), np.uint32)
+    n = lib().ref_features_in_area(_p(xy), _p(octave), len(xy), _p(off), _p(idx), float(minx), float(miny), float(gw_inv),
+                                   float(gh_inv), float(x), float(y), float(r), int(min_level), int(max_level), _p(out), out.size)
+    assert n >= 0
+    return out[:n].copy()
+
+
+def distinctive(pool, off, idx):
+    """MapPoint::ComputeDistinctiveDescriptors per map point -> (descriptor[npoints, 32], has[npoints])"""
+    pool = np.ascontiguousarray(pool, np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(off, np.uint32)
+    idx = np.ascontiguousarray(idx, np.uint32)
+    npnt = len(off) - 1
+    best = np.zeros((max(npnt, 1), 32), np.uint8)
+    has = np.zeros(max(npnt, 1), np.uint8)
+    lib().ref_distinctive(_p(pool), len(pool), _p(off), _p(idx), npnt, _p(best), _p(has))
+    return best[:npnt], has[:npnt]
+
+
+def predict_scale(max_distance, current_dist, log_scale_factor, nlevels):
+    return lib().ref_predict_scale(float(max_distance), float(current_dist), float(log_scale_factor), int(nlevels))

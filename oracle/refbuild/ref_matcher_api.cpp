@@ -32,33 +32,9 @@ namespace ORB_SLAM2
 {
 float Frame::mnMinX = 0, Frame::mnMaxX = 640, Frame::mnMinY = 0, Frame::mnMaxY = 480;
 
-/* The projection family (M4) is compiled from the reference but not exercised by oracle/_ref: its grid queries
- * belong to Frame.cc / KeyFrame.cc, which are outside this library. */
-static void not_wired(const char *what)
-{
-    fprintf(stderr, "oracle/_ref: %s is not wired (M4 family is compiled, not exercised)\n", what);
-    abort();
-}
-vector<size_t> Frame::GetFeaturesInArea(const float &, const float &, const float &, const int, const int) const
-{
-    not_wired("Frame::GetFeaturesInArea");
-    return vector<size_t>();
-}
-std::vector<size_t> KeyFrame::GetFeaturesInArea(const float &, const float &, const float &) const
-{
-    not_wired("KeyFrame::GetFeaturesInArea");
-    return std::vector<size_t>();
-}
-int MapPoint::PredictScale(const float &, KeyFrame *)
-{
-    not_wired("MapPoint::PredictScale");
-    return 0;
-}
-int MapPoint::PredictScale(const float &, Frame *)
-{
-    not_wired("MapPoint::PredictScale");
-    return 0;
-}
+/* Frame::GetFeaturesInArea / PosInGrid / AssignFeaturesToGrid, KeyFrame::GetFeaturesInArea, MapPoint::PredictScale and
+ * MapPoint::ComputeDistinctiveDescriptors are the reference's own bodies, sliced verbatim into ref_slices.cpp. */
+float Frame::mfGridElementWidthInv = 0.1f, Frame::mfGridElementHeightInv = 0.1f;
 } // namespace ORB_SLAM2
 #endif
 
@@ -89,7 +65,7 @@ void fill_mappoints(std::vector<MapPoint> &pool, std::vector<MapPoint *> &ptr, c
     for (int i = 0; i < n; i++) {
         const int v = valid ? valid[i] : 1;
         if (v == 0) continue;
-        pool[(size_t)i].bad = (v == 2);
+        pool[(size_t)i].mbBad = (v == 2);
         ptr[(size_t)i] = &pool[(size_t)i];
     }
 }

@@ -13,6 +13,7 @@
 #define ORBFE_REF_MOCKS_H
 
 #include <map>
+#include <mutex>
 #include <set>
 #include <vector>
 
@@ -36,27 +37,46 @@ class MapPoint
   public:
     MapPoint()
         : mTrackProjX(0), mTrackProjY(0), mTrackProjXR(0), mbTrackInView(false), mnTrackScaleLevel(0),
-          mTrackViewCos(0), mnLastFrameSeen(0), mnFuseCandidateForKF(0), bad(false), nobs(0), min_dist(0),
-          max_dist(1e9f), replaced(0)
+          mTrackViewCos(0), mnLastFrameSeen(0), mnFuseCandidateForKF(0), mbBad(false), nObs(0), mfMinDistance(0),
+          mfMaxDistance(1e9f), replaced(0)
     {
+    }
+    MapPoint(const MapPoint &o)
+        : mTrackProjX(o.mTrackProjX), mTrackProjY(o.mTrackProjY), mTrackProjXR(o.mTrackProjXR),
+          mbTrackInView(o.mbTrackInView), mnTrackScaleLevel(o.mnTrackScaleLevel), mTrackViewCos(o.mTrackViewCos),
+          mnLastFrameSeen(o.mnLastFrameSeen), mnFuseCandidateForKF(o.mnFuseCandidateForKF), mbBad(o.mbBad), nObs(o.nObs),
+          mfMinDistance(o.mfMinDistance), mfMaxDistance(o.mfMaxDistance), replaced(o.replaced), world_pos(o.world_pos),
+          normal(o.normal), mDescriptor(o.mDescriptor), mObservations(o.mObservations)
+    {
+    }
+    MapPoint &operator=(const MapPoint &o) /* the mutexes are not state */
+    {
+        mTrackProjX = o.mTrackProjX; mTrackProjY = o.mTrackProjY; mTrackProjXR = o.mTrackProjXR;
+        mbTrackInView = o.mbTrackInView; mnTrackScaleLevel = o.mnTrackScaleLevel; mTrackViewCos = o.mTrackViewCos;
+        mnLastFrameSeen = o.mnLastFrameSeen; mnFuseCandidateForKF = o.mnFuseCandidateForKF; mbBad = o.mbBad; nObs = o.nObs;
+        mfMinDistance = o.mfMinDistance; mfMaxDistance = o.mfMaxDistance; replaced = o.replaced; world_pos = o.world_pos;
+        normal = o.normal; mDescriptor = o.mDescriptor; mObservations = o.mObservations;
+        return *this;
     }
     cv::Mat GetWorldPos() { return world_pos.clone(); }
     cv::Mat GetNormal() { return normal.clone(); }
-    int Observations() { return nobs; }
+    int Observations() { return nObs; }
     void AddObservation(KeyFrame *pKF, size_t idx)
     {
-        if (!observations.count(pKF)) nobs++;
-        observations[pKF] = idx;
+        if (!mObservations.count(pKF)) nObs++;
+        mObservations[pKF] = idx;
     }
-    int GetIndexInKeyFrame(KeyFrame *pKF) { return observations.count(pKF) ? (int)observations[pKF] : -1; }
-    bool IsInKeyFrame(KeyFrame *pKF) { return observations.count(pKF) != 0; }
-    bool isBad() { return bad; }
-    void Replace(MapPoint *pMP) { replaced = pMP; bad = true; }
-    cv::Mat GetDescriptor() { return descriptor.clone(); }
-    float GetMinDistanceInvariance() { return 0.8f * min_dist; }
-    float GetMaxDistanceInvariance() { return 1.2f * max_dist; }
+    int GetIndexInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
+    bool IsInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) != 0; }
+    bool isBad() { return mbBad; }
+    void Replace(MapPoint *pMP) { replaced = pMP; mbBad = true; }
+    cv::Mat GetDescriptor() { return mDescriptor.clone(); }
+    float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+    float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+    /* bodies sliced verbatim from src/MapPoint.cc by oracle/refbuild/slice.py (ref_slices.cpp) */
     int PredictScale(const float &currentDist, KeyFrame *pKF);
     int PredictScale(const float &currentDist, Frame *pF);
+    void ComputeDistinctiveDescriptors();
 
     float mTrackProjX, mTrackProjY, mTrackProjXR;
     bool mbTrackInView;
@@ -65,21 +85,27 @@ class MapPoint
     long unsigned int mnLastFrameSeen;
     long unsigned int mnFuseCandidateForKF;
 
-    /* mock state */
-    bool bad;
-    int nobs;
-    float min_dist, max_dist;
+    /* state under the reference's member names (include/MapPoint.h:118-153) where the sliced bodies touch it */
+    bool mbBad;
+    int nObs;
+    float mfMinDistance, mfMaxDistance;
     MapPoint *replaced;
-    cv::Mat world_pos, normal, descriptor;
-    std::map<KeyFrame *, size_t> observations;
+    cv::Mat world_pos, normal, mDescriptor;
+    std::map<KeyFrame *, size_t> mObservations;
+    std::mutex mMutexFeatures, mMutexPos;
 };
 
 class Frame
 {
   public:
     Frame() : fx(1), fy(1), cx(0), cy(0), mbf(0), mb(0), N(0), mnScaleLevels(8), mfLogScaleFactor(0.18232156f) {}
+    /* bodies sliced verbatim from src/Frame.cc by oracle/refbuild/slice.py (ref_slices.cpp) */
     vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1,
                                      const int maxLevel = -1) const;
+    bool PosInGrid(const cv::KeyPoint &kp, int &posX, int &posY);
+    void AssignFeaturesToGrid();
+    static float mfGridElementWidthInv, mfGridElementHeightInv;
+    std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
     float fx, fy, cx, cy;
     float mbf, mb;
     int N;
@@ -101,7 +127,8 @@ class KeyFrame
   public:
     KeyFrame()
         : fx(1), fy(1), cx(0), cy(0), mbf(0), mb(0), N(0), mnScaleLevels(8), mfLogScaleFactor(0.18232156f), mnMinX(0),
-          mnMinY(0), mnMaxX(640), mnMaxY(480), mnId(0)
+          mnMinY(0), mnMaxX(640), mnMaxY(480), mnId(0), mnGridCols(FRAME_GRID_COLS), mnGridRows(FRAME_GRID_ROWS),
+          mfGridElementWidthInv(0.1f), mfGridElementHeightInv(0.1f), mbBad(false)
     {
     }
     cv::Mat GetCameraCenter() { return Ow.clone(); }
@@ -117,7 +144,9 @@ class KeyFrame
             if (mvpMapPoints[i] && !mvpMapPoints[i]->isBad()) s.insert(mvpMapPoints[i]);
         return s;
     }
+    /* body sliced verbatim from src/KeyFrame.cc (ref_slices.cpp) */
     std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r) const;
+    bool isBad() { return mbBad; }
     bool IsInImage(const float &x, const float &y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }
 
     float fx, fy, cx, cy, mbf, mb;
@@ -131,6 +160,10 @@ class KeyFrame
     std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
     int mnMinX, mnMinY, mnMaxX, mnMaxY;
     long unsigned int mnId;
+    int mnGridCols, mnGridRows;
+    float mfGridElementWidthInv, mfGridElementHeightInv;
+    std::vector<std::vector<std::vector<size_t> > > mGrid;
+    bool mbBad;
 
     /* mock state */
     std::vector<MapPoint *> mvpMapPoints;

@@ -32,7 +32,7 @@ SYMBOLS = (
     "orbfe_bow_transform_batch_device", "orbfe_search_by_bow_batch_device", "orbfe_matcher_set_bf_kernel",
     "orbfe_mapio_keyframe_bytes", "orbfe_mapio_write_keyframe", "orbfe_mapio_read_keyframe", "orbfe_mapio_pack_records_device",
     "orbfe_vocfile_load", "orbfe_vocfile_free", "orbfe_vocfile_info", "orbfe_vocfile_arrays", "orbfe_vocfile_save_binary",
-    "orbfe_vocabulary_create_from_file", "orbfe_interleaved_to_gray_device",
+    "orbfe_vocabulary_create_from_file", "orbfe_interleaved_to_gray_device", "orbfe_hamming_csr_ex", "orbfe_hamming_csr_device",
 )
 
 
@@ -120,6 +120,8 @@ def lib():
     L.orbfe_match_bf_frames_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, f32, i32, i32, vp, vp, vp]
     L.orbfe_search_by_bow.argtypes = ([vp] + [vp, i32, vp, vp, vp, vp, vp, i32] * 2 + [f32, i32, i32, i32, vp, vp])
     L.orbfe_hamming_csr.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]
+    L.orbfe_hamming_csr_ex.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.orbfe_hamming_csr_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orbfe_assign_grid.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp]
     L.orbfe_vocabulary_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32, vp]
     L.orbfe_vocabulary_destroy.argtypes = [vp]

@@ -554,7 +554,8 @@ __global__ __launch_bounds__(256) void k_rot_prune_bow(int32_t *__restrict__ mat
 __global__ __launch_bounds__(256) void k_hamming_csr(const uint8_t *__restrict__ q, int nq,
                                                      const uint8_t *__restrict__ t, const uint32_t *__restrict__ off,
                                                      const uint32_t *__restrict__ cand, int32_t *__restrict__ best_idx,
-                                                     int32_t *__restrict__ best, int32_t *__restrict__ second)
+                                                     int32_t *__restrict__ best, int32_t *__restrict__ second,
+                                                     int32_t *__restrict__ second_idx)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nq) return;
@@ -562,16 +563,19 @@ __global__ __launch_bounds__(256) void k_hamming_csr(const uint8_t *__restrict__
     const uint32_t *p = (const uint32_t *)(q + (int64_t)i * 32);
 #pragma unroll
     for (int k = 0; k < 8; ++k) dq.w[k] = p[k];
-    int b1 = 256, b2 = 256, bi = -1;
+    // the reference's update idiom (:128-140) with the bookkeeping it attaches to the runner-up (bestLevel2 = the level of
+    // whichever candidate last set bestDist2): si = that candidate
+    int b1 = 256, b2 = 256, bi = -1, si = -1;
     for (uint32_t j = off[i]; j < off[i + 1]; ++j) {
         const uint32_t c = cand[j];
         const int d = hamming8(dq, (const uint32_t *)(t + (int64_t)c * 32));
-        if (d < b1) { b2 = b1; b1 = d; bi = (int)c; }
-        else if (d < b2) { b2 = d; }
+        if (d < b1) { b2 = b1; si = bi; b1 = d; bi = (int)c; }
+        else if (d < b2) { b2 = d; si = (int)c; }
     }
     best_idx[i] = bi;
     best[i] = b1;
     second[i] = b2;
+    if (second_idx) second_idx[i] = si;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -855,9 +859,9 @@ extern "C" orbfe_status orbfe_search_by_bow(orbfe_matcher *m, const uint8_t *des
     return ORBFE_OK;
 }
 
-extern "C" orbfe_status orbfe_hamming_csr(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
-                                          const uint32_t *off, const uint32_t *cand, int32_t *best_idx, int32_t *best,
-                                          int32_t *second)
+extern "C" orbfe_status orbfe_hamming_csr_ex(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
+                                             const uint32_t *off, const uint32_t *cand, int32_t *best_idx, int32_t *best,
+                                             int32_t *second, int32_t *second_idx)
 {
     if (!m || nq < 0 || nt < 0 || (nq > 0 && (!q || !off || !best_idx || !best || !second))) {
         orbfe_set_error("bad argument to orbfe_hamming_csr");
@@ -878,18 +882,44 @@ extern "C" orbfe_status orbfe_hamming_csr(orbfe_matcher *m, const uint8_t *q, in
     ORBFE_HIP(m->b[4].ensure((size_t)nq * 4));
     ORBFE_HIP(m->b[5].ensure((size_t)nq * 4));
     ORBFE_HIP(m->b[6].ensure((size_t)nq * 4));
+    ORBFE_HIP(m->b[7].ensure((size_t)nq * 4));
     ORBFE_HIP(hipMemcpyAsync(m->b[0].p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     if (nt > 0) ORBFE_HIP(hipMemcpyAsync(m->b[1].p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
     ORBFE_HIP(hipMemcpyAsync(m->b[2].p, off, (size_t)(nq + 1) * 4, hipMemcpyHostToDevice, st));
     if (nc > 0) ORBFE_HIP(hipMemcpyAsync(m->b[3].p, cand, nc * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_hamming_csr, dim3((nq + 255) / 256), dim3(256), 0, st, (const uint8_t *)m->b[0].p, nq,
                        (const uint8_t *)m->b[1].p, (const uint32_t *)m->b[2].p, (const uint32_t *)m->b[3].p,
-                       (int32_t *)m->b[4].p, (int32_t *)m->b[5].p, (int32_t *)m->b[6].p);
+                       (int32_t *)m->b[4].p, (int32_t *)m->b[5].p, (int32_t *)m->b[6].p, (int32_t *)m->b[7].p);
     ORBFE_HIP(hipGetLastError());
+    if (second_idx) ORBFE_HIP(hipMemcpyAsync(second_idx, m->b[7].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipMemcpyAsync(best_idx, m->b[4].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipMemcpyAsync(best, m->b[5].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipMemcpyAsync(second, m->b[6].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipStreamSynchronize(st));
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_hamming_csr(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
+                                          const uint32_t *off, const uint32_t *cand, int32_t *best_idx, int32_t *best,
+                                          int32_t *second)
+{
+    return orbfe_hamming_csr_ex(m, q, nq, t, nt, off, cand, best_idx, best, second, nullptr);
+}
+
+// device-resident form: everything already in HBM (e.g. descriptors of an extractor output block), enqueued on `stream`
+extern "C" orbfe_status orbfe_hamming_csr_device(orbfe_matcher *m, const uint8_t *d_q, int32_t nq, const uint8_t *d_t,
+                                                 const uint32_t *d_off, const uint32_t *d_cand, int32_t *d_best_idx,
+                                                 int32_t *d_best, int32_t *d_second, int32_t *d_second_idx, void *stream)
+{
+    if (!m || nq < 0 || (nq > 0 && (!d_q || !d_t || !d_off || !d_cand || !d_best_idx || !d_best || !d_second))) {
+        orbfe_set_error("bad argument to orbfe_hamming_csr_device");
+        return ORBFE_ERR_ARG;
+    }
+    if (nq == 0) return ORBFE_OK;
+    MDeviceGuard g(m->device);
+    hipLaunchKernelGGL(k_hamming_csr, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_q, nq, d_t, d_off, d_cand,
+                       d_best_idx, d_best, d_second, d_second_idx);
+    ORBFE_HIP(hipGetLastError());
     return ORBFE_OK;
 }
 

@@ -129,6 +129,18 @@ class ORBmatcher:
         check(st, "orbfe_hamming_csr")
         return bi, b, s
 
+    def HammingCSR2(self, descQ, descT, off, cand):
+        """HammingCSR plus second_idx: the candidate owning the runner-up distance (orbfe_hamming_csr_ex)."""
+        q = np.ascontiguousarray(descQ, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(descT, np.uint8).reshape(-1, 32)
+        off = np.ascontiguousarray(off, np.uint32)
+        cand = np.ascontiguousarray(cand, np.uint32)
+        bi, si = np.full(len(q), -1, np.int32), np.full(len(q), -1, np.int32)
+        b, s = np.full(len(q), 256, np.int32), np.full(len(q), 256, np.int32)
+        check(self._L.orbfe_hamming_csr_ex(self._m, ptr(q), len(q), ptr(t), len(t), ptr(off), ptr(cand), ptr(bi), ptr(b), ptr(s),
+                                           ptr(si)), "orbfe_hamming_csr_ex")
+        return bi, b, s, si
+
     def ComputeStereoMatches(self, extractorLeft, extractorRight, keysL, descL, keysR, descR, mbf, mb):
         """SURVEY 8(f).2: Frame::ComputeStereoMatches (src/Frame.cc:642-846).  The two ORBextractor mirrors must have
         just processed the left / right image (their device-resident pyramids are read).  Returns (mvuRight, mvDepth)."""

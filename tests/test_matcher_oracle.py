@@ -116,3 +116,27 @@ def test_hamming_csr(oracle):
             elif d < b2:
                 b2 = d
         assert (bi[i], b[i], s[i]) == (ix, b1, b2)
+
+
+def test_hamming_csr2_second_owner(oracle):
+    """second_idx = the candidate that last set bestDist2 in the sequential idiom of src/ORBmatcher.cc:128-140, checked
+    against a literal Python replay (ties, single candidates, empty lists)."""
+    rng = np.random.default_rng(9)
+    t = make_desc(rng, 300)
+    t[rng.integers(0, 300, 120)] = t[rng.integers(0, 300, 120)]
+    q = make_desc(rng, 200, base=t[rng.integers(0, 300, 200)], flips=12)
+    lens = rng.integers(0, 25, 200)
+    lens[:5] = [0, 1, 2, 1, 0]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    cand = rng.integers(0, 300, int(off[-1])).astype(np.uint32)
+    bi, b, s, si = oracle.hamming_csr2(q, t, off, cand)
+    for i in range(200):
+        b1, b2, i1, i2 = 256, 256, -1, -1
+        for c in cand[off[i]:off[i + 1]]:
+            d = int(np.unpackbits(q[i] ^ t[c]).sum())
+            if d < b1:
+                b2, i2, b1, i1 = b1, i1, d, int(c)
+            elif d < b2:
+                b2, i2 = d, int(c)
+        assert (bi[i], b[i], s[i], si[i]) == (i1, b1, b2, i2), i
+    assert np.array_equal(oracle.hamming_csr(q, t, off, cand)[2], s)

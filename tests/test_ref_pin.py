@@ -321,3 +321,37 @@ def test_search_by_bow_kf_kf_equals_reference(ref, oracle, seed):
         o12 = np.full(n1, -1, np.int32)
         o12[o21[o21 >= 0]] = np.flatnonzero(o21 >= 0)
         assert rn == on and np.array_equal(r12, o12), (seed, it, n1, n2)
+
+
+# ---------------------------------------------------------------------------------------------- (f) rows: sliced reference bodies
+def test_frame_grid_equals_sliced_reference(ref, oracle):
+    """8(f).2: oracle assign_grid / features_in_area == Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea cut
+    verbatim out of src/Frame.cc:319-334, 465-531 (keypoints on cell borders, outside the grid, level filters, radii that
+    leave the image)."""
+    from test_grid import grid_case, queries
+    for seed in range(12):
+        xy, octave, minx, miny, gwi, ghi = grid_case(seed, [0, 1, 50, 1000, 2500][seed % 5])
+        ro, ri = ref.assign_grid(xy, minx, miny, gwi, ghi)
+        oo, oi = oracle.assign_grid(xy, minx, miny, gwi, ghi)
+        assert np.array_equal(ro, oo) and np.array_equal(ri, oi), seed
+        q, lv = queries(seed, 120)
+        for i in range(len(q)):
+            a = ref.features_in_area(xy, octave, ro, ri, minx, miny, gwi, ghi, q[i, 0], q[i, 1], q[i, 2], lv[i, 0], lv[i, 1])
+            b = oracle.features_in_area(xy, octave, oo, oi, minx, miny, gwi, ghi, float(q[i, 0]), float(q[i, 1]), float(q[i, 2]),
+                                        int(lv[i, 0]), int(lv[i, 1]))
+            assert np.array_equal(a, b), (seed, i)
+
+
+def test_distinctive_descriptors_equal_sliced_reference(ref, oracle):
+    """8(f).4: oracle distinctive == MapPoint::ComputeDistinctiveDescriptors cut verbatim out of src/MapPoint.cc:284-345
+    (median at index 0.5*(N-1), first least median wins; 1..90 observations, duplicates)."""
+    from test_distinctive import make_case
+    for seed in range(10):
+        pool, off, idx = make_case(seed, [1, 5, 60, 300][seed % 4], [1, 2, 9, 90][seed % 4])
+        best, has = ref.distinctive(pool, off, idx)
+        bi, med = oracle.distinctive(pool, off, idx)
+        for p in range(len(off) - 1):
+            if off[p + 1] == off[p]:
+                assert not has[p] and bi[p] == -1
+            else:
+                assert has[p] and np.array_equal(best[p], pool[idx[off[p] + bi[p]]]), (seed, p)
