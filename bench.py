@@ -490,6 +490,7 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
 
     if world == 1:
         result["bow_chain"] = bow_leg(args, local_rank)
+        result["host_api"] = host_api_leg(args, local_rank, d_gray[:F])
 
     if world == 1 and not args.no_cpu_baseline:
         # online (single-frame, host buffers in / out) latency of ORBextractor::operator(): replicas-only path
@@ -624,6 +625,35 @@ def workload_legs(args, eng, d_S, local_rank):
         out[name] = row
     eng.ext.set_fast_mode(args.fast_mode)
     return out
+
+
+def host_api_leg(args, local_rank, d_src, nframes=8192, chunk=512):
+    """The library's own host entry point (orbfe_extract_batch: host frames in, host keypoints / descriptors out, extract
+    only) on page-locked buffers: chunks of `chunk` frames pipelined inside liborbfe.so on three streams."""
+    import ctypes as C
+    from orb_slam2_ssd_semantic_amd import ORBextractor, _ffi
+    w, h, nf = args.width, args.height, args.nfeatures
+    nb = d_src.shape[0]
+    ext = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=chunk, device=local_rank)
+    cap = ext.capacity()
+    pf = d_src.cpu().pin_memory()
+    pk = torch.empty((nframes, cap, 7), dtype=torch.int32).pin_memory()
+    pd = torch.empty((nframes, cap, 32), dtype=torch.uint8).pin_memory()
+    pn = torch.zeros(nframes, dtype=torch.int32).pin_memory()
+    arr = (C.c_void_p * nframes)(*[pf[i % nb].data_ptr() for i in range(nframes)])
+    L = _ffi.lib()
+
+    def run():
+        _ffi.check(L.orbfe_extract_batch(ext.handle, arr, nframes, w, h, w, pk.data_ptr(), pd.data_ptr(), cap, pn.data_ptr()),
+                   "orbfe_extract_batch")
+    run()
+    t = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        run()
+    dt = (time.perf_counter() - t) / reps
+    return {"frames_per_s": round(nframes / dt, 1), "frames_per_call": nframes, "chunk": chunk, "mean_keypoints": round(float(pn.float().mean()), 1),
+            "what": "orbfe_extract_batch on page-locked host frames / outputs (extract only; the pipeline is inside liborbfe.so)"}
 
 
 def bow_leg(args, local_rank, npairs=256, steps=10, warmup=3, standalone=False):

@@ -100,7 +100,12 @@ orbfe_status orbfe_extract(orbfe_handle *h, const uint8_t *gray, int32_t w, int3
                            orbfe_keypoint *kps, uint8_t *desc /* cap x 32 */, int32_t cap, int32_t *n_out);
 
 /* Batched keyframe mode, HOST buffers: frames are independent.  grays[i] points to
- * frame i (all w x ht, same stride).  Frame i writes kps[i*cap ..], desc[i*cap*32 ..], n_out[i]. */
+ * frame i (all w x ht, same stride).  Frame i writes kps[i*cap ..], desc[i*cap*32 ..], n_out[i].
+ * More than max_batch frames run as a pipeline (H2D of the next chunk, kernels of the current one and D2H of the previous
+ * one overlap on three streams).  Page-locked memory (hipHostMalloc / hipHostRegister / torch pin_memory) is used as it
+ * is: frames with stride == w are copied straight from the caller's buffers, and page-locked kps / desc / n_out arrays
+ * receive the padded device blocks directly (slots >= n_out[i] zero-filled); pageable memory goes through the handle's
+ * own pinned staging sets. */
 orbfe_status orbfe_extract_batch(orbfe_handle *h, const uint8_t *const *grays, int32_t nframes, int32_t w,
                                  int32_t ht, int32_t stride, orbfe_keypoint *kps, uint8_t *desc, int32_t cap,
                                  int32_t *n_out);

@@ -153,8 +153,11 @@ struct orbfe_handle {
     hipStream_t last_stream = nullptr;  // stream of the most recent batched call (synchronised before re-planning)
     bool last_stream_valid = false;
     // host-API staging
-    DevBuf d_stage, d_okps, d_odesc, d_on;
-    PinBuf h_stage, h_okps, h_odesc, h_on;
+    // two sets, so that the H2D of chunk i+1, the kernels of chunk i and the D2H of chunk i-1 overlap
+    DevBuf d_stage[2], d_okps[2], d_odesc[2], d_on[2];
+    PinBuf h_stage[2], h_okps[2], h_odesc[2], h_on[2];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     // last call (for taps / mvImagePyramid)
     const uint8_t *last_gray = nullptr;
     int64_t last_gray_fstride = 0;
@@ -587,6 +590,18 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
         orbfe_set_error("side stream / event creation failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(ORBFE_ERR_HIP);
     }
+    if (hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess) {
+        orbfe_set_error("copy stream creation failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(ORBFE_ERR_HIP);
+    }
+    for (int k = 0; k < 2; ++k)
+        if (hipEventCreateWithFlags(&h->ev_in[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_cmp[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_out[k], hipEventDisableTiming) != hipSuccess) {
+            orbfe_set_error("pipeline event creation failed");
+            return fail(ORBFE_ERR_HIP);
+        }
     if (const char *e = getenv("ORBFE_OVERLAP")) h->overlap = std::max(0, std::min(2, atoi(e)));
     int umax[16];
     host_umax(umax);
@@ -607,12 +622,21 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (!h) return;
     DeviceGuard g(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_stage,
-                      &h->d_okps, &h->d_odesc, &h->d_on};
+    if (h->s_in) (void)hipStreamSynchronize(h->s_in);
+    if (h->s_out) (void)hipStreamSynchronize(h->s_out);
+    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys,
+                      &h->d_stage[0], &h->d_okps[0], &h->d_odesc[0], &h->d_on[0], &h->d_stage[1], &h->d_okps[1], &h->d_odesc[1], &h->d_on[1]};
     for (DevBuf *b : bufs) b->release();
     h->d_misc.release();
-    PinBuf *pins[] = {&h->h_stage, &h->h_okps, &h->h_odesc, &h->h_on};
+    PinBuf *pins[] = {&h->h_stage[0], &h->h_okps[0], &h->h_odesc[0], &h->h_on[0], &h->h_stage[1], &h->h_okps[1], &h->h_odesc[1], &h->h_on[1]};
     for (PinBuf *b : pins) b->release();
+    for (int k = 0; k < 2; ++k) {
+        if (h->ev_in[k]) (void)hipEventDestroy(h->ev_in[k]);
+        if (h->ev_cmp[k]) (void)hipEventDestroy(h->ev_cmp[k]);
+        if (h->ev_out[k]) (void)hipEventDestroy(h->ev_out[k]);
+    }
+    if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_out) (void)hipStreamDestroy(h->s_out);
     if (h->ev_ok)
         for (int r = 0; r < ORBFE_PROF_RING; ++r)
             for (int i = 0; i < ORBFE_EV_N; ++i)
@@ -826,57 +850,143 @@ extern "C" orbfe_status orbfe_extract_batch_device(orbfe_handle *h, const uint8_
                      (hipStream_t)stream);
 }
 
-// host buffers: stage through pinned memory in chunks of max_batch frames
+// host buffers, in chunks of max_batch frames.  A single chunk (the online case: one frame) is a plain H2D -> kernels ->
+// D2H sequence on the handle's stream.  Several chunks run as a pipeline over two buffer sets and three streams: while
+// the kernels of chunk i run, chunk i+1 is copied in (s_in) and chunk i-1 is copied out (s_out) and unpacked by the host.
+// Frames in pinned (page-locked / hipHostRegister'ed) memory with stride == w are copied straight from the caller's
+// buffers; pageable frames are first gathered into the pinned staging set (the host memcpy then overlaps the GPU work).
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'ed memory: "invalid value", not an error of ours
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
 static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, int nframes, int w, int ht,
                                  int stride, orbfe_keypoint *kps, uint8_t *desc, int cap, int32_t *n_out)
 {
     DeviceGuard g(h->device);
     const int chunk_max = h->prm.max_batch;
-    const int pitch = orb_align_up(w, 64);
+    const int nchunks = (nframes + chunk_max - 1) / chunk_max;
+    const bool direct = stride == w && is_pinned_host(grays[0]) && is_pinned_host(grays[nframes - 1]);
+    // pinned output arrays receive the padded device blocks as they are (slots >= n_out[f] zero-filled): no host unpacking
+    const bool direct_out = is_pinned_host(kps) && is_pinned_host(desc) && is_pinned_host(n_out);
+    const int pitch = direct ? w : orb_align_up(w, 64);
     const size_t fbytes = (size_t)pitch * ht;
+    const int nset = nchunks > 1 ? 2 : 1;
+    const size_t nbmax = (size_t)std::min(chunk_max, nframes);
+    for (int k = 0; k < nset; ++k) {
+        if (!direct) ORBFE_HIP(h->h_stage[k].ensure(fbytes * nbmax));
+        ORBFE_HIP(h->d_stage[k].ensure(fbytes * nbmax + 64));
+        ORBFE_HIP(h->d_okps[k].ensure(sizeof(orbfe_keypoint) * (size_t)cap * nbmax));
+        ORBFE_HIP(h->d_odesc[k].ensure((size_t)32 * cap * nbmax));
+        ORBFE_HIP(h->d_on[k].ensure(sizeof(int32_t) * nbmax));
+        if (!direct_out) {
+            ORBFE_HIP(h->h_okps[k].ensure(sizeof(orbfe_keypoint) * (size_t)cap * nbmax));
+            ORBFE_HIP(h->h_odesc[k].ensure((size_t)32 * cap * nbmax));
+            ORBFE_HIP(h->h_on[k].ensure(sizeof(int32_t) * nbmax));
+        }
+    }
+    // size the plan and the per-batch blocks once, before anything is in flight
+    if (w > h->prm.max_width || ht > h->prm.max_height) {
+        orbfe_set_error("frame %dx%d larger than planned %dx%d", w, ht, h->prm.max_width, h->prm.max_height);
+        return ORBFE_ERR_SIZE;
+    }
+    orbfe_status sp = build_plan(h, w, ht);
+    if (sp != ORBFE_OK) return sp;
+    sp = ensure_batch_buffers(h, (int)nbmax);
+    if (sp != ORBFE_OK) return sp;
+
+    const bool piped = nchunks > 1;
+    hipStream_t s_in = piped ? h->s_in : h->stream, s_cmp = h->stream, s_out = piped ? h->s_out : h->stream;
     orbfe_status worst = ORBFE_OK;
-    for (int f0 = 0; f0 < nframes; f0 += chunk_max) {
-        const int nb = std::min(chunk_max, nframes - f0);
-        ORBFE_HIP(h->h_stage.ensure(fbytes * nb));
-        ORBFE_HIP(h->d_stage.ensure(fbytes * nb + 64));  // + slack: kernels read whole dwords past the last pixel
-        ORBFE_HIP(h->d_okps.ensure(sizeof(orbfe_keypoint) * (size_t)cap * nb));
-        ORBFE_HIP(h->d_odesc.ensure((size_t)32 * cap * nb));
-        ORBFE_HIP(h->d_on.ensure(sizeof(int32_t) * nb));
-        ORBFE_HIP(h->h_okps.ensure(sizeof(orbfe_keypoint) * (size_t)cap * nb));
-        ORBFE_HIP(h->h_odesc.ensure((size_t)32 * cap * nb));
-        ORBFE_HIP(h->h_on.ensure(sizeof(int32_t) * nb));
-        for (int f = 0; f < nb; ++f) {
-            uint8_t *dst = (uint8_t *)h->h_stage.p + fbytes * f;
-            const uint8_t *src = grays[f0 + f];
-            for (int y = 0; y < ht; ++y) memcpy(dst + (size_t)y * pitch, src + (size_t)y * stride, (size_t)w);
-        }
-        ORBFE_HIP(hipMemcpyAsync(h->d_stage.p, h->h_stage.p, fbytes * nb, hipMemcpyHostToDevice, h->stream));
-        orbfe_status s = run_batch(h, (const uint8_t *)h->d_stage.p, nb, w, ht, pitch, fbytes,
-                                   (orbfe_keypoint *)h->d_okps.p, (uint8_t *)h->d_odesc.p, cap, (int32_t *)h->d_on.p,
-                                   h->stream);
-        if (s != ORBFE_OK) return s;
-        ORBFE_HIP(hipMemcpyAsync(h->h_on.p, h->d_on.p, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, h->stream));
-        ORBFE_HIP(hipMemcpyAsync(h->h_okps.p, h->d_okps.p, sizeof(orbfe_keypoint) * (size_t)cap * nb,
-                                 hipMemcpyDeviceToHost, h->stream));
-        ORBFE_HIP(hipMemcpyAsync(h->h_odesc.p, h->d_odesc.p, (size_t)32 * cap * nb, hipMemcpyDeviceToHost, h->stream));
-        ORBFE_HIP(hipStreamSynchronize(h->stream));
-        {
-            int32_t ovf = 0;
-            orbfe_status so = read_overflow(h, &ovf);
-            if (so != ORBFE_OK) return so;
-            if (ovf & 3) {
-                orbfe_set_error("internal capacity exceeded (flags %d: 1 = FAST survivor list, 2 = quadtree selection); "
-                                "results of this batch are incomplete", ovf);
-                return ORBFE_ERR_CAP;
-            }
+    auto drain = [&]() {
+        (void)hipStreamSynchronize(h->s_in);
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->s_out);
+    };
+    auto unpack = [&](int c) -> orbfe_status {  // results of chunk c: wait for its D2H, hand them to the caller
+        const int k = c & (nset - 1), f0 = c * chunk_max, nb = std::min(chunk_max, nframes - f0);
+        ORBFE_HIP(hipEventSynchronize(h->ev_out[k]));
+        if (direct_out) {
+            for (int f = 0; f < nb; ++f)
+                if (n_out[f0 + f] > cap) worst = ORBFE_ERR_CAP;
+            return ORBFE_OK;
         }
         for (int f = 0; f < nb; ++f) {
-            const int n = ((int32_t *)h->h_on.p)[f];
+            const int n = ((int32_t *)h->h_on[k].p)[f];
             n_out[f0 + f] = n;
             if (n > cap) { worst = ORBFE_ERR_CAP; continue; }
-            memcpy(kps + (size_t)(f0 + f) * cap, (orbfe_keypoint *)h->h_okps.p + (size_t)f * cap,
-                   sizeof(orbfe_keypoint) * (size_t)n);
-            memcpy(desc + (size_t)(f0 + f) * cap * 32, (uint8_t *)h->h_odesc.p + (size_t)f * cap * 32, (size_t)32 * n);
+            memcpy(kps + (size_t)(f0 + f) * cap, (orbfe_keypoint *)h->h_okps[k].p + (size_t)f * cap, sizeof(orbfe_keypoint) * (size_t)n);
+            memcpy(desc + (size_t)(f0 + f) * cap * 32, (uint8_t *)h->h_odesc[k].p + (size_t)f * cap * 32, (size_t)32 * n);
+        }
+        return ORBFE_OK;
+    };
+    for (int c = 0; c < nchunks; ++c) {
+        const int k = c & (nset - 1), f0 = c * chunk_max, nb = std::min(chunk_max, nframes - f0);
+        if (c >= 2) {  // set k was last used by chunk c-2: collect its results before its buffers are reused
+            orbfe_status su = unpack(c - 2);
+            if (su != ORBFE_OK) { drain(); return su; }
+        }
+        // ---- in ----
+        if (piped && c >= 2) ORBFE_HIP(hipStreamWaitEvent(s_in, h->ev_cmp[k], 0));  // kernels of chunk c-2 read d_stage[k]
+        if (direct) {
+            bool contiguous = true;
+            for (int f = 1; f < nb && contiguous; ++f) contiguous = grays[f0 + f] == grays[f0] + fbytes * f;
+            if (contiguous) {
+                ORBFE_HIP(hipMemcpyAsync(h->d_stage[k].p, grays[f0], fbytes * nb, hipMemcpyHostToDevice, s_in));
+            } else {
+                for (int f = 0; f < nb; ++f)
+                    ORBFE_HIP(hipMemcpyAsync((uint8_t *)h->d_stage[k].p + fbytes * f, grays[f0 + f], fbytes, hipMemcpyHostToDevice, s_in));
+            }
+        } else {
+            // h_stage[k] was read by the H2D of chunk c-2, which the kernels of chunk c-2 waited for and whose results
+            // were just unpacked: free to overwrite
+            for (int f = 0; f < nb; ++f) {
+                uint8_t *dst = (uint8_t *)h->h_stage[k].p + fbytes * f;
+                const uint8_t *src = grays[f0 + f];
+                for (int y = 0; y < ht; ++y) memcpy(dst + (size_t)y * pitch, src + (size_t)y * stride, (size_t)w);
+            }
+            ORBFE_HIP(hipMemcpyAsync(h->d_stage[k].p, h->h_stage[k].p, fbytes * nb, hipMemcpyHostToDevice, s_in));
+        }
+        if (piped) {
+            ORBFE_HIP(hipEventRecord(h->ev_in[k], s_in));
+            ORBFE_HIP(hipStreamWaitEvent(s_cmp, h->ev_in[k], 0));
+            if (c >= 2) ORBFE_HIP(hipStreamWaitEvent(s_cmp, h->ev_out[k], 0));  // D2H of chunk c-2 read the output set k
+        }
+        // ---- kernels ----
+        orbfe_status s = run_batch(h, (const uint8_t *)h->d_stage[k].p, nb, w, ht, pitch, fbytes, (orbfe_keypoint *)h->d_okps[k].p,
+                                   (uint8_t *)h->d_odesc[k].p, cap, (int32_t *)h->d_on[k].p, s_cmp);
+        if (s != ORBFE_OK) { drain(); return s; }
+        if (piped) {
+            ORBFE_HIP(hipEventRecord(h->ev_cmp[k], s_cmp));
+            ORBFE_HIP(hipStreamWaitEvent(s_out, h->ev_cmp[k], 0));
+        }
+        // ---- out ----
+        void *on = direct_out ? (void *)(n_out + f0) : h->h_on[k].p;
+        void *ok = direct_out ? (void *)(kps + (size_t)f0 * cap) : h->h_okps[k].p;
+        void *od = direct_out ? (void *)(desc + (size_t)f0 * cap * 32) : h->h_odesc[k].p;
+        ORBFE_HIP(hipMemcpyAsync(on, h->d_on[k].p, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s_out));
+        ORBFE_HIP(hipMemcpyAsync(ok, h->d_okps[k].p, sizeof(orbfe_keypoint) * (size_t)cap * nb, hipMemcpyDeviceToHost, s_out));
+        ORBFE_HIP(hipMemcpyAsync(od, h->d_odesc[k].p, (size_t)32 * cap * nb, hipMemcpyDeviceToHost, s_out));
+        ORBFE_HIP(hipEventRecord(h->ev_out[k], s_out));
+    }
+    for (int c = std::max(0, nchunks - 2); c < nchunks; ++c) {
+        orbfe_status su = unpack(c);
+        if (su != ORBFE_OK) { drain(); return su; }
+    }
+    ORBFE_HIP(hipStreamSynchronize(s_cmp));
+    {
+        int32_t ovf = 0;
+        orbfe_status so = read_overflow(h, &ovf);
+        if (so != ORBFE_OK) return so;
+        if (ovf & 3) {
+            orbfe_set_error("internal capacity exceeded (flags %d: 1 = FAST survivor list, 2 = quadtree selection); "
+                            "results of this batch are incomplete", ovf);
+            return ORBFE_ERR_CAP;
         }
     }
     if (worst == ORBFE_ERR_CAP) orbfe_set_error("cap=%d too small; n_out holds the required counts", cap);

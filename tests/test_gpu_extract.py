@@ -274,3 +274,47 @@ def test_exact_sized_input_buffer_is_never_overrun(oracle):
         ok, od = oe(frames[i])
         gk = d_kps[i, :n[i]].cpu().numpy().copy().view(KP_DTYPE).reshape(-1)
         assert_same_output(gk, d_desc[i, :n[i]].cpu().numpy(), ok, od)
+
+
+def test_host_batch_pipeline_pageable_and_pinned(oracle):
+    """orbfe_extract_batch with more frames than max_batch: the three-stream pipeline over two buffer sets.  Pageable numpy
+    frames with a row stride (staged) and page-locked torch tensors in and out (copied directly, padded rows zero-filled)
+    must both give, frame by frame, what the oracle gives."""
+    import ctypes as C
+    import torch
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE, ORBextractor, _ffi
+    N, w, h = 19, 640, 480
+    frames = np.stack([synth_frame(800 + i, h, w, sparse=(i % 3 == 0)) for i in range(N)])
+    oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    expect = [oe(f) for f in frames]
+    for max_batch in (4, 8):
+        e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=max_batch)
+        cap = e.capacity()
+        # (a) pageable, strided rows
+        wide = np.zeros((N, h, w + 24), np.uint8)
+        wide[:, :, :w] = frames
+        arr = (C.c_void_p * N)(*[wide[i].ctypes.data for i in range(N)])
+        kps = np.zeros((N, cap), KP_DTYPE)
+        desc = np.zeros((N, cap, 32), np.uint8)
+        n = np.zeros(N, np.int32)
+        st = _ffi.lib().orbfe_extract_batch(e.handle, arr, N, w, h, w + 24, kps.ctypes.data, desc.ctypes.data, cap, n.ctypes.data)
+        _ffi.check(st, "orbfe_extract_batch")
+        for i in range(N):
+            ok, od = expect[i]
+            assert n[i] == len(ok) and np.array_equal(desc[i, :n[i]], od), (max_batch, i)
+            assert np.array_equal(kps[i, :n[i]].view(np.uint8), ok.view(np.uint8)), (max_batch, i)
+        # (b) page-locked in and out
+        pf = torch.from_numpy(frames).pin_memory()
+        pk = torch.full((N, cap, 7), -1, dtype=torch.int32).pin_memory()
+        pd = torch.full((N, cap, 32), 7, dtype=torch.uint8).pin_memory()
+        pn = torch.zeros(N, dtype=torch.int32).pin_memory()
+        arr = (C.c_void_p * N)(*[pf[i].data_ptr() for i in range(N)])
+        st = _ffi.lib().orbfe_extract_batch(e.handle, arr, N, w, h, w, pk.data_ptr(), pd.data_ptr(), cap, pn.data_ptr())
+        _ffi.check(st, "orbfe_extract_batch")
+        k2, d2, n2 = pk.numpy().view(KP_DTYPE).reshape(N, cap), pd.numpy(), pn.numpy()
+        for i in range(N):
+            ok, od = expect[i]
+            assert n2[i] == len(ok) and np.array_equal(d2[i, :n2[i]], od), (max_batch, i)
+            assert np.array_equal(k2[i, :n2[i]].view(np.uint8), ok.view(np.uint8)), (max_batch, i)
+            assert not d2[i, n2[i]:].any() and not k2[i, n2[i]:].view(np.uint8).any()   # padded slots zero-filled
+        assert e.overflow() == 0
