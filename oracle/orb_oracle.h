@@ -16,7 +16,9 @@
  *     oracle == _ref bit for bit, stage by stage, on the golden cases + 200 seeded frames + 300 quadtree sets +
  *     480 SearchByBoW cases: constructor tables, pyramid orchestration, the cell loop and threshold fallback,
  *     DistributeOctTree / DivideNode, IC_Angle, computeOrbDescriptor, rescale + order, DescriptorDistance,
- *     SearchByBoW x2, ComputeThreeMaxima.  tests/golden/orb_golden.npz is generated from _ref.
+ *     SearchByBoW x2, ComputeThreeMaxima.  tests/golden/orb_golden.npz is generated from _ref.  The (f) rows --
+ *     Frame grid + GetFeaturesInArea, ComputeStereoMatches, ComputeDistinctiveDescriptors -- are checked against the
+ *     reference's function bodies cut verbatim out of Frame.cc / MapPoint.cc at build time (oracle/refbuild/slice.py).
  *   - cv::resize, copyMakeBorder, cv::FAST, GaussianBlur, fastAtan2 are NOT in /root/reference (OpenCV is a
  *     non-vendored, un-pinned dependency and is not installed): inside _ref they are THIS file's restatements
  *     of the OpenCV 3.2 generic path, pinned only by known-answer tables and definition-level twins

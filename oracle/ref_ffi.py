@@ -80,6 +80,7 @@ def lib():
     L.ref_features_in_area.argtypes = [vp, vp, ci, vp, vp, cf, cf, cf, cf, cf, cf, cf, ci, ci, vp, ci]
     L.ref_distinctive.argtypes = [vp, ci, vp, vp, ci, vp, vp]
     L.ref_predict_scale.argtypes = [cf, cf, cf, ci]
+    L.ref_stereo_matches.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
     _lib = L
     return L
 
@@ -320,3 +321,15 @@ def distinctive(pool, off, idx):
 
 def predict_scale(max_distance, current_dist, log_scale_factor, nlevels):
     return lib().ref_predict_scale(float(max_distance), float(current_dist), float(log_scale_factor), int(nlevels))
+
+
+def stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mbf, mb):
+    """Frame::ComputeStereoMatches (src/Frame.cc:642-846, sliced) on the pyramids of two RefExtractors' last calls"""
+    kl = np.ascontiguousarray(kpsL, KP_DTYPE)
+    kr = np.ascontiguousarray(kpsR, KP_DTYPE)
+    dl = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+    dr = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+    u = np.zeros(max(len(kl), 1), np.float32)
+    d = np.zeros(max(len(kl), 1), np.float32)
+    lib().ref_stereo_matches(exL.h, exR.h, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), float(mbf), float(mb), _p(u), _p(d))
+    return u[:len(kl)], d[:len(kl)]

@@ -404,6 +404,10 @@ class Mat
     static MatExpr zeros(int rows, int cols, int type);
     static MatExpr zeros(Size size, int type);
     static MatExpr eye(int rows, int cols, int type);
+    static MatExpr ones(int rows, int cols, int type);
+    /* core/convert.cpp Mat::convertTo, only CV_8U / CV_32F -> CV_32F (alpha 1, beta 0); in-place use allocates a new
+     * buffer because the type changes, as OpenCV does */
+    void convertTo(Mat &dst, int rtype) const;
 
     /* float linear algebra used by the projection matchers of ORBmatcher.cc (eager; CV_32F only) */
     Mat t() const;
@@ -435,7 +439,7 @@ class Mat
 class MatExpr
 {
   public:
-    enum { ZEROS = 0, EYE = 1 };
+    enum { ZEROS = 0, EYE = 1, ONES = 2 };
     MatExpr(int k, int r, int c, int t) : kind(k), rows(r), cols(c), type(t) {}
     operator Mat() const
     {
@@ -446,7 +450,7 @@ class MatExpr
     void assign(Mat &m) const
     {
         m.create(rows, cols, type);
-        m.setTo(0);
+        m.setTo(kind == ONES ? 1 : 0);
         if (kind == EYE)
             for (int i = 0; i < std::min(rows, cols); i++) {
                 if (m.depth() == CV_32F) m.at<float>(i, i) = 1.f;
@@ -465,6 +469,15 @@ inline Mat &Mat::operator=(const MatExpr &e)
 inline MatExpr Mat::zeros(int r, int c, int t) { return MatExpr(MatExpr::ZEROS, r, c, t); }
 inline MatExpr Mat::zeros(Size s, int t) { return MatExpr(MatExpr::ZEROS, s.height, s.width, t); }
 inline MatExpr Mat::eye(int r, int c, int t) { return MatExpr(MatExpr::EYE, r, c, t); }
+inline MatExpr Mat::ones(int r, int c, int t) { return MatExpr(MatExpr::ONES, r, c, t); }
+inline void Mat::convertTo(Mat &dst, int rtype) const
+{
+    assert(CV_MAT_DEPTH(rtype) == CV_32F && channels() == 1 && (depth() == CV_8U || depth() == CV_32F));
+    Mat out(rows, cols, CV_32F);
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) out.at<float>(y, x) = depth() == CV_8U ? (float)at<uchar>(y, x) : at<float>(y, x);
+    dst = out;
+}
 
 /* ---- eager CV_32F algebra (only what ORBmatcher.cc's projection family needs; not on any tested path that
  *      claims bit-parity with OpenCV's gemm) ---- */
@@ -533,6 +546,17 @@ inline Mat operator-(const Mat &a, const Mat &b)
 }
 inline Mat operator-(const Mat &a) { return a * -1.0; }
 inline double norm(const Mat &a) { return std::sqrt(a.dot(a)); }
+enum { NORM_INF = 1, NORM_L1 = 2, NORM_L2 = 4 };
+/* core/stat.cpp cv::norm(src1, src2, NORM_L1) for CV_32F: sum of |a - b| accumulated in double */
+inline double norm(const Mat &a, const Mat &b, int normType)
+{
+    assert(normType == NORM_L1 && a.rows == b.rows && a.cols == b.cols && a.depth() == CV_32F && b.depth() == CV_32F);
+    (void)normType;
+    double s = 0;
+    for (int y = 0; y < a.rows; y++)
+        for (int x = 0; x < a.cols; x++) s += std::abs((double)(a.at<float>(y, x) - b.at<float>(y, x)));
+    return s;
+}
 
 /* ---------------------------------------------------------------- InputArray / OutputArray proxies */
 class _InputArray

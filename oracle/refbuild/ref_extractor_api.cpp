@@ -97,6 +97,9 @@ static_assert(sizeof(ref_keypoint) == sizeof(cv::KeyPoint), "layout");
 
 void ref_config_bump(int bump) { g_bump = bump ? 1 : 0; }
 
+/* the reference object behind a handle (for ref_slices.cpp: Frame::ComputeStereoMatches reads its mvImagePyramid) */
+void *ref_ext_object(void *h) { return static_cast<ORB_SLAM2::ORBextractor *>(((RefExt *)h)->ext); }
+
 void *ref_ext_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th)
 {
     RefExt *r = new RefExt();

@@ -20,6 +20,7 @@
 #include <opencv2/core/core.hpp>
 
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+#include "ORBextractor.h" /* the reference's own header (compiles against the cv stub): Frame holds two of them */
 
 #define FRAME_GRID_ROWS 48
 #define FRAME_GRID_COLS 64
@@ -98,7 +99,11 @@ class MapPoint
 class Frame
 {
   public:
-    Frame() : fx(1), fy(1), cx(0), cy(0), mbf(0), mb(0), N(0), mnScaleLevels(8), mfLogScaleFactor(0.18232156f) {}
+    Frame()
+        : mpORBextractorLeft(0), mpORBextractorRight(0), fx(1), fy(1), cx(0), cy(0), mbf(0), mb(0), N(0), mnScaleLevels(8),
+          mfLogScaleFactor(0.18232156f)
+    {
+    }
     /* bodies sliced verbatim from src/Frame.cc by oracle/refbuild/slice.py (ref_slices.cpp) */
     vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1,
                                      const int maxLevel = -1) const;
@@ -106,6 +111,10 @@ class Frame
     void AssignFeaturesToGrid();
     static float mfGridElementWidthInv, mfGridElementHeightInv;
     std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+    void ComputeStereoMatches(); /* src/Frame.cc:642-846, sliced */
+    ORBextractor *mpORBextractorLeft, *mpORBextractorRight;
+    std::vector<cv::KeyPoint> mvKeysRight;
+    cv::Mat mDescriptorsRight;
     float fx, fy, cx, cy;
     float mbf, mb;
     int N;

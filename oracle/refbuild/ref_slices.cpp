@@ -5,6 +5,7 @@
  * TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Pins the (f) rows of the oracle to the reference's own code:
  *   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea      src/Frame.cc:319-334, 522-531, 465-518
  *   KeyFrame::GetFeaturesInArea                                      src/KeyFrame.cc:659-698
+ *   Frame::ComputeStereoMatches                                      src/Frame.cc:642-846
  *   MapPoint::ComputeDistinctiveDescriptors, PredictScale x2         src/MapPoint.cc:284-345, 448-480
  * and gives the projection family of the compiled ORBmatcher.cc the grid queries it calls.
  */
@@ -96,6 +97,36 @@ int ref_distinctive(const uint8_t *pool, int npool, const uint32_t *off, const u
         mp.ComputeDistinctiveDescriptors();
         has[p] = mp.mDescriptor.empty() ? 0 : 1;
         if (has[p]) memcpy(best_desc + (size_t)p * 32, mp.mDescriptor.ptr(0), 32);
+    }
+    return 0;
+}
+
+/* Frame::ComputeStereoMatches on the pyramids two reference extractors built in their last operator() calls.
+ * The reference reads `mb` before its constructor assigns it (:682); here the caller supplies it. */
+void *ref_ext_object(void *h);
+struct ref_kp {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+};
+int ref_stereo_matches(void *extL, void *extR, const ref_kp *kpsL, const uint8_t *descL, int nL, const ref_kp *kpsR,
+                       const uint8_t *descR, int nR, float mbf, float mb, float *uRight, float *depth)
+{
+    Frame f;
+    f.mpORBextractorLeft = (ORBextractor *)ref_ext_object(extL);
+    f.mpORBextractorRight = (ORBextractor *)ref_ext_object(extR);
+    f.N = nL;
+    f.mvKeys.assign((const cv::KeyPoint *)kpsL, (const cv::KeyPoint *)kpsL + nL);
+    f.mvKeysRight.assign((const cv::KeyPoint *)kpsR, (const cv::KeyPoint *)kpsR + nR);
+    f.mDescriptors = cv::Mat(nL, 32, CV_8UC1, (void *)descL);
+    f.mDescriptorsRight = cv::Mat(nR, 32, CV_8UC1, (void *)descR);
+    f.mvScaleFactors = f.mpORBextractorLeft->GetScaleFactors();
+    f.mvInvScaleFactors = f.mpORBextractorLeft->GetInverseScaleFactors();
+    f.mbf = mbf;
+    f.mb = mb;
+    f.ComputeStereoMatches();
+    for (int i = 0; i < nL; i++) {
+        uRight[i] = f.mvuRight[(size_t)i];
+        depth[i] = f.mvDepth[(size_t)i];
     }
     return 0;
 }

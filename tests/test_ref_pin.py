@@ -355,3 +355,26 @@ def test_distinctive_descriptors_equal_sliced_reference(ref, oracle):
                 assert not has[p] and bi[p] == -1
             else:
                 assert has[p] and np.array_equal(best[p], pool[idx[off[p] + bi[p]]]), (seed, p)
+
+
+def test_stereo_matches_equal_sliced_reference(ref, oracle):
+    """8(f).2b: oracle stereo_matches == Frame::ComputeStereoMatches cut verbatim out of src/Frame.cc:642-846, run on the
+    pyramids the compiled reference extractors built (row-band search, 11x11 SAD over 11 shifts, parabola, disparity ->
+    depth, median-based rejection); mvuRight / mvDepth bit patterns."""
+    from test_stereo import stereo_pair
+    matched = 0
+    for seed, mbf, mb in ((1, 40.0, 0.1), (2, 120.0, 0.5), (3, 386.1, 0.08)):
+        left, right = stereo_pair(seed)
+        rl, rr = ref.RefExtractor(), ref.RefExtractor()
+        ol, orr = oracle.OracleExtractor(), oracle.OracleExtractor()
+        kL, dL = rl(left)
+        kR, dR = rr(right)
+        okL, odL = ol(left)
+        okR, odR = orr(right)
+        assert np.array_equal(kL.view(np.uint8), okL.view(np.uint8)) and np.array_equal(kR.view(np.uint8), okR.view(np.uint8))
+        ru, rd = ref.stereo_matches(rl, rr, kL, dL, kR, dR, mbf, mb)
+        ou, od, _ = oracle.stereo_matches(ol, orr, okL, odL, okR, odR, mbf, mb)
+        assert np.array_equal(ru.view(np.uint32), ou.view(np.uint32)), seed
+        assert np.array_equal(rd.view(np.uint32), od.view(np.uint32)), seed
+        matched += int((ru >= 0).sum())
+    assert matched > 300
