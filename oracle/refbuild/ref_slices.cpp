@@ -101,6 +101,7 @@ int ref_distinctive(const uint8_t *pool, int npool, const uint32_t *off, const u
     return 0;
 }
 
+#ifndef REF_SLICES_NO_EXTRACTOR /* libshim_ref.so carries the matcher only */
 /* Frame::ComputeStereoMatches on the pyramids two reference extractors built in their last operator() calls.
  * The reference reads `mb` before its constructor assigns it (:682); here the caller supplies it. */
 void *ref_ext_object(void *h);
@@ -130,6 +131,8 @@ int ref_stereo_matches(void *extL, void *extR, const ref_kp *kpsL, const uint8_t
     }
     return 0;
 }
+
+#endif
 
 int ref_predict_scale(float max_distance, float current_dist, float log_scale_factor, int nlevels)
 {
