@@ -620,8 +620,7 @@ __global__ __launch_bounds__(256) void k_fast_compass(const OrbPlan *__restrict_
     }
     const uint32_t tt = (uint32_t)max(plan->min_th, 1) * 0x00010001u;
     const int ys = wd.ys, nrows = wd.nrows;
-    // 8-slot ring: the seven rows y-3 .. y+3 of the current step plus the row fetched one step ahead
-    uint32_t R[8][3];
+    uint32_t R[7][3];
     auto fetch = [&](int row, uint32_t (&d)[3]) {
         const uint8_t *p = src + (__umul24((uint32_t)row, (uint32_t)pitch) + (uint32_t)xl);
         d[0] = *(const uint32_t *)(p - 4);
@@ -629,17 +628,17 @@ __global__ __launch_bounds__(256) void k_fast_compass(const OrbPlan *__restrict_
         d[2] = *(const uint32_t *)(p + 4);
     };
 #pragma unroll
-    for (int k = 0; k < 7; ++k) fetch(ys - 3 + k, R[k]);  // rows ys-3 .. ys+3 (ys >= 19, ys + nrows <= iy1 <= h - 19)
+    for (int k = 0; k < 6; ++k) fetch(ys - 3 + k, R[k]);  // rows ys-3 .. ys+2 (ys >= 19, ys + nrows <= iy1 <= h - 19)
     const int wq = (wd.x >> 5) + (lane >> 3);             // this lane group's dword in the bitmap row
-    for (int s0 = 0; s0 < nrows; s0 += 8) {
+    for (int s0 = 0; s0 < nrows; s0 += 7) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 7; ++k) {
             const int s = s0 + k;
             if (s >= nrows) break;
-            fetch(ys + s + 4, R[(k + 7) % 8]);  // next step's newest row (<= iy1 + 3 < h: always inside the level)
-            const uint32_t(&rm3)[3] = R[k % 8];
-            const uint32_t(&r0)[3] = R[(k + 3) % 8];
-            const uint32_t(&rp3)[3] = R[(k + 6) % 8];
+            fetch(ys + s + 3, R[(k + 6) % 7]);
+            const uint32_t(&rm3)[3] = R[k % 7];
+            const uint32_t(&r0)[3] = R[(k + 3) % 7];
+            const uint32_t(&rp3)[3] = R[(k + 6) % 7];
             const uint32_t q01 = fast_compass_pair<0>(rm3, r0, rp3, tt) & in01;
             const uint32_t q23 = fast_compass_pair<2>(rm3, r0, rp3, tt) & in23;
             uint32_t v = ((q01 & 0xFFFFu) ? 1u : 0u) | ((q01 >> 16) ? 2u : 0u) | ((q23 & 0xFFFFu) ? 4u : 0u) | ((q23 >> 16) ? 8u : 0u);
@@ -715,41 +714,28 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbPlan *__restrict__ 
     const int apitch = L.pitch;
     const int t = max(plan->min_th, 1);
     if (fstat && lane == 0) atomicAdd(&fstat[3], (unsigned long long)e.total);
-    // two candidates per lane and pass: their 34 byte loads are in flight together (the kernel is latency-, not issue-bound)
-    for (int base = 0; base < e.total; base += 128) {
-        int dd[2], pp[2], xx[2], yy[2], vv[2], c[2][16];
-        bool on[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int k = base + 64 * u + lane;
-            on[u] = k < e.total;
-            dd[u] = 0;
-            pp[u] = 0;
-            if (on[u]) bit_enum_get(e, k, dd[u], pp[u]);
-            const int idx = d0 + dd[u];
-            yy[u] = on[u] ? idx / L.wpr : ORBFE_EDGE;
-            xx[u] = on[u] ? (idx - yy[u] * L.wpr) * 32 + pp[u] : ORBFE_EDGE;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint8_t *p = src + (int64_t)yy[u] * pitch + xx[u];
+    for (int base = 0; base < e.total; base += 64) {
+        const int k = base + lane;
+        if (k < e.total) {
+            int d, pos;
+            bit_enum_get(e, k, d, pos);
+            const int idx = d0 + d, y = idx / L.wpr, x = (idx - y * L.wpr) * 32 + pos;
+            const uint8_t *p = src + (int64_t)y * pitch + x;
             const int p1 = pitch, p2 = 2 * pitch, p3 = 3 * pitch;
-            c[u][0] = p[p3];      c[u][1] = p[p3 + 1];   c[u][2] = p[p2 + 2];   c[u][3] = p[p1 + 3];
-            c[u][4] = p[3];       c[u][5] = p[-p1 + 3];  c[u][6] = p[-p2 + 2];  c[u][7] = p[-p3 + 1];
-            c[u][8] = p[-p3];     c[u][9] = p[-p3 - 1];  c[u][10] = p[-p2 - 2]; c[u][11] = p[-p1 - 3];
-            c[u][12] = p[-3];     c[u][13] = p[p1 - 3];  c[u][14] = p[p2 - 2];  c[u][15] = p[p3 - 1];
-            vv[u] = p[0];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
+            int c[16];
+            c[0] = p[p3];      c[1] = p[p3 + 1];   c[2] = p[p2 + 2];   c[3] = p[p1 + 3];
+            c[4] = p[3];       c[5] = p[-p1 + 3];  c[6] = p[-p2 + 2];  c[7] = p[-p3 + 1];
+            c[8] = p[-p3];     c[9] = p[-p3 - 1];  c[10] = p[-p2 - 2]; c[11] = p[-p1 - 3];
+            c[12] = p[-3];     c[13] = p[p1 - 3];  c[14] = p[p2 - 2];  c[15] = p[p3 - 1];
+            const int v = p[0];
             // the formulation of fast_strength_pair on plain integers (same operations, same result)
             int P[8], Q[8], ex[8], en[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                P[i] = min(c[u][2 * i + 1], c[u][(2 * i + 2) & 15]);
-                Q[i] = max(c[u][2 * i + 1], c[u][(2 * i + 2) & 15]);
-                ex[i] = max(c[u][2 * i], c[u][(2 * i + 9) & 15]);
-                en[i] = min(c[u][2 * i], c[u][(2 * i + 9) & 15]);
+                P[i] = min(c[2 * i + 1], c[(2 * i + 2) & 15]);
+                Q[i] = max(c[2 * i + 1], c[(2 * i + 2) & 15]);
+                ex[i] = max(c[2 * i], c[(2 * i + 9) & 15]);
+                en[i] = min(c[2 * i], c[(2 * i + 9) & 15]);
             }
             int maxmin = 0, minmax = 255;
 #pragma unroll
@@ -757,10 +743,10 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbPlan *__restrict__ 
                 maxmin = max(maxmin, min3i(min3i(P[i], P[(i + 1) & 7], P[(i + 2) & 7]), P[(i + 3) & 7], ex[i]));
                 minmax = min(minmax, max3i(max3i(Q[i], Q[(i + 1) & 7], Q[(i + 2) & 7]), Q[(i + 3) & 7], en[i]));
             }
-            const int A = max(max(vv[u] - minmax, maxmin - vv[u]), 0);
-            if (on[u] && A > t) {
-                am[yy[u] * apitch + xx[u]] = (uint8_t)A;
-                atomicOr(&s_corner[wv][dd[u]], 1u << pp[u]);
+            const int A = max(max(v - minmax, maxmin - v), 0);
+            if (A > t) {
+                am[y * apitch + x] = (uint8_t)A;
+                atomicOr(&s_corner[wv][d], 1u << pos);
             }
         }
     }
@@ -802,38 +788,27 @@ __global__ __launch_bounds__(256) void k_fast_nms(const OrbPlan *__restrict__ pl
             int d, pos;
             bit_enum_get(e, k, d, pos);
             const int idx = d0 + d, y = idx / wpr, wx = idx - y * wpr, x = wx * 32 + pos;
+            const int A = am[y * apitch + x];
             // neighbours outside the own cell's detectable interior count as 0 (per-cv::FAST-call semantics)
             const int rx = x - ORBFE_EDGE, ry = y - ORBFE_EDGE;
             const int cc = rx / wcell, xin = rx - cc * wcell, cr = ry / hcell, yin = ry - cr * hcell;
             const bool lok = xin != 0, rok = xin != wcell - 1, uok = yin != 0, dok = yin != hcell - 1;
-            // one round trip: the corner bits of the three rows (columns x-1 .. x+1 may straddle two dwords) and the nine
-            // strength bytes are requested together; a neighbour's byte only counts where its corner bit is set
-            const int wl = (x - 1) >> 5, wr = (x + 1) >> 5;  // rows / columns next to a corner are inside the image
-            uint32_t bl[3], br[3];
-            int av[3][3];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const uint32_t *row = bm + (y + dy - 1) * wpr;
-                bl[dy] = row[wl];
-                br[dy] = row[wr];
-                const uint8_t *ar = am + (y + dy - 1) * apitch + x;
-                av[dy][0] = ar[-1];
-                av[dy][1] = ar[0];
-                av[dy][2] = ar[1];
-            }
-            const int A = av[1][1];
-            int m = 0;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    if (dy == 1 && dx == 1) continue;
-                    const int xx = x + dx - 1;
-                    const uint32_t wd2 = (xx >> 5) == wl ? bl[dy] : br[dy];
-                    const bool ok = (dx == 0 ? lok : dx == 2 ? rok : true) && (dy == 0 ? uok : dy == 2 ? dok : true);
-                    const bool on = ok && ((wd2 >> (xx & 31)) & 1u);
-                    m = max(m, on ? av[dy][dx] : 0);
-                }
+            // corner bits of the 3 x 3 neighbourhood: columns x-1 .. x+1 may straddle two dwords
+            auto bit = [&](int yy, int xx) -> bool {
+                const int w2 = xx >> 5;
+                return (bm[yy * wpr + w2] >> (xx & 31)) & 1u;  // rows / columns next to a corner are inside the image (>= 18, <= w - 19)
+            };
+            auto nb = [&](int dy, int dx, bool ok) -> int {
+                return (ok && bit(y + dy, x + dx)) ? (int)am[(y + dy) * apitch + x + dx] : 0;
+            };
+            int m = nb(0, -1, lok);
+            m = max(m, nb(0, 1, rok));
+            m = max(m, nb(-1, 0, uok));
+            m = max(m, nb(1, 0, dok));
+            m = max(m, nb(-1, -1, uok && lok));
+            m = max(m, nb(-1, 1, uok && rok));
+            m = max(m, nb(1, -1, dok && lok));
+            m = max(m, nb(1, 1, dok && rok));
             keep = A > m;
             rec = make_uint2(orb_pack_key(x - ORBFE_MINB, y - ORBFE_MINB, A - 1),
                              ((uint32_t)(cr * L.ncc + cc) << 12) | ((uint32_t)yin << 6) | (uint32_t)xin);
