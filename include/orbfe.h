@@ -132,18 +132,11 @@ orbfe_status orbfe_extract_batch_device(orbfe_handle *h, const uint8_t *d_gray, 
  * clears the word: bit 0 = a level's FAST survivor list overflowed, bit 1 = a level's quadtree selection overflowed,
  * bit 2 = a frame produced more keypoints than `cap` (d_n_out holds the required count). */
 orbfe_status orbfe_get_overflow(orbfe_handle *h, int32_t *flags);
-/* FAST kernel variant.  Results are identical in every mode.
- *   0  dense (default): every pixel of the detectable interior gets the exact arc score
- *   1  dense with wave-uniform shortcuts (measured: never faster; kept for the record)
- *   2  sparse pipeline: exact 4-point pre-test for every pixel -> bitmap; arc score only for the candidates (one pixel per
- *      lane, flattened over the waves); corner-driven NMS.  Faster on camera-like frames (a few thousand FAST candidates),
- *      slower on corner-saturated ones
- *   3  auto: 2 while the previous batches averaged fewer than 9000 NMS survivors per frame, else 0 (the statistic is read
- *      back asynchronously; the first batch runs dense)
- * collect_stats != 0 counts {row steps, arc skips, NMS skips} (mode 1) and the candidates scored (mode 2). */
+/* FAST kernel variant: 0 = dense (default), 1 = wave-uniform shortcuts for frames with sparse corners (skips the arc
+ * evaluation of 256-pixel row pieces that fail a 4-point necessary test, and the suppression of rows without
+ * strength).  Results are identical in both modes.  collect_stats != 0 counts {row steps, arc skips, NMS skips}. */
 orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32_t collect_stats);
-int32_t orbfe_get_fast_choice(const orbfe_handle *h);   /* the variant the next batch will run (0, 1 or 2) */
-orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[4], int32_t reset);
+orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[3], int32_t reset);
 /* work model of the FAST kernel for the current frame size: out[0] = wave row steps per frame (one step = 64 lanes x 4
  * pixels of one row, halo rows included), out[1] = waves per frame.  bench.py prices its VALU ceiling with it. */
 orbfe_status orbfe_get_work_counts(const orbfe_handle *h, int64_t out[2]);

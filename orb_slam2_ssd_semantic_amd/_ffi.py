@@ -33,7 +33,6 @@ SYMBOLS = (
     "orbfe_mapio_keyframe_bytes", "orbfe_mapio_write_keyframe", "orbfe_mapio_read_keyframe", "orbfe_mapio_pack_records_device",
     "orbfe_vocfile_load", "orbfe_vocfile_free", "orbfe_vocfile_info", "orbfe_vocfile_arrays", "orbfe_vocfile_save_binary",
     "orbfe_vocabulary_create_from_file", "orbfe_interleaved_to_gray_device", "orbfe_hamming_csr_ex", "orbfe_hamming_csr_device",
-    "orbfe_get_fast_choice",
 )
 
 
@@ -110,7 +109,6 @@ def lib():
     L.orbfe_get_overflow.argtypes = [vp, vp]
     L.orbfe_set_fast_mode.argtypes = [vp, i32, i32]
     L.orbfe_get_fast_stats.argtypes = [vp, vp, i32]
-    L.orbfe_get_fast_choice.argtypes = [vp]
     L.orbfe_set_profiling.argtypes = [vp, i32]
     L.orbfe_get_stage_ms.argtypes = [vp, vp]
     L.orbfe_hamming.argtypes = [vp, vp]

@@ -142,17 +142,12 @@ struct orbfe_handle {
     bool plan_valid = false;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
-    DevBuf d_plan, d_tabs, d_flanes, d_blanes, d_awaves, d_cbits;
+    DevBuf d_plan, d_tabs, d_flanes, d_blanes;
     // per-batch blocks
     DevBuf d_pyr, d_blur, d_skeys, d_scount, d_knode, d_sel, d_nsel, d_nkeys;
     // sticky overflow word + FAST sparse-variant statistics: [0] int32 overflow bits, [2..7] 3 x uint64 counters
     DevBuf d_misc;
-    int fast_mode = 0;            // 0 dense, 1 dense + wave-uniform shortcuts, 2 sparse pipeline, 3 auto (orbfe_set_fast_mode)
-    int fast_auto_choice = 0;     // what mode 3 currently runs: 0 or 2
-    unsigned long long *h_auto = nullptr;   // pinned {survivors, frames} snapshots of the device counters
-    unsigned long long auto_last[2] = {0, 0};
-    hipEvent_t ev_auto = nullptr;
-    bool auto_pending = false;
+    int fast_mode = 0;            // 0 dense, 1 sparse shortcuts (orbfe_set_fast_mode)
     bool fast_stats = false;
     int64_t fast_row_steps = 0;
     hipStream_t last_stream = nullptr;  // stream of the most recent batched call (synchronised before re-planning)
@@ -459,33 +454,6 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         }
     }
     P.nbwaves = (int)(blanes.size() / 64);
-    // sparse FAST pipeline: bitmap geometry (1 bit per pixel, all rows) and the compass waves (256-px strips x 32 rows of the
-    // detectable interior [19, ix1) x [19, iy1))
-    std::vector<OrbLane> awaves;
-    {
-        int bm_off = 0, chunk0 = 0;
-        for (int l = 0; l < nl; ++l) {
-            OrbLevel &L = P.lv[l];
-            L.wpr = (L.w + 31) / 32;
-            L.bm_off = bm_off;
-            L.bchunk0 = chunk0;
-            bm_off += L.wpr * L.h;
-            chunk0 += (L.wpr * L.h + 63) / 64;
-            for (int y0 = ORBFE_EDGE; y0 < L.iy1; y0 += 32)
-                for (int x0 = 0; x0 < L.ix1; x0 += 256) {
-                    if (x0 + 255 < ORBFE_EDGE) continue;
-                    OrbLane wd;
-                    wd.x = (uint16_t)x0;
-                    wd.ys = (uint16_t)y0;
-                    wd.nrows = (uint16_t)std::min(32, L.iy1 - y0);
-                    wd.flags = (uint16_t)(l << 8);
-                    awaves.push_back(wd);
-                }
-        }
-        P.bm_frame_dwords = bm_off;
-        P.nbchunks = chunk0;
-        P.nawaves = (int)awaves.size();
-    }
     if (P.ini_th < P.min_th) {
         orbfe_set_error("iniThFAST (%d) must be >= minThFAST (%d)", P.ini_th, P.min_th);
         return ORBFE_ERR_ARG;
@@ -495,7 +463,6 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(h->d_tabs.ensure(tabs.size() * sizeof(OrbTab)));
     ORBFE_HIP(h->d_flanes.ensure(std::max<size_t>(flanes.size(), 1) * sizeof(OrbLane)));
     ORBFE_HIP(h->d_blanes.ensure(std::max<size_t>(blanes.size(), 1) * sizeof(OrbLane)));
-    ORBFE_HIP(h->d_awaves.ensure(std::max<size_t>(awaves.size(), 1) * sizeof(OrbLane)));
     // synchronous copies: plans change rarely (frame size change), never inside the timed region.  Earlier batches may
     // still be in flight on the handle's stream or on the caller's stream of the previous device call: both are drained
     // before the plan tables they read are overwritten.
@@ -507,8 +474,6 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         ORBFE_HIP(hipMemcpy(h->d_flanes.p, flanes.data(), flanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     if (!blanes.empty())
         ORBFE_HIP(hipMemcpy(h->d_blanes.p, blanes.data(), blanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
-    if (!awaves.empty())
-        ORBFE_HIP(hipMemcpy(h->d_awaves.p, awaves.data(), awaves.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     ORBFE_HIP(orbk_prepare_octree(M, P.max_nini, P.w, P.h, P.max_ncells));
     h->plan = P;
     h->fast_row_steps = fast_row_steps;
@@ -535,10 +500,9 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
     ORBFE_HIP(h->d_sel.ensure(B * (size_t)P.sel_per_frame * sizeof(uint32_t)));
     ORBFE_HIP(h->d_nsel.ensure(B * P.nlevels * sizeof(int32_t)));
     ORBFE_HIP(h->d_nkeys.ensure(B * P.nlevels * ORBFE_NK_STRIDE * sizeof(int32_t)));
-    if (h->fast_mode >= 2) ORBFE_HIP(h->d_cbits.ensure(B * (size_t)P.bm_frame_dwords * sizeof(uint32_t)));
     if (!h->d_misc.p) {
-        ORBFE_HIP(h->d_misc.ensure(128));
-        ORBFE_HIP(hipMemset(h->d_misc.p, 0, 128));
+        ORBFE_HIP(h->d_misc.ensure(64));
+        ORBFE_HIP(hipMemset(h->d_misc.p, 0, 64));
     }
     return ORBFE_OK;
 }
@@ -660,12 +624,10 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_awaves, &h->d_cbits, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys,
                       &h->d_stage[0], &h->d_okps[0], &h->d_odesc[0], &h->d_on[0], &h->d_stage[1], &h->d_okps[1], &h->d_odesc[1], &h->d_on[1]};
     for (DevBuf *b : bufs) b->release();
     h->d_misc.release();
-    if (h->h_auto) (void)hipHostFree(h->h_auto);
-    if (h->ev_auto) (void)hipEventDestroy(h->ev_auto);
     PinBuf *pins[] = {&h->h_stage[0], &h->h_okps[0], &h->h_odesc[0], &h->h_on[0], &h->h_stage[1], &h->h_okps[1], &h->h_odesc[1], &h->h_on[1]};
     for (PinBuf *b : pins) b->release();
     for (int k = 0; k < 2; ++k) {
@@ -772,38 +734,23 @@ extern "C" orbfe_status orbfe_get_overflow(orbfe_handle *h, int32_t *flags)
 
 extern "C" orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32_t collect_stats)
 {
-    if (!h || mode < 0 || mode > 3) return ORBFE_ERR_ARG;
-    DeviceGuard g(h->device);
-    if (mode >= 2 && !h->h_auto) {
-        ORBFE_HIP(hipHostMalloc((void **)&h->h_auto, 16, hipHostMallocDefault));
-        h->h_auto[0] = h->h_auto[1] = 0;
-        ORBFE_HIP(hipEventCreateWithFlags(&h->ev_auto, hipEventDisableTiming));
-    }
+    if (!h || mode < 0 || mode > 1) return ORBFE_ERR_ARG;
     h->fast_mode = mode;
-    h->fast_auto_choice = 0;
-    h->auto_pending = false;
     h->fast_stats = collect_stats != 0;
-    if (mode >= 2 && h->plan_valid) {  // the bitmap block of the sparse pipeline is allocated on first use
-        if (h->last_stream_valid) ORBFE_HIP(hipStreamSynchronize(h->last_stream));
-        ORBFE_HIP(hipStreamSynchronize(h->stream));
-        ORBFE_HIP(h->d_cbits.ensure((size_t)h->prm.max_batch * (size_t)h->plan.bm_frame_dwords * sizeof(uint32_t)));
-    }
     return ORBFE_OK;
 }
 
-extern "C" orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[4], int32_t reset)
+extern "C" orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[3], int32_t reset)
 {
     if (!h || !out) return ORBFE_ERR_ARG;
-    out[0] = out[1] = out[2] = out[3] = 0;
+    out[0] = out[1] = out[2] = 0;
     if (!h->d_misc.p) return ORBFE_OK;
     DeviceGuard g(h->device);
     if (h->last_stream_valid) ORBFE_HIP(hipStreamSynchronize(h->last_stream));
-    ORBFE_HIP(hipMemcpy(out, (char *)h->d_misc.p + 16, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) ORBFE_HIP(hipMemset((char *)h->d_misc.p + 16, 0, 4 * sizeof(uint64_t)));
+    ORBFE_HIP(hipMemcpy(out, (char *)h->d_misc.p + 16, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) ORBFE_HIP(hipMemset((char *)h->d_misc.p + 16, 0, 3 * sizeof(uint64_t)));
     return ORBFE_OK;
 }
-
-extern "C" int32_t orbfe_get_fast_choice(const orbfe_handle *h) { return h ? (h->fast_mode == 3 ? h->fast_auto_choice : h->fast_mode) : -1; }
 
 // ---------------------------------------------------------------------------------------------------
 // the batched device path (everything else funnels into this)
@@ -844,24 +791,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.cap = cap;
     a.d_n_out = d_n_out;
     a.d_ovf = (int32_t *)h->d_misc.p;
-    int fmode = h->fast_mode;
-    if (fmode == 3) {
-        // auto: the previous batches' NMS survivor count per frame picks the kernel (corner-saturated frames -> dense)
-        if (h->auto_pending && hipEventQuery(h->ev_auto) == hipSuccess) {
-            const unsigned long long surv = h->h_auto[0] - h->auto_last[0], fr = h->h_auto[1] - h->auto_last[1];
-            if (fr > 0) {
-                h->fast_auto_choice = (double)surv / (double)fr < (double)ORBFE_AUTO_SPARSE_MAX_SURVIVORS ? 2 : 0;
-                h->auto_last[0] = h->h_auto[0];
-                h->auto_last[1] = h->h_auto[1];
-            }
-            h->auto_pending = false;
-        }
-        fmode = h->fast_auto_choice;
-    }
-    a.fast_sparse = fmode;
-    a.d_awaves = (const OrbLane *)h->d_awaves.p;
-    a.d_cbits = (uint32_t *)h->d_cbits.p;
-    a.d_auto = h->fast_mode == 3 ? (unsigned long long *)((char *)h->d_misc.p + 64) : nullptr;
+    a.fast_sparse = h->fast_mode;
     a.d_fstat = h->fast_stats ? (unsigned long long *)((char *)h->d_misc.p + 16) : nullptr;
     h->last_stream = st;
     h->last_stream_valid = true;
@@ -869,7 +799,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     if (ev) ORBFE_HIP(hipEventRecord(ev[0], st));
     ORBFE_HIP(orbk_launch_pyramid(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[1], st));
-    const int ov = fmode == 2 ? 0 : h->overlap;  // the sparse FAST pipeline borrows the blurred block until the blur runs
+    const int ov = h->overlap;
     auto fork_blur = [&]() -> hipError_t {
         hipError_t e = hipEventRecord(h->ev_fork, st);
         if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->ev_fork, 0);
@@ -885,11 +815,6 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     if (ov == 2) ORBFE_HIP(fork_blur());
     ORBFE_HIP(orbk_launch_octree(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[3], st));
-    if (h->fast_mode == 3 && !h->auto_pending) {  // snapshot of the survivor statistics for the next decision
-        ORBFE_HIP(hipMemcpyAsync(h->h_auto, (char *)h->d_misc.p + 64, 16, hipMemcpyDeviceToHost, st));
-        ORBFE_HIP(hipEventRecord(h->ev_auto, st));
-        h->auto_pending = true;
-    }
     if (ov == 0) {
         if (ev) ORBFE_HIP(hipEventRecord(ev[6], st));
         ORBFE_HIP(orbk_launch_blur(a, st));

@@ -19,7 +19,6 @@
 #define ORBFE_MINB 16        // minBorderX/Y = EDGE_THRESHOLD-3 (:780)
 #define ORBFE_NK_STRIDE 32   // ints between per-(frame, level) key counters: one 128-B line each (atomic targets)
 #define ORBFE_LDS_MAX (160 * 1024)  // LDS of one gfx950 CU: the dynamic-LDS attribute of every kernel is set to this
-#define ORBFE_AUTO_SPARSE_MAX_SURVIVORS 9000  // fast mode 3: sparse pipeline while the batches average fewer NMS survivors per frame
 #define ORBFE_TILE_MAX 72    // FAST cell tile edge upper bound (cell+6 <= 66 when nCols == 1)
 
 // ---- thread-local error text ---------------------------------------------------------------------
@@ -58,10 +57,6 @@ struct OrbLevel {
     float patch_size;      // (float)(int)(PATCH_SIZE * scale)  (:846)
     int32_t root_x[5];     // root box x boundaries, nini+1 entries (nini <= 4)
     int32_t ix1, iy1;      // end of the union of the cells' detectable interiors ([19,ix1) x [19,iy1))
-    // candidate / corner bitmap of the sparse FAST pipeline: 1 bit per pixel, rows of `wpr` dwords, bit x % 32 of dword x / 32
-    int32_t wpr;           // dwords per bitmap row = ceil(w / 32)
-    int32_t bm_off;        // first dword of this level inside a frame's bitmap
-    int32_t bchunk0;       // first 64-dword chunk of this level in the frame's chunk numbering
 };
 
 // one FAST cell = one cv::FAST call of the reference (:798-838)
@@ -102,9 +97,6 @@ struct OrbPlan {
     int32_t dbg;               // developer knob (ORBFE_DEBUG env), 0 in production; 50 = quadtree streaming passes only
     int32_t nfwaves;           // FAST waves per frame (64 lane descriptors each)
     int32_t nbwaves;           // blur waves per frame (64 lane descriptors each)
-    int32_t nawaves;           // sparse FAST: compass waves per frame (one OrbLane descriptor each)
-    int32_t nbchunks;          // sparse FAST: 64-dword bitmap chunks per frame
-    int32_t bm_frame_dwords;   // sparse FAST: dwords of one frame's bitmap
     int64_t pyr_frame_bytes;   // bytes of one frame's pyramid slice (levels 1..n-1; level 0 kept too when owned)
     OrbLevel lv[ORBFE_MAX_LEVELS];
 };

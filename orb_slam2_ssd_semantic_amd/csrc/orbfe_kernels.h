@@ -35,10 +35,6 @@ struct OrbLaunch {
     // FAST variant: 1 = wave-uniform shortcuts for sparse-corner frames; d_fstat (optional) counts their effect
     int32_t fast_sparse;
     unsigned long long *d_fstat;
-    // sparse FAST pipeline (fast_sparse == 2): compass wave descriptors and the per-pixel candidate / corner bitmap
-    const OrbLane *d_awaves;
-    uint32_t *d_cbits;
-    unsigned long long *d_auto;  // {NMS survivors, frames} accumulated by the quadtree kernel (fast mode 3), or null
 };
 
 hipError_t orbk_upload_constants(const int *umax16);

@@ -580,251 +580,6 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2s  Sparse FAST pipeline (orbfe_set_fast_mode 2 / 3): the same survivor list as k_fast_map for frames whose corners are
-// sparse (camera images: a few % of the pixels), at a fraction of the arithmetic.
-//   k_fast_compass  dense and cheap: the exact necessary 4-point test of fast_compass_pair for every pixel of the
-//                   detectable interior -> 1 bit per pixel (bitmap rows of L.wpr dwords)
-//   k_fast_score    candidate-driven: a wave takes 64 bitmap dwords, flattens their set bits over its lanes (one candidate
-//                   pixel per lane), gathers the 16 circle pixels and evaluates the SAME arc-strength formula as
-//                   fast_strength_pair on plain integers; A goes to a byte map (the blurred block, free until the blur runs),
-//                   and the bitmap dwords are rewritten in place as CORNER bits (A > t)
-//   k_fast_nms      corner-driven: 3x3 strict maximum with the per-cv::FAST-call (cell seam) rules, survivors appended to
-//                   the level's {key, ord} list exactly as k_fast_map appends them
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fast_compass(const OrbPlan *__restrict__ plan, FrameSrc fs,
-                                                      const OrbLane *__restrict__ awaves, int nawaves,
-                                                      uint32_t *__restrict__ cbits)
-{
-    int b = blockIdx.y, bx = blockIdx.x;
-    xcd_frame_remap(bx, b);
-    const int lane = threadIdx.x & 63;
-    const int t = bx * 4 + (threadIdx.x >> 6);
-    if (t >= nawaves) return;
-    const OrbLane wd = awaves[t];  // wave-uniform: x = first column of the 256-px strip, ys / nrows = its rows
-    const int level = wd.flags >> 8;
-    const OrbLevel &L = plan->lv[level];
-    int pitch;
-    const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
-    uint32_t *bm = cbits + (int64_t)b * plan->bm_frame_dwords + L.bm_off;
-    const int x = wd.x + 4 * lane;
-    const int ix0 = ORBFE_EDGE, ix1 = L.ix1;
-    // lanes whose four pixels miss the interior shadow column 16 (its 12-byte window is inside the row) and output zeros
-    const bool lane_on = x + 3 >= ix0 && x < ix1;
-    const int xl = lane_on ? x : 16;
-    uint32_t in01 = 0, in23 = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool in = lane_on && x + j >= ix0 && x + j < ix1;
-        if (j < 2) in01 |= in ? (0xFFFFu << (16 * j)) : 0u;
-        else in23 |= in ? (0xFFFFu << (16 * (j - 2))) : 0u;
-    }
-    const uint32_t tt = (uint32_t)max(plan->min_th, 1) * 0x00010001u;
-    const int ys = wd.ys, nrows = wd.nrows;
-    uint32_t R[7][3];
-    auto fetch = [&](int row, uint32_t (&d)[3]) {
-        const uint8_t *p = src + (__umul24((uint32_t)row, (uint32_t)pitch) + (uint32_t)xl);
-        d[0] = *(const uint32_t *)(p - 4);
-        d[1] = *(const uint32_t *)(p);
-        d[2] = *(const uint32_t *)(p + 4);
-    };
-#pragma unroll
-    for (int k = 0; k < 6; ++k) fetch(ys - 3 + k, R[k]);  // rows ys-3 .. ys+2 (ys >= 19, ys + nrows <= iy1 <= h - 19)
-    const int wq = (wd.x >> 5) + (lane >> 3);             // this lane group's dword in the bitmap row
-    for (int s0 = 0; s0 < nrows; s0 += 7) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int s = s0 + k;
-            if (s >= nrows) break;
-            fetch(ys + s + 3, R[(k + 6) % 7]);
-            const uint32_t(&rm3)[3] = R[k % 7];
-            const uint32_t(&r0)[3] = R[(k + 3) % 7];
-            const uint32_t(&rp3)[3] = R[(k + 6) % 7];
-            const uint32_t q01 = fast_compass_pair<0>(rm3, r0, rp3, tt) & in01;
-            const uint32_t q23 = fast_compass_pair<2>(rm3, r0, rp3, tt) & in23;
-            uint32_t v = ((q01 & 0xFFFFu) ? 1u : 0u) | ((q01 >> 16) ? 2u : 0u) | ((q23 & 0xFFFFu) ? 4u : 0u) | ((q23 >> 16) ? 8u : 0u);
-            v <<= 4 * (lane & 7);
-            v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]: xor 1
-            v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]: xor 2
-            v |= (uint32_t)__shfl_xor((int)v, 4, 64);
-            if ((lane & 7) == 0 && wq < L.wpr) bm[(ys + s) * L.wpr + wq] = v;
-        }
-    }
-}
-
-// the set bits of 64 bitmap dwords, flattened over the lanes of a wave
-struct BitEnum {
-    uint32_t *s_word;  // [64] this wave's dwords
-    int *s_pre;        // [65] exclusive prefix of their popcounts
-    int total;
-};
-__device__ __forceinline__ void bit_enum_setup(BitEnum &e, uint32_t word, int lane)
-{
-    int c = __popc(word), incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-    e.s_word[lane] = word;
-    e.s_pre[lane] = incl - c;
-    if (lane == 63) e.s_pre[64] = incl;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    e.total = e.s_pre[64];
-}
-// k-th set bit (k < total): returns the dword index d and the bit position
-__device__ __forceinline__ void bit_enum_get(const BitEnum &e, int k, int &d, int &pos)
-{
-    int lo = 0;
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1)
-        if (e.s_pre[lo + step] <= k) lo += step;  // largest d with pre[d] <= k  (pre is non-decreasing, pre[64] = total > k)
-    // dwords without bits share their prefix with the next one: the largest index with pre <= k is the one holding bit k
-    d = lo;
-    uint32_t wv = e.s_word[d];
-    for (int r = k - e.s_pre[d]; r > 0; --r) wv &= wv - 1u;
-    pos = __ffs((int)wv) - 1;
-}
-
-__global__ __launch_bounds__(256) void k_fast_score(const OrbPlan *__restrict__ plan, FrameSrc fs,
-                                                    uint32_t *__restrict__ cbits, uint8_t *__restrict__ amap,
-                                                    int64_t amap_fstride, unsigned long long *__restrict__ fstat)
-{
-    __shared__ uint32_t s_word[4][64];
-    __shared__ int s_pre[4][65];
-    __shared__ uint32_t s_corner[4][64];
-    int b = blockIdx.y, bx = blockIdx.x;
-    xcd_frame_remap(bx, b);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int chunk = bx * 4 + wv;
-    if (chunk >= plan->nbchunks) return;
-    int level = 0;
-    for (int l = 1; l < plan->nlevels; ++l)
-        if (chunk >= plan->lv[l].bchunk0) level = l;
-    const OrbLevel &L = plan->lv[level];
-    const int ndw = L.wpr * L.h;                       // dwords of this level's bitmap
-    const int d0 = (chunk - L.bchunk0) * 64;
-    uint32_t *bm = cbits + (int64_t)b * plan->bm_frame_dwords + L.bm_off;
-    const uint32_t word = d0 + lane < ndw ? bm[d0 + lane] : 0u;
-    BitEnum e{s_word[wv], s_pre[wv], 0};
-    bit_enum_setup(e, word, lane);
-    s_corner[wv][lane] = 0u;
-    int pitch;
-    const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
-    uint8_t *am = amap + (int64_t)b * amap_fstride + L.off;
-    const int apitch = L.pitch;
-    const int t = max(plan->min_th, 1);
-    if (fstat && lane == 0) atomicAdd(&fstat[3], (unsigned long long)e.total);
-    for (int base = 0; base < e.total; base += 64) {
-        const int k = base + lane;
-        if (k < e.total) {
-            int d, pos;
-            bit_enum_get(e, k, d, pos);
-            const int idx = d0 + d, y = idx / L.wpr, x = (idx - y * L.wpr) * 32 + pos;
-            const uint8_t *p = src + (int64_t)y * pitch + x;
-            const int p1 = pitch, p2 = 2 * pitch, p3 = 3 * pitch;
-            int c[16];
-            c[0] = p[p3];      c[1] = p[p3 + 1];   c[2] = p[p2 + 2];   c[3] = p[p1 + 3];
-            c[4] = p[3];       c[5] = p[-p1 + 3];  c[6] = p[-p2 + 2];  c[7] = p[-p3 + 1];
-            c[8] = p[-p3];     c[9] = p[-p3 - 1];  c[10] = p[-p2 - 2]; c[11] = p[-p1 - 3];
-            c[12] = p[-3];     c[13] = p[p1 - 3];  c[14] = p[p2 - 2];  c[15] = p[p3 - 1];
-            const int v = p[0];
-            // the formulation of fast_strength_pair on plain integers (same operations, same result)
-            int P[8], Q[8], ex[8], en[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                P[i] = min(c[2 * i + 1], c[(2 * i + 2) & 15]);
-                Q[i] = max(c[2 * i + 1], c[(2 * i + 2) & 15]);
-                ex[i] = max(c[2 * i], c[(2 * i + 9) & 15]);
-                en[i] = min(c[2 * i], c[(2 * i + 9) & 15]);
-            }
-            int maxmin = 0, minmax = 255;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                maxmin = max(maxmin, min3i(min3i(P[i], P[(i + 1) & 7], P[(i + 2) & 7]), P[(i + 3) & 7], ex[i]));
-                minmax = min(minmax, max3i(max3i(Q[i], Q[(i + 1) & 7], Q[(i + 2) & 7]), Q[(i + 3) & 7], en[i]));
-            }
-            const int A = max(max(v - minmax, maxmin - v), 0);
-            if (A > t) {
-                am[y * apitch + x] = (uint8_t)A;
-                atomicOr(&s_corner[wv][d], 1u << pos);
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    if (d0 + lane < ndw) bm[d0 + lane] = s_corner[wv][lane];  // candidate bits -> corner bits, in place
-}
-
-__global__ __launch_bounds__(256) void k_fast_nms(const OrbPlan *__restrict__ plan, const uint32_t *__restrict__ cbits,
-                                                  const uint8_t *__restrict__ amap, int64_t amap_fstride,
-                                                  uint2 *__restrict__ skeys, int32_t *__restrict__ scount)
-{
-    __shared__ uint32_t s_word[4][64];
-    __shared__ int s_pre[4][65];
-    int b = blockIdx.y, bx = blockIdx.x;
-    xcd_frame_remap(bx, b);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int chunk = bx * 4 + wv;
-    if (chunk >= plan->nbchunks) return;
-    int level = 0;
-    for (int l = 1; l < plan->nlevels; ++l)
-        if (chunk >= plan->lv[l].bchunk0) level = l;
-    const OrbLevel &L = plan->lv[level];
-    const int ndw = L.wpr * L.h, wpr = L.wpr;
-    const int d0 = (chunk - L.bchunk0) * 64;
-    const uint32_t *bm = cbits + (int64_t)b * plan->bm_frame_dwords + L.bm_off;
-    const uint32_t word = d0 + lane < ndw ? bm[d0 + lane] : 0u;
-    BitEnum e{s_word[wv], s_pre[wv], 0};
-    bit_enum_setup(e, word, lane);
-    const uint8_t *am = amap + (int64_t)b * amap_fstride + L.off;
-    const int apitch = L.pitch;
-    uint2 *slist = skeys + (int64_t)b * plan->keys_per_frame + L.key_off;
-    int32_t *scnt = scount + (b * plan->nlevels + level) * ORBFE_NK_STRIDE;
-    const int wcell = L.wcell, hcell = L.hcell, key_cap = L.key_cap;
-    for (int base = 0; base < e.total; base += 64) {
-        const int k = base + lane;
-        bool keep = false;
-        uint2 rec = make_uint2(0u, 0u);
-        if (k < e.total) {
-            int d, pos;
-            bit_enum_get(e, k, d, pos);
-            const int idx = d0 + d, y = idx / wpr, wx = idx - y * wpr, x = wx * 32 + pos;
-            const int A = am[y * apitch + x];
-            // neighbours outside the own cell's detectable interior count as 0 (per-cv::FAST-call semantics)
-            const int rx = x - ORBFE_EDGE, ry = y - ORBFE_EDGE;
-            const int cc = rx / wcell, xin = rx - cc * wcell, cr = ry / hcell, yin = ry - cr * hcell;
-            const bool lok = xin != 0, rok = xin != wcell - 1, uok = yin != 0, dok = yin != hcell - 1;
-            // corner bits of the 3 x 3 neighbourhood: columns x-1 .. x+1 may straddle two dwords
-            auto bit = [&](int yy, int xx) -> bool {
-                const int w2 = xx >> 5;
-                return (bm[yy * wpr + w2] >> (xx & 31)) & 1u;  // rows / columns next to a corner are inside the image (>= 18, <= w - 19)
-            };
-            auto nb = [&](int dy, int dx, bool ok) -> int {
-                return (ok && bit(y + dy, x + dx)) ? (int)am[(y + dy) * apitch + x + dx] : 0;
-            };
-            int m = nb(0, -1, lok);
-            m = max(m, nb(0, 1, rok));
-            m = max(m, nb(-1, 0, uok));
-            m = max(m, nb(1, 0, dok));
-            m = max(m, nb(-1, -1, uok && lok));
-            m = max(m, nb(-1, 1, uok && rok));
-            m = max(m, nb(1, -1, dok && lok));
-            m = max(m, nb(1, 1, dok && rok));
-            keep = A > m;
-            rec = make_uint2(orb_pack_key(x - ORBFE_MINB, y - ORBFE_MINB, A - 1),
-                             ((uint32_t)(cr * L.ncc + cc) << 12) | ((uint32_t)yin << 6) | (uint32_t)xin);
-        }
-        const unsigned long long bal = __ballot(keep);
-        if (bal) {
-            int base_o = 0;
-            if (lane == 0) base_o = atomicAdd(scnt, __popcll(bal));
-            base_o = __shfl(base_o, 0, 64);
-            const int o = base_o + lanes_below(bal);
-            if (keep && o < key_cap) slist[o] = rec;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // K3  DistributeOctTree on the device.  One workgroup per (frame, level).
 //
 // The reference keeps a std::list of nodes: a pass visits nodes in some processing order, replaces each
@@ -1114,8 +869,7 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
                                                int32_t *__restrict__ nkeys,         // [B][nlevels] out (taps)
                                                uint32_t *__restrict__ sel,          // [B][sel_per_frame] out
                                                int32_t *__restrict__ nsel,          // [B][nlevels] out
-                                               int32_t *__restrict__ ovf,           // sticky overflow word
-                                               unsigned long long *__restrict__ autostat)  // {survivors, frames} or null
+                                               int32_t *__restrict__ ovf)           // sticky overflow word
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Workgroups go round-robin to the 8 XCDs in launch order; with level = blockIdx.x every XCD would own ONE pyramid
@@ -1140,10 +894,6 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     const int ns_all = scount[(b * plan->nlevels + level) * ORBFE_NK_STRIDE];
     const int ns = min(ns_all, L.key_cap);
     if (tid == 0 && ns_all > L.key_cap) atomicOr(ovf, 1);  // k_fast_map dropped survivors: results would be truncated
-    if (tid == 0 && autostat) {
-        atomicAdd(&autostat[0], (unsigned long long)ns_all);
-        if (level == 0) atomicAdd(&autostat[1], 1ull);
-    }
     uint32_t *cflag = q.cflag;  // bitmap over this level's cells; stays valid to the end of the kernel
     const int nwords = (L.ncells + 31) >> 5;
     for (int i = tid; i < nwords; i += QT) cflag[i] = 0u;
@@ -1866,17 +1616,7 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
     hipError_t e = hipMemsetAsync(a.d_scount, 0, sizeof(int32_t) * (size_t)a.nframes * a.h_plan->nlevels * ORBFE_NK_STRIDE, st);
     if (e != hipSuccess) return e;
     dim3 grid((a.h_plan->nfwaves + 3) / 4, a.nframes);
-    if (a.fast_sparse == 2) {
-        // candidate bitmap (rows outside the interior stay zero) -> scores of the candidates -> NMS of the corners
-        e = hipMemsetAsync(a.d_cbits, 0, sizeof(uint32_t) * (size_t)a.nframes * a.h_plan->bm_frame_dwords, st);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fast_compass, dim3((a.h_plan->nawaves + 3) / 4, a.nframes), dim3(256), 0, st, a.d_plan, fs,
-                           a.d_awaves, a.h_plan->nawaves, a.d_cbits);
-        const dim3 gb((a.h_plan->nbchunks + 3) / 4, a.nframes);
-        hipLaunchKernelGGL(k_fast_score, gb, dim3(256), 0, st, a.d_plan, fs, a.d_cbits, a.d_blur, a.pyr_fstride, a.d_fstat);
-        hipLaunchKernelGGL(k_fast_nms, gb, dim3(256), 0, st, a.d_plan, (const uint32_t *)a.d_cbits, (const uint8_t *)a.d_blur,
-                           a.pyr_fstride, a.d_skeys, a.d_scount);
-    } else if (a.fast_sparse)
+    if (a.fast_sparse)
         hipLaunchKernelGGL(k_fast_map<1>, grid, dim3(256), 0, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
                            a.d_scount, a.d_fstat);
     else
@@ -1891,7 +1631,7 @@ hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
     const size_t lds = orbk_octree_lds_bytes(a.h_plan->node_cap, a.h_plan->max_nini, a.h_plan->w, a.h_plan->h, a.h_plan->max_ncells);
     static const int qt = getenv("ORBFE_QT") ? atoi(getenv("ORBFE_QT")) : 512;  // must be <= QT_MAX
     hipLaunchKernelGGL(k_octree, grid, dim3(qt), lds, st, a.d_plan, a.d_skeys, a.d_scount, a.d_knode,
-                       a.d_nkeys, a.d_sel, a.d_nsel, a.d_ovf, a.d_auto);
+                       a.d_nkeys, a.d_sel, a.d_nsel, a.d_ovf);
     return hipGetLastError();
 }
 

@@ -123,13 +123,9 @@ class ORBextractor:
         check(self._L.orbfe_set_fast_mode(self._h, int(mode), int(collect_stats)), "orbfe_set_fast_mode")
 
     def fast_stats(self, reset=True):
-        out = np.zeros(4, np.uint64)
+        out = np.zeros(3, np.uint64)
         check(self._L.orbfe_get_fast_stats(self._h, ptr(out), int(reset)), "orbfe_get_fast_stats")
-        return dict(row_steps=int(out[0]), arc_skips=int(out[1]), nms_skips=int(out[2]), candidates=int(out[3]))
-
-    def fast_choice(self):
-        """the FAST variant the next batch will run (mode 3 = auto resolves to 0 or 2)"""
-        return int(self._L.orbfe_get_fast_choice(self._h))
+        return dict(row_steps=int(out[0]), arc_skips=int(out[1]), nms_skips=int(out[2]))
 
     def synchronize(self):
         check(self._L.orbfe_synchronize(self._h), "orbfe_synchronize")
