@@ -725,12 +725,12 @@ def bow_leg(args, local_rank, npairs=256, steps=10, warmup=3, standalone=False):
             r = O.bow_transform(voc, desc[fidx, :n[fidx]], 4)
             fvs.append((r["fv_node"], r["fv_off"], r["fv_idx"]))
         t_cpu_tr = (time.perf_counter() - t0) / 2
-        t0 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
+        t_cpu_se = 1e9
+        for _ in range(20):   # best of 20: the host is busy with the other legs' worker processes now and then
+            t0 = time.perf_counter()
             om, on = O.search_by_bow(desc[0, :n[0]], None, kps["angle"][0, :n[0]], fvs[0], desc[npairs, :n[npairs]], None,
                                      kps["angle"][npairs, :n[npairs]], fvs[1], 0.7, 50, False, True)
-        t_cpu_se = (time.perf_counter() - t0) / reps
+            t_cpu_se = min(t_cpu_se, time.perf_counter() - t0)
         assert np.array_equal(d_match[0, :n[npairs]].cpu().numpy(), om) and int(nm[0]) == on, "bow chain differs from the oracle"
         out["cpu_oracle_search_by_bow_us_per_pair"] = round(t_cpu_se * 1e6, 1)
         out["cpu_oracle_bow_transform_us_per_frame"] = round(t_cpu_tr * 1e6, 1)
