@@ -114,6 +114,72 @@ def shim_lib():
     return L
 
 
+_SHIMEXT = os.path.join(_OUT, "libshim_ext.so")
+_shimext = None
+
+
+def shimext_lib():
+    """oracle/_ref/libshim_ext.so: the PRODUCT's extractor shim (shim/ORBextractor.cc on its -DORBFE_WITH_OPENCV path)
+    driven by the reference's own Frame::ExtractORB (sliced from src/Frame.cc:337-343).  Extraction needs a GPU."""
+    global _shimext
+    if _shimext is not None:
+        return _shimext
+    build()
+    if not os.path.exists(_SHIMEXT):
+        raise RuntimeError("oracle/_ref/libshim_ext.so is missing")
+    L = C.CDLL(_SHIMEXT)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.shimext_create.restype = vp
+    L.shimext_create.argtypes = [ci, cf, ci, ci, ci]
+    L.shimext_destroy.argtypes = [vp]
+    L.shimext_extract_via_frame.argtypes = [vp, ci, vp, ci, ci, ci, vp, vp, ci, ci]
+    L.shimext_level.argtypes = [vp, ci, ci, vp, ci, vp, vp]
+    L.shimext_getters.argtypes = [vp] * 7
+    _shimext = L
+    return L
+
+
+class ShimExtractor:
+    """ORB_SLAM2::ORBextractor of the product's shim, called the way the reference's Frame calls it."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = shimext_lib()
+        self.h = self.L.shimext_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.shimext_destroy(self.h)
+            self.h = None
+
+    def getters(self):
+        n = self.nlevels
+        lv, sf = C.c_int(), C.c_float()
+        a, b, c, d = (np.zeros(n, np.float32) for _ in range(4))
+        self.L.shimext_getters(self.h, C.byref(lv), C.byref(sf), _p(a), _p(b), _p(c), _p(d))
+        return dict(levels=lv.value, scale_factor=sf.value, scale=a, inv_scale=b, sigma2=c, inv_sigma2=d)
+
+    def extract_via_frame(self, image, left=True, keep_pyramid=False, cap=None):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = image.shape
+        cap = cap or (self.nfeatures + 4 * self.nlevels + 64)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.shimext_extract_via_frame(self.h, int(left), _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap,
+                                             int(keep_pyramid))
+        if n < 0:
+            raise RuntimeError(f"shimext_extract_via_frame rc={n}")
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level(self, level, with_border=False, cap=1 << 24):
+        buf = np.zeros(cap, np.uint8)
+        w, h = C.c_int(), C.c_int()
+        rc = self.L.shimext_level(self.h, level, int(with_border), _p(buf), cap, C.byref(w), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"shimext_level rc={rc}")
+        return buf[:w.value * h.value].reshape(h.value, w.value).copy()
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

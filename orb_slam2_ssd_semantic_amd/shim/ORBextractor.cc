@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdexcept>
+#include <string>
+
 #include "orbfe.h"
 
 namespace ORB_SLAM2 {
@@ -52,8 +55,10 @@ bool ORBextractor::EnsureHandle(int w, int h)
     p.device = -1;
     mLastStatus = orbfe_create(&p, &mpHandle);
     if (mLastStatus != ORBFE_OK) {
-        fprintf(stderr, "ORBextractor: orbfe_create failed: %s (%s)\n", orbfe_strerror(mLastStatus), orbfe_last_error());
-        return false;
+        // The reference has no error path (its operator() cannot fail); a tracker silently fed with empty frames is
+        // worse than a crash, so device failures are loud: the exception is not caught anywhere in ORB-SLAM2.
+        throw std::runtime_error(std::string("ORBextractor (orbfe): orbfe_create failed: ") + orbfe_strerror(mLastStatus) + " (" +
+                                 orbfe_last_error() + ")");
     }
     mPlanW = p.max_width;
     mPlanH = p.max_height;
@@ -77,10 +82,9 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     mLastStatus = orbfe_extract(mpHandle, image.ptr<uint8_t>(0), image.cols, image.rows, (int)image.step,
                                 reinterpret_cast<orbfe_keypoint *>(_keypoints.data()), desc.ptr<uint8_t>(0), cap, &n);
     if (mLastStatus != ORBFE_OK) {
-        fprintf(stderr, "ORBextractor: orbfe_extract failed: %s (%s)\n", orbfe_strerror(mLastStatus), orbfe_last_error());
         _keypoints.clear();
-        _descriptors.release();
-        return;
+        throw std::runtime_error(std::string("ORBextractor (orbfe): orbfe_extract failed: ") + orbfe_strerror(mLastStatus) + " (" +
+                                 orbfe_last_error() + ")");
     }
     _keypoints.resize(n);
     if (n == 0) {

@@ -15,7 +15,11 @@
 // (oracle/refbuild: libshim_ref.so; tests/test_gpu_shim_ref.py compares it with the compiled reference bodies).
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
+#include <algorithm>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include <ORBmatcher.h>  // the reference's own header, found on the include path (NOT the stand-alone template form next to this file)
@@ -28,9 +32,10 @@ struct ThreadMatcher {
     ~ThreadMatcher() { orbfe_matcher_destroy(m); }
     orbfe_matcher *get()
     {
+        // the reference's matcher cannot fail; a device failure must not look like "no matches": it throws
         if (!m && orbfe_matcher_create(-1, &m) != ORBFE_OK) {
-            fprintf(stderr, "ORBmatcher (orbfe): %s\n", orbfe_last_error());
             m = nullptr;
+            throw std::runtime_error(std::string("ORBmatcher (orbfe): orbfe_matcher_create failed: ") + orbfe_last_error());
         }
         return m;
     }
@@ -84,7 +89,6 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
     const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
     vpMapPointMatches = std::vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));  // :222
     orbfe_matcher *m = t_matcher.get();
-    if (!m) return 0;
     std::vector<uint8_t> validKF, tk, tf;
     Valid(vpMapPointsKF, validKF);
     Csr kf, f;
@@ -100,10 +104,7 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
                                                Rows(F.mDescriptors, tf), F.N, NULL, angF.data(), f.node.data(), f.off.data(),
                                                f.idx.data(), (int)f.node.size(), mfNNratio, TH_LOW, 0, mbCheckOrientation ? 1 : 0,
                                                match.data(), &n);
-    if (s != ORBFE_OK) {
-        fprintf(stderr, "ORBmatcher::SearchByBoW (orbfe): %s\n", orbfe_last_error());
-        return 0;
-    }
+    if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByBoW (orbfe): ") + orbfe_last_error());
     for (int i = 0; i < F.N; ++i)
         if (match[(size_t)i] >= 0) vpMapPointMatches[(size_t)i] = vpMapPointsKF[(size_t)match[(size_t)i]];  // :298
     return n;
@@ -115,7 +116,6 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint
     const std::vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
     vpMatches12 = std::vector<MapPoint *>(vpMapPoints1.size(), static_cast<MapPoint *>(NULL));  // :677
     orbfe_matcher *m = t_matcher.get();
-    if (!m) return 0;
     std::vector<uint8_t> v1, v2, t1, t2;
     Valid(vpMapPoints1, v1);
     Valid(vpMapPoints2, v2);
@@ -132,10 +132,7 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint
                                                (int)v2.size(), v2.data(), a2.data(), c2.node.data(), c2.off.data(), c2.idx.data(),
                                                (int)c2.node.size(), mfNNratio, TH_LOW, 1, mbCheckOrientation ? 1 : 0,
                                                match.data(), &n);
-    if (s != ORBFE_OK) {
-        fprintf(stderr, "ORBmatcher::SearchByBoW (orbfe): %s\n", orbfe_last_error());
-        return 0;
-    }
+    if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByBoW (orbfe): ") + orbfe_last_error());
     for (size_t i2 = 0; i2 < v2.size(); ++i2)  // the reference's output is indexed by the KF1 feature (:751)
         if (match[i2] >= 0) vpMatches12[(size_t)match[i2]] = vpMapPoints2[i2];
     return n;

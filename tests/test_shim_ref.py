@@ -40,3 +40,34 @@ def test_shim_search_by_bow_equals_reference_bodies(seed):
         assert sn2 == rn2 and np.array_equal(s12, r12), ("KF,KF", seed, it, n1, n2)
         total += rn + rn2
     assert total > 50
+
+
+def test_extractor_shim_builds_on_its_opencv_path_and_keeps_the_getters():
+    """shim/ORBextractor.cc compiled with -DORBFE_WITH_OPENCV against the OpenCV-semantics stub and driven by the
+    reference's Frame::ExtractORB (oracle/_ref/libshim_ext.so): it loads, and the getters Frame reads (src/Frame.cc:186-192)
+    return the reference constructor's tables before any frame was seen (no GPU involved)."""
+    s = R.ShimExtractor(1000, 1.2, 8, 20, 7)
+    g = s.getters()
+    t = R.RefExtractor(1000, 1.2, 8, 20, 7).tables()
+    assert g["levels"] == 8 and abs(g["scale_factor"] - 1.2) < 1e-6
+    for a, b in (("scale", "scale"), ("inv_scale", "inv_scale"), ("sigma2", "sigma2"), ("inv_sigma2", "inv_sigma2")):
+        assert np.array_equal(g[a].view(np.uint32), t[b].view(np.uint32)), a
+
+
+@pytest.mark.gpu
+def test_reference_frame_extractorb_through_the_shim_equals_the_reference_class():
+    """Frame::ExtractORB (the reference's own caller code) -> product shim -> liborbfe.so (HIP)  ==  the reference's own
+    ORBextractor class (compiled, bump allocator, canonical sincos): keypoints, descriptors, order; and with mbKeepPyramid
+    the public mvImagePyramid (ROI and its 19-px REFLECT_101 border) equals the reference's."""
+    from orb_slam2_ssd_semantic_amd.synth import synth_frame, synth_tum_like
+    R.configure(bump=True, canonical_trig=True, blur_mode=0)
+    for nf, frames in ((1000, [synth_frame(40), synth_tum_like(41), synth_frame(42, sparse=True)]), (2000, [synth_frame(43)])):
+        shim, ref = R.ShimExtractor(nf, 1.2, 8, 20, 7), R.RefExtractor(nf, 1.2, 8, 20, 7)
+        for i, img in enumerate(frames):
+            sk, sd = shim.extract_via_frame(img, left=(i % 2 == 0), keep_pyramid=True, cap=nf + 128)
+            rk, rd = ref(img, cap=nf + 128)
+            assert len(sk) == len(rk) >= nf
+            assert np.array_equal(sk.view(np.uint8), rk.view(np.uint8)) and np.array_equal(sd, rd)
+            for l in range(8):
+                assert np.array_equal(shim.level(l), ref.level(l)), l
+                assert np.array_equal(shim.level(l, with_border=True), ref.level(l, with_border=True)), l
