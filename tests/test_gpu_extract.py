@@ -318,3 +318,36 @@ def test_host_batch_pipeline_pageable_and_pinned(oracle):
             assert np.array_equal(k2[i, :n2[i]].view(np.uint8), ok.view(np.uint8)), (max_batch, i)
             assert not d2[i, n2[i]:].any() and not k2[i, n2[i]:].view(np.uint8).any()   # padded slots zero-filled
         assert e.overflow() == 0
+
+
+def test_hip_path_equals_the_compiled_reference_directly():
+    """No oracle in between: 48 frames (S, S vignetted, S_tum; 1000 and 2000 features) through one batched device call each,
+    compared frame by frame with oracle/_ref -- the UNMODIFIED reference ORBextractor.cc compiled against the cv stub (bump
+    allocator = creation-order tie-break, canonical cos/sin): counts, keypoint bit patterns, descriptors, order."""
+    import torch
+    from oracle import ref_ffi as R
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE, ORBextractor
+    from orb_slam2_ssd_semantic_amd.synth import synth_tum_like
+    if not R.available():
+        pytest.skip("oracle/_ref/libref_orb.so not present")
+    R.configure(bump=True, canonical_trig=True, blur_mode=0)
+    w, h, B = 640, 480, 24
+    frames = np.stack([synth_frame(900 + i, h, w, sparse=(i % 3 == 1)) if i % 3 else synth_tum_like(900 + i, h, w) for i in range(B)])
+    for nf in (1000, 2000):
+        e = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+        cap = e.capacity()
+        dg = torch.from_numpy(frames).cuda()
+        dk = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
+        dd = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        dn = torch.zeros(B, dtype=torch.int32, device="cuda")
+        e.extract_batch_device(dg.data_ptr(), B, w, h, w, w * h, dk.data_ptr(), dd.data_ptr(), cap, dn.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert e.overflow() == 0
+        n, kps, desc = dn.cpu().numpy(), dk.cpu().numpy(), dd.cpu().numpy()
+        ref = R.RefExtractor(nf, 1.2, 8, 20, 7)
+        for i in range(B):
+            rk, rd = ref(frames[i], cap=nf + 128)
+            gk = kps[i, :n[i]].copy().view(KP_DTYPE).reshape(-1)
+            assert n[i] == len(rk), (nf, i)
+            assert np.array_equal(gk.view(np.uint8), rk.view(np.uint8)) and np.array_equal(desc[i, :n[i]], rd), (nf, i)
