@@ -223,7 +223,8 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 // Dense streaming formulation.
 //
 // k_fast_map   one wave per (level, 256-px strip piece, row block).  Every lane owns 4 adjacent pixels and walks down
-//              the rows with the last 7 image rows (3 dwords each) in registers -- no LDS, no byte loads.  With
+//              the rows with the last 7 image rows in registers (each unpacked once into its nine u16 pixel pairs,
+//              fast_unpack_row) -- no LDS, no byte loads.  With
 //              raw pixel values c[0..15] on the circle,  min over an arc of (v - c) = v - max(c)  and
 //              min over an arc of (c - v) = min(c) - v, so
 //                  A = max( v - min_k max(c[k..k+8]),  max_k min(c[k..k+8]) - v )
@@ -289,32 +290,49 @@ __device__ __forceinline__ uint32_t rowpair(const uint32_t (&w)[3])
     return __builtin_amdgcn_perm(w[(IDX >> 2) + 1 > 2 ? 2 : (IDX >> 2) + 1], w[IDX >> 2], 0x0c040c03u);
 }
 
+// Every row of the ring is unpacked ONCE, when it arrives, into the nine pixel pairs (i, i+1), i = 1..9, of its 12-byte
+// window (E[i-1]); each pair is then used by up to three centre rows and by both pixel pairs of the lane, instead of
+// being re-extracted with a v_perm at every use (34 -> 9 extractions per row step).
+#define FM_NE 9
+__device__ __forceinline__ void fast_unpack_row(const uint32_t (&w)[3], uint32_t (&e)[FM_NE])
+{
+    e[0] = rowpair<1>(w);
+    e[1] = rowpair<2>(w);
+    e[2] = rowpair<3>(w);
+    e[3] = rowpair<4>(w);
+    e[4] = rowpair<5>(w);
+    e[5] = rowpair<6>(w);
+    e[6] = rowpair<7>(w);
+    e[7] = rowpair<8>(w);
+    e[8] = rowpair<9>(w);
+}
+
 // thresholded arc strengths S = max(A - t, 0) of the pixel pair (J, J+1) of the lane, as two u16 halves;
-// R[dy+3] = 12-byte window (pixels x-4 .. x+7) of image row y+dy
+// rows are unpacked windows (fast_unpack_row) of image rows y-3 .. y+3
 template <int J>
-__device__ __forceinline__ uint32_t fast_strength_pair(const uint32_t (&rm3)[3], const uint32_t (&rm2)[3],
-                                                       const uint32_t (&rm1)[3], const uint32_t (&r0)[3],
-                                                       const uint32_t (&rp1)[3], const uint32_t (&rp2)[3],
-                                                       const uint32_t (&rp3)[3], uint32_t t)
+__device__ __forceinline__ uint32_t fast_strength_pair(const uint32_t (&rm3)[FM_NE], const uint32_t (&rm2)[FM_NE],
+                                                       const uint32_t (&rm1)[FM_NE], const uint32_t (&r0)[FM_NE],
+                                                       const uint32_t (&rp1)[FM_NE], const uint32_t (&rp2)[FM_NE],
+                                                       const uint32_t (&rp3)[FM_NE], uint32_t t)
 {
     uint32_t c[16];
-    c[0] = rowpair<4 + J>(rp3);
-    c[1] = rowpair<5 + J>(rp3);
-    c[2] = rowpair<6 + J>(rp2);
-    c[3] = rowpair<7 + J>(rp1);
-    c[4] = rowpair<7 + J>(r0);
-    c[5] = rowpair<7 + J>(rm1);
-    c[6] = rowpair<6 + J>(rm2);
-    c[7] = rowpair<5 + J>(rm3);
-    c[8] = rowpair<4 + J>(rm3);
-    c[9] = rowpair<3 + J>(rm3);
-    c[10] = rowpair<2 + J>(rm2);
-    c[11] = rowpair<1 + J>(rm1);
-    c[12] = rowpair<1 + J>(r0);
-    c[13] = rowpair<1 + J>(rp1);
-    c[14] = rowpair<2 + J>(rp2);
-    c[15] = rowpair<3 + J>(rp3);
-    const uint32_t v = rowpair<4 + J>(r0);
+    c[0] = rp3[3 + J];
+    c[1] = rp3[4 + J];
+    c[2] = rp2[5 + J];
+    c[3] = rp1[6 + J];
+    c[4] = r0[6 + J];
+    c[5] = rm1[6 + J];
+    c[6] = rm2[5 + J];
+    c[7] = rm3[4 + J];
+    c[8] = rm3[3 + J];
+    c[9] = rm3[2 + J];
+    c[10] = rm2[1 + J];
+    c[11] = rm1[0 + J];
+    c[12] = r0[0 + J];
+    c[13] = rp1[0 + J];
+    c[14] = rp2[1 + J];
+    c[15] = rp3[2 + J];
+    const uint32_t v = r0[3 + J];
     // Nine-arcs k and k+1 (k even) share the eight pixels c[k+1..k+8], so
     //   max(min arc_k, min arc_k+1) = min(c[k+1..k+8], max(c[k], c[k+9]))     (and dually for the dark polarity):
     // odd-aligned pairs P/Q, one 3-way and one closing 3-way op per arc pair -- 36 ops per polarity for all 16 arcs.
@@ -344,12 +362,12 @@ __device__ __forceinline__ uint32_t fast_strength_pair(const uint32_t (&rm3)[3],
 // least one pixel of each opposite pair, so a bright corner needs max(c0, c8) > v + t AND max(c4, c12) > v + t (and
 // dually for dark).  Non-zero half <=> that pixel may be a corner.  15 packed ops against 92 for the strength.
 template <int J>
-__device__ __forceinline__ uint32_t fast_compass_pair(const uint32_t (&rm3)[3], const uint32_t (&r0)[3],
-                                                      const uint32_t (&rp3)[3], uint32_t t)
+__device__ __forceinline__ uint32_t fast_compass_pair(const uint32_t (&rm3)[FM_NE], const uint32_t (&r0)[FM_NE],
+                                                      const uint32_t (&rp3)[FM_NE], uint32_t t)
 {
-    const uint32_t c0 = rowpair<4 + J>(rp3), c8 = rowpair<4 + J>(rm3);
-    const uint32_t c4 = rowpair<7 + J>(r0), c12 = rowpair<1 + J>(r0);
-    const uint32_t v = rowpair<4 + J>(r0);
+    const uint32_t c0 = rp3[3 + J], c8 = rm3[3 + J];
+    const uint32_t c4 = r0[6 + J], c12 = r0[0 + J];
+    const uint32_t v = r0[3 + J];
     const uint32_t mb = pk_min_u16(pk_max_u16(c0, c8), pk_max_u16(c4, c12));
     const uint32_t md = pk_max_u16(pk_min_u16(c0, c8), pk_min_u16(c4, c12));
     return pk_subsat_u16(pk_max_u16(pk_subsat_u16(mb, v), pk_subsat_u16(v, md)), t);
@@ -455,11 +473,16 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
     // key of pixel 0 in the NMS row of step 0 (detection-window coordinates = level - 16, reference :831-832)
     const uint32_t key00 = (uint32_t)(x - ORBFE_MINB) + ((uint32_t)(ys - 8 - ORBFE_MINB) << 12);
 
-    // 8-slot rings (7 live rows + the row being fetched one step ahead), statically indexed under the 8-fold unroll
-    uint32_t R[8][3];
+    // 8-slot ring of unpacked rows (7 live), statically indexed under the 8-fold unroll; the raw row of the next step is
+    // fetched one step ahead into one of two 12-byte buffers
+    uint32_t R[8][FM_NE], Raw[2][3];
     uint32_t S01[8], S23[8];  // S of the pixel pairs (0,1), (2,3) for the strength row computed in ring slot k
 #pragma unroll
-    for (int k = 0; k < 8; ++k) R[k][0] = R[k][1] = R[k][2] = S01[k] = S23[k] = 0u;
+    for (int k = 0; k < 8; ++k) {
+        S01[k] = S23[k] = 0u;
+#pragma unroll
+        for (int i = 0; i < FM_NE; ++i) R[k][i] = 0u;
+    }
     auto fetch = [&](int s, uint32_t (&dst3)[3]) {
         const int r = ys - 4 + s;  // image row of step s (lanes past their run re-read a valid row)
         const uint8_t *row = src + (__umul24((uint32_t)min(r, H - 1), (uint32_t)pitch) + (uint32_t)x);
@@ -467,24 +490,25 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
         dst3[1] = *(const uint32_t *)(row);
         dst3[2] = *(const uint32_t *)(row + 4);
     };
-    fetch(0, R[0]);
+    fetch(0, Raw[0]);
 
     for (int s0 = 0; s0 < nsteps; s0 += 8) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int s = s0 + k;
             if (s >= nsteps) break;    // wave-uniform
-            fetch(s + 1, R[(k + 1) % 8]);
+            fetch(s + 1, Raw[(k + 1) % 2]);
+            fast_unpack_row(Raw[k % 2], R[k]);
             if (s < 6) continue;
             // ---- strength row rc = r - 3 (newest ring slot k is row rc+3, slot (k+2)%8 is row rc-3) ----
             {
-                const uint32_t(&rm3)[3] = R[(k + 2) % 8];
-                const uint32_t(&rm2)[3] = R[(k + 3) % 8];
-                const uint32_t(&rm1)[3] = R[(k + 4) % 8];
-                const uint32_t(&r0)[3] = R[(k + 5) % 8];
-                const uint32_t(&rp1)[3] = R[(k + 6) % 8];
-                const uint32_t(&rp2)[3] = R[(k + 7) % 8];
-                const uint32_t(&rp3)[3] = R[k];
+                const uint32_t(&rm3)[FM_NE] = R[(k + 2) % 8];
+                const uint32_t(&rm2)[FM_NE] = R[(k + 3) % 8];
+                const uint32_t(&rm1)[FM_NE] = R[(k + 4) % 8];
+                const uint32_t(&r0)[FM_NE] = R[(k + 5) % 8];
+                const uint32_t(&rp1)[FM_NE] = R[(k + 6) % 8];
+                const uint32_t(&rp2)[FM_NE] = R[(k + 7) % 8];
+                const uint32_t(&rp3)[FM_NE] = R[k];
                 const bool rowok = (uint32_t)(ysrel + s) < hrange;  // iy0 <= rc < iy1
                 const uint32_t tt = rowok ? tzz : 0x03FF03FFu;
                 bool arcs = true;
