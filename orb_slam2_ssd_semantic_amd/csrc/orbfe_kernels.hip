@@ -1262,7 +1262,12 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
     const bool full = x + 4 <= W;
     const int dpitch = L.pitch;
 
-    uint32_t S[7][4];  // row sums (<= 255 * 257) of the last seven rows
+    // Row sums are <= 255 * 257 = 65535, i.e. u16: ring slot k holds, per pixel, the pair (row sum of step s-1, row sum of
+    // step s) as two u16 halves, so the vertical pass is three v_dot2_u32_u16 (pairs of taps) plus one multiply-add
+    // for the newest row instead of seven multiply / add steps.
+    uint32_t S[7][4], Sprev[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Sprev[j] = 0u;
 #pragma unroll
     for (int k = 0; k < 7; ++k)
 #pragma unroll
@@ -1302,17 +1307,20 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
                     if (blur_hw(j, d) != 0u) h = __builtin_amdgcn_udot4(w[d], blur_hw(j, d), h, false);
-                S[k][j] = h;
+                S[k][j] = Sprev[j] | (h << 16);
+                Sprev[j] = h;
             }
             if (s >= 6) {
                 const int y = yin - 3;
                 uint32_t tq[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    // newest row sum is slot k (offset +3), oldest is slot (k+1)%7 (offset -3)
-                    // 24-bit multiplies (operands < 2^18): v_mad_u32_u24, not the quarter-rate 32-bit multiply
-                    const uint32_t acc = __umul24(18u, S[(k + 1) % 7][j] + S[k][j]) + __umul24(34u, S[(k + 2) % 7][j] + S[(k + 6) % 7][j]) +
-                                         __umul24(49u, S[(k + 3) % 7][j] + S[(k + 5) % 7][j]) + __umul24(55u, S[(k + 4) % 7][j]) + 32768u;
+                    // rows y-3 .. y+3 are steps s-6 .. s: pairs (s-6, s-5), (s-4, s-3), (s-2, s-1) sit in the slots written at
+                    // steps s-5, s-3, s-1; the newest row sum is Sprev
+                    uint32_t acc = __umul24(18u, Sprev[j]) + 32768u;  // v_mad_u32_u24
+                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 2) % 7][j]), __builtin_bit_cast(orb_u2, 0x00220012u), acc, false);
+                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 4) % 7][j]), __builtin_bit_cast(orb_u2, 0x00370031u), acc, false);
+                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 6) % 7][j]), __builtin_bit_cast(orb_u2, 0x00220031u), acc, false);
                     uint32_t q = acc;  // (q >> 16) = value rounded half-up, <= 257
                     if (MODE == 1 && (acc & 0xFFFFu) == 0u && (x + j) < vec_w && (q & 0x10000u)) q -= 0x10000u;  // SSE2 half-even
                     tq[j] = min(q, 0x00FFFFFFu);  // byte 2 = saturate_cast<uchar>
