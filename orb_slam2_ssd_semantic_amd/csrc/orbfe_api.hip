@@ -317,7 +317,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         L.patch_size = (float)(int)(ORBFE_PATCH * h->scale[l]);  // :846
         if (l >= 1) {
             const OrbLevel &S = P.lv[l - 1];
-            if (S.w >= 2 * L.w) {  // k_pyr_resize: the 4 source pairs of a lane must fit one 8-byte window
+            if (S.w >= 2 * L.w) {  // k_pyr_walk: the 4 source pairs of a lane must fit one 8-byte window
                 orbfe_set_error("scale factor too large: level %d is less than half as wide as level %d", l, l - 1);
                 return ORBFE_ERR_ARG;
             }
@@ -333,6 +333,16 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             };
             L.xtab = add_axis(S.w, L.w, true);
             L.ytab = add_axis(S.h, L.h, false);
+            // k_pyr_walk completes at most one destination row per source row: the source row index must grow strictly
+            for (int d = 1; d < L.h; ++d)
+                if (tabs[(size_t)L.ytab + d].s <= tabs[(size_t)L.ytab + d - 1].s) {
+                    orbfe_set_error("level %d: vertical resize taps are not strictly increasing", l);
+                    return ORBFE_ERR_ARG;
+                }
+            if (orbk_pyramid_lds_bytes(L.h) > 64 * 1024) {
+                orbfe_set_error("level %d too tall for the pyramid kernel's LDS tap table", l);
+                return ORBFE_ERR_SIZE;
+            }
         }
         if (L.w > 4095 + 2 * ORBFE_MINB || L.h > 4095 + 2 * ORBFE_MINB) {
             orbfe_set_error("level %d exceeds the 12-bit key coordinate range", l);

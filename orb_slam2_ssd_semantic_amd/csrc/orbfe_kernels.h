@@ -40,6 +40,7 @@ struct OrbLaunch {
 hipError_t orbk_upload_constants(const int *umax16);
 size_t orbk_octree_lds_bytes(int node_cap, int max_nini, int w, int h, int ncells);
 hipError_t orbk_prepare_octree(int node_cap, int max_nini, int w, int h, int ncells);
+size_t orbk_pyramid_lds_bytes(int dh);  // dynamic LDS of the pyramid kernel for a destination level of dh rows
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st);

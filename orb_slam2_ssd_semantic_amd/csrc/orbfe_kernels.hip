@@ -1,7 +1,7 @@
 // orbfe_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the ORB extractor.
 //
 // Reference behaviour restated (paths relative to /root/reference):
-//   K1 k_pyr_resize      ComputePyramid + cv::resize INTER_LINEAR   src/ORBextractor.cc:1117-1145
+//   K1 k_pyr_walk        ComputePyramid + cv::resize INTER_LINEAR   src/ORBextractor.cc:1117-1145
 //   K2 k_fast_cells      per-cell cv::FAST + NMS + minTh fallback   src/ORBextractor.cc:798-838
 //   K3 k_octree          DistributeOctTree / DivideNode             src/ORBextractor.cc:478-765
 //   K4 k_blur7           GaussianBlur 7x7 sigma 2 REFLECT_101       src/ORBextractor.cc:1094-1095
@@ -108,62 +108,53 @@ __device__ __forceinline__ void xcd_frame_remap(int &bx, int &b)
 
 // ---------------------------------------------------------------------------------------------------
 // K1  bilinear pyramid level:  dst(level) = resize(src(level-1))      
-// One wave per 256 x 32 destination tile: every lane owns 4 adjacent destination pixels and walks down the rows.
-// Its horizontal taps (source column, the two 11-bit coefficients) are per-lane constants; per source row it
-// loads a 12-byte window (3 aligned dwords) and forms the four horizontal sums H = S[sx]*a0 + S[sx+1]*a1.
-// Consecutive destination rows share source rows (sy1 of one row is sy0 of the next ~5 times out of 6), so the
-// H row is carried in registers.  Vertical step: ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2, one dword store.
-// Coefficient tables are precomputed on the host in fp64/fp32 exactly as cv::resize does; all kernel math is int32.
+// cv::resize(INTER_LINEAR) in its 8-bit fixed-point form: horizontal sums H = S[sx]*a0 + S[sx+1]*a1 with 11-bit
+// coefficients, vertical step ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2.  The level's geometry travels as kernel
+// arguments; the taps (source index + the two coefficients per destination column / row) come from host-built tables
+// computed with the exact fp64 / fp32 operation sequence of cv::resize; all kernel math is int32.
 // ---------------------------------------------------------------------------------------------------
-#define PY_RB 4  // destination rows per lane (2 and 8 measured slower)
-
-// The level's geometry travels as kernel arguments; the bilinear taps (source index + two 11-bit coefficients per
-// destination column / row) come from host-built tables computed with the exact fp64 / fp32 operation sequence of
-// cv::resize: a lane fetches the taps of its 4 pixels and PY_RB rows with 16-byte loads.
 struct PyrArgs {
     const uint8_t *src;  // level l-1, frame 0
     uint8_t *dst;        // level l, frame 0
     int64_t src_fstride, dst_fstride;
     int32_t sw, sh, spitch;
     int32_t dw, dh, dpitch;
-    const OrbTab *xtab, *ytab;  // cv::resize taps of the two axes (host-built, 4-entry aligned, padded by 4 entries)
+    const OrbTab *xtab, *ytab;  // cv::resize taps of the two axes (host-built, 4-entry aligned, padded by 8 entries)
+    int32_t rb, nrblk;          // destination rows per lane run, number of runs
 };
 
-// one lane's work: 4 adjacent destination pixels x PY_RB rows of frame b; `flat` indexes (row block, 4-pixel column group)
-__device__ __forceinline__ void pyr_lane(const PyrArgs &a, int b, int flat)
+// A lane owns 4 adjacent destination pixels and a run of a.rb destination rows and walks down the SOURCE rows
+// r = sy(y0), sy(y0)+1, ... once: the four source pairs of its pixels lie in one unaligned 8-byte window per source row
+// (level-to-level scale < 2, checked on the host; pair selection by per-lane v_perm selectors, one v_dot2_u32_u16 per
+// tap pair), so the horizontal sums H_r of every source row are formed once and kept for one step; the destination row d is completed in the step whose row is sy(d) + 1 -- sy is strictly increasing (the
+// level-to-level ratio is >= 1, checked on the host), so a step completes at most one destination row.  Rows are
+// fetched PW_PF steps ahead (loads clamp to the last source row: the virtual row sh repeats row sh - 1, which is what
+// cv::resize's clamped second tap reads).  The loop issues loads only: completed dwords are parked in LDS
+// ([row of the run][thread], conflict-free) and stored in one burst after the walk, so that the wait for a prefetched row
+// never includes a store acknowledgement (stores and loads share one in-order counter on this part).  The level's
+// vertical taps sit in LDS as well.  The level pitch is a multiple of 64: the last column group stores its whole dword.
+#define PW_PF 2
+#define PW_ROWS 16  // destination rows per lane run (8, 24, 32 measured slower)
+__global__ __launch_bounds__(256) void k_pyr_walk(PyrArgs a)
 {
+    extern __shared__ uint2 s_dyn[];
+    uint2 *s_yt = s_dyn;                                   // [dh + 8]: .x = b0 | b1 << 16, .y = sy (low half)
+    uint32_t *s_out = (uint32_t *)(s_dyn + (a.dh + 8));    // [rb][256]
+    const int b = blockIdx.y;
     const int W = a.dw, H = a.dh;
-    // lanes are a flat index over (row block, 4-pixel column group): no lane idles on levels narrower than a strip
-    const int ncol4 = (W + 3) >> 2, nrblk = (H + PY_RB - 1) / PY_RB;
-    const bool active = flat < ncol4 * nrblk;
-    const int fl = min(flat, ncol4 * nrblk - 1);
+    for (int i = threadIdx.x; i < H + 8; i += 256) s_yt[i] = ((const uint2 *)a.ytab)[i];
+    const int ncol4 = (W + 3) >> 2;
+    const int nlanes = ncol4 * a.nrblk;
+    const int fl = min((int)(blockIdx.x * 256 + threadIdx.x), nlanes - 1);  // surplus lanes repeat the last lane's work
     const int rblk = fl / ncol4;
     const int dx0 = (fl - rblk * ncol4) * 4;
-    const int y0 = rblk * PY_RB;
-    const int nrows = min(PY_RB, H - y0);
+    const int y0 = rblk * a.rb, yend = min(y0 + a.rb, H);
     const uint8_t *src = a.src + (int64_t)b * a.src_fstride;
     uint8_t *dst = a.dst + (int64_t)b * a.dst_fstride;
 
-    // per-lane horizontal taps.  The four source pairs (S[sx], S[sx+1]) of a lane lie inside the 8 bytes starting at
-    // its first source column (level-to-level scale < 2, checked by the host), so ONE unaligned 8-byte load per
-    // source row feeds all four pixels: pixel j picks its pair with a per-lane v_perm selector (-> two u16 halves)
-    // and the horizontal sum S[sx]*a0 + S[sx+1]*a1 is one v_dot2_u32_u16 against the packed coefficients.
-    // taps of the lane's 4 pixels and 4 rows: four 16-byte loads from the host-built tables (exact cv::resize taps)
     const uint4 tx01 = *(const uint4 *)(a.xtab + dx0), tx23 = *(const uint4 *)(a.xtab + dx0 + 2);
-    const uint32_t xc[4] = {tx01.x, tx01.z, tx23.x, tx23.z};  // coefficient pairs c0 | c1 << 16
+    const uint32_t xc[4] = {tx01.x, tx01.z, tx23.x, tx23.z};
     const int xs[4] = {(int)(short)tx01.y, (int)(short)tx01.w, (int)(short)tx23.y, (int)(short)tx23.w};
-    uint32_t yc[PY_RB];
-    int ys4[PY_RB];
-#pragma unroll
-    for (int d = 0; d < PY_RB; d += 2) {
-        const uint4 ty = *(const uint4 *)(a.ytab + y0 + d);
-        yc[d] = ty.x;
-        yc[d + 1] = ty.z;
-        ys4[d] = (int)(short)ty.y;
-        ys4[d + 1] = (int)(short)ty.w;
-    }
-    // the window never leaves the source row: at the right edge it is pulled back to end at the last pixel (the
-    // second byte of a pair at the last column has coefficient 0, any byte serves)
     const int sx0 = min(xs[0], a.sw - 8);
     uint32_t sel[4];
     orb_u2 coef[4];
@@ -173,43 +164,78 @@ __device__ __forceinline__ void pyr_lane(const PyrArgs &a, int b, int flat)
         sel[j] = 0x0c000c00u | (min(o + 1u, 7u) << 16) | o;
         coef[j] = __builtin_bit_cast(orb_u2, xc[j]);
     }
-    // straight-line: all source windows of the tile in flight at once, then the arithmetic (no control flow)
-    uint2 q0[PY_RB], q1[PY_RB];
-    int vb0[PY_RB], vb1[PY_RB];
+    __syncthreads();
+    uint2 cur = s_yt[y0];
+    const int r0 = (int)(short)cur.y;
+    int nsteps = (int)(short)s_yt[yend - 1].y + 2 - r0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps);
     const uint32_t sp = (uint32_t)a.spitch;
+    const int rlast = a.sh - 1;
+    // uniform base + 32-bit per-lane offset (global_load with an SGPR base)
+    auto fetch = [&](int s, uint2 &q) { q = *(const uint2 *)(src + (__umul24((uint32_t)min(r0 + s, rlast), sp) + (uint32_t)sx0)); };
+    auto hsum = [&](const uint2 &q, uint32_t (&h)[4]) {
 #pragma unroll
-    for (int d = 0; d < PY_RB; ++d) {
-        const int tys = ys4[d];
-        vb0[d] = (int)(yc[d] & 0xFFFFu);
-        vb1[d] = (int)(yc[d] >> 16);
-        const int sy0 = min(max(tys, 0), a.sh - 1), sy1 = min(max(tys + 1, 0), a.sh - 1);
-        q0[d] = *(const uint2 *)(src + (__umul24((uint32_t)sy0, sp) + (uint32_t)sx0));
-        q1[d] = *(const uint2 *)(src + (__umul24((uint32_t)sy1, sp) + (uint32_t)sx0));
-    }
-    const bool full = dx0 + 4 <= W;
+        for (int j = 0; j < 4; ++j)
+            h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, __builtin_amdgcn_perm(q.y, q.x, sel[j])), coef[j], 0u, false) >> 4;
+    };
+    uint2 raw[4];
+    fetch(0, raw[0]);
+    fetch(1, raw[1]);
+    fetch(2, raw[2]);
+    uint32_t Hp[4];
+    hsum(raw[0], Hp);  // step 0: source row sy(y0), completes nothing
+    int d = y0;
+    uint32_t *park = s_out + threadIdx.x;
+    // steps run in groups of four (static ring indices, no exit inside a group): surplus steps re-read the clamped last
+    // row and complete nothing
+    for (int s0 = 1; s0 < nsteps; s0 += 4) {
 #pragma unroll
-    for (int d = 0; d < PY_RB; ++d) {
-        uint32_t v4[4];
+        for (int k = 0; k < 4; ++k) {
+            const int s = s0 + k;
+            fetch(s + PW_PF, raw[(k + 1 + PW_PF) % 4]);
+            uint32_t Hs[4];
+            hsum(raw[(k + 1) % 4], Hs);
+            const bool emit = d < yend && (int)(short)cur.y + 1 == r0 + s;
+            // ((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2: the "+ 2" rides in the second product (+ 2 << 16, no carry
+            // into it from below), the two ">> 16" are the SDWA word selects of one add, whose result lands in the low /
+            // high half of a pair register; ">> 2" is then one packed shift per pixel pair
+            const uint32_t b0 = cur.x & 0xFFFFu, b1 = cur.x >> 16;
+            uint32_t pa[4], pb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t ha = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, __builtin_amdgcn_perm(q0[d].y, q0[d].x, sel[j])), coef[j], 0u, false);
-            const uint32_t hb = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, __builtin_amdgcn_perm(q1[d].y, q1[d].x, sel[j])), coef[j], 0u, false);
-            v4[j] = ((__umul24((uint32_t)vb0[d], ha >> 4) >> 16) + (__umul24((uint32_t)vb1[d], hb >> 4) >> 16) + 2u) >> 2;
+            for (int j = 0; j < 4; ++j) {
+                pa[j] = __umul24(b0, Hp[j]);
+                pb[j] = __umul24(b1, Hs[j]) + 0x20000u;
+            }
+            uint32_t t01, t23;
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t01) : "v"(pa[0]), "v"(pb[0]));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t01) : "v"(pa[1]), "v"(pb[1]));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t23) : "v"(pa[2]), "v"(pb[2]));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t23) : "v"(pa[3]), "v"(pb[3]));
+            const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t01) >> (orb_u2)(2));
+            const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t23) >> (orb_u2)(2));
+            if (emit) {
+                *park = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
+                park += 256;
+                d += 1;
+            }
+            cur = s_yt[d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Hp[j] = Hs[j];
         }
-        const uint32_t packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v4[3], v4[2], 0x0c0c0400u),
-                                                      __builtin_amdgcn_perm(v4[1], v4[0], 0x0c0c0400u), 0x05040100u);
-        if (active && d < nrows) {
-            uint8_t *o = dst + (__umul24((uint32_t)(y0 + d), (uint32_t)a.dpitch) + (uint32_t)dx0);
-            if (full) *(uint32_t *)o = packed;
-            else
-                for (int j = 0; j < 4 && dx0 + j < W; ++j) o[j] = (uint8_t)(packed >> (8 * j));
-        }
     }
-}
-
-__global__ __launch_bounds__(256) void k_pyr_resize(PyrArgs a)
-{
-    pyr_lane(a, blockIdx.y, (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63));
+    // burst store of the run (every lane reads back its own LDS column: no barrier)
+    uint32_t oofs = __umul24((uint32_t)y0, (uint32_t)a.dpitch) + (uint32_t)dx0;
+    const int nrows = yend - y0;
+    for (int i0 = 0; i0 < a.rb; i0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = s_out[min(i0 + i, a.rb - 1) * 256 + threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i0 + i < nrows) *(uint32_t *)(dst + (oofs + (uint32_t)(i0 + i) * (uint32_t)a.dpitch)) = v[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1611,11 +1637,14 @@ static FrameSrc make_src(const OrbLaunch &a)
     return fs;
 }
 
+size_t orbk_pyramid_lds_bytes(int dh) { return (size_t)(dh + 8) * sizeof(uint2) + (size_t)PW_ROWS * 256 * 4; }
+
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
 {
-    // One launch per level (level l reads level l-1, :1134).  Measured alternative, not kept: all levels of a frame in one
-    // launch (a 1024-thread workgroup per frame, workgroup barriers between levels) -- 0.66 ms against 0.63 ms per 1024
-    // frames; with an agent-scope fence between the levels (an L2 write-back on this part) 4.8 ms.
+    // One launch per level (level l reads level l-1, :1134).  Measured alternative (on the earlier tile form of the kernel),
+    // not kept: all levels of a frame in one launch (a 1024-thread workgroup per frame, workgroup barriers between
+    // levels) -- 0.66 ms against 0.63 ms per 1024 frames; with an agent-scope fence between the levels (an L2 write-back
+    // on this part) 4.8 ms.
     for (int l = 1; l < a.h_plan->nlevels; ++l) {
         const OrbLevel &D = a.h_plan->lv[l];
         const OrbLevel &S = a.h_plan->lv[l - 1];
@@ -1635,9 +1664,12 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
         pa.dw = D.w; pa.dh = D.h; pa.dpitch = D.pitch;
         pa.xtab = a.d_tabs + D.xtab;
         pa.ytab = a.d_tabs + D.ytab;
-        const int nlanes = ((D.w + 3) / 4) * ((D.h + PY_RB - 1) / PY_RB);
+        const int nb = (D.h + PW_ROWS - 1) / PW_ROWS;
+        pa.rb = (D.h + nb - 1) / nb;               // balanced run length
+        pa.nrblk = (D.h + pa.rb - 1) / pa.rb;      // no empty run
+        const int nlanes = ((D.w + 3) / 4) * pa.nrblk;
         dim3 grid((nlanes + 255) / 256, a.nframes);
-        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(k_pyr_walk, grid, dim3(256), orbk_pyramid_lds_bytes(D.h), st, pa);
     }
     return hipGetLastError();
 }
