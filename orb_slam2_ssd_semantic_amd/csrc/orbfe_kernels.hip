@@ -1478,6 +1478,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     __shared__ float4 s_pat[256];  // (x0, y0, x1, y1) of every test pair as floats
     int b = blockIdx.y, bx = blockIdx.x;
     xcd_frame_remap(bx, b);
+    b = __builtin_amdgcn_readfirstlane(b);  // workgroup-uniform: frame offsets are scalar 64-bit products
+    bx = __builtin_amdgcn_readfirstlane(bx);
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = lane & 15, quad = tid >> 4;  // quad 0..15 inside the workgroup = one keypoint
     int32_t cnt[ORBFE_MAX_LEVELS];
@@ -1533,13 +1535,13 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     int m10 = 0, rs15 = 0, m01 = 0;
     {
         const int k = sub & 7, r0 = sub >> 3;
-        const uint8_t *p = img + (int64_t)(y - 15) * pitch + (x - 15) + 4 * k;
+        // 32-bit offsets from 24-bit multiplies (the 32-bit multiply and the 64-bit multiply-add are quarter rate):
+        // rows r0, r0 + 2, ...; the 16th row of the odd lanes (31) is clamped to 30 and not used
+        const uint8_t *p = img + (__umul24((uint32_t)(y - 15 + r0), (uint32_t)pitch) + (uint32_t)(x - 15 + 4 * k));
         uint32_t w[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = min(r0 + 2 * i, 30);
-            w[i] = *(const uint32_t *)(p + (int64_t)row * pitch);  // unaligned dword
-        }
+        for (int i = 0; i < 16; ++i)  // unaligned dwords; explicit 24-bit multiplies (left alone by the compiler)
+            w[i] = *(const uint32_t *)(p + __umul24(i < 15 ? (uint32_t)(2 * i) : (uint32_t)(30 - r0), (uint32_t)pitch));
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = r0 + 2 * i;
@@ -1549,7 +1551,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
                 const uint32_t s1 = __builtin_amdgcn_udot4(w[i], wt.y, 0u, false); // sum I
                 m10 += (int)a;
                 rs15 += (int)s1;
-                m01 += (row - 15) * (int)s1;
+                m01 += __mul24(row - 15, (int)s1);  // |row - 15| <= 15, s1 <= 1020
             }
         }
         m10 -= 15 * rs15;
@@ -1565,19 +1567,24 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     uint8_t *patch = s_patch[quad];
     {
         const int bpitch = L.pitch;
-        const uint8_t *bp = blur + (int64_t)b * blur_fstride + L.off + (int64_t)(y - 18) * bpitch + (x - 18);
+        // uniform base (frame b of the blurred pyramid) + a 32-bit per-lane offset that advances by additions
+        const uint8_t *bbase = blur + (int64_t)b * blur_fstride;
         // dword f = it * 16 + sub of the 37 x 10 dword patch: (row, k) advance by (1, 6) per iteration, with carry
         int row = sub >= 10 ? 1 : 0, kk = sub >= 10 ? sub - 10 : sub;
+        uint32_t go = (uint32_t)L.off + __umul24((uint32_t)(y - 18 + row), (uint32_t)bpitch) + (uint32_t)(x - 18 + 4 * kk);
+        int lo = row * DS_PP + 4 * kk;
         uint32_t v[24];
         int lofs[24];
 #pragma unroll
         for (int it = 0; it < 24; ++it) {
-            const int rr = min(row, DS_PR - 1);
-            v[it] = *(const uint32_t *)(bp + (uint32_t)(rr * bpitch + 4 * kk));  // unaligned dword
-            lofs[it] = row < DS_PR ? row * DS_PP + 4 * kk : -1;
-            kk += 6;
-            row += 1;
-            if (kk >= 10) { kk -= 10; row += 1; }
+            v[it] = *(const uint32_t *)(bbase + go);  // unaligned dword (rows past the patch re-read its last row)
+            lofs[it] = row < DS_PR ? lo : -1;
+            const bool carry = kk >= 4;  // kk + 6 >= 10
+            const int nrow = row + (carry ? 2 : 1);
+            go += (uint32_t)(carry ? -16 : 24) + (nrow < DS_PR ? (carry ? 2u : 1u) * (uint32_t)bpitch : (row < DS_PR - 1 ? (uint32_t)bpitch : 0u));
+            lo += carry ? 2 * DS_PP - 16 : DS_PP + 24;
+            kk += carry ? -4 : 6;
+            row = nrow;
         }
 #pragma unroll
         for (int it = 0; it < 24; ++it)
