@@ -411,7 +411,7 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
 
         def gbs(name):
             return ab[name] * F / (stage_k[name] * 1e-3) / 1e9 if stage_k[name] > 0 else 0.0
-        kname = {"pyramid": "k_pyr_resize (7 launches)", "fast": "k_fast_map", "octree": "k_octree",
+        kname = {"pyramid": "k_pyr_walk (7 launches)", "fast": "k_fast_map", "octree": "k_octree",
                  "blur": "k_blur7", "describe": "k_orient_describe"}
         roof = {"bound": "hbm", "kernel": kname[dom], "achieved": round(gbs(dom), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs(dom) / HBM_PEAK_GBS, 5), "traffic": None,
@@ -455,6 +455,14 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
                     break
                 except Exception:
                     pass
+        try:  # what a plain device copy reaches on this part (tools/hbm_rate.py), next to the 8 TB/s datasheet peak
+            hr = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_rate.json")))
+            roof["hbm_rate_measured"] = {"copy_GBps": round(hr["copy_read_plus_write_TBps"] * 1e3, 1),
+                                         "read_GBps": round(hr["read_only_sum_TBps"] * 1e3, 1),
+                                         "write_GBps": round(hr["write_only_fill_TBps"] * 1e3, 1),
+                                         "source": "profiles/r02_hbm_rate.json (tools/hbm_rate.py, committed file)"}
+        except Exception:
+            pass
         pf_ms = stage_k["pyramid"] + stage_k["fast"]
         pf_gbs = (ab["pyramid"] + ab["fast"]) * F / (pf_ms * 1e-3) / 1e9
         stages = {k: {"ms": round(v, 4), "GBps": round(gbs(k), 2), "frac": round(gbs(k) / HBM_PEAK_GBS, 5)}
