@@ -575,8 +575,8 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
             const uint32_t v01 = pk_max_u16(u01, d01), v23 = pk_max_u16(u23, d23);   // vertical neighbours
             const uint32_t c01 = pk_max_u16(v01, m01), c23 = pk_max_u16(v23, m23);   // column maxima
             // neighbour lanes by DPP wave shifts (lane 0 / 63 read back 0: they have no such neighbour)
-            const uint32_t cL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c23, 0x138, 0xF, 0xF, false);  // wave_shr:1, .hi = column x-1
-            const uint32_t cR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c01, 0x130, 0xF, 0xF, false);  // wave_shl:1, .lo = column x+4
+            const uint32_t cL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c23, 0x138, 0xF, 0xF, true);  // wave_shr:1, .hi = column x-1
+            const uint32_t cR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c01, 0x130, 0xF, 0xF, true);  // wave_shl:1, .lo = column x+4
             const uint32_t l01 = __builtin_amdgcn_alignbit(c01, cL, 16) & lv01;      // columns (x-1, x)
             const uint32_t x12 = __builtin_amdgcn_alignbit(c23, c01, 16);            // columns (x+1, x+2)
             const uint32_t r23 = __builtin_amdgcn_alignbit(cR, c23, 16) & rv23;      // columns (x+3, x+4)
