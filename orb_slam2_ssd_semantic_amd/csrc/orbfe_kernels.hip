@@ -1716,7 +1716,10 @@ hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
     // (every launch has its own tail).
     const OrbPlan &P = *a.h_plan;
     const int nl = P.nlevels;
-    const int cut[4] = {0, std::max(1, nl / 8), std::max(1, nl / 2), nl};
+    // Small batches do not fill the chip: there the launches would only add their latencies (a workgroup's serial
+    // bookkeeping, ~45 us each: single-frame host latency 0.26 -> 0.35 ms), so they take one launch.
+    const bool grouped = a.nframes >= 128;
+    const int cut[4] = {0, grouped ? std::max(1, nl / 8) : nl, grouped ? std::max(1, nl / 2) : nl, nl};
     const int qts[3] = {512, 256, 128};
     for (int gi = 0; gi < 3; ++gi) {
         const int l0 = cut[gi], l1 = std::min(cut[gi + 1], nl);
