@@ -300,8 +300,8 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         L.nfeat = h->feat[l];
         // quadtree roots (src/ORBextractor.cc:545-559)
         L.nini = (int)roundf((float)(maxbx - minb) / (float)(maxby - minb));
-        if (L.nini < 1 || L.nini > 4) {
-            orbfe_set_error("level %d aspect ratio gives %d quadtree roots (supported: 1..4)", l, L.nini);
+        if (L.nini < 1 || L.nini > ORBFE_MAX_ROOTS) {  // 0 roots: the reference divides by zero (:547)
+            orbfe_set_error("level %d aspect ratio gives %d quadtree roots (supported: 1..%d)", l, L.nini, ORBFE_MAX_ROOTS);
             return ORBFE_ERR_SIZE;
         }
         L.hx = (float)(maxbx - minb) / L.nini;
@@ -358,13 +358,13 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     // node arrays: one slot more than the largest list, rounded to 64 (only the sort buffer inside is a power of two)
     const int M = orb_align_up(std::max(max_sel + 1, 64), 64);
     P.node_cap = M;
-    if (orbk_octree_lds_bytes(M, 4, w, ht, P.max_ncells) > 160 * 1024) {
-        orbfe_set_error("nfeatures too large: the quadtree of one level (%d nodes) does not fit the 160 KB LDS "
-                        "(about 1700 features asked of a single level)", max_sel);
-        return ORBFE_ERR_ARG;
-    }
     P.max_nini = 1;
     for (int l = 0; l < nl; ++l) P.max_nini = std::max(P.max_nini, P.lv[l].nini);
+    if (orbk_octree_lds_bytes(M, std::max(4, P.max_nini), w, ht, P.max_ncells) > 160 * 1024) {
+        orbfe_set_error("nfeatures too large: the quadtree of one level (%d nodes, %d roots) does not fit the 160 KB LDS "
+                        "(about 1700 features asked of a single level)", max_sel, P.max_nini);
+        return ORBFE_ERR_ARG;
+    }
     for (int l = 0; l < nl; ++l)
         if (P.lv[l].ncells >= (1 << 16) || P.lv[l].wcell > 63 || P.lv[l].hcell > 63) {
             orbfe_set_error("level %d: %d FAST cells / cell size exceed the 16 + 6 + 6 bit candidate-order key", l, P.lv[l].ncells);

@@ -13,6 +13,7 @@
 #include "orbfe.h"
 
 #define ORBFE_MAX_LEVELS 16
+#define ORBFE_MAX_ROOTS 8   // quadtree roots of a level = round(width / height) of its detection window (:545)
 #define ORBFE_EDGE 19        // EDGE_THRESHOLD   (reference src/ORBextractor.cc:54)
 #define ORBFE_HALF_PATCH 15  // HALF_PATCH_SIZE  (:53)
 #define ORBFE_PATCH 31       // PATCH_SIZE       (:52)
@@ -55,7 +56,7 @@ struct OrbLevel {
     int32_t xtab, ytab;    // offsets into the resize tables (entries), level >= 1
     float scale;           // mvScaleFactor[l]
     float patch_size;      // (float)(int)(PATCH_SIZE * scale)  (:846)
-    int32_t root_x[5];     // root box x boundaries, nini+1 entries (nini <= 4)
+    int32_t root_x[ORBFE_MAX_ROOTS + 1];  // root box x boundaries, nini+1 entries
     int32_t ix1, iy1;      // end of the union of the cells' detectable interiors ([19,ix1) x [19,iy1))
 };
 
