@@ -2,13 +2,13 @@
 //
 // Reference behaviour restated (paths relative to /root/reference):
 //   K1 k_pyr_walk        ComputePyramid + cv::resize INTER_LINEAR   src/ORBextractor.cc:1117-1145
-//   K2 k_fast_cells      per-cell cv::FAST + NMS + minTh fallback   src/ORBextractor.cc:798-838
+//   K2 k_fast_map        per-cell cv::FAST + NMS + minTh fallback   src/ORBextractor.cc:798-838
 //   K3 k_octree          DistributeOctTree / DivideNode             src/ORBextractor.cc:478-765
 //   K4 k_blur7           GaussianBlur 7x7 sigma 2 REFLECT_101       src/ORBextractor.cc:1094-1095
 //   K5 k_orient_describe IC_Angle + computeOrbDescriptor + rescale  src/ORBextractor.cc:59-131, 846-857, 1103-1110
 //
-// Integer / byte work bounded by HBM and LDS, no MFMA.  Float steps that decide an output bit use
-// explicitly rounded single operations (__fmul_rn/__fadd_rn/__fdiv_rn, no FMA contraction).
+// Integer / byte work bounded by VALU issue (FAST), HBM (pyramid, blur) and LDS latency (quadtree); no MFMA.  Float steps
+// that decide an output bit use explicitly rounded single operations (__fmul_rn/__fadd_rn/__fdiv_rn, no FMA contraction).
 #include <stdlib.h>
 #include <algorithm>
 
