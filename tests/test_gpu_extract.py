@@ -358,3 +358,41 @@ def test_hip_path_equals_the_compiled_reference_directly():
             gk = kps[i, :n[i]].copy().view(KP_DTYPE).reshape(-1)
             assert n[i] == len(rk), (nf, i)
             assert np.array_equal(gk.view(np.uint8), rk.view(np.uint8)) and np.array_equal(desc[i, :n[i]], rd), (nf, i)
+
+
+def test_side_stream_blur_and_grouped_quadtree_equal_the_inline_single_launch_path(oracle, monkeypatch):
+    """Batches of >= 128 frames run the blur on the handle's side stream next to the quadtree and launch the quadtree per
+    level group; smaller batches (and ORBFE_OVERLAP=0) keep one stream / one launch.  All of it must be invisible:
+    136 frames through the large-batch path == the same frames in chunks of 8 through the small-batch path == ORBFE_OVERLAP=0,
+    and a sample of them == the oracle."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE, ORBextractor
+    w, h, B = 640, 480, 136
+    frames = np.stack([synth_frame(4000 + i, h, w, sparse=(i % 2 == 1)) for i in range(B)])
+    dg = torch.from_numpy(frames).cuda()
+
+    def run(chunk, env):
+        if env is None:
+            monkeypatch.delenv("ORBFE_OVERLAP", raising=False)
+        else:
+            monkeypatch.setenv("ORBFE_OVERLAP", env)
+        e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=chunk)
+        cap = e.capacity()
+        dk = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
+        dd = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        dn = torch.zeros(B, dtype=torch.int32, device="cuda")
+        for i in range(0, B, chunk):
+            e.extract_batch_device(dg[i:].data_ptr(), min(chunk, B - i), w, h, w, w * h, dk[i:].data_ptr(), dd[i:].data_ptr(), cap,
+                                   dn[i:].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert e.overflow() == 0
+        return dn.cpu().numpy(), dk.cpu().numpy(), dd.cpu().numpy()
+
+    n0, k0, d0 = run(B, None)
+    for chunk, env in ((8, None), (B, "0"), (B, "1")):
+        n1, k1, d1 = run(chunk, env)
+        assert np.array_equal(n0, n1) and np.array_equal(k0, k1) and np.array_equal(d0, d1), (chunk, env)
+    oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    for i in (0, 67, 135):
+        ok, od = oe(frames[i], cap=1200)
+        assert_same_output(k0[i, :n0[i]].copy().view(KP_DTYPE).reshape(-1), d0[i, :n0[i]], ok, od)
