@@ -504,6 +504,7 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
 
     if world == 1:
         result["bow_chain"] = bow_leg(args, local_rank)
+        result["stereo_chain"] = stereo_leg(args, local_rank)
         result["host_api"] = host_api_leg(args, local_rank, d_gray[:F])
 
     if world == 1 and not args.no_cpu_baseline:
@@ -668,6 +669,77 @@ def host_api_leg(args, local_rank, d_src, nframes=8192, chunk=512):
     dt = (time.perf_counter() - t) / reps
     return {"frames_per_s": round(nframes / dt, 1), "frames_per_call": nframes, "chunk": chunk, "mean_keypoints": round(float(pn.float().mean()), 1),
             "what": "orbfe_extract_batch on page-locked host frames / outputs (extract only; the pipeline is inside liborbfe.so)"}
+
+
+def stereo_leg(args, local_rank, npairs=256, steps=10, warmup=3):
+    """The stereo Frame constructor as a device-resident chain (src/Frame.cc:58-116): left and right images of `npairs`
+    stereo pairs through two batched extractor calls, then Frame::ComputeStereoMatches for every pair on their output
+    blocks (orbfe_stereo_matches_batch_device), one stream, nothing leaves HBM.  Right image = left image shifted by a
+    disparity that grows towards the bottom, plus noise.  CPU side: the oracle's stereo matcher on one pair."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor, ORBmatcher
+    w, h, nf = args.width, args.height, args.nfeatures
+    stream = torch.cuda.current_stream().cuda_stream
+    gl = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=npairs, device=local_rank)
+    gr = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=npairs, device=local_rank)
+    mat = ORBmatcher(0.9, True, device=local_rank)
+    cap = gl.capacity()
+    left = expand_frames(torch.from_numpy(base_frames("S", 32, w, h, 50000)).cuda(), npairs)
+    disp = 4 + (20 * torch.arange(h, device="cuda")) // h                       # per row
+    idx = (torch.arange(w, device="cuda")[None, :] + disp[:, None]) % w        # right[y, x] = left[y, x + d(y)]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    right = torch.gather(left, 2, idx[None].expand(npairs, h, w))
+    right = (right.to(torch.int16) + torch.randint(-3, 4, right.shape, device="cuda", generator=g, dtype=torch.int16)).clamp(0, 255).to(torch.uint8)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")  # noqa: E731
+    oL = (z((npairs, cap, 7), torch.int32), z((npairs, cap, 32), torch.uint8), z(npairs, torch.int32))
+    oR = (z((npairs, cap, 7), torch.int32), z((npairs, cap, 32), torch.uint8), z(npairs, torch.int32))
+    du, dz = z((npairs, cap), torch.float32), z((npairs, cap), torch.float32)
+    mbf, mb = 40.0, 0.08
+
+    def extract():
+        gl.extract_batch_device(left.data_ptr(), npairs, w, h, w, w * h, oL[0].data_ptr(), oL[1].data_ptr(), cap, oL[2].data_ptr(), stream)
+        gr.extract_batch_device(right.data_ptr(), npairs, w, h, w, w * h, oR[0].data_ptr(), oR[1].data_ptr(), cap, oR[2].data_ptr(), stream)
+
+    def stereo():
+        mat.ComputeStereoMatches_batch_device(gl, gr, oL[0].data_ptr(), oL[1].data_ptr(), oL[2].data_ptr(), oR[0].data_ptr(), oR[1].data_ptr(),
+                                              oR[2].data_ptr(), cap, npairs, mbf, mb, du.data_ptr(), dz.data_ptr(), stream)
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    t_ex = timed(extract)
+    t_st = timed(stereo)
+    nL = oL[2].cpu().numpy()
+    u = du.cpu().numpy()
+    matched = float(np.mean([(u[i, :nL[i]] >= 0).sum() for i in range(npairs)]))
+    out = {"pairs": npairs, "features_per_image": round(float(nL.mean()), 1), "mean_stereo_matches_per_pair": round(matched, 1),
+           "extract_left_right_ms_per_batch": round(t_ex, 4), "stereo_matches_ms_per_batch": round(t_st, 4),
+           "stereo_matches_us_per_pair": round(t_st * 1e3 / npairs, 3),
+           "stereo_pairs_per_s": round(npairs / ((t_ex + t_st) * 1e-3), 1)}
+    if not args.no_cpu_baseline:
+        from oracle import oracle_ffi as O
+        from orb_slam2_ssd_semantic_amd import KP_DTYPE
+        l0, r0 = left[0].cpu().numpy(), right[0].cpu().numpy()
+        exL, exR = O.OracleExtractor(nf, 1.2, 8, 20, 7), O.OracleExtractor(nf, 1.2, 8, 20, 7)
+        kL, dL = exL(l0)
+        kR, dR = exR(r0)
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            ru, rd, _ = O.stereo_matches(exL, exR, kL, dL, kR, dR, mbf, mb)
+        out["cpu_oracle_stereo_matches_us_per_pair"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+        out["pair0_equals_oracle"] = bool(np.array_equal(u[0, :nL[0]].view(np.uint32), ru.view(np.uint32)) and nL[0] == len(kL)
+                                          and np.array_equal(oL[0][0, :nL[0]].cpu().numpy().copy().view(KP_DTYPE).reshape(-1).view(np.uint8), kL.view(np.uint8)))
+    return out
 
 
 def bow_leg(args, local_rank, npairs=256, steps=10, warmup=3, standalone=False):

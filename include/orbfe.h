@@ -292,6 +292,18 @@ orbfe_status orbfe_stereo_matches(orbfe_matcher *m, orbfe_handle *left, orbfe_ha
                                   const uint8_t *descL, int32_t nL, const orbfe_keypoint *kpsR, const uint8_t *descR,
                                   int32_t nR, float mbf, float mb, float *uRight, float *depth);
 
+/* The same for a whole batch, without leaving the device: frame pair f = frame f of the LAST orbfe_extract_batch_device
+ * call of `left` and of `right` (the stereo Frame constructor runs the two extractors side by side, src/Frame.cc:82-87),
+ * their output blocks exactly as those calls wrote them -- d_kps* [nframes][cap], d_desc* [nframes][cap][32], d_n*
+ * [nframes] -- and d_uRight / d_depth [nframes][cap] floats (slots >= the frame's count are left untouched).  Everything
+ * is enqueued on `stream` (the stream the two extract calls ran on, or one ordered after it); d_gray of both calls must
+ * still be alive.  No host synchronisation. */
+orbfe_status orbfe_stereo_matches_batch_device(orbfe_matcher *m, orbfe_handle *left, orbfe_handle *right,
+                                               const orbfe_keypoint *d_kpsL, const uint8_t *d_descL, const int32_t *d_nL,
+                                               const orbfe_keypoint *d_kpsR, const uint8_t *d_descR, const int32_t *d_nR,
+                                               int32_t cap, int32_t nframes, float mbf, float mb, float *d_uRight,
+                                               float *d_depth, void *stream);
+
 /* DBoW2 TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) as called by
  * Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:553, src/KeyFrame.cc:82; levelsup = 4).  DBoW2 is not vendored
  * by the reference; the algorithm is restated from the published one.  The tree is handed over as arrays:

@@ -1111,7 +1111,9 @@ int32_t orbfe_internal_pyramid_view(orbfe_handle *h, int frame, OrbPyrView *v)
         v->h[l] = L.h;
         v->scale[l] = h->scale[l];
         v->inv_scale[l] = h->inv_scale[l];
+        v->fstride[l] = l == 0 ? h->last_gray_fstride : (int64_t)h->plan.pyr_frame_bytes;
     }
+    v->nframes = h->last_nframes;
     return ORBFE_OK;
 }
 

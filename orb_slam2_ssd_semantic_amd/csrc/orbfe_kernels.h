@@ -53,6 +53,8 @@ struct OrbPyrView {
     const uint8_t *ptr[ORBFE_MAX_LEVELS];
     int32_t pitch[ORBFE_MAX_LEVELS], w[ORBFE_MAX_LEVELS], h[ORBFE_MAX_LEVELS];
     float scale[ORBFE_MAX_LEVELS], inv_scale[ORBFE_MAX_LEVELS];
+    int64_t fstride[ORBFE_MAX_LEVELS];  // bytes from a level of one frame of the batch to the same level of the next
+    int32_t nframes;                    // frames in the handle's last batch
 };
 struct orbfe_handle;
 // fills `v` for frame `frame` of the last batch and waits for the handle's own stream; ORBFE_ERR_STATE before any call

@@ -1261,14 +1261,26 @@ struct StereoArgs {
     float mbf, mb;
 };
 
+// Batched form: grid.y = frame pair f of the two extractors' last batches; keypoints / descriptors / results of frame f
+// start at slot f * cap and the counts come from the extractors' own count arrays (d_nL / d_nR, clamped to cap).  The
+// single-pair host entry point passes cap = 0 and null count arrays.
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a, const orbfe_keypoint *__restrict__ kpsL,
                                                       const uint8_t *__restrict__ descL, int nL,
                                                       const orbfe_keypoint *__restrict__ kpsR,
                                                       const uint8_t *__restrict__ descR, int nR,
                                                       float *__restrict__ uRight, float *__restrict__ depth,
-                                                      int32_t *__restrict__ sad)
+                                                      int32_t *__restrict__ sad, int cap,
+                                                      const int32_t *__restrict__ d_nL, const int32_t *__restrict__ d_nR)
 {
     const int lane = threadIdx.x & 63;
+    const int f = blockIdx.y;
+    if (d_nL) {
+        nL = min(d_nL[f], cap);
+        nR = min(d_nR[f], cap);
+        const int64_t o = (int64_t)f * cap;
+        kpsL += o; descL += o * 32; kpsR += o; descR += o * 32;
+        uRight += o; depth += o; sad += o;
+    }
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (iL >= nL) return;
     const orbfe_keypoint kL = kpsL[iL];
@@ -1276,6 +1288,10 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a, const orbfe_
     const float uL = kL.x, vL = kL.y;
     float out_u = -1.0f, out_d = -1.0f;
     int out_sad = -1;
+    if ((unsigned)levelL >= (unsigned)a.L.nlevels) {  // not an extractor output: no match (the host entry point rejects it)
+        if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; sad[iL] = -1; }
+        return;
+    }
     const float minD = 0.f, maxD = __fdiv_rn(a.mbf, a.mb);
     const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
     const int rowL = (int)vL;
@@ -1289,6 +1305,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a, const orbfe_
         }
         for (int iR = lane; iR < nR; iR += 64) {
             const orbfe_keypoint kR = kpsR[iR];
+            if ((unsigned)kR.octave >= (unsigned)a.R.nlevels) continue;
             const float r = __fmul_rn(2.0f, a.R.scale[kR.octave]);
             const int maxr = (int)ceilf(__fadd_rn(kR.y, r)), minr = (int)floorf(__fsub_rn(kR.y, r));
             if (rowL < minr || rowL > maxr) continue;
@@ -1311,7 +1328,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a, const orbfe_
         const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)Ls), (float)w);
         const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)Ls), (float)w), 1.0f);
         if (!(iniu < 0 || endu >= (float)a.R.w[levelL])) {
-            const uint8_t *imL = a.L.ptr[levelL], *imR = a.R.ptr[levelL];
+            const uint8_t *imL = a.L.ptr[levelL] + f * a.L.fstride[levelL], *imR = a.R.ptr[levelL] + f * a.R.fstride[levelL];
             const int pl = a.L.pitch[levelL], pr = a.R.pitch[levelL];
             const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
             const int cl = imL[cv * pl + cu];
@@ -1366,10 +1383,16 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a, const orbfe_
 }
 
 __global__ __launch_bounds__(1024) void k_stereo_filter(int nL, float *__restrict__ uRight, float *__restrict__ depth,
-                                                        const int32_t *__restrict__ sad)
+                                                        const int32_t *__restrict__ sad, int cap,
+                                                        const int32_t *__restrict__ d_nL)
 {
     __shared__ int s_n, s_median;
     const int tid = threadIdx.x;
+    if (d_nL) {  // batched: one workgroup per frame pair
+        nL = min(d_nL[blockIdx.x], cap);
+        const int64_t o = (int64_t)blockIdx.x * cap;
+        uRight += o; depth += o; sad += o;
+    }
     if (tid == 0) { s_n = 0; s_median = -1; }
     __syncthreads();
     int cnt = 0;
@@ -1443,13 +1466,54 @@ extern "C" orbfe_status orbfe_stereo_matches(orbfe_matcher *m, orbfe_handle *lef
     }
     hipLaunchKernelGGL(k_stereo_match, dim3((nL + 3) / 4), dim3(256), 0, st, a, (const orbfe_keypoint *)m->b[0].p,
                        (const uint8_t *)m->b[1].p, nL, (const orbfe_keypoint *)m->b[2].p, (const uint8_t *)m->b[3].p, nR,
-                       (float *)m->b[4].p, (float *)m->b[5].p, (int32_t *)m->b[6].p);
+                       (float *)m->b[4].p, (float *)m->b[5].p, (int32_t *)m->b[6].p, 0, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr);
     hipLaunchKernelGGL(k_stereo_filter, dim3(1), dim3(1024), 0, st, nL, (float *)m->b[4].p, (float *)m->b[5].p,
-                       (const int32_t *)m->b[6].p);
+                       (const int32_t *)m->b[6].p, 0, (const int32_t *)nullptr);
     ORBFE_HIP(hipGetLastError());
     ORBFE_HIP(hipMemcpyAsync(uRight, m->b[4].p, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipMemcpyAsync(depth, m->b[5].p, (size_t)nL * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipStreamSynchronize(st));
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_stereo_matches_batch_device(orbfe_matcher *m, orbfe_handle *left, orbfe_handle *right,
+                                                          const orbfe_keypoint *d_kpsL, const uint8_t *d_descL,
+                                                          const int32_t *d_nL, const orbfe_keypoint *d_kpsR,
+                                                          const uint8_t *d_descR, const int32_t *d_nR, int32_t cap,
+                                                          int32_t nframes, float mbf, float mb, float *d_uRight,
+                                                          float *d_depth, void *stream)
+{
+    if (!m || !left || !right || nframes < 0 || cap < 0 || cap >= (1 << 20) ||
+        (nframes > 0 && cap > 0 && (!d_kpsL || !d_descL || !d_nL || !d_kpsR || !d_descR || !d_nR || !d_uRight || !d_depth))) {
+        orbfe_set_error("bad argument to orbfe_stereo_matches_batch_device");
+        return ORBFE_ERR_ARG;
+    }
+    if (nframes == 0 || cap == 0) return ORBFE_OK;
+    StereoArgs a;
+    orbfe_status s = (orbfe_status)orbfe_internal_pyramid_view(left, 0, &a.L);
+    if (s != ORBFE_OK) return s;
+    s = (orbfe_status)orbfe_internal_pyramid_view(right, 0, &a.R);
+    if (s != ORBFE_OK) return s;
+    if (a.L.device != m->device || a.R.device != m->device || a.L.nlevels != a.R.nlevels) {
+        orbfe_set_error("stereo: the two extractors and the matcher must share a device and a pyramid shape");
+        return ORBFE_ERR_ARG;
+    }
+    if (nframes > a.L.nframes || nframes > a.R.nframes) {
+        orbfe_set_error("stereo: %d frame pairs asked, the extractors' last batches hold %d / %d frames", nframes, a.L.nframes,
+                        a.R.nframes);
+        return ORBFE_ERR_ARG;
+    }
+    a.mbf = mbf;
+    a.mb = mb;
+    MDeviceGuard g(m->device);
+    hipStream_t st = (hipStream_t)stream;
+    ORBFE_HIP(m->b[6].ensure((size_t)nframes * cap * 4));  // SAD distances of the kept matches, read by the filter
+    hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, nframes), dim3(256), 0, st, a, d_kpsL, d_descL, 0, d_kpsR, d_descR, 0,
+                       d_uRight, d_depth, (int32_t *)m->b[6].p, cap, d_nL, d_nR);
+    hipLaunchKernelGGL(k_stereo_filter, dim3(nframes), dim3(1024), 0, st, 0, d_uRight, d_depth, (const int32_t *)m->b[6].p, cap,
+                       d_nL);
+    ORBFE_HIP(hipGetLastError());
     return ORBFE_OK;
 }
 

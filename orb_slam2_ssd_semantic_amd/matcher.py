@@ -157,6 +157,15 @@ class ORBmatcher:
         check(st, "orbfe_stereo_matches")
         return u[:n].copy(), d[:n].copy()
 
+    def ComputeStereoMatches_batch_device(self, extractorLeft, extractorRight, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, cap,
+                                          nframes, mbf, mb, d_uRight, d_depth, stream=None):
+        """Frame::ComputeStereoMatches for every frame pair of the two extractors' last device batches; all arguments are
+        device pointers (ints) to the blocks those calls wrote; results [nframes][cap] floats on `stream`."""
+        st = self._L.orbfe_stereo_matches_batch_device(self._m, extractorLeft.handle, extractorRight.handle, d_kpsL, d_descL, d_nL,
+                                                       d_kpsR, d_descR, d_nR, int(cap), int(nframes), float(mbf), float(mb),
+                                                       d_uRight, d_depth, stream)
+        check(st, "orbfe_stereo_matches_batch_device")
+
     def ComputeDistinctiveDescriptors(self, pool, off, idx):
         """SURVEY 8(f).4: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) for a batch of map points.
         pool: descriptors; map point p observes pool[idx[off[p]:off[p+1]]].  Returns (best position inside the

@@ -72,3 +72,50 @@ def test_gpu_stereo_no_matches(oracle):
     ru, rd, _ = oracle.stereo_matches(exL, exR, okL, odL, okR, odR, 40.0, 0.08)
     u, d = ORBmatcher(0.9, True).ComputeStereoMatches(gl, gr, kL, dL, kR, dR, 40.0, 0.08)
     assert np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_stereo_batch_device_chain(oracle):
+    """Device-resident chain: two batched extractor calls (left / right images of 10 stereo pairs, one of them an unrelated
+    pair) and orbfe_stereo_matches_batch_device on their output blocks, on one stream, no host buffer in between; every
+    frame pair against the oracle chain (mvuRight / mvDepth bit patterns)."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE, ORBextractor, ORBmatcher
+    w, h, B = 640, 480, 10
+    pairs = [stereo_pair(20 + i) for i in range(B)]
+    pairs[4] = (synth_frame(8, h, w), synth_frame(9, h, w))
+    L = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    R = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    gl = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    gr = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    cap = gl.capacity()
+    out = {}
+    st = torch.cuda.current_stream().cuda_stream
+    for name, e, img in (("L", gl, L), ("R", gr, R)):
+        dk = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
+        dd = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        dn = torch.zeros(B, dtype=torch.int32, device="cuda")
+        e.extract_batch_device(img.data_ptr(), B, w, h, w, w * h, dk.data_ptr(), dd.data_ptr(), cap, dn.data_ptr(), st)
+        out[name] = (dk, dd, dn)
+    du = torch.full((B, cap), 7.0, dtype=torch.float32, device="cuda")
+    dz = torch.full((B, cap), 7.0, dtype=torch.float32, device="cuda")
+    mbf, mb = 40.0, 0.08
+    ORBmatcher(0.9, True).ComputeStereoMatches_batch_device(gl, gr, out["L"][0].data_ptr(), out["L"][1].data_ptr(), out["L"][2].data_ptr(),
+                                                            out["R"][0].data_ptr(), out["R"][1].data_ptr(), out["R"][2].data_ptr(), cap, B,
+                                                            mbf, mb, du.data_ptr(), dz.data_ptr(), st)
+    torch.cuda.synchronize()
+    nL = out["L"][2].cpu().numpy()
+    u, z = du.cpu().numpy(), dz.cpu().numpy()
+    total = 0
+    for i, (left, right) in enumerate(pairs):
+        exL, exR = oracle.OracleExtractor(), oracle.OracleExtractor()
+        kL, dL = exL(left)
+        kR, dR = exR(right)
+        assert nL[i] == len(kL)
+        assert np.array_equal(out["L"][0][i, :nL[i]].cpu().numpy().copy().view(KP_DTYPE).reshape(-1).view(np.uint8), kL.view(np.uint8))
+        ru, rd, _ = oracle.stereo_matches(exL, exR, kL, dL, kR, dR, mbf, mb)
+        assert np.array_equal(u[i, :nL[i]].view(np.uint32), ru.view(np.uint32)), i
+        assert np.array_equal(z[i, :nL[i]].view(np.uint32), rd.view(np.uint32)), i
+        assert np.all(u[i, nL[i]:] == 7.0) and np.all(z[i, nL[i]:] == 7.0)   # slots past the count are not touched
+        total += int((ru >= 0).sum())
+    assert total > 1000
