@@ -271,6 +271,14 @@ orbfe_status orbfe_hamming_csr_device(orbfe_matcher *m, const uint8_t *d_q, int3
 #define ORBFE_GRID_ROWS 48 /* FRAME_GRID_ROWS include/Frame.h:25 */
 orbfe_status orbfe_assign_grid(orbfe_matcher *m, const float *xy, int32_t n, float minx, float miny, float gw_inv,
                                float gh_inv, uint32_t *cell_off, uint32_t *cell_idx, int32_t *n_in_grid);
+/* AssignFeaturesToGrid for every frame of an extractor output block, device-resident: frame f's keypoints are
+ * d_kps[f * cap .. f * cap + d_n[f]) as orbfe_extract_batch_device wrote them (mvKeysUn == mvKeys: no lens distortion, as
+ * for TUM fr3); d_cell_off [nframes][ORBFE_GRID_COLS * ORBFE_GRID_ROWS + 1], d_cell_idx [nframes][cap], d_n_in_grid
+ * [nframes].  Enqueued on `stream`, no host synchronisation. */
+orbfe_status orbfe_assign_grid_batch_device(orbfe_matcher *m, const orbfe_keypoint *d_kps, const int32_t *d_n, int32_t cap,
+                                            int32_t nframes, float minx, float miny, float gw_inv, float gh_inv,
+                                            uint32_t *d_cell_off, uint32_t *d_cell_idx, int32_t *d_n_in_grid, void *stream);
+
 /* Frame::GetFeaturesInArea (src/Frame.cc:465-518) for a batch of nq queries (x, y, r, minLevel, maxLevel):
  *   qxyr[nq*3], qlevels[nq*2] (may be NULL = -1,-1);  octave[n] = mvKeysUn[i].octave
  *   off[nq+1], cand[cap]: per query the keypoint indices in the reference's iteration order (ix, iy, cell order).

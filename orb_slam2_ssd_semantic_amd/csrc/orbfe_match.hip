@@ -938,17 +938,29 @@ __device__ __forceinline__ int grid_cell_of(float x, float y, float minx, float 
 
 // one workgroup: histogram over the 3072 cells (LDS), scan, placement, then each cell's short list is put into
 // ascending keypoint order (the reference push_backs in keypoint order)
+// xs = floats between consecutive points (2 for packed (x, y), 7 for orbfe_keypoint records).  Batched form (d_n != null):
+// workgroup f takes frame f of an extractor output block -- points at f * cap * xs, count d_n[f] -- and writes its own
+// cell_off [GRID_NC + 1], cell_idx [cap] and n_in.
 __global__ __launch_bounds__(1024) void k_assign_grid(const float *__restrict__ xy, int n, float minx, float miny, float gwi,
                                                       float ghi, uint32_t *__restrict__ cell_off,
-                                                      uint32_t *__restrict__ cell_idx, int32_t *__restrict__ n_in)
+                                                      uint32_t *__restrict__ cell_idx, int32_t *__restrict__ n_in, int xs,
+                                                      int cap, const int32_t *__restrict__ d_n)
 {
     __shared__ uint32_t s_cnt[GRID_NC], s_off[GRID_NC + 1];
     __shared__ uint32_t s_part[1024];
     const int tid = threadIdx.x;
+    if (d_n) {
+        const int f = blockIdx.x;
+        n = min(d_n[f], cap);
+        xy += (int64_t)f * cap * xs;
+        cell_off += (int64_t)f * (GRID_NC + 1);
+        cell_idx += (int64_t)f * cap;
+        n_in += f;
+    }
     for (int c = tid; c < GRID_NC; c += 1024) s_cnt[c] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
-        const int c = grid_cell_of(xy[2 * i], xy[2 * i + 1], minx, miny, gwi, ghi);
+        const int c = grid_cell_of(xy[(int64_t)xs * i], xy[(int64_t)xs * i + 1], minx, miny, gwi, ghi);
         if (c >= 0) atomicAdd(&s_cnt[c], 1u);
     }
     __syncthreads();
@@ -972,7 +984,7 @@ __global__ __launch_bounds__(1024) void k_assign_grid(const float *__restrict__ 
     for (int c = tid; c < GRID_NC; c += 1024) s_cnt[c] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
-        const int c = grid_cell_of(xy[2 * i], xy[2 * i + 1], minx, miny, gwi, ghi);
+        const int c = grid_cell_of(xy[(int64_t)xs * i], xy[(int64_t)xs * i + 1], minx, miny, gwi, ghi);
         if (c >= 0) cell_idx[s_off[c] + atomicAdd(&s_cnt[c], 1u)] = (uint32_t)i;
     }
     __syncthreads();
@@ -1093,7 +1105,7 @@ extern "C" orbfe_status orbfe_assign_grid(orbfe_matcher *m, const float *xy, int
     ORBFE_HIP(m->b[3].ensure(4));
     if (n > 0) ORBFE_HIP(hipMemcpyAsync(m->b[0].p, xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_assign_grid, dim3(1), dim3(1024), 0, st, (const float *)m->b[0].p, n, minx, miny, gw_inv, gh_inv,
-                       (uint32_t *)m->b[1].p, (uint32_t *)m->b[2].p, (int32_t *)m->b[3].p);
+                       (uint32_t *)m->b[1].p, (uint32_t *)m->b[2].p, (int32_t *)m->b[3].p, 2, 0, (const int32_t *)nullptr);
     ORBFE_HIP(hipGetLastError());
     int32_t nin = 0;
     ORBFE_HIP(hipMemcpyAsync(cell_off, m->b[1].p, (size_t)(GRID_NC + 1) * 4, hipMemcpyDeviceToHost, st));
@@ -1101,6 +1113,24 @@ extern "C" orbfe_status orbfe_assign_grid(orbfe_matcher *m, const float *xy, int
     ORBFE_HIP(hipStreamSynchronize(st));
     if (nin > 0) ORBFE_HIP(hipMemcpy(cell_idx, m->b[2].p, (size_t)nin * 4, hipMemcpyDeviceToHost));
     if (n_in_grid) *n_in_grid = nin;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_assign_grid_batch_device(orbfe_matcher *m, const orbfe_keypoint *d_kps, const int32_t *d_n,
+                                                       int32_t cap, int32_t nframes, float minx, float miny, float gw_inv,
+                                                       float gh_inv, uint32_t *d_cell_off, uint32_t *d_cell_idx,
+                                                       int32_t *d_n_in_grid, void *stream)
+{
+    if (!m || nframes < 0 || cap < 0 || (nframes > 0 && (!d_kps || !d_n || !d_cell_off || !d_cell_idx || !d_n_in_grid))) {
+        orbfe_set_error("bad argument to orbfe_assign_grid_batch_device");
+        return ORBFE_ERR_ARG;
+    }
+    if (nframes == 0) return ORBFE_OK;
+    MDeviceGuard g(m->device);
+    static_assert(sizeof(orbfe_keypoint) == 7 * sizeof(float), "keypoint record = 7 floats, (x, y) first");
+    hipLaunchKernelGGL(k_assign_grid, dim3(nframes), dim3(1024), 0, (hipStream_t)stream, (const float *)d_kps, 0, minx, miny, gw_inv,
+                       gh_inv, d_cell_off, d_cell_idx, d_n_in_grid, 7, cap, d_n);
+    ORBFE_HIP(hipGetLastError());
     return ORBFE_OK;
 }
 

@@ -157,6 +157,13 @@ class ORBmatcher:
         check(st, "orbfe_stereo_matches")
         return u[:n].copy(), d[:n].copy()
 
+    def AssignFeaturesToGrid_batch_device(self, d_kps, d_n, cap, nframes, minx, miny, gw_inv, gh_inv, d_cell_off, d_cell_idx,
+                                          d_n_in_grid, stream=None):
+        """Frame::AssignFeaturesToGrid for every frame of an extractor output block (device pointers as ints)."""
+        check(self._L.orbfe_assign_grid_batch_device(self._m, d_kps, d_n, int(cap), int(nframes), float(minx), float(miny),
+                                                     float(gw_inv), float(gh_inv), d_cell_off, d_cell_idx, d_n_in_grid, stream),
+              "orbfe_assign_grid_batch_device")
+
     def ComputeStereoMatches_batch_device(self, extractorLeft, extractorRight, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, cap,
                                           nframes, mbf, mb, d_uRight, d_depth, stream=None):
         """Frame::ComputeStereoMatches for every frame pair of the two extractors' last device batches; all arguments are
