@@ -339,6 +339,13 @@ orbfe_status orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocabulary *v, co
 orbfe_status orbfe_distinctive_descriptors(orbfe_matcher *m, const uint8_t *pool, int32_t npool, const uint32_t *off,
                                            const uint32_t *idx, int32_t npoints, int32_t *best_idx, int32_t *median);
 
+/* The same on device buffers (the pool is typically the all-gathered descriptor block of the keyframes: observation index
+ * = keyframe * cap + slot): nothing is validated or copied, the launch goes to `stream`.  max_obs (1..1024) sizes the
+ * kernel's LDS; a point with more observations than that gets -2 / -2 instead of a result. */
+orbfe_status orbfe_distinctive_descriptors_device(orbfe_matcher *m, const uint8_t *d_pool, const uint32_t *d_off,
+                                                  const uint32_t *d_idx, int32_t npoints, int32_t max_obs,
+                                                  int32_t *d_best_idx, int32_t *d_median, void *stream);
+
 /* ---- the same chain DEVICE-RESIDENT and BATCHED: extractor output block -> BoW -> SearchByBoW, one stream, no host
  * round trip (Frame::ComputeBoW src/Frame.cc:546-555 / KeyFrame::ComputeBoW src/KeyFrame.cc:74-84, then
  * ORBmatcher::SearchByBoW src/ORBmatcher.cc:217-363 / :665-812 for a batch of (KeyFrame, Frame) pairs).

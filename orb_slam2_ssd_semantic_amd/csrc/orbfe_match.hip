@@ -1192,14 +1192,14 @@ extern "C" orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy
 
 __global__ __launch_bounds__(64) void k_distinctive(const uint8_t *__restrict__ pool, const uint32_t *__restrict__ off,
                                                     const uint32_t *__restrict__ idx, int32_t *__restrict__ best_idx,
-                                                    int32_t *__restrict__ median)
+                                                    int32_t *__restrict__ median, int max_obs)
 {
-    extern __shared__ uint4 s_obs[];  // [n][2]
+    extern __shared__ uint4 s_obs[];  // [max_obs][2]
     const int p = blockIdx.x, lane = threadIdx.x;
     const uint32_t o0 = off[p];
     const int n = (int)(off[p + 1] - o0);
-    if (n <= 0) {
-        if (lane == 0) { best_idx[p] = -1; median[p] = -1; }
+    if (n <= 0 || n > max_obs) {  // no observation: -1; more than the LDS was sized for (device entry point only): -2
+        if (lane == 0) { best_idx[p] = n <= 0 ? -1 : -2; median[p] = n <= 0 ? -1 : -2; }
         return;
     }
     for (int t = lane; t < 2 * n; t += 64) s_obs[t] = ((const uint4 *)pool)[(size_t)idx[o0 + (t >> 1)] * 2 + (t & 1)];
@@ -1268,11 +1268,27 @@ extern "C" orbfe_status orbfe_distinctive_descriptors(orbfe_matcher *m, const ui
     if (nc > 0) ORBFE_HIP(hipMemcpyAsync(m->b[3].p, idx, nc * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_distinctive, dim3(npoints), dim3(64), (size_t)std::max(maxn, 1u) * 32, st,
                        (const uint8_t *)m->b[0].p, (const uint32_t *)m->b[2].p, (const uint32_t *)m->b[3].p,
-                       (int32_t *)m->b[4].p, (int32_t *)m->b[5].p);
+                       (int32_t *)m->b[4].p, (int32_t *)m->b[5].p, (int)std::max(maxn, 1u));
     ORBFE_HIP(hipGetLastError());
     ORBFE_HIP(hipMemcpyAsync(best_idx, m->b[4].p, (size_t)npoints * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipMemcpyAsync(median, m->b[5].p, (size_t)npoints * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipStreamSynchronize(st));
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_distinctive_descriptors_device(orbfe_matcher *m, const uint8_t *d_pool, const uint32_t *d_off,
+                                                             const uint32_t *d_idx, int32_t npoints, int32_t max_obs,
+                                                             int32_t *d_best_idx, int32_t *d_median, void *stream)
+{
+    if (!m || npoints < 0 || max_obs < 1 || max_obs > DD_MAX_OBS || (npoints > 0 && (!d_pool || !d_off || !d_idx || !d_best_idx || !d_median))) {
+        orbfe_set_error("bad argument to orbfe_distinctive_descriptors_device (max_obs 1..%d)", DD_MAX_OBS);
+        return ORBFE_ERR_ARG;
+    }
+    if (npoints == 0) return ORBFE_OK;
+    MDeviceGuard g(m->device);
+    hipLaunchKernelGGL(k_distinctive, dim3(npoints), dim3(64), (size_t)max_obs * 32, (hipStream_t)stream, d_pool, d_off, d_idx, d_best_idx,
+                       d_median, max_obs);
+    ORBFE_HIP(hipGetLastError());
     return ORBFE_OK;
 }
 

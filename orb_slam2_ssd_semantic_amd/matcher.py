@@ -157,6 +157,11 @@ class ORBmatcher:
         check(st, "orbfe_stereo_matches")
         return u[:n].copy(), d[:n].copy()
 
+    def ComputeDistinctiveDescriptors_device(self, d_pool, d_off, d_idx, npoints, max_obs, d_best, d_median, stream=None):
+        """MapPoint::ComputeDistinctiveDescriptors on device buffers (pointers as ints); -2 marks points beyond max_obs."""
+        check(self._L.orbfe_distinctive_descriptors_device(self._m, d_pool, d_off, d_idx, int(npoints), int(max_obs), d_best, d_median,
+                                                           stream), "orbfe_distinctive_descriptors_device")
+
     def AssignFeaturesToGrid_batch_device(self, d_kps, d_n, cap, nframes, minx, miny, gw_inv, gh_inv, d_cell_off, d_cell_idx,
                                           d_n_in_grid, stream=None):
         """Frame::AssignFeaturesToGrid for every frame of an extractor output block (device pointers as ints)."""

@@ -70,3 +70,28 @@ def test_gpu_distinctive_parity(oracle, seed, npoints, max_obs):
 def test_distinctive_bad_args_cpu():
     from orb_slam2_ssd_semantic_amd import _ffi
     assert _ffi.lib().orbfe_distinctive_descriptors(None, None, 0, None, None, 0, None, None) == _ffi.ORBFE_ERR_ARG
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,npoints,max_obs,lds_obs", [(0, 300, 12, 12), (1, 40, 70, 128), (4, 3, 200, 1024), (6, 50, 30, 16)])
+def test_gpu_distinctive_device_buffers(oracle, seed, npoints, max_obs, lds_obs):
+    """The device entry point on torch tensors: same answers as the oracle; points with more observations than the LDS was
+    sized for (last case) are marked -2 instead of being computed."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import ORBmatcher
+    pool, off, idx = make_case(seed, npoints, max_obs)
+    rb, rm = oracle.distinctive(pool, off, idx)
+    dp = torch.from_numpy(pool).cuda()
+    do = torch.from_numpy(off.astype(np.int32)).cuda()
+    di = torch.from_numpy(np.ascontiguousarray(idx).astype(np.int32)).cuda() if len(idx) else torch.zeros(1, dtype=torch.int32, device="cuda")
+    db = torch.full((npoints,), 99, dtype=torch.int32, device="cuda")
+    dm = torch.full((npoints,), 99, dtype=torch.int32, device="cuda")
+    ORBmatcher(0.9, True).ComputeDistinctiveDescriptors_device(dp.data_ptr(), do.data_ptr(), di.data_ptr(), npoints, lds_obs, db.data_ptr(),
+                                                               dm.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    b, m = db.cpu().numpy(), dm.cpu().numpy()
+    nobs = np.diff(off.astype(np.int64))
+    big = nobs > lds_obs
+    assert np.array_equal(b[~big], rb[~big]) and np.array_equal(m[~big], rm[~big])
+    assert np.all(b[big] == -2) and np.all(m[big] == -2)
+    assert big.any() == (lds_obs < max_obs and nobs.max() > lds_obs)
