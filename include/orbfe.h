@@ -289,6 +289,16 @@ orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy, const int
                                     float gw_inv, float gh_inv, const float *qxyr, const int32_t *qlevels, int32_t nq,
                                     uint32_t *off, uint32_t *cand, int32_t cap);
 
+/* GetFeaturesInArea on device buffers, for ONE frame of an extractor output block: d_kps = that frame's keypoint records
+ * (x, y, octave are read in place), d_cell_off / d_cell_idx = its grid (orbfe_assign_grid_batch_device), d_qxyr[nq*3] /
+ * d_qlevels[nq*2] (may be NULL) the queries; d_off[nq+1] and d_cand[cap] come out in the order orbfe_hamming_csr_device
+ * consumes.  Enqueued on `stream`, nothing validated.  If the total exceeds cap nothing is written to d_cand and
+ * d_off[nq] (the required size) tells so. */
+orbfe_status orbfe_features_in_area_device(orbfe_matcher *m, const orbfe_keypoint *d_kps, const uint32_t *d_cell_off,
+                                           const uint32_t *d_cell_idx, float minx, float miny, float gw_inv, float gh_inv,
+                                           const float *d_qxyr, const int32_t *d_qlevels, int32_t nq, uint32_t *d_off,
+                                           uint32_t *d_cand, int32_t cap, void *stream);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:642-846): row-band descriptor search in the right image,
  * 11 x 11 SAD refinement over 11 shifts on the two extractors' device-resident pyramids (mvImagePyramid of the LAST
  * call of `left` / `right`, frame 0), parabola fit, disparity -> depth, and the median-based outlier rejection.

@@ -27,7 +27,7 @@ SYMBOLS = (
     "orbfe_set_profiling", "orbfe_get_stage_ms", "orbfe_hamming", "orbfe_matcher_create",
     "orbfe_matcher_destroy", "orbfe_matcher_get_stream", "orbfe_match_bf", "orbfe_match_bf_device", "orbfe_match_bf_frames_device",
     "orbfe_search_by_bow", "orbfe_hamming_csr", "orbfe_assign_grid", "orbfe_features_in_area",
-    "orbfe_distinctive_descriptors", "orbfe_distinctive_descriptors_device", "orbfe_stereo_matches", "orbfe_stereo_matches_batch_device", "orbfe_assign_grid_batch_device", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
+    "orbfe_distinctive_descriptors", "orbfe_distinctive_descriptors_device", "orbfe_stereo_matches", "orbfe_stereo_matches_batch_device", "orbfe_assign_grid_batch_device", "orbfe_features_in_area_device", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy",
     "orbfe_bow_transform", "orbfe_get_overflow", "orbfe_set_fast_mode", "orbfe_get_fast_stats", "orbfe_get_work_counts",
     "orbfe_bow_transform_batch_device", "orbfe_search_by_bow_batch_device", "orbfe_matcher_set_bf_kernel",
     "orbfe_mapio_keyframe_bytes", "orbfe_mapio_write_keyframe", "orbfe_mapio_read_keyframe", "orbfe_mapio_pack_records_device",
@@ -129,6 +129,7 @@ def lib():
     L.orbfe_bow_transform.argtypes = [vp, vp, vp, i32, i32] + [vp] * 10
     L.orbfe_stereo_matches.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp]
     L.orbfe_distinctive_descriptors_device.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.orbfe_features_in_area_device.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32, vp, vp, i32, vp, vp, i32, vp]
     L.orbfe_assign_grid_batch_device.argtypes = [vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp]
     L.orbfe_stereo_matches_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp]
     L.orbfe_distinctive_descriptors.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]

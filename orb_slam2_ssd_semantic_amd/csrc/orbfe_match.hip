@@ -10,6 +10,7 @@
 // All-pairs brute force (M3): by default an EXACT int8 dot product on the matrix cores (k_match_bf); the xor / popcount
 // all-pairs kernel the north star names is kept as k_match_popc (orbfe_matcher_set_bf_kernel), bit-identical, slower
 // (profiles/r02_match_variants.json).  No CPU path.
+#include <stddef.h>
 #include <algorithm>
 #include <new>
 
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(1024) void k_assign_grid(const float *__restrict__ 
 __device__ int area_query(const float *__restrict__ xy, const int32_t *__restrict__ octave,
                           const uint32_t *__restrict__ cell_off, const uint32_t *__restrict__ cell_idx, float minx,
                           float miny, float gwi, float ghi, float x, float y, float r, int minL, int maxL,
-                          uint32_t *out, bool write)
+                          uint32_t *out, bool write, int xs = 2, int os = 1)
 {
     int nminx = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minx), r), gwi));  // :470
     nminx = max(nminx, 0);
@@ -1026,11 +1027,11 @@ __device__ int area_query(const float *__restrict__ xy, const int32_t *__restric
             for (uint32_t j = cell_off[c]; j < cell_off[c + 1]; ++j) {
                 const uint32_t k = cell_idx[j];
                 if (check) {
-                    const int o = octave[k];
+                    const int o = octave[(size_t)os * k];
                     if (o < minL) continue;
                     if (maxL >= 0 && o > maxL) continue;
                 }
-                const float dx = __fsub_rn(xy[2 * k], x), dy = __fsub_rn(xy[2 * k + 1], y);
+                const float dx = __fsub_rn(xy[(size_t)xs * k], x), dy = __fsub_rn(xy[(size_t)xs * k + 1], y);
                 if (fabsf(dx) < r && fabsf(dy) < r) {
                     if (write) out[cnt] = k;
                     ++cnt;
@@ -1043,12 +1044,12 @@ __device__ int area_query(const float *__restrict__ xy, const int32_t *__restric
 __global__ __launch_bounds__(256) void k_area_count(const float *xy, const int32_t *octave, const uint32_t *cell_off,
                                                     const uint32_t *cell_idx, float minx, float miny, float gwi,
                                                     float ghi, const float *qxyr, const int32_t *qlv, int nq,
-                                                    uint32_t *cnt)
+                                                    uint32_t *cnt, int xs, int os)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nq) return;
     cnt[i] = (uint32_t)area_query(xy, octave, cell_off, cell_idx, minx, miny, gwi, ghi, qxyr[3 * i], qxyr[3 * i + 1],
-                                  qxyr[3 * i + 2], qlv ? qlv[2 * i] : -1, qlv ? qlv[2 * i + 1] : -1, nullptr, false);
+                                  qxyr[3 * i + 2], qlv ? qlv[2 * i] : -1, qlv ? qlv[2 * i + 1] : -1, nullptr, false, xs, os);
 }
 
 // single-workgroup exclusive scan cnt[0..nq) -> off[0..nq]
@@ -1081,12 +1082,40 @@ __global__ __launch_bounds__(1024) void k_scan_u32(const uint32_t *__restrict__ 
 __global__ __launch_bounds__(256) void k_area_write(const float *xy, const int32_t *octave, const uint32_t *cell_off,
                                                     const uint32_t *cell_idx, float minx, float miny, float gwi,
                                                     float ghi, const float *qxyr, const int32_t *qlv, int nq,
-                                                    const uint32_t *off, uint32_t *cand, uint32_t cap)
+                                                    const uint32_t *off, uint32_t *cand, uint32_t cap, int xs, int os)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nq || off[nq] > cap) return;
     area_query(xy, octave, cell_off, cell_idx, minx, miny, gwi, ghi, qxyr[3 * i], qxyr[3 * i + 1], qxyr[3 * i + 2],
-               qlv ? qlv[2 * i] : -1, qlv ? qlv[2 * i + 1] : -1, cand + off[i], true);
+               qlv ? qlv[2 * i] : -1, qlv ? qlv[2 * i + 1] : -1, cand + off[i], true, xs, os);
+}
+
+extern "C" orbfe_status orbfe_features_in_area_device(orbfe_matcher *m, const orbfe_keypoint *d_kps,
+                                                      const uint32_t *d_cell_off, const uint32_t *d_cell_idx, float minx,
+                                                      float miny, float gw_inv, float gh_inv, const float *d_qxyr,
+                                                      const int32_t *d_qlevels, int32_t nq, uint32_t *d_off,
+                                                      uint32_t *d_cand, int32_t cap, void *stream)
+{
+    if (!m || nq < 0 || cap < 0 || !d_off || (nq > 0 && (!d_kps || !d_cell_off || !d_cell_idx || !d_qxyr || (cap > 0 && !d_cand)))) {
+        orbfe_set_error("bad argument to orbfe_features_in_area_device");
+        return ORBFE_ERR_ARG;
+    }
+    MDeviceGuard g(m->device);
+    hipStream_t st = (hipStream_t)stream;
+    ORBFE_HIP(m->b[7].ensure((size_t)std::max(nq, 1) * 4));  // per-query counts
+    const float *xy = (const float *)d_kps;                  // record = 7 floats: (x, y) first, octave sixth
+    const int32_t *oct = (const int32_t *)d_kps + 5;
+    static_assert(offsetof(orbfe_keypoint, octave) == 20 && sizeof(orbfe_keypoint) == 28, "keypoint record layout");
+    if (nq > 0) {
+        hipLaunchKernelGGL(k_area_count, dim3((nq + 255) / 256), dim3(256), 0, st, xy, oct, d_cell_off, d_cell_idx, minx, miny, gw_inv,
+                           gh_inv, d_qxyr, d_qlevels, nq, (uint32_t *)m->b[7].p, 7, 7);
+    }
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, (const uint32_t *)m->b[7].p, nq, d_off);
+    if (nq > 0)
+        hipLaunchKernelGGL(k_area_write, dim3((nq + 255) / 256), dim3(256), 0, st, xy, oct, d_cell_off, d_cell_idx, minx, miny, gw_inv,
+                           gh_inv, d_qxyr, d_qlevels, nq, (const uint32_t *)d_off, d_cand, (uint32_t)cap, 7, 7);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
 }
 
 extern "C" orbfe_status orbfe_assign_grid(orbfe_matcher *m, const float *xy, int32_t n, float minx, float miny,
@@ -1164,12 +1193,12 @@ extern "C" orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy
     const int32_t *dql = qlevels ? (const int32_t *)m->b[5].p : nullptr;
     hipLaunchKernelGGL(k_area_count, dim3((nq + 255) / 256), dim3(256), 0, st, (const float *)m->b[0].p,
                        (const int32_t *)m->b[1].p, (const uint32_t *)m->b[2].p, (const uint32_t *)m->b[3].p, minx, miny,
-                       gw_inv, gh_inv, (const float *)m->b[4].p, dql, nq, (uint32_t *)m->b[7].p);
+                       gw_inv, gh_inv, (const float *)m->b[4].p, dql, nq, (uint32_t *)m->b[7].p, 2, 1);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, (const uint32_t *)m->b[7].p, nq, (uint32_t *)m->b[6].p);
     hipLaunchKernelGGL(k_area_write, dim3((nq + 255) / 256), dim3(256), 0, st, (const float *)m->b[0].p,
                        (const int32_t *)m->b[1].p, (const uint32_t *)m->b[2].p, (const uint32_t *)m->b[3].p, minx, miny,
                        gw_inv, gh_inv, (const float *)m->b[4].p, dql, nq, (const uint32_t *)m->b[6].p,
-                       (uint32_t *)m->b[8].p, (uint32_t)cap);
+                       (uint32_t *)m->b[8].p, (uint32_t)cap, 2, 1);
     ORBFE_HIP(hipGetLastError());
     ORBFE_HIP(hipMemcpyAsync(off, m->b[6].p, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipStreamSynchronize(st));

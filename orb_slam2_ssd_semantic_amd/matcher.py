@@ -169,6 +169,13 @@ class ORBmatcher:
                                                      float(gw_inv), float(gh_inv), d_cell_off, d_cell_idx, d_n_in_grid, stream),
               "orbfe_assign_grid_batch_device")
 
+    def GetFeaturesInArea_device(self, d_kps, d_cell_off, d_cell_idx, minx, miny, gw_inv, gh_inv, d_qxyr, d_qlevels, nq, d_off, d_cand,
+                                 cap, stream=None):
+        """Frame::GetFeaturesInArea for nq queries on one frame of an extractor output block (device pointers as ints)."""
+        check(self._L.orbfe_features_in_area_device(self._m, d_kps, d_cell_off, d_cell_idx, float(minx), float(miny), float(gw_inv),
+                                                    float(gh_inv), d_qxyr, d_qlevels, int(nq), d_off, d_cand, int(cap), stream),
+              "orbfe_features_in_area_device")
+
     def ComputeStereoMatches_batch_device(self, extractorLeft, extractorRight, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, cap,
                                           nframes, mbf, mb, d_uRight, d_depth, stream=None):
         """Frame::ComputeStereoMatches for every frame pair of the two extractors' last device batches; all arguments are

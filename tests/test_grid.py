@@ -175,3 +175,66 @@ def test_gpu_grid_batch_device_on_extractor_output(oracle):
             roff, ridx = oracle.assign_grid(xy, minx, miny, gwi, ghi)
             assert nin[i] == len(ridx) and (minx > 0 or nin[i] == n[i])
             assert np.array_equal(off[i], roff) and np.array_equal(idx[i, :nin[i]], ridx), i
+
+
+@pytest.mark.gpu
+def test_gpu_projection_search_chain_device_resident(oracle):
+    """The SearchByProjection inner loop without leaving the device: extractor block -> grid of every frame -> for frame f,
+    GetFeaturesInArea of 400 queries (orbfe_features_in_area_device) -> best / second-best Hamming over the candidate lists
+    (orbfe_hamming_csr_device, query descriptors = the previous frame's).  Candidate lists and matches against the oracle's
+    two stages on the same keypoints; a too small `cap` reports the required size and writes nothing."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE, ORBextractor, ORBmatcher, _ffi
+    from orb_slam2_ssd_semantic_amd.synth import synth_frame
+    w, h, B, nq = 640, 480, 4, 400
+    frames = np.stack([synth_frame(700 + i, h, w) for i in range(B)])
+    e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    mt = ORBmatcher(0.9, True)
+    cap = e.capacity()
+    st = torch.cuda.current_stream().cuda_stream
+    dg = torch.from_numpy(frames).cuda()
+    dk = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
+    dd = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    dn = torch.zeros(B, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(dg.data_ptr(), B, w, h, w, w * h, dk.data_ptr(), dd.data_ptr(), cap, dn.data_ptr(), st)
+    minx, miny = 0.0, 0.0
+    gwi, ghi = float(F(64) / F(w)), float(F(48) / F(h))
+    g_off = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    g_idx = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    g_nin = torch.zeros(B, dtype=torch.int32, device="cuda")
+    mt.AssignFeaturesToGrid_batch_device(dk.data_ptr(), dn.data_ptr(), cap, B, minx, miny, gwi, ghi, g_off.data_ptr(), g_idx.data_ptr(),
+                                         g_nin.data_ptr(), st)
+    q, lv = queries(21, nq)
+    dq, dlv = torch.from_numpy(q).cuda(), torch.from_numpy(lv).cuda()
+    ccap = 60000
+    c_off = torch.zeros(nq + 1, dtype=torch.int32, device="cuda")
+    c_cand = torch.full((ccap,), -1, dtype=torch.int32, device="cuda")
+    res = [torch.zeros(nq, dtype=torch.int32, device="cuda") for _ in range(4)]
+    f = 2
+    mt.GetFeaturesInArea_device(dk[f].data_ptr(), g_off[f].data_ptr(), g_idx[f].data_ptr(), minx, miny, gwi, ghi, dq.data_ptr(),
+                                dlv.data_ptr(), nq, c_off.data_ptr(), c_cand.data_ptr(), ccap, st)
+    rc = _ffi.lib().orbfe_hamming_csr_device(mt.handle, dd[f - 1].data_ptr(), nq, dd[f].data_ptr(), c_off.data_ptr(), c_cand.data_ptr(),
+                                             res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), res[3].data_ptr(), st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    n = dn.cpu().numpy()
+    k = dk[f, :n[f]].cpu().numpy().copy().view(KP_DTYPE).reshape(-1)
+    xy = np.stack([k["x"], k["y"]], 1)
+    roff, ridx = oracle.assign_grid(xy, minx, miny, gwi, ghi)
+    off = c_off.cpu().numpy().view(np.uint32)
+    cand = c_cand.cpu().numpy().view(np.uint32)[:off[nq]]
+    ro, rc_ = [0], []
+    for i in range(nq):
+        c = oracle.features_in_area(xy, k["octave"], roff, ridx, minx, miny, gwi, ghi, q[i, 0], q[i, 1], q[i, 2], lv[i, 0], lv[i, 1])
+        rc_.extend(c.tolist())
+        ro.append(len(rc_))
+    assert np.array_equal(off, np.array(ro, np.uint32)) and np.array_equal(cand, np.array(rc_, np.uint32)) and off[nq] > 2000
+    desc = dd.cpu().numpy()
+    rbi, rb, rs = oracle.hamming_csr(desc[f - 1, :nq], desc[f, :n[f]], off, cand)
+    assert np.array_equal(res[0].cpu().numpy(), rbi) and np.array_equal(res[1].cpu().numpy(), rb) and np.array_equal(res[2].cpu().numpy(), rs)
+    # cap too small: the required size comes back in off[nq], the candidate buffer is not touched
+    c_cand.fill_(-7)
+    mt.GetFeaturesInArea_device(dk[f].data_ptr(), g_off[f].data_ptr(), g_idx[f].data_ptr(), minx, miny, gwi, ghi, dq.data_ptr(),
+                                dlv.data_ptr(), nq, c_off.data_ptr(), c_cand.data_ptr(), 100, st)
+    torch.cuda.synchronize()
+    assert c_off.cpu().numpy().view(np.uint32)[nq] == off[nq] and bool((c_cand == -7).all())
