@@ -22,7 +22,12 @@
  *   - cv::resize, copyMakeBorder, cv::FAST, GaussianBlur, fastAtan2 are NOT in /root/reference (OpenCV is a
  *     non-vendored, un-pinned dependency and is not installed): inside _ref they are THIS file's restatements
  *     of the OpenCV 3.2 generic path, pinned only by known-answer tables and definition-level twins
- *     (tests/test_oracle_kat.py, tests/twins.py).  For those five stages parity remains "unpinned".
+ *     (tests/test_oracle_kat.py, tests/twins.py) and anchored on independent third-party code where that exists
+ *     (tests/test_thirdparty.py): scikit-image's own FAST-9 classifies every pixel as this file's score does, its
+ *     rBRIEF table / umax / 749-pixel mask equal ours, numpy.pad == the REFLECT_101 border, scipy's int64 correlation
+ *     with the q8 taps == the blur byte for byte, float64 half-pixel bilinear (scipy) within one grey level of the
+ *     resize, numpy.arctan2 within 0.3 degrees of fastAtan2.  For those five stages parity remains "unpinned by real
+ *     OpenCV" (FAST's score value / NMS and the resize's internal truncations have no third-party anchor).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * link or call this library.  The product (orb_slam2_ssd_semantic_amd/csrc)
