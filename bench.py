@@ -35,11 +35,12 @@ import subprocess
 import sys
 import time
 
-# The extractor runs its blur on a side stream and this script adds copy and collective streams of its own; the ROCm runtime
-# multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that land on
-# one queue serialise -- measured here: the PCIe-inclusive leg drops from 179 k to 118 k frames/s when a copy stream
-# shares a queue with the blur.  Eight queues keep them apart ("streams").  Must be set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Every extractor handle runs its blur on a side stream and this script adds matcher, copy and collective streams of its
+# own (a dozen over all legs); the ROCm runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4), and two streams that land on one queue serialise -- measured here: the PCIe-inclusive leg drops from 177 k
+# to 95-118 k frames/s when a copy stream shares a queue with a kernel stream (4 and 8 queues), 16 keep them apart
+# ("streams").  Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -3,7 +3,7 @@ usage: python tools/two_stream_probe.py"""
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from orb_slam2_ssd_semantic_amd import ORBextractor
