@@ -633,6 +633,10 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
 {
     if (!h) return;
     DeviceGuard g(h->device);
+    // nothing of this handle may still be running when its buffers go: the caller's last stream, the side stream of the
+    // blur, the host pipeline's copy streams
+    if (h->last_stream_valid) (void)hipStreamSynchronize(h->last_stream);
+    if (h->side) (void)hipStreamSynchronize(h->side);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
@@ -653,7 +657,6 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
         for (int r = 0; r < ORBFE_PROF_RING; ++r)
             for (int i = 0; i < ORBFE_EV_N; ++i)
                 if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
-    if (h->side) (void)hipStreamSynchronize(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
