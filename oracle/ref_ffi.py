@@ -32,13 +32,32 @@ def available():
     return os.path.exists(_LIB) or have_reference()
 
 
+def _make(target):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "refbuild"), f"REF={REFERENCE}", target])
+
+
 def build():
-    """make -C oracle/refbuild when the reference sources are present; otherwise require the prebuilt library."""
+    """make -C oracle/refbuild ref (libref_orb.so only: gcc/g++ + the reference sources, nothing of the product) when the
+    reference sources are present; otherwise require the prebuilt library."""
     if have_reference():
-        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "refbuild"), f"REF={REFERENCE}"])
+        _make("ref")
     if not os.path.exists(_LIB):
         raise RuntimeError("oracle/_ref/libref_orb.so is missing and /root/reference is not available to build it")
     return _LIB
+
+
+def build_shims():
+    """make -C oracle/refbuild shims: the product's shims inside the reference's classes.  Needs the product library
+    (orb_slam2_ssd_semantic_amd/liborbfe.so, hipcc) to exist; called only by the shim tests / the driver's build()."""
+    build()
+    if have_reference():
+        import sys
+        root = os.path.dirname(_HERE)
+        if root not in sys.path:
+            sys.path.insert(0, root)
+        from orb_slam2_ssd_semantic_amd import _build
+        _build.build()  # hipcc; raises if the product library cannot be built
+        _make("shims")
 
 
 _lib = None
@@ -100,7 +119,7 @@ def shim_lib():
     global _shim
     if _shim is not None:
         return _shim
-    build()
+    build_shims()
     if not os.path.exists(_SHIM):
         raise RuntimeError("oracle/_ref/libshim_ref.so is missing")
     L = C.CDLL(_SHIM)
@@ -124,7 +143,7 @@ def shimext_lib():
     global _shimext
     if _shimext is not None:
         return _shimext
-    build()
+    build_shims()
     if not os.path.exists(_SHIMEXT):
         raise RuntimeError("oracle/_ref/libshim_ext.so is missing")
     L = C.CDLL(_SHIMEXT)
