@@ -150,12 +150,17 @@ struct orbfe_handle {
     int fast_mode = 0;            // 0 dense, 1 sparse shortcuts (orbfe_set_fast_mode)
     bool fast_stats = false;
     int64_t fast_row_steps = 0;
-    hipStream_t last_stream = nullptr;  // stream of the most recent batched call (synchronised before re-planning)
+    // The most recent batched call: its stream (only compared, never dereferenced: the caller may have destroyed it) and an
+    // event recorded behind its last launch.  All calls of a handle share the scratch blocks, so a call on another stream
+    // waits for that event first, and whoever needs the results on the host (taps, mvImagePyramid, re-planning, the
+    // overflow word, destroy) synchronises the event, not the stream.
+    hipStream_t last_stream = nullptr;
     bool last_stream_valid = false;
+    hipEvent_t ev_last = nullptr;
     // host-API staging
     // two sets, so that the H2D of chunk i+1, the kernels of chunk i and the D2H of chunk i-1 overlap
     DevBuf d_stage[2], d_okps[2], d_odesc[2], d_on[2];
-    PinBuf h_stage[2], h_okps[2], h_odesc[2], h_on[2];
+    PinBuf h_stage[2], h_okps[2], h_odesc[2], h_on[2], h_ovf;
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     // last call (for taps / mvImagePyramid)
@@ -176,6 +181,13 @@ struct orbfe_handle {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
+
+// waits until the last batched call of the handle has finished, on whichever stream it ran
+static hipError_t wait_last_call(orbfe_handle *h)
+{
+    if (!h->last_stream_valid) return hipSuccess;
+    return hipEventSynchronize(h->ev_last);
+}
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }  // cvRound: half-to-even
 
@@ -479,7 +491,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     // still be in flight on the handle's stream or on the caller's stream of the previous device call: both are drained
     // before the plan tables they read are overwritten.
     ORBFE_HIP(hipStreamSynchronize(h->stream));
-    if (h->last_stream_valid && h->last_stream != h->stream) ORBFE_HIP(hipStreamSynchronize(h->last_stream));
+    ORBFE_HIP(wait_last_call(h));
     ORBFE_HIP(hipMemcpy(h->d_plan.p, &P, sizeof(OrbPlan), hipMemcpyHostToDevice));
     ORBFE_HIP(hipMemcpy(h->d_tabs.p, tabs.data(), tabs.size() * sizeof(OrbTab), hipMemcpyHostToDevice));
     if (!flanes.empty())
@@ -502,7 +514,7 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
     if (B * (size_t)P.pyr_frame_bytes > h->d_pyr.bytes || B * (size_t)P.keys_per_frame * sizeof(uint2) > h->d_skeys.bytes) {
         // a block is about to be re-allocated: nothing may still be reading the old one
         ORBFE_HIP(hipStreamSynchronize(h->stream));
-        if (h->last_stream_valid && h->last_stream != h->stream) ORBFE_HIP(hipStreamSynchronize(h->last_stream));
+        ORBFE_HIP(wait_last_call(h));
     }
     ORBFE_HIP(h->d_pyr.ensure(B * (size_t)P.pyr_frame_bytes));
     ORBFE_HIP(h->d_blur.ensure(B * (size_t)P.pyr_frame_bytes));
@@ -524,7 +536,7 @@ static orbfe_status read_overflow(orbfe_handle *h, int32_t *flags)
 {
     *flags = 0;
     if (!h->d_misc.p) return ORBFE_OK;
-    if (h->last_stream_valid) ORBFE_HIP(hipStreamSynchronize(h->last_stream));
+    ORBFE_HIP(wait_last_call(h));
     ORBFE_HIP(hipMemcpy(flags, h->d_misc.p, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (*flags) ORBFE_HIP(hipMemset(h->d_misc.p, 0, sizeof(int32_t)));
     return ORBFE_OK;
@@ -597,6 +609,7 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
         for (int i = 0; i < ORBFE_EV_N; ++i)
             if (hipEventCreate(&h->ev[r][i]) != hipSuccess) { orbfe_set_error("hipEventCreate failed"); return fail(ORBFE_ERR_HIP); }
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
         orbfe_set_error("side stream / event creation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -635,7 +648,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     DeviceGuard g(h->device);
     // nothing of this handle may still be running when its buffers go: the caller's last stream, the side stream of the
     // blur, the host pipeline's copy streams
-    if (h->last_stream_valid) (void)hipStreamSynchronize(h->last_stream);
+    if (h->last_stream_valid && h->ev_last) (void)hipEventSynchronize(h->ev_last);
     if (h->side) (void)hipStreamSynchronize(h->side);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
@@ -646,6 +659,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     h->d_misc.release();
     PinBuf *pins[] = {&h->h_stage[0], &h->h_okps[0], &h->h_odesc[0], &h->h_on[0], &h->h_stage[1], &h->h_okps[1], &h->h_odesc[1], &h->h_on[1]};
     for (PinBuf *b : pins) b->release();
+    h->h_ovf.release();
     for (int k = 0; k < 2; ++k) {
         if (h->ev_in[k]) (void)hipEventDestroy(h->ev_in[k]);
         if (h->ev_cmp[k]) (void)hipEventDestroy(h->ev_cmp[k]);
@@ -657,6 +671,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
         for (int r = 0; r < ORBFE_PROF_RING; ++r)
             for (int i = 0; i < ORBFE_EV_N; ++i)
                 if (h->ev[r][i]) (void)hipEventDestroy(h->ev[r][i]);
+    if (h->ev_last) (void)hipEventDestroy(h->ev_last);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -761,7 +776,7 @@ extern "C" orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[3], i
     out[0] = out[1] = out[2] = 0;
     if (!h->d_misc.p) return ORBFE_OK;
     DeviceGuard g(h->device);
-    if (h->last_stream_valid) ORBFE_HIP(hipStreamSynchronize(h->last_stream));
+    ORBFE_HIP(wait_last_call(h));
     ORBFE_HIP(hipMemcpy(out, (char *)h->d_misc.p + 16, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (reset) ORBFE_HIP(hipMemset((char *)h->d_misc.p + 16, 0, 3 * sizeof(uint64_t)));
     return ORBFE_OK;
@@ -808,8 +823,9 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_ovf = (int32_t *)h->d_misc.p;
     a.fast_sparse = h->fast_mode;
     a.d_fstat = h->fast_stats ? (unsigned long long *)((char *)h->d_misc.p + 16) : nullptr;
-    h->last_stream = st;
-    h->last_stream_valid = true;
+    // every call of a handle uses the same scratch blocks (pyramid, blur, survivor lists, selections): a call on another
+    // stream than its predecessor's waits, at stream level, for that predecessor to finish
+    if (h->last_stream_valid && h->last_stream != st) ORBFE_HIP(hipStreamWaitEvent(st, h->ev_last, 0));
     hipEvent_t *ev = h->profiling ? h->ev[h->prof_calls % ORBFE_PROF_RING] : nullptr;
     if (ev) ORBFE_HIP(hipEventRecord(ev[0], st));
     ORBFE_HIP(orbk_launch_pyramid(a, st));
@@ -843,6 +859,9 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
         ORBFE_HIP(hipEventRecord(ev[5], st));
         h->prof_calls++;
     }
+    ORBFE_HIP(hipEventRecord(h->ev_last, st));
+    h->last_stream = st;
+    h->last_stream_valid = true;
     h->last_gray = d_gray;
     h->last_gray_fstride = (int64_t)frame_stride;
     h->last_gray_pitch = stride;
@@ -886,9 +905,12 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
     DeviceGuard g(h->device);
     const int chunk_max = h->prm.max_batch;
     const int nchunks = (nframes + chunk_max - 1) / chunk_max;
-    const bool direct = stride == w && is_pinned_host(grays[0]) && is_pinned_host(grays[nframes - 1]);
+    // The page-locked probes (hipPointerGetAttributes: an error path for plain malloc'ed memory) cost more than they can
+    // save on the online single-frame call, which goes through the handle's own pinned staging either way.
+    const bool probe = nframes > 1;
+    const bool direct = probe && stride == w && is_pinned_host(grays[0]) && is_pinned_host(grays[nframes - 1]);
     // pinned output arrays receive the padded device blocks as they are (slots >= n_out[f] zero-filled): no host unpacking
-    const bool direct_out = is_pinned_host(kps) && is_pinned_host(desc) && is_pinned_host(n_out);
+    const bool direct_out = probe && is_pinned_host(kps) && is_pinned_host(desc) && is_pinned_host(n_out);
     const int pitch = direct ? w : orb_align_up(w, 64);
     const size_t fbytes = (size_t)pitch * ht;
     const int nset = nchunks > 1 ? 2 : 1;
@@ -923,6 +945,13 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamSynchronize(h->s_out);
     };
+    // Every early return below leaves copies / kernels in flight that write into the caller's arrays (direct_out) or read
+    // its frames (direct): whatever way the pipeline loop is left, the three streams are drained first.
+    struct DrainGuard {
+        decltype(drain) &fn;
+        bool armed = true;
+        ~DrainGuard() { if (armed) fn(); }
+    } drain_guard{drain};
     auto unpack = [&](int c) -> orbfe_status {  // results of chunk c: wait for its D2H, hand them to the caller
         const int k = c & (nset - 1), f0 = c * chunk_max, nb = std::min(chunk_max, nframes - f0);
         ORBFE_HIP(hipEventSynchronize(h->ev_out[k]));
@@ -993,11 +1022,15 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
         orbfe_status su = unpack(c);
         if (su != ORBFE_OK) { drain(); return su; }
     }
+    // the sticky overflow word travels with the results: an asynchronous 4-byte copy into pinned memory behind the last
+    // kernels, read after the one synchronisation the call needs anyway
+    ORBFE_HIP(h->h_ovf.ensure(sizeof(int32_t)));
+    ORBFE_HIP(hipMemcpyAsync(h->h_ovf.p, h->d_misc.p, sizeof(int32_t), hipMemcpyDeviceToHost, s_cmp));
     ORBFE_HIP(hipStreamSynchronize(s_cmp));
+    drain_guard.armed = false;  // everything has been waited for (unpack() synchronised the output events)
     {
-        int32_t ovf = 0;
-        orbfe_status so = read_overflow(h, &ovf);
-        if (so != ORBFE_OK) return so;
+        const int32_t ovf = *(const int32_t *)h->h_ovf.p;
+        if (ovf) ORBFE_HIP(hipMemset(h->d_misc.p, 0, sizeof(int32_t)));
         if (ovf & 3) {
             orbfe_set_error("internal capacity exceeded (flags %d: 1 = FAST survivor list, 2 = quadtree selection); "
                             "results of this batch are incomplete", ovf);
@@ -1068,7 +1101,7 @@ static orbfe_status fetch_level(orbfe_handle *h, const uint8_t *base, int pitch,
                                 int dst_stride, int border)
 {
     std::vector<uint8_t> tmp((size_t)w * ht);
-    ORBFE_HIP(hipStreamSynchronize(h->stream));
+    ORBFE_HIP(wait_last_call(h));
     ORBFE_HIP(hipMemcpy2D(tmp.data(), (size_t)w, base, (size_t)pitch, (size_t)w, (size_t)ht, hipMemcpyDeviceToHost));
     for (int y = -border; y < ht + border; ++y) {
         const uint8_t *s = tmp.data() + (size_t)host_reflect101(y, ht) * w;
@@ -1097,12 +1130,22 @@ extern "C" orbfe_status orbfe_get_pyramid_level(orbfe_handle *h, int32_t frame, 
                        dst, dst_stride, border);
 }
 
+// makes `stream` (a hipStream_t) wait for the handle's last batched call, wherever it ran: the pyramid readers of the
+// matcher (stereo) order themselves behind the extractor with it, without a host synchronisation
+int32_t orbfe_internal_order_after_last_call(orbfe_handle *h, void *stream)
+{
+    if (!h) return ORBFE_ERR_ARG;
+    if (!h->last_stream_valid || h->last_stream == (hipStream_t)stream) return ORBFE_OK;
+    DeviceGuard g(h->device);
+    ORBFE_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_last, 0));
+    return ORBFE_OK;
+}
+
 int32_t orbfe_internal_pyramid_view(orbfe_handle *h, int frame, OrbPyrView *v)
 {
     orbfe_status s = check_tap(h, frame, 0);
     if (s != ORBFE_OK) return s;
     DeviceGuard g(h->device);
-    ORBFE_HIP(hipStreamSynchronize(h->stream));
     v->nlevels = h->plan.nlevels;
     v->device = h->device;
     for (int l = 0; l < h->plan.nlevels; ++l) {
@@ -1142,7 +1185,7 @@ extern "C" orbfe_status orbfe_tap_candidates(orbfe_handle *h, int32_t frame, int
     DeviceGuard g(h->device);
     const OrbPlan &P = h->plan;
     const OrbLevel &L = P.lv[level];
-    ORBFE_HIP(hipStreamSynchronize(h->stream));
+    ORBFE_HIP(wait_last_call(h));
     int32_t nk = 0, nsv = 0;
     ORBFE_HIP(hipMemcpy(&nk, (int32_t *)h->d_nkeys.p + ((size_t)frame * P.nlevels + level) * ORBFE_NK_STRIDE, sizeof(int32_t),
                         hipMemcpyDeviceToHost));
@@ -1193,7 +1236,7 @@ extern "C" orbfe_status orbfe_tap_selected(orbfe_handle *h, int32_t frame, int32
     DeviceGuard g(h->device);
     const OrbPlan &P = h->plan;
     const OrbLevel &L = P.lv[level];
-    ORBFE_HIP(hipStreamSynchronize(h->stream));
+    ORBFE_HIP(wait_last_call(h));
     int32_t ns = 0;
     ORBFE_HIP(hipMemcpy(&ns, (int32_t *)h->d_nsel.p + (size_t)frame * P.nlevels + level, sizeof(int32_t),
                         hipMemcpyDeviceToHost));

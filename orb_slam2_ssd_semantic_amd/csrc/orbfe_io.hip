@@ -291,6 +291,18 @@ static orbfe_status load_binary(std::ifstream &f, orbfe_vocfile *v)
     f.read((char *)&v->scoring, 4);
     f.read((char *)&v->weighting, 4);
     if (!f || sz != 41 || nb < 1) { orbfe_set_error("vocabulary binary header: nb_nodes %u, size_node %u (expected 41)", nb, sz); return ORBFE_ERR_ARG; }
+    {
+        // a corrupt node count must not drive the allocations below: the file has to hold (nb - 1) node records
+        const std::streampos here = f.tellg();
+        f.seekg(0, std::ios::end);
+        const std::streampos end = f.tellg();
+        f.seekg(here);
+        if (!f || end < here || (uint64_t)(end - here) < (uint64_t)(nb - 1) * 41) {
+            orbfe_set_error("vocabulary binary file truncated: header says %u nodes, %lld bytes of records present", nb,
+                            (long long)(end - here));
+            return ORBFE_ERR_SIZE;
+        }
+    }
     v->parent.assign(nb, 0);
     v->leaf.assign(nb, 0);
     v->desc.assign((size_t)nb * 32, 0);
@@ -330,8 +342,17 @@ extern "C" orbfe_status orbfe_vocfile_load(const char *path, orbfe_vocfile **out
     const bool binary = sz == 41;
     orbfe_vocfile *v = new (std::nothrow) orbfe_vocfile();
     if (!v) return ORBFE_ERR_NOMEM;
-    orbfe_status s = binary ? load_binary(f, v) : load_text(f, v);
-    if (s == ORBFE_OK) s = finish_vocfile(v);
+    orbfe_status s;
+    try {  // nothing may throw through the C boundary
+        s = binary ? load_binary(f, v) : load_text(f, v);
+        if (s == ORBFE_OK) s = finish_vocfile(v);
+    } catch (const std::bad_alloc &) {
+        orbfe_set_error("out of memory while loading vocabulary file %s", path);
+        s = ORBFE_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        orbfe_set_error("vocabulary file %s: %s", path, e.what());
+        s = ORBFE_ERR_SIZE;
+    }
     if (s != ORBFE_OK) {
         delete v;
         return s;
@@ -377,13 +398,19 @@ extern "C" orbfe_status orbfe_vocfile_save_binary(const orbfe_vocfile *v, const 
     std::ofstream f(path, std::ios::out | std::ios::binary);
     if (!f) { orbfe_set_error("cannot write %s", path); return ORBFE_ERR_ARG; }
     const uint32_t nb = (uint32_t)v->parent.size(), sz = 41;
+    if (nb < 1) { orbfe_set_error("vocabulary has no root node"); return ORBFE_ERR_ARG; }
     f.write((const char *)&nb, 4);
     f.write((const char *)&sz, 4);
     f.write((const char *)&v->k, 4);
     f.write((const char *)&v->L, 4);
     f.write((const char *)&v->scoring, 4);
     f.write((const char *)&v->weighting, 4);
-    std::vector<char> buf((size_t)(nb - 1) * 41);
+    std::vector<char> buf;
+    try {
+        buf.resize((size_t)(nb - 1) * 41);
+    } catch (const std::bad_alloc &) {
+        return ORBFE_ERR_NOMEM;
+    }
     for (uint32_t i = 1; i < nb; ++i) {
         char *r = buf.data() + (size_t)(i - 1) * 41;
         const float w = (float)v->weight[i];

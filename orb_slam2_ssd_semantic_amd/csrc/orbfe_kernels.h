@@ -59,3 +59,4 @@ struct OrbPyrView {
 struct orbfe_handle;
 // fills `v` for frame `frame` of the last batch and waits for the handle's own stream; ORBFE_ERR_STATE before any call
 int32_t orbfe_internal_pyramid_view(orbfe_handle *h, int frame, OrbPyrView *v);
+int32_t orbfe_internal_order_after_last_call(orbfe_handle *h, void *stream);

@@ -610,7 +610,24 @@ struct orbfe_matcher {
     hipStream_t stream = nullptr;
     MDevBuf b[16];
     int bf_kernel = 0;  // 0 = k_match_bf (int8 dot product on the matrix cores), 1 = k_match_popc (xor / popcount)
+    // Device entry points that use the scratch blocks b[] run on the CALLER's stream: one that arrives on another stream
+    // than its predecessor waits (at stream level) for the event recorded behind that predecessor's last launch.
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
+    hipEvent_t ev_scratch = nullptr;
 };
+
+static hipError_t scratch_acquire(orbfe_matcher *m, hipStream_t st)
+{
+    if (m->scratch_used && m->scratch_stream != st) return hipStreamWaitEvent(st, m->ev_scratch, 0);
+    return hipSuccess;
+}
+static hipError_t scratch_release(orbfe_matcher *m, hipStream_t st)
+{
+    m->scratch_stream = st;
+    m->scratch_used = true;
+    return hipEventRecord(m->ev_scratch, st);
+}
 
 struct MDeviceGuard {
     int prev = -1, dev = -1;
@@ -654,8 +671,10 @@ extern "C" orbfe_status orbfe_matcher_create(int32_t device, orbfe_matcher **out
     if (!m) return ORBFE_ERR_NOMEM;
     m->device = device;
     MDeviceGuard g(device);
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
-        orbfe_set_error("hipStreamCreate failed");
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_scratch, hipEventDisableTiming) != hipSuccess) {
+        orbfe_set_error("hipStreamCreate / hipEventCreate failed");
+        if (m->stream) (void)hipStreamDestroy(m->stream);
         delete m;
         return ORBFE_ERR_HIP;
     }
@@ -677,7 +696,9 @@ extern "C" void orbfe_matcher_destroy(orbfe_matcher *m)
     if (!m) return;
     MDeviceGuard g(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->scratch_used) (void)hipEventSynchronize(m->ev_scratch);
     for (auto &b : m->b) b.release();
+    if (m->ev_scratch) (void)hipEventDestroy(m->ev_scratch);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -733,6 +754,7 @@ extern "C" orbfe_status orbfe_match_bf(orbfe_matcher *m, const uint8_t *q, int32
     }
     MDeviceGuard g(m->device);
     hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));  // a device-buffer call on another stream may still be using the scratch blocks
     const bool ori = check_ori && q_angle && t_angle;
     ORBFE_HIP(m->b[0].ensure((size_t)nq * 32));
     ORBFE_HIP(m->b[1].ensure((size_t)nt * 32));
@@ -832,6 +854,7 @@ extern "C" orbfe_status orbfe_search_by_bow(orbfe_matcher *m, const uint8_t *des
     }
     MDeviceGuard g(m->device);
     hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));  // a device-buffer call on another stream may still be using the scratch blocks
     const size_t nikf = offKF[nnodesKF], nif = offF[nnodesF];
     const size_t sz[14] = {(size_t)nKF * 32, (size_t)nKF, (size_t)nKF * 4, (size_t)nnodesKF * 4,
                            (size_t)(nnodesKF + 1) * 4, nikf * 4, (size_t)nF * 32, (size_t)nF, (size_t)nF * 4,
@@ -876,6 +899,7 @@ extern "C" orbfe_status orbfe_hamming_csr_ex(orbfe_matcher *m, const uint8_t *q,
         if (cand[k] >= (uint32_t)nt) { orbfe_set_error("candidate index out of range"); return ORBFE_ERR_ARG; }
     MDeviceGuard g(m->device);
     hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));  // a device-buffer call on another stream may still be using the scratch blocks
     ORBFE_HIP(m->b[0].ensure((size_t)nq * 32));
     ORBFE_HIP(m->b[1].ensure((size_t)nt * 32));
     ORBFE_HIP(m->b[2].ensure((size_t)(nq + 1) * 4));
@@ -1102,6 +1126,7 @@ extern "C" orbfe_status orbfe_features_in_area_device(orbfe_matcher *m, const or
     }
     MDeviceGuard g(m->device);
     hipStream_t st = (hipStream_t)stream;
+    ORBFE_HIP(scratch_acquire(m, st));
     ORBFE_HIP(m->b[7].ensure((size_t)std::max(nq, 1) * 4));  // per-query counts
     const float *xy = (const float *)d_kps;                  // record = 7 floats: (x, y) first, octave sixth
     const int32_t *oct = (const int32_t *)d_kps + 5;
@@ -1115,6 +1140,7 @@ extern "C" orbfe_status orbfe_features_in_area_device(orbfe_matcher *m, const or
         hipLaunchKernelGGL(k_area_write, dim3((nq + 255) / 256), dim3(256), 0, st, xy, oct, d_cell_off, d_cell_idx, minx, miny, gw_inv,
                            gh_inv, d_qxyr, d_qlevels, nq, (const uint32_t *)d_off, d_cand, (uint32_t)cap, 7, 7);
     ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(scratch_release(m, st));
     return ORBFE_OK;
 }
 
@@ -1128,6 +1154,7 @@ extern "C" orbfe_status orbfe_assign_grid(orbfe_matcher *m, const float *xy, int
     }
     MDeviceGuard g(m->device);
     hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));  // a device-buffer call on another stream may still be using the scratch blocks
     ORBFE_HIP(m->b[0].ensure((size_t)n * 8));
     ORBFE_HIP(m->b[1].ensure((size_t)(GRID_NC + 1) * 4));
     ORBFE_HIP(m->b[2].ensure((size_t)n * 4));
@@ -1183,6 +1210,7 @@ extern "C" orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy
     if (nq == 0) return ORBFE_OK;
     MDeviceGuard g(m->device);
     hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));  // a device-buffer call on another stream may still be using the scratch blocks
     const size_t sz[8] = {(size_t)n * 8, (size_t)n * 4, (size_t)(GRID_NC + 1) * 4, (size_t)nin * 4, (size_t)nq * 12,
                           (size_t)nq * 8, (size_t)(nq + 1) * 4, (size_t)nq * 4};
     for (int i = 0; i < 8; ++i) ORBFE_HIP(m->b[i].ensure(sz[i]));
@@ -1287,6 +1315,7 @@ extern "C" orbfe_status orbfe_distinctive_descriptors(orbfe_matcher *m, const ui
         if (idx[k] >= (uint32_t)npool) { orbfe_set_error("observation index out of range"); return ORBFE_ERR_ARG; }
     MDeviceGuard g(m->device);
     hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));  // a device-buffer call on another stream may still be using the scratch blocks
     ORBFE_HIP(m->b[0].ensure((size_t)std::max(npool, 1) * 32));
     ORBFE_HIP(m->b[2].ensure((size_t)(npoints + 1) * 4));
     ORBFE_HIP(m->b[3].ensure(std::max(nc, (size_t)1) * 4));
@@ -1526,6 +1555,11 @@ extern "C" orbfe_status orbfe_stereo_matches(orbfe_matcher *m, orbfe_handle *lef
     a.mb = mb;
     MDeviceGuard g(m->device);
     hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));  // a device-buffer call on another stream may still be using the scratch blocks
+    // the kernels read the two extractors' pyramids: behind their last calls, on whichever streams those ran
+    s = (orbfe_status)orbfe_internal_order_after_last_call(left, st);
+    if (s == ORBFE_OK) s = (orbfe_status)orbfe_internal_order_after_last_call(right, st);
+    if (s != ORBFE_OK) return s;
     ORBFE_HIP(m->b[0].ensure((size_t)nL * sizeof(orbfe_keypoint)));
     ORBFE_HIP(m->b[1].ensure((size_t)nL * 32));
     ORBFE_HIP(m->b[2].ensure((size_t)std::max(nR, 1) * sizeof(orbfe_keypoint)));
@@ -1583,12 +1617,17 @@ extern "C" orbfe_status orbfe_stereo_matches_batch_device(orbfe_matcher *m, orbf
     a.mb = mb;
     MDeviceGuard g(m->device);
     hipStream_t st = (hipStream_t)stream;
+    s = (orbfe_status)orbfe_internal_order_after_last_call(left, st);
+    if (s == ORBFE_OK) s = (orbfe_status)orbfe_internal_order_after_last_call(right, st);
+    if (s != ORBFE_OK) return s;
+    ORBFE_HIP(scratch_acquire(m, st));
     ORBFE_HIP(m->b[6].ensure((size_t)nframes * cap * 4));  // SAD distances of the kept matches, read by the filter
     hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, nframes), dim3(256), 0, st, a, d_kpsL, d_descL, 0, d_kpsR, d_descR, 0,
                        d_uRight, d_depth, (int32_t *)m->b[6].p, cap, d_nL, d_nR);
     hipLaunchKernelGGL(k_stereo_filter, dim3(nframes), dim3(1024), 0, st, 0, d_uRight, d_depth, (const int32_t *)m->b[6].p, cap,
                        d_nL);
     ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(scratch_release(m, st));
     return ORBFE_OK;
 }
 
@@ -1865,6 +1904,7 @@ extern "C" orbfe_status orbfe_bow_transform(orbfe_matcher *m, const orbfe_vocabu
     if (n == 0) return ORBFE_OK;
     MDeviceGuard g(m->device);
     hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));  // a device-buffer call on another stream may still be using the scratch blocks
     int P = 2;
     while (P < n) P <<= 1;
     ORBFE_HIP(m->b[0].ensure((size_t)n * 32));

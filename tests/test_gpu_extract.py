@@ -108,6 +108,36 @@ def test_1080p_4000_features(oracle):
         assert np.array_equal(e.candidates(l), cand_array(oe.candidates(l)))
 
 
+def test_config5_batched_device_path_1080p_4000(oracle):
+    """BASELINE config 5 through the path bench.py times: 32 distinct 1920x1080 frames, 4000 features, ONE
+    orbfe_extract_batch_device call (level 0 asks for 869 keypoints: the largest quadtrees the LDS carve-up sees, grouped
+    quadtree launches are off below 128 frames, so a second call with 130 frames covers the grouped launch path on a
+    subset), every frame against the oracle: count, keypoint bit patterns, descriptors, order."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE, ORBextractor
+    w, h, nf = 1920, 1080, 4000
+    oe = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    imgs = [synth_frame(20000 + i, h, w, sparse=(i % 5 == 4)) for i in range(32)]
+    ref = [oe(im, cap=4400) for im in imgs]
+    e = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=130)
+    cap = e.capacity()
+    for B, order in ((32, list(range(32))), (130, [(7 * i) % 32 for i in range(130)])):
+        d_gray = torch.from_numpy(np.stack([imgs[i] for i in order])).cuda()
+        d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+        e.extract_batch_device(d_gray.data_ptr(), B, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert e.overflow() == 0
+        n, kps, desc = d_n.cpu().numpy(), d_kps.cpu().numpy(), d_desc.cpu().numpy()
+        for b, i in enumerate(order):
+            ok, od = ref[i]
+            assert_same_output(kps[b, :n[b]].copy().view(KP_DTYPE).reshape(-1), desc[b, :n[b]], ok, od)
+            assert not desc[b, n[b]:].any() and not kps[b, n[b]:].any()   # padding stays zero (all-gather ready)
+        del d_gray, d_kps, d_desc, d_n
+
+
 @pytest.mark.parametrize("seed,box", [(0, (200, 150, 96, 96)), (1, (19, 19, 60, 60)), (2, (500, 380, 120, 80)), (3, (300, 30, 40, 400))])
 def test_clustered_corners_deep_quadtree(oracle, ext, seed, box):
     """All corners inside a small box.  Boxes 0-2: the reference quadtree stops as soon as a pass leaves the node count

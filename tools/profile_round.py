@@ -51,6 +51,10 @@ if bench_line:
     json.dump(bench_line, open(os.path.join(OUT, f"{tag}_bench_under_rocprof.json"), "w"), indent=1)
 
 frames = bench_line["config"]["frames_per_launch"] if bench_line else 1024
+# the shape the counters belong to: bench.py attaches counter-derived figures to a line only when all five keys match
+cfg = bench_line["config"] if bench_line else {}
+shape = {"width": cfg.get("width", 640), "height": cfg.get("height", 480), "nfeatures": cfg.get("nfeatures", 1000),
+         "workload": cfg.get("workload_name", "S"), "frames_per_launch": frames}
 
 
 def pmc_multi(counters):
@@ -71,7 +75,7 @@ def pmc(counter):
 
 
 fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
-hbm = {"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "frames_per_launch": frames,
+hbm = {"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "frames_per_launch": frames, "shape": shape,
        "command": " ".join(["python", "bench.py"] + bench_args),
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB per launch as reported. "
                "gfx950 correction calibrated on this repo's access shapes (profiles/r01_fetch_calibration.txt): HBM read "
@@ -81,7 +85,7 @@ hbm = {"FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "frames_per_launch": fram
 json.dump(hbm, open(os.path.join(OUT, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 vb = pmc("VALUBusy")
 sq = pmc_multi(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"])
-json.dump({"VALUBusy_percent": {k: v["mean_per_launch"] for k, v in vb.items()}, "frames_per_launch": frames,
+json.dump({"VALUBusy_percent": {k: v["mean_per_launch"] for k, v in vb.items()}, "frames_per_launch": frames, "shape": shape,
            "SQ_INSTS_VALU_per_launch": {k: v["mean_per_launch"] for k, v in sq["SQ_INSTS_VALU"].items()},
            "SQ_INSTS_SALU_per_launch": {k: v["mean_per_launch"] for k, v in sq["SQ_INSTS_SALU"].items()},
            "SQ_WAVES_per_launch": {k: v["mean_per_launch"] for k, v in sq["SQ_WAVES"].items()},
