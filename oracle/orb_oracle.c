@@ -1156,6 +1156,147 @@ int orc_features_in_area(const float *xy, const int32_t *octave, const uint32_t 
     return n;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * M4  projection-gated searches (src/ORBmatcher.cc:63-157, :1578-1724)
+ * ---------------------------------------------------------------------------------------------- */
+int orc_search_by_projection(const uint8_t *descF, const float *xyF, const int32_t *octF, int nF, const uint32_t *cell_off,
+                             const uint32_t *cell_idx, float minx, float miny, float gw_inv, float gh_inv,
+                             const float *uRight, const uint8_t *blocked, const orc_proj_query *q, const uint8_t *qdesc,
+                             int nq, int th, float nnratio, int ratio_rule, int32_t *match, int32_t *best, int32_t *second)
+{
+    if (nF < 0 || nq < 0) return -1;
+    uint8_t *taken = (uint8_t *)calloc((size_t)(nF > 0 ? nF : 1), 1); /* slot holds a MapPoint with Observations() > 0 */
+    uint32_t *cand = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nF > 0 ? nF : 1));
+    if (blocked)
+        for (int i = 0; i < nF; i++) taken[i] = blocked[i] ? 1 : 0;
+    for (int i = 0; i < nq; i++) {
+        const orc_proj_query *Q = &q[i];
+        match[i] = -1;
+        if (best) best[i] = 256;
+        if (second) second[i] = 256;
+        const int nc = orc_features_in_area(xyF, octF, cell_off, cell_idx, minx, miny, gw_inv, gh_inv, Q->u, Q->v, Q->r,
+                                            Q->min_level, Q->max_level, cand, nF);
+        if (nc <= 0) continue; /* :94 / :1635 */
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = (int)cand[k];
+            if (taken[idx]) continue; /* :108-110 / :1647-1649 */
+            if ((Q->flags & 2) && uRight && uRight[idx] > 0) { /* :114-119 / :1654-1660 */
+                const float er = fabsf(Q->ur - uRight[idx]);
+                if (er > Q->r) continue;
+            }
+            const int dist = orc_hamming(qdesc + (size_t)i * 32, descF + (size_t)idx * 32);
+            if (dist < bestDist) { /* :128-140 */
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = octF[idx];
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = octF[idx];
+                bestDist2 = dist;
+            }
+        }
+        if (best) best[i] = bestDist;
+        if (second) second[i] = bestDist2;
+        if (bestDist <= th) { /* :143 / :1673 */
+            if (ratio_rule && bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            match[i] = bestIdx;                   /* F.mvpMapPoints[bestIdx] = pMP */
+            taken[bestIdx] = (Q->flags & 1) ? 1 : 0; /* later queries skip the slot iff this point has observations */
+        }
+    }
+    free(taken);
+    free(cand);
+    return 0;
+}
+
+/* r = A (3x3, row-major, row stride sa) * b (3 vector), the stub's float accumulation or OpenCV's double accumulation */
+static void mat3_mul_vec(const float *A, int sa, const float b[3], int gemm_double, float r[3])
+{
+    for (int y = 0; y < 3; y++) {
+        if (gemm_double) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (double)A[y * sa + k] * (double)b[k];
+            r[y] = (float)s;
+        } else {
+            float s = 0;
+            for (int k = 0; k < 3; k++) s += A[y * sa + k] * b[k];
+            r[y] = s;
+        }
+    }
+}
+
+int orc_proj_queries_last_frame(const float Tcw_cur[16], const float Tcw_last[16], float fx, float fy, float cx, float cy,
+                                float mbf, float mb, float minx, float maxx, float miny, float maxy,
+                                const float *scale_factors, int nlast, const uint8_t *has_mp, const uint8_t *outlier,
+                                const float *world_pos, const int32_t *octave_last, const uint8_t *mp_obs_gt0, float th,
+                                int mono, int gemm_double, orc_proj_query *q, uint8_t *valid)
+{
+    /* :1593-1607: Rcw, tcw, twc = -Rcw.t() * tcw, Rlw, tlw, tlc = Rlw * twc + tlw */
+    float Rt_neg[9], tcw[3], twc[3], tlw[3], tlc[3];
+    for (int y = 0; y < 3; y++) {
+        tcw[y] = Tcw_cur[y * 4 + 3];
+        tlw[y] = Tcw_last[y * 4 + 3];
+        for (int x = 0; x < 3; x++) Rt_neg[y * 3 + x] = (float)((double)Tcw_cur[x * 4 + y] * -1.0); /* -(Rcw.t()) */
+    }
+    mat3_mul_vec(Rt_neg, 3, tcw, gemm_double, twc);
+    mat3_mul_vec(Tcw_last, 4, twc, gemm_double, tlc);
+    for (int y = 0; y < 3; y++) tlc[y] = tlc[y] + tlw[y];
+    const int forward = tlc[2] > mb && !mono;   /* :1604 */
+    const int backward = -tlc[2] > mb && !mono; /* :1607 */
+    for (int i = 0; i < nlast; i++) {
+        valid[i] = 0;
+        memset(&q[i], 0, sizeof(q[i]));
+        if (!has_mp[i] || outlier[i]) continue; /* :1613-1617 */
+        float x3Dc[3];
+        mat3_mul_vec(Tcw_cur, 4, world_pos + 3 * (size_t)i, gemm_double, x3Dc); /* :1621 Rcw * x3Dw + tcw */
+        for (int y = 0; y < 3; y++) x3Dc[y] = x3Dc[y] + tcw[y];
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / (double)x3Dc[2]); /* :1624 */
+        if (invzc < 0) continue;
+        const float u = fx * xc * invzc + cx;
+        const float v = fy * yc * invzc + cy;
+        if (u < minx || u > maxx) continue; /* :1629-1632 */
+        if (v < miny || v > maxy) continue;
+        const int nLastOctave = octave_last[i];
+        const float radius = th * scale_factors[nLastOctave]; /* :1642 */
+        q[i].u = u;
+        q[i].v = v;
+        q[i].r = radius;
+        if (forward) { q[i].min_level = nLastOctave; q[i].max_level = -1; }          /* :1645 */
+        else if (backward) { q[i].min_level = 0; q[i].max_level = nLastOctave; }     /* :1647 */
+        else { q[i].min_level = nLastOctave - 1; q[i].max_level = nLastOctave + 1; } /* :1649 */
+        q[i].ur = u - mbf * invzc; /* :1656 */
+        q[i].flags = (mp_obs_gt0[i] ? 1 : 0) | 2;
+        valid[i] = 1;
+    }
+    return 0;
+}
+
+int orc_proj_queries_local_map(const float *scale_factors, int nmp, const uint8_t *in_view, const uint8_t *bad,
+                               const int32_t *scale_level, const float *view_cos, const float *proj_xyr,
+                               const uint8_t *mp_obs_gt0, float th, orc_proj_query *q, uint8_t *valid)
+{
+    const int bFactor = th != 1.0; /* :67 */
+    for (int i = 0; i < nmp; i++) {
+        valid[i] = 0;
+        memset(&q[i], 0, sizeof(q[i]));
+        if (!in_view[i] || bad[i]) continue; /* :73-77 */
+        const int lvl = scale_level[i];
+        float r = (double)view_cos[i] > 0.998 ? 2.5f : 4.0f; /* RadiusByViewingCos :159-165 */
+        if (bFactor) r *= th;
+        q[i].u = proj_xyr[3 * i];
+        q[i].v = proj_xyr[3 * i + 1];
+        q[i].r = r * scale_factors[lvl]; /* :91 */
+        q[i].min_level = lvl - 1;
+        q[i].max_level = lvl;
+        q[i].ur = proj_xyr[3 * i + 2];
+        q[i].flags = (mp_obs_gt0[i] ? 1 : 0) | 2;
+        valid[i] = 1;
+    }
+    return 0;
+}
+
 /* ---- 8(f).4: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) ---- */
 static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
 

@@ -167,6 +167,43 @@ int orc_features_in_area(const float *xy, const int32_t *octave, const uint32_t 
                          float minx, float miny, float gw_inv, float gh_inv, float x, float y, float r, int min_level,
                          int max_level, uint32_t *out, int cap);
 
+/* ---- M4: the projection-gated searches (src/ORBmatcher.cc:63-157 local map, :1578-1724 last frame; perfect/ :1727-1911) ----
+ * One query = one MapPoint that survived the reference's gating: GetFeaturesInArea(u, v, r, min_level, max_level) on the
+ * frame, the right-image gate (candidate idx skipped when uRight[idx] > 0 and fabs(ur - uRight[idx]) > r, :114-119 /
+ * :1654-1660; both call sites compare against the very expression they pass as the search radius), best / second-best
+ * with the :128-140 idiom over the candidates whose slot is free.  A slot is taken when the frame feature already holds a
+ * MapPoint with Observations() > 0 (blocked[], :108-110 / :1647-1649) or when an EARLIER query of this call put such a
+ * point there -- the loop assigns F.mvpMapPoints[bestIdx] = pMP as it goes, so queries are not independent.
+ * flags: bit 0 = the query's MapPoint has Observations() > 0 (its assignment takes the slot), bit 1 = right-image gate on.
+ * ratio_rule 1 = reject when bestLevel == bestLevel2 && bestDist > nnratio * bestDist2 (:143-146); 0 = none (:1673).
+ * match[q] = frame feature the query is assigned to (the host replays F.mvpMapPoints[match] = pMP; nmatches++ in query
+ * order), -1 = none. */
+typedef struct orc_proj_query {
+    float u, v, r;
+    int32_t min_level, max_level;
+    float ur;
+    int32_t flags;
+    int32_t pad;
+} orc_proj_query;
+int orc_search_by_projection(const uint8_t *descF, const float *xyF, const int32_t *octF, int nF, const uint32_t *cell_off,
+                             const uint32_t *cell_idx, float minx, float miny, float gw_inv, float gh_inv,
+                             const float *uRight /* nF or NULL */, const uint8_t *blocked /* nF or NULL */,
+                             const orc_proj_query *q, const uint8_t *qdesc, int nq, int th, float nnratio, int ratio_rule,
+                             int32_t *match, int32_t *best, int32_t *second);
+/* The reference's host steps in front of that core, restated with the float operation order of the code as compiled
+ * against oracle/refbuild's cv stub (cv::Mat products accumulate in float, k ascending; real OpenCV's gemm accumulates
+ * floats in double -- gemm_double = 1 -- the product's shim uses whatever cv::Mat it is linked with):
+ * last-frame variant (:1593-1640): valid[i] = 0 when last feature i yields no query. */
+int orc_proj_queries_last_frame(const float Tcw_cur[16], const float Tcw_last[16], float fx, float fy, float cx, float cy,
+                                float mbf, float mb, float minx, float maxx, float miny, float maxy,
+                                const float *scale_factors, int nlast, const uint8_t *has_mp, const uint8_t *outlier,
+                                const float *world_pos /* nlast x 3 */, const int32_t *octave_last, const uint8_t *mp_obs_gt0,
+                                float th, int mono, int gemm_double, orc_proj_query *q, uint8_t *valid);
+/* local-map variant (:67-92): track_in_view / bad / scale level / view cos / proj x, y, xr per MapPoint */
+int orc_proj_queries_local_map(const float *scale_factors, int nmp, const uint8_t *in_view, const uint8_t *bad,
+                               const int32_t *scale_level, const float *view_cos, const float *proj_xyr /* nmp x 3 */,
+                               const uint8_t *mp_obs_gt0, float th, orc_proj_query *q, uint8_t *valid);
+
 /* ---- 8(f).4: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) for a batch of map points ----
  * point p observes descriptors pool[idx[off[p] .. off[p+1])]; best_idx[p] = position (inside the point's list) of the
  * descriptor with the least median distance to the others (first on ties), median[p] that median; -1 / -1 if empty. */

@@ -151,6 +151,159 @@ int REF_NAME(search_by_bow_kf_kf)(const uint8_t *desc1, int n1, const uint8_t *v
     return n;
 }
 
+/* ---- M4 / M9: the two per-frame projection searches on mock Frames built from flat arrays --------------------------
+ * Current frame: descriptors, keypoints (x, y, octave, angle), mvuRight, per-feature MapPoint state stateC (0 = NULL,
+ * 1 = a MapPoint with Observations() == 0, 2 = one with Observations() > 0), pose, intrinsics, image bounds, grid cell
+ * inverses, scale factors; its grid is built by the reference's own Frame::AssignFeaturesToGrid (sliced).
+ * assigned[nC] on return: -1 = NULL, -2 = the pre-existing MapPoint is still there, k >= 0 = the MapPoint of query k. */
+struct RefFrameArgs {
+    const uint8_t *desc;
+    const float *xy;      /* nC x 2 */
+    const int32_t *octave;
+    const float *angle;
+    const float *uRight;
+    const uint8_t *state;
+    int n;
+    const float *Tcw;     /* 16 floats, row-major 4x4 */
+    float fx, fy, cx, cy, mbf, mb;
+    float minx, maxx, miny, maxy, gw_inv, gh_inv;
+    const float *scale_factors;
+    int nlevels;
+};
+
+static void build_frame(const RefFrameArgs &a, Frame &f, std::vector<MapPoint> &own)
+{
+    f.N = a.n;
+    f.mDescriptors = cv::Mat(a.n, 32, CV_8UC1, (void *)a.desc);
+    f.mvKeys.assign((size_t)a.n, cv::KeyPoint());
+    for (int i = 0; i < a.n; i++) {
+        f.mvKeys[(size_t)i].pt = cv::Point2f(a.xy[2 * i], a.xy[2 * i + 1]);
+        f.mvKeys[(size_t)i].octave = a.octave[i];
+        f.mvKeys[(size_t)i].angle = a.angle ? a.angle[i] : 0.f;
+    }
+    f.mvKeysUn = f.mvKeys;
+    f.mvuRight.assign((size_t)a.n, -1.f);
+    if (a.uRight) f.mvuRight.assign(a.uRight, a.uRight + a.n);
+    f.mvDepth.assign((size_t)a.n, -1.f);
+    own.assign((size_t)a.n, MapPoint());
+    f.mvpMapPoints.assign((size_t)a.n, (MapPoint *)0);
+    for (int i = 0; i < a.n; i++)
+        if (a.state && a.state[i]) {
+            own[(size_t)i].nObs = a.state[i] == 2 ? 3 : 0;
+            f.mvpMapPoints[(size_t)i] = &own[(size_t)i];
+        }
+    f.mvbOutlier.assign((size_t)a.n, false);
+    if (a.Tcw) {
+        f.mTcw = cv::Mat(4, 4, CV_32F);
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) f.mTcw.at<float>(y, x) = a.Tcw[y * 4 + x];
+    }
+    f.fx = a.fx; f.fy = a.fy; f.cx = a.cx; f.cy = a.cy; f.mbf = a.mbf; f.mb = a.mb;
+    Frame::mnMinX = a.minx; Frame::mnMaxX = a.maxx; Frame::mnMinY = a.miny; Frame::mnMaxY = a.maxy;
+    Frame::mfGridElementWidthInv = a.gw_inv;
+    Frame::mfGridElementHeightInv = a.gh_inv;
+    f.mnScaleLevels = a.nlevels;
+    f.mvScaleFactors.assign(a.scale_factors, a.scale_factors + a.nlevels);
+    f.mvInvScaleFactors.assign((size_t)a.nlevels, 1.f);
+    for (int l = 0; l < a.nlevels; l++) f.mvInvScaleFactors[(size_t)l] = 1.0f / a.scale_factors[l];
+    f.AssignFeaturesToGrid();
+}
+
+static void flatten_assigned(const Frame &f, const std::vector<MapPoint> &own, const std::vector<MapPoint> &qpool, int32_t *assigned)
+{
+    for (int i = 0; i < f.N; i++) {
+        const MapPoint *p = f.mvpMapPoints[(size_t)i];
+        if (!p) assigned[i] = -1;
+        else if (!own.empty() && p >= own.data() && p < own.data() + own.size()) assigned[i] = -2;
+        else assigned[i] = (int32_t)(p - qpool.data());
+    }
+}
+
+/* SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)  src/ORBmatcher.cc:1578-1724.
+ * Last frame: per feature has_mp / outlier / world position / MapPoint descriptor / Observations() > 0, octave, angle, pose.
+ * pts_last / pts_cur / npts (perfect/ overload only, :1727-1911): the 2-D point pairs it returns. */
+int REF_NAME(search_by_projection_last_frame)(const RefFrameArgs *cur, const float *TcwL, int nL, const uint8_t *has_mp,
+                                              const uint8_t *outlier, const float *world_pos, const uint8_t *mpdesc,
+                                              const uint8_t *obs_gt0, const int32_t *octL, const float *angL,
+                                              const float *xyL, float th, int mono, float nnratio, int check_ori,
+                                              int32_t *assigned, float *pts_last, float *pts_cur, int32_t *npts)
+{
+    Frame C, L;
+    std::vector<MapPoint> own, pool((size_t)(nL > 0 ? nL : 1));
+    build_frame(*cur, C, own);
+    L.N = nL;
+    L.mTcw = cv::Mat(4, 4, CV_32F);
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++) L.mTcw.at<float>(y, x) = TcwL[y * 4 + x];
+    L.mvKeys.assign((size_t)nL, cv::KeyPoint());
+    L.mvpMapPoints.assign((size_t)nL, (MapPoint *)0);
+    L.mvbOutlier.assign((size_t)nL, false);
+    for (int i = 0; i < nL; i++) {
+        L.mvKeys[(size_t)i].octave = octL[i];
+        L.mvKeys[(size_t)i].angle = angL ? angL[i] : 0.f;
+        if (xyL) L.mvKeys[(size_t)i].pt = cv::Point2f(xyL[2 * i], xyL[2 * i + 1]);
+        L.mvbOutlier[(size_t)i] = outlier[i] != 0;
+        if (has_mp[i]) {
+            MapPoint &mp = pool[(size_t)i];
+            mp.world_pos = cv::Mat(3, 1, CV_32F);
+            for (int k = 0; k < 3; k++) mp.world_pos.at<float>(k) = world_pos[3 * i + k];
+            mp.mDescriptor = cv::Mat(1, 32, CV_8UC1, (void *)(mpdesc + (size_t)i * 32)).clone();
+            mp.nObs = obs_gt0[i] ? 2 : 0;
+            L.mvpMapPoints[(size_t)i] = &mp;
+        }
+    }
+    L.mvKeysUn = L.mvKeys;
+    ORBmatcher m(nnratio, check_ori != 0);
+    int n;
+#ifdef REF_PERFECT
+    if (pts_last) {
+        std::vector<cv::Point2f> pl, pc;
+        n = m.SearchByProjection(C, L, th, mono != 0, pl, pc);
+        *npts = (int32_t)pl.size();
+        for (size_t k = 0; k < pl.size(); k++) {
+            pts_last[2 * k] = pl[k].x; pts_last[2 * k + 1] = pl[k].y;
+            pts_cur[2 * k] = pc[k].x; pts_cur[2 * k + 1] = pc[k].y;
+        }
+    } else
+#endif
+    {
+        (void)pts_last; (void)pts_cur;
+        if (npts) *npts = -1;
+        n = m.SearchByProjection(C, L, th, mono != 0);
+    }
+    flatten_assigned(C, own, pool, assigned);
+    return n;
+}
+
+/* SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th)  src/ORBmatcher.cc:63-157 */
+int REF_NAME(search_by_projection_local_map)(const RefFrameArgs *cur, int nmp, const uint8_t *in_view, const uint8_t *bad,
+                                             const int32_t *scale_level, const float *view_cos, const float *proj_xyr,
+                                             const uint8_t *mpdesc, const uint8_t *obs_gt0, float th, float nnratio,
+                                             int32_t *assigned)
+{
+    Frame F;
+    std::vector<MapPoint> own, pool((size_t)(nmp > 0 ? nmp : 1));
+    build_frame(*cur, F, own);
+    std::vector<MapPoint *> v((size_t)nmp);
+    for (int i = 0; i < nmp; i++) {
+        MapPoint &mp = pool[(size_t)i];
+        mp.mbTrackInView = in_view[i] != 0;
+        mp.mbBad = bad[i] != 0;
+        mp.mnTrackScaleLevel = scale_level[i];
+        mp.mTrackViewCos = view_cos[i];
+        mp.mTrackProjX = proj_xyr[3 * i];
+        mp.mTrackProjY = proj_xyr[3 * i + 1];
+        mp.mTrackProjXR = proj_xyr[3 * i + 2];
+        mp.mDescriptor = cv::Mat(1, 32, CV_8UC1, (void *)(mpdesc + (size_t)i * 32)).clone();
+        mp.nObs = obs_gt0[i] ? 2 : 0;
+        v[(size_t)i] = &mp;
+    }
+    ORBmatcher m(nnratio, true);
+    const int n = m.SearchByProjection(F, v, th);
+    flatten_assigned(F, own, pool, assigned);
+    return n;
+}
+
 void REF_NAME(matcher_constants)(int *th_low, int *th_high, int *histo_length)
 {
     *th_low = ORBmatcher::TH_LOW;
