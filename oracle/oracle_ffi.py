@@ -90,6 +90,10 @@ def lib():
     L.orc_stereo_matches.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
     L.orc_bow_transform.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int] + [vp] * 6 + [vp] * 4
     L.orc_distinctive.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp]
+    cf, ci = C.c_float, C.c_int
+    L.orc_search_by_projection.argtypes = [vp, vp, vp, ci, vp, vp, cf, cf, cf, cf, vp, vp, vp, vp, ci, ci, cf, ci, vp, vp, vp]
+    L.orc_proj_queries_last_frame.argtypes = [vp, vp] + [cf] * 10 + [vp, ci, vp, vp, vp, vp, vp, cf, ci, ci, vp, vp]
+    L.orc_proj_queries_local_map.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp]
     _lib = L
     return L
 
@@ -437,3 +441,61 @@ def bow_transform(voc, desc, levelsup=4):
     return dict(word=fw[:n].copy(), node=fn[:n].copy(), weight=fwt[:n].copy(), bow_id=bid[:nb.value].copy(),
                 bow_val=bval[:nb.value].copy(), fv_node=fvn[:nf.value].copy(), fv_off=fvo[:nf.value + 1].copy(),
                 fv_idx=fvi[:int(fvo[nf.value])].copy())
+
+
+# ---- M4: projection-gated searches ------------------------------------------------------------------------------------
+PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                             ("ur", "<f4"), ("flags", "<i4"), ("pad", "<i4")])
+
+
+def search_by_projection(descF, xyF, octF, grid, bounds, uRight, blocked, queries, qdesc, th, nnratio, ratio_rule):
+    """orc_search_by_projection: grid = (cell_off, cell_idx), bounds = (minx, miny, gw_inv, gh_inv); returns
+    (match[nq], best[nq], second[nq])"""
+    descF = np.ascontiguousarray(descF, np.uint8).reshape(-1, 32)
+    xyF = np.ascontiguousarray(xyF, np.float32).reshape(-1, 2)
+    octF = np.ascontiguousarray(octF, np.int32)
+    off, idx = (np.ascontiguousarray(a, np.uint32) for a in grid)
+    uR = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+    bl = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+    q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE)
+    qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+    assert len(qd) == len(q)
+    m, b, s2 = (np.zeros(len(q), np.int32) for _ in range(3))
+    rc = lib().orc_search_by_projection(_p(descF), _p(xyF), _p(octF), len(descF), _p(off), _p(idx), *[float(v) for v in bounds],
+                                        _p(uR), _p(bl), _p(q), _p(qd), len(q), int(th), float(nnratio), int(ratio_rule),
+                                        _p(m), _p(b), _p(s2))
+    assert rc == 0
+    return m, b, s2
+
+
+def proj_queries_last_frame(TcwC, TcwL, K, bounds_img, scale_factors, has_mp, outlier, world_pos, octL, obs_gt0, th, mono,
+                            gemm_double=False):
+    """the host gating of SearchByProjection(CurrentFrame, LastFrame) (:1593-1640): K = (fx, fy, cx, cy, mbf, mb),
+    bounds_img = (minx, maxx, miny, maxy); returns (queries, valid)"""
+    n = len(has_mp)
+    q = np.zeros(n, PROJ_QUERY_DTYPE)
+    valid = np.zeros(n, np.uint8)
+    a = [np.ascontiguousarray(TcwC, np.float32).reshape(16), np.ascontiguousarray(TcwL, np.float32).reshape(16)]
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    hm, ol, og = (np.ascontiguousarray(x, np.uint8) for x in (has_mp, outlier, obs_gt0))
+    wp = np.ascontiguousarray(world_pos, np.float32).reshape(-1, 3)
+    oc = np.ascontiguousarray(octL, np.int32)
+    rc = lib().orc_proj_queries_last_frame(_p(a[0]), _p(a[1]), *[float(v) for v in K], *[float(v) for v in bounds_img], _p(sf), n,
+                                           _p(hm), _p(ol), _p(wp), _p(oc), _p(og), float(th), int(mono), int(gemm_double),
+                                           _p(q), _p(valid))
+    assert rc == 0
+    return q, valid
+
+
+def proj_queries_local_map(scale_factors, in_view, bad, scale_level, view_cos, proj_xyr, obs_gt0, th):
+    n = len(in_view)
+    q = np.zeros(n, PROJ_QUERY_DTYPE)
+    valid = np.zeros(n, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    iv, bd, og = (np.ascontiguousarray(x, np.uint8) for x in (in_view, bad, obs_gt0))
+    sl = np.ascontiguousarray(scale_level, np.int32)
+    vc = np.ascontiguousarray(view_cos, np.float32)
+    pr = np.ascontiguousarray(proj_xyr, np.float32).reshape(-1, 3)
+    rc = lib().orc_proj_queries_local_map(_p(sf), n, _p(iv), _p(bd), _p(sl), _p(vc), _p(pr), _p(og), float(th), _p(q), _p(valid))
+    assert rc == 0
+    return q, valid

@@ -61,6 +61,29 @@ def build_shims():
 
 
 _lib = None
+_PERFECT = os.path.join(_OUT, "libref_perfect.so")
+_perfect = None
+
+
+class RefFrameArgs(C.Structure):
+    """oracle/refbuild/ref_matcher_api.cpp: the current frame of the projection searches as flat arrays"""
+    _fields_ = [("desc", C.c_void_p), ("xy", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p),
+                ("uRight", C.c_void_p), ("state", C.c_void_p), ("n", C.c_int), ("Tcw", C.c_void_p),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float),
+                ("mb", C.c_float), ("minx", C.c_float), ("maxx", C.c_float), ("miny", C.c_float), ("maxy", C.c_float),
+                ("gw_inv", C.c_float), ("gh_inv", C.c_float), ("scale_factors", C.c_void_p), ("nlevels", C.c_int)]
+
+
+def perfect_lib():
+    """oracle/_ref/libref_perfect.so: the same recipe over perfect/src + perfect/include (the reference's second copy of
+    the path; its ORBmatcher has the extra SearchByProjection overload of SURVEY 8(a) M9)"""
+    global _perfect
+    if _perfect is None:
+        build()
+        if not os.path.exists(_PERFECT):
+            raise RuntimeError("oracle/_ref/libref_perfect.so is missing")
+        _perfect = _declare(C.CDLL(_PERFECT))
+    return _perfect
 
 
 def lib():
@@ -68,7 +91,27 @@ def lib():
     if _lib is not None:
         return _lib
     build()
-    L = C.CDLL(_LIB)
+    _lib = _declare(C.CDLL(_LIB))
+    return _lib
+
+
+class use_perfect:
+    """with use_perfect(): every ref_* call of this module (RefExtractor, search_by_bow_*, ...) goes to
+    libref_perfect.so -- the reference's perfect/src + perfect/include copy -- instead of libref_orb.so"""
+
+    def __enter__(self):
+        global _lib
+        self.prev = lib()
+        _lib = perfect_lib()
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
+def _declare(L):
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     L.ref_ext_create.restype = vp
     L.ref_ext_create.argtypes = [ci, cf, ci, ci, ci]
@@ -100,8 +143,15 @@ def lib():
     L.ref_distinctive.argtypes = [vp, ci, vp, vp, ci, vp, vp]
     L.ref_predict_scale.argtypes = [cf, cf, cf, ci]
     L.ref_stereo_matches.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
-    _lib = L
+    _declare_projection(L, "ref_")
     return L
+
+
+def _declare_projection(L, prefix):
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    getattr(L, prefix + "search_by_projection_last_frame").argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, cf, ci,
+                                                                       vp, vp, vp, vp]
+    getattr(L, prefix + "search_by_projection_local_map").argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp]
 
 
 _SHIM = os.path.join(_OUT, "libshim_ref.so")
@@ -129,6 +179,7 @@ def shim_lib():
     L.shim_search_by_bow_kf_f.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, cf, ci, vp]
     L.shim_search_by_bow_kf_kf.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci] * 2 + [cf, ci, vp]
     L.shim_matcher_constants.argtypes = [vp, vp, vp]
+    _declare_projection(L, "shim_")
     _shim = L
     return L
 
@@ -418,3 +469,67 @@ def stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mbf, mb):
     d = np.zeros(max(len(kl), 1), np.float32)
     lib().ref_stereo_matches(exL.h, exR.h, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), float(mbf), float(mb), _p(u), _p(d))
     return u[:len(kl)], d[:len(kl)]
+
+
+# ---- M4 / M9: the per-frame projection searches on mock Frames ----------------------------------------------------------
+def _frame_args(cur, keep):
+    """cur: dict(desc, xy, octave, angle, uRight, state, Tcw, K=(fx, fy, cx, cy, mbf, mb), bounds=(minx, maxx, miny, maxy),
+    gw_inv, gh_inv, scale_factors)"""
+    a = RefFrameArgs()
+    arrs = dict(desc=np.ascontiguousarray(cur["desc"], np.uint8).reshape(-1, 32), xy=np.ascontiguousarray(cur["xy"], np.float32).reshape(-1, 2),
+                octave=np.ascontiguousarray(cur["octave"], np.int32), angle=np.ascontiguousarray(cur["angle"], np.float32),
+                uRight=np.ascontiguousarray(cur["uRight"], np.float32), state=np.ascontiguousarray(cur["state"], np.uint8),
+                Tcw=np.ascontiguousarray(cur["Tcw"], np.float32).reshape(16),
+                scale_factors=np.ascontiguousarray(cur["scale_factors"], np.float32))
+    keep.append(arrs)
+    for k, v in arrs.items():
+        setattr(a, k, v.ctypes.data)
+    a.n = len(arrs["desc"])
+    a.fx, a.fy, a.cx, a.cy, a.mbf, a.mb = [float(v) for v in cur["K"]]
+    a.minx, a.maxx, a.miny, a.maxy = [float(v) for v in cur["bounds"]]
+    a.gw_inv, a.gh_inv = float(cur["gw_inv"]), float(cur["gh_inv"])
+    a.nlevels = len(arrs["scale_factors"])
+    return a
+
+
+def search_by_projection_last_frame(cur, last, th, mono, nnratio=0.9, check_ori=True, shim=False, perfect=False, points=False):
+    """ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (src/ORBmatcher.cc:1578-1724).
+    last: dict(Tcw, has_mp, outlier, world_pos, mpdesc, obs_gt0, octave, angle, xy).  Returns (assigned[nC], return value)
+    and, with points=True (perfect/ overload :1727-1911 only), the two 2-D point lists."""
+    keep = []
+    a = _frame_args(cur, keep)
+    n = len(last["has_mp"])
+    L = dict(Tcw=np.ascontiguousarray(last["Tcw"], np.float32).reshape(16), has_mp=np.ascontiguousarray(last["has_mp"], np.uint8),
+             outlier=np.ascontiguousarray(last["outlier"], np.uint8), world_pos=np.ascontiguousarray(last["world_pos"], np.float32).reshape(-1, 3),
+             mpdesc=np.ascontiguousarray(last["mpdesc"], np.uint8).reshape(-1, 32), obs_gt0=np.ascontiguousarray(last["obs_gt0"], np.uint8),
+             octave=np.ascontiguousarray(last["octave"], np.int32), angle=np.ascontiguousarray(last["angle"], np.float32),
+             xy=np.ascontiguousarray(last["xy"], np.float32).reshape(-1, 2))
+    assigned = np.full(a.n, -9, np.int32)
+    pl, pc, npts = np.zeros((max(n, 1), 2), np.float32), np.zeros((max(n, 1), 2), np.float32), C.c_int32(-1)
+    lb = shim_lib() if shim else (perfect_lib() if perfect else lib())
+    fn = getattr(lb, ("shim_" if shim else "ref_") + "search_by_projection_last_frame")
+    rv = fn(C.byref(a), _p(L["Tcw"]), n, _p(L["has_mp"]), _p(L["outlier"]), _p(L["world_pos"]), _p(L["mpdesc"]), _p(L["obs_gt0"]),
+            _p(L["octave"]), _p(L["angle"]), _p(L["xy"]), float(th), int(mono), float(nnratio), int(check_ori), _p(assigned),
+            _p(pl) if points else None, _p(pc) if points else None, C.byref(npts))
+    if points:
+        assert npts.value >= 0, "this library has no SearchByProjection overload that returns point pairs"
+        return assigned, rv, pl[:npts.value].copy(), pc[:npts.value].copy()
+    return assigned, rv
+
+
+def search_by_projection_local_map(cur, mps, th, nnratio=0.8, shim=False, perfect=False):
+    """ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:63-157).
+    mps: dict(in_view, bad, scale_level, view_cos, proj_xyr, mpdesc, obs_gt0).  Returns (assigned[nF], return value)."""
+    keep = []
+    a = _frame_args(cur, keep)
+    n = len(mps["in_view"])
+    M = dict(in_view=np.ascontiguousarray(mps["in_view"], np.uint8), bad=np.ascontiguousarray(mps["bad"], np.uint8),
+             scale_level=np.ascontiguousarray(mps["scale_level"], np.int32), view_cos=np.ascontiguousarray(mps["view_cos"], np.float32),
+             proj_xyr=np.ascontiguousarray(mps["proj_xyr"], np.float32).reshape(-1, 3),
+             mpdesc=np.ascontiguousarray(mps["mpdesc"], np.uint8).reshape(-1, 32), obs_gt0=np.ascontiguousarray(mps["obs_gt0"], np.uint8))
+    assigned = np.full(a.n, -9, np.int32)
+    lb = shim_lib() if shim else (perfect_lib() if perfect else lib())
+    fn = getattr(lb, ("shim_" if shim else "ref_") + "search_by_projection_local_map")
+    rv = fn(C.byref(a), n, _p(M["in_view"]), _p(M["bad"]), _p(M["scale_level"]), _p(M["view_cos"]), _p(M["proj_xyr"]), _p(M["mpdesc"]),
+            _p(M["obs_gt0"]), float(th), float(nnratio), _p(assigned))
+    return assigned, rv

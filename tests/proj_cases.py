@@ -1,0 +1,190 @@
+"""Seeded cases for the projection-gated searches (ORBmatcher::SearchByProjection(Frame&, const Frame&,
+th, bMono) src/ORBmatcher.cc:1578-1724, (Frame&, const vector<MapPoint*>&, th) :63-157) and the host-side replay that turns
+the core's per-query matches into what the reference leaves in CurrentFrame.mvpMapPoints.  Test support only."""
+import numpy as np
+
+from oracle import oracle_ffi as O
+
+GRID_COLS, GRID_ROWS = 64, 48
+SCALE = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+
+
+def scale_factors(nlevels=8, sf=1.2):
+    s = np.ones(nlevels, np.float32)
+    for i in range(1, nlevels):
+        s[i] = np.float32(s[i - 1] * np.float32(sf))   # mvScaleFactor[i] = mvScaleFactor[i-1] * scaleFactor (float)
+    return s
+
+
+def _rot(rng, deg):
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    a = np.deg2rad(rng.normal(0, deg))
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+
+
+def _pose(rng, rot_deg, trans):
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = _rot(rng, rot_deg).astype(np.float32)
+    T[:3, 3] = np.asarray(trans, np.float32)
+    return T
+
+
+def current_frame(rng, n, w=640, h=480, stereo=True, dense_states=True):
+    """a mock current frame: keypoints over the image (some clustered so that search windows hold many candidates), random
+    descriptors, octaves, angles, mvuRight, and a MapPoint state per feature (0 none, 1 Observations() == 0, 2 > 0)"""
+    sf = scale_factors()
+    xy = np.stack([rng.uniform(0, w, n), rng.uniform(0, h, n)], 1).astype(np.float32)
+    if n > 20:   # clusters
+        k = n // 4
+        c = rng.integers(0, n, 6)
+        xy[:k] = (xy[c[rng.integers(0, 6, k)]] + rng.normal(0, 6, (k, 2))).astype(np.float32)
+        xy[:, 0] = np.clip(xy[:, 0], 0, w - 1e-3)
+        xy[:, 1] = np.clip(xy[:, 1], 0, h - 1e-3)
+    octave = rng.integers(0, 8, n).astype(np.int32)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    angle = rng.uniform(0, 360, n).astype(np.float32)
+    uR = np.full(n, -1, np.float32)
+    if stereo:
+        m = rng.random(n) < 0.7
+        uR[m] = (xy[m, 0] - rng.uniform(2, 60, m.sum())).astype(np.float32)
+    state = rng.choice([0, 0, 0, 1, 2], n).astype(np.uint8) if dense_states else np.zeros(n, np.uint8)
+    fx, fy, cx, cy = 535.4, 539.2, 320.1, 247.6   # TUM3.yaml
+    bf = 40.0
+    return dict(desc=desc, xy=xy, octave=octave, angle=angle, uRight=uR, state=state, Tcw=np.eye(4, dtype=np.float32),
+                K=(fx, fy, cx, cy, bf, bf / fx), bounds=(0.0, float(w), 0.0, float(h)),
+                gw_inv=np.float32(GRID_COLS) / np.float32(w), gh_inv=np.float32(GRID_ROWS) / np.float32(h), scale_factors=sf)
+
+
+def noisy_copy(rng, desc, max_flips):
+    d = desc.copy()
+    bits = np.unpackbits(d, axis=1)
+    for i in range(len(d)):
+        k = int(rng.integers(0, max_flips + 1))
+        if k:
+            bits[i, rng.choice(256, k, replace=False)] ^= 1
+    return np.packbits(bits, axis=1)
+
+
+def last_frame_case(rng, nC, nL, motion="small", stereo=True):
+    """(cur, last): last-frame MapPoints are 3-D points that project near features of the current frame under the poses;
+    several last features may target the same current feature (the greedy "slot taken" rule is exercised)"""
+    cur = current_frame(rng, nC, stereo=stereo)
+    fx, fy, cx, cy, mbf, mb = cur["K"]
+    tz = {"small": 0.0, "forward": 0.4, "backward": -0.4}[motion]
+    TcwL = _pose(rng, 2.0, rng.normal(0, 0.05, 3))
+    TcwC = TcwL.copy()
+    TcwC[:3, :3] = (_rot(rng, 1.0) @ TcwL[:3, :3].astype(np.float64)).astype(np.float32)
+    TcwC[:3, 3] = TcwL[:3, 3] + np.array([rng.normal(0, 0.02), rng.normal(0, 0.02), -tz], np.float32)
+    cur["Tcw"] = TcwC
+    tgt = rng.integers(0, max(nC, 1), nL) if nC else np.zeros(nL, np.int64)
+    if nL > 8 and nC:
+        tgt[: nL // 5] = tgt[rng.integers(0, nL, nL // 5)]   # shared targets
+    z = rng.uniform(0.4, 9.0, nL)
+    if nL > 10:
+        z[rng.integers(0, nL, 3)] *= -1   # behind the camera: invzc < 0
+    px = (cur["xy"][tgt] if nC else np.zeros((nL, 2))) + rng.normal(0, 2.5, (nL, 2))
+    if nL > 10:
+        px[rng.integers(0, nL, 3)] += 900   # outside the image bounds
+    Xc = np.stack([(px[:, 0] - cx) / fx * z, (px[:, 1] - cy) / fy * z, z], 1)
+    Rcw, tcw = TcwC[:3, :3].astype(np.float64), TcwC[:3, 3].astype(np.float64)
+    world = ((Xc - tcw) @ Rcw).astype(np.float32)   # Rcw^T (Xc - tcw)
+    octL = (np.clip(cur["octave"][tgt] + rng.integers(-1, 2, nL), 0, 7) if nC else np.zeros(nL)).astype(np.int32)
+    mpdesc = noisy_copy(rng, cur["desc"][tgt] if nC else np.zeros((nL, 32), np.uint8), 70)
+    last = dict(Tcw=TcwL, has_mp=(rng.random(nL) < 0.85).astype(np.uint8), outlier=(rng.random(nL) < 0.08).astype(np.uint8),
+                world_pos=world, mpdesc=mpdesc, obs_gt0=(rng.random(nL) < 0.8).astype(np.uint8), octave=octL,
+                angle=((cur["angle"][tgt] if nC else np.zeros(nL)) + rng.choice([0, 0, 0, 35, 120], nL) + rng.normal(0, 4, nL)).astype(np.float32) % np.float32(360),
+                xy=px.astype(np.float32))
+    return cur, last
+
+
+def local_map_case(rng, nF, nmp):
+    cur = current_frame(rng, nF)
+    tgt = rng.integers(0, max(nF, 1), nmp) if nF else np.zeros(nmp, np.int64)
+    if nmp > 8 and nF:
+        tgt[: nmp // 5] = tgt[rng.integers(0, nmp, nmp // 5)]
+    pxy = (cur["xy"][tgt] if nF else np.zeros((nmp, 2))) + rng.normal(0, 2.0, (nmp, 2))
+    uR = cur["uRight"][tgt] if nF else np.zeros(nmp)
+    pxr = np.where(uR > 0, uR + rng.normal(0, 3.0, nmp), pxy[:, 0] - 10)
+    mps = dict(in_view=(rng.random(nmp) < 0.9).astype(np.uint8), bad=(rng.random(nmp) < 0.05).astype(np.uint8),
+               scale_level=(np.clip(cur["octave"][tgt] + rng.integers(0, 2, nmp), 0, 7) if nF else np.zeros(nmp)).astype(np.int32),
+               view_cos=rng.choice([0.9, 0.99, 0.9985, 1.0], nmp).astype(np.float32),
+               proj_xyr=np.concatenate([pxy, pxr[:, None]], 1).astype(np.float32),
+               mpdesc=noisy_copy(rng, cur["desc"][tgt] if nF else np.zeros((nmp, 32), np.uint8), 80),
+               obs_gt0=(rng.random(nmp) < 0.85).astype(np.uint8))
+    return cur, mps
+
+
+def frame_grid(cur):
+    """(cell_off, cell_idx) of the frame as Frame::AssignFeaturesToGrid builds it (oracle; pinned to the sliced reference body)"""
+    minx, _, miny, _ = cur["bounds"]
+    return O.assign_grid(cur["xy"], minx, miny, cur["gw_inv"], cur["gh_inv"])
+
+
+def core_inputs(cur):
+    minx, _, miny, _ = cur["bounds"]
+    blocked = (np.asarray(cur["state"]) == 2).astype(np.uint8)   # a MapPoint with Observations() > 0 sits in the slot
+    return dict(descF=cur["desc"], xyF=cur["xy"], octF=cur["octave"], grid=frame_grid(cur),
+                bounds=(minx, miny, cur["gw_inv"], cur["gh_inv"]), uRight=cur["uRight"], blocked=blocked)
+
+
+def replay_last_frame(cur, last, valid, match_valid, check_ori=True):
+    """what the reference's loop leaves behind, from the core's per-query matches (queries = the valid last features in
+    order): assigned[nC] (-1 NULL, -2 pre-existing MapPoint, i >= 0 the MapPoint of last feature i), the return value, and
+    the (last, current) feature pairs in match order (the perfect/ overload's point lists)"""
+    nC = len(cur["desc"])
+    assigned = np.where(np.asarray(cur["state"]) > 0, -2, -1).astype(np.int32)
+    hist = [[] for _ in range(30)]
+    pairs = []
+    nm = 0
+    vi = np.nonzero(valid)[0]
+    for k, i in enumerate(vi):
+        f = int(match_valid[k])
+        if f < 0:
+            continue
+        assigned[f] = i
+        nm += 1
+        pairs.append((int(i), f))
+        if check_ori:
+            hist[O.rot_bin(float(last["angle"][i]), float(cur["angle"][f]))].append(f)
+    if check_ori:
+        keep = O.three_maxima([len(b) for b in hist])
+        for b in range(30):
+            if b not in keep:
+                for f in hist[b]:
+                    assigned[f] = -1
+                    nm -= 1
+    assert nC == len(assigned)
+    return assigned, nm, pairs
+
+
+def replay_local_map(cur, valid, match_valid):
+    assigned = np.where(np.asarray(cur["state"]) > 0, -2, -1).astype(np.int32)
+    nm = 0
+    vi = np.nonzero(valid)[0]
+    for k, i in enumerate(vi):
+        f = int(match_valid[k])
+        if f >= 0:
+            assigned[f] = i
+            nm += 1
+    return assigned, nm
+
+
+def oracle_last_frame(cur, last, th, mono, check_ori=True, th_high=100):
+    """oracle end to end: host gating (orc_proj_queries_last_frame) -> core (orc_search_by_projection) -> replay"""
+    q, valid = O.proj_queries_last_frame(cur["Tcw"], last["Tcw"], cur["K"], cur["bounds"], cur["scale_factors"], last["has_mp"],
+                                         last["outlier"], last["world_pos"], last["octave"], last["obs_gt0"], th, mono)
+    sel = valid.astype(bool)
+    m, b, s = O.search_by_projection(queries=q[sel], qdesc=np.asarray(last["mpdesc"]).reshape(-1, 32)[sel], th=th_high, nnratio=0.0,
+                                     ratio_rule=0, **core_inputs(cur))
+    return replay_last_frame(cur, last, valid, m, check_ori) + (q, valid, m)
+
+
+def oracle_local_map(cur, mps, th, nnratio=0.8, th_high=100):
+    q, valid = O.proj_queries_local_map(cur["scale_factors"], mps["in_view"], mps["bad"], mps["scale_level"], mps["view_cos"],
+                                        mps["proj_xyr"], mps["obs_gt0"], th)
+    sel = valid.astype(bool)
+    m, b, s = O.search_by_projection(queries=q[sel], qdesc=np.asarray(mps["mpdesc"]).reshape(-1, 32)[sel], th=th_high, nnratio=nnratio,
+                                     ratio_rule=1, **core_inputs(cur))
+    return replay_local_map(cur, valid, m) + (q, valid, m)

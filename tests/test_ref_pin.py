@@ -378,3 +378,100 @@ def test_stereo_matches_equal_sliced_reference(ref, oracle):
         assert np.array_equal(rd.view(np.uint32), od.view(np.uint32)), seed
         matched += int((ru >= 0).sum())
     assert matched > 300
+
+
+# ---------------------------------------------------------------------------------------------- M4 / M9
+def test_search_by_projection_last_frame_equals_reference(ref, oracle):
+    """SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (src/ORBmatcher.cc:1578-1724), the
+    per-frame matcher of TrackWithMotionModel: oracle (host gating + core + replay) == the reference's compiled body on mock
+    Frames -- CurrentFrame.mvpMapPoints slot by slot and the return value; forward / backward / small motion, mono and
+    stereo, rotation check on / off, slots taken by earlier queries and by pre-existing MapPoints, empty sides."""
+    import proj_cases as PC
+    total = 0
+    for seed in range(150):
+        rng = np.random.default_rng(7_000 + seed)
+        nC, nL = int(rng.choice([0, 1, 30, 300, 1000])), int(rng.choice([0, 1, 40, 400, 1000]))
+        mono = seed % 4 == 3
+        cur, last = PC.last_frame_case(rng, nC, nL, ["small", "forward", "backward"][seed % 3], stereo=not mono)
+        th, ori = float(rng.choice([7, 15, 15, 30])), bool(seed % 5)
+        a_ref, n_ref = ref.search_by_projection_last_frame(cur, last, th, mono, check_ori=ori)
+        a_or, n_or = PC.oracle_last_frame(cur, last, th, mono, check_ori=ori)[:2]
+        assert n_ref == n_or and np.array_equal(a_ref, a_or), (seed, nC, nL, mono, th)
+        total += n_ref
+    assert total > 5000
+
+
+def test_search_by_projection_local_map_equals_reference(ref, oracle):
+    """SearchByProjection(Frame &F, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:63-157, Tracking::SearchLocalPoints):
+    the bestLevel == bestLevel2 ratio rule, RadiusByViewingCos, the right-image gate, slots taken on the way."""
+    import proj_cases as PC
+    total = 0
+    for seed in range(150):
+        rng = np.random.default_rng(8_000 + seed)
+        nF, nmp = int(rng.choice([0, 1, 30, 300, 1000])), int(rng.choice([0, 1, 40, 400, 1500]))
+        cur, mps = PC.local_map_case(rng, nF, nmp)
+        th, nn = float(rng.choice([1, 1, 3, 5])), float(rng.choice([0.8, 0.7, 0.9]))
+        a_ref, n_ref = ref.search_by_projection_local_map(cur, mps, th, nn)
+        a_or, n_or = PC.oracle_local_map(cur, mps, th, nn)[:2]
+        assert n_ref == n_or and np.array_equal(a_ref, a_or), (seed, nF, nmp, th, nn)
+        total += n_ref
+    assert total > 5000
+
+
+# ---------------------------------------------------------------------------------------------- perfect/ (SURVEY 8(a) M9)
+def test_perfect_copy_of_the_path_equals_the_oracle(ref, oracle):
+    """The reference carries a second copy of the path, perfect/src + perfect/include (the tree its CMakeLists builds;
+    oracle/_ref/libref_perfect.so).  Its extractor and matcher must pin the oracle exactly like the top-level copy:
+    constructor tables, the golden frames stage by stage, SearchByBoW x2, DescriptorDistance, ComputeThreeMaxima."""
+    with ref.use_perfect():
+        ref.configure(bump=True, canonical_trig=True, blur_mode=0)
+        t = ref.RefExtractor(1000, 1.2, 8, 20, 7).tables()
+        oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+        assert np.array_equal(u32(t["scale"]), u32(oe.scales()[0])) and np.array_equal(t["features_per_level"], oe.features_per_level())
+        assert np.array_equal(t["pattern"], oracle.pattern().astype(np.int32)) and np.array_equal(t["umax"], oracle.umax())
+        for seed in (0, 2, 9, 25, 31, 47):
+            img, params = _case(seed)
+            _compare_frame(ref, oracle, img, params)
+        rng = np.random.default_rng(77)
+        d = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+        for i in range(0, 64, 2):
+            assert ref.descriptor_distance(d[i], d[i + 1]) == oracle.hamming(d[i], d[i + 1])
+        for _ in range(50):
+            c = rng.integers(0, 40, 30) * (rng.random(30) < 0.5)
+            assert ref.three_maxima(c) == oracle.three_maxima(c)
+        for it in range(40):
+            n1, n2 = int(rng.choice([1, 7, 150, 1000])), int(rng.choice([1, 9, 180, 1000]))
+            (d1, v1, a1, fv1), (d2, v2, a2, fv2) = _bow_case(rng, n1, n2, int(rng.choice([1, 4, 30, 120])), 0.8, it % 2)
+            rm, rn = ref.search_by_bow_kf_f(d1, v1, a1, fv1, d2, a2, fv2, 0.7, True)
+            om, on = oracle.search_by_bow(d1, (v1 == 1).astype(np.uint8), a1, fv1, d2, None, a2, fv2, 0.7, 50, False, True)
+            assert rn == on and np.array_equal(rm, om)
+            r12, rn2 = ref.search_by_bow_kf_kf(d1, v1, a1, fv1, d2, v2, a2, fv2, 0.75, True)
+            o21, on2 = oracle.search_by_bow(d1, (v1 == 1).astype(np.uint8), a1, fv1, d2, (v2 == 1).astype(np.uint8), a2, fv2, 0.75, 50, True, True)
+            o12 = np.full(n1, -1, np.int32)
+            o12[o21[o21 >= 0]] = np.nonzero(o21 >= 0)[0]
+            assert rn2 == on2 and np.array_equal(r12, o12)
+    ref.configure(bump=True, canonical_trig=True, blur_mode=0)
+
+
+def test_perfect_search_by_projection_with_point_pairs_equals_oracle(ref, oracle):
+    """M9: perfect/src/ORBmatcher.cc:1727-1911, SearchByProjection(CurrentFrame, LastFrame, th, bMono, points_last,
+    points_current) (perfect/src/Tracking.cc:1362): the last-frame search plus the 2-D point pairs of every accepted match in
+    match order (NOT pruned by the rotation check); also perfect/'s plain overloads against the top-level ones."""
+    import proj_cases as PC
+    for seed in range(60):
+        rng = np.random.default_rng(9_000 + seed)
+        nC, nL = int(rng.choice([1, 30, 300, 1000])), int(rng.choice([1, 40, 400, 1000]))
+        mono = seed % 4 == 3
+        cur, last = PC.last_frame_case(rng, nC, nL, ["small", "forward", "backward"][seed % 3], stereo=not mono)
+        th = float(rng.choice([7, 15, 30]))
+        a, n, pl, pc = ref.search_by_projection_last_frame(cur, last, th, mono, perfect=True, points=True)
+        a2, n2 = ref.search_by_projection_last_frame(cur, last, th, mono, perfect=True)
+        ao, no, pairs = PC.oracle_last_frame(cur, last, th, mono)[:3]
+        opl = np.array([last["xy"][i] for i, f in pairs], np.float32).reshape(-1, 2)
+        opc = np.array([cur["xy"][f] for i, f in pairs], np.float32).reshape(-1, 2)
+        assert n == n2 == no and np.array_equal(a, ao) and np.array_equal(a2, ao), seed
+        assert np.array_equal(pl, opl) and np.array_equal(pc, opc), seed
+        cur2, mps = PC.local_map_case(rng, nC, nL)
+        am, nm = ref.search_by_projection_local_map(cur2, mps, 3.0, 0.8, perfect=True)
+        om, onm = PC.oracle_local_map(cur2, mps, 3.0, 0.8)[:2]
+        assert nm == onm and np.array_equal(am, om), seed
