@@ -299,6 +299,43 @@ orbfe_status orbfe_features_in_area_device(orbfe_matcher *m, const orbfe_keypoin
                                            const float *d_qxyr, const int32_t *d_qlevels, int32_t nq, uint32_t *d_off,
                                            uint32_t *d_cand, int32_t cap, void *stream);
 
+/* the projection-gated searches of the per-frame tracker --
+ *   ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th)       src/ORBmatcher.cc:63-157
+ *   ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)   src/ORBmatcher.cc:1578-1724
+ *   (and the perfect/ overload that also returns the 2-D point pairs, perfect/src/ORBmatcher.cc:1727-1911).
+ * The pose projection and its gates (isBad, mbTrackInView, depth sign, image bounds, forward / backward level window) stay
+ * with the caller (shim/ORBmatcher_orbfe.cc does them on cv::Mat exactly as the reference); one query = one MapPoint that
+ * passed them.  Per query: Frame::GetFeaturesInArea(u, v, r, min_level, max_level) on the frame's grid, the right-image gate
+ * (candidate idx skipped when uRight[idx] > 0 && fabs(ur - uRight[idx]) > r -- both call sites compare against the very
+ * expression they pass as the search radius, :114-119 / :1654-1660), best / second-best Hamming with the :128-140 idiom
+ * over the candidates whose slot is free, acceptance: best <= th (th <= 255; TH_HIGH / ORBdist in the reference) and, with ratio_rule != 0, not (bestLevel == bestLevel2 &&
+ * best > nnratio * second) (:143-146; ratio_rule 0 for the last-frame form, :1673).
+ * Queries are NOT independent in the reference: an accepted query puts its MapPoint into F.mvpMapPoints[bestIdx], and a
+ * slot holding a MapPoint with Observations() > 0 is skipped by every later candidate scan (:108-110 / :1647-1649).
+ * blocked[nF] marks slots taken before the call; ORBFE_PROJ_CLAIMS marks a query whose MapPoint has Observations() > 0.
+ * The result equals the reference's sequential loop (fixed point by relaxation).
+ *   match[nq]: frame feature assigned to query i, -1 = none.  The caller replays, in query order,
+ *              F.mvpMapPoints[match[i]] = pMP_i; nmatches++  (later queries may overwrite a slot whose point has no
+ *              observations: the reference counts both), then its rotation histogram (:1683-1721) where it has one.
+ *   best / second[nq] (may be NULL): bestDist / bestDist2 of the scan that decided the query (256 = none).
+ * HOST buffers; xyF = mvKeysUn[i].pt, octF = mvKeysUn[i].octave, (cell_off, cell_idx) = Frame::mGrid as orbfe_assign_grid
+ * lays it out; at most 15360 frame features. */
+typedef struct orbfe_proj_query {
+    float u, v, r;                   /* GetFeaturesInArea(u, v, r, min_level, max_level) */
+    int32_t min_level, max_level;
+    float ur;                        /* projected right-image coordinate (mTrackProjXR / u - mbf * invzc) */
+    int32_t flags;                   /* ORBFE_PROJ_* */
+    int32_t pad;
+} orbfe_proj_query;
+#define ORBFE_PROJ_CLAIMS 1          /* the query's MapPoint has Observations() > 0: its slot is skipped by later queries */
+#define ORBFE_PROJ_RIGHT_GATE 2      /* apply the right-image gate (both Frame overloads do; the KeyFrame forms do not) */
+orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF,
+                                        int32_t nF, const uint32_t *cell_off, const uint32_t *cell_idx, float minx, float miny,
+                                        float gw_inv, float gh_inv, const float *uRight /* nF or NULL */,
+                                        const uint8_t *blocked /* nF or NULL */, const orbfe_proj_query *q,
+                                        const uint8_t *qdesc /* nq x 32 */, int32_t nq, int32_t th, float nnratio,
+                                        int32_t ratio_rule, int32_t *match, int32_t *best, int32_t *second);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:642-846): row-band descriptor search in the right image,
  * 11 x 11 SAD refinement over 11 shifts on the two extractors' device-resident pyramids (mvImagePyramid of the LAST
  * call of `left` / `right`, frame 0), parabola fit, disparity -> depth, and the median-based outlier rejection.

@@ -1164,7 +1164,7 @@ int orc_search_by_projection(const uint8_t *descF, const float *xyF, const int32
                              const float *uRight, const uint8_t *blocked, const orc_proj_query *q, const uint8_t *qdesc,
                              int nq, int th, float nnratio, int ratio_rule, int32_t *match, int32_t *best, int32_t *second)
 {
-    if (nF < 0 || nq < 0) return -1;
+    if (nF < 0 || nq < 0 || th > 255) return -1; /* th = TH_HIGH / ORBdist (<= 100 in the reference): 256 is "no candidate" */
     uint8_t *taken = (uint8_t *)calloc((size_t)(nF > 0 ? nF : 1), 1); /* slot holds a MapPoint with Observations() > 0 */
     uint32_t *cand = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nF > 0 ? nF : 1));
     if (blocked)

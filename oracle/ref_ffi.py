@@ -155,7 +155,9 @@ def _declare_projection(L, prefix):
 
 
 _SHIM = os.path.join(_OUT, "libshim_ref.so")
+_SHIM_PERFECT = os.path.join(_OUT, "libshim_perfect.so")
 _shim = None
+_shim_perfect = None
 
 
 def shim_available():
@@ -182,6 +184,20 @@ def shim_lib():
     _declare_projection(L, "shim_")
     _shim = L
     return L
+
+
+def shim_perfect_lib():
+    """oracle/_ref/libshim_perfect.so: the same shim compiled with -DORBFE_SHIM_PERFECT inside perfect/'s ORBmatcher class
+    (the overload of SearchByProjection that also returns the 2-D point pairs, perfect/src/ORBmatcher.cc:1727-1911)"""
+    global _shim_perfect
+    if _shim_perfect is None:
+        build_shims()
+        if not os.path.exists(_SHIM_PERFECT):
+            raise RuntimeError("oracle/_ref/libshim_perfect.so is missing")
+        L = C.CDLL(_SHIM_PERFECT)
+        _declare_projection(L, "shim_")
+        _shim_perfect = L
+    return _shim_perfect
 
 
 _SHIMEXT = os.path.join(_OUT, "libshim_ext.so")
@@ -506,7 +522,7 @@ def search_by_projection_last_frame(cur, last, th, mono, nnratio=0.9, check_ori=
              xy=np.ascontiguousarray(last["xy"], np.float32).reshape(-1, 2))
     assigned = np.full(a.n, -9, np.int32)
     pl, pc, npts = np.zeros((max(n, 1), 2), np.float32), np.zeros((max(n, 1), 2), np.float32), C.c_int32(-1)
-    lb = shim_lib() if shim else (perfect_lib() if perfect else lib())
+    lb = (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
     fn = getattr(lb, ("shim_" if shim else "ref_") + "search_by_projection_last_frame")
     rv = fn(C.byref(a), _p(L["Tcw"]), n, _p(L["has_mp"]), _p(L["outlier"]), _p(L["world_pos"]), _p(L["mpdesc"]), _p(L["obs_gt0"]),
             _p(L["octave"]), _p(L["angle"]), _p(L["xy"]), float(th), int(mono), float(nnratio), int(check_ori), _p(assigned),
@@ -528,7 +544,7 @@ def search_by_projection_local_map(cur, mps, th, nnratio=0.8, shim=False, perfec
              proj_xyr=np.ascontiguousarray(mps["proj_xyr"], np.float32).reshape(-1, 3),
              mpdesc=np.ascontiguousarray(mps["mpdesc"], np.uint8).reshape(-1, 32), obs_gt0=np.ascontiguousarray(mps["obs_gt0"], np.uint8))
     assigned = np.full(a.n, -9, np.int32)
-    lb = shim_lib() if shim else (perfect_lib() if perfect else lib())
+    lb = (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
     fn = getattr(lb, ("shim_" if shim else "ref_") + "search_by_projection_local_map")
     rv = fn(C.byref(a), n, _p(M["in_view"]), _p(M["bad"]), _p(M["scale_level"]), _p(M["view_cos"]), _p(M["proj_xyr"]), _p(M["mpdesc"]),
             _p(M["obs_gt0"]), float(th), float(nnratio), _p(assigned))

@@ -33,7 +33,14 @@ SYMBOLS = (
     "orbfe_mapio_keyframe_bytes", "orbfe_mapio_write_keyframe", "orbfe_mapio_read_keyframe", "orbfe_mapio_pack_records_device",
     "orbfe_vocfile_load", "orbfe_vocfile_free", "orbfe_vocfile_info", "orbfe_vocfile_arrays", "orbfe_vocfile_save_binary",
     "orbfe_vocabulary_create_from_file", "orbfe_interleaved_to_gray_device", "orbfe_hamming_csr_ex", "orbfe_hamming_csr_device",
+    "orbfe_search_by_projection",
 )
+
+
+PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                             ("ur", "<f4"), ("flags", "<i4"), ("pad", "<i4")])   # orbfe_proj_query
+assert PROJ_QUERY_DTYPE.itemsize == 32
+PROJ_CLAIMS, PROJ_RIGHT_GATE = 1, 2
 
 
 class OrbfeParams(C.Structure):
@@ -134,6 +141,7 @@ def lib():
     L.orbfe_stereo_matches_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp]
     L.orbfe_distinctive_descriptors.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]
     L.orbfe_features_in_area.argtypes = [vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, i32, vp, vp, i32]
+    L.orbfe_search_by_projection.argtypes = [vp, vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp, vp, i32, i32, f32, i32, vp, vp, vp]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int:  # default -> orbfe_status / int32

@@ -1239,6 +1239,234 @@ extern "C" orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy
 }
 
 // ---------------------------------------------------------------------------------------------------
+// the projection-gated searches of the per-frame tracker
+//   ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th)                 src/ORBmatcher.cc:63-157
+//   ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) src/ORBmatcher.cc:1578-1724
+//   (+ the perfect/ overload that also returns the 2-D point pairs, perfect/src/ORBmatcher.cc:1727-1911)
+// The pose projection and its gates stay on the host (they run on cv::Mat in the caller's arithmetic); what comes here is
+// one query per surviving MapPoint: GetFeaturesInArea on the frame's grid, the right-image gate, best / second-best Hamming
+// over the candidates whose slot is free, the acceptance rule.  The reference's loop is NOT a map over the queries: an
+// accepted query writes its MapPoint into F.mvpMapPoints[bestIdx], and later queries skip a slot that holds a point with
+// Observations() > 0 (:108-110 / :1647-1649).  That dependency only points backwards (query i sees the assignments of
+// j < i), so the sequential result is the unique fixed point of "every query picks its best among the slots no EARLIER
+// claiming query took", and it is reached by relaxation: all queries choose in parallel against the owner table of the
+// previous round (owner[f] = lowest claiming query matched to f), the table is rebuilt, until no choice changes.  Query i
+// is final one round after all j < i are -- rounds = longest dependency chain + 1 (2-4 on real frames, <= nq + 1 always).
+// One workgroup per search: candidate lists and distances are materialised once (cand | dist << 16 per entry), the
+// rounds only re-scan them.
+// ---------------------------------------------------------------------------------------------------
+#define PJ_T 1024
+#define PJ_SKIP 0x1FFu           // distance field of an entry whose slot is blocked before the call / fails the right-image gate
+#define PJ_MAX_NF 15360          // owner table in LDS (int32 per frame feature)
+struct ProjArgs {
+    const uint8_t *descF;
+    const float *xyF;
+    const int32_t *octF;
+    int32_t nF, xs, os;          // xs / os: floats / ints between consecutive points (2 / 1 packed, 7 / 7 keypoint records)
+    const uint32_t *cell_off, *cell_idx;
+    float minx, miny, gwi, ghi;
+    const float *uRight;         // may be null
+    const uint8_t *blocked;      // may be null
+    const orbfe_proj_query *q;
+    const uint8_t *qdesc;
+    int32_t nq, th, ratio_rule;
+    float nnratio;
+    int32_t *match, *best, *second;  // best / second may be null
+    uint32_t *off;               // [nq + 1] scratch
+    uint32_t *ent;               // [ent_cap] scratch
+    uint32_t ent_cap;
+    int32_t *status;             // [0] = entries needed when ent_cap is too small (else 0), [1] = rounds run
+};
+
+__global__ __launch_bounds__(PJ_T) void k_search_by_projection(ProjArgs a)
+{
+    extern __shared__ int32_t s_owner[];   // [nF]
+    __shared__ uint32_t s_part[PJ_T];
+    __shared__ uint32_t s_carry;
+    __shared__ int s_changed;
+    const int tid = threadIdx.x;
+    const int nq = a.nq, nF = a.nF;
+    // ---- candidate counts -> offsets ----
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nq; base += PJ_T) {
+        const int i = base + tid;
+        uint32_t c = 0;
+        if (i < nq) {
+            const orbfe_proj_query Q = a.q[i];
+            c = (uint32_t)area_query(a.xyF, a.octF, a.cell_off, a.cell_idx, a.minx, a.miny, a.gwi, a.ghi, Q.u, Q.v, Q.r, Q.min_level,
+                                     Q.max_level, nullptr, false, a.xs, a.os);
+        }
+        s_part[tid] = c;
+        __syncthreads();
+        for (int d = 1; d < PJ_T; d <<= 1) {
+            const uint32_t t = tid >= d ? s_part[tid - d] : 0u;
+            __syncthreads();
+            s_part[tid] += t;
+            __syncthreads();
+        }
+        if (i < nq) a.off[i] = s_carry + s_part[tid] - c;
+        __syncthreads();
+        if (tid == PJ_T - 1) s_carry += s_part[PJ_T - 1];
+        __syncthreads();
+    }
+    const uint32_t total = s_carry;
+    if (tid == 0) {
+        a.off[nq] = total;
+        a.status[0] = total > a.ent_cap ? (int32_t)total : 0;
+        a.status[1] = 0;
+    }
+    if (total > a.ent_cap) return;   // workgroup-uniform: the host grows the scratch and launches again
+    __syncthreads();
+    // ---- candidate lists in the reference's iteration order, one distance per entry ----
+    for (int i = tid; i < nq; i += PJ_T) {
+        const orbfe_proj_query Q = a.q[i];
+        const uint32_t o = a.off[i];
+        const int n = area_query(a.xyF, a.octF, a.cell_off, a.cell_idx, a.minx, a.miny, a.gwi, a.ghi, Q.u, Q.v, Q.r, Q.min_level,
+                                 Q.max_level, a.ent + o, true, a.xs, a.os);
+        Desc8 dq;
+        const uint32_t *p = (const uint32_t *)(a.qdesc + (int64_t)i * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dq.w[k] = p[k];
+        const bool gate = (Q.flags & ORBFE_PROJ_RIGHT_GATE) && a.uRight;
+        for (int k = 0; k < n; ++k) {
+            const uint32_t f = a.ent[o + k];
+            uint32_t d;
+            bool skip = a.blocked && a.blocked[f];                        // :108-110 / :1647-1649, state before the call
+            if (!skip && gate) {                                          // :114-119 / :1654-1660
+                const float ur = a.uRight[f];
+                skip = ur > 0.f && fabsf(__fsub_rn(Q.ur, ur)) > Q.r;
+            }
+            d = skip ? PJ_SKIP : (uint32_t)hamming8(dq, (const uint32_t *)(a.descF + (int64_t)f * 32));
+            a.ent[o + k] = f | (d << 16);
+        }
+    }
+    for (int f = tid; f < nF; f += PJ_T) s_owner[f] = 0x7FFFFFFF;
+    for (int i = tid; i < nq; i += PJ_T) a.match[i] = -1;
+    __syncthreads();
+    // ---- relaxation rounds ----
+    int round = 0;
+    for (; round <= nq + 1; ++round) {
+        if (tid == 0) s_changed = 0;
+        __syncthreads();
+        bool changed = false;
+        for (int i = tid; i < nq; i += PJ_T) {
+            const uint32_t o = a.off[i], e = a.off[i + 1];
+            int bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, bestIdx = -1;
+            for (uint32_t k = o; k < e; ++k) {
+                const uint32_t en = a.ent[k];
+                const int f = (int)(en & 0xFFFFu), d = (int)(en >> 16);
+                if (d == (int)PJ_SKIP || s_owner[f] < i) continue;   // the slot was taken by an earlier query of this call
+                if (d < bestDist) {            // :128-140
+                    bestDist2 = bestDist;
+                    bestDist = d;
+                    bestLevel2 = bestLevel;
+                    bestLevel = a.ratio_rule ? a.octF[(size_t)a.os * f] : 0;
+                    bestIdx = f;
+                } else if (d < bestDist2) {
+                    bestLevel2 = a.ratio_rule ? a.octF[(size_t)a.os * f] : 0;
+                    bestDist2 = d;
+                }
+            }
+            int mt = -1;
+            if (bestDist <= a.th) {            // :143-148 / :1673
+                const bool reject = a.ratio_rule && bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2);
+                if (!reject) mt = bestIdx;
+            }
+            if (mt != a.match[i]) {
+                a.match[i] = mt;
+                changed = true;
+            }
+            if (a.best) a.best[i] = bestDist;
+            if (a.second) a.second[i] = bestDist2;
+        }
+        if (changed) s_changed = 1;
+        __syncthreads();
+        if (!s_changed) break;                 // workgroup-uniform
+        for (int f = tid; f < nF; f += PJ_T) s_owner[f] = 0x7FFFFFFF;
+        __syncthreads();
+        for (int i = tid; i < nq; i += PJ_T) {
+            const int mt = a.match[i];
+            if (mt >= 0 && (a.q[i].flags & ORBFE_PROJ_CLAIMS)) atomicMin(&s_owner[mt], i);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.status[1] = round + 1;
+}
+
+extern "C" orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF,
+                                                   int32_t nF, const uint32_t *cell_off, const uint32_t *cell_idx, float minx,
+                                                   float miny, float gw_inv, float gh_inv, const float *uRight,
+                                                   const uint8_t *blocked, const orbfe_proj_query *q, const uint8_t *qdesc,
+                                                   int32_t nq, int32_t th, float nnratio, int32_t ratio_rule, int32_t *match,
+                                                   int32_t *best, int32_t *second)
+{
+    if (!m || nF < 0 || nq < 0 || !cell_off || (nq > 0 && (!q || !qdesc || !match)) || (nF > 0 && (!descF || !xyF || !octF || !cell_idx))) {
+        orbfe_set_error("bad argument to orbfe_search_by_projection");
+        return ORBFE_ERR_ARG;
+    }
+    if (nF > PJ_MAX_NF) { orbfe_set_error("orbfe_search_by_projection: at most %d frame features", PJ_MAX_NF); return ORBFE_ERR_SIZE; }
+    if (th > 255) { orbfe_set_error("orbfe_search_by_projection: th must be below 256 (256 is the 'no candidate' distance)"); return ORBFE_ERR_ARG; }
+    const uint32_t nin = cell_off[GRID_NC];
+    if (nin > (uint32_t)nF) { orbfe_set_error("cell_off inconsistent with nF"); return ORBFE_ERR_ARG; }
+    for (int c = 0; c < GRID_NC; ++c)
+        if (cell_off[c + 1] < cell_off[c]) { orbfe_set_error("cell_off must not decrease"); return ORBFE_ERR_ARG; }
+    for (uint32_t k = 0; k < nin; ++k)
+        if (cell_idx[k] >= (uint32_t)nF) { orbfe_set_error("cell_idx out of range"); return ORBFE_ERR_ARG; }
+    if (nq == 0) return ORBFE_OK;
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));
+    const size_t sz[9] = {(size_t)nF * 32, (size_t)nF * 8, (size_t)nF * 4, (size_t)(GRID_NC + 1) * 4, (size_t)nin * 4,
+                          uRight ? (size_t)nF * 4 : 0, blocked ? (size_t)nF : 0, (size_t)nq * sizeof(orbfe_proj_query), (size_t)nq * 32};
+    const void *src[9] = {descF, xyF, octF, cell_off, cell_idx, uRight, blocked, q, qdesc};
+    for (int i = 0; i < 9; ++i) {
+        ORBFE_HIP(m->b[i].ensure(sz[i]));
+        if (sz[i]) ORBFE_HIP(hipMemcpyAsync(m->b[i].p, src[i], sz[i], hipMemcpyHostToDevice, st));
+    }
+    ORBFE_HIP(m->b[9].ensure((size_t)nq * 12));
+    ORBFE_HIP(m->b[10].ensure((size_t)(nq + 1) * 4));
+    ORBFE_HIP(m->b[12].ensure(8));
+    ProjArgs a;
+    a.descF = (const uint8_t *)m->b[0].p;
+    a.xyF = (const float *)m->b[1].p;
+    a.octF = (const int32_t *)m->b[2].p;
+    a.nF = nF; a.xs = 2; a.os = 1;
+    a.cell_off = (const uint32_t *)m->b[3].p;
+    a.cell_idx = (const uint32_t *)m->b[4].p;
+    a.minx = minx; a.miny = miny; a.gwi = gw_inv; a.ghi = gh_inv;
+    a.uRight = uRight ? (const float *)m->b[5].p : nullptr;
+    a.blocked = blocked ? (const uint8_t *)m->b[6].p : nullptr;
+    a.q = (const orbfe_proj_query *)m->b[7].p;
+    a.qdesc = (const uint8_t *)m->b[8].p;
+    a.nq = nq; a.th = th; a.ratio_rule = ratio_rule ? 1 : 0; a.nnratio = nnratio;
+    a.match = (int32_t *)m->b[9].p;
+    a.best = a.match + nq;
+    a.second = a.match + 2 * (size_t)nq;
+    a.off = (uint32_t *)m->b[10].p;
+    a.status = (int32_t *)m->b[12].p;
+    size_t ent_cap = std::max<size_t>((size_t)nq * 64, 1 << 16);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        ORBFE_HIP(m->b[11].ensure(ent_cap * 4));
+        a.ent = (uint32_t *)m->b[11].p;
+        a.ent_cap = (uint32_t)std::min<size_t>(m->b[11].bytes / 4, 0xFFFFFFFFu);
+        hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(PJ_T), (size_t)std::max(nF, 1) * 4, st, a);
+        ORBFE_HIP(hipGetLastError());
+        int32_t status[2] = {0, 0};
+        ORBFE_HIP(hipMemcpyAsync(status, a.status, 8, hipMemcpyDeviceToHost, st));
+        ORBFE_HIP(hipStreamSynchronize(st));
+        if (status[0] == 0) break;
+        if (attempt == 1) { orbfe_set_error("candidate scratch still too small (%d entries)", status[0]); return ORBFE_ERR_NOMEM; }
+        ent_cap = (size_t)status[0];   // the exact need: second launch cannot fail on it
+    }
+    ORBFE_HIP(hipMemcpyAsync(match, a.match, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    if (best) ORBFE_HIP(hipMemcpyAsync(best, a.best, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    if (second) ORBFE_HIP(hipMemcpyAsync(second, a.second, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    return ORBFE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // SURVEY 8(f).4  MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345), batched over map points.
 // One wave per map point: its observed descriptors are staged in LDS, lane i owns row i of the distance matrix and
 // finds that row's median -- element (int)(0.5 * (N - 1)) of the sorted row, self distance 0 included (:332-334) --

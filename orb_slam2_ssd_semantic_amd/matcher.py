@@ -141,6 +141,28 @@ class ORBmatcher:
                                            ptr(si)), "orbfe_hamming_csr_ex")
         return bi, b, s, si
 
+    def SearchByProjectionCore(self, descF, xyF, octF, grid, bounds, uRight, blocked, queries, qdesc, th, nnratio, ratio_rule):
+        """orbfe_search_by_projection: the device core of ORBmatcher::SearchByProjection (Frame&, const Frame&, th, bMono)
+        (src/ORBmatcher.cc:1578-1724) and (Frame&, const vector<MapPoint*>&, th) (:63-157).  grid = (cell_off, cell_idx) of
+        the frame, bounds = (minx, miny, gw_inv, gh_inv), queries: PROJ_QUERY_DTYPE records, one per MapPoint that passed the
+        host-side gates.  Returns (match[nq], best[nq], second[nq])."""
+        descF = np.ascontiguousarray(descF, np.uint8).reshape(-1, 32)
+        xyF = np.ascontiguousarray(xyF, np.float32).reshape(-1, 2)
+        octF = np.ascontiguousarray(octF, np.int32)
+        off, idx = (np.ascontiguousarray(a, np.uint32) for a in grid)
+        uR = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+        bl = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+        q = np.ascontiguousarray(queries, _ffi.PROJ_QUERY_DTYPE)
+        qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+        assert len(qd) == len(q) and len(xyF) == len(descF) == len(octF)
+        m, b, s2 = (np.full(len(q), -1, np.int32) for _ in range(3))
+        _ffi.check(_ffi.lib().orbfe_search_by_projection(self.handle, _ffi.ptr(descF), _ffi.ptr(xyF), _ffi.ptr(octF), len(descF),
+                                                         _ffi.ptr(off), _ffi.ptr(idx), *[float(v) for v in bounds], _ffi.ptr(uR),
+                                                         _ffi.ptr(bl), _ffi.ptr(q), _ffi.ptr(qd), len(q), int(th), float(nnratio),
+                                                         int(ratio_rule), _ffi.ptr(m), _ffi.ptr(b), _ffi.ptr(s2)),
+                   "orbfe_search_by_projection")
+        return m, b, s2
+
     def ComputeStereoMatches(self, extractorLeft, extractorRight, keysL, descL, keysR, descR, mbf, mb):
         """SURVEY 8(f).2: Frame::ComputeStereoMatches (src/Frame.cc:642-846).  The two ORBextractor mirrors must have
         just processed the left / right image (their device-resident pyramids are read).  Returns (mvuRight, mvDepth)."""

@@ -2,22 +2,32 @@
 //
 // The reference's OWN include/ORBmatcher.h stays as it is (so Tracking.cc, LocalMapping.cc, LoopClosing.cc and the
 // projection family SearchByProjection x4 / SearchForInitialization / SearchForTriangulation / SearchBySim3 / Fuse x2
-// in src/ORBmatcher.cc compile unchanged).  This file supplies the three members that carry the Hamming work, over
+// in src/ORBmatcher.cc compile unchanged).  This file supplies the members that carry the Hamming work, over
 // the C-ABI of liborbfe.so:
 //     static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)              src/ORBmatcher.cc:1968-1984
 //     int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&)                src/ORBmatcher.cc:217-363
 //     int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&)             src/ORBmatcher.cc:665-812
-// Integration: add this file to the ORB_SLAM2 library, delete (or #if 0) those three bodies in src/ORBmatcher.cc, link
+//     int ORBmatcher::SearchByProjection(Frame&, const std::vector<MapPoint*>&, float)       src/ORBmatcher.cc:63-157
+//     int ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)                  src/ORBmatcher.cc:1578-1724
+//     (with -DORBFE_SHIM_PERFECT, for the perfect/ tree) the overload that also returns the 2-D point pairs,
+//                                                                                             perfect/src/ORBmatcher.cc:1727-1911
+// The two SearchByProjection members are the per-frame matchers of Tracking (TrackWithMotionModel src/Tracking.cc:1346,
+// SearchLocalPoints :1960): the pose projection and its gates run here, on cv::Mat, statement for statement as in the
+// reference; the candidate search (GetFeaturesInArea + Hamming + the "slot already taken" rule) is ONE
+// orbfe_search_by_projection call per invocation; the assignments and the rotation histogram are replayed from its result.
+// Integration: add this file to the ORB_SLAM2 library, delete (or #if 0) those bodies in src/ORBmatcher.cc, link
 // liborbfe.so.  The class gets no new data member: the device matcher handle is per thread, which is also
 // what the C-ABI asks for (Tracking, LocalMapping and LoopClosing call the matcher concurrently).
 //
 // Built and tested in this repo against the reference's unmodified header with mock KeyFrame / Frame / MapPoint types
 // (oracle/refbuild: libshim_ref.so; tests/test_gpu_shim_ref.py compares it with the compiled reference bodies).
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -74,10 +84,191 @@ const uint8_t *Rows(const cv::Mat &d, std::vector<uint8_t> &tmp)
     for (int i = 0; i < d.rows; ++i) memcpy(&tmp[(size_t)i * 32], d.ptr<uint8_t>(i), 32);
     return tmp.data();
 }
+// The frame side of a projection search as flat arrays: mDescriptors, mvKeysUn (pt, octave), mvuRight, the slots that hold a
+// MapPoint with Observations() > 0 (:108-110 / :1647-1649) and Frame::mGrid in the (ix, iy) order GetFeaturesInArea walks it.
+struct FrameSide {
+    std::vector<float> xy;
+    std::vector<int32_t> oct;
+    std::vector<uint8_t> blocked, tmp;
+    std::vector<uint32_t> cell_off, cell_idx;
+    const uint8_t *desc = nullptr;
+    explicit FrameSide(ORB_SLAM2::Frame &F)
+    {
+        const size_t n = (size_t)F.N;
+        xy.resize(2 * n);
+        oct.resize(n);
+        blocked.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            xy[2 * i] = F.mvKeysUn[i].pt.x;
+            xy[2 * i + 1] = F.mvKeysUn[i].pt.y;
+            oct[i] = F.mvKeysUn[i].octave;
+            ORB_SLAM2::MapPoint *p = F.mvpMapPoints[i];
+            blocked[i] = p && p->Observations() > 0;
+        }
+        cell_off.reserve(ORBFE_GRID_COLS * ORBFE_GRID_ROWS + 1);
+        cell_off.push_back(0);
+        for (int ix = 0; ix < ORBFE_GRID_COLS; ++ix)
+            for (int iy = 0; iy < ORBFE_GRID_ROWS; ++iy) {
+                const std::vector<std::size_t> &c = F.mGrid[ix][iy];
+                for (size_t k = 0; k < c.size(); ++k) cell_idx.push_back((uint32_t)c[k]);
+                cell_off.push_back((uint32_t)cell_idx.size());
+            }
+        desc = Rows(F.mDescriptors, tmp);
+    }
+};
+
+struct Queries {
+    std::vector<orbfe_proj_query> q;
+    std::vector<uint8_t> desc;
+    std::vector<ORB_SLAM2::MapPoint *> mp;
+    std::vector<int> src;  // index of the query in the caller's list
+    void Add(ORB_SLAM2::MapPoint *p, int from, float u, float v, float r, int minLevel, int maxLevel, float ur)
+    {
+        orbfe_proj_query e;
+        e.u = u; e.v = v; e.r = r; e.min_level = minLevel; e.max_level = maxLevel; e.ur = ur;
+        e.flags = ORBFE_PROJ_RIGHT_GATE | (p->Observations() > 0 ? ORBFE_PROJ_CLAIMS : 0);
+        e.pad = 0;
+        q.push_back(e);
+        const cv::Mat d = p->GetDescriptor();
+        desc.insert(desc.end(), d.ptr<uint8_t>(0), d.ptr<uint8_t>(0) + 32);
+        mp.push_back(p);
+        src.push_back(from);
+    }
+};
+
+void RunSearch(ORB_SLAM2::Frame &F, const Queries &qs, int th, float nnratio, int ratio_rule, std::vector<int32_t> &match)
+{
+    match.assign(qs.q.size(), -1);
+    if (qs.q.empty() || F.N == 0) return;
+    FrameSide fs(F);
+    const orbfe_status s = orbfe_search_by_projection(
+        t_matcher.get(), fs.desc, fs.xy.data(), fs.oct.data(), F.N, fs.cell_off.data(), fs.cell_idx.data(), ORB_SLAM2::Frame::mnMinX,
+        ORB_SLAM2::Frame::mnMinY, ORB_SLAM2::Frame::mfGridElementWidthInv, ORB_SLAM2::Frame::mfGridElementHeightInv,
+        F.mvuRight.empty() ? NULL : F.mvuRight.data(), fs.blocked.data(), qs.q.data(), qs.desc.data(), (int32_t)qs.q.size(), th, nnratio,
+        ratio_rule, match.data(), NULL, NULL);
+    if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbfe): ") + orbfe_last_error());
+}
 }  // namespace
 
 namespace ORB_SLAM2
 {
+
+// src/ORBmatcher.cc:63-157
+int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th)
+{
+    const bool bFactor = th != 1.0;  // :67
+    Queries qs;
+    for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {
+        MapPoint *pMP = vpMapPoints[iMP];
+        if (!pMP->mbTrackInView) continue;  // :73
+        if (pMP->isBad()) continue;         // :76
+        const int &nPredictedLevel = pMP->mnTrackScaleLevel;
+        float r = RadiusByViewingCos(pMP->mTrackViewCos);  // :84
+        if (bFactor) r *= th;
+        // :90-91 GetFeaturesInArea(mTrackProjX, mTrackProjY, r * mvScaleFactors[level], level - 1, level); the right-image
+        // gate of :114-119 compares against the same product
+        qs.Add(pMP, (int)iMP, pMP->mTrackProjX, pMP->mTrackProjY, r * F.mvScaleFactors[nPredictedLevel], nPredictedLevel - 1,
+               nPredictedLevel, pMP->mTrackProjXR);
+    }
+    std::vector<int32_t> match;
+    RunSearch(F, qs, TH_HIGH, mfNNratio, 1, match);
+    int nmatches = 0;
+    for (size_t k = 0; k < match.size(); ++k)
+        if (match[k] >= 0) {  // :150-151
+            F.mvpMapPoints[(size_t)match[k]] = qs.mp[k];
+            nmatches++;
+        }
+    return nmatches;
+}
+
+// src/ORBmatcher.cc:1578-1724; points_last / points_current: the extra outputs of perfect/src/ORBmatcher.cc:1727-1911
+typedef std::function<void(std::vector<int> *, int &, int &, int &)> ThreeMaxima;  // ORBmatcher::ComputeThreeMaxima is protected
+static int SearchLastFrame(const bool mbCheckOrientation, Frame &CurrentFrame, const Frame &LastFrame, const float th,
+                           const bool bMono, std::vector<cv::Point2f> *points_last, std::vector<cv::Point2f> *points_current,
+                           const ThreeMaxima &three_maxima)
+{
+    const int HISTO_LENGTH = ORBmatcher::HISTO_LENGTH;
+    const float factor = 1.0f / HISTO_LENGTH;  // :1586
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat twc = -Rcw.t() * tcw;
+    const cv::Mat Rlw = LastFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tlw = LastFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat tlc = Rlw * twc + tlw;
+    const bool bForward = tlc.at<float>(2) > CurrentFrame.mb && !bMono;    // :1604
+    const bool bBackward = -tlc.at<float>(2) > CurrentFrame.mb && !bMono;  // :1607
+    Queries qs;
+    for (int i = 0; i < LastFrame.N; i++) {
+        MapPoint *pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP) continue;
+        if (LastFrame.mvbOutlier[i]) continue;
+        cv::Mat x3Dw = pMP->GetWorldPos();  // :1620-1632
+        cv::Mat x3Dc = Rcw * x3Dw + tcw;
+        const float xc = x3Dc.at<float>(0);
+        const float yc = x3Dc.at<float>(1);
+        const float invzc = 1.0 / x3Dc.at<float>(2);
+        if (invzc < 0) continue;
+        float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+        float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+        int nLastOctave = LastFrame.mvKeys[i].octave;
+        float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];  // :1642
+        int minLevel, maxLevel;
+        if (bForward) { minLevel = nLastOctave; maxLevel = -1; }            // :1645 GetFeaturesInArea(u, v, radius, nLastOctave)
+        else if (bBackward) { minLevel = 0; maxLevel = nLastOctave; }       // :1647
+        else { minLevel = nLastOctave - 1; maxLevel = nLastOctave + 1; }    // :1649
+        const float ur = u - CurrentFrame.mbf * invzc;                      // :1656
+        qs.Add(pMP, i, u, v, radius, minLevel, maxLevel, ur);
+    }
+    std::vector<int32_t> match;
+    RunSearch(CurrentFrame, qs, ORBmatcher::TH_HIGH, 0.f, 0, match);
+    int nmatches = 0;
+    std::vector<int> rotHist[ORBmatcher::HISTO_LENGTH];
+    for (size_t k = 0; k < match.size(); ++k) {
+        if (match[k] < 0) continue;
+        const int bestIdx2 = match[k], i = qs.src[k];
+        CurrentFrame.mvpMapPoints[bestIdx2] = qs.mp[k];  // :1675-1676
+        nmatches++;
+        if (points_last) {
+            points_last->push_back(LastFrame.mvKeys[i].pt);
+            points_current->push_back(CurrentFrame.mvKeys[bestIdx2].pt);
+        }
+        if (mbCheckOrientation) {  // :1679-1689
+            float rot = LastFrame.mvKeysUn[i].angle - CurrentFrame.mvKeysUn[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back(bestIdx2);
+        }
+    }
+    if (mbCheckOrientation) {  // :1696-1719
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, ind1, ind2, ind3);  // :1912-1957, the reference's own member
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                    CurrentFrame.mvpMapPoints[rotHist[i][j]] = static_cast<MapPoint *>(NULL);
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+{
+    return SearchLastFrame(mbCheckOrientation, CurrentFrame, LastFrame, th, bMono, NULL, NULL,
+                           [this](std::vector<int> *h, int &a, int &b, int &c) { ComputeThreeMaxima(h, HISTO_LENGTH, a, b, c); });
+}
+
+#ifdef ORBFE_SHIM_PERFECT
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono,
+                                   std::vector<cv::Point2f> &points_last, std::vector<cv::Point2f> &points_current)
+{
+    return SearchLastFrame(mbCheckOrientation, CurrentFrame, LastFrame, th, bMono, &points_last, &points_current,
+                           [this](std::vector<int> *h, int &a, int &b, int &c) { ComputeThreeMaxima(h, HISTO_LENGTH, a, b, c); });
+}
+#endif
 
 int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
 {

@@ -1,0 +1,160 @@
+"""The projection-gated searches of the per-frame tracker:
+  ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)   src/ORBmatcher.cc:1578-1724
+  ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th)       src/ORBmatcher.cc:63-157
+  (+ the perfect/ overload that also returns the 2-D point pairs, perfect/src/ORBmatcher.cc:1727-1911)
+GPU: orbfe_search_by_projection (HIP) == the oracle's sequential core on the same queries, bit for bit, including the
+"slot taken by an earlier query" dependency (relaxation on the device, a plain loop in the oracle); and the product's shim
+members, called through the reference's own class on mock Frames, == the reference's compiled bodies.  The oracle itself is
+pinned to those bodies on the CPU (tests/test_ref_pin.py)."""
+import numpy as np
+import pytest
+
+import proj_cases as PC
+from oracle import oracle_ffi as O
+from oracle import ref_ffi as R
+
+
+def _core_both(mat, cur, q, qdesc, th, nnratio, rule):
+    ci = PC.core_inputs(cur)
+    om, ob, os_ = O.search_by_projection(queries=q, qdesc=qdesc, th=th, nnratio=nnratio, ratio_rule=rule, **ci)
+    gm, gb, gs = mat.SearchByProjectionCore(queries=q, qdesc=qdesc, th=th, nnratio=nnratio, ratio_rule=rule, **ci)
+    return (om, ob, os_), (gm, gb, gs)
+
+
+@pytest.fixture(scope="module")
+def mat():
+    from orb_slam2_ssd_semantic_amd import ORBmatcher
+    return ORBmatcher(0.9, True)
+
+
+@pytest.mark.gpu
+def test_core_equals_oracle_on_tracker_shaped_cases(mat):
+    nq_tot = nm_tot = 0
+    for seed in range(120):
+        rng = np.random.default_rng(11_000 + seed)
+        if seed % 2 == 0:
+            nC, nL = int(rng.choice([1, 30, 300, 1000, 2000])), int(rng.choice([1, 40, 400, 1000, 2500]))
+            mono = seed % 8 == 6
+            cur, last = PC.last_frame_case(rng, nC, nL, ["small", "forward", "backward"][(seed // 2) % 3], stereo=not mono)
+            q, valid = O.proj_queries_last_frame(cur["Tcw"], last["Tcw"], cur["K"], cur["bounds"], cur["scale_factors"], last["has_mp"],
+                                                 last["outlier"], last["world_pos"], last["octave"], last["obs_gt0"],
+                                                 float(rng.choice([7, 15, 30])), mono)
+            sel = valid.astype(bool)
+            q, qd, th, nn, rule = q[sel], last["mpdesc"][sel], 100, 0.0, 0
+        else:
+            nF, nmp = int(rng.choice([1, 30, 300, 1000, 2000])), int(rng.choice([1, 40, 400, 1500, 3000]))
+            cur, mps = PC.local_map_case(rng, nF, nmp)
+            q, valid = O.proj_queries_local_map(cur["scale_factors"], mps["in_view"], mps["bad"], mps["scale_level"], mps["view_cos"],
+                                                mps["proj_xyr"], mps["obs_gt0"], float(rng.choice([1, 3, 5])))
+            sel = valid.astype(bool)
+            q, qd, th, nn, rule = q[sel], mps["mpdesc"][sel], int(rng.choice([100, 50])), float(rng.choice([0.8, 0.7])), 1
+        (om, ob, os_), (gm, gb, gs) = _core_both(mat, cur, q, qd, th, nn, rule)
+        assert np.array_equal(gm, om), (seed, np.nonzero(gm != om)[0][:5])
+        assert np.array_equal(gb, ob) and np.array_equal(gs, os_), seed
+        nq_tot += len(q)
+        nm_tot += int((om >= 0).sum())
+    assert nq_tot > 30_000 and nm_tot > 8_000
+
+
+@pytest.mark.gpu
+def test_core_long_dependency_chains(mat):
+    """Every query wants the same few slots: query i can only settle after all earlier claiming queries have -- the device's
+    relaxation needs as many rounds as the chain is long and must still land on the sequential result."""
+    for seed, (nF, nq) in enumerate([(64, 64), (300, 300), (40, 500), (1000, 1200)]):
+        rng = np.random.default_rng(500 + seed)
+        cur = PC.current_frame(rng, nF, stereo=False, dense_states=False)
+        cur["xy"][:] = (np.array([320.0, 240.0]) + rng.normal(0, 3.0, (nF, 2))).astype(np.float32)   # one tight cluster
+        cur["octave"][:] = 2
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        bits = np.tile(np.unpackbits(base), (nF, 1))
+        for i in range(nF):   # slot i is at distance ~i / 4 from the common query descriptor: a strict preference order
+            bits[i, rng.choice(256, min(i // 4, 200), replace=False)] ^= 1
+        cur["desc"] = np.packbits(bits, axis=1)
+        q = np.zeros(nq, O.PROJ_QUERY_DTYPE)
+        q["u"], q["v"], q["r"] = 320.0, 240.0, 40.0
+        q["min_level"], q["max_level"] = 1, 3
+        q["flags"] = np.where(rng.random(nq) < 0.9, 1, 0) | 2
+        qd = np.tile(base, (nq, 1))
+        for th, nn, rule in ((100, 0.0, 0), (255, 0.9, 1)):
+            (om, ob, os_), (gm, gb, gs) = _core_both(mat, cur, q, qd, th, nn, rule)
+            assert np.array_equal(gm, om) and np.array_equal(gb, ob) and np.array_equal(gs, os_), (seed, th)
+            assert len(set(om[(om >= 0) & ((q["flags"] & 1) == 1)].tolist())) == int(((om >= 0) & ((q["flags"] & 1) == 1)).sum())
+
+
+@pytest.mark.gpu
+def test_core_edge_cases(mat):
+    rng = np.random.default_rng(3)
+    cur = PC.current_frame(rng, 50)
+    ci = PC.core_inputs(cur)
+    q0 = np.zeros(0, O.PROJ_QUERY_DTYPE)
+    m, b, s = mat.SearchByProjectionCore(queries=q0, qdesc=np.zeros((0, 32), np.uint8), th=100, nnratio=0.8, ratio_rule=1, **ci)
+    assert len(m) == 0
+    # queries far outside the grid, zero radius, every slot blocked
+    q = np.zeros(5, O.PROJ_QUERY_DTYPE)
+    q["u"], q["v"], q["r"] = [-500, 5000, 320, 320, 320], [-500, 5000, 240, 240, 240], [10, 10, 0, 1000, 1000]
+    q["min_level"], q["max_level"], q["flags"] = -1, -1, 3
+    qd = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+    for blocked in (ci["blocked"], np.ones(50, np.uint8), None):
+        ci2 = dict(ci, blocked=blocked)
+        om, ob, os_ = O.search_by_projection(queries=q, qdesc=qd, th=255, nnratio=0.8, ratio_rule=0, **ci2)
+        gm, gb, gs = mat.SearchByProjectionCore(queries=q, qdesc=qd, th=255, nnratio=0.8, ratio_rule=0, **ci2)
+        assert np.array_equal(gm, om) and np.array_equal(gb, ob) and np.array_equal(gs, os_)
+    with pytest.raises(Exception):   # th >= 256 would accept "no candidate"
+        mat.SearchByProjectionCore(queries=q, qdesc=qd, th=256, nnratio=0.8, ratio_rule=0, **ci)
+    # an empty frame
+    cur0 = PC.current_frame(rng, 0)
+    (om, _, _), (gm, _, _) = _core_both(mat, cur0, q, qd, 100, 0.8, 1)
+    assert np.array_equal(gm, om) and (gm == -1).all()
+
+
+needs_shim = pytest.mark.skipif(not R.shim_available(), reason="oracle/_ref/libshim_ref.so not built and /root/reference absent")
+
+
+@needs_shim
+def test_shims_export_the_projection_members():
+    for L in (R.shim_lib(), R.shim_perfect_lib()):
+        assert L.shim_search_by_projection_last_frame and L.shim_search_by_projection_local_map
+
+
+@needs_shim
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(4))
+def test_shim_search_by_projection_equals_reference_bodies(block):
+    """reference class -> shim member (host gating on cv::Mat, one orbfe_search_by_projection call, replay) == the reference's
+    own compiled body on the same mock Frames: CurrentFrame.mvpMapPoints slot by slot + the return value; 240 cases over both
+    overloads, mono / stereo, forward / backward / small motion, rotation check on / off."""
+    total = 0
+    for it in range(30):
+        seed = block * 30 + it
+        rng = np.random.default_rng(13_000 + seed)
+        nC, nL = int(rng.choice([0, 1, 30, 300, 1000])), int(rng.choice([0, 1, 40, 400, 1000]))
+        mono = seed % 4 == 3
+        cur, last = PC.last_frame_case(rng, nC, nL, ["small", "forward", "backward"][seed % 3], stereo=not mono)
+        th, ori = float(rng.choice([7, 15, 15, 30])), bool(seed % 5)
+        ra, rn = R.search_by_projection_last_frame(cur, last, th, mono, check_ori=ori)
+        sa, sn = R.search_by_projection_last_frame(cur, last, th, mono, check_ori=ori, shim=True)
+        assert sn == rn and np.array_equal(sa, ra), ("last frame", seed, nC, nL, mono, th)
+        cur2, mps = PC.local_map_case(rng, nC, nL + 200)
+        th2, nn = float(rng.choice([1, 3, 5])), float(rng.choice([0.8, 0.7, 0.9]))
+        ra2, rn2 = R.search_by_projection_local_map(cur2, mps, th2, nn)
+        sa2, sn2 = R.search_by_projection_local_map(cur2, mps, th2, nn, shim=True)
+        assert sn2 == rn2 and np.array_equal(sa2, ra2), ("local map", seed, nC, nL, th2, nn)
+        total += rn + rn2
+    assert total > 1000
+
+
+@needs_shim
+@pytest.mark.gpu
+def test_shim_perfect_overload_with_point_pairs_equals_reference_body():
+    """M9 through perfect/'s class: the shim built with -DORBFE_SHIM_PERFECT against perfect/include/ORBmatcher.h"""
+    for seed in range(40):
+        rng = np.random.default_rng(15_000 + seed)
+        nC, nL = int(rng.choice([1, 30, 300, 1000])), int(rng.choice([1, 40, 400, 1000]))
+        mono = seed % 4 == 3
+        cur, last = PC.last_frame_case(rng, nC, nL, ["small", "forward", "backward"][seed % 3], stereo=not mono)
+        th = float(rng.choice([7, 15, 30]))
+        ra, rn, rpl, rpc = R.search_by_projection_last_frame(cur, last, th, mono, perfect=True, points=True)
+        sa, sn, spl, spc = R.search_by_projection_last_frame(cur, last, th, mono, perfect=True, points=True, shim=True)
+        assert sn == rn and np.array_equal(sa, ra) and np.array_equal(spl, rpl) and np.array_equal(spc, rpc), seed
+        sa2, sn2 = R.search_by_projection_last_frame(cur, last, th, mono, perfect=True, shim=True)
+        assert sn2 == rn and np.array_equal(sa2, ra), seed
