@@ -605,6 +605,8 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
     if rank == 0:
         result["config4"] = c4
 
+    if world == 1 and not args.no_cpu_baseline:
+        result["projection_chain"] = projection_leg(local_rank)
     if world == 1:
         result["config5"] = config5_leg(args, local_rank, check=not args.no_cpu_baseline)
         result["bow_chain"] = bow_leg(args, local_rank)
@@ -931,6 +933,65 @@ def bow_leg(args, local_rank, npairs=256, steps=10, warmup=3, standalone=False):
                 "ms_per_step": round(t_se, 4), "higher_is_better": True, "dtype": "u8", "data": "synthetic",
                 "config": {"workload": "256 (KeyFrame, Frame) pairs of 1000 x 1000 ORB features, ~100 vocabulary nodes each"},
                 "bow_chain": out}
+    return out
+
+
+def projection_leg(local_rank, reps=40):
+    """The per-frame matchers of Tracking under the reference's own signatures: SearchByProjection(Frame&,
+    const Frame&, th, bMono) (TrackWithMotionModel, src/ORBmatcher.cc:1578-1724) on 1000 x 1000 features and
+    SearchByProjection(Frame&, vector<MapPoint*>&, th) (SearchLocalPoints, :63-157) on 1000 features x 3000 map points.
+    GPU side: the product's shim member called through the reference's class (oracle/_ref/libshim_ref.so: host gating on
+    cv::Mat, ONE orbfe_search_by_projection call, replay) and that C-ABI call alone; cpu_baseline: the reference's compiled
+    body (oracle/_ref/libref_orb.so) on the same mock Frames, one thread.  Times are the member call alone."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import proj_cases as PC
+    from oracle import oracle_ffi as O
+    from oracle import ref_ffi as R
+    from orb_slam2_ssd_semantic_amd import ORBmatcher
+    if not (R.available() and R.shim_available()):
+        return {"skipped": "oracle/_ref libraries not present"}
+    mat = ORBmatcher(0.9, True, device=local_rank)
+    rng = np.random.default_rng(2026)
+    out = {}
+
+    def med(fn, n):
+        v = []
+        for _ in range(n):
+            v.append(fn())
+        return float(np.median(v))
+    # ---- last frame ----
+    cur, last = PC.last_frame_case(rng, 1000, 1000, "small")
+    ra, rn = R.search_by_projection_last_frame(cur, last, 15.0, False)
+    sa, sn = R.search_by_projection_last_frame(cur, last, 15.0, False, shim=True)
+    assert sn == rn and np.array_equal(sa, ra), "projection_chain: shim differs from the reference body"
+    q, valid = O.proj_queries_last_frame(cur["Tcw"], last["Tcw"], cur["K"], cur["bounds"], cur["scale_factors"], last["has_mp"],
+                                         last["outlier"], last["world_pos"], last["octave"], last["obs_gt0"], 15.0, False)
+    sel = valid.astype(bool)
+    ci = PC.core_inputs(cur)
+
+    def core():
+        t = time.perf_counter()
+        mat.SearchByProjectionCore(queries=q[sel], qdesc=last["mpdesc"][sel], th=100, nnratio=0.0, ratio_rule=0, **ci)
+        return (time.perf_counter() - t) * 1e3
+    core()
+    cpu = med(lambda: (R.search_by_projection_last_frame(cur, last, 15.0, False), R.last_call_ms())[1], 15)
+    gpu = med(lambda: (R.search_by_projection_last_frame(cur, last, 15.0, False, shim=True), R.last_call_ms(shim=True))[1], reps)
+    out["last_frame"] = {"frame_features": 1000, "last_frame_features": 1000, "queries": int(sel.sum()), "matches": int(rn), "th": 15,
+                         "shim_member_ms": round(gpu, 4), "cabi_call_ms": round(med(core, reps), 4),
+                         "cpu_reference_member_ms": round(cpu, 4), "speedup_vs_cpu_1thread": round(cpu / gpu, 2)}
+    # ---- local map ----
+    cur, mps = PC.local_map_case(rng, 1000, 3000)
+    ra, rn = R.search_by_projection_local_map(cur, mps, 3.0, 0.8)
+    sa, sn = R.search_by_projection_local_map(cur, mps, 3.0, 0.8, shim=True)
+    assert sn == rn and np.array_equal(sa, ra), "projection_chain: shim differs from the reference body (local map)"
+    cpu = med(lambda: (R.search_by_projection_local_map(cur, mps, 3.0, 0.8), R.last_call_ms())[1], 15)
+    gpu = med(lambda: (R.search_by_projection_local_map(cur, mps, 3.0, 0.8, shim=True), R.last_call_ms(shim=True))[1], reps)
+    out["local_map"] = {"frame_features": 1000, "map_points": 3000, "matches": int(rn), "th": 3,
+                        "shim_member_ms": round(gpu, 4), "cpu_reference_member_ms": round(cpu, 4),
+                        "speedup_vs_cpu_1thread": round(cpu / gpu, 2)}
+    out["cpu_baseline"] = {"kind": "reference", "cores": 1, "unit": "ms per call",
+                           "sample": "median of 15 calls of the reference's compiled SearchByProjection bodies on the same mock Frames"}
+    out["exact_checked"] = True
     return out
 
 

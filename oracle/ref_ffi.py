@@ -152,6 +152,7 @@ def _declare_projection(L, prefix):
     getattr(L, prefix + "search_by_projection_last_frame").argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, cf, ci,
                                                                        vp, vp, vp, vp]
     getattr(L, prefix + "search_by_projection_local_map").argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp]
+    getattr(L, prefix + "last_call_ms").restype = C.c_double
 
 
 _SHIM = os.path.join(_OUT, "libshim_ref.so")
@@ -549,3 +550,9 @@ def search_by_projection_local_map(cur, mps, th, nnratio=0.8, shim=False, perfec
     rv = fn(C.byref(a), n, _p(M["in_view"]), _p(M["bad"]), _p(M["scale_level"]), _p(M["view_cos"]), _p(M["proj_xyr"]), _p(M["mpdesc"]),
             _p(M["obs_gt0"]), float(th), float(nnratio), _p(assigned))
     return assigned, rv
+
+
+def last_call_ms(shim=False, perfect=False):
+    """wall time of the last SearchByProjection member call alone (mock construction excluded)"""
+    lb = (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
+    return float(getattr(lb, ("shim_" if shim else "ref_") + "last_call_ms")())

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -156,6 +157,14 @@ int REF_NAME(search_by_bow_kf_kf)(const uint8_t *desc1, int n1, const uint8_t *v
  * 1 = a MapPoint with Observations() == 0, 2 = one with Observations() > 0), pose, intrinsics, image bounds, grid cell
  * inverses, scale factors; its grid is built by the reference's own Frame::AssignFeaturesToGrid (sliced).
  * assigned[nC] on return: -1 = NULL, -2 = the pre-existing MapPoint is still there, k >= 0 = the MapPoint of query k. */
+/* wall time of the last SearchByProjection member call alone (mock construction excluded), for bench.py's CPU baseline */
+static double g_last_call_ms = 0;
+struct CallTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~CallTimer() { g_last_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+extern "C" double REF_NAME(last_call_ms)(void) { return g_last_call_ms; }
+
 struct RefFrameArgs {
     const uint8_t *desc;
     const float *xy;      /* nC x 2 */
@@ -258,7 +267,10 @@ int REF_NAME(search_by_projection_last_frame)(const RefFrameArgs *cur, const flo
 #ifdef REF_PERFECT
     if (pts_last) {
         std::vector<cv::Point2f> pl, pc;
-        n = m.SearchByProjection(C, L, th, mono != 0, pl, pc);
+        {
+            CallTimer tm;
+            n = m.SearchByProjection(C, L, th, mono != 0, pl, pc);
+        }
         *npts = (int32_t)pl.size();
         for (size_t k = 0; k < pl.size(); k++) {
             pts_last[2 * k] = pl[k].x; pts_last[2 * k + 1] = pl[k].y;
@@ -269,6 +281,7 @@ int REF_NAME(search_by_projection_last_frame)(const RefFrameArgs *cur, const flo
     {
         (void)pts_last; (void)pts_cur;
         if (npts) *npts = -1;
+        CallTimer tm;
         n = m.SearchByProjection(C, L, th, mono != 0);
     }
     flatten_assigned(C, own, pool, assigned);
@@ -299,7 +312,11 @@ int REF_NAME(search_by_projection_local_map)(const RefFrameArgs *cur, int nmp, c
         v[(size_t)i] = &mp;
     }
     ORBmatcher m(nnratio, true);
-    const int n = m.SearchByProjection(F, v, th);
+    int n;
+    {
+        CallTimer tm;
+        n = m.SearchByProjection(F, v, th);
+    }
     flatten_assigned(F, own, pool, assigned);
     return n;
 }

@@ -40,13 +40,14 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     cc = hipcc()
+    extra = os.environ.get("ORBFE_EXTRA_FLAGS", "").split()   # developer A/B builds on the GPU box (e.g. -DQT_MIN_WAVES=7)
     objs = []
     bdir = os.path.join(_PKG, "build")
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for s in SOURCES:
         o = os.path.join(bdir, s.replace(".hip", ".o"))
-        cmd = [cc, *FLAGS, "-I", os.path.join(_ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [cc, *FLAGS, *extra, "-I", os.path.join(_ROOT, "include"), "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

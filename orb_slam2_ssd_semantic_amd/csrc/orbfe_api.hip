@@ -144,7 +144,7 @@ struct orbfe_handle {
     std::vector<OrbTab> tabs;
     DevBuf d_plan, d_tabs, d_flanes, d_blanes;
     // per-batch blocks
-    DevBuf d_pyr, d_blur, d_skeys, d_scount, d_knode, d_sel, d_nsel, d_nkeys;
+    DevBuf d_pyr, d_blur, d_skeys, d_scount, d_cflag, d_knode, d_qtbox, d_sel, d_nsel, d_nkeys;
     // sticky overflow word + FAST sparse-variant statistics: [0] int32 overflow bits, [2..7] 3 x uint64 counters
     DevBuf d_misc;
     int fast_mode = 0;            // 0 dense, 1 sparse shortcuts (orbfe_set_fast_mode)
@@ -520,13 +520,15 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
     ORBFE_HIP(h->d_blur.ensure(B * (size_t)P.pyr_frame_bytes));
     ORBFE_HIP(h->d_skeys.ensure(B * (size_t)P.keys_per_frame * sizeof(uint2)));
     ORBFE_HIP(h->d_scount.ensure(B * P.nlevels * ORBFE_NK_STRIDE * sizeof(int32_t)));
+    ORBFE_HIP(h->d_cflag.ensure(B * P.nlevels * (size_t)((P.max_ncells + 31) / 32) * sizeof(uint32_t)));
     ORBFE_HIP(h->d_knode.ensure(B * (size_t)P.keys_per_frame * sizeof(uint16_t)));
+    ORBFE_HIP(h->d_qtbox.ensure(B * (size_t)P.nlevels * orbk_octree_box_bytes(P.node_cap)));  // deep quadtrees only
     ORBFE_HIP(h->d_sel.ensure(B * (size_t)P.sel_per_frame * sizeof(uint32_t)));
     ORBFE_HIP(h->d_nsel.ensure(B * P.nlevels * sizeof(int32_t)));
     ORBFE_HIP(h->d_nkeys.ensure(B * P.nlevels * ORBFE_NK_STRIDE * sizeof(int32_t)));
     if (!h->d_misc.p) {
-        ORBFE_HIP(h->d_misc.ensure(64));
-        ORBFE_HIP(hipMemset(h->d_misc.p, 0, 64));
+        ORBFE_HIP(h->d_misc.ensure(1024));
+        ORBFE_HIP(hipMemset(h->d_misc.p, 0, 1024));
     }
     return ORBFE_OK;
 }
@@ -653,7 +655,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_sel, &h->d_nsel, &h->d_nkeys,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_cflag, &h->d_knode, &h->d_qtbox, &h->d_sel, &h->d_nsel, &h->d_nkeys,
                       &h->d_stage[0], &h->d_okps[0], &h->d_odesc[0], &h->d_on[0], &h->d_stage[1], &h->d_okps[1], &h->d_odesc[1], &h->d_on[1]};
     for (DevBuf *b : bufs) b->release();
     h->d_misc.release();
@@ -762,6 +764,17 @@ extern "C" orbfe_status orbfe_get_overflow(orbfe_handle *h, int32_t *flags)
     return read_overflow(h, flags);
 }
 
+// developer builds (-DQT_PROFILE): the 1024-byte block behind the overflow word; reset != 0 clears everything but the word
+extern "C" orbfe_status orbfe_internal_read_misc(orbfe_handle *h, void *out, int32_t reset)
+{
+    if (!h || !out || !h->d_misc.p) return ORBFE_ERR_ARG;
+    DeviceGuard g(h->device);
+    ORBFE_HIP(wait_last_call(h));
+    ORBFE_HIP(hipMemcpy(out, h->d_misc.p, 1024, hipMemcpyDeviceToHost));
+    if (reset) ORBFE_HIP(hipMemset((char *)h->d_misc.p + 64, 0, 960));
+    return ORBFE_OK;
+}
+
 extern "C" orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32_t collect_stats)
 {
     if (!h || mode < 0 || mode > 1) return ORBFE_ERR_ARG;
@@ -812,7 +825,11 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.pyr_fstride = h->plan.pyr_frame_bytes;
     a.d_skeys = (uint2 *)h->d_skeys.p;
     a.d_scount = (int32_t *)h->d_scount.p;
+    a.d_cflag = (uint32_t *)h->d_cflag.p;
+    a.cf_words = (h->plan.max_ncells + 31) / 32;
     a.d_knode = (uint16_t *)h->d_knode.p;
+    a.d_qtbox = (int16_t *)h->d_qtbox.p;
+    a.qtbox_stride = (int32_t)(orbk_octree_box_bytes(h->plan.node_cap) / sizeof(int16_t));
     a.d_sel = (uint32_t *)h->d_sel.p;
     a.d_nsel = (int32_t *)h->d_nsel.p;
     a.d_nkeys = (int32_t *)h->d_nkeys.p;

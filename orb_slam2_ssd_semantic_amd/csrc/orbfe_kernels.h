@@ -20,7 +20,11 @@ struct OrbLaunch {
     int64_t pyr_fstride;
     uint2 *d_skeys;      // unordered NMS survivors {key, ord} per level (k_fast_map)
     int32_t *d_scount;
+    uint32_t *d_cflag;   // [B][nlevels][cf_words] bit = the FAST cell has a survivor above iniTh (k_fast_map -> k_octree)
+    int32_t cf_words;
     uint16_t *d_knode;
+    int16_t *d_qtbox;      // [B][nlevels][qtbox_stride] node boxes of deep quadtrees (global scratch)
+    int32_t qtbox_stride;  // int16 elements per (frame, level)
     uint32_t *d_sel;
     int32_t *d_nsel;
     int32_t *d_nkeys;
@@ -39,6 +43,7 @@ struct OrbLaunch {
 
 hipError_t orbk_upload_constants(const int *umax16);
 size_t orbk_octree_lds_bytes(int node_cap, int max_nini, int w, int h, int ncells);
+size_t orbk_octree_box_bytes(int node_cap);
 hipError_t orbk_prepare_octree(int node_cap, int max_nini, int w, int h, int ncells);
 size_t orbk_pyramid_lds_bytes(int dh);  // dynamic LDS of the pyramid kernel for a destination level of dh rows
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st);

@@ -9,6 +9,7 @@
 //
 // Integer / byte work bounded by VALU issue (FAST), HBM (pyramid, blur) and LDS latency (quadtree); no MFMA.  Float steps
 // that decide an output bit use explicitly rounded single operations (__fmul_rn/__fadd_rn/__fdiv_rn, no FMA contraction).
+#include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
 
@@ -408,13 +409,24 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
 #define FM_BUF 384       // per-wave LDS staging of survivors before one atomic reserves their run in the level's list
 #define FM_ROW_MAX 140   // a row adds at most 2 per lane + 1 per lane that straddles a cell seam (<= 9 of them)
 
-__device__ __forceinline__ void fm_flush(uint2 *slist, int32_t *scnt, const uint2 *sbuf, int nbuf, int key_cap, int lane)
+// The staged survivors go to the level's list, and every survivor above iniTh marks its FAST cell in the WAVE's cell bitmap
+// in LDS (the per-cell threshold fallback :818-825 needs "does this cell have an iniTh corner" before any key can be
+// judged, so the quadtree kernel would otherwise spend a whole pass over the keys on it).  The wave's bitmap goes to the
+// level's bitmap in global memory once, when the wave ends: a wave covers a 256-px x 40-row strip, i.e. a handful of cells.
+__device__ __forceinline__ void fm_flush(uint2 *slist, int32_t *scnt, const uint2 *sbuf, int nbuf, int key_cap, int lane,
+                                         uint32_t *lflag, int ini)
 {
     int base = 0;
     if (lane == 0) base = atomicAdd(scnt, nbuf);
     base = __shfl(base, 0, 64);
-    for (int i = lane; i < nbuf; i += 64)
-        if (base + i < key_cap) slist[base + i] = sbuf[i];
+    for (int i = lane; i < nbuf; i += 64) {
+        const uint2 e = sbuf[i];
+        if (base + i < key_cap) slist[base + i] = e;
+        if (orb_key_r(e.x) >= ini) {  // cv score = A - 1 >= iniTh  <=>  A > iniTh
+            const uint32_t cell = e.y >> 12;
+            atomicOr(&lflag[cell >> 5], 1u << (cell & 31));  // LDS, result unused: ds_or_b32
+        }
+    }
 }
 
 // SPARSE = 1: wave-uniform shortcuts for frames whose corners are sparse (real camera images): a row step whose 256
@@ -425,15 +437,20 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
                                                   const OrbLane *__restrict__ lanes, int nwaves,
                                                   uint2 *__restrict__ skeys,      // [B][keys_per_frame] {key, ord}
                                                   int32_t *__restrict__ scount,   // [B][nlevels] * NK_STRIDE, zeroed
+                                                  uint32_t *__restrict__ cflags,  // [B][nlevels][cf_words], zeroed
+                                                  int32_t cf_words,
                                                   unsigned long long *__restrict__ fstat)  // {row steps, arc skips, nms skips} or null
 {
     __shared__ uint2 s_buf[4][FM_BUF];
+    extern __shared__ uint32_t s_cf[];  // [4][cf_words]: per-wave bitmap of the level's cells with a survivor above iniTh
     int b = blockIdx.y, bx = blockIdx.x;
     xcd_frame_remap(bx, b);
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int t = bx * (blockDim.x >> 6) + wv;
     if (t >= nwaves) return;
+    uint32_t *lflag = s_cf + wv * cf_words;
+    for (int i = lane; i < cf_words; i += 64) lflag[i] = 0u;  // wave-private: its own DS operations execute in order
     // Work is described per LANE: a 4-pixel column, a run of rows, "halo" (contributes neighbour strengths only).
     // The host packs the column strips of all row blocks of one level back to back into 64-lane waves, so narrow
     // levels do not leave lanes idle; neighbouring lanes are neighbouring columns inside one strip.
@@ -444,6 +461,8 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
     const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
     uint2 *slist = skeys + (int64_t)b * plan->keys_per_frame + L.key_off;
     int32_t *scnt = scount + (b * plan->nlevels + level) * ORBFE_NK_STRIDE;
+    uint32_t *cflag = cflags + (int64_t)(b * plan->nlevels + level) * cf_words;
+    const int ini_th = plan->ini_th;
     uint2 *sbuf = s_buf[wv];
     int nbuf = 0;  // wave-uniform fill of sbuf
     int st_rows = 0, st_arc = 0, st_nms = 0;  // SPARSE statistics (wave-uniform)
@@ -616,13 +635,18 @@ __global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ pl
                     }
                 }
                 if (nbuf > FM_BUF - FM_ROW_MAX) {
-                    fm_flush(slist, scnt, sbuf, nbuf, key_cap, lane);
+                    fm_flush(slist, scnt, sbuf, nbuf, key_cap, lane, lflag, ini_th);
                     nbuf = 0;
                 }
             }
         }
     }
-    if (nbuf > 0) fm_flush(slist, scnt, sbuf, nbuf, key_cap, lane);
+    if (nbuf > 0) fm_flush(slist, scnt, sbuf, nbuf, key_cap, lane, lflag, ini_th);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    for (int i = lane; i < cf_words; i += 64) {
+        const uint32_t v = lflag[i];
+        if (v) atomicOr(&cflag[i], v);
+    }
     if (SPARSE && fstat && lane == 0) {
         atomicAdd(&fstat[0], (unsigned long long)st_rows);
         atomicAdd(&fstat[1], (unsigned long long)st_arc);
@@ -674,16 +698,16 @@ struct QtShared {
     // two generations of the node list (current / next), addressed arithmetically -- an array of pointers indexed by
     // a run-time generation would live in scratch memory
     int M;
-    int16_t *box0;       // [2][4][M] ulx, uly, urx, bry
     int32_t *cnt0;       // [2][M]
     uint32_t *path0;     // [2][M] prefix | depth << 12 | root << 16
-    __device__ __forceinline__ int16_t *box(int g, int j) const { return box0 + (g * 4 + j) * M; }
     __device__ __forceinline__ int32_t *cnt(int g) const { return cnt0 + g * M; }
     __device__ __forceinline__ uint32_t *path(int g) const { return path0 + g * M; }
-    int32_t *cc;         // [M*4] quadrant counts of the current pass
-    int32_t *childpos;   // [M*4] position of child (node, quadrant) in the next list, -1 if empty
+    // [M*4] quadrant counts of the current pass; the node phase turns the entry of (node, quadrant) into the position of
+    // that child in the next list (-1 if empty): the same words, read as `cc` before and as `childpos` after
+    int32_t *cc;
     int32_t *P;          // processing order -> node index
-    int32_t *rankOf;     // node index -> processing rank or -1
+    int32_t *rankOf0;    // [2][M] node index -> processing rank or -1 (per list generation)
+    __device__ __forceinline__ int32_t *rankOf(int g) const { return rankOf0 + g * M; }
     int32_t *acc;        // inclusive sums over ranks
     int32_t *newIdx;     // next-list position of an unprocessed node, -1 for a processed one
     unsigned long long *skey;
@@ -691,7 +715,11 @@ struct QtShared {
     uint16_t *xtab;      // [w] window column -> root << 10 | x half of the 5-level path code (bits 8,6,4,2,0)
     uint16_t *ytab;      // [h] window row    -> y half of the path code (bits 9,7,5,3,1)
     uint32_t *cflag;     // [ncells / 32] bit = the FAST cell has a survivor above iniTh
-    int32_t *misc;
+    int32_t *misc;       // [64]: 0..15 state, 16..23 root slots, 32..49 scan scratch
+    // node boxes exist only for trees that go deeper than the histogram (clustered candidates): two generations of
+    // (ulx, uly, urx, bry) in GLOBAL scratch of this (frame, level) -- [2][4][M] int16
+    int16_t *gbox;
+    __device__ __forceinline__ int16_t *box(int g, int j) const { return gbox + (g * 4 + j) * M; }
 };
 
 __host__ __device__ inline int qt_pow2(int v)
@@ -706,15 +734,13 @@ __device__ __forceinline__ void qt_carve(char *base, int M, int nroots, int w, i
     char *p = base;
     q.skey = (unsigned long long *)p; p += (size_t)qt_pow2(M) * 8;  // the largest-first sort is bitonic: power of two
     q.cc = (int32_t *)p; p += (size_t)M * 16;
-    q.childpos = (int32_t *)p; p += (size_t)M * 16;
     q.M = M;
     q.cnt0 = (int32_t *)p; p += (size_t)M * 8;
     q.path0 = (uint32_t *)p; p += (size_t)M * 8;
     q.P = (int32_t *)p; p += (size_t)M * 4;
-    q.rankOf = (int32_t *)p; p += (size_t)M * 4;
+    q.rankOf0 = (int32_t *)p; p += (size_t)M * 8;
     q.acc = (int32_t *)p; p += (size_t)M * 4;
     q.newIdx = (int32_t *)p; p += (size_t)M * 4;
-    q.box0 = (int16_t *)p; p += (size_t)M * 16;
     q.hist = (int32_t *)p; p += (size_t)nroots * FF_PER_ROOT * 4;
     q.misc = (int32_t *)p; p += 64 * 4;
     q.xtab = (uint16_t *)p; p += (size_t)((w + 1) & ~1) * 2;
@@ -724,27 +750,12 @@ __device__ __forceinline__ void qt_carve(char *base, int M, int nroots, int w, i
 
 size_t orbk_octree_lds_bytes(int M, int nroots, int w, int h, int ncells)
 {
-    return (size_t)qt_pow2(M) * 8 + (size_t)M * (16 + 16 + 8 + 8 + 16 + 16) + (size_t)nroots * FF_PER_ROOT * 4 + 64 * 4 +
+    return (size_t)qt_pow2(M) * 8 + (size_t)M * (16 + 8 + 8 + 20) + (size_t)nroots * FF_PER_ROOT * 4 + 64 * 4 +
            (size_t)(((w + 1) & ~1) + ((h + 1) & ~1)) * 2 + (size_t)((ncells + 31) / 32) * 4;
 }
 
-// LDS ordering inside ONE wave: its DS operations execute in order, the fence only keeps the compiler honest
-#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
-
-// wave-synchronous inclusive scan of arr[0..n) in LDS, in place; returns the total
-__device__ __forceinline__ int wscan_inclusive(int32_t *arr, int n, int lane)
-{
-    int carry = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const int v = i < n ? arr[i] : 0;
-        const int incl = wave_incl_scan(v);
-        if (i < n) arr[i] = carry + incl;
-        carry += __shfl(incl, 63, 64);
-    }
-    WSYNC();
-    return carry;
-}
+// bytes of global scratch one (frame, level) workgroup may need for the node boxes of a deep tree
+size_t orbk_octree_box_bytes(int M) { return (size_t)M * 2 * 4 * sizeof(int16_t); }
 
 __device__ __forceinline__ int wave_min_i(int v)
 {
@@ -753,106 +764,267 @@ __device__ __forceinline__ int wave_min_i(int v)
     return v;
 }
 
-// counters[idx] += 1 for every active lane, with ONE LDS atomic per distinct idx in the wave
-__device__ __forceinline__ void wave_agg_inc(int32_t *counters, int idx, bool active, int lane)
+// inclusive scan of arr[0..n) in LDS, in place, by all threads of the workgroup; returns the total.  Ends with a barrier.
+__device__ __forceinline__ int bscan_inclusive(int32_t *arr, int n, int32_t *sw)
 {
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lidx = __shfl(idx, leader, 64);
-        const unsigned long long same = __ballot(active && idx == lidx);
-        if (lane == leader) atomicAdd(&counters[lidx], __popcll(same));
-        todo &= ~same;
+    const int tid = threadIdx.x, QT = blockDim.x, wid = tid >> 6, lane = tid & 63, nw = QT >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += QT) {
+        const int i = base + tid;
+        const int v = i < n ? arr[i] : 0;
+        const int incl = wave_incl_scan(v);
+        if (lane == 63) sw[wid] = incl;
+        __syncthreads();
+        int pre = 0, tot = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int t = sw[w];
+            pre += w < wid ? t : 0;
+            tot += t;
+        }
+        if (i < n) arr[i] = carry + pre + incl;
+        carry += tot;
+        __syncthreads();
+    }
+    return carry;
+}
+
+// One generic pass at node level, executed by ALL threads of the workgroup (barriers between its steps).
+// In:  q.cc[i*4+qd] for every node i in P (quadrant sizes), list `cur` of size S, processing order P[0..m), rankOf.
+// Out: list `cur^1` (sizes, paths; boxes when DEEP), the old->new map (newIdx / cc-as-childpos), next P / rankOf, S, m,
+//      modeB, finish -- all workgroup-uniform.
+// largest-first processing order (:686-687): q.skey[0..Mp) holds (size << 32 | (creation seq + 1) << 16 | list position) for
+// the nToExpand multi-key children (zero beyond); sorts descending and writes P / rankOf of list generation nx
+__device__ __forceinline__ void qt_sort_assign(const QtShared &q, int Mp, int nToExpand, int S2, int nx)
+{
+    const int tid = threadIdx.x, QT = blockDim.x;
+    for (int kk = 2; kk <= Mp; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < Mp; i += QT) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = q.skey[i], c2 = q.skey[ixj];
+                    const bool desc = (i & kk) == 0;  // overall descending
+                    if (desc ? (a < c2) : (a > c2)) { q.skey[i] = c2; q.skey[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < S2; i += QT) q.rankOf(nx)[i] = -1;
+    __syncthreads();
+    for (int r = tid; r < nToExpand; r += QT) {
+        const int pos = (int)(q.skey[r] & 0xFFFFull);
+        q.P[r] = pos;
+        q.rankOf(nx)[pos] = r;
     }
 }
 
-// node of the current list a key belongs to, from its entry of the previous streaming pass (node | quadrant << 14)
-__device__ __forceinline__ int qt_follow(const QtShared &q, uint32_t kn)
+// Two inclusive scans with shared barriers: a[0..na) and b[0..nb) in LDS, in place, by all threads.  Ends with a barrier.
+__device__ __forceinline__ void bscan2_inclusive(int32_t *a, int na, int32_t *b, int nb, int32_t *sw, int &ta, int &tb)
 {
-    const int i = (int)(kn & KNODE_MASK);
-    const int ni = q.newIdx[i];
-    return ni >= 0 ? ni : q.childpos[i * 4 + (int)(kn >> 14)];
+    const int tid = threadIdx.x, QT = blockDim.x, wid = tid >> 6, lane = tid & 63, nw = QT >> 6;
+    int ca = 0, cb = 0;
+    for (int base = 0; base < max(na, nb); base += QT) {
+        const int i = base + tid;
+        const int va = i < na ? a[i] : 0, vb = i < nb ? b[i] : 0;
+        const int ia = wave_incl_scan(va), ib = wave_incl_scan(vb);
+        if (lane == 63) { sw[wid] = ia; sw[8 + wid] = ib; }
+        __syncthreads();
+        int pa = 0, pb = 0, sa = 0, sb = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int x = sw[w], y = sw[8 + w];
+            pa += w < wid ? x : 0;
+            pb += w < wid ? y : 0;
+            sa += x;
+            sb += y;
+        }
+        if (i < na) a[i] = ca + pa + ia;
+        if (i < nb) b[i] = cb + pb + ib;
+        ca += sa;
+        cb += sb;
+        __syncthreads();
+    }
+    ta = ca;
+    tb = cb;
 }
 
-// One generic pass at node level, executed by ONE wave (wave-synchronous, no barriers).
-// In:  q.cc[i*4+qd] for every node i in P (quadrant sizes), list `cur` of size S, processing order P[0..m), rankOf.
-// Out: list `cur^1` (boxes, sizes, paths), the old->new map (newIdx / childpos), next P / rankOf, S, m, modeB, finish.
-__device__ __forceinline__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur, int &modeB, bool &finish, int lane)
+// A breadth-first pass (:608-667) of a tree whose node sizes come from the leaf histogram: every multi-key node of the list
+// is split, in list order.  Same result as qt_node_phase<false> with modeB == 0, in 4 barriers instead of 15: children
+// and multi-key-children counts per rank are scanned together (packed), the unprocessed-node flags in the same barrier pair,
+// and the next processing order (list order of the new multi-key nodes, or the sort keys when the largest-first mode
+// begins) is written together with the next list -- a multi-key child of rank r sits at multi-rank
+// totalMulti - inclMulti[r] + (its index among r's multi-key children in n4..n1 order), creation sequence
+// inclMulti[r] - nMulti[r] + (index in n1..n4 order).
+__device__ __forceinline__ void qt_pass_bfs_hist(const QtShared &q, int N, int &S, int &m, int &cur, int &modeB, bool &finish)
 {
+    const int tid = threadIdx.x, QT = blockDim.x;
     const int nx = cur ^ 1;
+    int32_t *sw = q.misc + 32;
+    int32_t *pk = q.acc, *un = q.newIdx;
+    auto quad = [&](int i) {
+        const uint32_t pth = q.path(cur)[i];
+        const int d = (int)((pth >> 12) & 0xFu), root = (int)(pth >> 16);
+        return &q.hist[root * FF_PER_ROOT + ff_off(d + 1) + (int)((pth & 0xFFFu) << 2)];
+    };
+    for (int r = tid; r < m; r += QT) {
+        const int32_t *c = quad(q.P[r]);
+        pk[r] = ((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) | (((c[0] > 1) + (c[1] > 1) + (c[2] > 1) + (c[3] > 1)) << 16);
+    }
+    for (int i = tid; i < S; i += QT) un[i] = q.rankOf(cur)[i] < 0 ? 1 : 0;
+    __syncthreads();
+    int tpk, nUnproc;
+    bscan2_inclusive(pk, m, un, S, sw, tpk, nUnproc);
+    const int totalChildren = tpk & 0xFFFF, nToExpand = tpk >> 16;
+    const int S2 = totalChildren + nUnproc;
+    finish = (S2 >= N) || (S2 == S);  // :671
+    const int modeB2 = (!finish && (S2 + 3 * nToExpand > N)) ? 1 : 0;  // :675
+    int Mp = 2;
+    if (modeB2) {
+        while (Mp < nToExpand) Mp <<= 1;
+        for (int i = tid; i < Mp; i += QT) q.skey[i] = 0ull;
+        __syncthreads();
+    }
+    for (int i = tid; i < S; i += QT) {
+        const int r = q.rankOf(cur)[i];
+        const uint32_t pth = q.path(cur)[i];
+        if (r >= 0) {
+            const int inc = pk[r];
+            const int32_t *c = quad(i);
+            const int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+            const int cn[4] = {c0, c1, c2, c3};
+            int pos = totalChildren - (inc & 0xFFFF);
+            int mr = nToExpand - (inc >> 16);                                                 // multi-rank of the first multi-key child in list order
+            int seq = (inc >> 16) - ((c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1));              // creation sequence of n1's slot
+            int seqq[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) { seqq[qd] = seq; seq += cn[qd] > 1 ? 1 : 0; }
+            const uint32_t cpath = (pth & 0xFFFF0000u) | ((((pth >> 12) & 0xFu) + 1u) << 12) | ((pth & 0xFFFu) << 2);
+#pragma unroll
+            for (int qd = 3; qd >= 0; --qd) {  // list front holds n4, then n3, n2, n1 (:623-662)
+                if (cn[qd] > 0) {
+                    q.cnt(nx)[pos] = cn[qd];
+                    q.path(nx)[pos] = cpath | (uint32_t)qd;
+                    if (cn[qd] > 1) {
+                        if (modeB2) {
+                            q.skey[seqq[qd]] = ((unsigned long long)(uint32_t)cn[qd] << 32) |
+                                               ((unsigned long long)(uint32_t)(seqq[qd] + 1) << 16) | (unsigned long long)pos;
+                        } else {
+                            q.P[mr] = pos;
+                            q.rankOf(nx)[pos] = mr;
+                        }
+                        ++mr;
+                    } else if (!modeB2) {
+                        q.rankOf(nx)[pos] = -1;
+                    }
+                    ++pos;
+                }
+            }
+        } else {
+            const int pos = totalChildren + un[i] - 1;
+            q.cnt(nx)[pos] = q.cnt(cur)[i];
+            q.path(nx)[pos] = pth;
+            if (!modeB2) q.rankOf(nx)[pos] = -1;
+        }
+    }
+    __syncthreads();
+    if (!finish && modeB2) qt_sort_assign(q, Mp, nToExpand, S2, nx);
+    __syncthreads();
+    S = S2;
+    m = finish ? 0 : nToExpand;
+    cur = nx;
+    modeB = modeB2;
+}
+
+template <bool DEEP>
+__device__ __forceinline__ void qt_node_phase(const QtShared &q, int N, int &S, int &m, int &cur, int &modeB, bool &finish)
+{
+    const int tid = threadIdx.x, QT = blockDim.x, lane = tid & 63;
+    const int nx = cur ^ 1;
+    int32_t *sw = q.misc + 32;
+    int32_t *childpos = q.cc;
     // non-empty children per processing rank, inclusive sums, stop rank R
-    for (int r = lane; r < m; r += 64) {
+    for (int r = tid; r < m; r += QT) {
         const int i = q.P[r];
         q.acc[r] = (q.cc[i * 4] > 0) + (q.cc[i * 4 + 1] > 0) + (q.cc[i * 4 + 2] > 0) + (q.cc[i * 4 + 3] > 0);
     }
-    WSYNC();
-    wscan_inclusive(q.acc, m, lane);
+    if (tid == 0) q.misc[6] = m;
+    __syncthreads();
+    bscan_inclusive(q.acc, m, sw);
     int R = m;
     if (modeB) {  // first rank whose split brings the list to >= N nodes (:732)
         int rmin = m;
-        for (int r = lane; r < m; r += 64)
+        for (int r = tid; r < m; r += QT)
             if (S + q.acc[r] - (r + 1) >= N) rmin = min(rmin, r + 1);
-        R = wave_min_i(rmin);
+        rmin = wave_min_i(rmin);
+        if (lane == 0 && rmin < m) atomicMin(&q.misc[6], rmin);
+        __syncthreads();
+        R = q.misc[6];
     }
     const int totalChildren = R > 0 ? q.acc[R - 1] : 0;
     // unprocessed nodes keep their relative order behind the new children
-    for (int i = lane; i < S; i += 64) {
-        const int r = q.rankOf[i];
+    for (int i = tid; i < S; i += QT) {
+        const int r = q.rankOf(cur)[i];
         q.newIdx[i] = (r >= 0 && r < R) ? 0 : 1;
     }
-    WSYNC();
-    const int nUnproc = wscan_inclusive(q.newIdx, S, lane);
+    __syncthreads();
+    const int nUnproc = bscan_inclusive(q.newIdx, S, sw);
     const int S2 = totalChildren + nUnproc;
     // write the next list; leave the old->new map (newIdx / childpos) for whoever follows the keys
-    for (int i = lane; i < S; i += 64) {
-        const int r = q.rankOf[i];
+    for (int i = tid; i < S; i += QT) {
+        const int r = q.rankOf(cur)[i];
         const uint32_t pth = q.path(cur)[i];
         if (r >= 0 && r < R) {
             int pos = totalChildren - q.acc[r];
-            const int ulx = q.box(cur, 0)[i], uly = q.box(cur, 1)[i];
-            const int urx = q.box(cur, 2)[i], bry = q.box(cur, 3)[i];
-            const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);  // ceil(w/2) (:480-481)
+            int ulx = 0, uly = 0, urx = 0, bry = 0, midx = 0, midy = 0;
+            if (DEEP) {
+                ulx = q.box(cur, 0)[i]; uly = q.box(cur, 1)[i];
+                urx = q.box(cur, 2)[i]; bry = q.box(cur, 3)[i];
+                midx = ulx + ((urx - ulx + 1) >> 1); midy = uly + ((bry - uly + 1) >> 1);  // ceil(w/2) (:480-481)
+            }
             const uint32_t cpath = (pth & 0xFFFF0000u) | ((((pth >> 12) & 0xFu) + 1u) << 12) | ((pth & 0xFFFu) << 2);
             for (int qd = 3; qd >= 0; --qd) {  // list front holds n4, then n3, n2, n1 (:623-662)
                 const int cn = q.cc[i * 4 + qd];
                 if (cn > 0) {
-                    q.box(nx, 0)[pos] = (int16_t)((qd & 1) ? midx : ulx);
-                    q.box(nx, 1)[pos] = (int16_t)((qd & 2) ? midy : uly);
-                    q.box(nx, 2)[pos] = (int16_t)((qd & 1) ? urx : midx);
-                    q.box(nx, 3)[pos] = (int16_t)((qd & 2) ? bry : midy);
+                    if (DEEP) {
+                        q.box(nx, 0)[pos] = (int16_t)((qd & 1) ? midx : ulx);
+                        q.box(nx, 1)[pos] = (int16_t)((qd & 2) ? midy : uly);
+                        q.box(nx, 2)[pos] = (int16_t)((qd & 1) ? urx : midx);
+                        q.box(nx, 3)[pos] = (int16_t)((qd & 2) ? bry : midy);
+                    }
                     q.cnt(nx)[pos] = cn;
                     q.path(nx)[pos] = cpath | (uint32_t)qd;
-                    q.childpos[i * 4 + qd] = pos;
+                    childpos[i * 4 + qd] = pos;
                     ++pos;
                 } else {
-                    q.childpos[i * 4 + qd] = -1;
+                    childpos[i * 4 + qd] = -1;
                 }
             }
             q.newIdx[i] = -1;
         } else {
             const int pos = totalChildren + q.newIdx[i] - 1;
-            q.box(nx, 0)[pos] = q.box(cur, 0)[i];
-            q.box(nx, 1)[pos] = q.box(cur, 1)[i];
-            q.box(nx, 2)[pos] = q.box(cur, 2)[i];
-            q.box(nx, 3)[pos] = q.box(cur, 3)[i];
+            if (DEEP) {
+                q.box(nx, 0)[pos] = q.box(cur, 0)[i];
+                q.box(nx, 1)[pos] = q.box(cur, 1)[i];
+                q.box(nx, 2)[pos] = q.box(cur, 2)[i];
+                q.box(nx, 3)[pos] = q.box(cur, 3)[i];
+            }
             q.cnt(nx)[pos] = q.cnt(cur)[i];
             q.path(nx)[pos] = pth;
             q.newIdx[i] = pos;
         }
     }
-    WSYNC();
+    __syncthreads();
     // multi-key children in creation order (rank asc, n1..n4): counts per rank -> sequence numbers
-    for (int r = lane; r < R; r += 64) {
+    for (int r = tid; r < R; r += QT) {
         const int i = q.P[r];
         int mc = 0;
         for (int qd = 0; qd < 4; ++qd) {
-            const int pos = q.childpos[i * 4 + qd];
+            const int pos = childpos[i * 4 + qd];
             if (pos >= 0 && q.cnt(nx)[pos] > 1) ++mc;
         }
         q.acc[r] = mc;
     }
-    WSYNC();
-    const int nToExpand = wscan_inclusive(q.acc, R, lane);
+    __syncthreads();
+    const int nToExpand = bscan_inclusive(q.acc, R, sw);
     // termination / next mode (:671-675, :736)
     finish = (S2 >= N) || (S2 == S);
     int modeB2 = modeB;
@@ -861,31 +1033,32 @@ __device__ __forceinline__ void qt_node_phase(const QtShared &q, int N, int &S, 
     if (!finish) {
         if (!modeB2) {
             // list order of the multi-key nodes of the new list; P/rankOf of the OLD list are dead now
-            for (int i = lane; i < S2; i += 64) ((int32_t *)q.skey)[i] = q.cnt(nx)[i] > 1 ? 1 : 0;
-            WSYNC();
-            m2 = wscan_inclusive((int32_t *)q.skey, S2, lane);
-            for (int i = lane; i < S2; i += 64) {
+            int32_t *flag = (int32_t *)q.skey;
+            for (int i = tid; i < S2; i += QT) flag[i] = q.cnt(nx)[i] > 1 ? 1 : 0;
+            __syncthreads();
+            m2 = bscan_inclusive(flag, S2, sw);
+            for (int i = tid; i < S2; i += QT) {
                 const bool multi = q.cnt(nx)[i] > 1;
-                const int r = ((int32_t *)q.skey)[i] - 1;
-                q.rankOf[i] = multi ? r : -1;
+                const int r = flag[i] - 1;
+                q.rankOf(nx)[i] = multi ? r : -1;
                 if (multi) q.P[r] = i;
             }
         } else {
             // sort the new multi-key children by (size desc, creation seq desc) (:686-687)
             int Mp = 2;
             while (Mp < nToExpand) Mp <<= 1;
-            for (int i = lane; i < Mp; i += 64) q.skey[i] = 0ull;
-            WSYNC();
-            for (int r = lane; r < R; r += 64) {
+            for (int i = tid; i < Mp; i += QT) q.skey[i] = 0ull;
+            __syncthreads();
+            for (int r = tid; r < R; r += QT) {
                 const int i = q.P[r];
                 int mc = 0;
                 for (int qd = 0; qd < 4; ++qd) {
-                    const int pos = q.childpos[i * 4 + qd];
+                    const int pos = childpos[i * 4 + qd];
                     if (pos >= 0 && q.cnt(nx)[pos] > 1) ++mc;
                 }
                 int seq = q.acc[r] - mc;  // acc is inclusive
                 for (int qd = 0; qd < 4; ++qd) {
-                    const int pos = q.childpos[i * 4 + qd];
+                    const int pos = childpos[i * 4 + qd];
                     if (pos >= 0 && q.cnt(nx)[pos] > 1) {
                         q.skey[seq] = ((unsigned long long)(uint32_t)q.cnt(nx)[pos] << 32) |
                                       ((unsigned long long)(uint32_t)(seq + 1) << 16) | (unsigned long long)pos;
@@ -893,40 +1066,43 @@ __device__ __forceinline__ void qt_node_phase(const QtShared &q, int N, int &S, 
                     }
                 }
             }
-            WSYNC();
-            for (int kk = 2; kk <= Mp; kk <<= 1)
-                for (int j = kk >> 1; j > 0; j >>= 1) {
-                    for (int i = lane; i < Mp; i += 64) {
-                        const int ixj = i ^ j;
-                        if (ixj > i) {
-                            const unsigned long long a = q.skey[i], c2 = q.skey[ixj];
-                            const bool desc = (i & kk) == 0;  // overall descending
-                            if (desc ? (a < c2) : (a > c2)) { q.skey[i] = c2; q.skey[ixj] = a; }
-                        }
-                    }
-                    WSYNC();
-                }
-            for (int i = lane; i < S2; i += 64) q.rankOf[i] = -1;
-            WSYNC();
-            for (int r = lane; r < nToExpand; r += 64) {
-                const int pos = (int)(q.skey[r] & 0xFFFFull);
-                q.P[r] = pos;
-                q.rankOf[pos] = r;
-            }
+            __syncthreads();
+            qt_sort_assign(q, Mp, nToExpand, S2, nx);
             m2 = nToExpand;
         }
     }
-    WSYNC();
+    __syncthreads();
     S = S2;
     m = m2;
     cur = nx;
     modeB = modeB2;
 }
 
-__global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict__ plan,
+// -DQT_PROFILE: per-phase clock stamps of k_octree summed into the words behind the overflow word (developer builds only;
+// read with orbfe_internal_read_misc, tools/octree_phases.py)
+#ifdef QT_PROFILE
+#define QT_STAMP(p)                                                                                              \
+    do {                                                                                                         \
+        if (tid == 0) {                                                                                          \
+            const unsigned long long t_now = wall_clock64();                                                     \
+            atomicAdd((unsigned long long *)ovf + 8 + (p) + 8 * min(level, 14), t_now - t_prev);               \
+            t_prev = t_now;                                                                                      \
+        }                                                                                                        \
+    } while (0)
+#else
+#define QT_STAMP(p)
+#endif
+#ifndef QT_MIN_WAVES
+#define QT_MIN_WAVES 6   // waves per SIMD the register allocation must allow (A/B on the GPU box: tools/ab_build.sh)
+#endif
+__global__ __launch_bounds__(QT_MAX, QT_MIN_WAVES) void k_octree(const OrbPlan *__restrict__ plan,
                                                const uint2 *__restrict__ skeys,     // [B][keys_per_frame] {key, ord} from k_fast_map
                                                const int32_t *__restrict__ scount,  // [B][nlevels] * NK_STRIDE
+                                               const uint32_t *__restrict__ cflags, // [B][nlevels][cf_words] from k_fast_map
+                                               int32_t cf_words,
                                                uint16_t *__restrict__ knode,        // [B][keys_per_frame] scratch (deep trees only)
+                                               int16_t *__restrict__ qtbox,         // [B][nlevels][box_stride] scratch (deep trees only)
+                                               int32_t box_stride,
                                                int32_t *__restrict__ nkeys,         // [B][nlevels] out (taps)
                                                uint32_t *__restrict__ sel,          // [B][sel_per_frame] out
                                                int32_t *__restrict__ nsel,          // [B][nlevels] out
@@ -938,26 +1114,34 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     // level of all frames, and level 0 carries ~10x the keys of level 7.  Rotating the level by the frame index gives
     // every XCD the same mix of levels.
     const int b = blockIdx.y, level = g.level0 + (int)((blockIdx.x + blockIdx.y) % gridDim.x), tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63;
     const int QT = blockDim.x;  // 128 .. 512 (per level group)
     const OrbLevel &L = plan->lv[level];
     const int N = L.nfeat;
     QtShared q;
     qt_carve(smem, g.M, g.nini, g.tw, g.th, g.ncells, q);
+    q.gbox = qtbox + ((int64_t)b * plan->nlevels + level) * box_stride;
     int32_t *misc = q.misc;
     const uint2 *SK = skeys + (int64_t)b * plan->keys_per_frame + L.key_off;
     uint16_t *KN = knode + (int64_t)b * plan->keys_per_frame + L.key_off;
     const int nini = L.nini;
     const int ybot = L.h - 2 * ORBFE_MINB;  // maxBorderY - minBorderY
+#ifdef QT_PROFILE
+    unsigned long long t_prev = wall_clock64();
+#endif
 
-    // ---- prologue 1: the reference's per-cell threshold fallback (:818-825) on the unordered survivor list ----
-    // A cell contributes {A > iniTh} if that is non-empty, else all its NMS survivors ({A > minTh}).
+    // ---- prologue 1: the reference's per-cell threshold fallback (:818-825): a cell contributes {A > iniTh} if that is
+    // non-empty, else all its NMS survivors ({A > minTh}).  Which cells have an iniTh survivor was recorded by k_fast_map as
+    // it emitted them (one bit per cell): no pass over the keys is spent on it here.
     const int ns_all = scount[(b * plan->nlevels + level) * ORBFE_NK_STRIDE];
     const int ns = min(ns_all, L.key_cap);
     if (tid == 0 && ns_all > L.key_cap) atomicOr(ovf, 1);  // k_fast_map dropped survivors: results would be truncated
     uint32_t *cflag = q.cflag;  // bitmap over this level's cells; stays valid to the end of the kernel
     const int nwords = (L.ncells + 31) >> 5;
-    for (int i = tid; i < nwords; i += QT) cflag[i] = 0u;
+    {
+        const uint32_t *gflag = cflags + (int64_t)(b * plan->nlevels + level) * cf_words;
+        for (int i = tid; i < nwords; i += QT) cflag[i] = gflag[i];
+    }
     for (int i = tid; i < nini * FF_PER_ROOT; i += QT) q.hist[i] = 0;
     if (tid == 0) misc[5] = 0;
     // DivideNode (:478-522) halves x and y independently (mid = UL + ceil(extent / 2)), so a key's 5-level quadrant
@@ -987,20 +1171,9 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
         else q.ytab[v] = (uint16_t)(code << 1);
     }
     __syncthreads();
+    QT_STAMP(0);
     const int ini = plan->ini_th;
-    for (int k0 = tid; k0 < ns; k0 += QT * KUNROLL) {
-        uint2 e[KUNROLL];
-#pragma unroll
-        for (int u = 0; u < KUNROLL; ++u) e[u] = SK[min(k0 + u * QT, ns - 1)];
-#pragma unroll
-        for (int u = 0; u < KUNROLL; ++u)
-            if (k0 + u * QT < ns && orb_key_r(e[u].x) >= ini) {  // cv score = A - 1 >= iniTh  <=>  A > iniTh
-                const uint32_t cell = e[u].y >> 12;
-                // neighbouring keys share cells (and flag words): test first, the atomics would serialise
-                if (!((cflag[cell >> 5] >> (cell & 31)) & 1u)) atomicOr(&cflag[cell >> 5], 1u << (cell & 31));
-            }
-    }
-    __syncthreads();
+    QT_STAMP(1);
     // ---- prologue 2: leaf histogram of the kept keys (a key is kept if it is above iniTh or its cell has no such key).
     // Keys are never moved or copied: whoever needs a key later re-derives "kept" and its path code from the key.
     auto key_kept = [&](const uint2 &e) {
@@ -1029,46 +1202,47 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     __syncthreads();
     const int n = misc[5];
     if (tid == 0) nkeys[(b * plan->nlevels + level) * ORBFE_NK_STRIDE] = n;
+    QT_STAMP(2);
 
-    // ---- histogram passes: wave 0 alone, no key is touched ----
-    if (wid == 0) {
-        for (int d = FFD - 1; d >= 1; --d) {  // quadrant sizes of every possible node of depth d-1 .. 4
-            const int cntd = nini << (2 * d);
-            for (int e = lane; e < cntd; e += 64) {
-                const int r = e >> (2 * d), p = e & ((1 << (2 * d)) - 1);
-                const int32_t *src = &q.hist[r * FF_PER_ROOT + ff_off(d + 1) + (p << 2)];
-                q.hist[r * FF_PER_ROOT + ff_off(d) + p] = src[0] + src[1] + src[2] + src[3];
-            }
-            WSYNC();
+    // ---- histogram passes: node-level bookkeeping by the whole workgroup, no key is touched ----
+    for (int d = FFD - 1; d >= 1; --d) {  // quadrant sizes of every possible node of depth d-1 .. 4
+        const int cntd = nini << (2 * d);
+        for (int e = tid; e < cntd; e += QT) {
+            const int r = e >> (2 * d), p = e & ((1 << (2 * d)) - 1);
+            const int32_t *src = &q.hist[r * FF_PER_ROOT + ff_off(d + 1) + (p << 2)];
+            q.hist[r * FF_PER_ROOT + ff_off(d) + p] = src[0] + src[1] + src[2] + src[3];
         }
-        int S = 0, m = 0, cur = 0, modeB = 0;
-        bool finish = false;
-        if (lane == 0) {  // roots (:545-587): nini boxes, empty roots erased
-            for (int r = 0; r < nini; ++r) {
-                const int32_t *h1 = &q.hist[r * FF_PER_ROOT];
-                const int cn = h1[0] + h1[1] + h1[2] + h1[3];
-                if (cn > 0) {
-                    q.box(0, 0)[S] = (int16_t)L.root_x[r];
-                    q.box(0, 1)[S] = 0;
-                    q.box(0, 2)[S] = (int16_t)L.root_x[r + 1];
-                    q.box(0, 3)[S] = (int16_t)ybot;
-                    q.cnt(0)[S] = cn;
-                    q.path(0)[S] = (uint32_t)r << 16;
-                    ++S;
-                }
-            }
-            for (int i = 0; i < S; ++i) {  // initial processing order: multi-key roots in list order
-                if (q.cnt(0)[i] > 1) { q.P[m] = i; q.rankOf[i] = m; ++m; }
-                else q.rankOf[i] = -1;
+        __syncthreads();
+    }
+    if (tid == 0) {  // roots (:545-587): nini boxes, empty roots erased; initial processing order: multi-key roots in list order
+        int S0 = 0, m0 = 0;
+        for (int r = 0; r < nini; ++r) {
+            const int32_t *h1 = &q.hist[r * FF_PER_ROOT];
+            const int cn = h1[0] + h1[1] + h1[2] + h1[3];
+            if (cn > 0) {
+                q.cnt(0)[S0] = cn;
+                q.path(0)[S0] = (uint32_t)r << 16;
+                if (cn > 1) { q.P[m0] = S0; q.rankOf(0)[S0] = m0; ++m0; }
+                else q.rankOf(0)[S0] = -1;
+                ++S0;
             }
         }
-        S = __shfl(S, 0, 64);
-        m = __shfl(m, 0, 64);
-        WSYNC();
+        misc[0] = S0;
+        misc[1] = m0;
+    }
+    __syncthreads();
+    int S = misc[0], m = misc[1], cur = 0, modeB = 0;
+    bool finish = false;
+    {
         int npass = 0;
         const int ffd = plan->dbg == 50 ? 0 : FFD;  // developer knob: 50 = streaming passes only
         while (!finish && npass < ffd) {  // nodes processed in pass p have depth <= p-1 <= 4: sizes come from the histogram
-            for (int r = lane; r < m; r += 64) {
+            if (!modeB && !(plan->dbg == 51)) {  // breadth-first pass (developer knob 51: generic passes only)
+                qt_pass_bfs_hist(q, N, S, m, cur, modeB, finish);
+                ++npass;
+                continue;
+            }
+            for (int r = tid; r < m; r += QT) {
                 const int i = q.P[r];
                 const uint32_t pth = q.path(cur)[i];
                 const int d = (int)((pth >> 12) & 0xFu), root = (int)(pth >> 16);
@@ -1078,39 +1252,29 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
                 q.cc[i * 4 + 2] = src[2];
                 q.cc[i * 4 + 3] = src[3];
             }
-            WSYNC();
-            qt_node_phase(q, N, S, m, cur, modeB, finish, lane);
+            __syncthreads();
+            qt_node_phase<false>(q, N, S, m, cur, modeB, finish);
             ++npass;
         }
-        // path -> node table of the current list (overwrites the histogram): exactly one node of a key's path exists
-        for (int i = lane; i < nini * FF_PER_ROOT; i += 64) q.hist[i] = -1;
-        if (lane < 4) misc[8 + lane] = -1;
-        WSYNC();
-        for (int i = lane; i < S; i += 64) {
-            const uint32_t pth = q.path(cur)[i];
-            const int d = (int)((pth >> 12) & 0xFu), root = (int)(pth >> 16);
-            if (d == 0) misc[8 + root] = i;
-            else q.hist[root * FF_PER_ROOT + ff_off(d) + (int)(pth & 0xFFFu)] = i;
-            q.newIdx[i] = i;  // identity map for keys that already carry a node index
-        }
-        WSYNC();
-        if (lane == 0) {
-            misc[0] = S;
-            misc[1] = m;
-            misc[2] = cur;
-            misc[3] = finish ? 1 : 0;
-            misc[4] = modeB;
-        }
+    }
+    const bool ff_done = finish;
+    QT_STAMP(3);
+    // path -> node table of the current list (overwrites the histogram): exactly one node of a key's path exists
+    for (int i = tid; i < nini * FF_PER_ROOT; i += QT) q.hist[i] = -1;
+    if (tid < ORBFE_MAX_ROOTS) misc[16 + tid] = -1;
+    __syncthreads();
+    for (int i = tid; i < S; i += QT) {
+        const uint32_t pth = q.path(cur)[i];
+        const int d = (int)((pth >> 12) & 0xFu), root = (int)(pth >> 16);
+        if (d == 0) misc[16 + root] = i;
+        else q.hist[root * FF_PER_ROOT + ff_off(d) + (int)(pth & 0xFFFu)] = i;
     }
     __syncthreads();
-    int S = misc[0], m = misc[1], cur = misc[2];
-    const bool ff_done = misc[3] != 0;
-
     // flatten the path -> node table: every leaf learns the one node of its path that exists (the deepest table hit),
     // in place -- a leaf entry is read and written by its own thread only, the shallower levels are read-only here
     for (int i = tid; i < nini << (2 * FFD); i += QT) {
         const int root = i >> (2 * FFD), code = i & ((1 << (2 * FFD)) - 1);
-        int idx = misc[8 + root];
+        int idx = misc[16 + root];
 #pragma unroll
         for (int d = 1; d < FFD; ++d) {
             const int t = q.hist[root * FF_PER_ROOT + ff_off(d) + (code >> (2 * (FFD - d)))];
@@ -1122,9 +1286,26 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     }
     __syncthreads();
     auto node_of_code = [&](uint32_t kn) { return q.hist[(int)(kn >> 10) * FF_PER_ROOT + ff_off(FFD) + (int)(kn & 0x3FFu)]; };
+    QT_STAMP(4);
 
     if (!ff_done) {
-        // ---- deeper trees: keys take their node index and the passes stream over the keys ----
+        // ---- deeper trees (clustered candidates): boxes of the current nodes from their paths, keys take their node
+        // index, and the passes stream over the keys ----
+        for (int i = tid; i < S; i += QT) {
+            const uint32_t pth = q.path(cur)[i];
+            const int d = (int)((pth >> 12) & 0xFu), root = (int)(pth >> 16);
+            int ulx = L.root_x[root], urx = L.root_x[root + 1], uly = 0, bry = ybot;
+            for (int s = d - 1; s >= 0; --s) {  // DivideNode along the path (:478-522)
+                const int qd = (int)((pth >> (2 * s)) & 3u);
+                const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);
+                if (qd & 1) ulx = midx; else urx = midx;
+                if (qd & 2) uly = midy; else bry = midy;
+            }
+            q.box(cur, 0)[i] = (int16_t)ulx;
+            q.box(cur, 1)[i] = (int16_t)uly;
+            q.box(cur, 2)[i] = (int16_t)urx;
+            q.box(cur, 3)[i] = (int16_t)bry;
+        }
         for (int k = tid; k < ns; k += QT) {
             const uint2 e = SK[k];
             KN[k] = key_kept(e) ? (uint16_t)node_of_code(key_code(e)) : (uint16_t)0xFFFFu;  // 0xFFFF = dropped key
@@ -1145,39 +1326,31 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
                 for (int u = 0; u < KUNROLL; ++u) {
                     const int k = k0 + u * QT;
                     if (k < ns && kn[u] != 0xFFFFu) {
-                        const int i = qt_follow(q, kn[u]);
-                        uint32_t out = (uint32_t)i;
+                        const int i = (int)kn[u];  // node of the current list
                         if (q.cnt(cur)[i] > 1) {
                             const int ulx = q.box(cur, 0)[i], uly = q.box(cur, 1)[i];
                             const int midx = ulx + ((q.box(cur, 2)[i] - ulx + 1) >> 1);  // UL.x + ceil(w/2)  (:480)
                             const int midy = uly + ((q.box(cur, 3)[i] - uly + 1) >> 1);
                             const int qd = (orb_key_x(kv[u]) < midx ? 0 : 1) + (orb_key_y(kv[u]) < midy ? 0 : 2);
                             atomicAdd(&q.cc[i * 4 + qd], 1);
-                            out |= (uint32_t)qd << 14;
+                            KN[k] = (uint16_t)((uint32_t)i | ((uint32_t)qd << 14));
                         }
-                        KN[k] = (uint16_t)out;
                     }
                 }
             }
             __syncthreads();
-            if (wid == 0) {
-                int modeB = misc[4];
-                bool finish = false;
-                int S1 = S, m1 = m, c1 = cur;
-                qt_node_phase(q, N, S1, m1, c1, modeB, finish, lane);
-                if (lane == 0) {
-                    misc[0] = S1;
-                    misc[1] = m1;
-                    misc[2] = c1;
-                    misc[3] = finish ? 1 : 0;
-                    misc[4] = modeB;
+            qt_node_phase<true>(q, N, S, m, cur, modeB, finish);
+            // keys follow their nodes into the new list (the quadrant counts have just become child positions)
+            for (int k = tid; k < ns; k += QT) {
+                const uint32_t kn = KN[k];
+                if (kn != 0xFFFFu) {
+                    const int i = (int)(kn & KNODE_MASK);
+                    const int ni = q.newIdx[i];
+                    KN[k] = (uint16_t)(ni >= 0 ? ni : q.cc[i * 4 + (int)(kn >> 14)]);
                 }
             }
             __syncthreads();
-            S = misc[0];
-            m = misc[1];
-            cur = misc[2];
-            if (misc[3]) break;
+            if (finish) break;
         }
     }
 
@@ -1186,6 +1359,7 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
     unsigned long long *best = q.skey;
     for (int i = tid; i < S; i += QT) best[i] = 0ull;
     __syncthreads();
+    QT_STAMP(5);
     for (int k0 = tid; k0 < ns; k0 += QT * KUNROLL) {
         uint2 e[KUNROLL];
         uint32_t kn[KUNROLL];
@@ -1199,7 +1373,7 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
         for (int u = 0; u < KUNROLL; ++u) {
             const int k = k0 + u * QT;
             if (k < ns && (ff_done ? key_kept(e[u]) : kn[u] != 0xFFFFu)) {
-                const int i = ff_done ? node_of_code(key_code(e[u])) : qt_follow(q, kn[u]);
+                const int i = ff_done ? node_of_code(key_code(e[u])) : (int)kn[u];
                 const unsigned long long cand = ((unsigned long long)orb_key_r(e[u].x) << 52) |
                                                 ((unsigned long long)(0x0FFFFFFFu - e[u].y) << 24) | (unsigned long long)k;
                 // neighbouring keys share nodes: a plain read filters most of them before the (serialising) atomic
@@ -1208,6 +1382,7 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
         }
     }
     __syncthreads();
+    QT_STAMP(6);
     uint32_t *out = sel + (int64_t)b * plan->sel_per_frame + L.sel_off;
     const int nout = min(S, L.sel_cap);
     for (int i = tid; i < nout; i += QT) {
@@ -1219,6 +1394,7 @@ __global__ __launch_bounds__(QT_MAX, 8) void k_octree(const OrbPlan *__restrict_
         nsel[b * plan->nlevels + level] = nout;
         if (S > L.sel_cap) atomicOr(ovf, 2);
     }
+    QT_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1697,13 +1873,15 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
     const FrameSrc fs = make_src(a);
     hipError_t e = hipMemsetAsync(a.d_scount, 0, sizeof(int32_t) * (size_t)a.nframes * a.h_plan->nlevels * ORBFE_NK_STRIDE, st);
     if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.d_cflag, 0, sizeof(uint32_t) * (size_t)a.nframes * a.h_plan->nlevels * a.cf_words, st);
+    if (e != hipSuccess) return e;
     dim3 grid((a.h_plan->nfwaves + 3) / 4, a.nframes);
     if (a.fast_sparse)
-        hipLaunchKernelGGL(k_fast_map<1>, grid, dim3(256), 0, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
-                           a.d_scount, a.d_fstat);
+        hipLaunchKernelGGL(k_fast_map<1>, grid, dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
+                           a.d_scount, a.d_cflag, a.cf_words, a.d_fstat);
     else
-        hipLaunchKernelGGL(k_fast_map<0>, grid, dim3(256), 0, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
-                           a.d_scount, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_fast_map<0>, grid, dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
+                           a.d_scount, a.d_cflag, a.cf_words, (unsigned long long *)nullptr);
     return hipGetLastError();
 }
 
@@ -1720,7 +1898,13 @@ hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
     // bookkeeping, ~45 us each: single-frame host latency 0.26 -> 0.35 ms), so they take one launch.
     const bool grouped = a.nframes >= 128;
     const int cut[4] = {0, grouped ? std::max(1, nl / 8) : nl, grouped ? std::max(1, nl / 2) : nl, nl};
-    const int qts[3] = {512, 256, 128};
+    int qts[3] = {512, 256, 128};
+    if (const char *e = getenv("ORBFE_QT")) {  // developer knob: threads per workgroup of the three level groups
+        int v[3];
+        if (sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3)
+            for (int i = 0; i < 3; ++i)
+                if (v[i] >= 64 && v[i] <= QT_MAX && v[i] % 64 == 0) qts[i] = v[i];
+    }
     for (int gi = 0; gi < 3; ++gi) {
         const int l0 = cut[gi], l1 = std::min(cut[gi + 1], nl);
         if (l1 <= l0) continue;
@@ -1737,8 +1921,8 @@ hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
         }
         const size_t lds = orbk_octree_lds_bytes(g.M, g.nini, g.tw, g.th, g.ncells);
         const int qt = qts[gi];
-        hipLaunchKernelGGL(k_octree, dim3(l1 - l0, a.nframes), dim3(qt), lds, st, a.d_plan, a.d_skeys, a.d_scount, a.d_knode,
-                           a.d_nkeys, a.d_sel, a.d_nsel, a.d_ovf, g);
+        hipLaunchKernelGGL(k_octree, dim3(l1 - l0, a.nframes), dim3(qt), lds, st, a.d_plan, a.d_skeys, a.d_scount, a.d_cflag, a.cf_words, a.d_knode,
+                           a.d_qtbox, a.qtbox_stride, a.d_nkeys, a.d_sel, a.d_nsel, a.d_ovf, g);
     }
     return hipGetLastError();
 }

@@ -170,6 +170,25 @@ def test_streaming_quadtree_passes_only(oracle):
         del os.environ["ORBFE_DEBUG"]
 
 
+def test_generic_quadtree_passes_only(oracle):
+    """ORBFE_DEBUG=51 disables the fused breadth-first pass of the histogram mode: every pass goes through the generic node
+    phase (the one the largest-first passes and the deep trees use) and must give the same trees."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    os.environ["ORBFE_DEBUG"] = "51"
+    try:
+        e = ORBextractor(1000, 1.2, 8, 20, 7)
+        for seed, sparse in ((0, False), (2, True), (5, False)):
+            img = synth_frame(seed, sparse=sparse)
+            oe = oracle.OracleExtractor()
+            ok, od = oe(img)
+            gk, gd = e(img)
+            for l in range(8):
+                assert np.array_equal(e.selected(l), cand_array(oe.selected(l))), f"quadtree level {l}"
+            assert_same_output(gk, gd, ok, od)
+    finally:
+        del os.environ["ORBFE_DEBUG"]
+
+
 def test_edge_cases(oracle, ext):
     from orb_slam2_ssd_semantic_amd import ORBextractor, OrbfeError, _ffi
     # empty image: silent return, outputs untouched (src/ORBextractor.cc:1055-1056)

@@ -1,4 +1,5 @@
-"""Stage times of the batched extractor on B distinct S(seed) frames (GPU box).  usage: B=256 python tools/stage_times.py"""
+"""Stage times of the batched extractor on B distinct S(seed) frames (GPU box).
+usage: B=256 [W=1920 H=1080 NF=4000] [ORBFE_OVERLAP=0] python tools/stage_times.py"""
 import os
 import sys
 
@@ -9,8 +10,8 @@ from bench import base_frames, expand_frames
 
 B = int(os.environ.get("B", "256"))
 GEN = os.environ.get("GEN", "S")
-w, h = 640, 480
-ext = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+w, h, NF = int(os.environ.get("W", "640")), int(os.environ.get("H", "480")), int(os.environ.get("NF", "1000"))
+ext = ORBextractor(NF, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
 ext.set_fast_mode(int(os.environ.get("FAST_MODE", "0")))
 cap = ext.capacity()
 fr = expand_frames(torch.from_numpy(base_frames(GEN, min(B, 32), w, h, 10000)).cuda(), B)
