@@ -264,6 +264,27 @@ class FakeEngine:
         desc[lo:lo + self.F, :, 0] = s.to(torch.uint8)
 
 
+class c_stdout_to_stderr:
+    """RCCL prints a version banner on the C stdout when a communicator is created; this script's stdout carries ONE JSON
+    line.  Inside the block, file descriptor 1 points at stderr (C stdio is flushed on both sides)."""
+
+    def __enter__(self):
+        import ctypes
+        self.libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self.libc.fflush(None)
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -431,10 +452,14 @@ def main():
     if not fake:
         extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fence)
     if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)   # anything a native library left in the C stdout buffer goes out BEFORE the line
         print(json.dumps(result), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        with c_stdout_to_stderr():
+            dist.barrier()
+            dist.destroy_process_group()
+    os.dup2(2, 1)   # nothing may follow the JSON line on stdout (buffers flushed at exit by native libraries)
 
 
 def self_check(eng, d_gray, out_set, nf, seed=2026):
@@ -1053,6 +1078,68 @@ def config5_leg(args, local_rank, nframes=512, nfeat=4000, w=1920, h=1080, warmu
     return out
 
 
+def config4_group(args, rank, local_rank, world, fence, allf, lo, hi, global_batch, nfeat, steps, ncand=8):
+    """Config 4 through the C-ABI's own multi-device layer (include/orbfe.h orbfe_group_*, one rank per process): extract the
+    shard into its slice of the padded blocks, ONE in-place ncclAllGather (RCCL, loaded by liborbfe.so itself) and the
+    consumer of the gather (src/LoopClosing.cc:312-342): every own frame is brute-force matched against `ncand`
+    candidate frames spread over the whole gathered batch, i.e. over the other ranks' shards."""
+    from orb_slam2_ssd_semantic_amd.distributed import KeyframeGroup
+    w, h = args.width, args.height
+    idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        with c_stdout_to_stderr():
+            idt.copy_(torch.frombuffer(bytearray(KeyframeGroup.unique_id()), dtype=torch.uint8))
+    if world > 1:
+        dist.broadcast(idt, 0)
+    with c_stdout_to_stderr():
+        g = KeyframeGroup(nfeat, 1.2, 8, 20, 7, w, h, global_batch, rank_of_world=(rank, world, bytes(idt.cpu().numpy().tobytes())),
+                          device=local_rank)
+    shard = allf[lo:hi].contiguous()
+    nloc = hi - lo
+    qf = np.repeat(np.arange(lo, hi), ncand)
+    tf = (qf + 1 + (np.arange(len(qf)) % ncand) * (global_batch // ncand)) % global_batch   # candidates in every shard
+    g.nframes = global_batch
+    qb = torch.tensor([g.block_index(int(f)) for f in qf], dtype=torch.int32, device="cuda")
+    tb = torch.tensor([g.block_index(int(f)) for f in tf], dtype=torch.int32, device="cuda")
+    d_match = torch.zeros((len(qf), g.cap), dtype=torch.int32, device="cuda")
+    d_nm = torch.zeros(len(qf), dtype=torch.int32, device="cuda")
+
+    def one():
+        g.extract_shard_device(0, shard.data_ptr(), global_batch, w, h, w, w * h)
+        g.allgather()
+        g.match_device(0, qb.data_ptr(), tb.data_ptr(), len(qf), d_match.data_ptr(), d_nm.data_ptr(), 0.9, 100, True)
+    for _ in range(2):
+        one()
+    g.synchronize()
+    fence()
+    t = time.perf_counter()
+    for _ in range(steps):
+        one()
+    g.synchronize()
+    fence()
+    dt = time.perf_counter() - t
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    nm = d_nm.cpu().numpy()
+    res = {"frames_per_s": round(global_batch * steps / dt, 1), "pairs_per_rank": int(len(qf)), "candidates_per_frame": ncand,
+           "mean_matches_per_pair": round(float(nm.mean()), 1), "frames_per_gpu": nloc,
+           "what": "orbfe_group_extract_shard_device + orbfe_group_allgather (in-place ncclAllGather of counts / keypoints / "
+                   "descriptors) + orbfe_group_match_device (own frames x candidate frames of the gathered batch), strong scaling"}
+    if rank == 0 and not args.no_cpu_baseline:   # two pairs against the oracle, one of them across the batch
+        from oracle import oracle_ffi as O
+        oe = O.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+        for p in (0, len(qf) - 1):
+            (qk, qd), (tk, td) = oe(allf[int(qf[p])].cpu().numpy()), oe(allf[int(tf[p])].cpu().numpy())
+            om, _, _, on = O.match_bf(qd, td, qk["angle"], tk["angle"], 0.9, 100, True)
+            if not (int(nm[p]) == on and np.array_equal(d_match[p, :len(qk)].cpu().numpy(), om)):
+                raise SystemExit(f"bench.py config 4: gathered-set match of pair {p} differs from the oracle")
+        res["exact_checked"] = True
+    g.close()
+    return res
+
+
 def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2000, steps=10):
     """BASELINE config 4: a 1024-frame keyframe batch S(10000+i), 2000 features, contiguous shards, one all-gather of
     counts + padded keypoints + descriptors.  Strong figure: the fixed global batch; weak: 1024 frames on every rank."""
@@ -1108,6 +1195,10 @@ def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2
 
     run(allf[lo:hi].contiguous(), hi - lo, "strong")
     run(allf, global_batch, "weak")
+    try:
+        out["cabi_group"] = config4_group(args, rank, local_rank, world, fence, allf, lo, hi, global_batch, nfeat, steps)
+    except Exception as e:   # a second communicator next to torch's: report, never lose the line over it
+        out["cabi_group"] = {"error": f"{type(e).__name__}: {e}"}
     out["nfeatures"], out["global_batch"], out["cap"], out["n_gpus"] = nfeat, global_batch, cap, world
     out["note"] = ("strong: the 1024-frame batch sharded in contiguous blocks (SURVEY 8(d) row 4); weak: 1024 frames on every "
                    "rank.  The all-gather is synchronous here (its cost is visible); the main timed region overlaps it.")

@@ -421,6 +421,65 @@ orbfe_status orbfe_search_by_bow_batch_device(orbfe_matcher *m, const orbfe_keyp
                                               int32_t *d_nmatches, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batched keyframe mode over several devices (north star: "shards independent frames across the 8 GPUs of one
+ * node with an RCCL all-gather of descriptors over xGMI", host stays C++).
+ *
+ * A batch of nframes independent frames is cut into contiguous shards of ceil(nframes / world) frames, shard r on rank r
+ * (orbfe_group_shard_range).  Every rank owns three padded blocks for the WHOLE batch -- counts [F], keypoints [F][cap],
+ * descriptors [F][cap][32], F = world * shard, rank r's frames at block indices [r * shard, (r + 1) * shard)
+ * (orbfe_group_block_index) -- extracts its shard straight into its own slice, and ONE in-place all-gather per block
+ * (ncclAllGather, RCCL) leaves the whole batch on every rank.  The consumer of the gather, what KeyFrameDatabase /
+ * LoopClosing do serially per candidate keyframe (src/LoopClosing.cc:312-342), is orbfe_group_match: frames of the own shard
+ * against candidate frames anywhere in the gathered set.
+ *
+ * Two ways to form a group; every other call is the same:
+ *   orbfe_group_create_local  ONE process drives ndevices devices (ncclCommInitAll): the shape of a C++ SLAM process
+ *   orbfe_group_create_rank   one process per device: rank 0 makes an id (orbfe_group_unique_id), hands the 128 bytes to the
+ *                             other ranks by any means it has, every rank calls this (ncclCommInitRank)
+ * p->max_batch = the largest GLOBAL batch; p->device is ignored.  RCCL is loaded at run time (the copy already mapped into
+ * the process if there is one, else librccl.so.1 / $ORBFE_RCCL_LIB); without it the create calls fail with ORBFE_ERR_STATE.
+ * A group is used by one thread at a time.  Calls only enqueue work (compute stream + communication stream per member,
+ * ordered by events); orbfe_group_synchronize / _get_frame / _match wait.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct orbfe_group orbfe_group;
+void orbfe_group_shard_range(int32_t nframes, int32_t rank, int32_t world, int32_t *lo, int32_t *hi);
+orbfe_status orbfe_group_unique_id(uint8_t id[128]);
+orbfe_status orbfe_group_create_local(const orbfe_params *p, const int32_t *devices, int32_t ndevices, orbfe_group **out);
+orbfe_status orbfe_group_create_rank(const orbfe_params *p, int32_t device, int32_t rank, int32_t world, const uint8_t id[128],
+                                     orbfe_group **out);
+void orbfe_group_destroy(orbfe_group *g);
+int32_t orbfe_group_world(const orbfe_group *g);
+int32_t orbfe_group_capacity(const orbfe_group *g);      /* cap: keypoint slots per frame of the blocks */
+int32_t orbfe_group_frames_padded(const orbfe_group *g); /* F = world * shard */
+int32_t orbfe_group_block_index(const orbfe_group *g, int32_t nframes, int32_t frame);
+/* HOST frames of the global batch (grays[i] = frame i, w x ht, row pitch stride): every member of this process copies and
+ * extracts its own shard (a rank group reads only grays[lo .. hi) of its rank) */
+orbfe_status orbfe_group_extract_batch(orbfe_group *g, const uint8_t *const *grays, int32_t nframes, int32_t w, int32_t ht,
+                                       int32_t stride);
+/* DEVICE frames: d_gray = the shard of member `member` (its frames only, on its device), nframes_global = the size of the
+ * whole batch (the shard bounds follow from it) */
+orbfe_status orbfe_group_extract_shard_device(orbfe_group *g, int32_t member, const uint8_t *d_gray, int32_t nframes_global, int32_t w,
+                                              int32_t ht, int32_t stride, size_t frame_stride);
+/* the one exchange step: in-place ncclAllGather of the three blocks on the members' communication streams, behind the
+ * extraction; later calls on the compute streams are ordered behind it */
+orbfe_status orbfe_group_allgather(orbfe_group *g);
+orbfe_status orbfe_group_synchronize(orbfe_group *g);
+/* device pointers of member `member`'s blocks and its compute stream (hipStream_t), for consumers of the gathered batch */
+orbfe_status orbfe_group_blocks(orbfe_group *g, int32_t member, int32_t **d_n, orbfe_keypoint **d_kps, uint8_t **d_desc,
+                                void **compute_stream);
+/* one frame of the (gathered) batch of the last extract call to the host */
+orbfe_status orbfe_group_get_frame(orbfe_group *g, int32_t frame, orbfe_keypoint *kps, uint8_t *desc, int32_t cap, int32_t *n_out);
+/* pair p: brute-force match (as orbfe_match_bf: best <= th, ratio, rotation histogram) of frame qframe[p] -- a frame of a
+ * shard of THIS process -- against frame tframe[p], any frame of the batch; match [npairs][cap] (train index or -1, slots
+ * >= the query frame's count are -1), nmatches [npairs].  HOST arrays; call after orbfe_group_allgather. */
+orbfe_status orbfe_group_match(orbfe_group *g, const int32_t *qframe, const int32_t *tframe, int32_t npairs, float nnratio, int32_t th,
+                               int32_t check_ori, int32_t *match, int32_t *nmatches);
+/* the same on one member with everything on its device: pairs as BLOCK indices (orbfe_group_block_index), results
+ * [npairs][cap] / [npairs] in device memory, enqueued on the member's compute stream */
+orbfe_status orbfe_group_match_device(orbfe_group *g, int32_t member, const int32_t *d_qblock, const int32_t *d_tblock, int32_t npairs,
+                                      float nnratio, int32_t th, int32_t check_ori, int32_t *d_match, int32_t *d_nmatches);
+
+/* ---------------------------------------------------------------------------------------------
  * Formats: the on-disk keyframe records of Map::Save / Map::Load and the ORB vocabulary files
  * ------------------------------------------------------------------------------------------- */
 /* Keyframe block of Map::Save (perfect/src/Map.cc:330-381 _WriteKeyFrame, read back by _ReadKeyFrame :143-187):

@@ -34,6 +34,10 @@ SYMBOLS = (
     "orbfe_vocfile_load", "orbfe_vocfile_free", "orbfe_vocfile_info", "orbfe_vocfile_arrays", "orbfe_vocfile_save_binary",
     "orbfe_vocabulary_create_from_file", "orbfe_interleaved_to_gray_device", "orbfe_hamming_csr_ex", "orbfe_hamming_csr_device",
     "orbfe_search_by_projection",
+    "orbfe_group_shard_range", "orbfe_group_unique_id", "orbfe_group_create_local", "orbfe_group_create_rank", "orbfe_group_destroy",
+    "orbfe_group_world", "orbfe_group_capacity", "orbfe_group_frames_padded", "orbfe_group_block_index", "orbfe_group_extract_batch",
+    "orbfe_group_extract_shard_device", "orbfe_group_allgather", "orbfe_group_synchronize", "orbfe_group_blocks", "orbfe_group_get_frame",
+    "orbfe_group_match", "orbfe_group_match_device",
 )
 
 
@@ -142,6 +146,24 @@ def lib():
     L.orbfe_distinctive_descriptors.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]
     L.orbfe_features_in_area.argtypes = [vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, i32, vp, vp, i32]
     L.orbfe_search_by_projection.argtypes = [vp, vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp, vp, i32, i32, f32, i32, vp, vp, vp]
+    L.orbfe_group_shard_range.argtypes = [i32, i32, i32, vp, vp]
+    L.orbfe_group_shard_range.restype = None
+    L.orbfe_group_unique_id.argtypes = [vp]
+    L.orbfe_group_create_local.argtypes = [C.POINTER(OrbfeParams), vp, i32, C.POINTER(vp)]
+    L.orbfe_group_create_rank.argtypes = [C.POINTER(OrbfeParams), i32, i32, i32, vp, C.POINTER(vp)]
+    L.orbfe_group_destroy.argtypes = [vp]
+    L.orbfe_group_destroy.restype = None
+    for nm in ("orbfe_group_world", "orbfe_group_capacity", "orbfe_group_frames_padded"):
+        getattr(L, nm).argtypes = [vp]
+    L.orbfe_group_block_index.argtypes = [vp, i32, i32]
+    L.orbfe_group_extract_batch.argtypes = [vp, vp, i32, i32, i32, i32]
+    L.orbfe_group_extract_shard_device.argtypes = [vp, i32, vp, i32, i32, i32, i32, sz]
+    L.orbfe_group_allgather.argtypes = [vp]
+    L.orbfe_group_synchronize.argtypes = [vp]
+    L.orbfe_group_blocks.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.orbfe_group_get_frame.argtypes = [vp, i32, vp, vp, i32, vp]
+    L.orbfe_group_match.argtypes = [vp, vp, vp, i32, f32, i32, i32, vp, vp]
+    L.orbfe_group_match_device.argtypes = [vp, i32, vp, vp, i32, f32, i32, i32, vp, vp]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int:  # default -> orbfe_status / int32

@@ -605,6 +605,29 @@ struct MDevBuf {
     }
 };
 
+struct MPinBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need == 0) need = 4;
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        need = (need * 3 / 2 + 4095) & ~(size_t)4095;
+        hipError_t e = hipHostMalloc(&p, need, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
 struct orbfe_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -615,6 +638,7 @@ struct orbfe_matcher {
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
     hipEvent_t ev_scratch = nullptr;
+    MPinBuf pin_in, pin_out;  // page-locked staging of the latency-bound per-frame calls (orbfe_search_by_projection)
 };
 
 static hipError_t scratch_acquire(orbfe_matcher *m, hipStream_t st)
@@ -698,6 +722,8 @@ extern "C" void orbfe_matcher_destroy(orbfe_matcher *m)
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->scratch_used) (void)hipEventSynchronize(m->ev_scratch);
     for (auto &b : m->b) b.release();
+    m->pin_in.release();
+    m->pin_out.release();
     if (m->ev_scratch) (void)hipEventDestroy(m->ev_scratch);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -1252,10 +1278,14 @@ extern "C" orbfe_status orbfe_features_in_area(orbfe_matcher *m, const float *xy
 // claiming query took", and it is reached by relaxation: all queries choose in parallel against the owner table of the
 // previous round (owner[f] = lowest claiming query matched to f), the table is rebuilt, until no choice changes.  Query i
 // is final one round after all j < i are -- rounds = longest dependency chain + 1 (2-4 on real frames, <= nq + 1 always).
-// One workgroup per search: candidate lists and distances are materialised once (cand | dist << 16 per entry), the
-// rounds only re-scan them.
+// Launch structure: the candidate lists (GetFeaturesInArea) and the Hamming distances are independent per query and are
+// spread over the chip with 16 lanes per query (k_proj_count -> k_scan_u32 -> k_proj_fill; every (cand | dist << 16) entry is
+// materialised once); the relaxation rounds only re-scan those entries and run in ONE workgroup (k_proj_resolve, 16 lanes
+// per query, owner table in LDS).
 // ---------------------------------------------------------------------------------------------------
 #define PJ_T 1024
+#define PJ_L 16                  // lanes per query in the relaxation rounds
+#define PJ_LC 64                 // lanes per query in the candidate search (one wave: a search window covers ~100 grid cells)
 #define PJ_SKIP 0x1FFu           // distance field of an entry whose slot is blocked before the call / fails the right-image gate
 #define PJ_MAX_NF 15360          // owner table in LDS (int32 per frame feature)
 struct ProjArgs {
@@ -1271,114 +1301,177 @@ struct ProjArgs {
     const uint8_t *qdesc;
     int32_t nq, th, ratio_rule;
     float nnratio;
-    int32_t *match, *best, *second;  // best / second may be null
-    uint32_t *off;               // [nq + 1] scratch
-    uint32_t *ent;               // [ent_cap] scratch
+    int32_t *match, *best, *second;
+    uint32_t *cnt;               // [nq] candidates per query
+    uint16_t *lcnt;              // [nq * PJ_LC] candidates found by each lane of the query's wave
+    uint32_t *off;               // [nq + 1]
+    uint32_t *ent;               // [ent_cap] cand | dist << 16
     uint32_t ent_cap;
     int32_t *status;             // [0] = entries needed when ent_cap is too small (else 0), [1] = rounds run
 };
 
-__global__ __launch_bounds__(PJ_T) void k_search_by_projection(ProjArgs a)
+// The cell rectangle of GetFeaturesInArea (:470-484) and the level filter; false = the query has no candidates
+struct ProjRect {
+    int x0, y0, nx, ny;
+    bool check;
+};
+__device__ __forceinline__ bool proj_rect(const ProjArgs &a, const orbfe_proj_query &Q, ProjRect &R)
+{
+    int nminx = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.u, a.minx), Q.r), a.gwi));
+    nminx = max(nminx, 0);
+    if (nminx >= ORBFE_GRID_COLS) return false;
+    int nmaxx = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.u, a.minx), Q.r), a.gwi));
+    nmaxx = min(nmaxx, ORBFE_GRID_COLS - 1);
+    if (nmaxx < 0) return false;
+    int nminy = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.v, a.miny), Q.r), a.ghi));
+    nminy = max(nminy, 0);
+    if (nminy >= ORBFE_GRID_ROWS) return false;
+    int nmaxy = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.v, a.miny), Q.r), a.ghi));
+    nmaxy = min(nmaxy, ORBFE_GRID_ROWS - 1);
+    if (nmaxy < 0) return false;
+    R.x0 = nminx; R.y0 = nminy; R.nx = nmaxx - nminx + 1; R.ny = nmaxy - nminy + 1;
+    R.check = (Q.min_level > 0) || (Q.max_level >= 0);  // :486
+    return R.nx > 0 && R.ny > 0;
+}
+
+// Lane `sub` of a query's wave walks its contiguous share of the cell sequence (ix outer, iy inner: the reference's
+// order), so lane order = candidate order.  f(k) is called for every feature that passes the level filter and the box test.
+template <typename F>
+__device__ __forceinline__ void proj_walk(const ProjArgs &a, const orbfe_proj_query &Q, const ProjRect &R, int sub, F f)
+{
+    const int ncell = R.nx * R.ny, chunk = (ncell + PJ_LC - 1) / PJ_LC;
+    const int c0 = sub * chunk, c1 = min(c0 + chunk, ncell);
+    for (int c = c0; c < c1; ++c) {
+        const int ix = R.x0 + c / R.ny, iy = R.y0 + c % R.ny;
+        const int cell = ix * ORBFE_GRID_ROWS + iy;
+        for (uint32_t j = a.cell_off[cell]; j < a.cell_off[cell + 1]; ++j) {
+            const uint32_t k = a.cell_idx[j];
+            if (R.check) {
+                const int o = a.octF[(size_t)a.os * k];
+                if (o < Q.min_level) continue;
+                if (Q.max_level >= 0 && o > Q.max_level) continue;
+            }
+            const float dx = __fsub_rn(a.xyF[(size_t)a.xs * k], Q.u), dy = __fsub_rn(a.xyF[(size_t)a.xs * k + 1], Q.v);
+            if (fabsf(dx) < Q.r && fabsf(dy) < Q.r) f(k);
+        }
+    }
+}
+
+__device__ __forceinline__ int wave_incl_scan_m(int v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_proj_count(ProjArgs a)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, i = t / PJ_LC, sub = t % PJ_LC;
+    if (i >= a.nq) return;   // whole waves leave together
+    const orbfe_proj_query Q = a.q[i];
+    ProjRect R;
+    int n = 0;
+    if (proj_rect(a, Q, R)) proj_walk(a, Q, R, sub, [&](uint32_t) { ++n; });
+    a.lcnt[(size_t)i * PJ_LC + sub] = (uint16_t)n;
+    int tot = n;
+#pragma unroll
+    for (int o = PJ_LC / 2; o > 0; o >>= 1) tot += __shfl_xor(tot, o, PJ_LC);
+    if (sub == 0) a.cnt[i] = (uint32_t)tot;
+}
+
+__global__ __launch_bounds__(256) void k_proj_fill(ProjArgs a)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, i = t / PJ_LC, sub = t % PJ_LC;
+    if (i >= a.nq || a.off[a.nq] > a.ent_cap) return;
+    const orbfe_proj_query Q = a.q[i];
+    ProjRect R;
+    if (!proj_rect(a, Q, R)) return;   // wave-uniform
+    const int mine = a.lcnt[(size_t)i * PJ_LC + sub];
+    uint32_t o = a.off[i] + (uint32_t)(wave_incl_scan_m(mine) - mine);
+    Desc8 dq;
+    const uint32_t *p = (const uint32_t *)(a.qdesc + (int64_t)i * 32);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dq.w[k] = p[k];
+    const bool gate = (Q.flags & ORBFE_PROJ_RIGHT_GATE) && a.uRight;
+    proj_walk(a, Q, R, sub, [&](uint32_t f) {
+        bool skip = a.blocked && a.blocked[f];                        // :108-110 / :1647-1649, state before the call
+        if (!skip && gate) {                                          // :114-119 / :1654-1660
+            const float ur = a.uRight[f];
+            skip = ur > 0.f && fabsf(__fsub_rn(Q.ur, ur)) > Q.r;
+        }
+        const uint32_t d = skip ? PJ_SKIP : (uint32_t)hamming8(dq, (const uint32_t *)(a.descF + (int64_t)f * 32));
+        a.ent[o++] = f | (d << 16);
+    });
+}
+
+// key of an entry in the reduction: distance (9 bits) above the position in the query's list (first in list order wins ties)
+#define PJ_NOKEY 0xFFFFFFFFu
+__global__ __launch_bounds__(PJ_T) void k_proj_resolve(ProjArgs a)
 {
     extern __shared__ int32_t s_owner[];   // [nF]
-    __shared__ uint32_t s_part[PJ_T];
-    __shared__ uint32_t s_carry;
     __shared__ int s_changed;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, sub = tid % PJ_L, grp = tid / PJ_L;
     const int nq = a.nq, nF = a.nF;
-    // ---- candidate counts -> offsets ----
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nq; base += PJ_T) {
-        const int i = base + tid;
-        uint32_t c = 0;
-        if (i < nq) {
-            const orbfe_proj_query Q = a.q[i];
-            c = (uint32_t)area_query(a.xyF, a.octF, a.cell_off, a.cell_idx, a.minx, a.miny, a.gwi, a.ghi, Q.u, Q.v, Q.r, Q.min_level,
-                                     Q.max_level, nullptr, false, a.xs, a.os);
-        }
-        s_part[tid] = c;
-        __syncthreads();
-        for (int d = 1; d < PJ_T; d <<= 1) {
-            const uint32_t t = tid >= d ? s_part[tid - d] : 0u;
-            __syncthreads();
-            s_part[tid] += t;
-            __syncthreads();
-        }
-        if (i < nq) a.off[i] = s_carry + s_part[tid] - c;
-        __syncthreads();
-        if (tid == PJ_T - 1) s_carry += s_part[PJ_T - 1];
-        __syncthreads();
-    }
-    const uint32_t total = s_carry;
     if (tid == 0) {
-        a.off[nq] = total;
+        const uint32_t total = a.off[nq];
         a.status[0] = total > a.ent_cap ? (int32_t)total : 0;
         a.status[1] = 0;
     }
-    if (total > a.ent_cap) return;   // workgroup-uniform: the host grows the scratch and launches again
-    __syncthreads();
-    // ---- candidate lists in the reference's iteration order, one distance per entry ----
-    for (int i = tid; i < nq; i += PJ_T) {
-        const orbfe_proj_query Q = a.q[i];
-        const uint32_t o = a.off[i];
-        const int n = area_query(a.xyF, a.octF, a.cell_off, a.cell_idx, a.minx, a.miny, a.gwi, a.ghi, Q.u, Q.v, Q.r, Q.min_level,
-                                 Q.max_level, a.ent + o, true, a.xs, a.os);
-        Desc8 dq;
-        const uint32_t *p = (const uint32_t *)(a.qdesc + (int64_t)i * 32);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dq.w[k] = p[k];
-        const bool gate = (Q.flags & ORBFE_PROJ_RIGHT_GATE) && a.uRight;
-        for (int k = 0; k < n; ++k) {
-            const uint32_t f = a.ent[o + k];
-            uint32_t d;
-            bool skip = a.blocked && a.blocked[f];                        // :108-110 / :1647-1649, state before the call
-            if (!skip && gate) {                                          // :114-119 / :1654-1660
-                const float ur = a.uRight[f];
-                skip = ur > 0.f && fabsf(__fsub_rn(Q.ur, ur)) > Q.r;
-            }
-            d = skip ? PJ_SKIP : (uint32_t)hamming8(dq, (const uint32_t *)(a.descF + (int64_t)f * 32));
-            a.ent[o + k] = f | (d << 16);
-        }
-    }
+    if (a.off[nq] > a.ent_cap) return;   // workgroup-uniform: the host grows the scratch and launches again
     for (int f = tid; f < nF; f += PJ_T) s_owner[f] = 0x7FFFFFFF;
     for (int i = tid; i < nq; i += PJ_T) a.match[i] = -1;
     __syncthreads();
-    // ---- relaxation rounds ----
     int round = 0;
     for (; round <= nq + 1; ++round) {
         if (tid == 0) s_changed = 0;
         __syncthreads();
         bool changed = false;
-        for (int i = tid; i < nq; i += PJ_T) {
-            const uint32_t o = a.off[i], e = a.off[i + 1];
-            int bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, bestIdx = -1;
-            for (uint32_t k = o; k < e; ++k) {
+        for (int i0 = 0; i0 < nq; i0 += PJ_T / PJ_L) {
+            const int i = i0 + grp;
+            uint32_t k1 = PJ_NOKEY, k2 = PJ_NOKEY;   // the two smallest keys (dist << 16 | position) among the free slots
+            uint32_t o = 0, e = 0;
+            if (i < nq) { o = a.off[i]; e = a.off[i + 1]; }
+            for (uint32_t k = o + sub; k < e; k += PJ_L) {
                 const uint32_t en = a.ent[k];
-                const int f = (int)(en & 0xFFFFu), d = (int)(en >> 16);
-                if (d == (int)PJ_SKIP || s_owner[f] < i) continue;   // the slot was taken by an earlier query of this call
-                if (d < bestDist) {            // :128-140
-                    bestDist2 = bestDist;
-                    bestDist = d;
-                    bestLevel2 = bestLevel;
-                    bestLevel = a.ratio_rule ? a.octF[(size_t)a.os * f] : 0;
-                    bestIdx = f;
-                } else if (d < bestDist2) {
-                    bestLevel2 = a.ratio_rule ? a.octF[(size_t)a.os * f] : 0;
-                    bestDist2 = d;
+                const uint32_t f = en & 0xFFFFu, d = en >> 16;
+                if (d == PJ_SKIP || s_owner[f] < i) continue;   // the slot was taken by an earlier query of this call
+                const uint32_t key = (d << 16) | (k - o);
+                if (key < k1) { k2 = k1; k1 = key; }
+                else if (key < k2) k2 = key;
+            }
+#pragma unroll
+            for (int s = PJ_L / 2; s > 0; s >>= 1) {   // merge the lanes' pairs: the two smallest keys of the group
+                const uint32_t o1 = __shfl_xor(k1, s, PJ_L), o2 = __shfl_xor(k2, s, PJ_L);
+                const uint32_t lo = min(k1, o1), hi = max(k1, o1);
+                k2 = min(hi, min(k2, o2));
+                k1 = lo;
+            }
+            if (i < nq && sub == 0) {
+                // :128-140: bestDist = smallest distance, first in list order; bestDist2 / bestLevel2 = the smallest among the
+                // others, first in list order
+                const int bestDist = k1 == PJ_NOKEY ? 256 : (int)(k1 >> 16), bestDist2 = k2 == PJ_NOKEY ? 256 : (int)(k2 >> 16);
+                int mt = -1;
+                if (bestDist <= a.th) {            // :143-148 / :1673
+                    const int bestIdx = (int)(a.ent[o + (k1 & 0xFFFFu)] & 0xFFFFu);
+                    bool reject = false;
+                    if (a.ratio_rule) {
+                        const int bestLevel = a.octF[(size_t)a.os * bestIdx];
+                        const int bestLevel2 = k2 == PJ_NOKEY ? -1 : a.octF[(size_t)a.os * (a.ent[o + (k2 & 0xFFFFu)] & 0xFFFFu)];
+                        reject = bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2);
+                    }
+                    if (!reject) mt = bestIdx;
                 }
+                if (mt != a.match[i]) {
+                    a.match[i] = mt;
+                    changed = true;
+                }
+                a.best[i] = bestDist;
+                a.second[i] = bestDist2;
             }
-            int mt = -1;
-            if (bestDist <= a.th) {            // :143-148 / :1673
-                const bool reject = a.ratio_rule && bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2);
-                if (!reject) mt = bestIdx;
-            }
-            if (mt != a.match[i]) {
-                a.match[i] = mt;
-                changed = true;
-            }
-            if (a.best) a.best[i] = bestDist;
-            if (a.second) a.second[i] = bestDist2;
         }
         if (changed) s_changed = 1;
         __syncthreads();
@@ -1417,52 +1510,70 @@ extern "C" orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8
     MDeviceGuard g(m->device);
     hipStream_t st = m->stream;
     ORBFE_HIP(scratch_acquire(m, st));
+    // One pinned staging block in, one out: the per-frame call is latency-bound, nine pageable copies cost more than the
+    // kernels.  Layout (256-byte aligned pieces): descF | xyF | octF | cell_off | cell_idx | uRight | blocked | q | qdesc
     const size_t sz[9] = {(size_t)nF * 32, (size_t)nF * 8, (size_t)nF * 4, (size_t)(GRID_NC + 1) * 4, (size_t)nin * 4,
                           uRight ? (size_t)nF * 4 : 0, blocked ? (size_t)nF : 0, (size_t)nq * sizeof(orbfe_proj_query), (size_t)nq * 32};
     const void *src[9] = {descF, xyF, octF, cell_off, cell_idx, uRight, blocked, q, qdesc};
-    for (int i = 0; i < 9; ++i) {
-        ORBFE_HIP(m->b[i].ensure(sz[i]));
-        if (sz[i]) ORBFE_HIP(hipMemcpyAsync(m->b[i].p, src[i], sz[i], hipMemcpyHostToDevice, st));
-    }
-    ORBFE_HIP(m->b[9].ensure((size_t)nq * 12));
-    ORBFE_HIP(m->b[10].ensure((size_t)(nq + 1) * 4));
-    ORBFE_HIP(m->b[12].ensure(8));
+    size_t at[10];
+    at[0] = 0;
+    for (int i = 0; i < 9; ++i) at[i + 1] = (at[i] + sz[i] + 255) & ~(size_t)255;
+    const size_t out_bytes = (size_t)nq * 12 + 8;   // match | best | second | status[2]
+    ORBFE_HIP(m->pin_in.ensure(at[9]));
+    ORBFE_HIP(m->pin_out.ensure(out_bytes));
+    ORBFE_HIP(m->b[0].ensure(at[9]));
+    ORBFE_HIP(m->b[1].ensure(out_bytes));
+    ORBFE_HIP(m->b[2].ensure((size_t)nq * 4));                 // cnt
+    ORBFE_HIP(m->b[3].ensure((size_t)nq * PJ_LC * 2));         // lcnt
+    ORBFE_HIP(m->b[4].ensure((size_t)(nq + 1) * 4));           // off
+    for (int i = 0; i < 9; ++i)
+        if (sz[i]) memcpy((char *)m->pin_in.p + at[i], src[i], sz[i]);
+    ORBFE_HIP(hipMemcpyAsync(m->b[0].p, m->pin_in.p, at[9], hipMemcpyHostToDevice, st));
+    const char *din = (const char *)m->b[0].p;
     ProjArgs a;
-    a.descF = (const uint8_t *)m->b[0].p;
-    a.xyF = (const float *)m->b[1].p;
-    a.octF = (const int32_t *)m->b[2].p;
+    a.descF = (const uint8_t *)(din + at[0]);
+    a.xyF = (const float *)(din + at[1]);
+    a.octF = (const int32_t *)(din + at[2]);
     a.nF = nF; a.xs = 2; a.os = 1;
-    a.cell_off = (const uint32_t *)m->b[3].p;
-    a.cell_idx = (const uint32_t *)m->b[4].p;
+    a.cell_off = (const uint32_t *)(din + at[3]);
+    a.cell_idx = (const uint32_t *)(din + at[4]);
     a.minx = minx; a.miny = miny; a.gwi = gw_inv; a.ghi = gh_inv;
-    a.uRight = uRight ? (const float *)m->b[5].p : nullptr;
-    a.blocked = blocked ? (const uint8_t *)m->b[6].p : nullptr;
-    a.q = (const orbfe_proj_query *)m->b[7].p;
-    a.qdesc = (const uint8_t *)m->b[8].p;
+    a.uRight = uRight ? (const float *)(din + at[5]) : nullptr;
+    a.blocked = blocked ? (const uint8_t *)(din + at[6]) : nullptr;
+    a.q = (const orbfe_proj_query *)(din + at[7]);
+    a.qdesc = (const uint8_t *)(din + at[8]);
     a.nq = nq; a.th = th; a.ratio_rule = ratio_rule ? 1 : 0; a.nnratio = nnratio;
-    a.match = (int32_t *)m->b[9].p;
+    a.match = (int32_t *)m->b[1].p;
     a.best = a.match + nq;
     a.second = a.match + 2 * (size_t)nq;
-    a.off = (uint32_t *)m->b[10].p;
-    a.status = (int32_t *)m->b[12].p;
-    size_t ent_cap = std::max<size_t>((size_t)nq * 64, 1 << 16);
+    a.status = a.match + 3 * (size_t)nq;
+    a.cnt = (uint32_t *)m->b[2].p;
+    a.lcnt = (uint16_t *)m->b[3].p;
+    a.off = (uint32_t *)m->b[4].p;
+    const int ngrp = (nq * PJ_LC + 255) / 256;
+    size_t ent_cap = std::max<size_t>((size_t)nq * 96, 1 << 16);
+    const int32_t *hout = (const int32_t *)m->pin_out.p;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        ORBFE_HIP(m->b[11].ensure(ent_cap * 4));
-        a.ent = (uint32_t *)m->b[11].p;
-        a.ent_cap = (uint32_t)std::min<size_t>(m->b[11].bytes / 4, 0xFFFFFFFFu);
-        hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(PJ_T), (size_t)std::max(nF, 1) * 4, st, a);
+        ORBFE_HIP(m->b[5].ensure(ent_cap * 4));
+        a.ent = (uint32_t *)m->b[5].p;
+        a.ent_cap = (uint32_t)std::min<size_t>(m->b[5].bytes / 4, 0xFFFFFFFFu);
+        if (attempt == 0) {
+            hipLaunchKernelGGL(k_proj_count, dim3(ngrp), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, (const uint32_t *)a.cnt, nq, a.off);
+        }
+        hipLaunchKernelGGL(k_proj_fill, dim3(ngrp), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(PJ_T), (size_t)std::max(nF, 1) * 4, st, a);
         ORBFE_HIP(hipGetLastError());
-        int32_t status[2] = {0, 0};
-        ORBFE_HIP(hipMemcpyAsync(status, a.status, 8, hipMemcpyDeviceToHost, st));
+        ORBFE_HIP(hipMemcpyAsync(m->pin_out.p, m->b[1].p, out_bytes, hipMemcpyDeviceToHost, st));
         ORBFE_HIP(hipStreamSynchronize(st));
-        if (status[0] == 0) break;
-        if (attempt == 1) { orbfe_set_error("candidate scratch still too small (%d entries)", status[0]); return ORBFE_ERR_NOMEM; }
-        ent_cap = (size_t)status[0];   // the exact need: second launch cannot fail on it
+        const int32_t need = hout[3 * (size_t)nq];
+        if (need == 0) break;
+        if (attempt == 1) { orbfe_set_error("candidate scratch still too small (%d entries)", need); return ORBFE_ERR_NOMEM; }
+        ent_cap = (size_t)need;   // the exact need: the second launch cannot fail on it
     }
-    ORBFE_HIP(hipMemcpyAsync(match, a.match, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    if (best) ORBFE_HIP(hipMemcpyAsync(best, a.best, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    if (second) ORBFE_HIP(hipMemcpyAsync(second, a.second, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    ORBFE_HIP(hipStreamSynchronize(st));
+    memcpy(match, hout, (size_t)nq * 4);
+    if (best) memcpy(best, hout + nq, (size_t)nq * 4);
+    if (second) memcpy(second, hout + 2 * (size_t)nq, (size_t)nq * 4);
     return ORBFE_OK;
 }
 

@@ -84,3 +84,113 @@ class OverlappedKeyframeGather:
     def result(self, k):
         self.acquire(k)
         return self.gathered[k]
+
+
+class KeyframeGroup:
+    """ctypes mirror of the C-ABI's multi-device layer (include/orbfe.h, orbfe_group_*): the batched keyframe mode for
+    C / C++ hosts -- contiguous shards, one in-place ncclAllGather (RCCL) of the padded count / keypoint / descriptor blocks,
+    and the consumer of the gather (own frames against candidate frames anywhere in the batch).  `devices` = the devices
+    ONE process drives (ncclCommInitAll); `rank_of_world=(rank, world, id_bytes)` = one process per device."""
+
+    def __init__(self, nfeatures, scale_factor, nlevels, ini_th, min_th, max_width, max_height, max_batch, devices=(0,),
+                 rank_of_world=None, device=None):
+        import ctypes as C
+        from . import _ffi
+        self._ffi, self._C = _ffi, C
+        L = _ffi.lib()
+        p = _ffi.OrbfeParams(nfeatures, scale_factor, nlevels, ini_th, min_th, max_width, max_height, max_batch, -1, 0)
+        h = C.c_void_p()
+        if rank_of_world is None:
+            devs = (C.c_int32 * len(devices))(*devices)
+            _ffi.check(L.orbfe_group_create_local(C.byref(p), devs, len(devices), C.byref(h)), "orbfe_group_create_local")
+        else:
+            rank, world, idb = rank_of_world
+            buf = (C.c_uint8 * 128).from_buffer_copy(bytes(idb))
+            _ffi.check(L.orbfe_group_create_rank(C.byref(p), -1 if device is None else device, rank, world, buf, C.byref(h)),
+                       "orbfe_group_create_rank")
+        self.handle = h
+        self.L = L
+        self.world = L.orbfe_group_world(h)
+        self.cap = L.orbfe_group_capacity(h)
+        self.frames_padded = L.orbfe_group_frames_padded(h)
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _ffi
+        buf = (C.c_uint8 * 128)()
+        _ffi.check(_ffi.lib().orbfe_group_unique_id(buf), "orbfe_group_unique_id")
+        return bytes(buf)
+
+    @staticmethod
+    def shard_range_c(nframes, rank, world):
+        import ctypes as C
+        from . import _ffi
+        lo, hi = C.c_int32(), C.c_int32()
+        _ffi.lib().orbfe_group_shard_range(nframes, rank, world, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.orbfe_group_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def extract_batch(self, frames):
+        """frames: uint8 [n, h, w] numpy (host).  Every member extracts its shard."""
+        import numpy as np
+        C = self._C
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w = frames.shape
+        ptrs = (C.c_void_p * n)(*[frames[i].ctypes.data for i in range(n)])
+        self._ffi.check(self.L.orbfe_group_extract_batch(self.handle, ptrs, n, w, h, w), "orbfe_group_extract_batch")
+        self.nframes = n
+
+    def extract_shard_device(self, member, d_gray_ptr, nframes_global, w, h, stride, frame_stride):
+        self._ffi.check(self.L.orbfe_group_extract_shard_device(self.handle, member, d_gray_ptr, nframes_global, w, h, stride, frame_stride),
+                        "orbfe_group_extract_shard_device")
+        self.nframes = nframes_global
+
+    def allgather(self):
+        self._ffi.check(self.L.orbfe_group_allgather(self.handle), "orbfe_group_allgather")
+
+    def synchronize(self):
+        self._ffi.check(self.L.orbfe_group_synchronize(self.handle), "orbfe_group_synchronize")
+
+    def block_index(self, frame):
+        return self.L.orbfe_group_block_index(self.handle, self.nframes, frame)
+
+    def blocks(self, member=0):
+        C = self._C
+        dn, dk, dd, st = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ffi.check(self.L.orbfe_group_blocks(self.handle, member, C.byref(dn), C.byref(dk), C.byref(dd), C.byref(st)), "orbfe_group_blocks")
+        return dn.value, dk.value, dd.value, st.value
+
+    def get_frame(self, frame):
+        import numpy as np
+        C = self._C
+        kps = np.zeros(self.cap, self._ffi.KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int32()
+        self._ffi.check(self.L.orbfe_group_get_frame(self.handle, frame, self._ffi.ptr(kps), self._ffi.ptr(desc), self.cap, C.byref(n)),
+                        "orbfe_group_get_frame")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def match_device(self, member, d_qblock_ptr, d_tblock_ptr, npairs, d_match_ptr, d_nm_ptr, nnratio=0.9, th=100, check_ori=True):
+        self._ffi.check(self.L.orbfe_group_match_device(self.handle, member, d_qblock_ptr, d_tblock_ptr, npairs, nnratio, th, int(check_ori),
+                                                        d_match_ptr, d_nm_ptr), "orbfe_group_match_device")
+
+    def match(self, qframe, tframe, nnratio=0.9, th=100, check_ori=True):
+        import numpy as np
+        q = np.ascontiguousarray(qframe, np.int32)
+        t = np.ascontiguousarray(tframe, np.int32)
+        m = np.full((len(q), self.cap), -1, np.int32)
+        nm = np.zeros(len(q), np.int32)
+        self._ffi.check(self.L.orbfe_group_match(self.handle, self._ffi.ptr(q), self._ffi.ptr(t), len(q), nnratio, th, int(check_ori),
+                                                 self._ffi.ptr(m), self._ffi.ptr(nm)), "orbfe_group_match")
+        return m, nm
