@@ -432,8 +432,14 @@ __device__ __forceinline__ void fm_flush(uint2 *slist, int32_t *scnt, const uint
 // SPARSE = 1: wave-uniform shortcuts for frames whose corners are sparse (real camera images): a row step whose 256
 // pixels all fail the compass test skips the arc evaluation, and an NMS row with no strength in its 3-row
 // neighbourhood skips the NMS / emission block.  Results are identical; on corner-saturated frames the tests only cost.
+// -DFM_WAVES_PER_EU=n caps the kernel's occupancy (A/B: leaving register file to a memory-bound kernel on a side stream)
+#ifdef FM_WAVES_PER_EU
+#define FM_OCC __attribute__((amdgpu_waves_per_eu(FM_WAVES_PER_EU, FM_WAVES_PER_EU)))
+#else
+#define FM_OCC
+#endif
 template <int SPARSE>
-__global__ __launch_bounds__(256) void k_fast_map(const OrbPlan *__restrict__ plan, FrameSrc fs,
+__global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restrict__ plan, FrameSrc fs,
                                                   const OrbLane *__restrict__ lanes, int nwaves,
                                                   uint2 *__restrict__ skeys,      // [B][keys_per_frame] {key, ord}
                                                   int32_t *__restrict__ scount,   // [B][nlevels] * NK_STRIDE, zeroed
@@ -1621,7 +1627,9 @@ __device__ __forceinline__ void canon_sincos(float angle_deg, float *ca, float *
 //   B  fastAtan2 / canonical sincos per lane (16x redundant instead of 64x).
 //   C  rBRIEF: the 37 x 40 blurred patch is staged in LDS with coalesced dword loads; lane `sub` evaluates pairs
 //      16*sub .. 16*sub+15, i.e. descriptor bytes 2*sub and 2*sub+1, from LDS byte reads.
-#define DS_PP 40   // LDS patch pitch (bytes): columns x-18 .. x+21
+#ifndef DS_PP
+#define DS_PP 40   // LDS patch pitch (bytes): columns x-18 .. x+21 (44 = an odd number of dwords per row: A/B in DESIGN.md)
+#endif
 #define DS_PR 37   // patch rows y-18 .. y+18
 
 __constant__ uint2 c_momw[31 * 8];  // per (row v+15, dword k): .x = weights (u+15) or 0, .y = 1 or 0 per byte
