@@ -144,7 +144,7 @@ struct orbfe_handle {
     std::vector<OrbTab> tabs;
     DevBuf d_plan, d_tabs, d_flanes, d_blanes;
     // per-batch blocks
-    DevBuf d_pyr, d_blur, d_skeys, d_scount, d_cflag, d_knode, d_qtbox, d_sel, d_nsel, d_nkeys;
+    DevBuf d_pyr, d_blur, d_skeys, d_scount, d_cflag, d_knode, d_qtbox, d_qtnodes, d_sel, d_nsel, d_nkeys;
     // sticky overflow word + FAST sparse-variant statistics: [0] int32 overflow bits, [2..7] 3 x uint64 counters
     DevBuf d_misc;
     int fast_mode = 0;            // 0 dense, 1 sparse shortcuts (orbfe_set_fast_mode)
@@ -374,9 +374,10 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     P.node_cap = M;
     P.max_nini = 1;
     for (int l = 0; l < nl; ++l) P.max_nini = std::max(P.max_nini, P.lv[l].nini);
-    if (orbk_octree_lds_bytes(M, std::max(4, P.max_nini), w, ht, P.max_ncells) > 160 * 1024) {
-        orbfe_set_error("nfeatures too large: the quadtree of one level (%d nodes, %d roots) does not fit the 160 KB LDS "
-                        "(about 1700 features asked of a single level)", max_sel, P.max_nini);
+    // Node arrays normally sit in LDS; a level asking for more nodes than fit (about 2400 features on ONE level) keeps them
+    // in global scratch.  What remains is the width of the node index the keys of deep trees carry (14 bits).
+    if (M > 16383) {
+        orbfe_set_error("nfeatures too large: %d quadtree nodes on one level (at most 16383)", max_sel);
         return ORBFE_ERR_ARG;
     }
     for (int l = 0; l < nl; ++l)
@@ -523,6 +524,8 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
     ORBFE_HIP(h->d_cflag.ensure(B * P.nlevels * (size_t)((P.max_ncells + 31) / 32) * sizeof(uint32_t)));
     ORBFE_HIP(h->d_knode.ensure(B * (size_t)P.keys_per_frame * sizeof(uint16_t)));
     ORBFE_HIP(h->d_qtbox.ensure(B * (size_t)P.nlevels * orbk_octree_box_bytes(P.node_cap)));  // deep quadtrees only
+    if (orbk_octree_lds_bytes(P.node_cap, std::max(1, P.max_nini), P.w, P.h, P.max_ncells) > (size_t)ORBFE_LDS_MAX)
+        ORBFE_HIP(h->d_qtnodes.ensure(B * (size_t)P.nlevels * orbk_octree_node_bytes(P.node_cap)));  // quadtrees beyond the LDS
     ORBFE_HIP(h->d_sel.ensure(B * (size_t)P.sel_per_frame * sizeof(uint32_t)));
     ORBFE_HIP(h->d_nsel.ensure(B * P.nlevels * sizeof(int32_t)));
     ORBFE_HIP(h->d_nkeys.ensure(B * P.nlevels * ORBFE_NK_STRIDE * sizeof(int32_t)));
@@ -655,7 +658,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_cflag, &h->d_knode, &h->d_qtbox, &h->d_sel, &h->d_nsel, &h->d_nkeys,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_cflag, &h->d_knode, &h->d_qtbox, &h->d_qtnodes, &h->d_sel, &h->d_nsel, &h->d_nkeys,
                       &h->d_stage[0], &h->d_okps[0], &h->d_odesc[0], &h->d_on[0], &h->d_stage[1], &h->d_okps[1], &h->d_odesc[1], &h->d_on[1]};
     for (DevBuf *b : bufs) b->release();
     h->d_misc.release();
@@ -830,6 +833,8 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_knode = (uint16_t *)h->d_knode.p;
     a.d_qtbox = (int16_t *)h->d_qtbox.p;
     a.qtbox_stride = (int32_t)(orbk_octree_box_bytes(h->plan.node_cap) / sizeof(int16_t));
+    a.d_qtnodes = (char *)h->d_qtnodes.p;
+    a.qtnodes_stride = (int64_t)orbk_octree_node_bytes(h->plan.node_cap);
     a.d_sel = (uint32_t *)h->d_sel.p;
     a.d_nsel = (int32_t *)h->d_nsel.p;
     a.d_nkeys = (int32_t *)h->d_nkeys.p;

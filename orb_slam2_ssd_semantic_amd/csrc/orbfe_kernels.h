@@ -25,6 +25,8 @@ struct OrbLaunch {
     uint16_t *d_knode;
     int16_t *d_qtbox;      // [B][nlevels][qtbox_stride] node boxes of deep quadtrees (global scratch)
     int32_t qtbox_stride;  // int16 elements per (frame, level)
+    char *d_qtnodes;       // [B][nlevels][qtnodes_stride] node arrays of quadtrees too large for the LDS (else null)
+    int64_t qtnodes_stride;
     uint32_t *d_sel;
     int32_t *d_nsel;
     int32_t *d_nkeys;
@@ -44,6 +46,7 @@ struct OrbLaunch {
 hipError_t orbk_upload_constants(const int *umax16);
 size_t orbk_octree_lds_bytes(int node_cap, int max_nini, int w, int h, int ncells);
 size_t orbk_octree_box_bytes(int node_cap);
+size_t orbk_octree_node_bytes(int node_cap);  // global scratch per (frame, level) when the node arrays do not fit the LDS
 hipError_t orbk_prepare_octree(int node_cap, int max_nini, int w, int h, int ncells);
 size_t orbk_pyramid_lds_bytes(int dh);  // dynamic LDS of the pyramid kernel for a destination level of dh rows
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st);

