@@ -153,6 +153,7 @@ def _declare_projection(L, prefix):
                                                                        vp, vp, vp, vp]
     getattr(L, prefix + "search_by_projection_local_map").argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp]
     getattr(L, prefix + "last_call_ms").restype = C.c_double
+    getattr(L, prefix + "fuse").argtypes = ([vp] * 6 + [ci, vp, vp, vp] + [cf] * 11 + [vp, vp, ci, cf, ci] + [vp] * 9 + [cf, vp, vp, vp])
 
 
 _SHIM = os.path.join(_OUT, "libshim_ref.so")
@@ -556,3 +557,32 @@ def last_call_ms(shim=False, perfect=False):
     """wall time of the last SearchByProjection member call alone (mock construction excluded)"""
     lb = (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
     return float(getattr(lb, ("shim_" if shim else "ref_") + "last_call_ms")())
+
+
+def fuse(kf, mps, th, shim=False, perfect=False):
+    """ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:1031-1182) on a mock KeyFrame.
+    kf: dict(desc, xy, octave, uRight, state, obs, Rcw, tcw, Ow, K=(fx, fy, cx, cy, mbf), bounds, gw_inv, gh_inv, scale_factors,
+    inv_sigma2, log_scale); mps: dict(null, bad, in_kf, world_pos, normal, max_dist, min_dist, mpdesc, obs).
+    Returns (kf_assigned[nKF], mp_replaced[nmp], own_replaced[nKF], return value)."""
+    f32, i32, u8 = np.float32, np.int32, np.uint8
+    K = dict(desc=np.ascontiguousarray(kf["desc"], u8).reshape(-1, 32), xy=np.ascontiguousarray(kf["xy"], f32).reshape(-1, 2),
+             octave=np.ascontiguousarray(kf["octave"], i32), uRight=np.ascontiguousarray(kf["uRight"], f32),
+             state=np.ascontiguousarray(kf["state"], u8), obs=np.ascontiguousarray(kf["obs"], i32),
+             Rcw=np.ascontiguousarray(kf["Rcw"], f32).reshape(9), tcw=np.ascontiguousarray(kf["tcw"], f32).reshape(3),
+             Ow=np.ascontiguousarray(kf["Ow"], f32).reshape(3), sf=np.ascontiguousarray(kf["scale_factors"], f32),
+             is2=np.ascontiguousarray(kf["inv_sigma2"], f32))
+    M = dict(null=np.ascontiguousarray(mps["null"], u8), bad=np.ascontiguousarray(mps["bad"], u8), in_kf=np.ascontiguousarray(mps["in_kf"], u8),
+             wp=np.ascontiguousarray(mps["world_pos"], f32).reshape(-1, 3), nr=np.ascontiguousarray(mps["normal"], f32).reshape(-1, 3),
+             mx=np.ascontiguousarray(mps["max_dist"], f32), mn=np.ascontiguousarray(mps["min_dist"], f32),
+             d=np.ascontiguousarray(mps["mpdesc"], u8).reshape(-1, 32), obs=np.ascontiguousarray(mps["obs"], i32))
+    nKF, nmp = len(K["desc"]), len(M["null"])
+    ka, mr, orr = np.full(max(nKF, 1), -9, i32), np.full(max(nmp, 1), -9, i32), np.full(max(nKF, 1), -9, i32)
+    lb = (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
+    fn = getattr(lb, ("shim_" if shim else "ref_") + "fuse")
+    fx, fy, cx, cy, mbf = [float(v) for v in kf["K"][:5]]
+    minx, maxx, miny, maxy = [float(v) for v in kf["bounds"]]
+    rv = fn(_p(K["desc"]), _p(K["xy"]), _p(K["octave"]), _p(K["uRight"]), _p(K["state"]), _p(K["obs"]), nKF, _p(K["Rcw"]), _p(K["tcw"]),
+            _p(K["Ow"]), fx, fy, cx, cy, mbf, minx, maxx, miny, maxy, float(kf["gw_inv"]), float(kf["gh_inv"]), _p(K["sf"]), _p(K["is2"]),
+            len(K["sf"]), float(kf["log_scale"]), nmp, _p(M["null"]), _p(M["bad"]), _p(M["in_kf"]), _p(M["wp"]), _p(M["nr"]), _p(M["mx"]),
+            _p(M["mn"]), _p(M["d"]), _p(M["obs"]), float(th), _p(ka), _p(mr), _p(orr))
+    return ka[:nKF], mr[:nmp], orr[:nKF], rv

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <vector>
@@ -318,6 +319,99 @@ int REF_NAME(search_by_projection_local_map)(const RefFrameArgs *cur, int nmp, c
         n = m.SearchByProjection(F, v, th);
     }
     flatten_assigned(F, own, pool, assigned);
+    return n;
+}
+
+/* Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th)  src/ORBmatcher.cc:1031-1182 on a mock KeyFrame.
+ * KeyFrame: keypoints (xy, octave), mvuRight, descriptors, pose (Rcw 9, tcw 3, Ow 3), intrinsics, level tables, per-feature
+ * MapPoint state kf_state (0 none, 1 good with kf_obs[i] observations, 2 bad).  MapPoints: ptr_null, bad, already in the
+ * KeyFrame, world pos, normal, max / min distance, descriptor, observations.
+ * Out: kf_assigned[nKF] (-1 none, -2 the KeyFrame's own point, i >= 0 fused point i), mp_replaced[nmp] (-1 not replaced,
+ * -2 - j replaced by the KeyFrame's own point of feature j ... encoded as -(j + 2); k >= 0 does not occur), own_replaced[nKF]
+ * (index of the fused point that replaced the KeyFrame's own point, -1 none). */
+int REF_NAME(fuse)(const uint8_t *descKF, const float *xyKF, const int32_t *octKF, const float *uRightKF, const uint8_t *kf_state,
+                   const int32_t *kf_obs, int nKF, const float *Rcw, const float *tcw, const float *Ow, float fx, float fy, float cx,
+                   float cy, float mbf, float minx, float maxx, float miny, float maxy, float gw_inv, float gh_inv,
+                   const float *scale_factors, const float *inv_sigma2, int nlevels, float log_scale, int nmp, const uint8_t *mp_null,
+                   const uint8_t *mp_bad, const uint8_t *mp_in_kf, const float *world_pos, const float *normal,
+                   const float *max_dist, const float *min_dist, const uint8_t *mpdesc, const int32_t *mp_obs, float th,
+                   int32_t *kf_assigned, int32_t *mp_replaced, int32_t *own_replaced)
+{
+    KeyFrame kf;
+    kf.N = nKF;
+    kf.mDescriptors = cv::Mat(nKF, 32, CV_8UC1, (void *)descKF);
+    kf.mvKeysUn.assign((size_t)nKF, cv::KeyPoint());
+    for (int i = 0; i < nKF; i++) {
+        kf.mvKeysUn[(size_t)i].pt = cv::Point2f(xyKF[2 * i], xyKF[2 * i + 1]);
+        kf.mvKeysUn[(size_t)i].octave = octKF[i];
+    }
+    kf.mvKeys = kf.mvKeysUn;
+    kf.mvuRight.assign(uRightKF, uRightKF + nKF);
+    kf.fx = fx; kf.fy = fy; kf.cx = cx; kf.cy = cy; kf.mbf = mbf;
+    kf.mnMinX = (int)minx; kf.mnMaxX = (int)maxx; kf.mnMinY = (int)miny; kf.mnMaxY = (int)maxy;
+    kf.mfGridElementWidthInv = gw_inv; kf.mfGridElementHeightInv = gh_inv;
+    kf.mnScaleLevels = nlevels;
+    kf.mfLogScaleFactor = log_scale;
+    kf.mvScaleFactors.assign(scale_factors, scale_factors + nlevels);
+    kf.mvInvLevelSigma2.assign(inv_sigma2, inv_sigma2 + nlevels);
+    kf.mvLevelSigma2.assign((size_t)nlevels, 1.f);
+    kf.Rcw = cv::Mat(3, 3, CV_32F);
+    kf.tcw = cv::Mat(3, 1, CV_32F);
+    kf.Ow = cv::Mat(3, 1, CV_32F);
+    for (int k = 0; k < 9; k++) kf.Rcw.at<float>(k / 3, k % 3) = Rcw[k];
+    for (int k = 0; k < 3; k++) { kf.tcw.at<float>(k) = tcw[k]; kf.Ow.at<float>(k) = Ow[k]; }
+    /* the KeyFrame's grid as its constructor copies it from the Frame (src/KeyFrame.cc:47-55): Frame::AssignFeaturesToGrid */
+    {
+        Frame f;
+        f.N = nKF;
+        f.mvKeysUn = kf.mvKeysUn;
+        Frame::mnMinX = minx; Frame::mnMinY = miny;
+        Frame::mfGridElementWidthInv = gw_inv; Frame::mfGridElementHeightInv = gh_inv;
+        f.AssignFeaturesToGrid();
+        kf.mGrid.resize(FRAME_GRID_COLS);
+        for (int i = 0; i < FRAME_GRID_COLS; i++) {
+            kf.mGrid[(size_t)i].resize(FRAME_GRID_ROWS);
+            for (int j = 0; j < FRAME_GRID_ROWS; j++) kf.mGrid[(size_t)i][(size_t)j] = f.mGrid[i][j];
+        }
+    }
+    std::vector<MapPoint> own((size_t)std::max(nKF, 1)), pool((size_t)std::max(nmp, 1));
+    kf.mvpMapPoints.assign((size_t)nKF, (MapPoint *)0);
+    for (int i = 0; i < nKF; i++)
+        if (kf_state[i]) {
+            own[(size_t)i].mbBad = kf_state[i] == 2;
+            own[(size_t)i].nObs = kf_obs[i];
+            kf.mvpMapPoints[(size_t)i] = &own[(size_t)i];
+        }
+    std::vector<MapPoint *> v((size_t)nmp, (MapPoint *)0);
+    for (int i = 0; i < nmp; i++) {
+        if (mp_null[i]) continue;
+        MapPoint &mp = pool[(size_t)i];
+        mp.mbBad = mp_bad[i] != 0;
+        mp.nObs = mp_obs[i];
+        if (mp_in_kf[i]) mp.mObservations[&kf] = 0;
+        mp.world_pos = cv::Mat(3, 1, CV_32F);
+        mp.normal = cv::Mat(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) { mp.world_pos.at<float>(k) = world_pos[3 * i + k]; mp.normal.at<float>(k) = normal[3 * i + k]; }
+        mp.mfMaxDistance = max_dist[i];
+        mp.mfMinDistance = min_dist[i];
+        mp.mDescriptor = cv::Mat(1, 32, CV_8UC1, (void *)(mpdesc + (size_t)i * 32)).clone();
+        v[(size_t)i] = &mp;
+    }
+    ORBmatcher m(0.6f, true);
+    int n;
+    {
+        CallTimer tm;
+        n = m.Fuse(&kf, v, th);
+    }
+    for (int i = 0; i < nKF; i++) {
+        const MapPoint *p = kf.mvpMapPoints[(size_t)i];
+        kf_assigned[i] = !p ? -1 : (p >= own.data() && p < own.data() + own.size()) ? -2 : (int32_t)(p - pool.data());
+        own_replaced[i] = own[(size_t)i].replaced ? (int32_t)(own[(size_t)i].replaced - pool.data()) : -1;
+    }
+    for (int i = 0; i < nmp; i++) {
+        const MapPoint *r = pool[(size_t)i].replaced;
+        mp_replaced[i] = !r ? -1 : -(int32_t)(r - own.data()) - 2;
+    }
     return n;
 }
 

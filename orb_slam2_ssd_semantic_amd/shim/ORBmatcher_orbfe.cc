@@ -11,6 +11,10 @@
 //     int ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)                  src/ORBmatcher.cc:1578-1724
 //     (with -DORBFE_SHIM_PERFECT, for the perfect/ tree) the overload that also returns the 2-D point pairs,
 //                                                                                             perfect/src/ORBmatcher.cc:1727-1911
+//     int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                  src/ORBmatcher.cc:1031-1182
+//       (LocalMapping::SearchInNeighbors): the candidate scans do not look at the state the loop mutates, so all gates run
+//       first, ONE orbfe_hamming_csr call gives every point's best candidate, and the Replace / AddMapPoint decisions are
+//       replayed in order on the live objects
 // The two SearchByProjection members are the per-frame matchers of Tracking (TrackWithMotionModel src/Tracking.cc:1346,
 // SearchLocalPoints :1960): the pose projection and its gates run here, on cv::Mat, statement for statement as in the
 // reference; the candidate search (GetFeaturesInArea + Hamming + the "slot already taken" rule) is ONE
@@ -269,6 +273,111 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
                            [this](std::vector<int> *h, int &a, int &b, int &c) { ComputeThreeMaxima(h, HISTO_LENGTH, a, b, c); });
 }
 #endif
+
+// src/ORBmatcher.cc:1031-1182
+int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th)
+{
+    cv::Mat Rcw = pKF->GetRotation();
+    cv::Mat tcw = pKF->GetTranslation();
+    const float &fx = pKF->fx;
+    const float &fy = pKF->fy;
+    const float &cx = pKF->cx;
+    const float &cy = pKF->cy;
+    const float &bf = pKF->mbf;
+    cv::Mat Ow = pKF->GetCameraCenter();
+    const int nMPs = (int)vpMapPoints.size();
+    // ---- phase 1: every gate that does not depend on what the loop mutates (:1060-1143), candidate lists as CSR ----
+    std::vector<uint32_t> off(1, 0), cand;
+    std::vector<uint8_t> qdesc;
+    std::vector<int> slot((size_t)nMPs, -1);  // query index of MapPoint i, -1 = gated out / no candidates
+    for (int i = 0; i < nMPs; i++) {
+        MapPoint *pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0f) continue;  // :1068
+        const float invz = 1 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz;
+        const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;  // :1080
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist3D = cv::norm(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;  // :1090
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) continue;  // :1096
+        int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        const std::vector<size_t> vIndices = pKF->GetFeaturesInArea(u, v, radius);  // :1103
+        if (vIndices.empty()) continue;
+        const size_t before = cand.size();
+        for (std::vector<size_t>::const_iterator vit = vIndices.begin(), vend = vIndices.end(); vit != vend; vit++) {
+            const size_t idx = *vit;
+            const cv::KeyPoint &kp = pKF->mvKeysUn[idx];
+            const int &kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;  // :1119
+            if (pKF->mvuRight[idx] >= 0) {  // :1122-1135
+                const float ur = u - bf * invz;
+                const float &kpx = kp.pt.x;
+                const float &kpy = kp.pt.y;
+                const float &kpr = pKF->mvuRight[idx];
+                const float ex = u - kpx;
+                const float ey = v - kpy;
+                const float er = ur - kpr;
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 7.8) continue;
+            } else {  // :1137-1145
+                const float &kpx = kp.pt.x;
+                const float &kpy = kp.pt.y;
+                const float ex = u - kpx;
+                const float ey = v - kpy;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 5.99) continue;
+            }
+            cand.push_back((uint32_t)idx);
+        }
+        if (cand.size() == before) continue;  // no candidate passed: bestDist stays 256 (:1159)
+        slot[(size_t)i] = (int)off.size() - 1;
+        off.push_back((uint32_t)cand.size());
+        const cv::Mat dMP = pMP->GetDescriptor();
+        qdesc.insert(qdesc.end(), dMP.ptr<uint8_t>(0), dMP.ptr<uint8_t>(0) + 32);
+    }
+    // ---- the Hamming work: best candidate per point, first in list order on ties (:1149-1156) ----
+    const int nq = (int)off.size() - 1;
+    std::vector<int32_t> bestIdx((size_t)std::max(nq, 1), -1), best((size_t)std::max(nq, 1), 256), second((size_t)std::max(nq, 1), 256);
+    if (nq > 0) {
+        std::vector<uint8_t> tmp;
+        const orbfe_status s = orbfe_hamming_csr(t_matcher.get(), qdesc.data(), nq, Rows(pKF->mDescriptors, tmp), pKF->mDescriptors.rows,
+                                                 off.data(), cand.data(), bestIdx.data(), best.data(), second.data());
+        if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::Fuse (orbfe): ") + orbfe_last_error());
+    }
+    // ---- phase 2: the loop's decisions, in order, on the live objects (:1049-1056, :1159-1180) ----
+    int nFused = 0;
+    for (int i = 0; i < nMPs; i++) {
+        MapPoint *pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+        if (slot[(size_t)i] < 0) continue;
+        const int k = slot[(size_t)i];
+        if (best[(size_t)k] <= TH_LOW) {
+            MapPoint *pMPinKF = pKF->GetMapPoint((size_t)bestIdx[(size_t)k]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, (size_t)bestIdx[(size_t)k]);
+                pKF->AddMapPoint(pMP, (size_t)bestIdx[(size_t)k]);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
+}
 
 int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
 {

@@ -188,3 +188,44 @@ def oracle_local_map(cur, mps, th, nnratio=0.8, th_high=100):
     m, b, s = O.search_by_projection(queries=q[sel], qdesc=np.asarray(mps["mpdesc"]).reshape(-1, 32)[sel], th=th_high, nnratio=nnratio,
                                      ratio_rule=1, **core_inputs(cur))
     return replay_local_map(cur, valid, m) + (q, valid, m)
+
+
+def fuse_case(rng, nKF, nmp):
+    """(kf, mps) for ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th): map points that project near keypoints of the
+    keyframe at a distance consistent with the keypoint's octave, some null / bad / already observed by the keyframe, some
+    behind the camera, out of the image, out of their distance range or seen from the wrong side"""
+    cur = current_frame(rng, nKF)
+    fx, fy, cx, cy, mbf, mb = cur["K"]
+    T = _pose(rng, 5.0, rng.normal(0, 0.2, 3))
+    Rcw, tcw = T[:3, :3], T[:3, 3]
+    Ow = (-(Rcw.astype(np.float64).T @ tcw.astype(np.float64))).astype(np.float32)
+    sf = cur["scale_factors"]
+    kf = dict(desc=cur["desc"], xy=cur["xy"], octave=cur["octave"], uRight=cur["uRight"], state=rng.choice([0, 0, 1, 1, 2], nKF).astype(np.uint8),
+              obs=rng.integers(0, 6, nKF).astype(np.int32), Rcw=Rcw, tcw=tcw, Ow=Ow, K=(fx, fy, cx, cy, mbf), bounds=cur["bounds"],
+              gw_inv=cur["gw_inv"], gh_inv=cur["gh_inv"], scale_factors=sf, inv_sigma2=(1.0 / (sf * sf)).astype(np.float32),
+              log_scale=np.float32(np.log(np.float32(1.2))))
+    tgt = rng.integers(0, max(nKF, 1), nmp) if nKF else np.zeros(nmp, np.int64)
+    z = rng.uniform(0.5, 8.0, nmp)
+    if nmp > 12:
+        z[rng.integers(0, nmp, 3)] *= -1
+    px = (cur["xy"][tgt] if nKF else np.zeros((nmp, 2))) + rng.normal(0, 1.5, (nmp, 2))
+    if nmp > 12:
+        px[rng.integers(0, nmp, 3)] += 900
+    Xc = np.stack([(px[:, 0] - cx) / fx * z, (px[:, 1] - cy) / fy * z, z], 1)
+    world = ((Xc - tcw.astype(np.float64)) @ Rcw.astype(np.float64)).astype(np.float32)
+    PO = world.astype(np.float64) - Ow.astype(np.float64)
+    d3 = np.linalg.norm(PO, axis=1)
+    lvl = (cur["octave"][tgt] if nKF else np.zeros(nmp)).astype(np.float64) + rng.choice([0, 0, 0, 1], nmp)
+    maxd = (d3 * 1.2 ** lvl * rng.uniform(0.93, 0.999, nmp)).astype(np.float32)   # PredictScale -> about lvl
+    mind = (maxd / 1.2 ** 7).astype(np.float32)
+    if nmp > 12:
+        maxd[rng.integers(0, nmp, 3)] *= 0.3   # out of the distance range
+    normal = PO / np.maximum(d3[:, None], 1e-9) + rng.normal(0, 0.3, (nmp, 3))
+    normal /= np.maximum(np.linalg.norm(normal, axis=1, keepdims=True), 1e-9)
+    if nmp > 12:
+        normal[rng.integers(0, nmp, 4)] *= -1
+    mps = dict(null=(rng.random(nmp) < 0.03).astype(np.uint8), bad=(rng.random(nmp) < 0.05).astype(np.uint8),
+               in_kf=(rng.random(nmp) < 0.05).astype(np.uint8), world_pos=world, normal=normal.astype(np.float32), max_dist=maxd,
+               min_dist=mind, mpdesc=noisy_copy(rng, cur["desc"][tgt] if nKF else np.zeros((nmp, 32), np.uint8), 60),
+               obs=rng.integers(0, 6, nmp).astype(np.int32))
+    return kf, mps

@@ -158,3 +158,22 @@ def test_shim_perfect_overload_with_point_pairs_equals_reference_body():
         assert sn == rn and np.array_equal(sa, ra) and np.array_equal(spl, rpl) and np.array_equal(spc, rpc), seed
         sa2, sn2 = R.search_by_projection_last_frame(cur, last, th, mono, perfect=True, shim=True)
         assert sn2 == rn and np.array_equal(sa2, ra), seed
+
+
+@needs_shim
+@pytest.mark.gpu
+def test_shim_fuse_equals_reference_body():
+    """ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:1031-1182, LocalMapping::SearchInNeighbors)
+    through the reference's class: shim (all gates on the host, ONE orbfe_hamming_csr call, decisions replayed in order) ==
+    the reference's compiled body -- the keyframe's MapPoint per feature, which points were replaced by which, the count."""
+    fused = 0
+    for seed in range(80):
+        rng = np.random.default_rng(17_000 + seed)
+        nKF, nmp = int(rng.choice([1, 30, 300, 1000])), int(rng.choice([1, 40, 400, 1500]))
+        kf, mps = PC.fuse_case(rng, nKF, nmp)
+        th = float(rng.choice([3.0, 3.0, 5.0]))
+        r = R.fuse(kf, mps, th)
+        s = R.fuse(kf, mps, th, shim=True)
+        assert s[3] == r[3] and all(np.array_equal(a, b) for a, b in zip(s[:3], r[:3])), (seed, nKF, nmp, r[3], s[3])
+        fused += r[3]
+    assert fused > 2000
