@@ -363,6 +363,46 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             return ORBFE_ERR_SIZE;
         }
     }
+    // Two pyramid levels per launch: for B = 1, 3, 5, ... with a level C = B + 1 above it, the tiling of B and the first
+    // C column / row every tile column / row owns (C pixel (x2, y2) belongs to the tile that holds its top-left tap
+    // (sx(x2), sy(y2)) in its own -- non-overlap -- part).
+    for (int l = 1; l + 1 < nl; l += 2) {
+        OrbLevel &B = P.lv[l];
+        const OrbLevel &C = P.lv[l + 1];
+        const int ngroups = (B.w + 3) / 4;
+        const int ntx0 = (ngroups + 63) / 64;
+        int gx = std::max(2, std::min(64, (ngroups + ntx0 - 1) / ntx0 + (ntx0 > 1 ? 1 : 0)));
+        int gy = std::max(1, 256 / gx);
+        const int trows = gy * ORBFE_PW_ROWS;
+        if (trows < 2 || orbk_pyramid2_lds_bytes(gx, gy) > 60 * 1024) continue;
+        const int tiles_x = ngroups <= gx ? 1 : (ngroups - 1 + gx - 2) / (gx - 1);
+        const int tiles_y = B.h <= trows ? 1 : (B.h - 1 + trows - 2) / (trows - 1);
+        auto add_i32 = [&](const std::vector<int32_t> &v) {
+            while (tabs.size() % 4) tabs.push_back(OrbTab{0, 0, 0, 0});
+            const int at = (int)tabs.size();
+            tabs.resize(tabs.size() + (v.size() + 1) / 2 + 1);
+            memcpy(&tabs[(size_t)at], v.data(), v.size() * sizeof(int32_t));
+            return at;
+        };
+        std::vector<int32_t> cxs((size_t)tiles_x + 1), cys((size_t)tiles_y + 1);
+        for (int t = 0; t <= tiles_x; ++t) {
+            int x2 = 0;
+            if (t == tiles_x) x2 = C.w;
+            else
+                while (x2 < C.w && tabs[(size_t)C.xtab + x2].s < t * (gx - 1) * 4) ++x2;
+            cxs[(size_t)t] = x2;
+        }
+        for (int t = 0; t <= tiles_y; ++t) {
+            int y2 = 0;
+            if (t == tiles_y) y2 = C.h;
+            else
+                while (y2 < C.h && tabs[(size_t)C.ytab + y2].s < t * (trows - 1)) ++y2;
+            cys[(size_t)t] = y2;
+        }
+        B.p2_gx = gx; B.p2_gy = gy; B.p2_tx = tiles_x; B.p2_ty = tiles_y;
+        B.p2_cxs = add_i32(cxs);
+        B.p2_cys = add_i32(cys);
+    }
     P.ncells = (int)cells.size();
     P.cell_cap = cell_cap;
     P.max_ncells = 1;

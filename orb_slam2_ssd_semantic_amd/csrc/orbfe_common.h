@@ -58,6 +58,11 @@ struct OrbLevel {
     float patch_size;      // (float)(int)(PATCH_SIZE * scale)  (:846)
     int32_t root_x[ORBFE_MAX_ROOTS + 1];  // root box x boundaries, nini+1 entries
     int32_t ix1, iy1;      // end of the union of the cells' detectable interiors ([19,ix1) x [19,iy1))
+    // two pyramid levels per launch (k_pyr_walk2): this level (B) is produced tile by tile from level l-1 and level l+1 (C)
+    // from the tile while it is in LDS.  Tile = p2_gx column groups (4 px) x p2_gy row runs; tiles overlap by one column
+    // group and one row; p2_cxs / p2_cys: first column / row of level l+1 each tile column / row owns (int32 tables inside
+    // the tap-table block, offsets in OrbTab entries).  p2_tx == 0: not fused.
+    int32_t p2_gx, p2_gy, p2_tx, p2_ty, p2_cxs, p2_cys;
 };
 
 // one FAST cell = one cv::FAST call of the reference (:798-838)

@@ -48,7 +48,9 @@ size_t orbk_octree_lds_bytes(int node_cap, int max_nini, int w, int h, int ncell
 size_t orbk_octree_box_bytes(int node_cap);
 size_t orbk_octree_node_bytes(int node_cap);  // global scratch per (frame, level) when the node arrays do not fit the LDS
 hipError_t orbk_prepare_octree(int node_cap, int max_nini, int w, int h, int ncells);
-size_t orbk_pyramid_lds_bytes(int dh);  // dynamic LDS of the pyramid kernel for a destination level of dh rows
+size_t orbk_pyramid_lds_bytes(int dh);
+#define ORBFE_PW_ROWS 16  // destination rows per lane run of the pyramid kernels (= PW_ROWS)
+size_t orbk_pyramid2_lds_bytes(int gx, int gy);  // dynamic LDS of the two-level pyramid kernel for a tile of gx column groups x gy runs  // dynamic LDS of the pyramid kernel for a destination level of dh rows
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st);

@@ -240,6 +240,178 @@ __global__ __launch_bounds__(256) void k_pyr_walk(PyrArgs a)
     }
 }
 
+// Two levels per launch.  The workgroup owns a tile of level B = l: p2_gx column groups x p2_gy runs of a.rb rows, produced
+// from level A = l - 1 exactly as k_pyr_walk does (same row walk, same arithmetic); the finished tile stays in LDS
+// ([row][p2_gx] dwords), is stored to B in a burst, and level C = l + 1 is then resized from the LDS tile: every C pixel whose
+// top-left tap falls on the tile's own part (tiles overlap by one column group and one row, so its other three taps are in
+// the tile too) -- level B is never re-read from HBM.  Same fixed-point formula for C: H = (S[sx] * c0 + S[sx+1] * c1) >> 4 on
+// both source rows, ((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2) >> 2.
+struct Pyr2Args {
+    PyrArgs ab;                 // A -> B as in k_pyr_walk (rb = rows per run; nrblk unused)
+    uint8_t *dstC;              // level C, frame 0
+    int32_t cw, ch, cpitch;
+    const OrbTab *xtabC, *ytabC;
+    const int32_t *cxs, *cys;   // [tiles_x + 1], [tiles_y + 1]
+    int32_t gx, gy, tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256) void k_pyr_walk2(Pyr2Args p)
+{
+    extern __shared__ uint2 s_dyn[];
+    const PyrArgs &a = p.ab;
+    const int GX = p.gx, trows = p.gy * a.rb;
+    uint2 *s_yt = s_dyn;                                     // [trows + 8] vertical taps of the tile's B rows
+    uint32_t *s_tile = (uint32_t *)(s_dyn + (trows + 8));    // [trows][GX] dwords = the B tile
+    const int b = blockIdx.y;
+    const int tx = (int)blockIdx.x % p.tiles_x, ty = (int)blockIdx.x / p.tiles_x;
+    const int W = a.dw, H = a.dh;
+    const int g0 = tx * (GX - 1), by0 = ty * (trows - 1);    // first column group / row of the tile
+    for (int i = threadIdx.x; i < trows + 8; i += 256) s_yt[i] = ((const uint2 *)a.ytab)[min(by0 + i, H + 7)];
+    const int ncol4 = (W + 3) >> 2;
+    const int lane_ok = (int)threadIdx.x < GX * p.gy;
+    const int tl = min((int)threadIdx.x, GX * p.gy - 1);     // surplus lanes repeat the last lane's work
+    const int run = tl / GX, cg = tl - run * GX;
+    const int dx0 = min(g0 + cg, ncol4 - 1) * 4;             // column groups past the level repeat its last group
+    const int y0 = min(by0 + run * a.rb, H - 1), yend = min(by0 + (run + 1) * a.rb, H);
+    const uint8_t *src = a.src + (int64_t)b * a.src_fstride;
+    uint8_t *dst = a.dst + (int64_t)b * a.dst_fstride;
+
+    const uint4 tx01 = *(const uint4 *)(a.xtab + dx0), tx23 = *(const uint4 *)(a.xtab + dx0 + 2);
+    const uint32_t xc[4] = {tx01.x, tx01.z, tx23.x, tx23.z};
+    const int xs[4] = {(int)(short)tx01.y, (int)(short)tx01.w, (int)(short)tx23.y, (int)(short)tx23.w};
+    const int sx0 = min(xs[0], a.sw - 8);
+    uint32_t sel[4];
+    orb_u2 coef[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t o = (uint32_t)min(max(xs[j] - sx0, 0), 7);
+        sel[j] = 0x0c000c00u | (min(o + 1u, 7u) << 16) | o;
+        coef[j] = __builtin_bit_cast(orb_u2, xc[j]);
+    }
+    __syncthreads();
+    const int yl0 = y0 - by0;                                // tile-local row of the lane's first destination row
+    uint2 cur = s_yt[yl0];
+    const int r0 = (int)(short)cur.y;
+    int nsteps = (int)(short)s_yt[max(yend - 1, y0) - by0].y + 2 - r0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+    const uint32_t sp = (uint32_t)a.spitch;
+    const int rlast = a.sh - 1;
+    auto fetch = [&](int s, uint2 &q) { q = *(const uint2 *)(src + (__umul24((uint32_t)min(r0 + s, rlast), sp) + (uint32_t)sx0)); };
+    auto hsum = [&](const uint2 &q, uint32_t (&h)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, __builtin_amdgcn_perm(q.y, q.x, sel[j])), coef[j], 0u, false) >> 4;
+    };
+    uint2 raw[4];
+    fetch(0, raw[0]);
+    fetch(1, raw[1]);
+    fetch(2, raw[2]);
+    uint32_t Hp[4];
+    hsum(raw[0], Hp);
+    int d = y0;
+    uint32_t *park = s_tile + yl0 * GX + cg;
+    for (int s0 = 1; s0 < nsteps; s0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s = s0 + k;
+            fetch(s + PW_PF, raw[(k + 1 + PW_PF) % 4]);
+            uint32_t Hs[4];
+            hsum(raw[(k + 1) % 4], Hs);
+            const bool emit = lane_ok && d < yend && (int)(short)cur.y + 1 == r0 + s;
+            const uint32_t b0 = cur.x & 0xFFFFu, b1 = cur.x >> 16;
+            uint32_t pa[4], pb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pa[j] = __umul24(b0, Hp[j]);
+                pb[j] = __umul24(b1, Hs[j]) + 0x20000u;
+            }
+            uint32_t t01, t23;
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t01) : "v"(pa[0]), "v"(pb[0]));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t01) : "v"(pa[1]), "v"(pb[1]));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t23) : "v"(pa[2]), "v"(pb[2]));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t23) : "v"(pa[3]), "v"(pb[3]));
+            const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t01) >> (orb_u2)(2));
+            const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t23) >> (orb_u2)(2));
+            if (emit) {
+                *park = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
+                park += GX;
+                d += 1;
+            }
+            cur = s_yt[min(d, yend) - by0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Hp[j] = Hs[j];
+        }
+    }
+    // burst store of the lane's column of the B tile (its own LDS words: no barrier needed)
+    if (lane_ok && g0 + cg < ncol4) {
+        uint32_t oofs = __umul24((uint32_t)y0, (uint32_t)a.dpitch) + (uint32_t)dx0;
+        const int nrows = yend - y0;
+        for (int i0 = 0; i0 < a.rb; i0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = s_tile[(yl0 + min(i0 + i, a.rb - 1)) * GX + cg];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i0 + i < nrows) *(uint32_t *)(dst + (oofs + (uint32_t)(i0 + i) * (uint32_t)a.dpitch)) = v[i];
+        }
+    }
+    __syncthreads();
+    // ---- level C from the tile ----
+    // A thread owns one aligned 4-pixel column group of the tile's C part (its four horizontal taps live in registers) and a
+    // contiguous share of the tile's C rows; per row: the vertical tap from LDS, 16 byte reads of the tile, one dword store.
+    const int cx0 = p.cxs[tx], cx1 = p.cxs[tx + 1], cy0 = p.cys[ty], cy1 = p.cys[ty + 1];
+    if (cx1 <= cx0 || cy1 <= cy0) return;
+    const int gq0 = cx0 >> 2, ngc = ((cx1 - 1) >> 2) - gq0 + 1;
+    const int nch = max(1, 256 / ngc);                       // row shares
+    const int gi = (int)threadIdx.x % ngc, chn = (int)threadIdx.x / ngc;
+    if (chn >= nch) return;
+    const int nrowsC = cy1 - cy0, per = (nrowsC + nch - 1) / nch;
+    const int ya = cy0 + chn * per, yb = min(ya + per, cy1);
+    const uint8_t *T = (const uint8_t *)s_tile;
+    const int tpitch = GX * 4, bx0 = g0 * 4;
+    const int colmax = min(GX * 4, W - bx0) - 1, rowmax = min(trows, H - by0) - 1;   // clamps of the second taps
+    uint8_t *dstC = p.dstC + (int64_t)b * a.dst_fstride;
+    const int xg = (gq0 + gi) * 4;
+    int c0i[4], c1i[4];
+    uint32_t cc0[4], cc1[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x2 = xg + j;
+        ok[j] = x2 >= cx0 && x2 < cx1;
+        const OrbTab tt = p.xtabC[min(x2, p.cw - 1)];
+        c0i[j] = min(max((int)tt.s - bx0, 0), colmax);
+        c1i[j] = min(c0i[j] + 1, colmax);
+        cc0[j] = (uint32_t)(uint16_t)tt.c0;
+        cc1[j] = (uint32_t)(uint16_t)tt.c1;
+    }
+    const bool full = ok[0] && ok[1] && ok[2] && ok[3];
+    OrbTab tyn = p.ytabC[min(ya, p.ch - 1)];
+    for (int y2 = ya; y2 < yb; ++y2) {
+        const OrbTab ty_ = tyn;
+        tyn = p.ytabC[min(y2 + 1, p.ch - 1)];   // next row's vertical tap is in flight while this row is computed
+        const int rr0 = (int)ty_.s - by0, rr1 = min(rr0 + 1, rowmax);
+        const uint32_t b0 = (uint32_t)(uint16_t)ty_.c0, b1 = (uint32_t)(uint16_t)ty_.c1;
+        const uint8_t *R0 = T + rr0 * tpitch, *R1 = T + rr1 * tpitch;
+        uint32_t px[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t H0 = (R0[c0i[j]] * cc0[j] + R0[c1i[j]] * cc1[j]) >> 4, H1 = (R1[c0i[j]] * cc0[j] + R1[c1i[j]] * cc1[j]) >> 4;
+            px[j] = ((((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2u) >> 2) & 0xFFu;
+        }
+        uint8_t *o = dstC + (__umul24((uint32_t)y2, (uint32_t)p.cpitch) + (uint32_t)xg);
+        if (full) {
+            *(uint32_t *)o = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ok[j]) o[j] = (uint8_t)px[j];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K2  FAST-9/16 with the reference's per-cell semantics: corner at t <=> A > t for the arc strength
 //   A = max(A_dark, A_bright), cv score = A - 1, 3x3 strict NMS inside each cell's detectable interior, iniTh list
@@ -1852,34 +2024,65 @@ static FrameSrc make_src(const OrbLaunch &a)
 
 size_t orbk_pyramid_lds_bytes(int dh) { return (size_t)(dh + 8) * sizeof(uint2) + (size_t)PW_ROWS * 256 * 4; }
 
+size_t orbk_pyramid2_lds_bytes(int gx, int gy) { return (size_t)(gy * PW_ROWS + 8) * sizeof(uint2) + (size_t)gy * PW_ROWS * gx * 4; }
+
+static void pyr_args(const OrbLaunch &a, int l, PyrArgs &pa)
+{
+    const OrbLevel &D = a.h_plan->lv[l];
+    const OrbLevel &S = a.h_plan->lv[l - 1];
+    if (l == 1) {
+        pa.src = a.d_gray;
+        pa.src_fstride = a.gray_fstride;
+        pa.spitch = a.gray_pitch;
+    } else {
+        pa.src = a.d_pyr + S.off;
+        pa.src_fstride = a.pyr_fstride;
+        pa.spitch = S.pitch;
+    }
+    pa.dst = a.d_pyr + D.off;
+    pa.dst_fstride = a.pyr_fstride;
+    pa.sw = S.w; pa.sh = S.h;
+    pa.dw = D.w; pa.dh = D.h; pa.dpitch = D.pitch;
+    pa.xtab = a.d_tabs + D.xtab;
+    pa.ytab = a.d_tabs + D.ytab;
+    const int nb = (D.h + PW_ROWS - 1) / PW_ROWS;
+    pa.rb = (D.h + nb - 1) / nb;               // balanced run length
+    pa.nrblk = (D.h + pa.rb - 1) / pa.rb;      // no empty run
+}
+
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
 {
-    // One launch per level (level l reads level l-1, :1134).  Measured alternative (on the earlier tile form of the kernel),
-    // not kept: all levels of a frame in one launch (a 1024-thread workgroup per frame, workgroup barriers between
-    // levels) -- 0.66 ms against 0.63 ms per 1024 frames; with an agent-scope fence between the levels (an L2 write-back
-    // on this part) 4.8 ms.
-    for (int l = 1; l < a.h_plan->nlevels; ++l) {
+    // Level l reads level l-1 (:1134): one launch per level.  ORBFE_PYR_FUSE=1 selects the two-levels-per-launch form instead
+    // (k_pyr_walk2: level l from l-1 in tiles, level l+1 from the tile while it is in LDS -- the odd levels are not re-read
+    // from HBM, an 8-level pyramid takes 4 launches).  It is byte-exact and tested, and it is SLOWER on this part: 0.574 vs
+    // 0.505 ms per 1024 640x480 frames, 0.424 vs 0.397 ms per 128 1080p frames (profiles/r03_ab_experiments.json) -- the
+    // chained kernels are latency-bound, not traffic-bound (3.7 of ~5 TB/s), and the second phase lengthens every
+    // workgroup's dependent chain by more than the saved 0.37 GB of reads are worth.  Also measured, not kept: all levels
+    // of a frame in one launch (a 1024-thread workgroup per frame, workgroup barriers between levels) -- 0.66 ms against
+    // 0.63 ms per 1024 frames; with an agent-scope fence between the levels 4.8 ms.
+    const char *fe = getenv("ORBFE_PYR_FUSE");
+    const bool fuse = fe && atoi(fe) == 1;
+    const int nl = a.h_plan->nlevels;
+    for (int l = 1; l < nl; ++l) {
         const OrbLevel &D = a.h_plan->lv[l];
-        const OrbLevel &S = a.h_plan->lv[l - 1];
         PyrArgs pa;
-        if (l == 1) {
-            pa.src = a.d_gray;
-            pa.src_fstride = a.gray_fstride;
-            pa.spitch = a.gray_pitch;
-        } else {
-            pa.src = a.d_pyr + S.off;
-            pa.src_fstride = a.pyr_fstride;
-            pa.spitch = S.pitch;
+        pyr_args(a, l, pa);
+        if (fuse && l + 1 < nl && D.p2_tx > 0) {
+            const OrbLevel &C = a.h_plan->lv[l + 1];
+            Pyr2Args p2;
+            p2.ab = pa;
+            p2.ab.rb = PW_ROWS;
+            p2.dstC = a.d_pyr + C.off;
+            p2.cw = C.w; p2.ch = C.h; p2.cpitch = C.pitch;
+            p2.xtabC = a.d_tabs + C.xtab;
+            p2.ytabC = a.d_tabs + C.ytab;
+            p2.cxs = (const int32_t *)(a.d_tabs + D.p2_cxs);
+            p2.cys = (const int32_t *)(a.d_tabs + D.p2_cys);
+            p2.gx = D.p2_gx; p2.gy = D.p2_gy; p2.tiles_x = D.p2_tx; p2.tiles_y = D.p2_ty;
+            hipLaunchKernelGGL(k_pyr_walk2, dim3(D.p2_tx * D.p2_ty, a.nframes), dim3(256), orbk_pyramid2_lds_bytes(D.p2_gx, D.p2_gy), st, p2);
+            ++l;
+            continue;
         }
-        pa.dst = a.d_pyr + D.off;
-        pa.dst_fstride = a.pyr_fstride;
-        pa.sw = S.w; pa.sh = S.h;
-        pa.dw = D.w; pa.dh = D.h; pa.dpitch = D.pitch;
-        pa.xtab = a.d_tabs + D.xtab;
-        pa.ytab = a.d_tabs + D.ytab;
-        const int nb = (D.h + PW_ROWS - 1) / PW_ROWS;
-        pa.rb = (D.h + nb - 1) / nb;               // balanced run length
-        pa.nrblk = (D.h + pa.rb - 1) / pa.rb;      // no empty run
         const int nlanes = ((D.w + 3) / 4) * pa.nrblk;
         dim3 grid((nlanes + 255) / 256, a.nframes);
         hipLaunchKernelGGL(k_pyr_walk, grid, dim3(256), orbk_pyramid_lds_bytes(D.h), st, pa);

@@ -200,6 +200,27 @@ def test_large_nfeatures_node_arrays_beyond_the_lds(oracle, nf, h, w):
         assert_same_output(kps[b, :n[b]].copy().view(KP_DTYPE).reshape(-1), desc[b, :n[b]], *ref[b])
 
 
+def test_two_pyramid_levels_per_launch(oracle):
+    """ORBFE_PYR_FUSE=1: k_pyr_walk2 produces level l in LDS tiles and level l+1 from the tile (the odd levels are not
+    re-read from HBM).  Not the default (it is slower on this part, see the launcher), but byte-exact: every level of odd
+    and even sized frames, 8 and 5 levels, scale factors 1.2 and 1.35, against the oracle."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    os.environ["ORBFE_PYR_FUSE"] = "1"
+    try:
+        for (h, w, nl, sf, seed) in ((480, 640, 8, 1.2, 1), (389, 517, 8, 1.2, 7), (1080, 1920, 8, 1.2, 3), (301, 1203, 5, 1.35, 9),
+                                     (600, 431, 7, 1.2, 4)):
+            img = synth_frame(seed, h, w)
+            oe = oracle.OracleExtractor(700, sf, nl, 20, 7)
+            ok, od = oe(img, cap=1200)
+            e = ORBextractor(700, sf, nl, 20, 7, max_width=w, max_height=h)
+            gk, gd = e(img)
+            for l in range(nl):
+                assert np.array_equal(e.pyramid_level(l), oe.level(l)), (h, w, l)
+            assert_same_output(gk, gd, ok, od)
+    finally:
+        del os.environ["ORBFE_PYR_FUSE"]
+
+
 def test_generic_quadtree_passes_only(oracle):
     """ORBFE_DEBUG=51 disables the fused breadth-first pass of the histogram mode: every pass goes through the generic node
     phase (the one the largest-first passes and the deep trees use) and must give the same trees."""
