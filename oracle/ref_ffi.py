@@ -153,6 +153,8 @@ def _declare_projection(L, prefix):
                                                                        vp, vp, vp, vp]
     getattr(L, prefix + "search_by_projection_local_map").argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp]
     getattr(L, prefix + "last_call_ms").restype = C.c_double
+    getattr(L, prefix + "search_by_projection_frame_kf").argtypes = [vp, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
+    getattr(L, prefix + "search_by_projection_kf_sim3").argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp]
     getattr(L, prefix + "fuse").argtypes = ([vp] * 6 + [ci, vp, vp, vp] + [cf] * 11 + [vp, vp, ci, cf, ci] + [vp] * 9 + [cf, vp, vp, vp])
 
 
@@ -586,3 +588,59 @@ def fuse(kf, mps, th, shim=False, perfect=False):
             len(K["sf"]), float(kf["log_scale"]), nmp, _p(M["null"]), _p(M["bad"]), _p(M["in_kf"]), _p(M["wp"]), _p(M["nr"]), _p(M["mx"]),
             _p(M["mn"]), _p(M["d"]), _p(M["obs"]), float(th), _p(ka), _p(mr), _p(orr))
     return ka[:nKF], mr[:nmp], orr[:nKF], rv
+
+
+class RefKfArgs(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("xy", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p), ("uRight", C.c_void_p),
+                ("n", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float),
+                ("minx", C.c_float), ("maxx", C.c_float), ("miny", C.c_float), ("maxy", C.c_float), ("gw_inv", C.c_float),
+                ("gh_inv", C.c_float), ("scale_factors", C.c_void_p), ("inv_sigma2", C.c_void_p), ("nlevels", C.c_int),
+                ("log_scale", C.c_float)]
+
+
+def _pick(shim, perfect):
+    return (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
+
+
+def search_by_projection_frame_kf(cur, kfp, th, orbdist, check_ori=True, shim=False, perfect=False):
+    """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist) (src/ORBmatcher.cc:1757-1867,
+    Tracking::Relocalization).  kfp: dict(angle, has, bad, found, world_pos, max_dist, min_dist, mpdesc).  Returns
+    (assigned[nC], return value)."""
+    keep = []
+    a = _frame_args(cur, keep)
+    f32, u8 = np.float32, np.uint8
+    K = dict(angle=np.ascontiguousarray(kfp["angle"], f32), has=np.ascontiguousarray(kfp["has"], u8), bad=np.ascontiguousarray(kfp["bad"], u8),
+             found=np.ascontiguousarray(kfp["found"], u8), wp=np.ascontiguousarray(kfp["world_pos"], f32).reshape(-1, 3),
+             mx=np.ascontiguousarray(kfp["max_dist"], f32), mn=np.ascontiguousarray(kfp["min_dist"], f32),
+             d=np.ascontiguousarray(kfp["mpdesc"], u8).reshape(-1, 32))
+    assigned = np.full(max(a.n, 1), -9, np.int32)
+    fn = getattr(_pick(shim, perfect), ("shim_" if shim else "ref_") + "search_by_projection_frame_kf")
+    rv = fn(C.byref(a), float(np.log(np.float32(1.2))), len(K["has"]), _p(K["angle"]), _p(K["has"]), _p(K["bad"]), _p(K["found"]), _p(K["wp"]),
+            _p(K["mx"]), _p(K["mn"]), _p(K["d"]), float(th), int(orbdist), int(check_ori), _p(assigned))
+    return assigned[:a.n], rv
+
+
+def search_by_projection_kf_sim3(kf, Scw, pts, matched_in, th, shim=False, perfect=False):
+    """ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>&, th)
+    (src/ORBmatcher.cc:378-470, LoopClosing).  kf: as for fuse(); pts: dict(bad, world_pos, normal, max_dist, min_dist, mpdesc).
+    Returns (matched_out[nKF], return value)."""
+    f32, i32, u8 = np.float32, np.int32, np.uint8
+    K = dict(desc=np.ascontiguousarray(kf["desc"], u8).reshape(-1, 32), xy=np.ascontiguousarray(kf["xy"], f32).reshape(-1, 2),
+             octave=np.ascontiguousarray(kf["octave"], i32), uRight=np.ascontiguousarray(kf["uRight"], f32),
+             sf=np.ascontiguousarray(kf["scale_factors"], f32), is2=np.ascontiguousarray(kf["inv_sigma2"], f32))
+    a = RefKfArgs()
+    a.desc, a.xy, a.octave, a.angle, a.uRight = K["desc"].ctypes.data, K["xy"].ctypes.data, K["octave"].ctypes.data, None, K["uRight"].ctypes.data
+    a.n = len(K["desc"])
+    a.fx, a.fy, a.cx, a.cy, a.mbf = [float(v) for v in kf["K"][:5]]
+    a.minx, a.maxx, a.miny, a.maxy = [float(v) for v in kf["bounds"]]
+    a.gw_inv, a.gh_inv = float(kf["gw_inv"]), float(kf["gh_inv"])
+    a.scale_factors, a.inv_sigma2, a.nlevels, a.log_scale = K["sf"].ctypes.data, K["is2"].ctypes.data, len(K["sf"]), float(kf["log_scale"])
+    P = dict(bad=np.ascontiguousarray(pts["bad"], u8), wp=np.ascontiguousarray(pts["world_pos"], f32).reshape(-1, 3),
+             nr=np.ascontiguousarray(pts["normal"], f32).reshape(-1, 3), mx=np.ascontiguousarray(pts["max_dist"], f32),
+             mn=np.ascontiguousarray(pts["min_dist"], f32), d=np.ascontiguousarray(pts["mpdesc"], u8).reshape(-1, 32))
+    S = np.ascontiguousarray(Scw, f32).reshape(16)
+    mi = np.ascontiguousarray(matched_in, i32)
+    mo = np.full(max(a.n, 1), -9, i32)
+    fn = getattr(_pick(shim, perfect), ("shim_" if shim else "ref_") + "search_by_projection_kf_sim3")
+    rv = fn(C.byref(a), _p(S), len(P["bad"]), _p(P["bad"]), _p(P["wp"]), _p(P["nr"]), _p(P["mx"]), _p(P["mn"]), _p(P["d"]), _p(mi), int(th), _p(mo))
+    return mo[:a.n], rv

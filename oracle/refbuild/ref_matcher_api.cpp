@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <set>
+#include <stdexcept>
 #include <vector>
 
 #include "ORBmatcher.h" /* the reference's own header; its MapPoint.h / KeyFrame.h / Frame.h are ref_mocks.h */
@@ -322,12 +324,147 @@ int REF_NAME(search_by_projection_local_map)(const RefFrameArgs *cur, int nmp, c
     return n;
 }
 
+/* a mock KeyFrame from flat arrays (keypoints, descriptors, level tables, intrinsics, bounds; grid by the reference's own
+ * Frame::AssignFeaturesToGrid, which is what KeyFrame's constructor copies, src/KeyFrame.cc:47-55) */
+struct RefKfArgs {
+    const uint8_t *desc;
+    const float *xy;
+    const int32_t *octave;
+    const float *angle;
+    const float *uRight;
+    int n;
+    float fx, fy, cx, cy, mbf;
+    float minx, maxx, miny, maxy, gw_inv, gh_inv;
+    const float *scale_factors, *inv_sigma2;
+    int nlevels;
+    float log_scale;
+};
+static void build_keyframe(const RefKfArgs &a, KeyFrame &kf)
+{
+    kf.N = a.n;
+    kf.mDescriptors = cv::Mat(a.n, 32, CV_8UC1, (void *)a.desc);
+    kf.mvKeysUn.assign((size_t)a.n, cv::KeyPoint());
+    for (int i = 0; i < a.n; i++) {
+        kf.mvKeysUn[(size_t)i].pt = cv::Point2f(a.xy[2 * i], a.xy[2 * i + 1]);
+        kf.mvKeysUn[(size_t)i].octave = a.octave[i];
+        kf.mvKeysUn[(size_t)i].angle = a.angle ? a.angle[i] : 0.f;
+    }
+    kf.mvKeys = kf.mvKeysUn;
+    kf.mvuRight.assign((size_t)a.n, -1.f);
+    if (a.uRight) kf.mvuRight.assign(a.uRight, a.uRight + a.n);
+    kf.fx = a.fx; kf.fy = a.fy; kf.cx = a.cx; kf.cy = a.cy; kf.mbf = a.mbf;
+    kf.mnMinX = (int)a.minx; kf.mnMaxX = (int)a.maxx; kf.mnMinY = (int)a.miny; kf.mnMaxY = (int)a.maxy;
+    kf.mfGridElementWidthInv = a.gw_inv; kf.mfGridElementHeightInv = a.gh_inv;
+    kf.mnScaleLevels = a.nlevels;
+    kf.mfLogScaleFactor = a.log_scale;
+    kf.mvScaleFactors.assign(a.scale_factors, a.scale_factors + a.nlevels);
+    kf.mvInvLevelSigma2.assign(a.inv_sigma2, a.inv_sigma2 + a.nlevels);
+    kf.mvLevelSigma2.assign((size_t)a.nlevels, 1.f);
+    Frame f;
+    f.N = a.n;
+    f.mvKeysUn = kf.mvKeysUn;
+    Frame::mnMinX = a.minx; Frame::mnMinY = a.miny;
+    Frame::mfGridElementWidthInv = a.gw_inv; Frame::mfGridElementHeightInv = a.gh_inv;
+    f.AssignFeaturesToGrid();
+    kf.mGrid.resize(FRAME_GRID_COLS);
+    for (int i = 0; i < FRAME_GRID_COLS; i++) {
+        kf.mGrid[(size_t)i].resize(FRAME_GRID_ROWS);
+        for (int j = 0; j < FRAME_GRID_ROWS; j++) kf.mGrid[(size_t)i][(size_t)j] = f.mGrid[i][j];
+    }
+    kf.mvpMapPoints.assign((size_t)a.n, (MapPoint *)0);
+}
+static void fill_point(MapPoint &mp, const float *wp, const float *nr, float maxd, float mind, const uint8_t *desc, int bad, int obs)
+{
+    mp.mbBad = bad != 0;
+    mp.nObs = obs;
+    mp.world_pos = cv::Mat(3, 1, CV_32F);
+    mp.normal = cv::Mat(3, 1, CV_32F);
+    for (int k = 0; k < 3; k++) { mp.world_pos.at<float>(k) = wp[k]; mp.normal.at<float>(k) = nr ? nr[k] : 0.f; }
+    mp.mfMaxDistance = maxd;
+    mp.mfMinDistance = mind;
+    mp.mDescriptor = cv::Mat(1, 32, CV_8UC1, (void *)desc).clone();
+}
+
+/* SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
+ * src/ORBmatcher.cc:1757-1867.  The keyframe's features carry MapPoints (kf_has / bad / already found / world pos / distance
+ * range / descriptor); assigned[nC] as in the other Frame forms (index = keyframe feature). */
+int REF_NAME(search_by_projection_frame_kf)(const RefFrameArgs *cur, float log_scale, int nK, const float *angK, const uint8_t *kf_has,
+                                            const uint8_t *kf_bad, const uint8_t *kf_found, const float *world_pos,
+                                            const float *max_dist, const float *min_dist, const uint8_t *mpdesc, float th, int orbdist,
+                                            int check_ori, int32_t *assigned)
+{
+    Frame C;
+    std::vector<MapPoint> own, pool((size_t)std::max(nK, 1));
+    build_frame(*cur, C, own);
+    C.mfLogScaleFactor = log_scale;
+    KeyFrame kf;
+    kf.N = nK;
+    kf.mvKeysUn.assign((size_t)nK, cv::KeyPoint());
+    kf.mvpMapPoints.assign((size_t)nK, (MapPoint *)0);
+    std::set<MapPoint *> found;
+    for (int i = 0; i < nK; i++) {
+        kf.mvKeysUn[(size_t)i].angle = angK[i];
+        if (!kf_has[i]) continue;
+        fill_point(pool[(size_t)i], world_pos + 3 * i, 0, max_dist[i], min_dist[i], mpdesc + (size_t)i * 32, kf_bad[i], 1);
+        kf.mvpMapPoints[(size_t)i] = &pool[(size_t)i];
+        if (kf_found[i]) found.insert(&pool[(size_t)i]);
+    }
+    ORBmatcher m(0.9f, check_ori != 0);
+    int n;
+    try {
+        CallTimer tm;
+        n = m.SearchByProjection(C, &kf, found, th, orbdist);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "search_by_projection_frame_kf: %s\n", e.what());
+        return -999;
+    }
+    flatten_assigned(C, own, pool, assigned);
+    return n;
+}
+
+/* SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, th)
+ * src/ORBmatcher.cc:378-470.  matched_in[nKF]: -1 = NULL, k >= 0 = the slot already holds point k of vpPoints (so that
+ * spAlreadyFound has members), -2 = some other point.  matched_out[nKF]: the same encoding after the call. */
+int REF_NAME(search_by_projection_kf_sim3)(const RefKfArgs *kfa, const float *Scw, int np, const uint8_t *bad, const float *world_pos,
+                                           const float *normal, const float *max_dist, const float *min_dist, const uint8_t *mpdesc,
+                                           const int32_t *matched_in, int th, int32_t *matched_out)
+{
+    KeyFrame kf;
+    build_keyframe(*kfa, kf);
+    std::vector<MapPoint> pool((size_t)std::max(np, 1));
+    MapPoint other;
+    std::vector<MapPoint *> v((size_t)np);
+    for (int i = 0; i < np; i++) {
+        fill_point(pool[(size_t)i], world_pos + 3 * i, normal + 3 * i, max_dist[i], min_dist[i], mpdesc + (size_t)i * 32, bad[i], 1);
+        v[(size_t)i] = &pool[(size_t)i];
+    }
+    std::vector<MapPoint *> matched((size_t)kfa->n, (MapPoint *)0);
+    for (int i = 0; i < kfa->n; i++) matched[(size_t)i] = matched_in[i] == -1 ? (MapPoint *)0 : matched_in[i] == -2 ? &other : &pool[(size_t)matched_in[i]];
+    cv::Mat S(4, 4, CV_32F);
+    for (int k = 0; k < 16; k++) S.at<float>(k / 4, k % 4) = Scw[k];
+    ORBmatcher m(0.75f, true);
+    int n;
+    try {
+        CallTimer tm;
+        n = m.SearchByProjection(&kf, S, v, matched, th);
+    } catch (const std::exception &e) {  /* the product's shim throws on a device / argument error: report, do not abort the test run */
+        fprintf(stderr, "search_by_projection_kf_sim3: %s\n", e.what());
+        return -999;
+    }
+    for (int i = 0; i < kfa->n; i++) {
+        const MapPoint *p = matched[(size_t)i];
+        matched_out[i] = !p ? -1 : p == &other ? -2 : (int32_t)(p - pool.data());
+    }
+    return n;
+}
+
 /* Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th)  src/ORBmatcher.cc:1031-1182 on a mock KeyFrame.
  * KeyFrame: keypoints (xy, octave), mvuRight, descriptors, pose (Rcw 9, tcw 3, Ow 3), intrinsics, level tables, per-feature
  * MapPoint state kf_state (0 none, 1 good with kf_obs[i] observations, 2 bad).  MapPoints: ptr_null, bad, already in the
  * KeyFrame, world pos, normal, max / min distance, descriptor, observations.
  * Out: kf_assigned[nKF] (-1 none, -2 the KeyFrame's own point, i >= 0 fused point i), mp_replaced[nmp] (-1 not replaced,
- * -2 - j replaced by the KeyFrame's own point of feature j ... encoded as -(j + 2); k >= 0 does not occur), own_replaced[nKF]
+ * -(j + 2): replaced by the KeyFrame's own point of feature j; k >= 0: replaced by fused point k, which an earlier
+ * iteration had added to that slot), own_replaced[nKF]
  * (index of the fused point that replaced the KeyFrame's own point, -1 none). */
 int REF_NAME(fuse)(const uint8_t *descKF, const float *xyKF, const int32_t *octKF, const float *uRightKF, const uint8_t *kf_state,
                    const int32_t *kf_obs, int nKF, const float *Rcw, const float *tcw, const float *Ow, float fx, float fy, float cx,
@@ -410,7 +547,8 @@ int REF_NAME(fuse)(const uint8_t *descKF, const float *xyKF, const int32_t *octK
     }
     for (int i = 0; i < nmp; i++) {
         const MapPoint *r = pool[(size_t)i].replaced;
-        mp_replaced[i] = !r ? -1 : -(int32_t)(r - own.data()) - 2;
+        const bool in_own = r >= own.data() && r < own.data() + own.size();
+        mp_replaced[i] = !r ? -1 : in_own ? -(int32_t)(r - own.data()) - 2 : (int32_t)(r - pool.data());
     }
     return n;
 }

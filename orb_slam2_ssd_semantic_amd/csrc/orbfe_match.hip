@@ -1494,7 +1494,8 @@ extern "C" orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8
                                                    int32_t nq, int32_t th, float nnratio, int32_t ratio_rule, int32_t *match,
                                                    int32_t *best, int32_t *second)
 {
-    if (!m || nF < 0 || nq < 0 || !cell_off || (nq > 0 && (!q || !qdesc || !match)) || (nF > 0 && (!descF || !xyF || !octF || !cell_idx))) {
+    if (!m || nF < 0 || nq < 0 || !cell_off || (nq > 0 && (!q || !qdesc || !match)) || (nF > 0 && (!descF || !xyF || !octF)) ||
+        (cell_off[GRID_NC] > 0 && !cell_idx)) {   // an empty grid (no keypoint inside the image bounds) has no cell_idx
         orbfe_set_error("bad argument to orbfe_search_by_projection");
         return ORBFE_ERR_ARG;
     }

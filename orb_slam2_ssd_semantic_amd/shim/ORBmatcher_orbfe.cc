@@ -11,6 +11,9 @@
 //     int ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)                  src/ORBmatcher.cc:1578-1724
 //     (with -DORBFE_SHIM_PERFECT, for the perfect/ tree) the overload that also returns the 2-D point pairs,
 //                                                                                             perfect/src/ORBmatcher.cc:1727-1911
+//     int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, float, int) src/ORBmatcher.cc:1757-1867
+//     int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>&, int)
+//                                                                                             src/ORBmatcher.cc:378-470
 //     int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                  src/ORBmatcher.cc:1031-1182
 //       (LocalMapping::SearchInNeighbors): the candidate scans do not look at the state the loop mutates, so all gates run
 //       first, ONE orbfe_hamming_csr call gives every point's best candidate, and the Replace / AddMapPoint decisions are
@@ -32,6 +35,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -119,6 +123,29 @@ struct FrameSide {
             }
         desc = Rows(F.mDescriptors, tmp);
     }
+    // a KeyFrame as the searched side (:378-470): slots taken = vpMatched[idx] != NULL
+    FrameSide(ORB_SLAM2::KeyFrame *pKF, const std::vector<ORB_SLAM2::MapPoint *> &vpMatched)
+    {
+        const size_t n = pKF->mvKeysUn.size();
+        xy.resize(2 * n);
+        oct.resize(n);
+        blocked.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            xy[2 * i] = pKF->mvKeysUn[i].pt.x;
+            xy[2 * i + 1] = pKF->mvKeysUn[i].pt.y;
+            oct[i] = pKF->mvKeysUn[i].octave;
+            blocked[i] = vpMatched[i] != NULL;
+        }
+        cell_off.reserve(ORBFE_GRID_COLS * ORBFE_GRID_ROWS + 1);
+        cell_off.push_back(0);
+        for (int ix = 0; ix < ORBFE_GRID_COLS; ++ix)
+            for (int iy = 0; iy < ORBFE_GRID_ROWS; ++iy) {
+                const std::vector<size_t> &c = pKF->mGrid[(size_t)ix][(size_t)iy];
+                for (size_t k = 0; k < c.size(); ++k) cell_idx.push_back((uint32_t)c[k]);
+                cell_off.push_back((uint32_t)cell_idx.size());
+            }
+        desc = Rows(pKF->mDescriptors, tmp);
+    }
 };
 
 struct Queries {
@@ -126,11 +153,12 @@ struct Queries {
     std::vector<uint8_t> desc;
     std::vector<ORB_SLAM2::MapPoint *> mp;
     std::vector<int> src;  // index of the query in the caller's list
-    void Add(ORB_SLAM2::MapPoint *p, int from, float u, float v, float r, int minLevel, int maxLevel, float ur)
+    // flags < 0: the Frame overloads' rule (right-image gate on, the slot is taken iff the point has observations)
+    void Add(ORB_SLAM2::MapPoint *p, int from, float u, float v, float r, int minLevel, int maxLevel, float ur, int flags = -1)
     {
         orbfe_proj_query e;
         e.u = u; e.v = v; e.r = r; e.min_level = minLevel; e.max_level = maxLevel; e.ur = ur;
-        e.flags = ORBFE_PROJ_RIGHT_GATE | (p->Observations() > 0 ? ORBFE_PROJ_CLAIMS : 0);
+        e.flags = flags >= 0 ? flags : (ORBFE_PROJ_RIGHT_GATE | (p->Observations() > 0 ? ORBFE_PROJ_CLAIMS : 0));
         e.pad = 0;
         q.push_back(e);
         const cv::Mat d = p->GetDescriptor();
@@ -140,11 +168,14 @@ struct Queries {
     }
 };
 
-void RunSearch(ORB_SLAM2::Frame &F, const Queries &qs, int th, float nnratio, int ratio_rule, std::vector<int32_t> &match)
+void RunSearch(ORB_SLAM2::Frame &F, const Queries &qs, int th, float nnratio, int ratio_rule, std::vector<int32_t> &match,
+               bool any_point_blocks = false)
 {
     match.assign(qs.q.size(), -1);
     if (qs.q.empty() || F.N == 0) return;
     FrameSide fs(F);
+    if (any_point_blocks)  // :1812 `if(CurrentFrame.mvpMapPoints[i2]) continue;`
+        for (int i = 0; i < F.N; ++i) fs.blocked[(size_t)i] = F.mvpMapPoints[(size_t)i] != NULL;
     const orbfe_status s = orbfe_search_by_projection(
         t_matcher.get(), fs.desc, fs.xy.data(), fs.oct.data(), F.N, fs.cell_off.data(), fs.cell_idx.data(), ORB_SLAM2::Frame::mnMinX,
         ORB_SLAM2::Frame::mnMinY, ORB_SLAM2::Frame::mfGridElementWidthInv, ORB_SLAM2::Frame::mfGridElementHeightInv,
@@ -180,6 +211,127 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
     for (size_t k = 0; k < match.size(); ++k)
         if (match[k] >= 0) {  // :150-151
             F.mvpMapPoints[(size_t)match[k]] = qs.mp[k];
+            nmatches++;
+        }
+    return nmatches;
+}
+
+// src/ORBmatcher.cc:1757-1867 (Tracking::Relocalization): the keyframe's MapPoints projected into the current frame; a slot of
+// the frame is taken by ANY MapPoint (:1812), the rotation histogram uses the keyframe's keypoint angles
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th,
+                                   const int ORBdist)
+{
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat Ow = -Rcw.t() * tcw;
+    const float factor = 1.0f / HISTO_LENGTH;
+    const std::vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
+    Queries qs;
+    for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
+        MapPoint *pMP = vpMPs[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;  // :1778
+        cv::Mat x3Dw = pMP->GetWorldPos();
+        cv::Mat x3Dc = Rcw * x3Dw + tcw;
+        const float xc = x3Dc.at<float>(0);
+        const float yc = x3Dc.at<float>(1);
+        const float invzc = 1.0 / x3Dc.at<float>(2);
+        const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+        const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+        cv::Mat PO = x3Dw - Ow;
+        float dist3D = cv::norm(PO);
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;  // :1799
+        int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+        const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
+        qs.Add(pMP, (int)i, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, 0.f, ORBFE_PROJ_CLAIMS);  // :1806
+    }
+    std::vector<int32_t> match;
+    RunSearch(CurrentFrame, qs, ORBdist, 0.f, 0, match, /*any_point_blocks*/ true);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for (size_t k = 0; k < match.size(); ++k) {
+        if (match[k] < 0) continue;
+        const int bestIdx2 = match[k], i = qs.src[k];
+        CurrentFrame.mvpMapPoints[bestIdx2] = qs.mp[k];  // :1826
+        nmatches++;
+        if (mbCheckOrientation) {
+            float rot = pKF->mvKeysUn[i].angle - CurrentFrame.mvKeysUn[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back(bestIdx2);
+        }
+    }
+    if (mbCheckOrientation) {  // :1846-1863
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                    CurrentFrame.mvpMapPoints[rotHist[i][j]] = NULL;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}
+
+// src/ORBmatcher.cc:378-470 (LoopClosing::ComputeSim3 / SearchAndFuse): map points projected into a keyframe with a Sim3
+int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched,
+                                   int th)
+{
+    const float &fx = pKF->fx;
+    const float &fy = pKF->fy;
+    const float &cx = pKF->cx;
+    const float &cy = pKF->cy;
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    std::set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());  // :393, not updated by the loop
+    spAlreadyFound.erase(static_cast<MapPoint *>(NULL));
+    Queries qs;
+    for (int iMP = 0, iendMP = (int)vpPoints.size(); iMP < iendMP; iMP++) {
+        MapPoint *pMP = vpPoints[iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0) continue;
+        const float invz = 1 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz;
+        const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist = cv::norm(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist) continue;
+        int nPredictedLevel = pMP->PredictScale(dist, pKF);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        // :434 KeyFrame::GetFeaturesInArea(u, v, radius) + the level test of :447-448 inside the candidate loop
+        qs.Add(pMP, iMP, u, v, radius, nPredictedLevel - 1, nPredictedLevel, 0.f, ORBFE_PROJ_CLAIMS);
+    }
+    std::vector<int32_t> match(qs.q.size(), -1);
+    if (!qs.q.empty() && !pKF->mvKeysUn.empty()) {
+        FrameSide fs(pKF, vpMatched);
+        const orbfe_status s = orbfe_search_by_projection(
+            t_matcher.get(), fs.desc, fs.xy.data(), fs.oct.data(), (int32_t)pKF->mvKeysUn.size(), fs.cell_off.data(), fs.cell_idx.data(),
+            (float)pKF->mnMinX, (float)pKF->mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv, NULL, fs.blocked.data(),
+            qs.q.data(), qs.desc.data(), (int32_t)qs.q.size(), TH_LOW, 0.f, 0, match.data(), NULL, NULL);
+        if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbfe): ") + orbfe_last_error());
+    }
+    int nmatches = 0;
+    for (size_t k = 0; k < match.size(); ++k)
+        if (match[k] >= 0) {  // :463-464
+            vpMatched[(size_t)match[k]] = qs.mp[k];
             nmatches++;
         }
     return nmatches;

@@ -229,3 +229,52 @@ def fuse_case(rng, nKF, nmp):
                min_dist=mind, mpdesc=noisy_copy(rng, cur["desc"][tgt] if nKF else np.zeros((nmp, 32), np.uint8), 60),
                obs=rng.integers(0, 6, nmp).astype(np.int32))
     return kf, mps
+
+
+def frame_kf_case(rng, nC, nK):
+    """(cur, kfp) for SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (Tracking::Relocalization): the
+    keyframe's MapPoints project near features of the current frame at a distance consistent with their octave"""
+    cur = current_frame(rng, nC, stereo=False)
+    fx, fy, cx, cy, mbf, mb = cur["K"]
+    T = _pose(rng, 4.0, rng.normal(0, 0.15, 3))
+    cur["Tcw"] = T
+    Rcw, tcw = T[:3, :3].astype(np.float64), T[:3, 3].astype(np.float64)
+    Ow = -(Rcw.T @ tcw)
+    tgt = rng.integers(0, max(nC, 1), nK) if nC else np.zeros(nK, np.int64)
+    if nK > 8 and nC:
+        tgt[: nK // 5] = tgt[rng.integers(0, nK, nK // 5)]
+    z = rng.uniform(0.5, 8.0, nK)
+    px = (cur["xy"][tgt] if nC else np.zeros((nK, 2))) + rng.normal(0, 2.0, (nK, 2))
+    if nK > 12:
+        px[rng.integers(0, nK, 3)] += 900
+    Xc = np.stack([(px[:, 0] - cx) / fx * z, (px[:, 1] - cy) / fy * z, z], 1)
+    world = ((Xc - tcw) @ Rcw).astype(np.float32)
+    d3 = np.linalg.norm(world.astype(np.float64) - Ow, axis=1)
+    lvl = (cur["octave"][tgt] if nC else np.zeros(nK)).astype(np.float64) + rng.choice([-1, 0, 0, 1], nK)
+    maxd = (d3 * 1.2 ** np.clip(lvl, 0, 7) * rng.uniform(0.93, 0.999, nK)).astype(np.float32)
+    if nK > 12:
+        maxd[rng.integers(0, nK, 3)] *= 0.3
+    kfp = dict(angle=((cur["angle"][tgt] if nC else np.zeros(nK)) + rng.choice([0, 0, 0, 35, 120], nK) + rng.normal(0, 4, nK)).astype(np.float32) % np.float32(360),
+               has=(rng.random(nK) < 0.85).astype(np.uint8), bad=(rng.random(nK) < 0.05).astype(np.uint8),
+               found=(rng.random(nK) < 0.1).astype(np.uint8), world_pos=world, max_dist=maxd, min_dist=(maxd / 1.2 ** 7).astype(np.float32),
+               mpdesc=noisy_copy(rng, cur["desc"][tgt] if nC else np.zeros((nK, 32), np.uint8), 70))
+    return cur, kfp
+
+
+def kf_sim3_case(rng, nKF, npts):
+    """(kf, Scw, pts, matched_in) for SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (LoopClosing)"""
+    kf, mps = fuse_case(rng, nKF, npts)
+    s = float(rng.uniform(0.9, 1.1))
+    Scw = np.eye(4, dtype=np.float32)
+    Scw[:3, :3] = (s * kf["Rcw"].astype(np.float64)).astype(np.float32)
+    Scw[:3, 3] = (s * kf["tcw"].astype(np.float64)).astype(np.float32)
+    pts = dict(bad=mps["bad"], world_pos=mps["world_pos"], normal=mps["normal"], max_dist=mps["max_dist"], min_dist=mps["min_dist"],
+               mpdesc=mps["mpdesc"])
+    matched = np.full(nKF, -1, np.int32)
+    if nKF > 4:
+        k = max(1, nKF // 10)
+        matched[rng.choice(nKF, k, replace=False)] = -2
+        if npts > 4:
+            sl = rng.choice(nKF, max(1, nKF // 20), replace=False)
+            matched[sl] = rng.integers(0, npts, len(sl))
+    return kf, Scw, pts, matched

@@ -177,3 +177,29 @@ def test_shim_fuse_equals_reference_body():
         assert s[3] == r[3] and all(np.array_equal(a, b) for a, b in zip(s[:3], r[:3])), (seed, nKF, nmp, r[3], s[3])
         fused += r[3]
     assert fused > 2000
+
+
+@needs_shim
+@pytest.mark.gpu
+def test_shim_keyframe_side_search_by_projection_equals_reference_bodies():
+    """The two remaining SearchByProjection overloads through the reference's class: (Frame&, KeyFrame*, sAlreadyFound, th,
+    ORBdist) (src/ORBmatcher.cc:1757-1867, Tracking::Relocalization: any MapPoint takes a slot, rotation histogram on the
+    keyframe's angles) and (KeyFrame*, Scw, vpPoints, vpMatched, th) (:378-470, LoopClosing: a Sim3-projected search on a
+    KeyFrame's grid) -- both on the same device core as the per-frame forms."""
+    n1 = n2 = 0
+    for seed in range(60):
+        rng = np.random.default_rng(19_000 + seed)
+        nC, nK = int(rng.choice([1, 30, 300, 1000])), int(rng.choice([1, 40, 400, 1000]))
+        cur, kfp = PC.frame_kf_case(rng, nC, nK)
+        th, od, ori = float(rng.choice([10, 3, 15])), int(rng.choice([100, 64])), bool(seed % 4)
+        ra, rn = R.search_by_projection_frame_kf(cur, kfp, th, od, ori)
+        sa, sn = R.search_by_projection_frame_kf(cur, kfp, th, od, ori, shim=True)
+        assert sn == rn and np.array_equal(sa, ra), ("frame/kf", seed, nC, nK, rn, sn)
+        n1 += rn
+        kf, Scw, pts, mi = PC.kf_sim3_case(rng, nC, nK + 100)
+        th2 = int(rng.choice([10, 4]))
+        rm, rn2 = R.search_by_projection_kf_sim3(kf, Scw, pts, mi, th2)
+        sm, sn2 = R.search_by_projection_kf_sim3(kf, Scw, pts, mi, th2, shim=True)
+        assert sn2 == rn2 and np.array_equal(sm, rm), ("kf/sim3", seed, nC, nK, rn2, sn2)
+        n2 += rn2
+    assert n1 > 1000 and n2 > 1000
