@@ -336,6 +336,23 @@ orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8_t *descF, 
                                         const uint8_t *qdesc /* nq x 32 */, int32_t nq, int32_t th, float nnratio,
                                         int32_t ratio_rule, int32_t *match, int32_t *best, int32_t *second);
 
+/* the matching core of ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:827-1012,
+ * LocalMapping::CreateNewMapPoints).  For every feature of keyframe 1 with elig1 (no MapPoint; stereo if bOnlyStereo) whose
+ * vocabulary node also exists in keyframe 2: over that node's keyframe-2 features in FeatureVector order, the ones with elig2
+ * (no MapPoint; stereo if bOnlyStereo -- the reference's loop never sets vbMatched2, so the keyframe-1 features are
+ * independent), dist <= th_low, dist <= bestDist, farther than the epipole gate ((ex - x)^2 + (ey - y)^2 >= 100 * scale[octave],
+ * applied only when both keypoints are monocular, :900-907) and inside CheckDistEpipolarLine (:175-196: F12 row-major,
+ * dsqr < 3.84 * mvLevelSigma2[octave], the reference's float operation order) take over the best: the smallest distance, the
+ * LAST in order on ties.  match12[n1] = keyframe-2 feature or -1; the caller applies its rotation histogram (:966-985) and
+ * builds vMatchedPairs.  FeatureVectors as CSR (ascending node ids); HOST buffers. */
+orbfe_status orbfe_search_for_triangulation(orbfe_matcher *m, const uint8_t *desc1, const float *xy1, const uint8_t *elig1,
+                                            const uint8_t *stereo1, int32_t n1, const uint32_t *node1, const uint32_t *off1,
+                                            const uint32_t *idx1, int32_t nn1, const uint8_t *desc2, const float *xy2,
+                                            const int32_t *oct2, const uint8_t *elig2, const uint8_t *stereo2, int32_t n2,
+                                            const uint32_t *node2, const uint32_t *off2, const uint32_t *idx2, int32_t nn2,
+                                            const float F12[9], float ex, float ey, const float *scale_factors2,
+                                            const float *level_sigma2_2, int32_t nlevels2, int32_t th_low, int32_t *match12);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:642-846): row-band descriptor search in the right image,
  * 11 x 11 SAD refinement over 11 shifts on the two extractors' device-resident pyramids (mvImagePyramid of the LAST
  * call of `left` / `right`, frame 0), parabola fit, disparity -> depth, and the median-based outlier rejection.

@@ -94,6 +94,7 @@ def lib():
     L.orc_search_by_projection.argtypes = [vp, vp, vp, ci, vp, vp, cf, cf, cf, cf, vp, vp, vp, vp, ci, ci, cf, ci, vp, vp, vp]
     L.orc_proj_queries_last_frame.argtypes = [vp, vp] + [cf] * 10 + [vp, ci, vp, vp, vp, vp, vp, cf, ci, ci, vp, vp]
     L.orc_proj_queries_local_map.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp]
+    L.orc_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, cf, cf, vp, vp, ci, vp]
     _lib = L
     return L
 
@@ -499,3 +500,23 @@ def proj_queries_local_map(scale_factors, in_view, bad, scale_level, view_cos, p
     rc = lib().orc_proj_queries_local_map(_p(sf), n, _p(iv), _p(bd), _p(sl), _p(vc), _p(pr), _p(og), float(th), _p(q), _p(valid))
     assert rc == 0
     return q, valid
+
+
+def search_for_triangulation(k1, k2, F12, ex, ey, th_low=50):
+    """orc_search_for_triangulation: k1 = dict(desc, xy, elig, stereo, fv=(node, off, idx)), k2 = the same + octave,
+    scale_factors, level_sigma2.  Returns match12[n1]."""
+    u8, f32, i32, u32 = np.uint8, np.float32, np.int32, np.uint32
+    a = [np.ascontiguousarray(k1["desc"], u8).reshape(-1, 32), np.ascontiguousarray(k1["xy"], f32).reshape(-1, 2),
+         np.ascontiguousarray(k1["elig"], u8), np.ascontiguousarray(k1["stereo"], u8)]
+    fv1 = [np.ascontiguousarray(x, u32) for x in k1["fv"]]
+    b = [np.ascontiguousarray(k2["desc"], u8).reshape(-1, 32), np.ascontiguousarray(k2["xy"], f32).reshape(-1, 2),
+         np.ascontiguousarray(k2["octave"], i32), np.ascontiguousarray(k2["elig"], u8), np.ascontiguousarray(k2["stereo"], u8)]
+    fv2 = [np.ascontiguousarray(x, u32) for x in k2["fv"]]
+    F = np.ascontiguousarray(F12, f32).reshape(9)
+    sf, s2 = np.ascontiguousarray(k2["scale_factors"], f32), np.ascontiguousarray(k2["level_sigma2"], f32)
+    m = np.full(max(len(a[0]), 1), -1, i32)
+    rc = lib().orc_search_for_triangulation(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), len(a[0]), _p(fv1[0]), _p(fv1[1]), _p(fv1[2]), len(fv1[0]),
+                                            _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]), _p(b[4]), len(b[0]), _p(fv2[0]), _p(fv2[1]), _p(fv2[2]),
+                                            len(fv2[0]), _p(F), float(ex), float(ey), _p(sf), _p(s2), int(th_low), _p(m))
+    assert rc == 0
+    return m[:len(a[0])]

@@ -1297,6 +1297,64 @@ int orc_proj_queries_local_map(const float *scale_factors, int nmp, const uint8_
     return 0;
 }
 
+/* ---- M4: SearchForTriangulation (src/ORBmatcher.cc:827-1012) ---- */
+static int check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float F[9], float sigma2)
+{
+    /* :175-196, F12.at<float>(r, c) = F[3r + c] */
+    const float a = x1 * F[0] + y1 * F[3] + F[6];
+    const float b = x1 * F[1] + y1 * F[4] + F[7];
+    const float c = x1 * F[2] + y1 * F[5] + F[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return (double)dsqr < 3.84 * (double)sigma2;
+}
+
+int orc_search_for_triangulation(const uint8_t *desc1, const float *xy1, const uint8_t *elig1, const uint8_t *stereo1, int n1,
+                                 const uint32_t *node1, const uint32_t *off1, const uint32_t *idx1, int nn1,
+                                 const uint8_t *desc2, const float *xy2, const int32_t *oct2, const uint8_t *elig2,
+                                 const uint8_t *stereo2, int n2, const uint32_t *node2, const uint32_t *off2,
+                                 const uint32_t *idx2, int nn2, const float F12[9], float ex, float ey,
+                                 const float *scale_factors2, const float *level_sigma2_2, int th_low, int32_t *match12)
+{
+    (void)n2;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) { /* :849-964: merge walk over the two std::maps */
+        if (node1[a] == node2[b]) {
+            for (uint32_t i1 = off1[a]; i1 < off1[a + 1]; i1++) {
+                const uint32_t f1 = idx1[i1];
+                if (!elig1[f1]) continue; /* :860-868 */
+                const int bStereo1 = stereo1[f1];
+                int bestDist = th_low, bestIdx2 = -1;
+                for (uint32_t i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                    const uint32_t f2 = idx2[i2];
+                    if (!elig2[f2]) continue; /* :881-889 */
+                    const int dist = orc_hamming(desc1 + (size_t)f1 * 32, desc2 + (size_t)f2 * 32);
+                    if (dist > th_low || dist > bestDist) continue; /* :895 */
+                    if (!bStereo1 && !stereo2[f2]) { /* :900-907 */
+                        const float distex = ex - xy2[2 * f2], distey = ey - xy2[2 * f2 + 1];
+                        if (distex * distex + distey * distey < 100 * scale_factors2[oct2[f2]]) continue;
+                    }
+                    if (check_dist_epipolar_line(xy1[2 * f1], xy1[2 * f1 + 1], xy2[2 * f2], xy2[2 * f2 + 1], F12, level_sigma2_2[oct2[f2]])) {
+                        bestIdx2 = (int)f2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) match12[f1] = bestIdx2;
+            }
+            a++;
+            b++;
+        } else if (node1[a] < node2[b]) {
+            while (a < nn1 && node1[a] < node2[b]) a++; /* lower_bound */
+        } else {
+            while (b < nn2 && node2[b] < node1[a]) b++;
+        }
+    }
+    return 0;
+}
+
 /* ---- 8(f).4: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) ---- */
 static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
 

@@ -204,6 +204,20 @@ int orc_proj_queries_local_map(const float *scale_factors, int nmp, const uint8_
                                const int32_t *scale_level, const float *view_cos, const float *proj_xyr /* nmp x 3 */,
                                const uint8_t *mp_obs_gt0, float th, orc_proj_query *q, uint8_t *valid);
 
+/* ---- M4: SearchForTriangulation (src/ORBmatcher.cc:827-1012), the matching core ----
+ * For every feature idx1 of keyframe 1 that is eligible (no MapPoint, stereo if bOnlyStereo) and whose vocabulary node also
+ * exists in keyframe 2: over that node's features of keyframe 2, in FeatureVector order, the eligible ones (elig2: no MapPoint,
+ * stereo if bOnlyStereo -- vbMatched2 is never set by the reference's loop) with dist <= TH_LOW and dist <= bestDist that lie
+ * farther than the epipole gate (:906-911, only when both keypoints are monocular) and pass CheckDistEpipolarLine (:175-196)
+ * take over best (so: the smallest distance, LAST in order on ties).  match12[n1] = idx2 or -1, before the rotation check.
+ * node1 / off1 / idx1, node2 / off2 / idx2: the two FeatureVectors as CSR (ascending node ids). */
+int orc_search_for_triangulation(const uint8_t *desc1, const float *xy1, const uint8_t *elig1, const uint8_t *stereo1, int n1,
+                                 const uint32_t *node1, const uint32_t *off1, const uint32_t *idx1, int nn1,
+                                 const uint8_t *desc2, const float *xy2, const int32_t *oct2, const uint8_t *elig2,
+                                 const uint8_t *stereo2, int n2, const uint32_t *node2, const uint32_t *off2,
+                                 const uint32_t *idx2, int nn2, const float F12[9], float ex, float ey,
+                                 const float *scale_factors2, const float *level_sigma2_2, int th_low, int32_t *match12);
+
 /* ---- 8(f).4: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345) for a batch of map points ----
  * point p observes descriptors pool[idx[off[p] .. off[p+1])]; best_idx[p] = position (inside the point's list) of the
  * descriptor with the least median distance to the others (first on ties), median[p] that median; -1 / -1 if empty. */

@@ -155,6 +155,7 @@ def _declare_projection(L, prefix):
     getattr(L, prefix + "last_call_ms").restype = C.c_double
     getattr(L, prefix + "search_by_projection_frame_kf").argtypes = [vp, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
     getattr(L, prefix + "search_by_projection_kf_sim3").argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+    getattr(L, prefix + "search_for_triangulation").argtypes = [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, ci, vp]
     getattr(L, prefix + "fuse").argtypes = ([vp] * 6 + [ci, vp, vp, vp] + [cf] * 11 + [vp, vp, ci, cf, ci] + [vp] * 9 + [cf, vp, vp, vp])
 
 
@@ -644,3 +645,42 @@ def search_by_projection_kf_sim3(kf, Scw, pts, matched_in, th, shim=False, perfe
     fn = getattr(_pick(shim, perfect), ("shim_" if shim else "ref_") + "search_by_projection_kf_sim3")
     rv = fn(C.byref(a), _p(S), len(P["bad"]), _p(P["bad"]), _p(P["wp"]), _p(P["nr"]), _p(P["mx"]), _p(P["mn"]), _p(P["d"]), _p(mi), int(th), _p(mo))
     return mo[:a.n], rv
+
+
+def _kf_args(kf, keep):
+    f32, i32, u8 = np.float32, np.int32, np.uint8
+    K = dict(desc=np.ascontiguousarray(kf["desc"], u8).reshape(-1, 32), xy=np.ascontiguousarray(kf["xy"], f32).reshape(-1, 2),
+             octave=np.ascontiguousarray(kf["octave"], i32), angle=np.ascontiguousarray(kf["angle"], f32),
+             uRight=np.ascontiguousarray(kf["uRight"], f32), sf=np.ascontiguousarray(kf["scale_factors"], f32),
+             is2=np.ascontiguousarray(kf["inv_sigma2"], f32))
+    keep.append(K)
+    a = RefKfArgs()
+    a.desc, a.xy, a.octave, a.angle, a.uRight = (K[k].ctypes.data for k in ("desc", "xy", "octave", "angle", "uRight"))
+    a.n = len(K["desc"])
+    a.fx, a.fy, a.cx, a.cy, a.mbf = [float(v) for v in kf["K"][:5]]
+    a.minx, a.maxx, a.miny, a.maxy = [float(v) for v in kf["bounds"]]
+    a.gw_inv, a.gh_inv = float(kf["gw_inv"]), float(kf["gh_inv"])
+    a.scale_factors, a.inv_sigma2, a.nlevels, a.log_scale = K["sf"].ctypes.data, K["is2"].ctypes.data, len(K["sf"]), float(kf["log_scale"])
+    return a
+
+
+def search_for_triangulation(k1, k2, F12, only_stereo, check_ori=True, shim=False, perfect=False):
+    """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:827-1012) on two mock KeyFrames.  k1 / k2: keyframe dicts as
+    fuse() takes them + angle, has_mp, fv = (node, off, idx); k1["Ow"], k2["Rcw"], k2["tcw"], k2["level_sigma2"].
+    Returns (pairs[n, 2], return value)."""
+    keep = []
+    a, b = _kf_args(k1, keep), _kf_args(k2, keep)
+    u8, u32, f32 = np.uint8, np.uint32, np.float32
+    h1, h2 = np.ascontiguousarray(k1["has_mp"], u8), np.ascontiguousarray(k2["has_mp"], u8)
+    fv1 = [np.ascontiguousarray(x, u32) for x in k1["fv"]]
+    fv2 = [np.ascontiguousarray(x, u32) for x in k2["fv"]]
+    Ow, Rcw, tcw = (np.ascontiguousarray(x, f32).reshape(-1) for x in (k1["Ow"], k2["Rcw"], k2["tcw"]))
+    ls2 = np.ascontiguousarray(k2["level_sigma2"], f32)
+    F = np.ascontiguousarray(F12, f32).reshape(9)
+    cap = max(a.n, 1)
+    pairs = np.full((cap, 2), -1, np.int32)
+    npairs = C.c_int32(0)
+    fn = getattr(_pick(shim, perfect), ("shim_" if shim else "ref_") + "search_for_triangulation")
+    rv = fn(C.byref(a), _p(h1), _p(fv1[0]), _p(fv1[1]), _p(fv1[2]), len(fv1[0]), _p(Ow), C.byref(b), _p(h2), _p(fv2[0]), _p(fv2[1]), _p(fv2[2]),
+            len(fv2[0]), _p(Rcw), _p(tcw), _p(ls2), _p(F), int(only_stereo), int(check_ori), _p(pairs), cap, C.byref(npairs))
+    return pairs[:npairs.value].copy(), rv

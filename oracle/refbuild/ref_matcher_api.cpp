@@ -458,6 +458,51 @@ int REF_NAME(search_by_projection_kf_sim3)(const RefKfArgs *kfa, const float *Sc
     return n;
 }
 
+/* SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)  src/ORBmatcher.cc:827-1012 on two mock KeyFrames.
+ * has_mp1 / has_mp2: the feature already has a MapPoint; fv: FeatureVector CSR; pairs[2 * cap] out, returns the count (the
+ * reference's return value; *npairs = vMatchedPairs.size()). */
+int REF_NAME(search_for_triangulation)(const RefKfArgs *k1, const uint8_t *has_mp1, const uint32_t *node1, const uint32_t *off1,
+                                       const uint32_t *idx1, int nn1, const float *Ow1, const RefKfArgs *k2, const uint8_t *has_mp2,
+                                       const uint32_t *node2, const uint32_t *off2, const uint32_t *idx2, int nn2, const float *Rcw2,
+                                       const float *tcw2, const float *level_sigma2_2, const float *F12, int only_stereo, int check_ori,
+                                       int32_t *pairs, int cap, int32_t *npairs)
+{
+    KeyFrame a, b;
+    build_keyframe(*k1, a);
+    build_keyframe(*k2, b);
+    b.mvLevelSigma2.assign(level_sigma2_2, level_sigma2_2 + k2->nlevels);
+    fill_featvec(a.mFeatVec, node1, off1, idx1, nn1);
+    fill_featvec(b.mFeatVec, node2, off2, idx2, nn2);
+    std::vector<MapPoint> p1((size_t)std::max(k1->n, 1)), p2((size_t)std::max(k2->n, 1));
+    for (int i = 0; i < k1->n; i++)
+        if (has_mp1[i]) a.mvpMapPoints[(size_t)i] = &p1[(size_t)i];
+    for (int i = 0; i < k2->n; i++)
+        if (has_mp2[i]) b.mvpMapPoints[(size_t)i] = &p2[(size_t)i];
+    a.Ow = cv::Mat(3, 1, CV_32F);
+    b.Rcw = cv::Mat(3, 3, CV_32F);
+    b.tcw = cv::Mat(3, 1, CV_32F);
+    for (int k = 0; k < 3; k++) { a.Ow.at<float>(k) = Ow1[k]; b.tcw.at<float>(k) = tcw2[k]; }
+    for (int k = 0; k < 9; k++) b.Rcw.at<float>(k / 3, k % 3) = Rcw2[k];
+    cv::Mat F(3, 3, CV_32F);
+    for (int k = 0; k < 9; k++) F.at<float>(k / 3, k % 3) = F12[k];
+    ORBmatcher m(0.6f, check_ori != 0);
+    std::vector<std::pair<size_t, size_t> > out;
+    int n;
+    try {
+        CallTimer tm;
+        n = m.SearchForTriangulation(&a, &b, F, out, only_stereo != 0);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "search_for_triangulation: %s\n", e.what());
+        return -999;
+    }
+    *npairs = (int32_t)out.size();
+    for (size_t k = 0; k < out.size() && (int)k < cap; k++) {
+        pairs[2 * k] = (int32_t)out[k].first;
+        pairs[2 * k + 1] = (int32_t)out[k].second;
+    }
+    return n;
+}
+
 /* Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th)  src/ORBmatcher.cc:1031-1182 on a mock KeyFrame.
  * KeyFrame: keypoints (xy, octave), mvuRight, descriptors, pose (Rcw 9, tcw 3, Ow 3), intrinsics, level tables, per-feature
  * MapPoint state kf_state (0 none, 1 good with kf_obs[i] observations, 2 bad).  MapPoints: ptr_null, bad, already in the

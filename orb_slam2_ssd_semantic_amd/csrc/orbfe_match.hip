@@ -1579,6 +1579,151 @@ extern "C" orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:827-1012, LocalMapping::CreateNewMapPoints), the
+// matching core.  The reference's loop never sets vbMatched2, so the features of keyframe 1 are independent: one thread per
+// keyframe-1 feature scans its vocabulary node's features of keyframe 2 in FeatureVector order -- Hamming first, then the
+// epipole gate and CheckDistEpipolarLine (:175-196) in the reference's float operation order -- and keeps the smallest
+// distance, the LAST in order on ties (`dist > bestDist` skips, an equal distance takes over).
+// ---------------------------------------------------------------------------------------------------
+struct TriArgs {
+    const uint8_t *desc1, *desc2;
+    const float *xy1, *xy2;
+    const int32_t *oct2;
+    const uint8_t *elig1, *stereo1, *elig2, *stereo2;
+    const int32_t *range1;      // [n1][2]: the node's slice of idx2 for every keyframe-1 feature, (0, 0) = none
+    const uint32_t *idx2;
+    float F[9], ex, ey;
+    const float *scale2, *sigma2_2;
+    int32_t n1, th_low;
+    int32_t *match12;
+};
+
+__global__ __launch_bounds__(256) void k_triangulation(TriArgs a)
+{
+    const int f1 = blockIdx.x * 256 + threadIdx.x;
+    if (f1 >= a.n1) return;
+    int best = -1;
+    const int lo = a.range1[2 * f1], hi = a.range1[2 * f1 + 1];
+    if (hi > lo && a.elig1[f1]) {
+        Desc8 d1;
+        const uint32_t *p = (const uint32_t *)(a.desc1 + (int64_t)f1 * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d1.w[k] = p[k];
+        const bool st1 = a.stereo1[f1] != 0;
+        const float x1 = a.xy1[2 * f1], y1 = a.xy1[2 * f1 + 1];
+        // :175-182: a = kp1.x * F(0,0) + kp1.y * F(1,0) + F(2,0), every operation rounded separately
+        const float ea = __fadd_rn(__fadd_rn(__fmul_rn(x1, a.F[0]), __fmul_rn(y1, a.F[3])), a.F[6]);
+        const float eb = __fadd_rn(__fadd_rn(__fmul_rn(x1, a.F[1]), __fmul_rn(y1, a.F[4])), a.F[7]);
+        const float ec = __fadd_rn(__fadd_rn(__fmul_rn(x1, a.F[2]), __fmul_rn(y1, a.F[5])), a.F[8]);
+        const float den = __fadd_rn(__fmul_rn(ea, ea), __fmul_rn(eb, eb));
+        int bestDist = a.th_low;
+        for (int i2 = lo; i2 < hi; ++i2) {
+            const uint32_t f2 = a.idx2[i2];
+            if (!a.elig2[f2]) continue;
+            const int dist = hamming8(d1, (const uint32_t *)(a.desc2 + (int64_t)f2 * 32));
+            if (dist > a.th_low || dist > bestDist) continue;   // :895
+            const float x2 = a.xy2[2 * f2], y2 = a.xy2[2 * f2 + 1];
+            const int o2 = a.oct2[f2];
+            if (!st1 && !a.stereo2[f2]) {                         // :900-907
+                const float dx = __fsub_rn(a.ex, x2), dy = __fsub_rn(a.ey, y2);
+                if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, a.scale2[o2])) continue;
+            }
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(ea, x2), __fmul_rn(eb, y2)), ec);
+            if (den == 0.f) continue;
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if ((double)dsqr < __dmul_rn(3.84, (double)a.sigma2_2[o2])) {   // :195
+                best = (int)f2;
+                bestDist = dist;
+            }
+        }
+    }
+    a.match12[f1] = best;
+}
+
+extern "C" orbfe_status orbfe_search_for_triangulation(orbfe_matcher *m, const uint8_t *desc1, const float *xy1, const uint8_t *elig1,
+                                                       const uint8_t *stereo1, int32_t n1, const uint32_t *node1, const uint32_t *off1,
+                                                       const uint32_t *idx1, int32_t nn1, const uint8_t *desc2, const float *xy2,
+                                                       const int32_t *oct2, const uint8_t *elig2, const uint8_t *stereo2, int32_t n2,
+                                                       const uint32_t *node2, const uint32_t *off2, const uint32_t *idx2, int32_t nn2,
+                                                       const float F12[9], float ex, float ey, const float *scale_factors2,
+                                                       const float *level_sigma2_2, int32_t nlevels2, int32_t th_low, int32_t *match12)
+{
+    if (!m || n1 < 0 || n2 < 0 || nn1 < 0 || nn2 < 0 || nlevels2 < 1 || !F12 || !scale_factors2 || !level_sigma2_2 ||
+        (n1 > 0 && (!desc1 || !xy1 || !elig1 || !stereo1 || !match12)) || (n2 > 0 && (!desc2 || !xy2 || !oct2 || !elig2 || !stereo2)) ||
+        (nn1 > 0 && (!node1 || !off1 || !idx1)) || (nn2 > 0 && (!node2 || !off2 || !idx2))) {
+        orbfe_set_error("bad argument to orbfe_search_for_triangulation");
+        return ORBFE_ERR_ARG;
+    }
+    if (n1 == 0) return ORBFE_OK;
+    for (int i = 0; i < n2; ++i)
+        if (oct2[i] < 0 || oct2[i] >= nlevels2) { orbfe_set_error("keyframe-2 octave out of range"); return ORBFE_ERR_ARG; }
+    // the merge walk over the two FeatureVectors (:849-964) on the host: every keyframe-1 feature learns its node's slice of idx2
+    std::vector<int32_t> range((size_t)n1 * 2, 0);
+    const uint32_t total2 = nn2 > 0 ? off2[nn2] : 0;
+    for (uint32_t k = 0; k < total2; ++k)
+        if (idx2[k] >= (uint32_t)n2) { orbfe_set_error("FeatureVector 2 index out of range"); return ORBFE_ERR_ARG; }
+    {
+        int a = 0, b = 0;
+        while (a < nn1 && b < nn2) {
+            if (node1[a] == node2[b]) {
+                for (uint32_t k = off1[a]; k < off1[a + 1]; ++k) {
+                    if (idx1[k] >= (uint32_t)n1) { orbfe_set_error("FeatureVector 1 index out of range"); return ORBFE_ERR_ARG; }
+                    range[2 * (size_t)idx1[k]] = (int32_t)off2[b];
+                    range[2 * (size_t)idx1[k] + 1] = (int32_t)off2[b + 1];
+                }
+                ++a;
+                ++b;
+            } else if (node1[a] < node2[b]) ++a;
+            else ++b;
+        }
+    }
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));
+    const size_t sz[11] = {(size_t)n1 * 32, (size_t)n1 * 8, (size_t)n1, (size_t)n1, (size_t)n1 * 8, (size_t)n2 * 32, (size_t)n2 * 8, (size_t)n2 * 4,
+                           (size_t)n2, (size_t)n2, (size_t)total2 * 4};
+    const void *src[11] = {desc1, xy1, elig1, stereo1, range.data(), desc2, xy2, oct2, elig2, stereo2, idx2};
+    size_t at[13];
+    at[0] = 0;
+    for (int i = 0; i < 11; ++i) at[i + 1] = (at[i] + sz[i] + 255) & ~(size_t)255;
+    at[12] = at[11] + (((size_t)nlevels2 * 8 + 255) & ~(size_t)255);
+    ORBFE_HIP(m->pin_in.ensure(at[12]));
+    ORBFE_HIP(m->pin_out.ensure((size_t)n1 * 4));
+    ORBFE_HIP(m->b[0].ensure(at[12]));
+    ORBFE_HIP(m->b[1].ensure((size_t)n1 * 4));
+    for (int i = 0; i < 11; ++i)
+        if (sz[i]) memcpy((char *)m->pin_in.p + at[i], src[i], sz[i]);
+    memcpy((char *)m->pin_in.p + at[11], scale_factors2, (size_t)nlevels2 * 4);
+    memcpy((char *)m->pin_in.p + at[11] + (size_t)nlevels2 * 4, level_sigma2_2, (size_t)nlevels2 * 4);
+    ORBFE_HIP(hipMemcpyAsync(m->b[0].p, m->pin_in.p, at[12], hipMemcpyHostToDevice, st));
+    const char *d = (const char *)m->b[0].p;
+    TriArgs a;
+    a.desc1 = (const uint8_t *)(d + at[0]);
+    a.xy1 = (const float *)(d + at[1]);
+    a.elig1 = (const uint8_t *)(d + at[2]);
+    a.stereo1 = (const uint8_t *)(d + at[3]);
+    a.range1 = (const int32_t *)(d + at[4]);
+    a.desc2 = (const uint8_t *)(d + at[5]);
+    a.xy2 = (const float *)(d + at[6]);
+    a.oct2 = (const int32_t *)(d + at[7]);
+    a.elig2 = (const uint8_t *)(d + at[8]);
+    a.stereo2 = (const uint8_t *)(d + at[9]);
+    a.idx2 = (const uint32_t *)(d + at[10]);
+    a.scale2 = (const float *)(d + at[11]);
+    a.sigma2_2 = a.scale2 + nlevels2;
+    for (int k = 0; k < 9; ++k) a.F[k] = F12[k];
+    a.ex = ex; a.ey = ey;
+    a.n1 = n1; a.th_low = th_low;
+    a.match12 = (int32_t *)m->b[1].p;
+    hipLaunchKernelGGL(k_triangulation, dim3((n1 + 255) / 256), dim3(256), 0, st, a);
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpyAsync(m->pin_out.p, m->b[1].p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    memcpy(match12, m->pin_out.p, (size_t)n1 * 4);
+    return ORBFE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // SURVEY 8(f).4  MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:284-345), batched over map points.
 // One wave per map point: its observed descriptors are staged in LDS, lane i owns row i of the distance matrix and
 // finds that row's median -- element (int)(0.5 * (N - 1)) of the sorted row, self distance 0 included (:332-334) --

@@ -163,6 +163,26 @@ class ORBmatcher:
                    "orbfe_search_by_projection")
         return m, b, s2
 
+    def SearchForTriangulationCore(self, k1, k2, F12, ex, ey, th_low=50):
+        """orbfe_search_for_triangulation (src/ORBmatcher.cc:827-1012): k1 = dict(desc, xy, elig, stereo, fv=(node, off, idx)),
+        k2 = the same + octave, scale_factors, level_sigma2.  Returns match12[n1] (before the rotation check)."""
+        u8, f32, i32, u32 = np.uint8, np.float32, np.int32, np.uint32
+        a = [np.ascontiguousarray(k1["desc"], u8).reshape(-1, 32), np.ascontiguousarray(k1["xy"], f32).reshape(-1, 2),
+             np.ascontiguousarray(k1["elig"], u8), np.ascontiguousarray(k1["stereo"], u8)]
+        fv1 = [np.ascontiguousarray(x, u32) for x in k1["fv"]]
+        b = [np.ascontiguousarray(k2["desc"], u8).reshape(-1, 32), np.ascontiguousarray(k2["xy"], f32).reshape(-1, 2),
+             np.ascontiguousarray(k2["octave"], i32), np.ascontiguousarray(k2["elig"], u8), np.ascontiguousarray(k2["stereo"], u8)]
+        fv2 = [np.ascontiguousarray(x, u32) for x in k2["fv"]]
+        F = np.ascontiguousarray(F12, f32).reshape(9)
+        sf, s2 = np.ascontiguousarray(k2["scale_factors"], f32), np.ascontiguousarray(k2["level_sigma2"], f32)
+        m = np.full(max(len(a[0]), 1), -1, i32)
+        _ffi.check(_ffi.lib().orbfe_search_for_triangulation(
+            self.handle, _ffi.ptr(a[0]), _ffi.ptr(a[1]), _ffi.ptr(a[2]), _ffi.ptr(a[3]), len(a[0]), _ffi.ptr(fv1[0]), _ffi.ptr(fv1[1]),
+            _ffi.ptr(fv1[2]), len(fv1[0]), _ffi.ptr(b[0]), _ffi.ptr(b[1]), _ffi.ptr(b[2]), _ffi.ptr(b[3]), _ffi.ptr(b[4]), len(b[0]),
+            _ffi.ptr(fv2[0]), _ffi.ptr(fv2[1]), _ffi.ptr(fv2[2]), len(fv2[0]), _ffi.ptr(F), float(ex), float(ey), _ffi.ptr(sf), _ffi.ptr(s2),
+            len(sf), int(th_low), _ffi.ptr(m)), "orbfe_search_for_triangulation")
+        return m[:len(a[0])]
+
     def ComputeStereoMatches(self, extractorLeft, extractorRight, keysL, descL, keysR, descR, mbf, mb):
         """SURVEY 8(f).2: Frame::ComputeStereoMatches (src/Frame.cc:642-846).  The two ORBextractor mirrors must have
         just processed the left / right image (their device-resident pyramids are read).  Returns (mvuRight, mvDepth)."""

@@ -14,6 +14,8 @@
 //     int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, float, int) src/ORBmatcher.cc:1757-1867
 //     int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>&, int)
 //                                                                                             src/ORBmatcher.cc:378-470
+//     int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool)
+//                                                                                             src/ORBmatcher.cc:827-1012
 //     int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                  src/ORBmatcher.cc:1031-1182
 //       (LocalMapping::SearchInNeighbors): the candidate scans do not look at the state the loop mutates, so all gates run
 //       first, ONE orbfe_hamming_csr call gives every point's best candidate, and the Replace / AddMapPoint decisions are
@@ -38,6 +40,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <ORBmatcher.h>  // the reference's own header, found on the include path (NOT the stand-alone template form next to this file)
@@ -425,6 +428,88 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
                            [this](std::vector<int> *h, int &a, int &b, int &c) { ComputeThreeMaxima(h, HISTO_LENGTH, a, b, c); });
 }
 #endif
+
+// src/ORBmatcher.cc:827-1012 (LocalMapping::CreateNewMapPoints, once per neighbour keyframe): Hamming + epipolar gate of every
+// unmatched keyframe-1 feature against its vocabulary node's keyframe-2 features in ONE orbfe_search_for_triangulation call;
+// the epipole, the eligibility flags and the rotation histogram stay here
+int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> > &vMatchedPairs,
+                                       const bool bOnlyStereo)
+{
+    // :833-843 the epipole of keyframe 1 in keyframe 2
+    cv::Mat Cw = pKF1->GetCameraCenter();
+    cv::Mat R2w = pKF2->GetRotation();
+    cv::Mat t2w = pKF2->GetTranslation();
+    cv::Mat C2 = R2w * Cw + t2w;
+    const float invz = 1.0f / C2.at<float>(2);
+    const float ex = pKF2->fx * C2.at<float>(0) * invz + pKF2->cx;
+    const float ey = pKF2->fy * C2.at<float>(1) * invz + pKF2->cy;
+    const int n1 = pKF1->N, n2 = pKF2->N;
+    std::vector<int> vMatches12((size_t)n1, -1);
+    int nmatches = 0;
+    if (n1 > 0 && n2 > 0) {
+        std::vector<float> xy1((size_t)n1 * 2), xy2((size_t)n2 * 2);
+        std::vector<int32_t> oct2((size_t)n2);
+        std::vector<uint8_t> e1((size_t)n1), s1((size_t)n1), e2((size_t)n2), s2((size_t)n2), t1, t2;
+        for (int i = 0; i < n1; ++i) {
+            xy1[2 * (size_t)i] = pKF1->mvKeysUn[(size_t)i].pt.x;
+            xy1[2 * (size_t)i + 1] = pKF1->mvKeysUn[(size_t)i].pt.y;
+            s1[(size_t)i] = pKF1->mvuRight[(size_t)i] >= 0;                                   // :866
+            e1[(size_t)i] = !pKF1->GetMapPoint((size_t)i) && (!bOnlyStereo || s1[(size_t)i]);  // :860-870
+        }
+        for (int i = 0; i < n2; ++i) {
+            xy2[2 * (size_t)i] = pKF2->mvKeysUn[(size_t)i].pt.x;
+            xy2[2 * (size_t)i + 1] = pKF2->mvKeysUn[(size_t)i].pt.y;
+            oct2[(size_t)i] = pKF2->mvKeysUn[(size_t)i].octave;
+            s2[(size_t)i] = pKF2->mvuRight[(size_t)i] >= 0;                                   // :887
+            e2[(size_t)i] = !pKF2->GetMapPoint((size_t)i) && (!bOnlyStereo || s2[(size_t)i]);  // :881-891 (vbMatched2 is never set)
+        }
+        Csr c1, c2;
+        Flatten(pKF1->mFeatVec, c1);
+        Flatten(pKF2->mFeatVec, c2);
+        float F[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) F[3 * r + c] = F12.at<float>(r, c);
+        std::vector<int32_t> m12((size_t)n1, -1);
+        const orbfe_status st = orbfe_search_for_triangulation(
+            t_matcher.get(), Rows(pKF1->mDescriptors, t1), xy1.data(), e1.data(), s1.data(), n1, c1.node.data(), c1.off.data(), c1.idx.data(),
+            (int)c1.node.size(), Rows(pKF2->mDescriptors, t2), xy2.data(), oct2.data(), e2.data(), s2.data(), n2, c2.node.data(),
+            c2.off.data(), c2.idx.data(), (int)c2.node.size(), F, ex, ey, pKF2->mvScaleFactors.data(), pKF2->mvLevelSigma2.data(),
+            (int)pKF2->mvScaleFactors.size(), TH_LOW, m12.data());
+        if (st != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchForTriangulation (orbfe): ") + orbfe_last_error());
+        std::vector<int> rotHist[HISTO_LENGTH];
+        const float factor = 1.0f / HISTO_LENGTH;
+        for (int i = 0; i < n1; ++i) {
+            if (m12[(size_t)i] < 0) continue;
+            vMatches12[(size_t)i] = m12[(size_t)i];  // :917-918
+            nmatches++;
+            if (mbCheckOrientation) {
+                float rot = pKF1->mvKeysUn[(size_t)i].angle - pKF2->mvKeysUn[(size_t)m12[(size_t)i]].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(i);
+            }
+        }
+        if (mbCheckOrientation) {  // :966-985
+            int ind1 = -1, ind2 = -1, ind3 = -1;
+            ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                if (i == ind1 || i == ind2 || i == ind3) continue;
+                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                    vMatches12[(size_t)rotHist[i][j]] = -1;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    vMatchedPairs.clear();  // :987-997
+    vMatchedPairs.reserve((size_t)std::max(nmatches, 0));
+    for (size_t i = 0, iend = vMatches12.size(); i < iend; i++) {
+        if (vMatches12[i] < 0) continue;
+        vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
+    }
+    return nmatches;
+}
 
 // src/ORBmatcher.cc:1031-1182
 int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th)

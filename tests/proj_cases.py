@@ -278,3 +278,102 @@ def kf_sim3_case(rng, nKF, npts):
             sl = rng.choice(nKF, max(1, nKF // 20), replace=False)
             matched[sl] = rng.integers(0, npts, len(sl))
     return kf, Scw, pts, matched
+
+
+def _fv_csr(nodes_of_feature, present):
+    """FeatureVector of a keyframe as CSR: ascending node ids, features of a node in ascending index (DBoW2's insertion order)"""
+    ids = sorted(set(int(v) for v, p in zip(nodes_of_feature, present) if p))
+    node, off, idx = [], [0], []
+    for nid in ids:
+        node.append(nid)
+        idx += [i for i in range(len(nodes_of_feature)) if present[i] and nodes_of_feature[i] == nid]
+        off.append(len(idx))
+    return np.array(node, np.uint32), np.array(off, np.uint32), np.array(idx, np.uint32)
+
+
+def triangulation_case(rng, n1, n2, nnodes):
+    """(k1, k2, F12) for ORBmatcher::SearchForTriangulation: two keyframes of one scene with a known relative pose (F12 as
+    LocalMapping::ComputeF12 builds it), shared points with noisy descriptors in a common vocabulary node, keypoint noise
+    small or large against the epipolar gate, distractors, stereo / monocular keypoints, features that already have MapPoints"""
+    w, h = 640, 480
+    fx, fy, cx, cy, mbf = 535.4, 539.2, 320.1, 247.6, 40.0
+    sf = scale_factors()
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    T1 = _pose(rng, 3.0, rng.normal(0, 0.1, 3)).astype(np.float64)
+    T2 = T1.copy()
+    T2[:3, :3] = _rot(rng, 4.0) @ T1[:3, :3]
+    T2[:3, 3] = T1[:3, 3] + np.array([rng.choice([-1, 1]) * rng.uniform(0.1, 0.4), rng.normal(0, 0.05), rng.normal(0, 0.05)])
+    R1, t1, R2, t2 = T1[:3, :3], T1[:3, 3], T2[:3, :3], T2[:3, 3]
+    R12 = R1 @ R2.T
+    t12 = -R12 @ t2 + t1
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    F12 = (np.linalg.inv(K).T @ tx @ R12 @ np.linalg.inv(K)).astype(np.float32)
+    npts = max(n1, n2)
+    # world points in front of camera 1
+    z = rng.uniform(1.0, 8.0, npts)
+    p1 = np.stack([rng.uniform(20, w - 20, npts), rng.uniform(20, h - 20, npts)], 1)
+    Xc1 = np.stack([(p1[:, 0] - cx) / fx * z, (p1[:, 1] - cy) / fy * z, z], 1)
+    Xw = (Xc1 - t1) @ R1
+    Xc2 = Xw @ R2.T + t2
+    p2 = np.stack([fx * Xc2[:, 0] / Xc2[:, 2] + cx, fy * Xc2[:, 1] / Xc2[:, 2] + cy], 1)
+    base = rng.integers(0, 256, (npts, 32), dtype=np.uint8)
+    pnode = rng.integers(0, max(nnodes, 1), npts)
+
+    def side(n, pts, other):
+        sel = rng.permutation(npts)[:n]   # which scene points this keyframe sees
+        noise = np.where(rng.random(n)[:, None] < 0.8, rng.normal(0, 0.6, (n, 2)), rng.normal(0, 6.0, (n, 2)))
+        xy = (pts[sel] + noise).astype(np.float32)
+        octave = rng.integers(0, 8, n).astype(np.int32)
+        nodes = np.where(rng.random(n) < 0.9, pnode[sel], rng.integers(0, max(nnodes, 1), n))
+        present = rng.random(n) < 0.95
+        uR = np.where(rng.random(n) < 0.5, xy[:, 0] - rng.uniform(2, 40, n), -1).astype(np.float32)
+        return dict(desc=noisy_copy(rng, base[sel], 45), xy=xy, octave=octave, angle=(rng.choice([10.0, 10.0, 10.0, 200.0], n) + rng.normal(0, 5, n)).astype(np.float32) % np.float32(360),
+                    uRight=uR, has_mp=(rng.random(n) < 0.3).astype(np.uint8), fv=_fv_csr(nodes, present), K=(fx, fy, cx, cy, mbf),
+                    bounds=(0.0, float(w), 0.0, float(h)), gw_inv=np.float32(GRID_COLS) / np.float32(w), gh_inv=np.float32(GRID_ROWS) / np.float32(h),
+                    scale_factors=sf, inv_sigma2=(1.0 / (sf * sf)).astype(np.float32), level_sigma2=(sf * sf).astype(np.float32),
+                    log_scale=np.float32(np.log(np.float32(1.2))))
+    k1, k2 = side(n1, p1, None), side(n2, p2, None)
+    k1["Ow"] = (-(R1.T @ t1)).astype(np.float32)
+    k2["Rcw"], k2["tcw"] = R2.astype(np.float32), t2.astype(np.float32)
+    return k1, k2, F12
+
+
+def tri_core_inputs(k1, k2, only_stereo):
+    """the arrays of orbfe_search_for_triangulation / orc_search_for_triangulation from two keyframe dicts, as the shim builds them"""
+    def prep(k):
+        st = (np.asarray(k["uRight"]) >= 0).astype(np.uint8)
+        el = ((np.asarray(k["has_mp"]) == 0) & ((st == 1) | (not only_stereo))).astype(np.uint8)
+        return dict(desc=k["desc"], xy=k["xy"], elig=el, stereo=st, fv=k["fv"], octave=k["octave"], scale_factors=k["scale_factors"],
+                    level_sigma2=k["level_sigma2"])
+    # the epipole of keyframe 1 in keyframe 2 (:833-843), float operation order of the reference on the stub's cv::Mat
+    f32 = np.float32
+    R, t, C = np.asarray(k2["Rcw"], f32).reshape(3, 3), np.asarray(k2["tcw"], f32), np.asarray(k1["Ow"], f32)
+    C2 = np.zeros(3, f32)
+    for y in range(3):
+        s = f32(0)
+        for k in range(3):
+            s = f32(s + f32(R[y, k] * C[k]))
+        C2[y] = f32(s + t[y])
+    fx, fy, cx, cy = [f32(v) for v in k2["K"][:4]]
+    invz = f32(f32(1.0) / C2[2])
+    ex = f32(f32(f32(fx * C2[0]) * invz) + cx)
+    ey = f32(f32(f32(fy * C2[1]) * invz) + cy)
+    return prep(k1), prep(k2), ex, ey
+
+
+def replay_triangulation(k1, k2, m12, check_ori=True):
+    """rotation histogram (:919-985) and vMatchedPairs (:987-997) from the core's match12"""
+    m = np.array(m12, np.int32).copy()
+    nm = int((m >= 0).sum())
+    if check_ori:
+        hist = [[] for _ in range(30)]
+        for i in np.nonzero(m >= 0)[0]:
+            hist[O.rot_bin(float(k1["angle"][i]), float(k2["angle"][m[i]]))].append(i)
+        keep = O.three_maxima([len(b) for b in hist])
+        for b in range(30):
+            if b not in keep:
+                for i in hist[b]:
+                    m[i] = -1
+                    nm -= 1
+    pairs = np.array([(i, m[i]) for i in range(len(m)) if m[i] >= 0], np.int32).reshape(-1, 2)
+    return pairs, nm

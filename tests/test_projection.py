@@ -203,3 +203,38 @@ def test_shim_keyframe_side_search_by_projection_equals_reference_bodies():
         assert sn2 == rn2 and np.array_equal(sm, rm), ("kf/sim3", seed, nC, nK, rn2, sn2)
         n2 += rn2
     assert n1 > 1000 and n2 > 1000
+
+
+@pytest.mark.gpu
+def test_triangulation_core_equals_oracle(mat):
+    """orbfe_search_for_triangulation (HIP: one thread per keyframe-1 feature, Hamming + epipolar gate in the reference's float
+    operation order) == the oracle's loop, match12 element by element"""
+    tot = 0
+    for seed in range(80):
+        rng = np.random.default_rng(23_000 + seed)
+        n1, n2 = int(rng.choice([1, 30, 300, 1000, 2000])), int(rng.choice([1, 40, 400, 1000, 2000]))
+        k1, k2, F = PC.triangulation_case(rng, n1, n2, int(rng.choice([1, 10, 100, 400])))
+        a, b, ex, ey = PC.tri_core_inputs(k1, k2, seed % 3 == 0)
+        om = O.search_for_triangulation(a, b, F, ex, ey, 50)
+        gm = mat.SearchForTriangulationCore(a, b, F, ex, ey, 50)
+        assert np.array_equal(gm, om), (seed, n1, n2, np.nonzero(gm != om)[0][:5])
+        tot += int((om >= 0).sum())
+    assert tot > 3000
+
+
+@needs_shim
+@pytest.mark.gpu
+def test_shim_search_for_triangulation_equals_reference_body():
+    """ORBmatcher::SearchForTriangulation through the reference's class: shim (epipole and flags on the host, ONE device call,
+    rotation histogram replayed) == the reference's compiled body: vMatchedPairs and the return value"""
+    tot = 0
+    for seed in range(60):
+        rng = np.random.default_rng(25_000 + seed)
+        n1, n2 = int(rng.choice([1, 30, 300, 1000])), int(rng.choice([1, 40, 400, 1000]))
+        k1, k2, F = PC.triangulation_case(rng, n1, n2, int(rng.choice([1, 10, 100])))
+        only, ori = seed % 3 == 0, bool(seed % 4)
+        rp, rn = R.search_for_triangulation(k1, k2, F, only, ori)
+        sp, sn = R.search_for_triangulation(k1, k2, F, only, ori, shim=True)
+        assert sn == rn and np.array_equal(sp, rp), (seed, n1, n2, rn, sn)
+        tot += rn
+    assert tot > 800

@@ -475,3 +475,23 @@ def test_perfect_search_by_projection_with_point_pairs_equals_oracle(ref, oracle
         am, nm = ref.search_by_projection_local_map(cur2, mps, 3.0, 0.8, perfect=True)
         om, onm = PC.oracle_local_map(cur2, mps, 3.0, 0.8)[:2]
         assert nm == onm and np.array_equal(am, om), seed
+
+
+def test_search_for_triangulation_equals_reference(ref, oracle):
+    """SearchForTriangulation (src/ORBmatcher.cc:827-1012, LocalMapping::CreateNewMapPoints): oracle core
+    (orc_search_for_triangulation: vocabulary-node merge walk, Hamming, epipole gate, CheckDistEpipolarLine :175-196, last
+    smallest distance) + rotation histogram == the reference's compiled body on two mock KeyFrames with a consistent F12 --
+    vMatchedPairs pair by pair and the return value; bOnlyStereo on / off, rotation check on / off."""
+    import proj_cases as PC
+    total = 0
+    for seed in range(120):
+        rng = np.random.default_rng(21_000 + seed)
+        n1, n2 = int(rng.choice([1, 30, 300, 1000])), int(rng.choice([1, 40, 400, 1000]))
+        k1, k2, F = PC.triangulation_case(rng, n1, n2, int(rng.choice([1, 10, 100])))
+        only, ori = seed % 3 == 0, bool(seed % 4)
+        rp, rn = ref.search_for_triangulation(k1, k2, F, only, ori)
+        a, b, ex, ey = PC.tri_core_inputs(k1, k2, only)
+        op, on = PC.replay_triangulation(k1, k2, oracle.search_for_triangulation(a, b, F, ex, ey, 50), ori)
+        assert rn == on and np.array_equal(rp, op), (seed, n1, n2, rn, on)
+        total += rn
+    assert total > 2500
