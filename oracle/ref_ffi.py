@@ -156,6 +156,7 @@ def _declare_projection(L, prefix):
     getattr(L, prefix + "search_by_projection_frame_kf").argtypes = [vp, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
     getattr(L, prefix + "search_by_projection_kf_sim3").argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp]
     getattr(L, prefix + "search_for_triangulation").argtypes = [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, ci, vp]
+    getattr(L, prefix + "fuse_sim3").argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp]
     getattr(L, prefix + "fuse").argtypes = ([vp] * 6 + [ci, vp, vp, vp] + [cf] * 11 + [vp, vp, ci, cf, ci] + [vp] * 9 + [cf, vp, vp, vp])
 
 
@@ -684,3 +685,25 @@ def search_for_triangulation(k1, k2, F12, only_stereo, check_ori=True, shim=Fals
     rv = fn(C.byref(a), _p(h1), _p(fv1[0]), _p(fv1[1]), _p(fv1[2]), len(fv1[0]), _p(Ow), C.byref(b), _p(h2), _p(fv2[0]), _p(fv2[1]), _p(fv2[2]),
             len(fv2[0]), _p(Rcw), _p(tcw), _p(ls2), _p(F), int(only_stereo), int(check_ori), _p(pairs), cap, C.byref(npairs))
     return pairs[:npairs.value].copy(), rv
+
+
+def fuse_sim3(kf, Scw, mps, th, shim=False, perfect=False):
+    """ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, th, vector<MapPoint*> &vpReplacePoint)
+    (src/ORBmatcher.cc:1198-1299).  kf / mps as fuse().  Returns (kf_assigned[nKF], replace_point[np], return value)."""
+    keep = []
+    kk = dict(kf)
+    kk.setdefault("angle", np.zeros(len(np.asarray(kf["octave"])), np.float32))
+    a = _kf_args(kk, keep)
+    f32, u8 = np.float32, np.uint8
+    st = np.ascontiguousarray(kf["state"], u8)
+    M = dict(null=np.ascontiguousarray(mps["null"], u8), bad=np.ascontiguousarray(mps["bad"], u8),
+             wp=np.ascontiguousarray(mps["world_pos"], f32).reshape(-1, 3), nr=np.ascontiguousarray(mps["normal"], f32).reshape(-1, 3),
+             mx=np.ascontiguousarray(mps["max_dist"], f32), mn=np.ascontiguousarray(mps["min_dist"], f32),
+             d=np.ascontiguousarray(mps["mpdesc"], u8).reshape(-1, 32))
+    S = np.ascontiguousarray(Scw, f32).reshape(16)
+    n = len(M["null"])
+    ka, rp = np.full(max(a.n, 1), -9, np.int32), np.full(max(n, 1), -9, np.int32)
+    fn = getattr(_pick(shim, perfect), ("shim_" if shim else "ref_") + "fuse_sim3")
+    rv = fn(C.byref(a), _p(st), _p(S), n, _p(M["null"]), _p(M["bad"]), _p(M["wp"]), _p(M["nr"]), _p(M["mx"]), _p(M["mn"]), _p(M["d"]), float(th),
+            _p(ka), _p(rp))
+    return ka[:a.n], rp[:n], rv

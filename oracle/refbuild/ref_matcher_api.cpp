@@ -503,6 +503,50 @@ int REF_NAME(search_for_triangulation)(const RefKfArgs *k1, const uint8_t *has_m
     return n;
 }
 
+/* Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, th, vector<MapPoint*> &vpReplacePoint)
+ * src/ORBmatcher.cc:1198-1299.  kf_state as for fuse (0 none, 1 good, 2 bad).  Out: kf_assigned[nKF] (-1 none, -2 own point,
+ * i >= 0 fused point i), replace_point[np] (-1 NULL, j >= 0 the KeyFrame's own point of feature j, -(k + 2) fused point k that an
+ * earlier iteration had added). */
+int REF_NAME(fuse_sim3)(const RefKfArgs *kfa, const uint8_t *kf_state, const float *Scw, int np, const uint8_t *null_, const uint8_t *bad,
+                        const float *world_pos, const float *normal, const float *max_dist, const float *min_dist,
+                        const uint8_t *mpdesc, float th, int32_t *kf_assigned, int32_t *replace_point)
+{
+    KeyFrame kf;
+    build_keyframe(*kfa, kf);
+    std::vector<MapPoint> own((size_t)std::max(kfa->n, 1)), pool((size_t)std::max(np, 1));
+    for (int i = 0; i < kfa->n; i++)
+        if (kf_state[i]) {
+            own[(size_t)i].mbBad = kf_state[i] == 2;
+            kf.mvpMapPoints[(size_t)i] = &own[(size_t)i];
+        }
+    std::vector<MapPoint *> v((size_t)np, (MapPoint *)0), rep((size_t)np, (MapPoint *)0);
+    for (int i = 0; i < np; i++) {
+        if (null_[i]) continue;
+        fill_point(pool[(size_t)i], world_pos + 3 * i, normal + 3 * i, max_dist[i], min_dist[i], mpdesc + (size_t)i * 32, bad[i], 1);
+        v[(size_t)i] = &pool[(size_t)i];
+    }
+    cv::Mat S(4, 4, CV_32F);
+    for (int k = 0; k < 16; k++) S.at<float>(k / 4, k % 4) = Scw[k];
+    ORBmatcher m(0.8f, true);
+    int n;
+    try {
+        CallTimer tm;
+        n = m.Fuse(&kf, S, v, th, rep);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "fuse_sim3: %s\n", e.what());
+        return -999;
+    }
+    for (int i = 0; i < kfa->n; i++) {
+        const MapPoint *p = kf.mvpMapPoints[(size_t)i];
+        kf_assigned[i] = !p ? -1 : (p >= own.data() && p < own.data() + own.size()) ? -2 : (int32_t)(p - pool.data());
+    }
+    for (int i = 0; i < np; i++) {
+        const MapPoint *r = rep[(size_t)i];
+        replace_point[i] = !r ? -1 : (r >= own.data() && r < own.data() + own.size()) ? (int32_t)(r - own.data()) : -(int32_t)(r - pool.data()) - 2;
+    }
+    return n;
+}
+
 /* Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th)  src/ORBmatcher.cc:1031-1182 on a mock KeyFrame.
  * KeyFrame: keypoints (xy, octave), mvuRight, descriptors, pose (Rcw 9, tcw 3, Ow 3), intrinsics, level tables, per-feature
  * MapPoint state kf_state (0 none, 1 good with kf_obs[i] observations, 2 bad).  MapPoints: ptr_null, bad, already in the

@@ -17,6 +17,7 @@
 //     int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool)
 //                                                                                             src/ORBmatcher.cc:827-1012
 //     int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                  src/ORBmatcher.cc:1031-1182
+//     int ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, float, vector<MapPoint*>&) src/ORBmatcher.cc:1198-1299
 //       (LocalMapping::SearchInNeighbors): the candidate scans do not look at the state the loop mutates, so all gates run
 //       first, ONE orbfe_hamming_csr call gives every point's best candidate, and the Replace / AddMapPoint decisions are
 //       replayed in order on the live objects
@@ -606,6 +607,88 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, 
                     if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
                     else pMPinKF->Replace(pMP);
                 }
+            } else {
+                pMP->AddObservation(pKF, (size_t)bestIdx[(size_t)k]);
+                pKF->AddMapPoint(pMP, (size_t)bestIdx[(size_t)k]);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
+}
+
+// src/ORBmatcher.cc:1198-1299 (LoopClosing::SearchAndFuse): the Sim3 form -- no stereo gate, a hit on an occupied slot is
+// reported in vpReplacePoint instead of replaced; the same two phases as the plain Fuse
+int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint)
+{
+    const float &fx = pKF->fx;
+    const float &fy = pKF->fy;
+    const float &cx = pKF->cx;
+    const float &cy = pKF->cy;
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();  // :1212, fixed for the whole loop
+    const int nPoints = (int)vpPoints.size();
+    std::vector<uint32_t> off(1, 0), cand;
+    std::vector<uint8_t> qdesc;
+    std::vector<int> slot((size_t)nPoints, -1);
+    for (int iMP = 0; iMP < nPoints; iMP++) {
+        MapPoint *pMP = vpPoints[iMP];
+        if (!pMP) continue;
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;  // :1224 (neither changes inside the loop)
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0f) continue;
+        const float invz = 1.0 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz;
+        const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist3D = cv::norm(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) continue;
+        int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        const std::vector<size_t> vIndices = pKF->GetFeaturesInArea(u, v, radius);
+        if (vIndices.empty()) continue;
+        const size_t before = cand.size();
+        for (std::vector<size_t>::const_iterator vit = vIndices.begin(); vit != vIndices.end(); vit++) {
+            const size_t idx = *vit;
+            const int &kpLevel = pKF->mvKeysUn[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;  // :1268
+            cand.push_back((uint32_t)idx);
+        }
+        if (cand.size() == before) continue;
+        slot[(size_t)iMP] = (int)off.size() - 1;
+        off.push_back((uint32_t)cand.size());
+        const cv::Mat dMP = pMP->GetDescriptor();
+        qdesc.insert(qdesc.end(), dMP.ptr<uint8_t>(0), dMP.ptr<uint8_t>(0) + 32);
+    }
+    const int nq = (int)off.size() - 1;
+    std::vector<int32_t> bestIdx((size_t)std::max(nq, 1), -1), best((size_t)std::max(nq, 1), 256), second((size_t)std::max(nq, 1), 256);
+    if (nq > 0) {
+        std::vector<uint8_t> tmp;
+        const orbfe_status s = orbfe_hamming_csr(t_matcher.get(), qdesc.data(), nq, Rows(pKF->mDescriptors, tmp), pKF->mDescriptors.rows,
+                                                 off.data(), cand.data(), bestIdx.data(), best.data(), second.data());
+        if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::Fuse (orbfe): ") + orbfe_last_error());
+    }
+    int nFused = 0;
+    for (int iMP = 0; iMP < nPoints; iMP++) {  // :1282-1296 on the live objects, in order
+        if (slot[(size_t)iMP] < 0) continue;
+        const int k = slot[(size_t)iMP];
+        if (best[(size_t)k] <= TH_LOW) {
+            MapPoint *pMP = vpPoints[iMP];
+            MapPoint *pMPinKF = pKF->GetMapPoint((size_t)bestIdx[(size_t)k]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) vpReplacePoint[(size_t)iMP] = pMPinKF;
             } else {
                 pMP->AddObservation(pKF, (size_t)bestIdx[(size_t)k]);
                 pKF->AddMapPoint(pMP, (size_t)bestIdx[(size_t)k]);

@@ -238,3 +238,22 @@ def test_shim_search_for_triangulation_equals_reference_body():
         assert sn == rn and np.array_equal(sp, rp), (seed, n1, n2, rn, sn)
         tot += rn
     assert tot > 800
+
+
+@needs_shim
+@pytest.mark.gpu
+def test_shim_fuse_sim3_equals_reference_body():
+    """ORBmatcher::Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:1198-1299, LoopClosing::SearchAndFuse)
+    through the reference's class: the keyframe's MapPoint per feature, vpReplacePoint entry by entry, the count"""
+    fused = 0
+    for seed in range(60):
+        rng = np.random.default_rng(27_000 + seed)
+        nKF, nmp = int(rng.choice([1, 30, 300, 1000])), int(rng.choice([1, 40, 400, 1500]))
+        kf, Scw, pts, _ = PC.kf_sim3_case(rng, nKF, nmp)
+        mps = dict(pts, null=(rng.random(nmp) < 0.03).astype(np.uint8))
+        th = float(rng.choice([4.0, 10.0]))
+        r = R.fuse_sim3(kf, Scw, mps, th)
+        s = R.fuse_sim3(kf, Scw, mps, th, shim=True)
+        assert s[2] == r[2] and np.array_equal(s[0], r[0]) and np.array_equal(s[1], r[1]), (seed, nKF, nmp, r[2], s[2])
+        fused += r[2]
+    assert fused > 1500
