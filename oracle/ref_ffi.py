@@ -156,6 +156,7 @@ def _declare_projection(L, prefix):
     getattr(L, prefix + "search_by_projection_frame_kf").argtypes = [vp, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
     getattr(L, prefix + "search_by_projection_kf_sim3").argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp]
     getattr(L, prefix + "search_for_triangulation").argtypes = [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, ci, vp]
+    getattr(L, prefix + "search_by_sim3").argtypes = [vp, vp, vp, vp, cf, vp, vp, cf, vp]
     getattr(L, prefix + "fuse_sim3").argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp]
     getattr(L, prefix + "fuse").argtypes = ([vp] * 6 + [ci, vp, vp, vp] + [cf] * 11 + [vp, vp, ci, cf, ci] + [vp] * 9 + [cf, vp, vp, vp])
 
@@ -707,3 +708,40 @@ def fuse_sim3(kf, Scw, mps, th, shim=False, perfect=False):
     rv = fn(C.byref(a), _p(st), _p(S), n, _p(M["null"]), _p(M["bad"]), _p(M["wp"]), _p(M["nr"]), _p(M["mx"]), _p(M["mn"]), _p(M["d"]), float(th),
             _p(ka), _p(rp))
     return ka[:a.n], rp[:n], rv
+
+
+class RefKfPoints(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("world_pos", C.c_void_p), ("max_dist", C.c_void_p), ("min_dist", C.c_void_p),
+                ("mpdesc", C.c_void_p), ("Rcw", C.c_void_p), ("tcw", C.c_void_p)]
+
+
+def _kf_points(kf, keep):
+    f32, u8 = np.float32, np.uint8
+    K = dict(state=np.ascontiguousarray(kf["state"], u8), wp=np.ascontiguousarray(kf["world_pos"], f32).reshape(-1, 3),
+             mx=np.ascontiguousarray(kf["max_dist"], f32), mn=np.ascontiguousarray(kf["min_dist"], f32),
+             d=np.ascontiguousarray(kf["mpdesc"], u8).reshape(-1, 32), R=np.ascontiguousarray(kf["Rcw"], f32).reshape(9),
+             t=np.ascontiguousarray(kf["tcw"], f32).reshape(3))
+    keep.append(K)
+    p = RefKfPoints()
+    p.state, p.world_pos, p.max_dist, p.min_dist, p.mpdesc, p.Rcw, p.tcw = (K[k].ctypes.data for k in ("state", "wp", "mx", "mn", "d", "R", "t"))
+    return p
+
+
+def search_by_sim3(k1, k2, s12, R12, t12, th, matches_in, shim=False, perfect=False):
+    """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1334-1548) on two mock KeyFrames.  k1 / k2: keyframe dicts as fuse() takes
+    them + per-feature point arrays state / world_pos / max_dist / min_dist / mpdesc and the pose Rcw, tcw.  matches_in[N1]:
+    -1 NULL, j >= 0 the point of k2's feature j, -2 a point k2 does not observe.  Returns (matches_out[N1], return value)."""
+    keep = []
+    ka, kb = dict(k1), dict(k2)
+    for k in (ka, kb):
+        k.setdefault("angle", np.zeros(len(np.asarray(k["octave"])), np.float32))
+    a, b = _kf_args(ka, keep), _kf_args(kb, keep)
+    pa, pb = _kf_points(k1, keep), _kf_points(k2, keep)
+    R = np.ascontiguousarray(R12, np.float32).reshape(9)
+    t = np.ascontiguousarray(t12, np.float32).reshape(3)
+    m = np.ascontiguousarray(matches_in, np.int32).copy()
+    if len(m) == 0:
+        m = np.zeros(1, np.int32)
+    fn = getattr(_pick(shim, perfect), ("shim_" if shim else "ref_") + "search_by_sim3")
+    rv = fn(C.byref(a), C.byref(pa), C.byref(b), C.byref(pb), float(s12), _p(R), _p(t), float(th), _p(m))
+    return m[:a.n], rv

@@ -503,6 +503,59 @@ int REF_NAME(search_for_triangulation)(const RefKfArgs *k1, const uint8_t *has_m
     return n;
 }
 
+/* SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)  src/ORBmatcher.cc:1334-1548 on two mock KeyFrames.  Per keyframe:
+ * state[n] (0 no point, 1 good, 2 bad), world_pos / max_dist / min_dist / mpdesc of the feature's point, pose (Rcw[9], tcw[3]).
+ * matches[N1] in / out: -1 NULL, j >= 0 the point of pKF2's feature j, -2 a point pKF2 does not observe. */
+struct RefKfPoints {
+    const uint8_t *state;
+    const float *world_pos, *max_dist, *min_dist;
+    const uint8_t *mpdesc;
+    const float *Rcw, *tcw;
+};
+static void attach_points(KeyFrame &kf, const RefKfPoints &p, std::vector<MapPoint> &pts)
+{
+    for (int i = 0; i < kf.N; i++)
+        if (p.state[i]) {
+            fill_point(pts[(size_t)i], p.world_pos + 3 * i, 0, p.max_dist[i], p.min_dist[i], p.mpdesc + (size_t)i * 32, p.state[i] == 2, 1);
+            pts[(size_t)i].AddObservation(&kf, (size_t)i);
+            kf.mvpMapPoints[(size_t)i] = &pts[(size_t)i];
+        }
+    kf.Rcw = cv::Mat(3, 3, CV_32F);
+    kf.tcw = cv::Mat(3, 1, CV_32F);
+    for (int k = 0; k < 9; k++) kf.Rcw.at<float>(k / 3, k % 3) = p.Rcw[k];
+    for (int k = 0; k < 3; k++) kf.tcw.at<float>(k) = p.tcw[k];
+}
+int REF_NAME(search_by_sim3)(const RefKfArgs *k1, const RefKfPoints *p1, const RefKfArgs *k2, const RefKfPoints *p2, float s12,
+                             const float *R12, const float *t12, float th, int32_t *matches)
+{
+    KeyFrame a, b;
+    build_keyframe(*k1, a);
+    build_keyframe(*k2, b);
+    std::vector<MapPoint> pa((size_t)std::max(k1->n, 1)), pb((size_t)std::max(k2->n, 1));
+    attach_points(a, *p1, pa);
+    attach_points(b, *p2, pb);
+    MapPoint other;
+    std::vector<MapPoint *> m12((size_t)k1->n, (MapPoint *)0);
+    for (int i = 0; i < k1->n; i++) m12[(size_t)i] = matches[i] == -1 ? (MapPoint *)0 : matches[i] == -2 ? &other : &pb[(size_t)matches[i]];
+    cv::Mat R(3, 3, CV_32F), t(3, 1, CV_32F);
+    for (int k = 0; k < 9; k++) R.at<float>(k / 3, k % 3) = R12[k];
+    for (int k = 0; k < 3; k++) t.at<float>(k) = t12[k];
+    ORBmatcher m(0.75f, true);
+    int n;
+    try {
+        CallTimer tm;
+        n = m.SearchBySim3(&a, &b, m12, s12, R, t, th);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "search_by_sim3: %s\n", e.what());
+        return -999;
+    }
+    for (int i = 0; i < k1->n; i++) {
+        const MapPoint *q = m12[(size_t)i];
+        matches[i] = !q ? -1 : q == &other ? -2 : (int32_t)(q - pb.data());
+    }
+    return n;
+}
+
 /* Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, th, vector<MapPoint*> &vpReplacePoint)
  * src/ORBmatcher.cc:1198-1299.  kf_state as for fuse (0 none, 1 good, 2 bad).  Out: kf_assigned[nKF] (-1 none, -2 own point,
  * i >= 0 fused point i), replace_point[np] (-1 NULL, j >= 0 the KeyFrame's own point of feature j, -(k + 2) fused point k that an

@@ -18,6 +18,7 @@
 //                                                                                             src/ORBmatcher.cc:827-1012
 //     int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                  src/ORBmatcher.cc:1031-1182
 //     int ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, float, vector<MapPoint*>&) src/ORBmatcher.cc:1198-1299
+//     int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, vector<MapPoint*>&, s12, R12, t12, th)  src/ORBmatcher.cc:1334-1548
 //       (LocalMapping::SearchInNeighbors): the candidate scans do not look at the state the loop mutates, so all gates run
 //       first, ONE orbfe_hamming_csr call gives every point's best candidate, and the Replace / AddMapPoint decisions are
 //       replayed in order on the live objects
@@ -697,6 +698,110 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &
         }
     }
     return nFused;
+}
+
+// src/ORBmatcher.cc:1334-1516 (LoopClosing::ComputeSim3): the points of each keyframe are searched in the other one under the
+// candidate similarity, a match is kept when both directions agree.  No decision depends on an earlier one, so both
+// directions go to the device in ONE CSR call over the concatenated descriptor rows (pKF2's rows first).
+int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12,
+                             const cv::Mat &t12, const float th)
+{
+    const float &fx = pKF1->fx;
+    const float &fy = pKF1->fy;
+    const float &cx = pKF1->cx;
+    const float &cy = pKF1->cy;
+    cv::Mat R1w = pKF1->GetRotation();
+    cv::Mat t1w = pKF1->GetTranslation();
+    cv::Mat R2w = pKF2->GetRotation();
+    cv::Mat t2w = pKF2->GetTranslation();
+    cv::Mat sR12 = s12 * R12;
+    cv::Mat sR21 = (1.0 / s12) * R12.t();
+    cv::Mat t21 = -sR21 * t12;
+    const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const int N1 = (int)vpMapPoints1.size();
+    const std::vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N2 = (int)vpMapPoints2.size();
+    std::vector<bool> vbAlreadyMatched1((size_t)N1, false), vbAlreadyMatched2((size_t)N2, false);
+    for (int i = 0; i < N1; i++) {
+        MapPoint *pMP = vpMatches12[(size_t)i];
+        if (pMP) {
+            vbAlreadyMatched1[(size_t)i] = true;
+            int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+            if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[(size_t)idx2] = true;
+        }
+    }
+    const int nrows2 = pKF2->mDescriptors.rows, nrows1 = pKF1->mDescriptors.rows;
+    std::vector<uint32_t> off(1, 0), cand;
+    std::vector<uint8_t> qdesc;
+    std::vector<int> slot1((size_t)N1, -1), slot2((size_t)N2, -1);
+    // one direction: the points of keyframe A (pose Raw, taw) are taken into keyframe B by (sRba, tba) and looked up there
+    auto gather = [&](const std::vector<MapPoint *> &pts, const std::vector<bool> &already, const cv::Mat &Raw, const cv::Mat &taw,
+                      const cv::Mat &sRba, const cv::Mat &tba, KeyFrame *pKFb, uint32_t row0, std::vector<int> &slot) {
+        for (int i = 0; i < (int)pts.size(); i++) {
+            MapPoint *pMP = pts[(size_t)i];
+            if (!pMP || already[(size_t)i]) continue;
+            if (pMP->isBad()) continue;
+            cv::Mat p3Dw = pMP->GetWorldPos();
+            cv::Mat p3Da = Raw * p3Dw + taw;
+            cv::Mat p3Db = sRba * p3Da + tba;
+            if (p3Db.at<float>(2) < 0.0) continue;
+            const float invz = 1.0 / p3Db.at<float>(2);
+            const float x = p3Db.at<float>(0) * invz;
+            const float y = p3Db.at<float>(1) * invz;
+            const float u = fx * x + cx;
+            const float v = fy * y + cy;
+            if (!pKFb->IsInImage(u, v)) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            const float dist3D = cv::norm(p3Db);
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            const int nPredictedLevel = pMP->PredictScale(dist3D, pKFb);
+            const float radius = th * pKFb->mvScaleFactors[nPredictedLevel];
+            const std::vector<size_t> vIndices = pKFb->GetFeaturesInArea(u, v, radius);
+            if (vIndices.empty()) continue;
+            const size_t before = cand.size();
+            for (std::vector<size_t>::const_iterator vit = vIndices.begin(), vend = vIndices.end(); vit != vend; vit++) {
+                const size_t idx = *vit;
+                const cv::KeyPoint &kp = pKFb->mvKeysUn[idx];
+                if (kp.octave < nPredictedLevel - 1 || kp.octave > nPredictedLevel) continue;
+                cand.push_back(row0 + (uint32_t)idx);
+            }
+            if (cand.size() == before) continue;
+            slot[(size_t)i] = (int)off.size() - 1;
+            off.push_back((uint32_t)cand.size());
+            const cv::Mat dMP = pMP->GetDescriptor();
+            qdesc.insert(qdesc.end(), dMP.ptr<uint8_t>(0), dMP.ptr<uint8_t>(0) + 32);
+        }
+    };
+    gather(vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2, 0u, slot1);               // :1380-1453
+    gather(vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, pKF1, (uint32_t)nrows2, slot2);  // :1455-1529
+    const int nq = (int)off.size() - 1;
+    std::vector<int32_t> bestIdx((size_t)std::max(nq, 1), -1), best((size_t)std::max(nq, 1), 256), second((size_t)std::max(nq, 1), 256);
+    if (nq > 0) {
+        std::vector<uint8_t> rows((size_t)(nrows1 + nrows2) * 32), tmp;
+        if (nrows2 > 0) memcpy(rows.data(), Rows(pKF2->mDescriptors, tmp), (size_t)nrows2 * 32);
+        if (nrows1 > 0) memcpy(rows.data() + (size_t)nrows2 * 32, Rows(pKF1->mDescriptors, tmp), (size_t)nrows1 * 32);
+        const orbfe_status st = orbfe_hamming_csr(t_matcher.get(), qdesc.data(), nq, rows.data(), nrows1 + nrows2, off.data(), cand.data(),
+                                                  bestIdx.data(), best.data(), second.data());
+        if (st != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchBySim3 (orbfe): ") + orbfe_last_error());
+    }
+    std::vector<int> vnMatch1((size_t)N1, -1), vnMatch2((size_t)N2, -1);
+    for (int i1 = 0; i1 < N1; i1++)
+        if (slot1[(size_t)i1] >= 0 && best[(size_t)slot1[(size_t)i1]] <= TH_HIGH) vnMatch1[(size_t)i1] = bestIdx[(size_t)slot1[(size_t)i1]];
+    for (int i2 = 0; i2 < N2; i2++)
+        if (slot2[(size_t)i2] >= 0 && best[(size_t)slot2[(size_t)i2]] <= TH_HIGH) vnMatch2[(size_t)i2] = bestIdx[(size_t)slot2[(size_t)i2]] - nrows2;
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {  // :1532-1545
+        int idx2 = vnMatch1[(size_t)i1];
+        if (idx2 >= 0) {
+            int idx1 = vnMatch2[(size_t)idx2];
+            if (idx1 == i1) {
+                vpMatches12[(size_t)i1] = vpMapPoints2[(size_t)idx2];
+                nFound++;
+            }
+        }
+    }
+    return nFound;
 }
 
 int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)

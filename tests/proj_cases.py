@@ -280,6 +280,61 @@ def kf_sim3_case(rng, nKF, npts):
     return kf, Scw, pts, matched
 
 
+def sim3_pair_case(rng, n1, n2):
+    """(k1, k2, s12, R12, t12, matches_in) for ORBmatcher::SearchBySim3 (LoopClosing::ComputeSim3): two keyframes with poses of
+    their own and a candidate similarity between their camera frames; a share of the features are mutual pairs (the point of
+    k1's feature lands on k2's feature and the other way round), the rest aim at random features or nowhere"""
+    c1, c2 = current_frame(rng, n1), current_frame(rng, n2)
+    fx, fy, cx, cy, mbf, mb = c1["K"]
+    sf = c1["scale_factors"]
+    T1, T2 = _pose(rng, 5.0, rng.normal(0, 0.2, 3)).astype(np.float64), _pose(rng, 5.0, rng.normal(0, 0.2, 3)).astype(np.float64)
+    s12 = float(rng.uniform(0.85, 1.15))
+    R12 = _rot(rng, 3.0).astype(np.float64)
+    t12 = rng.normal(0, 0.05, 3)
+    sR21 = (1.0 / s12) * R12.T
+    t21 = -sR21 @ t12
+
+    def side(cs, n_s, T_s, co, n_o, to_other_R, to_other_t, back_R, back_t, tgt):
+        """points of the features of `cs` that land on features tgt of `co` after (to_other_R, to_other_t)"""
+        z = rng.uniform(0.5, 8.0, n_s)
+        px = (co["xy"][tgt] if n_o else np.zeros((n_s, 2))) + rng.normal(0, 1.5, (n_s, 2))
+        if n_s > 12:
+            z[rng.integers(0, n_s, 2)] *= -1
+            px[rng.integers(0, n_s, 2)] += 900
+        Xo = np.stack([(px[:, 0] - cx) / fx * z, (px[:, 1] - cy) / fy * z, z], 1)       # in the other camera
+        Xs = (Xo - to_other_t) @ np.linalg.inv(to_other_R).T                             # in the own camera
+        world = ((Xs - T_s[:3, 3]) @ T_s[:3, :3]).astype(np.float32)
+        d3 = np.linalg.norm(Xo, axis=1)
+        lvl = (co["octave"][tgt] if n_o else np.zeros(n_s)).astype(np.float64) + rng.choice([0, 0, 0, 1], n_s)
+        maxd = (d3 * 1.2 ** lvl * rng.uniform(0.93, 0.999, n_s)).astype(np.float32)
+        if n_s > 12:
+            maxd[rng.integers(0, n_s, 2)] *= 0.3
+        k = dict(desc=cs["desc"], xy=cs["xy"], octave=cs["octave"], uRight=cs["uRight"], K=(fx, fy, cx, cy, mbf), bounds=cs["bounds"],
+                 gw_inv=cs["gw_inv"], gh_inv=cs["gh_inv"], scale_factors=sf, inv_sigma2=(1.0 / (sf * sf)).astype(np.float32),
+                 log_scale=np.float32(np.log(np.float32(1.2))), state=rng.choice([0, 1, 1, 1, 1, 2], n_s).astype(np.uint8),
+                 world_pos=world, max_dist=maxd, min_dist=(maxd / 1.2 ** 7).astype(np.float32),
+                 mpdesc=noisy_copy(rng, co["desc"][tgt] if n_o else np.zeros((n_s, 32), np.uint8), 70),
+                 Rcw=T_s[:3, :3].astype(np.float32), tcw=T_s[:3, 3].astype(np.float32))
+        return k
+
+    tgt12 = rng.integers(0, max(n2, 1), n1)
+    tgt21 = rng.integers(0, max(n1, 1), n2)
+    if n1 and n2:   # mutual pairs: a random partial matching
+        m = min(n1, n2) * 3 // 5
+        a, b = rng.permutation(n1)[:m], rng.permutation(n2)[:m]
+        tgt12[a] = b
+        tgt21[b] = a
+    k1 = side(c1, n1, T1, c2, n2, sR21, t21, None, None, tgt12)
+    k2 = side(c2, n2, T2, c1, n1, s12 * R12, t12, None, None, tgt21)
+    matches = np.full(n1, -1, np.int32)
+    if n1 > 6 and n2 > 2:
+        sl = rng.choice(n1, n1 // 8, replace=False)
+        matches[sl] = np.where(rng.random(len(sl)) < 0.5, -2, rng.integers(0, n2, len(sl)))
+        good2 = k2["state"] > 0
+        matches[(matches >= 0) & ~good2[np.clip(matches, 0, n2 - 1)]] = -1   # a preset match is a point k2 really has
+    return k1, k2, s12, R12.astype(np.float32), t12.astype(np.float32), matches
+
+
 def _fv_csr(nodes_of_feature, present):
     """FeatureVector of a keyframe as CSR: ascending node ids, features of a node in ascending index (DBoW2's insertion order)"""
     ids = sorted(set(int(v) for v, p in zip(nodes_of_feature, present) if p))

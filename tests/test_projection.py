@@ -257,3 +257,21 @@ def test_shim_fuse_sim3_equals_reference_body():
         assert s[2] == r[2] and np.array_equal(s[0], r[0]) and np.array_equal(s[1], r[1]), (seed, nKF, nmp, r[2], s[2])
         fused += r[2]
     assert fused > 1500
+
+
+@needs_shim
+@pytest.mark.gpu
+def test_shim_search_by_sim3_equals_reference_body():
+    """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1334-1548, LoopClosing::ComputeSim3) through the reference's class: both
+    directions in one device call, then the mutual-agreement rule; vpMatches12 entry by entry and the count"""
+    found = 0
+    for seed in range(60):
+        rng = np.random.default_rng(28_000 + seed)
+        n1, n2 = int(rng.choice([1, 30, 300, 1000])), int(rng.choice([1, 40, 400, 1200]))
+        k1, k2, s12, R12, t12, m_in = PC.sim3_pair_case(rng, n1, n2)
+        th = float(rng.choice([7.5, 10.0]))
+        r = R.search_by_sim3(k1, k2, s12, R12, t12, th, m_in)
+        s = R.search_by_sim3(k1, k2, s12, R12, t12, th, m_in, shim=True)
+        assert s[1] == r[1] and np.array_equal(s[0], r[0]), (seed, n1, n2, r[1], s[1])
+        found += r[1]
+    assert found > 800

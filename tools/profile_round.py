@@ -8,6 +8,7 @@ domain other than the kernel trace):
    2. --kernel-trace --pmc FETCH_SIZE         \
    3. --kernel-trace --pmc WRITE_SIZE         /  -> <tag>_pmc_hbm.json (per kernel, per launch; 2 x FETCH + WRITE corrected bytes)
    4. --kernel-trace --pmc VALUBusy           -> <tag>_pmc_valubusy.json
+   5. --kernel-trace --stats of the default command (pipes) -> <tag>_kernel_stats_pipes.csv
 """
 import collections
 import csv
@@ -23,14 +24,17 @@ OUT = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1]
 bench_args = sys.argv[2:] or ["--no-extras", "--launches", "2", "--steps", "4", "--warmup", "2"]
 cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
-env = dict(os.environ, TMPDIR="/tmp")
+# the per-kernel passes run the step on ONE stream (ORBFE_BENCH_PIPES=1): with the default pipes, kernels of several
+# sub-batches share the CUs and a kernel's begin-to-end interval is not its own duration; the default command gets one more
+# kernel-trace pass of its own at the end (<tag>_kernel_stats_pipes.csv)
+env = dict(os.environ, TMPDIR="/tmp", ORBFE_BENCH_PIPES="1")
 
 
 def kname(n):
     return n.replace("void ", "").split("(")[0].split("<")[0]
 
 
-def rocprof(args, sub):
+def rocprof(args, sub, env=env, cmd=cmd):
     d = os.path.join(OUT, f"{tag}_{sub}")
     shutil.rmtree(d, ignore_errors=True)
     r = subprocess.run(["rocprofv3"] + args + ["--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env,
@@ -97,3 +101,15 @@ print(json.dumps(hbm["corrected_hbm_bytes_per_launch"]))
 print(json.dumps({k: v["mean_per_launch"] for k, v in vb.items()}))
 print(json.dumps({k: v["mean_per_launch"] for k, v in sq["SQ_INSTS_VALU"].items()}))
 shutil.rmtree(os.path.join(OUT, f"{tag}_trace"), ignore_errors=True)
+
+# the default command: several sub-batches in flight (intervals overlap; Calls and TotalDuration are what to read)
+env_p = dict(os.environ, TMPDIR="/tmp")
+env_p.pop("ORBFE_BENCH_PIPES", None)
+cmd_p = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-extras", "--steps", "4", "--warmup", "2"] if len(sys.argv) <= 2 else cmd
+d, line_p, _ = rocprof(["--kernel-trace", "--stats"], "trace_pipes", env=env_p, cmd=cmd_p)
+st = glob.glob(os.path.join(d, "*", "*kernel_stats.csv"))
+if st:
+    shutil.copy(st[0], os.path.join(OUT, f"{tag}_kernel_stats_pipes.csv"))
+if line_p:
+    json.dump(line_p, open(os.path.join(OUT, f"{tag}_bench_under_rocprof_pipes.json"), "w"), indent=1)
+shutil.rmtree(d, ignore_errors=True)
