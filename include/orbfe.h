@@ -255,6 +255,12 @@ orbfe_status orbfe_hamming_csr(orbfe_matcher *m, const uint8_t *q, int32_t nq, c
 orbfe_status orbfe_hamming_csr_ex(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
                                   const uint32_t *off, const uint32_t *cand, int32_t *best_idx, int32_t *best,
                                   int32_t *second, int32_t *second_idx);
+/* every distance of every list: dist[off[nq]] (0..256), for the one caller whose rule needs them all --
+ * ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:523-651) skips a candidate that an EARLIER query holds at a
+ * distance <= its own (:573), so its best / second-best depend on the matches made so far; the distances come from the
+ * device, the in-order rule stays with the caller.  HOST buffers. */
+orbfe_status orbfe_hamming_csr_all(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
+                                   const uint32_t *off, const uint32_t *cand, uint16_t *dist);
 /* DEVICE buffers (queries / train rows e.g. straight out of an extractor output block), enqueued on `stream`, no
  * validation of the candidate indices (they must be < the number of train rows); d_second_idx may be NULL */
 orbfe_status orbfe_hamming_csr_device(orbfe_matcher *m, const uint8_t *d_q, int32_t nq, const uint8_t *d_t,

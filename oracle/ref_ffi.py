@@ -156,6 +156,7 @@ def _declare_projection(L, prefix):
     getattr(L, prefix + "search_by_projection_frame_kf").argtypes = [vp, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
     getattr(L, prefix + "search_by_projection_kf_sim3").argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp]
     getattr(L, prefix + "search_for_triangulation").argtypes = [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, ci, vp]
+    getattr(L, prefix + "search_for_initialization").argtypes = [vp, vp, vp, ci, cf, ci, vp]
     getattr(L, prefix + "search_by_sim3").argtypes = [vp, vp, vp, vp, cf, vp, vp, cf, vp]
     getattr(L, prefix + "fuse_sim3").argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp]
     getattr(L, prefix + "fuse").argtypes = ([vp] * 6 + [ci, vp, vp, vp] + [cf] * 11 + [vp, vp, ci, cf, ci] + [vp] * 9 + [cf, vp, vp, vp])
@@ -191,6 +192,30 @@ def shim_lib():
     _declare_projection(L, "shim_")
     _shim = L
     return L
+
+
+_SHIM_FULL = os.path.join(_OUT, "libshim_full.so")
+_shim_full = None
+
+
+def shim_full_lib():
+    """oracle/_ref/libshim_full.so: shim/ORBmatcher_orbfe.cc with -DORBFE_SHIM_STANDALONE as the ONLY ORBmatcher translation
+    unit (the reference's src/ORBmatcher.cc is not in this library); same shim_* entry points.  Pass shim="full"."""
+    global _shim_full
+    if _shim_full is None:
+        build_shims()
+        if not os.path.exists(_SHIM_FULL):
+            raise RuntimeError("oracle/_ref/libshim_full.so is missing")
+        L = C.CDLL(_SHIM_FULL)
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.shim_descriptor_distance.argtypes = [vp, vp]
+        L.shim_three_maxima.argtypes = [vp, ci, vp, vp, vp]
+        L.shim_search_by_bow_kf_f.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, cf, ci, vp]
+        L.shim_search_by_bow_kf_kf.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci] * 2 + [cf, ci, vp]
+        L.shim_matcher_constants.argtypes = [vp, vp, vp]
+        _declare_projection(L, "shim_")
+        _shim_full = L
+    return _shim_full
 
 
 def shim_perfect_lib():
@@ -385,7 +410,7 @@ def glibc_sincosf(x):
 def descriptor_distance(a, b, shim=False):
     a = np.ascontiguousarray(a, np.uint8)
     b = np.ascontiguousarray(b, np.uint8)
-    return (shim_lib().shim_descriptor_distance if shim else lib().ref_descriptor_distance)(_p(a), _p(b))
+    return (_pick(shim, False).shim_descriptor_distance if shim else lib().ref_descriptor_distance)(_p(a), _p(b))
 
 
 def three_maxima(counts):
@@ -418,7 +443,7 @@ def search_by_bow_kf_f(descKF, validKF, angKF, fvKF, descF, angF, fvF, nnratio, 
     nk, ok, ik = _csr(fvKF)
     nf, of, if_ = _csr(fvF)
     out = np.full(descF.shape[0], -1, np.int32)
-    fn = shim_lib().shim_search_by_bow_kf_f if shim else lib().ref_search_by_bow_kf_f
+    fn = _pick(shim, False).shim_search_by_bow_kf_f if shim else lib().ref_search_by_bow_kf_f
     n = fn(_p(descKF), descKF.shape[0], _p(validKF), _p(angKF), _p(nk), _p(ok), _p(ik),
                                      nk.size, _p(descF), descF.shape[0], _p(angF), _p(nf), _p(of), _p(if_), nf.size,
                                      float(nnratio), int(check_ori), _p(out))
@@ -436,7 +461,7 @@ def search_by_bow_kf_kf(desc1, valid1, ang1, fv1, desc2, valid2, ang2, fv2, nnra
     n1_, o1, i1 = _csr(fv1)
     n2_, o2, i2 = _csr(fv2)
     out = np.full(desc1.shape[0], -1, np.int32)
-    fn = shim_lib().shim_search_by_bow_kf_kf if shim else lib().ref_search_by_bow_kf_kf
+    fn = _pick(shim, False).shim_search_by_bow_kf_kf if shim else lib().ref_search_by_bow_kf_kf
     n = fn(_p(desc1), desc1.shape[0], _p(valid1), _p(ang1), _p(n1_), _p(o1), _p(i1),
                                       n1_.size, _p(desc2), desc2.shape[0], _p(valid2), _p(ang2), _p(n2_), _p(o2),
                                       _p(i2), n2_.size, float(nnratio), int(check_ori), _p(out))
@@ -529,7 +554,7 @@ def search_by_projection_last_frame(cur, last, th, mono, nnratio=0.9, check_ori=
              xy=np.ascontiguousarray(last["xy"], np.float32).reshape(-1, 2))
     assigned = np.full(a.n, -9, np.int32)
     pl, pc, npts = np.zeros((max(n, 1), 2), np.float32), np.zeros((max(n, 1), 2), np.float32), C.c_int32(-1)
-    lb = (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
+    lb = _pick(shim, perfect)
     fn = getattr(lb, ("shim_" if shim else "ref_") + "search_by_projection_last_frame")
     rv = fn(C.byref(a), _p(L["Tcw"]), n, _p(L["has_mp"]), _p(L["outlier"]), _p(L["world_pos"]), _p(L["mpdesc"]), _p(L["obs_gt0"]),
             _p(L["octave"]), _p(L["angle"]), _p(L["xy"]), float(th), int(mono), float(nnratio), int(check_ori), _p(assigned),
@@ -551,7 +576,7 @@ def search_by_projection_local_map(cur, mps, th, nnratio=0.8, shim=False, perfec
              proj_xyr=np.ascontiguousarray(mps["proj_xyr"], np.float32).reshape(-1, 3),
              mpdesc=np.ascontiguousarray(mps["mpdesc"], np.uint8).reshape(-1, 32), obs_gt0=np.ascontiguousarray(mps["obs_gt0"], np.uint8))
     assigned = np.full(a.n, -9, np.int32)
-    lb = (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
+    lb = _pick(shim, perfect)
     fn = getattr(lb, ("shim_" if shim else "ref_") + "search_by_projection_local_map")
     rv = fn(C.byref(a), n, _p(M["in_view"]), _p(M["bad"]), _p(M["scale_level"]), _p(M["view_cos"]), _p(M["proj_xyr"]), _p(M["mpdesc"]),
             _p(M["obs_gt0"]), float(th), float(nnratio), _p(assigned))
@@ -560,7 +585,7 @@ def search_by_projection_local_map(cur, mps, th, nnratio=0.8, shim=False, perfec
 
 def last_call_ms(shim=False, perfect=False):
     """wall time of the last SearchByProjection member call alone (mock construction excluded)"""
-    lb = (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
+    lb = _pick(shim, perfect)
     return float(getattr(lb, ("shim_" if shim else "ref_") + "last_call_ms")())
 
 
@@ -582,7 +607,7 @@ def fuse(kf, mps, th, shim=False, perfect=False):
              d=np.ascontiguousarray(mps["mpdesc"], u8).reshape(-1, 32), obs=np.ascontiguousarray(mps["obs"], i32))
     nKF, nmp = len(K["desc"]), len(M["null"])
     ka, mr, orr = np.full(max(nKF, 1), -9, i32), np.full(max(nmp, 1), -9, i32), np.full(max(nKF, 1), -9, i32)
-    lb = (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
+    lb = _pick(shim, perfect)
     fn = getattr(lb, ("shim_" if shim else "ref_") + "fuse")
     fx, fy, cx, cy, mbf = [float(v) for v in kf["K"][:5]]
     minx, maxx, miny, maxy = [float(v) for v in kf["bounds"]]
@@ -602,6 +627,8 @@ class RefKfArgs(C.Structure):
 
 
 def _pick(shim, perfect):
+    if shim == "full":
+        return shim_full_lib()
     return (shim_perfect_lib() if perfect else shim_lib()) if shim else (perfect_lib() if perfect else lib())
 
 
@@ -745,3 +772,17 @@ def search_by_sim3(k1, k2, s12, R12, t12, th, matches_in, shim=False, perfect=Fa
     fn = getattr(_pick(shim, perfect), ("shim_" if shim else "ref_") + "search_by_sim3")
     rv = fn(C.byref(a), C.byref(pa), C.byref(b), C.byref(pb), float(s12), _p(R), _p(t), float(th), _p(m))
     return m[:a.n], rv
+
+
+def search_for_initialization(f1, f2, prev_matched, window, nnratio=0.9, check_ori=True, shim=False, perfect=False):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:523-651) on two mock Frames (dicts as _frame_args takes them).
+    Returns (matches12[n1], prev_matched_out[n1, 2], return value)."""
+    keep = []
+    a, b = _frame_args(f1, keep), _frame_args(f2, keep)
+    pm = np.ascontiguousarray(prev_matched, np.float32).reshape(-1, 2).copy()
+    if len(pm) == 0:
+        pm = np.zeros((1, 2), np.float32)
+    m = np.full(max(a.n, 1), -9, np.int32)
+    fn = getattr(_pick(shim, perfect), ("shim_" if shim else "ref_") + "search_for_initialization")
+    rv = fn(C.byref(a), C.byref(b), _p(pm), int(window), float(nnratio), int(bool(check_ori)), _p(m))
+    return m[:a.n], pm[:a.n], rv

@@ -503,6 +503,35 @@ int REF_NAME(search_for_triangulation)(const RefKfArgs *k1, const uint8_t *has_m
     return n;
 }
 
+/* SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)  src/ORBmatcher.cc:523-651 on two mock Frames.
+ * prev_matched[n1 * 2] in / out, matches12[n1] out; returns the reference's return value. */
+int REF_NAME(search_for_initialization)(const RefFrameArgs *a1, const RefFrameArgs *a2, float *prev_matched, int window, float nnratio,
+                                        int check_ori, int32_t *matches12)
+{
+    Frame f1, f2;
+    std::vector<MapPoint> o1, o2;
+    build_frame(*a1, f1, o1);
+    build_frame(*a2, f2, o2);
+    std::vector<cv::Point2f> prev((size_t)a1->n);
+    for (int i = 0; i < a1->n; i++) prev[(size_t)i] = cv::Point2f(prev_matched[2 * i], prev_matched[2 * i + 1]);
+    std::vector<int> m12;
+    ORBmatcher m(nnratio, check_ori != 0);
+    int n;
+    try {
+        CallTimer tm;
+        n = m.SearchForInitialization(f1, f2, prev, m12, window);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "search_for_initialization: %s\n", e.what());
+        return -999;
+    }
+    for (int i = 0; i < a1->n; i++) {
+        matches12[i] = m12[(size_t)i];
+        prev_matched[2 * i] = prev[(size_t)i].x;
+        prev_matched[2 * i + 1] = prev[(size_t)i].y;
+    }
+    return n;
+}
+
 /* SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)  src/ORBmatcher.cc:1334-1548 on two mock KeyFrames.  Per keyframe:
  * state[n] (0 no point, 1 good, 2 bad), world_pos / max_dist / min_dist / mpdesc of the feature's point, pose (Rcw[9], tcw[3]).
  * matches[N1] in / out: -1 NULL, j >= 0 the point of pKF2's feature j, -2 a point pKF2 does not observe. */

@@ -579,6 +579,25 @@ __global__ __launch_bounds__(256) void k_hamming_csr(const uint8_t *__restrict__
     if (second_idx) second_idx[i] = si;
 }
 
+// every distance of a candidate list, for callers whose acceptance rule needs more than the two smallest
+// (SearchForInitialization, src/ORBmatcher.cc:571-574: a candidate is skipped when an earlier query already holds it at a
+// smaller distance).  One wave per query, lanes over its candidates.
+__global__ __launch_bounds__(256) void k_hamming_csr_all(const uint8_t *__restrict__ q, int nq, const uint8_t *__restrict__ t,
+                                                         const uint32_t *__restrict__ off, const uint32_t *__restrict__ cand,
+                                                         uint16_t *__restrict__ dist)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nq) return;
+    const int lane = threadIdx.x & 63;
+    Desc8 dq;
+    const uint32_t *p = (const uint32_t *)(q + (int64_t)i * 32);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dq.w[k] = p[k];
+    const uint32_t e = off[i + 1];
+    for (uint32_t j = off[i] + (uint32_t)lane; j < e; j += 64u)
+        dist[j] = (uint16_t)hamming8(dq, (const uint32_t *)(t + (int64_t)cand[j] * 32));
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host API
 // ---------------------------------------------------------------------------------------------------
@@ -946,6 +965,41 @@ extern "C" orbfe_status orbfe_hamming_csr_ex(orbfe_matcher *m, const uint8_t *q,
     ORBFE_HIP(hipMemcpyAsync(best_idx, m->b[4].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipMemcpyAsync(best, m->b[5].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipMemcpyAsync(second, m->b[6].p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_hamming_csr_all(orbfe_matcher *m, const uint8_t *q, int32_t nq, const uint8_t *t, int32_t nt,
+                                              const uint32_t *off, const uint32_t *cand, uint16_t *dist)
+{
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && (!q || !off))) {
+        orbfe_set_error("bad argument to orbfe_hamming_csr_all");
+        return ORBFE_ERR_ARG;
+    }
+    if (nq == 0) return ORBFE_OK;
+    const size_t nc = off[nq];
+    for (int i = 0; i < nq; ++i)
+        if (off[i + 1] < off[i]) { orbfe_set_error("CSR offsets must not decrease"); return ORBFE_ERR_ARG; }
+    if (nc == 0) return ORBFE_OK;
+    if (!cand || !dist || !t) { orbfe_set_error("bad argument to orbfe_hamming_csr_all"); return ORBFE_ERR_ARG; }
+    for (size_t k = 0; k < nc; ++k)
+        if (cand[k] >= (uint32_t)nt) { orbfe_set_error("candidate index out of range"); return ORBFE_ERR_ARG; }
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));
+    ORBFE_HIP(m->b[0].ensure((size_t)nq * 32));
+    ORBFE_HIP(m->b[1].ensure((size_t)nt * 32));
+    ORBFE_HIP(m->b[2].ensure((size_t)(nq + 1) * 4));
+    ORBFE_HIP(m->b[3].ensure(nc * 4));
+    ORBFE_HIP(m->b[4].ensure(nc * 2));
+    ORBFE_HIP(hipMemcpyAsync(m->b[0].p, q, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    ORBFE_HIP(hipMemcpyAsync(m->b[1].p, t, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    ORBFE_HIP(hipMemcpyAsync(m->b[2].p, off, (size_t)(nq + 1) * 4, hipMemcpyHostToDevice, st));
+    ORBFE_HIP(hipMemcpyAsync(m->b[3].p, cand, nc * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_hamming_csr_all, dim3((nq + 3) / 4), dim3(256), 0, st, (const uint8_t *)m->b[0].p, nq,
+                       (const uint8_t *)m->b[1].p, (const uint32_t *)m->b[2].p, (const uint32_t *)m->b[3].p, (uint16_t *)m->b[4].p);
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpyAsync(dist, m->b[4].p, nc * 2, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipStreamSynchronize(st));
     return ORBFE_OK;
 }

@@ -129,6 +129,16 @@ class ORBmatcher:
         check(st, "orbfe_hamming_csr")
         return bi, b, s
 
+    def HammingCSRAll(self, descQ, descT, off, cand):
+        """Every distance of every candidate list (orbfe_hamming_csr_all): dist[off[-1]] uint16."""
+        q = np.ascontiguousarray(descQ, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(descT, np.uint8).reshape(-1, 32)
+        off = np.ascontiguousarray(off, np.uint32)
+        cand = np.ascontiguousarray(cand, np.uint32)
+        d = np.zeros(int(off[-1]) if len(off) else 0, np.uint16)
+        check(self._L.orbfe_hamming_csr_all(self._m, ptr(q), len(q), ptr(t), len(t), ptr(off), ptr(cand), ptr(d)), "orbfe_hamming_csr_all")
+        return d
+
     def HammingCSR2(self, descQ, descT, off, cand):
         """HammingCSR plus second_idx: the candidate owning the runner-up distance (orbfe_hamming_csr_ex)."""
         q = np.ascontiguousarray(descQ, np.uint8).reshape(-1, 32)

@@ -1,34 +1,35 @@
-// ORBmatcher_orbfe.cc -- link-level drop-in for the Hamming core of the reference's ORBmatcher.
+// ORBmatcher_orbfe.cc -- link-level drop-in for the reference's ORBmatcher (src/ORBmatcher.cc).
 //
-// The reference's OWN include/ORBmatcher.h stays as it is (so Tracking.cc, LocalMapping.cc, LoopClosing.cc and the
-// projection family SearchByProjection x4 / SearchForInitialization / SearchForTriangulation / SearchBySim3 / Fuse x2
-// in src/ORBmatcher.cc compile unchanged).  This file supplies the members that carry the Hamming work, over
-// the C-ABI of liborbfe.so:
-//     static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)              src/ORBmatcher.cc:1968-1984
-//     int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&)                src/ORBmatcher.cc:217-363
-//     int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&)             src/ORBmatcher.cc:665-812
-//     int ORBmatcher::SearchByProjection(Frame&, const std::vector<MapPoint*>&, float)       src/ORBmatcher.cc:63-157
-//     int ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)                  src/ORBmatcher.cc:1578-1724
-//     (with -DORBFE_SHIM_PERFECT, for the perfect/ tree) the overload that also returns the 2-D point pairs,
-//                                                                                             perfect/src/ORBmatcher.cc:1727-1911
-//     int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, float, int) src/ORBmatcher.cc:1757-1867
-//     int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>&, int)
-//                                                                                             src/ORBmatcher.cc:378-470
-//     int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool)
-//                                                                                             src/ORBmatcher.cc:827-1012
-//     int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                  src/ORBmatcher.cc:1031-1182
-//     int ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, float, vector<MapPoint*>&) src/ORBmatcher.cc:1198-1299
-//     int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, vector<MapPoint*>&, s12, R12, t12, th)  src/ORBmatcher.cc:1334-1548
-//       (LocalMapping::SearchInNeighbors): the candidate scans do not look at the state the loop mutates, so all gates run
-//       first, ONE orbfe_hamming_csr call gives every point's best candidate, and the Replace / AddMapPoint decisions are
-//       replayed in order on the live objects
-// The two SearchByProjection members are the per-frame matchers of Tracking (TrackWithMotionModel src/Tracking.cc:1346,
-// SearchLocalPoints :1960): the pose projection and its gates run here, on cv::Mat, statement for statement as in the
-// reference; the candidate search (GetFeaturesInArea + Hamming + the "slot already taken" rule) is ONE
-// orbfe_search_by_projection call per invocation; the assignments and the rotation histogram are replayed from its result.
-// Integration: add this file to the ORB_SLAM2 library, delete (or #if 0) those bodies in src/ORBmatcher.cc, link
-// liborbfe.so.  The class gets no new data member: the device matcher handle is per thread, which is also
-// what the C-ABI asks for (Tracking, LocalMapping and LoopClosing call the matcher concurrently).
+// The reference's OWN include/ORBmatcher.h stays as it is, so Tracking.cc, LocalMapping.cc and LoopClosing.cc compile
+// unchanged.  This file supplies EVERY public member of the class over the C-ABI of liborbfe.so:
+//     static int DescriptorDistance(const cv::Mat&, const cv::Mat&)                                 src/ORBmatcher.cc:1968-1984
+//     int SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&)                                   :217-363
+//     int SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&)                                :665-812
+//     int SearchByProjection(Frame&, const std::vector<MapPoint*>&, float)                          :63-157
+//     int SearchByProjection(Frame&, const Frame&, float, bool)                                     :1578-1724
+//       (with -DORBFE_SHIM_PERFECT, for the perfect/ tree) the overload that also returns the 2-D point pairs,
+//                                                                                                    perfect/src/ORBmatcher.cc:1727-1911
+//     int SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, float, int)                  :1757-1867
+//     int SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>&, int)  :378-470
+//     int SearchForInitialization(Frame&, Frame&, vector<cv::Point2f>&, vector<int>&, int)          :523-651
+//     int SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool)  :827-1012
+//     int SearchBySim3(KeyFrame*, KeyFrame*, vector<MapPoint*>&, s12, R12, t12, th)                 :1334-1548
+//     int Fuse(KeyFrame*, const std::vector<MapPoint*>&, float)                                     :1031-1182
+//     int Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, float, vector<MapPoint*>&)         :1198-1299
+// and, with -DORBFE_SHIM_STANDALONE, the rest of the translation unit (constants, constructor, RadiusByViewingCos,
+// CheckDistEpipolarLine, ComputeThreeMaxima), so that src/ORBmatcher.cc can leave the build altogether.
+//
+// One pattern throughout: the pose projection and its gates run here, on cv::Mat, statement for statement as in the
+// reference; the candidate scans (GetFeaturesInArea + Hamming + whatever rule couples the queries) are ONE device call per
+// invocation; the assignments / Replace / AddMapPoint decisions and the rotation histogram are replayed from its result, in
+// the reference's order, on the live objects.  The device call is orbfe_search_by_projection for the four SearchByProjection
+// members (it also resolves the "slot already taken by an earlier query" rule), orbfe_search_for_triangulation,
+// orbfe_search_by_bow, orbfe_hamming_csr for Fuse x2 / SearchBySim3 (no query looks at another's result) and
+// orbfe_hamming_csr_all for SearchForInitialization (whose rule needs every distance).
+// Integration: add this file to the ORB_SLAM2 library in place of src/ORBmatcher.cc (-DORBFE_SHIM_STANDALONE), or next to it
+// with the bodies listed above deleted (or #if 0), and link liborbfe.so.  The class gets no new data member:
+// the device matcher handle is per thread, which is also what the C-ABI asks for (Tracking, LocalMapping and LoopClosing call
+// the matcher concurrently).
 //
 // Built and tested in this repo against the reference's unmodified header with mock KeyFrame / Frame / MapPoint types
 // (oracle/refbuild: libshim_ref.so; tests/test_gpu_shim_ref.py compares it with the compiled reference bodies).
@@ -803,6 +804,143 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoin
     }
     return nFound;
 }
+
+// src/ORBmatcher.cc:523-651 (Tracking::MonocularInitialization).  A candidate is skipped when an earlier query already holds
+// it at a distance <= its own (:573), so best / second-best of a query depend on the matches made before it: the device
+// returns every distance of every window (one call), the in-order rule runs here on those numbers.
+int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize)
+{
+    int nmatches = 0;
+    vnMatches12 = std::vector<int>(F1.mvKeysUn.size(), -1);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(F2.mvKeysUn.size(), INT_MAX);
+    std::vector<int> vnMatches21(F2.mvKeysUn.size(), -1);
+    const size_t n1 = F1.mvKeysUn.size();
+    std::vector<uint32_t> off(1, 0), cand, qrow;
+    std::vector<int> slot(n1, -1);
+    for (size_t i1 = 0; i1 < n1; i1++) {
+        const int level1 = F1.mvKeysUn[i1].octave;
+        if (level1 > 0) continue;
+        std::vector<size_t> vIndices2 = F2.GetFeaturesInArea(vbPrevMatched[i1].x, vbPrevMatched[i1].y, windowSize, level1, level1);
+        if (vIndices2.empty()) continue;
+        for (std::vector<size_t>::const_iterator vit = vIndices2.begin(); vit != vIndices2.end(); vit++) cand.push_back((uint32_t)*vit);
+        slot[i1] = (int)off.size() - 1;
+        off.push_back((uint32_t)cand.size());
+        qrow.push_back((uint32_t)i1);
+    }
+    const int nq = (int)off.size() - 1;
+    std::vector<uint16_t> dist(cand.size() + 1);
+    if (nq > 0) {
+        std::vector<uint8_t> t1, t2, qdesc((size_t)nq * 32);
+        const uint8_t *d1 = Rows(F1.mDescriptors, t1);
+        for (int k = 0; k < nq; k++) memcpy(&qdesc[(size_t)k * 32], d1 + (size_t)qrow[(size_t)k] * 32, 32);
+        const orbfe_status st = orbfe_hamming_csr_all(t_matcher.get(), qdesc.data(), nq, Rows(F2.mDescriptors, t2), F2.mDescriptors.rows,
+                                                      off.data(), cand.data(), dist.data());
+        if (st != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchForInitialization (orbfe): ") + orbfe_last_error());
+    }
+    for (size_t i1 = 0; i1 < n1; i1++) {  // :538-617 on the device's distances
+        if (slot[i1] < 0) continue;
+        int bestDist = INT_MAX;
+        int bestDist2 = INT_MAX;
+        int bestIdx2 = -1;
+        for (uint32_t k = off[(size_t)slot[i1]]; k < off[(size_t)slot[i1] + 1]; k++) {
+            const size_t i2 = cand[k];
+            const int d = (int)dist[k];
+            if (vMatchedDistance[i2] <= d) continue;
+            if (d < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = d;
+                bestIdx2 = (int)i2;
+            } else if (d < bestDist2) {
+                bestDist2 = d;
+            }
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * mfNNratio) {
+                if (vnMatches21[(size_t)bestIdx2] >= 0) {
+                    vnMatches12[(size_t)vnMatches21[(size_t)bestIdx2]] = -1;
+                    nmatches--;
+                }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[(size_t)bestIdx2] = (int)i1;
+                vMatchedDistance[(size_t)bestIdx2] = bestDist;
+                nmatches++;
+                if (mbCheckOrientation) {
+                    float rot = F1.mvKeysUn[i1].angle - F2.mvKeysUn[(size_t)bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back((int)i1);
+                }
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                int idx1 = rotHist[i][j];
+                if (vnMatches12[(size_t)idx1] >= 0) {
+                    vnMatches12[(size_t)idx1] = -1;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    for (size_t i1 = 0, iend1 = vnMatches12.size(); i1 < iend1; i1++)
+        if (vnMatches12[i1] >= 0) vbPrevMatched[i1] = F2.mvKeysUn[(size_t)vnMatches12[i1]].pt;
+    return nmatches;
+}
+
+#ifdef ORBFE_SHIM_STANDALONE
+// With every public member supplied above, src/ORBmatcher.cc can leave the build altogether: -DORBFE_SHIM_STANDALONE adds
+// the rest of the class -- the constants (src/ORBmatcher.cc:39-41), the constructor (:43) and the three protected helpers
+// (:159-167, :175-191, :1912-1957) -- so that this file alone is the ORBmatcher translation unit.
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+float ORBmatcher::RadiusByViewingCos(const float &viewCos) { return viewCos > 0.998 ? 2.5 : 4.0; }
+
+// squared distance of kp2 to the epipolar line of kp1 against the 95 % chi-square bound of kp2's level (float arithmetic, the
+// bound in double as `3.84 * float` makes it)
+bool ORBmatcher::CheckDistEpipolarLine(const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const cv::Mat &F12, const KeyFrame *pKF2)
+{
+    float l[3];
+    for (int k = 0; k < 3; k++) l[k] = kp1.pt.x * F12.at<float>(0, k) + kp1.pt.y * F12.at<float>(1, k) + F12.at<float>(2, k);
+    const float num = l[0] * kp2.pt.x + l[1] * kp2.pt.y + l[2];
+    const float den = l[0] * l[0] + l[1] * l[1];
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * pKF2->mvLevelSigma2[kp2.octave];
+}
+
+// the three fullest bins, first bin wins ties; the second / third are dropped when they hold less than a tenth of the first
+void ORBmatcher::ComputeThreeMaxima(std::vector<int> *histo, const int L, int &ind1, int &ind2, int &ind3)
+{
+    int top[3] = {0, 0, 0}, idx[3] = {-1, -1, -1};
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        int r = 3;
+        while (r > 0 && s > top[r - 1]) r--;   // rank of bin i among the best so far (strictly greater moves up)
+        if (r == 3) continue;
+        for (int k = 2; k > r; k--) { top[k] = top[k - 1]; idx[k] = idx[k - 1]; }
+        top[r] = s;
+        idx[r] = i;
+    }
+    if (top[1] < 0.1f * (float)top[0]) idx[1] = idx[2] = -1;
+    else if (top[2] < 0.1f * (float)top[0]) idx[2] = -1;
+    ind1 = idx[0];
+    ind2 = idx[1];
+    ind3 = idx[2];
+}
+#endif  // ORBFE_SHIM_STANDALONE
 
 int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
 {

@@ -280,6 +280,27 @@ def kf_sim3_case(rng, nKF, npts):
     return kf, Scw, pts, matched
 
 
+def initialization_case(rng, n1, n2):
+    """(f1, f2, prev_matched) for ORBmatcher::SearchForInitialization: two monocular frames a small motion apart; most of f2's
+    level-0 features are noisy copies of f1 features (several f1 features may aim at one f2 feature, so matches get taken
+    over :590-598), angles mostly consistent"""
+    f1 = current_frame(rng, n1, stereo=False, dense_states=False)
+    f1["octave"] = rng.choice([0, 0, 0, 1, 2, 5], n1).astype(np.int32)
+    f2 = current_frame(rng, n2, stereo=False, dense_states=False)
+    f2["octave"] = rng.choice([0, 0, 0, 1, 3], n2).astype(np.int32)
+    if n1 and n2:
+        src = rng.integers(0, n1, n2)
+        m = rng.random(n2) < 0.75
+        shift = rng.normal(0, 12, 2)
+        f2["xy"][m] = np.clip(f1["xy"][src[m]] + shift + rng.normal(0, 3, (int(m.sum()), 2)), [0, 0], [639.9, 479.9]).astype(np.float32)
+        f2["desc"][m] = noisy_copy(rng, f1["desc"][src[m]], 45)
+        f2["angle"][m] = ((f1["angle"][src[m]] + rng.choice([0, 0, 0, 0, 40, 150], int(m.sum())) + rng.normal(0, 3, int(m.sum()))) % 360).astype(np.float32)
+        dup = rng.random(n2) < 0.1   # a second f2 feature with (almost) the same descriptor nearby: the ratio test has work
+        f2["desc"][dup] = noisy_copy(rng, f2["desc"][rng.integers(0, n2, int(dup.sum()))], 10)
+    prev = f1["xy"].copy()   # Tracking::MonocularInitialization starts from the features' own positions (:622-624)
+    return f1, f2, prev
+
+
 def sim3_pair_case(rng, n1, n2):
     """(k1, k2, s12, R12, t12, matches_in) for ORBmatcher::SearchBySim3 (LoopClosing::ComputeSim3): two keyframes with poses of
     their own and a candidate similarity between their camera frames; a share of the features are mutual pairs (the point of

@@ -275,3 +275,98 @@ def test_shim_search_by_sim3_equals_reference_body():
         assert s[1] == r[1] and np.array_equal(s[0], r[0]), (seed, n1, n2, r[1], s[1])
         found += r[1]
     assert found > 800
+
+
+@needs_shim
+@pytest.mark.gpu
+def test_shim_search_for_initialization_equals_reference_body():
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:523-651, Tracking::MonocularInitialization) through the
+    reference's class: vnMatches12, the updated vbPrevMatched and the count; a second call continues from the first one's
+    vbPrevMatched as the tracker does"""
+    total = 0
+    for seed in range(60):
+        rng = np.random.default_rng(29_000 + seed)
+        n1, n2 = int(rng.choice([1, 50, 500, 2000])), int(rng.choice([1, 60, 600, 2000]))
+        f1, f2, prev = PC.initialization_case(rng, n1, n2)
+        win = int(rng.choice([30, 100]))
+        ori = bool(seed % 5)
+        r = R.search_for_initialization(f1, f2, prev, win, 0.9, ori)
+        s = R.search_for_initialization(f1, f2, prev, win, 0.9, ori, shim=True)
+        assert s[2] == r[2] and np.array_equal(s[0], r[0]) and np.array_equal(s[1], r[1]), (seed, n1, n2, r[2], s[2])
+        r2 = R.search_for_initialization(f1, f2, r[1], win, 0.9, ori)
+        s2 = R.search_for_initialization(f1, f2, s[1], win, 0.9, ori, shim=True)
+        assert s2[2] == r2[2] and np.array_equal(s2[0], r2[0]) and np.array_equal(s2[1], r2[1]), (seed, "second call")
+        total += r[2]
+    assert total > 1000
+
+
+@needs_shim
+def test_standalone_shim_is_the_whole_translation_unit():
+    """libshim_full.so links with --no-undefined WITHOUT the reference's src/ORBmatcher.cc: constants, constructor, helpers and
+    every public member come from shim/ORBmatcher_orbfe.cc (-DORBFE_SHIM_STANDALONE).  Host-side members here, no GPU."""
+    L = R.shim_full_lib()
+    rng = np.random.default_rng(5)
+    d = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    for i in range(0, 64, 2):
+        assert R.descriptor_distance(d[i], d[i + 1], shim="full") == R.descriptor_distance(d[i], d[i + 1])
+    import ctypes as C
+    for it in range(300):   # ComputeThreeMaxima, restated in the shim, against the reference's (histograms with ties / empty bins)
+        counts = rng.integers(0, [2, 5, 40, 400][it % 4], 30).astype(np.int32)
+        if it % 7 == 0:
+            counts[rng.integers(0, 30, 25)] = 0
+        out = []
+        for lib, pre in ((L, "shim_"), (R.lib(), "ref_")):
+            i = [C.c_int(-7) for _ in range(3)]
+            getattr(lib, pre + "three_maxima")(counts.ctypes.data, 30, C.byref(i[0]), C.byref(i[1]), C.byref(i[2]))
+            out.append([v.value for v in i])
+        assert out[0] == out[1], (counts, out)
+    th = [np.zeros(1, np.int32) for _ in range(3)]
+    tr = [np.zeros(1, np.int32) for _ in range(3)]
+    L.shim_matcher_constants(*[a.ctypes.data for a in th])
+    R.lib().ref_matcher_constants(*[a.ctypes.data for a in tr])
+    assert [int(a[0]) for a in th] == [int(a[0]) for a in tr]
+
+
+@needs_shim
+@pytest.mark.gpu
+def test_standalone_shim_every_member_equals_reference_bodies():
+    """every public member of ORBmatcher through libshim_full.so (the shim alone, no reference ORBmatcher.cc behind it) against
+    the reference's compiled bodies"""
+    from test_ref_pin import _bow_case
+    for seed in range(12):
+        rng = np.random.default_rng(31_000 + seed)
+        n1, n2 = int(rng.choice([30, 300, 1000])), int(rng.choice([40, 400, 1000]))
+        mono = seed % 4 == 3
+        cur, last = PC.last_frame_case(rng, n1, n2, ["small", "forward", "backward"][seed % 3], stereo=not mono)
+        a, b = R.search_by_projection_last_frame(cur, last, 15.0, mono), R.search_by_projection_last_frame(cur, last, 15.0, mono, shim="full")
+        assert b[1] == a[1] and np.array_equal(a[0], b[0]), ("last frame", seed)
+        cur2, mps = PC.local_map_case(rng, n1, n2 + 200)
+        a, b = R.search_by_projection_local_map(cur2, mps, 3.0, 0.8), R.search_by_projection_local_map(cur2, mps, 3.0, 0.8, shim="full")
+        assert b[1] == a[1] and np.array_equal(a[0], b[0]), ("local map", seed)   # RadiusByViewingCos is the shim's own here
+        cur3, kfp = PC.frame_kf_case(rng, n1, n2)
+        a, b = R.search_by_projection_frame_kf(cur3, kfp, 10.0, 100, True), R.search_by_projection_frame_kf(cur3, kfp, 10.0, 100, True, shim="full")
+        assert b[1] == a[1] and np.array_equal(a[0], b[0]), ("frame/kf", seed)
+        kf, Scw, pts, mi = PC.kf_sim3_case(rng, n1, n2 + 100)
+        a, b = R.search_by_projection_kf_sim3(kf, Scw, pts, mi, 10), R.search_by_projection_kf_sim3(kf, Scw, pts, mi, 10, shim="full")
+        assert b[1] == a[1] and np.array_equal(a[0], b[0]), ("kf/sim3", seed)
+        m2 = dict(pts, null=np.zeros(len(pts["bad"]), np.uint8))
+        a, b = R.fuse_sim3(kf, Scw, m2, 4.0), R.fuse_sim3(kf, Scw, m2, 4.0, shim="full")
+        assert b[2] == a[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), ("fuse sim3", seed)
+        kf2, mps2 = PC.fuse_case(rng, n1, n2)
+        a, b = R.fuse(kf2, mps2, 3.0), R.fuse(kf2, mps2, 3.0, shim="full")
+        assert b[3] == a[3] and all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])), ("fuse", seed)
+        k1, k2, F12 = PC.triangulation_case(rng, n1, n2, 60)
+        a, b = R.search_for_triangulation(k1, k2, F12, False), R.search_for_triangulation(k1, k2, F12, False, shim="full")
+        assert b[1] == a[1] and np.array_equal(a[0], b[0]), ("triangulation", seed)
+        s1, s2, s12, R12, t12, m_in = PC.sim3_pair_case(rng, n1, n2)
+        a, b = R.search_by_sim3(s1, s2, s12, R12, t12, 7.5, m_in), R.search_by_sim3(s1, s2, s12, R12, t12, 7.5, m_in, shim="full")
+        assert b[1] == a[1] and np.array_equal(a[0], b[0]), ("sim3", seed)
+        f1, f2, prev = PC.initialization_case(rng, n1, n2)
+        a, b = R.search_for_initialization(f1, f2, prev, 100), R.search_for_initialization(f1, f2, prev, 100, shim="full")
+        assert b[2] == a[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), ("initialization", seed)
+        (d1, v1, a1, fv1), (d2, v2, a2, fv2) = _bow_case(rng, n1, n2, 30, 0.8, seed % 2)
+        a, b = R.search_by_bow_kf_f(d1, v1, a1, fv1, d2, a2, fv2, 0.7, True), R.search_by_bow_kf_f(d1, v1, a1, fv1, d2, a2, fv2, 0.7, True, shim="full")
+        assert b[1] == a[1] and np.array_equal(a[0], b[0]), ("bow kf/f", seed)
+        a = R.search_by_bow_kf_kf(d1, v1, a1, fv1, d2, v2, a2, fv2, 0.75, True)
+        b = R.search_by_bow_kf_kf(d1, v1, a1, fv1, d2, v2, a2, fv2, 0.75, True, shim="full")
+        assert b[1] == a[1] and np.array_equal(a[0], b[0]), ("bow kf/kf", seed)
