@@ -491,31 +491,38 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         for (int i = 0; i < 64; ++i) mx = std::max(mx, (int)flanes[(size_t)wv * 64 + i].nrows);
         fast_row_steps += mx + 8;
     }
-    // blur lane list: every 4-px column of every (balanced, <= ORBFE_ROWS_PER_WAVE rows) row block, single-level waves, no halos
+    // blur lane list: every 4-px column of every (balanced, <= ORBFE_ROWS_PER_WAVE rows) row block, single-level waves, no
+    // halos.  Lanes do not talk to each other, so the columns whose 12-byte window [x - 4, x + 8) lies inside the row (no
+    // reflected column: flag bit 1) are packed into waves of their own -- those skip the byte rearrangement of the border
+    // path; the few edge columns (2 - 3 per row block) of a level share separate waves.
     std::vector<OrbLane> blanes;
     for (int l = 0; l < nl; ++l) {
         const OrbLevel &L = P.lv[l];
         if (L.w < 16) { orbfe_set_error("level %d too narrow for the blur kernel", l); return ORBFE_ERR_SIZE; }
         const int brb = ORBFE_ROWS_PER_WAVE;
         const int ncol = (L.w + 3) / 4, nblk = (L.h + brb - 1) / brb, rb = (L.h + nblk - 1) / nblk;
-        for (int k = 0; k < nblk; ++k) {
-            const int ys = k * rb, nr = std::min(rb, L.h - ys);
-            for (int c = 0; c < ncol && nr > 0; ++c) {
-                OrbLane ln;
-                ln.x = (uint16_t)(4 * c);
-                ln.ys = (uint16_t)ys;
-                ln.nrows = (uint16_t)nr;
-                ln.flags = (uint16_t)(l << 8);
-                blanes.push_back(ln);
+        for (int pass = 0; pass < 2; ++pass) {  // 0: interior columns, 1: edge columns
+            for (int k = 0; k < nblk; ++k) {
+                const int ys = k * rb, nr = std::min(rb, L.h - ys);
+                for (int c = 0; c < ncol && nr > 0; ++c) {
+                    const bool interior = 4 * c >= 4 && 4 * c + 8 <= L.w;
+                    if (interior != (pass == 0)) continue;
+                    OrbLane ln;
+                    ln.x = (uint16_t)(4 * c);
+                    ln.ys = (uint16_t)ys;
+                    ln.nrows = (uint16_t)nr;
+                    ln.flags = (uint16_t)((l << 8) | (interior ? 2 : 0));
+                    blanes.push_back(ln);
+                }
             }
-        }
-        while (blanes.size() % 64) {  // dead lanes: shadow the level's first column, output nothing
-            OrbLane d;
-            d.x = 0;
-            d.ys = 0;
-            d.nrows = 0;
-            d.flags = (uint16_t)((l << 8) | 1);
-            blanes.push_back(d);
+            while (blanes.size() % 64) {  // dead lanes: shadow a column of the wave's kind, output nothing
+                OrbLane d;
+                d.x = (uint16_t)(pass == 0 ? 4 : 0);
+                d.ys = 0;
+                d.nrows = 0;
+                d.flags = (uint16_t)((l << 8) | 1 | (pass == 0 ? 2 : 0));
+                blanes.push_back(d);
+            }
         }
     }
     P.nbwaves = (int)(blanes.size() / 64);

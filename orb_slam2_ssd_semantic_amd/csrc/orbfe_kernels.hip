@@ -1610,8 +1610,13 @@ __host__ __device__ constexpr uint32_t blur_hw(int j, int d)
 // covers all (reflected) source pixels of its 12-byte window and rearranges them with per-lane byte selectors
 // (identity for interior lanes); row borders are a per-lane reflected row index.
 #define BL_PF 2  // prefetch distance in rows
+#ifdef BL_MIN_WAVES
+#define BL_BOUNDS __launch_bounds__(256, BL_MIN_WAVES)
+#else
+#define BL_BOUNDS __launch_bounds__(256)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
+__global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
                                                const OrbLane *__restrict__ lanes, int nwaves,
                                                uint8_t *__restrict__ blur, int64_t blur_fstride)
 {
@@ -1629,6 +1634,8 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
     const int W = L.w, H = L.h;
     const int x = ld.x, y0 = ld.ys, yend = y0 + ld.nrows;
     const bool active = !(ld.flags & 1);
+    // wave-uniform by construction (the host packs interior and edge columns into separate waves): no reflected column
+    const bool interior = __builtin_amdgcn_readfirstlane((int)(ld.flags & 2)) != 0;
     const int vec_w = W & ~3;
     int nsteps = ld.nrows;
 #pragma unroll
@@ -1646,7 +1653,7 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
     srcx[11] = srcx[10];
     // all ten sources lie in [base, base + 12) (checked on the host for every level width); at the right edge the
     // window is pulled back so that it ends at the last pixel of the row
-    const int base = min(lo & ~3, W - 12);
+    const int base = interior ? x - 4 : min(lo & ~3, W - 12);
     uint32_t selA[3], selB[3], mskB[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -1695,12 +1702,14 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
             const int yin = y0 - 3 + s;
             fetch(s + BL_PF, Lr[(k + BL_PF) % 7]);  // rows past the run re-read a valid (reflected / clamped) row
             const uint32_t l0 = Lr[k][0], l1 = Lr[k][1], l2 = Lr[k][2];
-            uint32_t w[3];
+            uint32_t w[3] = {l0, l1, l2};
+            if (!interior) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const uint32_t ta = __builtin_amdgcn_perm(l1, l0, selA[d]);
-                const uint32_t tb = __builtin_amdgcn_perm(l2, l2, selB[d]);
-                w[d] = (tb & mskB[d]) | (ta & ~mskB[d]);
+                for (int d = 0; d < 3; ++d) {
+                    const uint32_t ta = __builtin_amdgcn_perm(l1, l0, selA[d]);
+                    const uint32_t tb = __builtin_amdgcn_perm(l2, l2, selB[d]);
+                    w[d] = (tb & mskB[d]) | (ta & ~mskB[d]);
+                }
             }
             // horizontal taps as byte dot products against per-(pixel, dword) weight constants
 #pragma unroll
@@ -1723,10 +1732,21 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbPlan *__restrict__ plan,
                     acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 2) % 7][j]), __builtin_bit_cast(orb_u2, 0x00220012u), acc, false);
                     acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 4) % 7][j]), __builtin_bit_cast(orb_u2, 0x00370031u), acc, false);
                     acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 6) % 7][j]), __builtin_bit_cast(orb_u2, 0x00220031u), acc, false);
-                    uint32_t q = acc;  // (q >> 16) = value rounded half-up, <= 257
-                    if (MODE == 1 && (acc & 0xFFFFu) == 0u && (x + j) < vec_w && (q & 0x10000u)) q -= 0x10000u;  // SSE2 half-even
-                    tq[j] = min(q, 0x00FFFFFFu);  // byte 2 = saturate_cast<uchar>
+                    tq[j] = acc;  // (acc >> 16) = value rounded half-up, <= 257
                 }
+                if (MODE == 1) {
+                    // SSE2 half-even: an exact half (low 16 bits zero) rounds to the even value inside the vectorised part of
+                    // the row.  One pixel in 65536 is an exact half, so the test is one wave-uniform branch on the smallest
+                    // low half of the lane's four sums; the per-pixel correction runs only when some lane has one.
+                    const uint32_t lowmin = min(min(tq[0] & 0xFFFFu, tq[1] & 0xFFFFu), min(tq[2] & 0xFFFFu, tq[3] & 0xFFFFu));
+                    if (__ballot(lowmin == 0u) != 0ull) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if ((tq[j] & 0xFFFFu) == 0u && (x + j) < vec_w && (tq[j] & 0x10000u)) tq[j] -= 0x10000u;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tq[j] = min(tq[j], 0x00FFFFFFu);  // byte 2 = saturate_cast<uchar>
                 const uint32_t p01 = __builtin_amdgcn_perm(tq[1], tq[0], 0x0c0c0602u);
                 const uint32_t p23 = __builtin_amdgcn_perm(tq[3], tq[2], 0x0c0c0602u);
                 const uint32_t packed = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
