@@ -335,12 +335,27 @@ typedef struct orbfe_proj_query {
 } orbfe_proj_query;
 #define ORBFE_PROJ_CLAIMS 1          /* the query's MapPoint has Observations() > 0: its slot is skipped by later queries */
 #define ORBFE_PROJ_RIGHT_GATE 2      /* apply the right-image gate (both Frame overloads do; the KeyFrame forms do not) */
+#define ORBFE_PROJ_CHI2_GATE 4       /* Fuse (src/ORBmatcher.cc:1112-1139): skip a candidate whose reprojection error
+                                      * e2 * inv_level_sigma2[octave] exceeds 7.8 (uRight[idx] >= 0: e2 = ex^2 + ey^2 + er^2,
+                                      * er = ur - uRight[idx]) / 5.99 (monocular keypoint); needs the _chi2 entry point */
 orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF,
                                         int32_t nF, const uint32_t *cell_off, const uint32_t *cell_idx, float minx, float miny,
                                         float gw_inv, float gh_inv, const float *uRight /* nF or NULL */,
                                         const uint8_t *blocked /* nF or NULL */, const orbfe_proj_query *q,
                                         const uint8_t *qdesc /* nq x 32 */, int32_t nq, int32_t th, float nnratio,
                                         int32_t ratio_rule, int32_t *match, int32_t *best, int32_t *second);
+
+/* the same search with the per-level table the ORBFE_PROJ_CHI2_GATE queries need (KeyFrame::mvInvLevelSigma2); the other
+ * members of the family use it without claims: ORBmatcher::Fuse x2 (src/ORBmatcher.cc:1031, :1198) and SearchBySim3 (:1334)
+ * pass flags without ORBFE_PROJ_CLAIMS, blocked = NULL, ratio_rule 0 and read match[i] = the best candidate if its distance is
+ * <= th, so that GetFeaturesInArea runs on the device for them too */
+orbfe_status orbfe_search_by_projection_chi2(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF,
+                                             int32_t nF, const uint32_t *cell_off, const uint32_t *cell_idx, float minx, float miny,
+                                             float gw_inv, float gh_inv, const float *uRight /* nF or NULL */,
+                                             const uint8_t *blocked /* nF or NULL */, const float *inv_level_sigma2 /* nlevels or NULL */,
+                                             int32_t nlevels, const orbfe_proj_query *q, const uint8_t *qdesc /* nq x 32 */, int32_t nq,
+                                             int32_t th, float nnratio, int32_t ratio_rule, int32_t *match, int32_t *best,
+                                             int32_t *second);
 
 /* the matching core of ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:827-1012,
  * LocalMapping::CreateNewMapPoints).  For every feature of keyframe 1 with elig1 (no MapPoint; stereo if bOnlyStereo) whose

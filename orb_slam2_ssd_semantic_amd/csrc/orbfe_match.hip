@@ -1351,6 +1351,8 @@ struct ProjArgs {
     float minx, miny, gwi, ghi;
     const float *uRight;         // may be null
     const uint8_t *blocked;      // may be null
+    const float *inv_sigma2;     // per level, may be null (ORBFE_PROJ_CHI2_GATE then never applies)
+    int32_t nlevels;
     const orbfe_proj_query *q;
     const uint8_t *qdesc;
     int32_t nq, th, ratio_rule;
@@ -1451,11 +1453,25 @@ __global__ __launch_bounds__(256) void k_proj_fill(ProjArgs a)
 #pragma unroll
     for (int k = 0; k < 8; ++k) dq.w[k] = p[k];
     const bool gate = (Q.flags & ORBFE_PROJ_RIGHT_GATE) && a.uRight;
+    const bool chi2 = (Q.flags & ORBFE_PROJ_CHI2_GATE) && a.inv_sigma2;
     proj_walk(a, Q, R, sub, [&](uint32_t f) {
         bool skip = a.blocked && a.blocked[f];                        // :108-110 / :1647-1649, state before the call
         if (!skip && gate) {                                          // :114-119 / :1654-1660
             const float ur = a.uRight[f];
             skip = ur > 0.f && fabsf(__fsub_rn(Q.ur, ur)) > Q.r;
+        }
+        if (!skip && chi2) {                                          // Fuse :1112-1139: reprojection error against the level's sigma
+            const float ex = __fsub_rn(Q.u, a.xyF[(size_t)a.xs * f]), ey = __fsub_rn(Q.v, a.xyF[(size_t)a.xs * f + 1]);
+            float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+            const float kr = a.uRight ? a.uRight[f] : -1.f;
+            const int lv = min(max(a.octF[(size_t)a.os * f], 0), a.nlevels - 1);
+            double bound = 5.99;
+            if (kr >= 0.f) {
+                const float er = __fsub_rn(Q.ur, kr);
+                e2 = __fadd_rn(e2, __fmul_rn(er, er));
+                bound = 7.8;
+            }
+            skip = (double)__fmul_rn(e2, a.inv_sigma2[lv]) > bound;
         }
         const uint32_t d = skip ? PJ_SKIP : (uint32_t)hamming8(dq, (const uint32_t *)(a.descF + (int64_t)f * 32));
         a.ent[o++] = f | (d << 16);
@@ -1541,13 +1557,18 @@ __global__ __launch_bounds__(PJ_T) void k_proj_resolve(ProjArgs a)
     if (tid == 0) a.status[1] = round + 1;
 }
 
-extern "C" orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF,
-                                                   int32_t nF, const uint32_t *cell_off, const uint32_t *cell_idx, float minx,
-                                                   float miny, float gw_inv, float gh_inv, const float *uRight,
-                                                   const uint8_t *blocked, const orbfe_proj_query *q, const uint8_t *qdesc,
-                                                   int32_t nq, int32_t th, float nnratio, int32_t ratio_rule, int32_t *match,
-                                                   int32_t *best, int32_t *second)
+extern "C" orbfe_status orbfe_search_by_projection_chi2(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF,
+                                                        int32_t nF, const uint32_t *cell_off, const uint32_t *cell_idx, float minx,
+                                                        float miny, float gw_inv, float gh_inv, const float *uRight,
+                                                        const uint8_t *blocked, const float *inv_level_sigma2, int32_t nlevels,
+                                                        const orbfe_proj_query *q, const uint8_t *qdesc,
+                                                        int32_t nq, int32_t th, float nnratio, int32_t ratio_rule, int32_t *match,
+                                                        int32_t *best, int32_t *second)
 {
+    if (inv_level_sigma2 && (nlevels < 1 || nlevels > 64)) {
+        orbfe_set_error("bad argument to orbfe_search_by_projection_chi2");
+        return ORBFE_ERR_ARG;
+    }
     if (!m || nF < 0 || nq < 0 || !cell_off || (nq > 0 && (!q || !qdesc || !match)) || (nF > 0 && (!descF || !xyF || !octF)) ||
         (cell_off[GRID_NC] > 0 && !cell_idx)) {   // an empty grid (no keypoint inside the image bounds) has no cell_idx
         orbfe_set_error("bad argument to orbfe_search_by_projection");
@@ -1567,23 +1588,24 @@ extern "C" orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8
     ORBFE_HIP(scratch_acquire(m, st));
     // One pinned staging block in, one out: the per-frame call is latency-bound, nine pageable copies cost more than the
     // kernels.  Layout (256-byte aligned pieces): descF | xyF | octF | cell_off | cell_idx | uRight | blocked | q | qdesc
-    const size_t sz[9] = {(size_t)nF * 32, (size_t)nF * 8, (size_t)nF * 4, (size_t)(GRID_NC + 1) * 4, (size_t)nin * 4,
-                          uRight ? (size_t)nF * 4 : 0, blocked ? (size_t)nF : 0, (size_t)nq * sizeof(orbfe_proj_query), (size_t)nq * 32};
-    const void *src[9] = {descF, xyF, octF, cell_off, cell_idx, uRight, blocked, q, qdesc};
-    size_t at[10];
+    const size_t sz[10] = {(size_t)nF * 32, (size_t)nF * 8, (size_t)nF * 4, (size_t)(GRID_NC + 1) * 4, (size_t)nin * 4,
+                           uRight ? (size_t)nF * 4 : 0, blocked ? (size_t)nF : 0, (size_t)nq * sizeof(orbfe_proj_query), (size_t)nq * 32,
+                           inv_level_sigma2 ? (size_t)nlevels * 4 : 0};
+    const void *src[10] = {descF, xyF, octF, cell_off, cell_idx, uRight, blocked, q, qdesc, inv_level_sigma2};
+    size_t at[11];
     at[0] = 0;
-    for (int i = 0; i < 9; ++i) at[i + 1] = (at[i] + sz[i] + 255) & ~(size_t)255;
+    for (int i = 0; i < 10; ++i) at[i + 1] = (at[i] + sz[i] + 255) & ~(size_t)255;
     const size_t out_bytes = (size_t)nq * 12 + 8;   // match | best | second | status[2]
-    ORBFE_HIP(m->pin_in.ensure(at[9]));
+    ORBFE_HIP(m->pin_in.ensure(at[10]));
     ORBFE_HIP(m->pin_out.ensure(out_bytes));
-    ORBFE_HIP(m->b[0].ensure(at[9]));
+    ORBFE_HIP(m->b[0].ensure(at[10]));
     ORBFE_HIP(m->b[1].ensure(out_bytes));
     ORBFE_HIP(m->b[2].ensure((size_t)nq * 4));                 // cnt
     ORBFE_HIP(m->b[3].ensure((size_t)nq * PJ_LC * 2));         // lcnt
     ORBFE_HIP(m->b[4].ensure((size_t)(nq + 1) * 4));           // off
-    for (int i = 0; i < 9; ++i)
+    for (int i = 0; i < 10; ++i)
         if (sz[i]) memcpy((char *)m->pin_in.p + at[i], src[i], sz[i]);
-    ORBFE_HIP(hipMemcpyAsync(m->b[0].p, m->pin_in.p, at[9], hipMemcpyHostToDevice, st));
+    ORBFE_HIP(hipMemcpyAsync(m->b[0].p, m->pin_in.p, at[10], hipMemcpyHostToDevice, st));
     const char *din = (const char *)m->b[0].p;
     ProjArgs a;
     a.descF = (const uint8_t *)(din + at[0]);
@@ -1595,6 +1617,8 @@ extern "C" orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8
     a.minx = minx; a.miny = miny; a.gwi = gw_inv; a.ghi = gh_inv;
     a.uRight = uRight ? (const float *)(din + at[5]) : nullptr;
     a.blocked = blocked ? (const uint8_t *)(din + at[6]) : nullptr;
+    a.inv_sigma2 = inv_level_sigma2 ? (const float *)(din + at[9]) : nullptr;
+    a.nlevels = nlevels;
     a.q = (const orbfe_proj_query *)(din + at[7]);
     a.qdesc = (const uint8_t *)(din + at[8]);
     a.nq = nq; a.th = th; a.ratio_rule = ratio_rule ? 1 : 0; a.nnratio = nnratio;
@@ -1630,6 +1654,17 @@ extern "C" orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8
     if (best) memcpy(best, hout + nq, (size_t)nq * 4);
     if (second) memcpy(second, hout + 2 * (size_t)nq, (size_t)nq * 4);
     return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF,
+                                                   int32_t nF, const uint32_t *cell_off, const uint32_t *cell_idx, float minx,
+                                                   float miny, float gw_inv, float gh_inv, const float *uRight,
+                                                   const uint8_t *blocked, const orbfe_proj_query *q, const uint8_t *qdesc,
+                                                   int32_t nq, int32_t th, float nnratio, int32_t ratio_rule, int32_t *match,
+                                                   int32_t *best, int32_t *second)
+{
+    return orbfe_search_by_projection_chi2(m, descF, xyF, octF, nF, cell_off, cell_idx, minx, miny, gw_inv, gh_inv, uRight, blocked,
+                                           nullptr, 0, q, qdesc, nq, th, nnratio, ratio_rule, match, best, second);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -151,7 +151,8 @@ class ORBmatcher:
                                            ptr(si)), "orbfe_hamming_csr_ex")
         return bi, b, s, si
 
-    def SearchByProjectionCore(self, descF, xyF, octF, grid, bounds, uRight, blocked, queries, qdesc, th, nnratio, ratio_rule):
+    def SearchByProjectionCore(self, descF, xyF, octF, grid, bounds, uRight, blocked, queries, qdesc, th, nnratio, ratio_rule,
+                               inv_level_sigma2=None):
         """orbfe_search_by_projection: the device core of ORBmatcher::SearchByProjection (Frame&, const Frame&, th, bMono)
         (src/ORBmatcher.cc:1578-1724) and (Frame&, const vector<MapPoint*>&, th) (:63-157).  grid = (cell_off, cell_idx) of
         the frame, bounds = (minx, miny, gw_inv, gh_inv), queries: PROJ_QUERY_DTYPE records, one per MapPoint that passed the
@@ -166,6 +167,13 @@ class ORBmatcher:
         qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
         assert len(qd) == len(q) and len(xyF) == len(descF) == len(octF)
         m, b, s2 = (np.full(len(q), -1, np.int32) for _ in range(3))
+        if inv_level_sigma2 is not None:   # queries may carry ORBFE_PROJ_CHI2_GATE (Fuse, src/ORBmatcher.cc:1112-1139)
+            is2 = np.ascontiguousarray(inv_level_sigma2, np.float32)
+            _ffi.check(_ffi.lib().orbfe_search_by_projection_chi2(
+                self.handle, _ffi.ptr(descF), _ffi.ptr(xyF), _ffi.ptr(octF), len(descF), _ffi.ptr(off), _ffi.ptr(idx),
+                *[float(v) for v in bounds], _ffi.ptr(uR), _ffi.ptr(bl), _ffi.ptr(is2), len(is2), _ffi.ptr(q), _ffi.ptr(qd), len(q),
+                int(th), float(nnratio), int(ratio_rule), _ffi.ptr(m), _ffi.ptr(b), _ffi.ptr(s2)), "orbfe_search_by_projection_chi2")
+            return m, b, s2
         _ffi.check(_ffi.lib().orbfe_search_by_projection(self.handle, _ffi.ptr(descF), _ffi.ptr(xyF), _ffi.ptr(octF), len(descF),
                                                          _ffi.ptr(off), _ffi.ptr(idx), *[float(v) for v in bounds], _ffi.ptr(uR),
                                                          _ffi.ptr(bl), _ffi.ptr(q), _ffi.ptr(qd), len(q), int(th), float(nnratio),

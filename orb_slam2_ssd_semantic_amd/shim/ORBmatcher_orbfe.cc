@@ -22,10 +22,11 @@
 // One pattern throughout: the pose projection and its gates run here, on cv::Mat, statement for statement as in the
 // reference; the candidate scans (GetFeaturesInArea + Hamming + whatever rule couples the queries) are ONE device call per
 // invocation; the assignments / Replace / AddMapPoint decisions and the rotation histogram are replayed from its result, in
-// the reference's order, on the live objects.  The device call is orbfe_search_by_projection for the four SearchByProjection
-// members (it also resolves the "slot already taken by an earlier query" rule), orbfe_search_for_triangulation,
-// orbfe_search_by_bow, orbfe_hamming_csr for Fuse x2 / SearchBySim3 (no query looks at another's result) and
-// orbfe_hamming_csr_all for SearchForInitialization (whose rule needs every distance).
+// the reference's order, on the live objects.  The device call is orbfe_search_by_projection(_chi2) for the four
+// SearchByProjection members (it also resolves the "slot already taken by an earlier query" rule) and for Fuse x2 /
+// SearchBySim3 (independent queries on a KeyFrame's grid; Fuse's reprojection-error gate is ORBFE_PROJ_CHI2_GATE),
+// orbfe_search_for_triangulation, orbfe_search_by_bow, and orbfe_hamming_csr_all for SearchForInitialization (whose rule
+// needs every distance, so its windows are gathered here).
 // Integration: add this file to the ORB_SLAM2 library in place of src/ORBmatcher.cc (-DORBFE_SHIM_STANDALONE), or next to it
 // with the bodies listed above deleted (or #if 0), and link liborbfe.so.  The class gets no new data member:
 // the device matcher handle is per thread, which is also what the C-ABI asks for (Tracking, LocalMapping and LoopClosing call
@@ -129,8 +130,8 @@ struct FrameSide {
             }
         desc = Rows(F.mDescriptors, tmp);
     }
-    // a KeyFrame as the searched side (:378-470): slots taken = vpMatched[idx] != NULL
-    FrameSide(ORB_SLAM2::KeyFrame *pKF, const std::vector<ORB_SLAM2::MapPoint *> &vpMatched)
+    // a KeyFrame as the searched side (:378-470): slots taken = vpMatched[idx] != NULL (none for Fuse / SearchBySim3)
+    FrameSide(ORB_SLAM2::KeyFrame *pKF, const std::vector<ORB_SLAM2::MapPoint *> *vpMatched)
     {
         const size_t n = pKF->mvKeysUn.size();
         xy.resize(2 * n);
@@ -140,7 +141,7 @@ struct FrameSide {
             xy[2 * i] = pKF->mvKeysUn[i].pt.x;
             xy[2 * i + 1] = pKF->mvKeysUn[i].pt.y;
             oct[i] = pKF->mvKeysUn[i].octave;
-            blocked[i] = vpMatched[i] != NULL;
+            blocked[i] = vpMatched && (*vpMatched)[i] != NULL;
         }
         cell_off.reserve(ORBFE_GRID_COLS * ORBFE_GRID_ROWS + 1);
         cell_off.push_back(0);
@@ -188,6 +189,22 @@ void RunSearch(ORB_SLAM2::Frame &F, const Queries &qs, int th, float nnratio, in
         F.mvuRight.empty() ? NULL : F.mvuRight.data(), fs.blocked.data(), qs.q.data(), qs.desc.data(), (int32_t)qs.q.size(), th, nnratio,
         ratio_rule, match.data(), NULL, NULL);
     if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbfe): ") + orbfe_last_error());
+}
+// Independent queries on a KeyFrame's grid (Fuse x2, SearchBySim3): KeyFrame::GetFeaturesInArea, the level window, the
+// optional reprojection-error gate and the Hamming scan in one device call; match[k] = the best candidate (first in the
+// reference's order on ties) if its distance is <= th, else -1.  No query looks at another one's result.
+void RunKeyFrameSearch(ORB_SLAM2::KeyFrame *pKF, const Queries &qs, int th, bool chi2_gate, std::vector<int32_t> &match, const char *who)
+{
+    match.assign(qs.q.size(), -1);
+    if (qs.q.empty() || pKF->mvKeysUn.empty()) return;
+    FrameSide fs(pKF, NULL);
+    const orbfe_status s = orbfe_search_by_projection_chi2(
+        t_matcher.get(), fs.desc, fs.xy.data(), fs.oct.data(), (int32_t)pKF->mvKeysUn.size(), fs.cell_off.data(), fs.cell_idx.data(),
+        (float)pKF->mnMinX, (float)pKF->mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv,
+        chi2_gate ? pKF->mvuRight.data() : NULL, NULL, chi2_gate ? pKF->mvInvLevelSigma2.data() : NULL,
+        chi2_gate ? (int32_t)pKF->mvInvLevelSigma2.size() : 0, qs.q.data(), qs.desc.data(), (int32_t)qs.q.size(), th, 0.f, 0, match.data(),
+        NULL, NULL);
+    if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::") + who + " (orbfe): " + orbfe_last_error());
 }
 }  // namespace
 
@@ -327,7 +344,7 @@ int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector
     }
     std::vector<int32_t> match(qs.q.size(), -1);
     if (!qs.q.empty() && !pKF->mvKeysUn.empty()) {
-        FrameSide fs(pKF, vpMatched);
+        FrameSide fs(pKF, &vpMatched);
         const orbfe_status s = orbfe_search_by_projection(
             t_matcher.get(), fs.desc, fs.xy.data(), fs.oct.data(), (int32_t)pKF->mvKeysUn.size(), fs.cell_off.data(), fs.cell_idx.data(),
             (float)pKF->mnMinX, (float)pKF->mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv, NULL, fs.blocked.data(),
@@ -526,10 +543,9 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, 
     const float &bf = pKF->mbf;
     cv::Mat Ow = pKF->GetCameraCenter();
     const int nMPs = (int)vpMapPoints.size();
-    // ---- phase 1: every gate that does not depend on what the loop mutates (:1060-1143), candidate lists as CSR ----
-    std::vector<uint32_t> off(1, 0), cand;
-    std::vector<uint8_t> qdesc;
-    std::vector<int> slot((size_t)nMPs, -1);  // query index of MapPoint i, -1 = gated out / no candidates
+    // ---- phase 1: every gate that does not depend on what the loop mutates (:1060-1101); one query per point that passes ----
+    Queries qs;
+    std::vector<int> slot((size_t)nMPs, -1);  // query index of MapPoint i, -1 = gated out
     for (int i = 0; i < nMPs; i++) {
         MapPoint *pMP = vpMapPoints[i];
         if (!pMP) continue;
@@ -542,6 +558,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, 
         const float u = fx * x + cx;
         const float v = fy * y + cy;
         if (!pKF->IsInImage(u, v)) continue;  // :1080
+        const float ur = u - bf * invz;  // :1124
         const float maxDistance = pMP->GetMaxDistanceInvariance();
         const float minDistance = pMP->GetMinDistanceInvariance();
         cv::Mat PO = p3Dw - Ow;
@@ -551,49 +568,13 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, 
         if (PO.dot(Pn) < 0.5 * dist3D) continue;  // :1096
         int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
         const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
-        const std::vector<size_t> vIndices = pKF->GetFeaturesInArea(u, v, radius);  // :1103
-        if (vIndices.empty()) continue;
-        const size_t before = cand.size();
-        for (std::vector<size_t>::const_iterator vit = vIndices.begin(), vend = vIndices.end(); vit != vend; vit++) {
-            const size_t idx = *vit;
-            const cv::KeyPoint &kp = pKF->mvKeysUn[idx];
-            const int &kpLevel = kp.octave;
-            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;  // :1119
-            if (pKF->mvuRight[idx] >= 0) {  // :1122-1135
-                const float ur = u - bf * invz;
-                const float &kpx = kp.pt.x;
-                const float &kpy = kp.pt.y;
-                const float &kpr = pKF->mvuRight[idx];
-                const float ex = u - kpx;
-                const float ey = v - kpy;
-                const float er = ur - kpr;
-                const float e2 = ex * ex + ey * ey + er * er;
-                if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 7.8) continue;
-            } else {  // :1137-1145
-                const float &kpx = kp.pt.x;
-                const float &kpy = kp.pt.y;
-                const float ex = u - kpx;
-                const float ey = v - kpy;
-                const float e2 = ex * ex + ey * ey;
-                if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 5.99) continue;
-            }
-            cand.push_back((uint32_t)idx);
-        }
-        if (cand.size() == before) continue;  // no candidate passed: bestDist stays 256 (:1159)
-        slot[(size_t)i] = (int)off.size() - 1;
-        off.push_back((uint32_t)cand.size());
-        const cv::Mat dMP = pMP->GetDescriptor();
-        qdesc.insert(qdesc.end(), dMP.ptr<uint8_t>(0), dMP.ptr<uint8_t>(0) + 32);
+        // :1103 GetFeaturesInArea(u, v, radius), :1119 the level window, :1122-1145 the reprojection-error gate: on the device
+        slot[(size_t)i] = (int)qs.q.size();
+        qs.Add(pMP, i, u, v, radius, nPredictedLevel - 1, nPredictedLevel, ur, ORBFE_PROJ_CHI2_GATE);
     }
-    // ---- the Hamming work: best candidate per point, first in list order on ties (:1149-1156) ----
-    const int nq = (int)off.size() - 1;
-    std::vector<int32_t> bestIdx((size_t)std::max(nq, 1), -1), best((size_t)std::max(nq, 1), 256), second((size_t)std::max(nq, 1), 256);
-    if (nq > 0) {
-        std::vector<uint8_t> tmp;
-        const orbfe_status s = orbfe_hamming_csr(t_matcher.get(), qdesc.data(), nq, Rows(pKF->mDescriptors, tmp), pKF->mDescriptors.rows,
-                                                 off.data(), cand.data(), bestIdx.data(), best.data(), second.data());
-        if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::Fuse (orbfe): ") + orbfe_last_error());
-    }
+    // ---- the candidate scans: best candidate per point, first in list order on ties (:1149-1156), accepted at TH_LOW ----
+    std::vector<int32_t> bestIdx;
+    RunKeyFrameSearch(pKF, qs, TH_LOW, true, bestIdx, "Fuse");
     // ---- phase 2: the loop's decisions, in order, on the live objects (:1049-1056, :1159-1180) ----
     int nFused = 0;
     for (int i = 0; i < nMPs; i++) {
@@ -602,7 +583,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, 
         if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
         if (slot[(size_t)i] < 0) continue;
         const int k = slot[(size_t)i];
-        if (best[(size_t)k] <= TH_LOW) {
+        if (bestIdx[(size_t)k] >= 0) {  // :1159 bestDist <= TH_LOW
             MapPoint *pMPinKF = pKF->GetMapPoint((size_t)bestIdx[(size_t)k]);
             if (pMPinKF) {
                 if (!pMPinKF->isBad()) {
@@ -634,8 +615,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &
     cv::Mat Ow = -Rcw.t() * tcw;
     const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();  // :1212, fixed for the whole loop
     const int nPoints = (int)vpPoints.size();
-    std::vector<uint32_t> off(1, 0), cand;
-    std::vector<uint8_t> qdesc;
+    Queries qs;
     std::vector<int> slot((size_t)nPoints, -1);
     for (int iMP = 0; iMP < nPoints; iMP++) {
         MapPoint *pMP = vpPoints[iMP];
@@ -659,34 +639,17 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &
         if (PO.dot(Pn) < 0.5 * dist3D) continue;
         int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
         const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
-        const std::vector<size_t> vIndices = pKF->GetFeaturesInArea(u, v, radius);
-        if (vIndices.empty()) continue;
-        const size_t before = cand.size();
-        for (std::vector<size_t>::const_iterator vit = vIndices.begin(); vit != vIndices.end(); vit++) {
-            const size_t idx = *vit;
-            const int &kpLevel = pKF->mvKeysUn[idx].octave;
-            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;  // :1268
-            cand.push_back((uint32_t)idx);
-        }
-        if (cand.size() == before) continue;
-        slot[(size_t)iMP] = (int)off.size() - 1;
-        off.push_back((uint32_t)cand.size());
-        const cv::Mat dMP = pMP->GetDescriptor();
-        qdesc.insert(qdesc.end(), dMP.ptr<uint8_t>(0), dMP.ptr<uint8_t>(0) + 32);
+        // :1257 GetFeaturesInArea(u, v, radius) and the level window of :1268 run on the device
+        slot[(size_t)iMP] = (int)qs.q.size();
+        qs.Add(pMP, iMP, u, v, radius, nPredictedLevel - 1, nPredictedLevel, 0.f, 0);
     }
-    const int nq = (int)off.size() - 1;
-    std::vector<int32_t> bestIdx((size_t)std::max(nq, 1), -1), best((size_t)std::max(nq, 1), 256), second((size_t)std::max(nq, 1), 256);
-    if (nq > 0) {
-        std::vector<uint8_t> tmp;
-        const orbfe_status s = orbfe_hamming_csr(t_matcher.get(), qdesc.data(), nq, Rows(pKF->mDescriptors, tmp), pKF->mDescriptors.rows,
-                                                 off.data(), cand.data(), bestIdx.data(), best.data(), second.data());
-        if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::Fuse (orbfe): ") + orbfe_last_error());
-    }
+    std::vector<int32_t> bestIdx;
+    RunKeyFrameSearch(pKF, qs, TH_LOW, false, bestIdx, "Fuse");
     int nFused = 0;
     for (int iMP = 0; iMP < nPoints; iMP++) {  // :1282-1296 on the live objects, in order
         if (slot[(size_t)iMP] < 0) continue;
         const int k = slot[(size_t)iMP];
-        if (best[(size_t)k] <= TH_LOW) {
+        if (bestIdx[(size_t)k] >= 0) {  // :1281 bestDist <= TH_LOW
             MapPoint *pMP = vpPoints[iMP];
             MapPoint *pMPinKF = pKF->GetMapPoint((size_t)bestIdx[(size_t)k]);
             if (pMPinKF) {
@@ -702,8 +665,8 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &
 }
 
 // src/ORBmatcher.cc:1334-1516 (LoopClosing::ComputeSim3): the points of each keyframe are searched in the other one under the
-// candidate similarity, a match is kept when both directions agree.  No decision depends on an earlier one, so both
-// directions go to the device in ONE CSR call over the concatenated descriptor rows (pKF2's rows first).
+// candidate similarity, a match is kept when both directions agree.  No decision depends on an earlier one: each direction
+// is one device call (window search on the other keyframe's grid + Hamming).
 int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12,
                              const cv::Mat &t12, const float th)
 {
@@ -731,13 +694,11 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoin
             if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[(size_t)idx2] = true;
         }
     }
-    const int nrows2 = pKF2->mDescriptors.rows, nrows1 = pKF1->mDescriptors.rows;
-    std::vector<uint32_t> off(1, 0), cand;
-    std::vector<uint8_t> qdesc;
-    std::vector<int> slot1((size_t)N1, -1), slot2((size_t)N2, -1);
-    // one direction: the points of keyframe A (pose Raw, taw) are taken into keyframe B by (sRba, tba) and looked up there
-    auto gather = [&](const std::vector<MapPoint *> &pts, const std::vector<bool> &already, const cv::Mat &Raw, const cv::Mat &taw,
-                      const cv::Mat &sRba, const cv::Mat &tba, KeyFrame *pKFb, uint32_t row0, std::vector<int> &slot) {
+    // one direction: the points of keyframe A (pose Raw, taw) are taken into keyframe B by (sRba, tba) and looked up there;
+    // GetFeaturesInArea on B's grid, the level window and the Hamming scan are one device call per direction
+    auto search = [&](const std::vector<MapPoint *> &pts, const std::vector<bool> &already, const cv::Mat &Raw, const cv::Mat &taw,
+                      const cv::Mat &sRba, const cv::Mat &tba, KeyFrame *pKFb, std::vector<int> &vnMatch) {
+        Queries qs;
         for (int i = 0; i < (int)pts.size(); i++) {
             MapPoint *pMP = pts[(size_t)i];
             if (!pMP || already[(size_t)i]) continue;
@@ -758,39 +719,16 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoin
             if (dist3D < minDistance || dist3D > maxDistance) continue;
             const int nPredictedLevel = pMP->PredictScale(dist3D, pKFb);
             const float radius = th * pKFb->mvScaleFactors[nPredictedLevel];
-            const std::vector<size_t> vIndices = pKFb->GetFeaturesInArea(u, v, radius);
-            if (vIndices.empty()) continue;
-            const size_t before = cand.size();
-            for (std::vector<size_t>::const_iterator vit = vIndices.begin(), vend = vIndices.end(); vit != vend; vit++) {
-                const size_t idx = *vit;
-                const cv::KeyPoint &kp = pKFb->mvKeysUn[idx];
-                if (kp.octave < nPredictedLevel - 1 || kp.octave > nPredictedLevel) continue;
-                cand.push_back(row0 + (uint32_t)idx);
-            }
-            if (cand.size() == before) continue;
-            slot[(size_t)i] = (int)off.size() - 1;
-            off.push_back((uint32_t)cand.size());
-            const cv::Mat dMP = pMP->GetDescriptor();
-            qdesc.insert(qdesc.end(), dMP.ptr<uint8_t>(0), dMP.ptr<uint8_t>(0) + 32);
+            qs.Add(pMP, i, u, v, radius, nPredictedLevel - 1, nPredictedLevel, 0.f, 0);
         }
+        std::vector<int32_t> best;
+        RunKeyFrameSearch(pKFb, qs, TH_HIGH, false, best, "SearchBySim3");
+        for (size_t k = 0; k < best.size(); ++k)
+            if (best[k] >= 0) vnMatch[(size_t)qs.src[k]] = best[k];  // bestDist <= TH_HIGH (:1451, :1527)
     };
-    gather(vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2, 0u, slot1);               // :1380-1453
-    gather(vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, pKF1, (uint32_t)nrows2, slot2);  // :1455-1529
-    const int nq = (int)off.size() - 1;
-    std::vector<int32_t> bestIdx((size_t)std::max(nq, 1), -1), best((size_t)std::max(nq, 1), 256), second((size_t)std::max(nq, 1), 256);
-    if (nq > 0) {
-        std::vector<uint8_t> rows((size_t)(nrows1 + nrows2) * 32), tmp;
-        if (nrows2 > 0) memcpy(rows.data(), Rows(pKF2->mDescriptors, tmp), (size_t)nrows2 * 32);
-        if (nrows1 > 0) memcpy(rows.data() + (size_t)nrows2 * 32, Rows(pKF1->mDescriptors, tmp), (size_t)nrows1 * 32);
-        const orbfe_status st = orbfe_hamming_csr(t_matcher.get(), qdesc.data(), nq, rows.data(), nrows1 + nrows2, off.data(), cand.data(),
-                                                  bestIdx.data(), best.data(), second.data());
-        if (st != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchBySim3 (orbfe): ") + orbfe_last_error());
-    }
     std::vector<int> vnMatch1((size_t)N1, -1), vnMatch2((size_t)N2, -1);
-    for (int i1 = 0; i1 < N1; i1++)
-        if (slot1[(size_t)i1] >= 0 && best[(size_t)slot1[(size_t)i1]] <= TH_HIGH) vnMatch1[(size_t)i1] = bestIdx[(size_t)slot1[(size_t)i1]];
-    for (int i2 = 0; i2 < N2; i2++)
-        if (slot2[(size_t)i2] >= 0 && best[(size_t)slot2[(size_t)i2]] <= TH_HIGH) vnMatch2[(size_t)i2] = bestIdx[(size_t)slot2[(size_t)i2]] - nrows2;
+    search(vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2, vnMatch1);  // :1380-1453
+    search(vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, pKF1, vnMatch2);  // :1455-1529
     int nFound = 0;
     for (int i1 = 0; i1 < N1; i1++) {  // :1532-1545
         int idx2 = vnMatch1[(size_t)i1];
