@@ -92,6 +92,7 @@ def lib():
     L.orc_distinctive.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp]
     cf, ci = C.c_float, C.c_int
     L.orc_search_by_projection.argtypes = [vp, vp, vp, ci, vp, vp, cf, cf, cf, cf, vp, vp, vp, vp, ci, ci, cf, ci, vp, vp, vp]
+    L.orc_search_by_projection_chi2.argtypes = [vp, vp, vp, ci, vp, vp, cf, cf, cf, cf, vp, vp, vp, ci, vp, vp, ci, ci, cf, ci, vp, vp, vp]
     L.orc_proj_queries_last_frame.argtypes = [vp, vp] + [cf] * 10 + [vp, ci, vp, vp, vp, vp, vp, cf, ci, ci, vp, vp]
     L.orc_proj_queries_local_map.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp]
     L.orc_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, cf, cf, vp, vp, ci, vp]
@@ -449,9 +450,10 @@ PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_lev
                              ("ur", "<f4"), ("flags", "<i4"), ("pad", "<i4")])
 
 
-def search_by_projection(descF, xyF, octF, grid, bounds, uRight, blocked, queries, qdesc, th, nnratio, ratio_rule):
-    """orc_search_by_projection: grid = (cell_off, cell_idx), bounds = (minx, miny, gw_inv, gh_inv); returns
-    (match[nq], best[nq], second[nq])"""
+def search_by_projection(descF, xyF, octF, grid, bounds, uRight, blocked, queries, qdesc, th, nnratio, ratio_rule,
+                         inv_level_sigma2=None):
+    """orc_search_by_projection(_chi2): grid = (cell_off, cell_idx), bounds = (minx, miny, gw_inv, gh_inv); inv_level_sigma2
+    switches the reprojection-error gate on for the queries with flag 4; returns (match[nq], best[nq], second[nq])"""
     descF = np.ascontiguousarray(descF, np.uint8).reshape(-1, 32)
     xyF = np.ascontiguousarray(xyF, np.float32).reshape(-1, 2)
     octF = np.ascontiguousarray(octF, np.int32)
@@ -462,9 +464,10 @@ def search_by_projection(descF, xyF, octF, grid, bounds, uRight, blocked, querie
     qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
     assert len(qd) == len(q)
     m, b, s2 = (np.zeros(len(q), np.int32) for _ in range(3))
-    rc = lib().orc_search_by_projection(_p(descF), _p(xyF), _p(octF), len(descF), _p(off), _p(idx), *[float(v) for v in bounds],
-                                        _p(uR), _p(bl), _p(q), _p(qd), len(q), int(th), float(nnratio), int(ratio_rule),
-                                        _p(m), _p(b), _p(s2))
+    is2 = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+    rc = lib().orc_search_by_projection_chi2(_p(descF), _p(xyF), _p(octF), len(descF), _p(off), _p(idx), *[float(v) for v in bounds],
+                                             _p(uR), _p(bl), _p(is2), 0 if is2 is None else len(is2), _p(q), _p(qd), len(q), int(th),
+                                             float(nnratio), int(ratio_rule), _p(m), _p(b), _p(s2))
     assert rc == 0
     return m, b, s2
 

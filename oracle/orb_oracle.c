@@ -1164,6 +1164,19 @@ int orc_search_by_projection(const uint8_t *descF, const float *xyF, const int32
                              const float *uRight, const uint8_t *blocked, const orc_proj_query *q, const uint8_t *qdesc,
                              int nq, int th, float nnratio, int ratio_rule, int32_t *match, int32_t *best, int32_t *second)
 {
+    return orc_search_by_projection_chi2(descF, xyF, octF, nF, cell_off, cell_idx, minx, miny, gw_inv, gh_inv, uRight, blocked, 0, 0, q,
+                                         qdesc, nq, th, nnratio, ratio_rule, match, best, second);
+}
+
+/* the same loop with Fuse's candidate gate (src/ORBmatcher.cc:1112-1139) on the queries that carry flag 4: a candidate is
+ * skipped when its reprojection error e2 * mvInvLevelSigma2[octave] exceeds 7.8 (mvuRight[idx] >= 0, three terms) or 5.99
+ * (monocular keypoint, two terms); float arithmetic term by term, the bound compared in double as `float > 7.8` does */
+int orc_search_by_projection_chi2(const uint8_t *descF, const float *xyF, const int32_t *octF, int nF, const uint32_t *cell_off,
+                                  const uint32_t *cell_idx, float minx, float miny, float gw_inv, float gh_inv,
+                                  const float *uRight, const uint8_t *blocked, const float *inv_sigma2, int nlevels,
+                                  const orc_proj_query *q, const uint8_t *qdesc, int nq, int th, float nnratio, int ratio_rule,
+                                  int32_t *match, int32_t *best, int32_t *second)
+{
     if (nF < 0 || nq < 0 || th > 255) return -1; /* th = TH_HIGH / ORBdist (<= 100 in the reference): 256 is "no candidate" */
     uint8_t *taken = (uint8_t *)calloc((size_t)(nF > 0 ? nF : 1), 1); /* slot holds a MapPoint with Observations() > 0 */
     uint32_t *cand = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nF > 0 ? nF : 1));
@@ -1184,6 +1197,18 @@ int orc_search_by_projection(const uint8_t *descF, const float *xyF, const int32
             if ((Q->flags & 2) && uRight && uRight[idx] > 0) { /* :114-119 / :1654-1660 */
                 const float er = fabsf(Q->ur - uRight[idx]);
                 if (er > Q->r) continue;
+            }
+            if ((Q->flags & 4) && inv_sigma2) {
+                const float ex = Q->u - xyF[2 * idx], ey = Q->v - xyF[2 * idx + 1];
+                const int lv = octF[idx] < 0 ? 0 : (octF[idx] >= nlevels ? nlevels - 1 : octF[idx]);
+                if (uRight && uRight[idx] >= 0) {
+                    const float er = Q->ur - uRight[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_sigma2[lv] > 7.8) continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_sigma2[lv] > 5.99) continue;
+                }
             }
             const int dist = orc_hamming(qdesc + (size_t)i * 32, descF + (size_t)idx * 32);
             if (dist < bestDist) { /* :128-140 */

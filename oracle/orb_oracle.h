@@ -190,6 +190,11 @@ int orc_search_by_projection(const uint8_t *descF, const float *xyF, const int32
                              const float *uRight /* nF or NULL */, const uint8_t *blocked /* nF or NULL */,
                              const orc_proj_query *q, const uint8_t *qdesc, int nq, int th, float nnratio, int ratio_rule,
                              int32_t *match, int32_t *best, int32_t *second);
+int orc_search_by_projection_chi2(const uint8_t *descF, const float *xyF, const int32_t *octF, int nF, const uint32_t *cell_off,
+                                  const uint32_t *cell_idx, float minx, float miny, float gw_inv, float gh_inv,
+                                  const float *uRight, const uint8_t *blocked, const float *inv_sigma2, int nlevels,
+                                  const orc_proj_query *q, const uint8_t *qdesc, int nq, int th, float nnratio, int ratio_rule,
+                                  int32_t *match, int32_t *best, int32_t *second);
 /* The reference's host steps in front of that core, restated with the float operation order of the code as compiled
  * against oracle/refbuild's cv stub (cv::Mat products accumulate in float, k ascending; real OpenCV's gemm accumulates
  * floats in double -- gemm_double = 1 -- the product's shim uses whatever cv::Mat it is linked with):

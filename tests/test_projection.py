@@ -57,6 +57,39 @@ def test_core_equals_oracle_on_tracker_shaped_cases(mat):
 
 
 @pytest.mark.gpu
+def test_core_reprojection_error_gate_equals_oracle(mat):
+    """ORBFE_PROJ_CHI2_GATE (Fuse's candidate gate, src/ORBmatcher.cc:1112-1139) in the device core against the oracle's loop:
+    queries that land near features with sub-pixel to several-pixel offsets, stereo and monocular keypoints, all octaves,
+    mixed with queries without the flag.  The reference-side anchor of the flag is the Fuse shim test below (the shim's Fuse
+    runs through this path and equals the reference's compiled body)."""
+    tot = 0
+    for seed in range(40):
+        rng = np.random.default_rng(33_000 + seed)
+        nF, nq = int(rng.choice([1, 30, 300, 1000, 2000])), int(rng.choice([1, 40, 400, 2000]))
+        cur = PC.current_frame(rng, nF)
+        sf = cur["scale_factors"]
+        is2 = (1.0 / (sf * sf)).astype(np.float32)
+        tgt = rng.integers(0, nF, nq)
+        q = np.zeros(nq, O.PROJ_QUERY_DTYPE)
+        off = rng.normal(0, 1, (nq, 2)) * rng.choice([0.3, 1.5, 2.5, 6.0], (nq, 1)) * sf[cur["octave"][tgt]][:, None]
+        q["u"], q["v"] = (cur["xy"][tgt, 0] + off[:, 0]).astype(np.float32), (cur["xy"][tgt, 1] + off[:, 1]).astype(np.float32)
+        lvl = cur["octave"][tgt] + rng.choice([0, 0, 1], nq)
+        q["r"] = (rng.choice([3.0, 5.0], nq) * sf[np.clip(lvl, 0, 7)]).astype(np.float32)
+        q["min_level"], q["max_level"] = lvl - 1, lvl
+        q["ur"] = (np.where(cur["uRight"][tgt] >= 0, cur["uRight"][tgt], q["u"] - 20) + rng.normal(0, 1.5, nq)).astype(np.float32)
+        q["flags"] = np.where(rng.random(nq) < 0.85, 4, 0)
+        qd = PC.noisy_copy(rng, cur["desc"][tgt], 60)
+        ci = PC.core_inputs(cur)
+        ci["blocked"] = None
+        om = O.search_by_projection(queries=q, qdesc=qd, th=50, nnratio=0.0, ratio_rule=0, inv_level_sigma2=is2, **ci)
+        gm = mat.SearchByProjectionCore(queries=q, qdesc=qd, th=50, nnratio=0.0, ratio_rule=0, inv_level_sigma2=is2, **ci)
+        nogate = O.search_by_projection(queries=q, qdesc=qd, th=50, nnratio=0.0, ratio_rule=0, **ci)
+        assert all(np.array_equal(a, b) for a, b in zip(om, gm)), seed
+        tot += int((om[0] != nogate[0]).sum())
+    assert tot > 200   # the gate changed that many decisions
+
+
+@pytest.mark.gpu
 def test_core_long_dependency_chains(mat):
     """Every query wants the same few slots: query i can only settle after all earlier claiming queries have -- the device's
     relaxation needs as many rounds as the chain is long and must still land on the sequential result."""
