@@ -357,6 +357,15 @@ orbfe_status orbfe_search_by_projection_chi2(orbfe_matcher *m, const uint8_t *de
                                              int32_t th, float nnratio, int32_t ratio_rule, int32_t *match, int32_t *best,
                                              int32_t *second);
 
+/* The window search and the distances alone, as lists: off[nq + 1], ent[off[nq]] with ent = feature | distance << 16 in the
+ * reference's candidate order (GetFeaturesInArea's cell walk); flags / ur of the queries are ignored.  ORBFE_ERR_CAP (off[nq] =
+ * the size needed) when cap is too small.  ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:523-651) runs its in-order
+ * rule -- a candidate held by an earlier query at a smaller distance is skipped, :571-574 -- on these lists.  HOST buffers. */
+orbfe_status orbfe_window_distances(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF, int32_t nF,
+                                    const uint32_t *cell_off, const uint32_t *cell_idx, float minx, float miny, float gw_inv,
+                                    float gh_inv, const orbfe_proj_query *q, const uint8_t *qdesc, int32_t nq, uint32_t *off,
+                                    uint32_t *ent, int32_t cap);
+
 /* the matching core of ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:827-1012,
  * LocalMapping::CreateNewMapPoints).  For every feature of keyframe 1 with elig1 (no MapPoint; stereo if bOnlyStereo) whose
  * vocabulary node also exists in keyframe 2: over that node's keyframe-2 features in FeatureVector order, the ones with elig2

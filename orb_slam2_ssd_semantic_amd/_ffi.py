@@ -33,7 +33,7 @@ SYMBOLS = (
     "orbfe_mapio_keyframe_bytes", "orbfe_mapio_write_keyframe", "orbfe_mapio_read_keyframe", "orbfe_mapio_pack_records_device",
     "orbfe_vocfile_load", "orbfe_vocfile_free", "orbfe_vocfile_info", "orbfe_vocfile_arrays", "orbfe_vocfile_save_binary",
     "orbfe_vocabulary_create_from_file", "orbfe_interleaved_to_gray_device", "orbfe_hamming_csr_ex", "orbfe_hamming_csr_device",
-    "orbfe_hamming_csr_all", "orbfe_search_by_projection_chi2",
+    "orbfe_hamming_csr_all", "orbfe_search_by_projection_chi2", "orbfe_window_distances",
     "orbfe_search_by_projection", "orbfe_search_for_triangulation",
     "orbfe_group_shard_range", "orbfe_group_unique_id", "orbfe_group_create_local", "orbfe_group_create_rank", "orbfe_group_destroy",
     "orbfe_group_world", "orbfe_group_capacity", "orbfe_group_frames_padded", "orbfe_group_block_index", "orbfe_group_extract_batch",
@@ -149,6 +149,7 @@ def lib():
     L.orbfe_features_in_area.argtypes = [vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, i32, vp, vp, i32]
     L.orbfe_search_by_projection.argtypes = [vp, vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp, vp, i32, i32, f32, i32, vp, vp, vp]
     L.orbfe_search_by_projection_chi2.argtypes = [vp, vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, vp, vp, vp]
+    L.orbfe_window_distances.argtypes = [vp, vp, vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, i32, vp, vp, i32]
     L.orbfe_search_for_triangulation.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, f32, f32, vp,
                                                  vp, i32, i32, vp]
     L.orbfe_group_shard_range.argtypes = [i32, i32, i32, vp, vp]

@@ -1656,6 +1656,79 @@ extern "C" orbfe_status orbfe_search_by_projection_chi2(orbfe_matcher *m, const 
     return ORBFE_OK;
 }
 
+// The first two stages of the projection search on their own: GetFeaturesInArea for every query and the Hamming distance of
+// every candidate, handed back as lists (entry = feature | distance << 16, in the reference's candidate order).  For callers
+// whose acceptance rule is sequential in a way the device core does not implement (SearchForInitialization :571-574).
+extern "C" orbfe_status orbfe_window_distances(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF, int32_t nF,
+                                               const uint32_t *cell_off, const uint32_t *cell_idx, float minx, float miny, float gw_inv,
+                                               float gh_inv, const orbfe_proj_query *q, const uint8_t *qdesc, int32_t nq, uint32_t *off,
+                                               uint32_t *ent, int32_t cap)
+{
+    if (!m || nF < 0 || nq < 0 || cap < 0 || !cell_off || !off || (nq > 0 && (!q || !qdesc)) || (nF > 0 && (!descF || !xyF || !octF)) ||
+        (cell_off[GRID_NC] > 0 && !cell_idx) || (cap > 0 && !ent)) {
+        orbfe_set_error("bad argument to orbfe_window_distances");
+        return ORBFE_ERR_ARG;
+    }
+    if (nF > 65535) { orbfe_set_error("orbfe_window_distances: at most 65535 features (16-bit index in an entry)"); return ORBFE_ERR_SIZE; }
+    const uint32_t nin = cell_off[GRID_NC];
+    if (nin > (uint32_t)nF) { orbfe_set_error("cell_off inconsistent with nF"); return ORBFE_ERR_ARG; }
+    for (int c = 0; c < GRID_NC; ++c)
+        if (cell_off[c + 1] < cell_off[c]) { orbfe_set_error("cell_off must not decrease"); return ORBFE_ERR_ARG; }
+    for (uint32_t k = 0; k < nin; ++k)
+        if (cell_idx[k] >= (uint32_t)nF) { orbfe_set_error("cell_idx out of range"); return ORBFE_ERR_ARG; }
+    off[0] = 0;
+    if (nq == 0) return ORBFE_OK;
+    MDeviceGuard g(m->device);
+    hipStream_t st = m->stream;
+    ORBFE_HIP(scratch_acquire(m, st));
+    const size_t sz[7] = {(size_t)nF * 32, (size_t)nF * 8, (size_t)nF * 4, (size_t)(GRID_NC + 1) * 4, (size_t)nin * 4,
+                          (size_t)nq * sizeof(orbfe_proj_query), (size_t)nq * 32};
+    const void *src[7] = {descF, xyF, octF, cell_off, cell_idx, q, qdesc};
+    size_t at[8];
+    at[0] = 0;
+    for (int i = 0; i < 7; ++i) at[i + 1] = (at[i] + sz[i] + 255) & ~(size_t)255;
+    ORBFE_HIP(m->pin_in.ensure(at[7]));
+    ORBFE_HIP(m->b[0].ensure(at[7]));
+    ORBFE_HIP(m->b[2].ensure((size_t)nq * 4));
+    ORBFE_HIP(m->b[3].ensure((size_t)nq * PJ_LC * 2));
+    ORBFE_HIP(m->b[4].ensure((size_t)(nq + 1) * 4));
+    ORBFE_HIP(m->b[5].ensure(std::max<size_t>((size_t)cap, 1) * 4));
+    for (int i = 0; i < 7; ++i)
+        if (sz[i]) memcpy((char *)m->pin_in.p + at[i], src[i], sz[i]);
+    ORBFE_HIP(hipMemcpyAsync(m->b[0].p, m->pin_in.p, at[7], hipMemcpyHostToDevice, st));
+    const char *din = (const char *)m->b[0].p;
+    ProjArgs a;
+    memset(&a, 0, sizeof(a));
+    a.descF = (const uint8_t *)(din + at[0]);
+    a.xyF = (const float *)(din + at[1]);
+    a.octF = (const int32_t *)(din + at[2]);
+    a.nF = nF; a.xs = 2; a.os = 1;
+    a.cell_off = (const uint32_t *)(din + at[3]);
+    a.cell_idx = (const uint32_t *)(din + at[4]);
+    a.minx = minx; a.miny = miny; a.gwi = gw_inv; a.ghi = gh_inv;
+    a.q = (const orbfe_proj_query *)(din + at[5]);
+    a.qdesc = (const uint8_t *)(din + at[6]);
+    a.nq = nq;
+    a.cnt = (uint32_t *)m->b[2].p;
+    a.lcnt = (uint16_t *)m->b[3].p;
+    a.off = (uint32_t *)m->b[4].p;
+    a.ent = (uint32_t *)m->b[5].p;
+    a.ent_cap = (uint32_t)cap;
+    const int ngrp = (nq * PJ_LC + 255) / 256;
+    hipLaunchKernelGGL(k_proj_count, dim3(ngrp), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, (const uint32_t *)a.cnt, nq, a.off);
+    hipLaunchKernelGGL(k_proj_fill, dim3(ngrp), dim3(256), 0, st, a);   // writes nothing when the total exceeds cap
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpyAsync(off, a.off, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
+    ORBFE_HIP(hipStreamSynchronize(st));
+    if (off[nq] > (uint32_t)cap) { orbfe_set_error("orbfe_window_distances: %u entries needed, cap %d", off[nq], cap); return ORBFE_ERR_CAP; }
+    if (off[nq] > 0) {
+        ORBFE_HIP(hipMemcpyAsync(ent, a.ent, (size_t)off[nq] * 4, hipMemcpyDeviceToHost, st));
+        ORBFE_HIP(hipStreamSynchronize(st));
+    }
+    return ORBFE_OK;
+}
+
 extern "C" orbfe_status orbfe_search_by_projection(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF,
                                                    int32_t nF, const uint32_t *cell_off, const uint32_t *cell_idx, float minx,
                                                    float miny, float gw_inv, float gh_inv, const float *uRight,

@@ -181,6 +181,30 @@ class ORBmatcher:
                    "orbfe_search_by_projection")
         return m, b, s2
 
+    def WindowDistances(self, descF, xyF, octF, grid, bounds, queries, qdesc, cap=None):
+        """orbfe_window_distances: per query the features of GetFeaturesInArea(u, v, r, min_level, max_level) in the
+        reference's order with their Hamming distances.  Returns (off[nq + 1], cand[], dist[])."""
+        descF = np.ascontiguousarray(descF, np.uint8).reshape(-1, 32)
+        xyF = np.ascontiguousarray(xyF, np.float32).reshape(-1, 2)
+        octF = np.ascontiguousarray(octF, np.int32)
+        goff, gidx = (np.ascontiguousarray(a, np.uint32) for a in grid)
+        q = np.ascontiguousarray(queries, _ffi.PROJ_QUERY_DTYPE)
+        qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+        off = np.zeros(len(q) + 1, np.uint32)
+        cap = int(cap if cap is not None else max(64 * len(q), 1024))
+        for _ in range(2):
+            ent = np.zeros(max(cap, 1), np.uint32)
+            st = _ffi.lib().orbfe_window_distances(self.handle, _ffi.ptr(descF), _ffi.ptr(xyF), _ffi.ptr(octF), len(descF), _ffi.ptr(goff),
+                                                   _ffi.ptr(gidx), *[float(v) for v in bounds], _ffi.ptr(q), _ffi.ptr(qd), len(q),
+                                                   _ffi.ptr(off), _ffi.ptr(ent), cap)
+            if st == _ffi.ORBFE_ERR_CAP:
+                cap = int(off[-1])
+                continue
+            _ffi.check(st, "orbfe_window_distances")
+            break
+        n = int(off[-1])
+        return off, ent[:n] & 0xFFFF, ent[:n] >> 16
+
     def SearchForTriangulationCore(self, k1, k2, F12, ex, ey, th_low=50):
         """orbfe_search_for_triangulation (src/ORBmatcher.cc:827-1012): k1 = dict(desc, xy, elig, stereo, fv=(node, off, idx)),
         k2 = the same + octave, scale_factors, level_sigma2.  Returns match12[n1] (before the rotation check)."""

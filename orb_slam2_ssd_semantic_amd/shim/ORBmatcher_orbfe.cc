@@ -25,8 +25,8 @@
 // the reference's order, on the live objects.  The device call is orbfe_search_by_projection(_chi2) for the four
 // SearchByProjection members (it also resolves the "slot already taken by an earlier query" rule) and for Fuse x2 /
 // SearchBySim3 (independent queries on a KeyFrame's grid; Fuse's reprojection-error gate is ORBFE_PROJ_CHI2_GATE),
-// orbfe_search_for_triangulation, orbfe_search_by_bow, and orbfe_hamming_csr_all for SearchForInitialization (whose rule
-// needs every distance, so its windows are gathered here).
+// orbfe_search_for_triangulation, orbfe_search_by_bow, and orbfe_window_distances for SearchForInitialization (whose rule
+// needs every distance of every window; only the in-order acceptance runs here).
 // Integration: add this file to the ORB_SLAM2 library in place of src/ORBmatcher.cc (-DORBFE_SHIM_STANDALONE), or next to it
 // with the bodies listed above deleted (or #if 0), and link liborbfe.so.  The class gets no new data member:
 // the device matcher handle is per thread, which is also what the C-ABI asks for (Tracking, LocalMapping and LoopClosing call
@@ -745,7 +745,7 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoin
 
 // src/ORBmatcher.cc:523-651 (Tracking::MonocularInitialization).  A candidate is skipped when an earlier query already holds
 // it at a distance <= its own (:573), so best / second-best of a query depend on the matches made before it: the device
-// returns every distance of every window (one call), the in-order rule runs here on those numbers.
+// returns every window's candidates with their distances (orbfe_window_distances, one call), the in-order rule runs here.
 int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize)
 {
     int nmatches = 0;
@@ -756,27 +756,37 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
     std::vector<int> vMatchedDistance(F2.mvKeysUn.size(), INT_MAX);
     std::vector<int> vnMatches21(F2.mvKeysUn.size(), -1);
     const size_t n1 = F1.mvKeysUn.size();
-    std::vector<uint32_t> off(1, 0), cand, qrow;
+    // one query per level-0 feature of F1 (:543-545): GetFeaturesInArea(prev.x, prev.y, windowSize, 0, 0) on F2's grid and the
+    // distance of every candidate come back as lists in the reference's candidate order
+    std::vector<orbfe_proj_query> qs;
+    std::vector<uint8_t> qdesc, t1;
     std::vector<int> slot(n1, -1);
+    const uint8_t *d1 = Rows(F1.mDescriptors, t1);
     for (size_t i1 = 0; i1 < n1; i1++) {
         const int level1 = F1.mvKeysUn[i1].octave;
         if (level1 > 0) continue;
-        std::vector<size_t> vIndices2 = F2.GetFeaturesInArea(vbPrevMatched[i1].x, vbPrevMatched[i1].y, windowSize, level1, level1);
-        if (vIndices2.empty()) continue;
-        for (std::vector<size_t>::const_iterator vit = vIndices2.begin(); vit != vIndices2.end(); vit++) cand.push_back((uint32_t)*vit);
-        slot[i1] = (int)off.size() - 1;
-        off.push_back((uint32_t)cand.size());
-        qrow.push_back((uint32_t)i1);
+        orbfe_proj_query e;
+        e.u = vbPrevMatched[i1].x; e.v = vbPrevMatched[i1].y; e.r = (float)windowSize;
+        e.min_level = level1; e.max_level = level1; e.ur = 0.f; e.flags = 0; e.pad = 0;
+        slot[i1] = (int)qs.size();
+        qs.push_back(e);
+        qdesc.insert(qdesc.end(), d1 + i1 * 32, d1 + i1 * 32 + 32);
     }
-    const int nq = (int)off.size() - 1;
-    std::vector<uint16_t> dist(cand.size() + 1);
-    if (nq > 0) {
-        std::vector<uint8_t> t1, t2, qdesc((size_t)nq * 32);
-        const uint8_t *d1 = Rows(F1.mDescriptors, t1);
-        for (int k = 0; k < nq; k++) memcpy(&qdesc[(size_t)k * 32], d1 + (size_t)qrow[(size_t)k] * 32, 32);
-        const orbfe_status st = orbfe_hamming_csr_all(t_matcher.get(), qdesc.data(), nq, Rows(F2.mDescriptors, t2), F2.mDescriptors.rows,
-                                                      off.data(), cand.data(), dist.data());
-        if (st != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchForInitialization (orbfe): ") + orbfe_last_error());
+    const int nq = (int)qs.size();
+    std::vector<uint32_t> off((size_t)nq + 1, 0), ent;
+    if (nq > 0 && F2.N > 0) {
+        FrameSide fs(F2);
+        size_t cap = std::max<size_t>((size_t)nq * 64, 4096);
+        for (int attempt = 0;; ++attempt) {
+            ent.resize(cap);
+            const orbfe_status st = orbfe_window_distances(
+                t_matcher.get(), fs.desc, fs.xy.data(), fs.oct.data(), F2.N, fs.cell_off.data(), fs.cell_idx.data(), Frame::mnMinX,
+                Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv, qs.data(), qdesc.data(), nq, off.data(),
+                ent.data(), (int32_t)cap);
+            if (st == ORBFE_ERR_CAP && attempt == 0) { cap = off[(size_t)nq]; continue; }
+            if (st != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchForInitialization (orbfe): ") + orbfe_last_error());
+            break;
+        }
     }
     for (size_t i1 = 0; i1 < n1; i1++) {  // :538-617 on the device's distances
         if (slot[i1] < 0) continue;
@@ -784,8 +794,8 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
         int bestDist2 = INT_MAX;
         int bestIdx2 = -1;
         for (uint32_t k = off[(size_t)slot[i1]]; k < off[(size_t)slot[i1] + 1]; k++) {
-            const size_t i2 = cand[k];
-            const int d = (int)dist[k];
+            const size_t i2 = ent[k] & 0xFFFFu;
+            const int d = (int)(ent[k] >> 16);
             if (vMatchedDistance[i2] <= d) continue;
             if (d < bestDist) {
                 bestDist2 = bestDist;

@@ -90,6 +90,47 @@ def test_core_reprojection_error_gate_equals_oracle(mat):
 
 
 @pytest.mark.gpu
+def test_window_distances_and_csr_all_equal_oracle(mat):
+    """orbfe_window_distances: per query the candidates of Frame::GetFeaturesInArea in the reference's order (oracle
+    orc_features_in_area, pinned to the sliced reference body) with their Hamming distances; orbfe_hamming_csr_all: every
+    distance of caller-built lists.  Windows of SearchForInitialization's size (100 px), tracker-sized ones, empty ones,
+    out-of-image centres, level filters on and off."""
+    ncand = 0
+    for seed in range(25):
+        rng = np.random.default_rng(35_000 + seed)
+        nF, nq = int(rng.choice([1, 30, 300, 2000])), int(rng.choice([1, 40, 400]))
+        cur = PC.current_frame(rng, nF)
+        goff, gidx = PC.frame_grid(cur)
+        minx, _, miny, _ = cur["bounds"]
+        q = np.zeros(nq, O.PROJ_QUERY_DTYPE)
+        q["u"] = rng.uniform(-40, 680, nq).astype(np.float32)
+        q["v"] = rng.uniform(-40, 520, nq).astype(np.float32)
+        q["r"] = rng.choice([3.0, 15.0, 100.0], nq).astype(np.float32)
+        lv = rng.integers(0, 8, nq)
+        mode = rng.integers(0, 3, nq)   # 0: no level filter, 1: one level, 2: a window of levels
+        q["min_level"] = np.where(mode == 0, -1, np.where(mode == 1, lv, lv - 1))
+        q["max_level"] = np.where(mode == 0, -1, lv)
+        qd = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        off, cand, dist = mat.WindowDistances(cur["desc"], cur["xy"], cur["octave"], (goff, gidx), (minx, miny, cur["gw_inv"], cur["gh_inv"]),
+                                              q, qd, cap=64)   # cap too small on purpose for the larger cases: the retry path
+        ref_c, ref_off = [], [0]
+        for i in range(nq):
+            c = O.features_in_area(cur["xy"], cur["octave"], goff, gidx, minx, miny, cur["gw_inv"], cur["gh_inv"], float(q["u"][i]),
+                                   float(q["v"][i]), float(q["r"][i]), int(q["min_level"][i]), int(q["max_level"][i]))
+            ref_c.append(c)
+            ref_off.append(ref_off[-1] + len(c))
+        ref_c = np.concatenate(ref_c) if ref_c else np.zeros(0, np.uint32)
+        assert np.array_equal(off, np.array(ref_off, np.uint32)) and np.array_equal(cand, ref_c), seed
+        qi = np.repeat(np.arange(nq), np.diff(ref_off))
+        ref_d = np.unpackbits(qd[qi] ^ cur["desc"][ref_c], axis=1).sum(1) if len(ref_c) else np.zeros(0, np.int64)
+        assert np.array_equal(dist.astype(np.int64), ref_d), seed
+        d2 = mat.HammingCSRAll(qd, cur["desc"], np.array(ref_off, np.uint32), ref_c)
+        assert np.array_equal(d2.astype(np.int64), ref_d), seed
+        ncand += len(ref_c)
+    assert ncand > 30_000
+
+
+@pytest.mark.gpu
 def test_core_long_dependency_chains(mat):
     """Every query wants the same few slots: query i can only settle after all earlier claiming queries have -- the device's
     relaxation needs as many rounds as the chain is long and must still land on the sequential result."""
