@@ -241,6 +241,15 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     P.min_th = std::min(255, std::max(0, h->prm.min_th_fast));
     P.blur_rounding = h->prm.blur_rounding;
     P.dbg = getenv("ORBFE_DEBUG") ? atoi(getenv("ORBFE_DEBUG")) : 0;
+    // Rows a FAST / blur wave walks.  Long runs amortise the 8 (FAST) / 6 (blur) halo rows -- right for batches, whose waves
+    // fill the chip anyway.  A handle made for the online call (a frame or a few per call) is latency-bound instead: one wave's
+    // walk IS the kernel's duration, so it takes short runs and more waves: single 640x480 frame, FAST 41 -> 25 -> 21 us and blur
+    // 19 -> 11 -> 9 us with 40 -> 16 -> 8 rows (ORBFE_ROWS overrides, 8..64).
+    int rows_per_wave = h->prm.max_batch <= 2 ? 8 : (h->prm.max_batch <= 8 ? 16 : ORBFE_ROWS_PER_WAVE);
+    if (const char *e = getenv("ORBFE_ROWS")) {
+        const int v = atoi(e);
+        if (v >= 8 && v <= 64) rows_per_wave = v;
+    }
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
     int64_t off = 0;
@@ -437,7 +446,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             const OrbLevel &L = P.lv[l];
             const int rows = L.iy1 - ORBFE_EDGE, ncol = (L.ix1 - 16 + 3) / 4;
             if (rows <= 0 || ncol <= 0) continue;
-            const int frb = ORBFE_ROWS_PER_WAVE;
+            const int frb = rows_per_wave;
             const int nblk = (rows + frb - 1) / frb, rb = (rows + nblk - 1) / nblk;
             for (int k = 0; k < nblk; ++k) {
                 const int ys = ORBFE_EDGE + k * rb, nr = std::min(rb, L.iy1 - ys);
@@ -499,7 +508,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     for (int l = 0; l < nl; ++l) {
         const OrbLevel &L = P.lv[l];
         if (L.w < 16) { orbfe_set_error("level %d too narrow for the blur kernel", l); return ORBFE_ERR_SIZE; }
-        const int brb = ORBFE_ROWS_PER_WAVE;
+        const int brb = rows_per_wave;
         const int ncol = (L.w + 3) / 4, nblk = (L.h + brb - 1) / brb, rb = (L.h + nblk - 1) / nblk;
         for (int pass = 0; pass < 2; ++pass) {  // 0: interior columns, 1: edge columns
             for (int k = 0; k < nblk; ++k) {
@@ -567,8 +576,10 @@ static orbfe_status ensure_batch_buffers(orbfe_handle *h, int nframes)
     ORBFE_HIP(h->d_pyr.ensure(B * (size_t)P.pyr_frame_bytes));
     ORBFE_HIP(h->d_blur.ensure(B * (size_t)P.pyr_frame_bytes));
     ORBFE_HIP(h->d_skeys.ensure(B * (size_t)P.keys_per_frame * sizeof(uint2)));
-    ORBFE_HIP(h->d_scount.ensure(B * P.nlevels * ORBFE_NK_STRIDE * sizeof(int32_t)));
-    ORBFE_HIP(h->d_cflag.ensure(B * P.nlevels * (size_t)((P.max_ncells + 31) / 32) * sizeof(uint32_t)));
+    // survivor counts and cell flags are zeroed before every FAST pass: one block (counts | flags of the largest batch), so
+    // that one memset clears both -- a call with fewer frames passes the flags' offset for ITS frame count (run_batch)
+    ORBFE_HIP(h->d_scount.ensure(B * P.nlevels * ORBFE_NK_STRIDE * sizeof(int32_t) +
+                                 B * P.nlevels * (size_t)((P.max_ncells + 31) / 32) * sizeof(uint32_t)));
     ORBFE_HIP(h->d_knode.ensure(B * (size_t)P.keys_per_frame * sizeof(uint16_t)));
     ORBFE_HIP(h->d_qtbox.ensure(B * (size_t)P.nlevels * orbk_octree_box_bytes(P.node_cap)));  // deep quadtrees only
     if (orbk_octree_lds_bytes(P.node_cap, std::max(1, P.max_nini), P.w, P.h, P.max_ncells) > (size_t)ORBFE_LDS_MAX)
@@ -875,7 +886,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.pyr_fstride = h->plan.pyr_frame_bytes;
     a.d_skeys = (uint2 *)h->d_skeys.p;
     a.d_scount = (int32_t *)h->d_scount.p;
-    a.d_cflag = (uint32_t *)h->d_cflag.p;
+    a.d_cflag = (uint32_t *)(a.d_scount + (size_t)nframes * h->plan.nlevels * ORBFE_NK_STRIDE);  // right behind this call's counts
     a.cf_words = (h->plan.max_ncells + 31) / 32;
     a.d_knode = (uint16_t *)h->d_knode.p;
     a.d_qtbox = (int16_t *)h->d_qtbox.p;
@@ -984,16 +995,25 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
     const size_t fbytes = (size_t)pitch * ht;
     const int nset = nchunks > 1 ? 2 : 1;
     const size_t nbmax = (size_t)std::min(chunk_max, nframes);
+    // Output set k on the device.  When the results go through the handle's pinned staging (the online call), the three
+    // arrays are pieces of ONE block -- keypoints | descriptors | counts -- so that they come back in one D2H copy instead
+    // of three (each copy is a ~7 us round trip on the stream of a call that takes 0.25 ms in all).
+    const size_t kb = (sizeof(orbfe_keypoint) * (size_t)cap * nbmax + 255) & ~(size_t)255;
+    const size_t db = ((size_t)32 * cap * nbmax + 255) & ~(size_t)255;
+    const size_t cb = (sizeof(int32_t) * nbmax + 255) & ~(size_t)255;
+    uint8_t *d_ok[2] = {nullptr, nullptr}, *d_od[2] = {nullptr, nullptr}, *d_oc[2] = {nullptr, nullptr};
     for (int k = 0; k < nset; ++k) {
         if (!direct) ORBFE_HIP(h->h_stage[k].ensure(fbytes * nbmax));
         ORBFE_HIP(h->d_stage[k].ensure(fbytes * nbmax + 64));
-        ORBFE_HIP(h->d_okps[k].ensure(sizeof(orbfe_keypoint) * (size_t)cap * nbmax));
-        ORBFE_HIP(h->d_odesc[k].ensure((size_t)32 * cap * nbmax));
-        ORBFE_HIP(h->d_on[k].ensure(sizeof(int32_t) * nbmax));
-        if (!direct_out) {
-            ORBFE_HIP(h->h_okps[k].ensure(sizeof(orbfe_keypoint) * (size_t)cap * nbmax));
-            ORBFE_HIP(h->h_odesc[k].ensure((size_t)32 * cap * nbmax));
-            ORBFE_HIP(h->h_on[k].ensure(sizeof(int32_t) * nbmax));
+        if (direct_out) {
+            ORBFE_HIP(h->d_okps[k].ensure(kb));
+            ORBFE_HIP(h->d_odesc[k].ensure(db));
+            ORBFE_HIP(h->d_on[k].ensure(cb));
+            d_ok[k] = (uint8_t *)h->d_okps[k].p; d_od[k] = (uint8_t *)h->d_odesc[k].p; d_oc[k] = (uint8_t *)h->d_on[k].p;
+        } else {
+            ORBFE_HIP(h->d_okps[k].ensure(kb + db + cb));
+            ORBFE_HIP(h->h_okps[k].ensure(kb + db + cb));
+            d_ok[k] = (uint8_t *)h->d_okps[k].p; d_od[k] = d_ok[k] + kb; d_oc[k] = d_od[k] + db;
         }
     }
     // size the plan and the per-batch blocks once, before anything is in flight
@@ -1029,12 +1049,13 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
                 if (n_out[f0 + f] > cap) worst = ORBFE_ERR_CAP;
             return ORBFE_OK;
         }
+        const uint8_t *hb = (const uint8_t *)h->h_okps[k].p;   // keypoints | descriptors | counts
         for (int f = 0; f < nb; ++f) {
-            const int n = ((int32_t *)h->h_on[k].p)[f];
+            const int n = ((const int32_t *)(hb + kb + db))[f];
             n_out[f0 + f] = n;
             if (n > cap) { worst = ORBFE_ERR_CAP; continue; }
-            memcpy(kps + (size_t)(f0 + f) * cap, (orbfe_keypoint *)h->h_okps[k].p + (size_t)f * cap, sizeof(orbfe_keypoint) * (size_t)n);
-            memcpy(desc + (size_t)(f0 + f) * cap * 32, (uint8_t *)h->h_odesc[k].p + (size_t)f * cap * 32, (size_t)32 * n);
+            memcpy(kps + (size_t)(f0 + f) * cap, (const orbfe_keypoint *)hb + (size_t)f * cap, sizeof(orbfe_keypoint) * (size_t)n);
+            memcpy(desc + (size_t)(f0 + f) * cap * 32, hb + kb + (size_t)f * cap * 32, (size_t)32 * n);
         }
         return ORBFE_OK;
     };
@@ -1061,7 +1082,9 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
             for (int f = 0; f < nb; ++f) {
                 uint8_t *dst = (uint8_t *)h->h_stage[k].p + fbytes * f;
                 const uint8_t *src = grays[f0 + f];
-                for (int y = 0; y < ht; ++y) memcpy(dst + (size_t)y * pitch, src + (size_t)y * stride, (size_t)w);
+                if (stride == w && pitch == w) memcpy(dst, src, fbytes);
+                else
+                    for (int y = 0; y < ht; ++y) memcpy(dst + (size_t)y * pitch, src + (size_t)y * stride, (size_t)w);
             }
             ORBFE_HIP(hipMemcpyAsync(h->d_stage[k].p, h->h_stage[k].p, fbytes * nb, hipMemcpyHostToDevice, s_in));
         }
@@ -1071,31 +1094,34 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
             if (c >= 2) ORBFE_HIP(hipStreamWaitEvent(s_cmp, h->ev_out[k], 0));  // D2H of chunk c-2 read the output set k
         }
         // ---- kernels ----
-        orbfe_status s = run_batch(h, (const uint8_t *)h->d_stage[k].p, nb, w, ht, pitch, fbytes, (orbfe_keypoint *)h->d_okps[k].p,
-                                   (uint8_t *)h->d_odesc[k].p, cap, (int32_t *)h->d_on[k].p, s_cmp);
+        orbfe_status s = run_batch(h, (const uint8_t *)h->d_stage[k].p, nb, w, ht, pitch, fbytes, (orbfe_keypoint *)d_ok[k], d_od[k], cap,
+                                   (int32_t *)d_oc[k], s_cmp);
         if (s != ORBFE_OK) { drain(); return s; }
         if (piped) {
             ORBFE_HIP(hipEventRecord(h->ev_cmp[k], s_cmp));
             ORBFE_HIP(hipStreamWaitEvent(s_out, h->ev_cmp[k], 0));
         }
         // ---- out ----
-        void *on = direct_out ? (void *)(n_out + f0) : h->h_on[k].p;
-        void *ok = direct_out ? (void *)(kps + (size_t)f0 * cap) : h->h_okps[k].p;
-        void *od = direct_out ? (void *)(desc + (size_t)f0 * cap * 32) : h->h_odesc[k].p;
-        ORBFE_HIP(hipMemcpyAsync(on, h->d_on[k].p, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s_out));
-        ORBFE_HIP(hipMemcpyAsync(ok, h->d_okps[k].p, sizeof(orbfe_keypoint) * (size_t)cap * nb, hipMemcpyDeviceToHost, s_out));
-        ORBFE_HIP(hipMemcpyAsync(od, h->d_odesc[k].p, (size_t)32 * cap * nb, hipMemcpyDeviceToHost, s_out));
+        if (direct_out) {
+            ORBFE_HIP(hipMemcpyAsync(n_out + f0, d_oc[k], sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s_out));
+            ORBFE_HIP(hipMemcpyAsync(kps + (size_t)f0 * cap, d_ok[k], sizeof(orbfe_keypoint) * (size_t)cap * nb, hipMemcpyDeviceToHost, s_out));
+            ORBFE_HIP(hipMemcpyAsync(desc + (size_t)f0 * cap * 32, d_od[k], (size_t)32 * cap * nb, hipMemcpyDeviceToHost, s_out));
+        } else {
+            ORBFE_HIP(hipMemcpyAsync(h->h_okps[k].p, d_ok[k], kb + db + sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s_out));
+        }
+        if (c == nchunks - 1) {
+            // the sticky overflow word travels with the results of the last chunk: an asynchronous 4-byte copy into pinned
+            // memory behind the last kernels, in flight BEFORE the host starts waiting for results
+            ORBFE_HIP(h->h_ovf.ensure(sizeof(int32_t)));
+            ORBFE_HIP(hipMemcpyAsync(h->h_ovf.p, h->d_misc.p, sizeof(int32_t), hipMemcpyDeviceToHost, s_cmp));
+        }
         ORBFE_HIP(hipEventRecord(h->ev_out[k], s_out));
     }
     for (int c = std::max(0, nchunks - 2); c < nchunks; ++c) {
         orbfe_status su = unpack(c);
         if (su != ORBFE_OK) { drain(); return su; }
     }
-    // the sticky overflow word travels with the results: an asynchronous 4-byte copy into pinned memory behind the last
-    // kernels, read after the one synchronisation the call needs anyway
-    ORBFE_HIP(h->h_ovf.ensure(sizeof(int32_t)));
-    ORBFE_HIP(hipMemcpyAsync(h->h_ovf.p, h->d_misc.p, sizeof(int32_t), hipMemcpyDeviceToHost, s_cmp));
-    ORBFE_HIP(hipStreamSynchronize(s_cmp));
+    ORBFE_HIP(hipStreamSynchronize(s_cmp));   // the overflow word (enqueued with the last chunk) has landed
     drain_guard.armed = false;  // everything has been waited for (unpack() synchronised the output events)
     {
         const int32_t ovf = *(const int32_t *)h->h_ovf.p;

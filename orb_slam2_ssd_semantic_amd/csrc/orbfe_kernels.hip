@@ -2065,7 +2065,14 @@ static void pyr_args(const OrbLaunch &a, int l, PyrArgs &pa)
     pa.dw = D.w; pa.dh = D.h; pa.dpitch = D.pitch;
     pa.xtab = a.d_tabs + D.xtab;
     pa.ytab = a.d_tabs + D.ytab;
-    const int nb = (D.h + PW_ROWS - 1) / PW_ROWS;
+    // rows per lane run: PW_ROWS for batches; a call with a few frames is bound by the length of ONE lane's walk, so it takes
+    // short runs and more lanes (ORBFE_PW_ROWS overrides, 2..PW_ROWS)
+    int rows = a.nframes <= 8 ? 2 : PW_ROWS;
+    if (const char *e = getenv("ORBFE_PW_ROWS")) {
+        const int v = atoi(e);
+        if (v >= 2 && v <= PW_ROWS) rows = v;
+    }
+    const int nb = (D.h + rows - 1) / rows;
     pa.rb = (D.h + nb - 1) / nb;               // balanced run length
     pa.nrblk = (D.h + pa.rb - 1) / pa.rb;      // no empty run
 }
@@ -2080,6 +2087,7 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
     // workgroup's dependent chain by more than the saved 0.37 GB of reads are worth.  Also measured, not kept: all levels
     // of a frame in one launch (a 1024-thread workgroup per frame, workgroup barriers between levels) -- 0.66 ms against
     // 0.63 ms per 1024 frames; with an agent-scope fence between the levels 4.8 ms.
+    // (For a single frame the fused form does not win either: 49 us against 48 us for the seven chained launches.)
     const char *fe = getenv("ORBFE_PYR_FUSE");
     const bool fuse = fe && atoi(fe) == 1;
     const int nl = a.h_plan->nlevels;
@@ -2113,9 +2121,11 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
 hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
 {
     const FrameSrc fs = make_src(a);
-    hipError_t e = hipMemsetAsync(a.d_scount, 0, sizeof(int32_t) * (size_t)a.nframes * a.h_plan->nlevels * ORBFE_NK_STRIDE, st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(a.d_cflag, 0, sizeof(uint32_t) * (size_t)a.nframes * a.h_plan->nlevels * a.cf_words, st);
+    // the survivor counts and, right behind them, the cell flags of this call's frames: one clear
+    if ((const char *)a.d_cflag != (const char *)a.d_scount + sizeof(int32_t) * (size_t)a.nframes * a.h_plan->nlevels * ORBFE_NK_STRIDE)
+        return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(a.d_scount, 0, sizeof(int32_t) * (size_t)a.nframes * a.h_plan->nlevels * ORBFE_NK_STRIDE +
+                                                     sizeof(uint32_t) * (size_t)a.nframes * a.h_plan->nlevels * a.cf_words, st);
     if (e != hipSuccess) return e;
     dim3 grid((a.h_plan->nfwaves + 3) / 4, a.nframes);
     if (a.fast_sparse)
