@@ -1974,26 +1974,29 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
         const int bpitch = L.pitch;
         // uniform base (frame b of the blurred pyramid) + a 32-bit per-lane offset that advances by additions
         const uint8_t *bbase = blur + (int64_t)b * blur_fstride;
-        // dword f = it * 16 + sub of the 37 x 10 dword patch: (row, k) advance by (1, 6) per iteration, with carry
-        int row = sub >= 10 ? 1 : 0, kk = sub >= 10 ? sub - 10 : sub;
-        uint32_t go = (uint32_t)L.off + __umul24((uint32_t)(y - 18 + row), (uint32_t)bpitch) + (uint32_t)(x - 18 + 4 * kk);
-        int lo = row * DS_PP + 4 * kk;
+        // dword f = it * 16 + sub of the 37 x 10 dword patch (16 consecutive dwords per step: a row and the start of the
+        // next).  With the LDS pitch equal to the 40 patch bytes the LDS offset is simply 4 * f; the row of f is
+        // (f * 205) >> 11 (= f / 10 for f < 1029) and the global offset  base + row * (pitch - 40) + 4 * f,  whose
+        // "+ 64 * it" rides in the load's immediate offset: three VALU operations per load (the incremental carry logic this
+        // replaces took ten).
+        static_assert(DS_PR == 37 && DS_PP == 40, "patch staging: LDS pitch == patch bytes");
+        const uint32_t s205 = (uint32_t)sub * 205u;
+        const uint32_t bp40 = (uint32_t)bpitch - 40u;
+        const uint8_t *b4 = bbase + ((uint32_t)L.off + __umul24((uint32_t)(y - 18), (uint32_t)bpitch) + (uint32_t)(x - 18 + 4 * sub));
         uint32_t v[24];
-        int lofs[24];
 #pragma unroll
-        for (int it = 0; it < 24; ++it) {
-            v[it] = *(const uint32_t *)(bbase + go);  // unaligned dword (rows past the patch re-read its last row)
-            lofs[it] = row < DS_PR ? lo : -1;
-            const bool carry = kk >= 4;  // kk + 6 >= 10
-            const int nrow = row + (carry ? 2 : 1);
-            go += (uint32_t)(carry ? -16 : 24) + (nrow < DS_PR ? (carry ? 2u : 1u) * (uint32_t)bpitch : (row < DS_PR - 1 ? (uint32_t)bpitch : 0u));
-            lo += carry ? 2 * DS_PP - 16 : DS_PP + 24;
-            kk += carry ? -4 : 6;
-            row = nrow;
+        for (int it = 0; it < 23; ++it) {
+            const uint32_t row = (s205 + (uint32_t)(it * 16 * 205)) >> 11;
+            v[it] = *(const uint32_t *)(b4 + __umul24(row, bp40) + it * 64);  // unaligned dword
         }
+        {   // f = 368 + sub: only f = 368, 369 (row 36, columns 8, 9) exist; the other lanes re-read 369 and store nothing
+            const uint32_t fl = 368u + (uint32_t)min(sub, 1);
+            v[23] = *(const uint32_t *)(bbase + ((uint32_t)L.off + __umul24((uint32_t)(y + 18), (uint32_t)bpitch) + (uint32_t)(x - 18) + 4u * (fl - 360u)));
+        }
+        uint8_t *pl = patch + 4 * sub;
 #pragma unroll
-        for (int it = 0; it < 24; ++it)
-            if (lofs[it] >= 0) *(uint32_t *)(patch + lofs[it]) = v[it];
+        for (int it = 0; it < 23; ++it) *(uint32_t *)(pl + it * 64) = v[it];
+        if (sub < 2) *(uint32_t *)(pl + 23 * 64) = v[23];
     }
     float a, bb;
     canon_sincos(angle, &a, &bb);
