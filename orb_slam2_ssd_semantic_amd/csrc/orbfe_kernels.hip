@@ -1973,7 +1973,16 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     {
         const int bpitch = L.pitch;
         // uniform base (frame b of the blurred pyramid) + a 32-bit per-lane offset that advances by additions
-        const uint8_t *bbase = blur + (int64_t)b * blur_fstride;
+        typedef const __attribute__((address_space(1))) uint8_t *orb_gptr8;    // global memory, explicitly
+        typedef const __attribute__((address_space(1))) uint32_t *orb_gptr32;
+        orb_gptr8 bbase;
+        {   // pinned to a scalar register pair: the loads below then take it as their SGPR base (the 64-bit product is formed
+            // on the vector side, where the compiler no longer knows it is uniform)
+            const uint64_t bb = (uint64_t)(blur + (int64_t)b * blur_fstride);
+            const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bb);
+            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bb >> 32));
+            bbase = (orb_gptr8)(((uint64_t)hi32 << 32) | lo32);
+        }
         // dword f = it * 16 + sub of the 37 x 10 dword patch (16 consecutive dwords per step: a row and the start of the
         // next).  With the LDS pitch equal to the 40 patch bytes the LDS offset is simply 4 * f; the row of f is
         // (f * 205) >> 11 (= f / 10 for f < 1029) and the global offset  base + row * (pitch - 40) + 4 * f,  whose
@@ -1982,16 +1991,18 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
         static_assert(DS_PR == 37 && DS_PP == 40, "patch staging: LDS pitch == patch bytes");
         const uint32_t s205 = (uint32_t)sub * 205u;
         const uint32_t bp40 = (uint32_t)bpitch - 40u;
-        const uint8_t *b4 = bbase + ((uint32_t)L.off + __umul24((uint32_t)(y - 18), (uint32_t)bpitch) + (uint32_t)(x - 18 + 4 * sub));
+        // uniform base + one 32-bit per-lane offset + immediate: a global_load with an SGPR base, no 64-bit address arithmetic
+        const uint32_t o4 = (uint32_t)L.off + __umul24((uint32_t)(y - 18), (uint32_t)bpitch) + (uint32_t)(x - 18 + 4 * sub);
         uint32_t v[24];
 #pragma unroll
         for (int it = 0; it < 23; ++it) {
             const uint32_t row = (s205 + (uint32_t)(it * 16 * 205)) >> 11;
-            v[it] = *(const uint32_t *)(b4 + __umul24(row, bp40) + it * 64);  // unaligned dword
+            const uint32_t o = o4 + __umul24(row, bp40);
+            v[it] = *(orb_gptr32)((bbase + it * 64) + o);  // unaligned dword
         }
         {   // f = 368 + sub: only f = 368, 369 (row 36, columns 8, 9) exist; the other lanes re-read 369 and store nothing
             const uint32_t fl = 368u + (uint32_t)min(sub, 1);
-            v[23] = *(const uint32_t *)(bbase + ((uint32_t)L.off + __umul24((uint32_t)(y + 18), (uint32_t)bpitch) + (uint32_t)(x - 18) + 4u * (fl - 360u)));
+            v[23] = *(orb_gptr32)(bbase + ((uint32_t)L.off + __umul24((uint32_t)(y + 18), (uint32_t)bpitch) + (uint32_t)(x - 18) + 4u * (fl - 360u)));
         }
         uint8_t *pl = patch + 4 * sub;
 #pragma unroll
