@@ -1616,7 +1616,9 @@ __host__ __device__ constexpr uint32_t blur_hw(int j, int d)
 // no lane idles on narrow levels.  Column borders are branch-free: every lane loads 3 dwords from a per-lane base that
 // covers all (reflected) source pixels of its 12-byte window and rearranges them with per-lane byte selectors
 // (identity for interior lanes); row borders are a per-lane reflected row index.
+#ifndef BL_PF
 #define BL_PF 2  // prefetch distance in rows
+#endif
 #ifdef BL_MIN_WAVES
 #define BL_BOUNDS __launch_bounds__(256, BL_MIN_WAVES)
 #else
@@ -1691,9 +1693,19 @@ __global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
 
     // raw rows are fetched BL_PF steps ahead into the same 7-slot ring, so a wave keeps several rows in flight
     uint32_t Lr[7][3];
+    // A wave none of whose lanes comes within 3 rows of the level's top or bottom (three of four) walks plain rows: the
+    // offset advances by the pitch, no reflected row index per step.
+    const bool plain_rows = __ballot(!(y0 >= 3 && y0 - 3 + nsteps + BL_PF <= H)) == 0ull;
+    uint32_t ro = __umul24((uint32_t)max(y0 - 3, 0), (uint32_t)pitch) + (uint32_t)base;
     auto fetch = [&](int s, uint32_t (&dst3)[3]) {
-        const int yy = reflect101(min(y0 - 3 + s, H + 2), H);
-        const uint8_t *row = src + (__umul24((uint32_t)yy, (uint32_t)pitch) + (uint32_t)base);
+        const uint8_t *row;
+        if (plain_rows) {
+            row = src + ro;
+            ro += (uint32_t)pitch;
+        } else {
+            const int yy = reflect101(min(y0 - 3 + s, H + 2), H);
+            row = src + (__umul24((uint32_t)yy, (uint32_t)pitch) + (uint32_t)base);
+        }
         dst3[0] = *(const uint32_t *)(row);
         dst3[1] = *(const uint32_t *)(row + 4);
         dst3[2] = *(const uint32_t *)(row + 8);
@@ -1752,11 +1764,11 @@ __global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
                             if ((tq[j] & 0xFFFFu) == 0u && (x + j) < vec_w && (tq[j] & 0x10000u)) tq[j] -= 0x10000u;
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tq[j] = min(tq[j], 0x00FFFFFFu);  // byte 2 = saturate_cast<uchar>
-                const uint32_t p01 = __builtin_amdgcn_perm(tq[1], tq[0], 0x0c0c0602u);
-                const uint32_t p23 = __builtin_amdgcn_perm(tq[3], tq[2], 0x0c0c0602u);
-                const uint32_t packed = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                // (acc >> 16) <= 257: the high halves of two sums side by side, saturate_cast<uchar> as one packed u16 min, then
+                // the four low bytes into one dword
+                const uint32_t h01 = pk_min_u16(__builtin_amdgcn_perm(tq[1], tq[0], 0x07060302u), 0x00FF00FFu);
+                const uint32_t h23 = pk_min_u16(__builtin_amdgcn_perm(tq[3], tq[2], 0x07060302u), 0x00FF00FFu);
+                const uint32_t packed = __builtin_amdgcn_perm(h23, h01, 0x06040200u);
                 if (active && y < yend) {
                     uint8_t *o = dst + (__umul24((uint32_t)y, (uint32_t)dpitch) + (uint32_t)x);
                     if (full) {
