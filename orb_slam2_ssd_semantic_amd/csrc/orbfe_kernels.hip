@@ -417,6 +417,9 @@ __global__ __launch_bounds__(256) void k_pyr_walk2(Pyr2Args p)
 //   A = max(A_dark, A_bright), cv score = A - 1, 3x3 strict NMS inside each cell's detectable interior, iniTh list
 //   or -- for a cell where that is empty -- minTh list.
 // ---------------------------------------------------------------------------------------------------
+// The lane mask of a predicate straight from its compare (HIP's __ballot materialises the bool in a VGPR and compares it
+// again: two VALU instructions per ballot in the row loops)
+__device__ __forceinline__ unsigned long long orb_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
     const uint32_t rv01 = halves(rvalid, 0), rv23 = halves(rvalid, 2);
     // a cell seam between the two pixels of a pair lets BOTH be NMS survivors; at most one pair of a lane has one
     const bool split01 = (inside & 3) == 3 && !(lvalid & 2), split23 = (inside & 12) == 12 && !(lvalid & 8);
-    const bool wave_split = __ballot(split01 || split23) != 0ull;
+    const bool wave_split = orb_ballot(split01 || split23) != 0ull;
     const bool out_lane = !(ld.flags & 1) && inside != 0;
     const int nrows_out = out_lane ? (int)ld.nrows : 0;
     // per-pixel part of `ord`, the rank key of the reference's candidate order (cell-row-major, raster inside a cell):
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
                 if (SPARSE) {
                     const uint32_t p = (fast_compass_pair<0>(rm3, r0, rp3, tt) & in01) |
                                        (fast_compass_pair<2>(rm3, r0, rp3, tt) & in23);
-                    arcs = __ballot(p != 0u) != 0ull;  // wave-uniform
+                    arcs = orb_ballot(p != 0u) != 0ull;  // wave-uniform
                     if (fstat) { st_rows++; st_arc += arcs ? 0 : 1; }
                 }
                 if (arcs) {
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
                 ordy += wrap ? 64u + ord_wrap : 64u;
             }
             if (SPARSE) {  // no strength in the row being suppressed -> nothing can survive (wave-uniform)
-                if (__ballot((S01[km] | S23[km]) != 0u) == 0ull) {
+                if (orb_ballot((S01[km] | S23[km]) != 0u) == 0ull) {
                     if (fstat) st_nms++;
                     continue;
                 }
@@ -788,8 +791,11 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
             const uint32_t n23 = pk_max3(x12 & lv23, r23, v23);
             const uint32_t g01 = pk_subsat_u16(m01, n01), g23 = pk_subsat_u16(m23, n23);  // != 0 <=> survivor
             const bool row_out = s - 8 < nrows_out;  // per lane
+            // ballots of the plain compares, combined on the scalar side (a ballot of a combined predicate is lowered through a
+            // VGPR: select 0 / 1, compare again)
+            const unsigned long long brow = orb_ballot(row_out);
+            const unsigned long long b01 = orb_ballot(g01 != 0u) & brow, b23 = orb_ballot(g23 != 0u) & brow;
             const bool has01 = row_out && g01 != 0u, has23 = row_out && g23 != 0u;
-            const unsigned long long b01 = __ballot(has01), b23 = __ballot(has23);
             if (b01 | b23) {
                 const uint32_t keyrow = key00 + ((uint32_t)s << 12);
                 const int p01 = __popcll(b01);
@@ -809,7 +815,7 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
                 if (wave_split) {  // both pixels of a seam pair survived: the low one is still to be written
                     const uint32_t gs = split01 ? g01 : (split23 ? g23 : 0u);
                     const bool dbl = row_out && (gs & 0xFFFFu) != 0u && gs > 0xFFFFu;
-                    const unsigned long long bd = __ballot(dbl);
+                    const unsigned long long bd = orb_ballot(dbl);
                     if (bd) {
                         if (dbl) {
                             const uint32_t a = (split23 ? m23 : m01) & 0xFFFFu;
@@ -1695,7 +1701,7 @@ __global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
     uint32_t Lr[7][3];
     // A wave none of whose lanes comes within 3 rows of the level's top or bottom (three of four) walks plain rows: the
     // offset advances by the pitch, no reflected row index per step.
-    const bool plain_rows = __ballot(!(y0 >= 3 && y0 - 3 + nsteps + BL_PF <= H)) == 0ull;
+    const bool plain_rows = orb_ballot(!(y0 >= 3 && y0 - 3 + nsteps + BL_PF <= H)) == 0ull;
     uint32_t ro = __umul24((uint32_t)max(y0 - 3, 0), (uint32_t)pitch) + (uint32_t)base;
     auto fetch = [&](int s, uint32_t (&dst3)[3]) {
         const uint8_t *row;
@@ -1758,7 +1764,7 @@ __global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
                     // the row.  One pixel in 65536 is an exact half, so the test is one wave-uniform branch on the smallest
                     // low half of the lane's four sums; the per-pixel correction runs only when some lane has one.
                     const uint32_t lowmin = min(min(tq[0] & 0xFFFFu, tq[1] & 0xFFFFu), min(tq[2] & 0xFFFFu, tq[3] & 0xFFFFu));
-                    if (__ballot(lowmin == 0u) != 0ull) {
+                    if (orb_ballot(lowmin == 0u) != 0ull) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if ((tq[j] & 0xFFFFu) == 0u && (x + j) < vec_w && (tq[j] & 0x10000u)) tq[j] -= 0x10000u;
