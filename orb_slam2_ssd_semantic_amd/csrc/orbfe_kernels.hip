@@ -880,7 +880,9 @@ struct OctGroup {
     int32_t ncells;        // most FAST cells of a level in the group
 };
 #define KNODE_MASK 0x3FFFu
+#ifndef KUNROLL
 #define KUNROLL 8
+#endif
 #define FFD 5               // histogram depth
 #define FF_PER_ROOT 1364    // 4 + 16 + 64 + 256 + 1024
 __host__ __device__ inline int ff_off(int d) { return ((1 << (2 * d)) - 4) / 3; }  // first entry of depth d (1..5)
