@@ -244,11 +244,11 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     // Rows a FAST / blur wave walks.  Long runs amortise the 8 (FAST) / 6 (blur) halo rows -- right for batches, whose waves
     // fill the chip anyway.  A handle made for the online call (a frame or a few per call) is latency-bound instead: one wave's
     // walk IS the kernel's duration, so it takes short runs and more waves: single 640x480 frame, FAST 41 -> 25 -> 21 us and blur
-    // 19 -> 11 -> 9 us with 40 -> 16 -> 8 rows (ORBFE_ROWS overrides, 8..64).
+    // 19 -> 11 -> 9 us with 40 -> 16 -> 8 rows (ORBFE_ROWS overrides, 8..512).
     int rows_per_wave = h->prm.max_batch <= 2 ? 8 : (h->prm.max_batch <= 8 ? 16 : ORBFE_ROWS_PER_WAVE);
     if (const char *e = getenv("ORBFE_ROWS")) {
         const int v = atoi(e);
-        if (v >= 8 && v <= 64) rows_per_wave = v;
+        if (v >= 8 && v <= 512) rows_per_wave = v;
     }
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
