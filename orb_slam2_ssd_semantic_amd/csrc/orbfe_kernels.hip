@@ -1901,6 +1901,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[16][DS_PR * DS_PP];
     __shared__ uint2 s_momw[31 * 8];
     __shared__ float4 s_pat[256];  // (x0, y0, x1, y1) of every test pair as floats
+#ifdef DS_EXTRA_LDS   // occupancy probe: dead LDS that costs a workgroup slot per CU
+    __shared__ uint32_t s_pad[DS_EXTRA_LDS / 4];
+    if (nl < 0) s_pad[threadIdx.x] = 1u;
+    if (nl < -1) ovf[0] = (int32_t)s_pad[threadIdx.x ^ 1];
+#endif
     int b = blockIdx.y, bx = blockIdx.x;
     xcd_frame_remap(bx, b);
     b = __builtin_amdgcn_readfirstlane(b);  // workgroup-uniform: frame offsets are scalar 64-bit products
