@@ -471,11 +471,14 @@ orbfe_status orbfe_search_by_bow_batch_device(orbfe_matcher *m, const orbfe_keyp
  * Batched keyframe mode over several devices (north star: "shards independent frames across the 8 GPUs of one
  * node with an RCCL all-gather of descriptors over xGMI", host stays C++).
  *
- * A batch of nframes independent frames is cut into contiguous shards of ceil(nframes / world) frames, shard r on rank r
- * (orbfe_group_shard_range).  Every rank owns three padded blocks for the WHOLE batch -- counts [F], keypoints [F][cap],
- * descriptors [F][cap][32], F = world * shard, rank r's frames at block indices [r * shard, (r + 1) * shard)
- * (orbfe_group_block_index) -- extracts its shard straight into its own slice, and ONE in-place all-gather per block
- * (ncclAllGather, RCCL) leaves the whole batch on every rank.  The consumer of the gather, what KeyFrameDatabase /
+ * A batch of nframes independent frames is cut into contiguous shards, shard r on rank r.  orbfe_group_shard_range is the
+ * SINGLE source of truth for the cut: every rank gets nframes / world frames and the first nframes % world ranks one more
+ * (10 frames over 4 ranks: 3, 3, 2, 2 -- not ceil-sized shards with a short last one); a caller that shards the frames
+ * itself (orbfe_group_extract_shard_device) must use it.  Every rank owns three padded blocks for the WHOLE batch -- counts
+ * [F], keypoints [F][cap], descriptors [F][cap][32], F = world * shard with shard = ceil(max_batch / world) slots per rank;
+ * rank r's frames sit at block indices r * shard + (frame - lo_r) (orbfe_group_block_index; the unused slots of a slice are
+ * zero) -- it extracts its shard straight into its own slice, and ONE in-place all-gather per block (ncclAllGather, RCCL)
+ * leaves the whole batch on every rank.  The consumer of the gather, what KeyFrameDatabase /
  * LoopClosing do serially per candidate keyframe (src/LoopClosing.cc:312-342), is orbfe_group_match: frames of the own shard
  * against candidate frames anywhere in the gathered set.
  *
@@ -487,15 +490,30 @@ orbfe_status orbfe_search_by_bow_batch_device(orbfe_matcher *m, const orbfe_keyp
  * the process if there is one, else librccl.so.1 / $ORBFE_RCCL_LIB); without it the create calls fail with ORBFE_ERR_STATE.
  * A group is used by one thread at a time.  Calls only enqueue work (compute stream + communication stream per member,
  * ordered by events); orbfe_group_synchronize / _get_frame / _match wait.
+ *
+ * Transport of the exchange step.  ORBFE_GROUP_RCCL (default): ncclAllGather.  ORBFE_GROUP_COPY (local groups only,
+ * orbfe_group_create_local_ex or $ORBFE_GROUP_TRANSPORT=copy): every member pulls the other members' slices with
+ * hipMemcpyAsync / hipMemcpyPeerAsync on its communication stream behind the same events -- same bytes at the same offsets.
+ * It needs no communicator, so `devices` may name one device several times: several members on ONE GPU, which is how the
+ * multi-member paths are tested on a one-GPU box (RCCL refuses two ranks on one device).
  * ------------------------------------------------------------------------------------------- */
 typedef struct orbfe_group orbfe_group;
+enum { ORBFE_GROUP_RCCL = 0, ORBFE_GROUP_COPY = 1 };
 void orbfe_group_shard_range(int32_t nframes, int32_t rank, int32_t world, int32_t *lo, int32_t *hi);
+/* pure index arithmetic of the layout above (no group, no device): the rank that owns `frame`, and the frame's slot in the
+ * blocks of a group with `shard` slots per rank; -1 on a bad argument */
+int32_t orbfe_group_owner_rank(int32_t nframes, int32_t world, int32_t frame);
+int32_t orbfe_group_block_index_of(int32_t nframes, int32_t world, int32_t shard, int32_t frame);
 orbfe_status orbfe_group_unique_id(uint8_t id[128]);
 orbfe_status orbfe_group_create_local(const orbfe_params *p, const int32_t *devices, int32_t ndevices, orbfe_group **out);
+orbfe_status orbfe_group_create_local_ex(const orbfe_params *p, const int32_t *devices, int32_t ndevices, int32_t transport,
+                                         orbfe_group **out);
 orbfe_status orbfe_group_create_rank(const orbfe_params *p, int32_t device, int32_t rank, int32_t world, const uint8_t id[128],
                                      orbfe_group **out);
 void orbfe_group_destroy(orbfe_group *g);
 int32_t orbfe_group_world(const orbfe_group *g);
+int32_t orbfe_group_members(const orbfe_group *g);       /* members THIS process drives (world for a local group, 1 for a rank group) */
+int32_t orbfe_group_transport(const orbfe_group *g);
 int32_t orbfe_group_capacity(const orbfe_group *g);      /* cap: keypoint slots per frame of the blocks */
 int32_t orbfe_group_frames_padded(const orbfe_group *g); /* F = world * shard */
 int32_t orbfe_group_block_index(const orbfe_group *g, int32_t nframes, int32_t frame);
@@ -516,6 +534,11 @@ orbfe_status orbfe_group_blocks(orbfe_group *g, int32_t member, int32_t **d_n, o
                                 void **compute_stream);
 /* one frame of the (gathered) batch of the last extract call to the host */
 orbfe_status orbfe_group_get_frame(orbfe_group *g, int32_t frame, orbfe_keypoint *kps, uint8_t *desc, int32_t cap, int32_t *n_out);
+/* the same out of the blocks of member `member` (orbfe_group_get_frame reads member 0) */
+orbfe_status orbfe_group_get_frame_from(orbfe_group *g, int32_t member, int32_t frame, orbfe_keypoint *kps, uint8_t *desc, int32_t cap,
+                                        int32_t *n_out);
+/* the whole count block [F] of member `member` to the host (slots outside the shards' frames are 0) */
+orbfe_status orbfe_group_get_counts(orbfe_group *g, int32_t member, int32_t *n_out);
 /* pair p: brute-force match (as orbfe_match_bf: best <= th, ratio, rotation histogram) of frame qframe[p] -- a frame of a
  * shard of THIS process -- against frame tframe[p], any frame of the batch; match [npairs][cap] (train index or -1, slots
  * >= the query frame's count are -1), nmatches [npairs].  HOST arrays; call after orbfe_group_allgather. */

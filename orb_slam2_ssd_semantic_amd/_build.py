@@ -27,8 +27,20 @@ def hipcc():
     raise RuntimeError("hipcc not found: liborbfe.so cannot be built (there is no CPU fallback)")
 
 
+FLAGFILE = LIB + ".flags"   # the flag set the .so was built with (a variant left by an aborted A/B run must not pass for the default)
+
+
+def _flagset():
+    return " ".join(FLAGS + os.environ.get("ORBFE_EXTRA_FLAGS", "").split())
+
+
 def _stale():
     if not os.path.exists(LIB):
+        return True
+    try:
+        if open(FLAGFILE).read().strip() != _flagset():
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h)
@@ -40,6 +52,8 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     cc = hipcc()
+    if os.path.exists(FLAGFILE):
+        os.remove(FLAGFILE)   # no sidecar while a build is in flight: an aborted build is stale
     extra = os.environ.get("ORBFE_EXTRA_FLAGS", "").split()   # developer A/B builds on the GPU box (e.g. -DQT_MIN_WAVES=7)
     objs = []
     bdir = os.path.join(_PKG, "build")
@@ -62,6 +76,8 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    with open(FLAGFILE, "w") as f:
+        f.write(_flagset() + "\n")
     return LIB
 
 

@@ -38,7 +38,8 @@ SYMBOLS = (
     "orbfe_group_shard_range", "orbfe_group_unique_id", "orbfe_group_create_local", "orbfe_group_create_rank", "orbfe_group_destroy",
     "orbfe_group_world", "orbfe_group_capacity", "orbfe_group_frames_padded", "orbfe_group_block_index", "orbfe_group_extract_batch",
     "orbfe_group_extract_shard_device", "orbfe_group_allgather", "orbfe_group_synchronize", "orbfe_group_blocks", "orbfe_group_get_frame",
-    "orbfe_group_match", "orbfe_group_match_device",
+    "orbfe_group_match", "orbfe_group_match_device", "orbfe_group_owner_rank", "orbfe_group_block_index_of",
+    "orbfe_group_create_local_ex", "orbfe_group_members", "orbfe_group_transport", "orbfe_group_get_frame_from", "orbfe_group_get_counts",
 )
 
 
@@ -168,6 +169,13 @@ def lib():
     L.orbfe_group_synchronize.argtypes = [vp]
     L.orbfe_group_blocks.argtypes = [vp, i32, vp, vp, vp, vp]
     L.orbfe_group_get_frame.argtypes = [vp, i32, vp, vp, i32, vp]
+    L.orbfe_group_owner_rank.argtypes = [i32, i32, i32]
+    L.orbfe_group_block_index_of.argtypes = [i32, i32, i32, i32]
+    L.orbfe_group_create_local_ex.argtypes = [C.POINTER(OrbfeParams), vp, i32, i32, C.POINTER(vp)]
+    L.orbfe_group_members.argtypes = [vp]
+    L.orbfe_group_transport.argtypes = [vp]
+    L.orbfe_group_get_frame_from.argtypes = [vp, i32, i32, vp, vp, i32, vp]
+    L.orbfe_group_get_counts.argtypes = [vp, i32, vp]
     L.orbfe_group_match.argtypes = [vp, vp, vp, i32, f32, i32, i32, vp, vp]
     L.orbfe_group_match_device.argtypes = [vp, i32, vp, vp, i32, f32, i32, i32, vp, vp]
     for name in SYMBOLS:

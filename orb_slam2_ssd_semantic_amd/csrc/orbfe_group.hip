@@ -10,6 +10,12 @@
 //                             and handed to the other ranks by whatever means the host has): what bench.py launches
 // RCCL is loaded at run time (dlopen: the copy already in the process if there is one -- PyTorch ships its own librccl --
 // else librccl.so.1 / $ORBFE_RCCL_LIB); liborbfe.so itself has no link-time dependency on it.
+//
+// Transport of the exchange step (local groups): ORBFE_GROUP_RCCL = three in-place ncclAllGather calls; ORBFE_GROUP_COPY =
+// the same exchange as hipMemcpyAsync device-to-device copies (peer copies over xGMI between devices) from every other
+// member's slice into the member's blocks, on the same communication streams behind the same events.  The copy transport
+// needs no communicator, so several members may share ONE device: that is how the multi-member code paths (slice offsets,
+// uneven shards, zero tails, cross-shard matching) run under `-m gpu` on a one-GPU box.
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
@@ -78,6 +84,13 @@ Rccl &rccl()
         }                                                                                                   \
     } while (0)
 
+// the calling thread's device, restored on every exit path
+struct GDeviceGuard {
+    int prev = -1;
+    GDeviceGuard() { (void)hipGetDevice(&prev); }
+    ~GDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct Member {  // one device of the group that THIS process drives
     int device = 0, rank = 0;
     orbfe_handle *ext = nullptr;
@@ -98,6 +111,7 @@ struct Member {  // one device of the group that THIS process drives
 
 struct orbfe_group {
     orbfe_params prm;
+    int transport = ORBFE_GROUP_RCCL;
     int world = 1;           // ranks in the communicator
     int shard = 0;           // frames per rank slice of the blocks (= max_batch of every extractor)
     int cap = 0;
@@ -113,6 +127,28 @@ extern "C" void orbfe_group_shard_range(int32_t nframes, int32_t rank, int32_t w
     const int a = rank * base + std::min(rank, rem);
     if (lo) *lo = a;
     if (hi) *hi = a + base + (rank < rem ? 1 : 0);
+}
+
+// rank that owns global frame f of a batch of nframes cut by orbfe_group_shard_range
+static inline int owner_rank_of(int world, int nframes, int f)
+{
+    const int base = nframes / world, rem = nframes % world;
+    return f < rem * (base + 1) ? f / (base + 1) : rem + (f - rem * (base + 1)) / std::max(base, 1);
+}
+
+extern "C" int32_t orbfe_group_owner_rank(int32_t nframes, int32_t world, int32_t frame)
+{
+    if (world < 1 || nframes < 1 || frame < 0 || frame >= nframes) return -1;
+    return owner_rank_of(world, nframes, frame);
+}
+
+extern "C" int32_t orbfe_group_block_index_of(int32_t nframes, int32_t world, int32_t shard, int32_t frame)
+{
+    if (world < 1 || nframes < 1 || frame < 0 || frame >= nframes || shard * world < nframes) return -1;
+    const int r = owner_rank_of(world, nframes, frame);
+    int lo, hi;
+    orbfe_group_shard_range(nframes, r, world, &lo, &hi);
+    return r * shard + (frame - lo);
 }
 
 extern "C" orbfe_status orbfe_group_unique_id(uint8_t id[128])
@@ -147,10 +183,8 @@ static void destroy_member(Member &m)
 extern "C" void orbfe_group_destroy(orbfe_group *g)
 {
     if (!g) return;
-    int prev = -1;
-    (void)hipGetDevice(&prev);
+    GDeviceGuard guard;
     for (Member &m : g->mem) destroy_member(m);
-    if (prev >= 0) (void)hipSetDevice(prev);
     delete g;
 }
 
@@ -179,37 +213,43 @@ static orbfe_status init_member(orbfe_group *g, Member &m)
     return ORBFE_OK;
 }
 
-static orbfe_status group_alloc(const orbfe_params *p, int world, orbfe_group **out)
+static orbfe_status group_alloc(const orbfe_params *p, int world, int transport, orbfe_group **out)
 {
     if (!p || !out || world < 1 || p->max_batch < 1) { orbfe_set_error("bad argument to orbfe_group_create"); return ORBFE_ERR_ARG; }
-    if (!rccl().ok) { orbfe_set_error("RCCL could not be loaded (librccl.so / $ORBFE_RCCL_LIB)"); return ORBFE_ERR_STATE; }
+    if (transport == ORBFE_GROUP_RCCL && !rccl().ok) { orbfe_set_error("RCCL could not be loaded (librccl.so / $ORBFE_RCCL_LIB)"); return ORBFE_ERR_STATE; }
     orbfe_group *g = new (std::nothrow) orbfe_group();
     if (!g) return ORBFE_ERR_NOMEM;
     g->prm = *p;
+    g->transport = transport;
     g->world = world;
     g->shard = (p->max_batch + world - 1) / world;  // max_batch = the largest GLOBAL batch
     *out = g;
     return ORBFE_OK;
 }
 
-extern "C" orbfe_status orbfe_group_create_local(const orbfe_params *p, const int32_t *devices, int32_t ndevices, orbfe_group **out)
+extern "C" orbfe_status orbfe_group_create_local_ex(const orbfe_params *p, const int32_t *devices, int32_t ndevices, int32_t transport,
+                                                    orbfe_group **out)
 {
     if (out) *out = nullptr;
-    if (!devices || ndevices < 1) { orbfe_set_error("bad argument to orbfe_group_create_local"); return ORBFE_ERR_ARG; }
+    if (!devices || ndevices < 1 || (transport != ORBFE_GROUP_RCCL && transport != ORBFE_GROUP_COPY)) {
+        orbfe_set_error("bad argument to orbfe_group_create_local");
+        return ORBFE_ERR_ARG;
+    }
     orbfe_group *g = nullptr;
-    orbfe_status s = group_alloc(p, ndevices, &g);
+    orbfe_status s = group_alloc(p, ndevices, transport, &g);
     if (s != ORBFE_OK) return s;
-    int prev = -1;
-    (void)hipGetDevice(&prev);
+    GDeviceGuard guard;
     g->mem.resize((size_t)ndevices);
-    std::vector<ncclComm_t> comms((size_t)ndevices);
+    std::vector<ncclComm_t> comms((size_t)ndevices, nullptr);
     std::vector<int> devs(devices, devices + ndevices);
-    const ncclResult_t nr = rccl().CommInitAll(comms.data(), ndevices, devs.data());
-    if (nr != ncclSuccess) {
-        orbfe_set_error("ncclCommInitAll failed: %s", rccl().GetErrorString ? rccl().GetErrorString(nr) : "?");
-        g->mem.clear();
-        orbfe_group_destroy(g);
-        return ORBFE_ERR_HIP;
+    if (transport == ORBFE_GROUP_RCCL) {
+        const ncclResult_t nr = rccl().CommInitAll(comms.data(), ndevices, devs.data());
+        if (nr != ncclSuccess) {
+            orbfe_set_error("ncclCommInitAll failed: %s", rccl().GetErrorString ? rccl().GetErrorString(nr) : "?");
+            g->mem.clear();
+            orbfe_group_destroy(g);
+            return ORBFE_ERR_HIP;
+        }
     }
     for (int r = 0; r < ndevices; ++r) {
         g->mem[(size_t)r].device = devs[(size_t)r];
@@ -217,10 +257,27 @@ extern "C" orbfe_status orbfe_group_create_local(const orbfe_params *p, const in
         g->mem[(size_t)r].comm = comms[(size_t)r];
     }
     for (int r = 0; r < ndevices && s == ORBFE_OK; ++r) s = init_member(g, g->mem[(size_t)r]);
-    if (prev >= 0) (void)hipSetDevice(prev);
+    if (s == ORBFE_OK && transport == ORBFE_GROUP_COPY)
+        // peer access between distinct devices, so that the exchange copies go over xGMI directly (already-enabled is fine)
+        for (int a = 0; a < ndevices; ++a)
+            for (int b = 0; b < ndevices; ++b) {
+                if (devs[(size_t)a] == devs[(size_t)b]) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devs[(size_t)a], devs[(size_t)b]) == hipSuccess && can && hipSetDevice(devs[(size_t)a]) == hipSuccess) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(devs[(size_t)b], 0);
+                    if (e != hipSuccess) (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled
+                }
+            }
     if (s != ORBFE_OK) { orbfe_group_destroy(g); return s; }
     *out = g;
     return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_group_create_local(const orbfe_params *p, const int32_t *devices, int32_t ndevices, orbfe_group **out)
+{
+    // $ORBFE_GROUP_TRANSPORT = "copy" selects the copy transport for groups made through this entry point
+    const char *t = getenv("ORBFE_GROUP_TRANSPORT");
+    return orbfe_group_create_local_ex(p, devices, ndevices, t && !strcmp(t, "copy") ? ORBFE_GROUP_COPY : ORBFE_GROUP_RCCL, out);
 }
 
 extern "C" orbfe_status orbfe_group_create_rank(const orbfe_params *p, int32_t device, int32_t rank, int32_t world, const uint8_t id[128],
@@ -229,11 +286,10 @@ extern "C" orbfe_status orbfe_group_create_rank(const orbfe_params *p, int32_t d
     if (out) *out = nullptr;
     if (!id || rank < 0 || rank >= world) { orbfe_set_error("bad argument to orbfe_group_create_rank"); return ORBFE_ERR_ARG; }
     orbfe_group *g = nullptr;
-    orbfe_status s = group_alloc(p, world, &g);
+    orbfe_status s = group_alloc(p, world, ORBFE_GROUP_RCCL, &g);
     if (s != ORBFE_OK) return s;
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    if (device < 0) device = prev >= 0 ? prev : 0;
+    GDeviceGuard guard;
+    if (device < 0) device = guard.prev >= 0 ? guard.prev : 0;
     g->mem.resize(1);
     Member &m = g->mem[0];
     m.device = device;
@@ -249,22 +305,19 @@ extern "C" orbfe_status orbfe_group_create_rank(const orbfe_params *p, int32_t d
         return ORBFE_ERR_HIP;
     }
     s = init_member(g, m);
-    if (prev >= 0) (void)hipSetDevice(prev);
     if (s != ORBFE_OK) { orbfe_group_destroy(g); return s; }
     *out = g;
     return ORBFE_OK;
 }
 
+extern "C" int32_t orbfe_group_transport(const orbfe_group *g) { return g ? g->transport : -1; }
+extern "C" int32_t orbfe_group_members(const orbfe_group *g) { return g ? (int32_t)g->mem.size() : 0; }
 extern "C" int32_t orbfe_group_world(const orbfe_group *g) { return g ? g->world : 0; }
 extern "C" int32_t orbfe_group_capacity(const orbfe_group *g) { return g ? g->cap : 0; }
 extern "C" int32_t orbfe_group_frames_padded(const orbfe_group *g) { return g ? g->world * g->shard : 0; }
 
 // rank that owns global frame f of a batch of nframes, and the frame's index in the gathered blocks
-static inline int owner_rank(const orbfe_group *g, int nframes, int f)
-{
-    const int base = nframes / g->world, rem = nframes % g->world;
-    return f < rem * (base + 1) ? f / (base + 1) : rem + (f - rem * (base + 1)) / std::max(base, 1);
-}
+static inline int owner_rank(const orbfe_group *g, int nframes, int f) { return owner_rank_of(g->world, nframes, f); }
 static inline int block_index(const orbfe_group *g, int nframes, int f)
 {
     const int r = owner_rank(g, nframes, f);
@@ -282,16 +335,20 @@ extern "C" int32_t orbfe_group_block_index(const orbfe_group *g, int32_t nframes
 static orbfe_status extract_member(orbfe_group *g, Member &m, const uint8_t *d_gray, int nsh, int w, int ht, int stride, size_t fstride)
 {
     // the extractor writes its shard into slice `rank` of the member's blocks; the unused tail of the slice is cleared so
-    // that a short last shard gathers as empty frames
+    // that a short last shard gathers as empty frames.  First the previous gather has to be done with the slice: it read
+    // it on the communication stream (copy transport: on EVERY member's communication stream -- the others pull it).
     const size_t at = (size_t)m.rank * g->shard;
+    if (g->transport == ORBFE_GROUP_COPY) {
+        for (Member &o : g->mem) ORBFE_HIP(hipStreamWaitEvent(m.s_cmp, o.ev_comm, 0));
+    } else {
+        ORBFE_HIP(hipStreamWaitEvent(m.s_cmp, m.ev_comm, 0));
+    }
     if (nsh < g->shard) {
         ORBFE_HIP(hipMemsetAsync(m.d_n + at + nsh, 0, (size_t)(g->shard - nsh) * sizeof(int32_t), m.s_cmp));
         ORBFE_HIP(hipMemsetAsync(m.d_kps + (at + nsh) * g->cap, 0, (size_t)(g->shard - nsh) * g->cap * sizeof(orbfe_keypoint), m.s_cmp));
         ORBFE_HIP(hipMemsetAsync(m.d_desc + (at + nsh) * g->cap * 32, 0, (size_t)(g->shard - nsh) * g->cap * 32, m.s_cmp));
     }
     if (nsh > 0) {
-        // the previous gather read these slices on the communication stream
-        ORBFE_HIP(hipStreamWaitEvent(m.s_cmp, m.ev_comm, 0));
         const orbfe_status s = orbfe_extract_batch_device(m.ext, d_gray, nsh, w, ht, stride, fstride, m.d_kps + at * g->cap,
                                                           m.d_desc + at * g->cap * 32, g->cap, m.d_n + at, (void *)m.s_cmp);
         if (s != ORBFE_OK) return s;
@@ -307,8 +364,7 @@ extern "C" orbfe_status orbfe_group_extract_batch(orbfe_group *g, const uint8_t 
         orbfe_set_error("bad argument to orbfe_group_extract_batch (at most %d frames)", g ? g->world * g->shard : 0);
         return ORBFE_ERR_ARG;
     }
-    int prev = -1;
-    (void)hipGetDevice(&prev);
+    GDeviceGuard guard;
     orbfe_status rs = ORBFE_OK;
     for (Member &m : g->mem) {
         int lo, hi;
@@ -317,7 +373,10 @@ extern "C" orbfe_status orbfe_group_extract_batch(orbfe_group *g, const uint8_t 
         if (hipSetDevice(m.device) != hipSuccess) { rs = ORBFE_ERR_HIP; break; }
         const size_t fbytes = (size_t)w * ht, need = fbytes * (size_t)std::max(nsh, 1);
         if (need > m.stage_bytes) {
-            if (m.d_stage) (void)hipFree(m.d_stage);
+            if (m.d_stage) {
+                (void)hipStreamSynchronize(m.s_cmp);  // a previous extraction may still read the old staging block
+                (void)hipFree(m.d_stage);
+            }
             m.d_stage = nullptr;
             m.stage_bytes = 0;
             if (hipMalloc((void **)&m.d_stage, need + 64) != hipSuccess) { rs = ORBFE_ERR_NOMEM; break; }
@@ -330,7 +389,6 @@ extern "C" orbfe_status orbfe_group_extract_batch(orbfe_group *g, const uint8_t 
         if (rs == ORBFE_OK) rs = extract_member(g, m, m.d_stage, nsh, w, ht, w, fbytes);
         if (rs != ORBFE_OK) break;
     }
-    if (prev >= 0) (void)hipSetDevice(prev);
     if (rs == ORBFE_OK) g->last_nframes = nframes;
     return rs;
 }
@@ -346,22 +404,16 @@ extern "C" orbfe_status orbfe_group_extract_shard_device(orbfe_group *g, int32_t
     int lo, hi;
     orbfe_group_shard_range(nframes_global, m.rank, g->world, &lo, &hi);
     if (hi > lo && !d_gray) { orbfe_set_error("orbfe_group_extract_shard_device: null frames"); return ORBFE_ERR_ARG; }
-    int prev = -1;
-    (void)hipGetDevice(&prev);
+    GDeviceGuard guard;
     ORBFE_HIP(hipSetDevice(m.device));
     const orbfe_status s = extract_member(g, m, d_gray, hi - lo, w, ht, stride, frame_stride);
-    if (prev >= 0) (void)hipSetDevice(prev);
     if (s == ORBFE_OK) g->last_nframes = nframes_global;
     return s;
 }
 
-extern "C" orbfe_status orbfe_group_allgather(orbfe_group *g)
+// the RCCL calls of one exchange step; the caller closes the NCCL group on every path
+static orbfe_status allgather_rccl_enqueue(orbfe_group *g)
 {
-    if (!g) return ORBFE_ERR_ARG;
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    // in-place all-gather of the three padded blocks: every rank's slice sits at rank * shard of the receive buffer
-    ORBFE_NCCL(rccl().GroupStart());
     for (Member &m : g->mem) {
         ORBFE_HIP(hipSetDevice(m.device));
         ORBFE_HIP(hipStreamWaitEvent(m.s_comm, m.ev_cmp, 0));
@@ -370,27 +422,69 @@ extern "C" orbfe_status orbfe_group_allgather(orbfe_group *g)
         ORBFE_NCCL(rccl().AllGather(m.d_kps + at * g->cap, m.d_kps, S * g->cap * sizeof(orbfe_keypoint), ncclUint8, m.comm, m.s_comm));
         ORBFE_NCCL(rccl().AllGather(m.d_desc + at * g->cap * 32, m.d_desc, S * g->cap * 32, ncclUint8, m.comm, m.s_comm));
     }
-    ORBFE_NCCL(rccl().GroupEnd());
+    return ORBFE_OK;
+}
+
+// the copy transport: member m pulls slice r of every other member o (rank r) into slice r of its own blocks -- the same
+// bytes at the same offsets an in-place all-gather leaves there -- on m's communication stream, behind o's extraction
+static orbfe_status allgather_copy_enqueue(orbfe_group *g)
+{
+    const size_t S = (size_t)g->shard;
+    for (Member &m : g->mem) {
+        ORBFE_HIP(hipSetDevice(m.device));
+        for (Member &o : g->mem) ORBFE_HIP(hipStreamWaitEvent(m.s_comm, o.ev_cmp, 0));
+        for (Member &o : g->mem) {
+            if (&o == &m) continue;
+            const size_t at = (size_t)o.rank * S;
+            if (o.device == m.device) {
+                ORBFE_HIP(hipMemcpyAsync(m.d_n + at, o.d_n + at, S * sizeof(int32_t), hipMemcpyDeviceToDevice, m.s_comm));
+                ORBFE_HIP(hipMemcpyAsync(m.d_kps + at * g->cap, o.d_kps + at * g->cap, S * g->cap * sizeof(orbfe_keypoint), hipMemcpyDeviceToDevice, m.s_comm));
+                ORBFE_HIP(hipMemcpyAsync(m.d_desc + at * g->cap * 32, o.d_desc + at * g->cap * 32, S * g->cap * 32, hipMemcpyDeviceToDevice, m.s_comm));
+            } else {
+                ORBFE_HIP(hipMemcpyPeerAsync(m.d_n + at, m.device, o.d_n + at, o.device, S * sizeof(int32_t), m.s_comm));
+                ORBFE_HIP(hipMemcpyPeerAsync(m.d_kps + at * g->cap, m.device, o.d_kps + at * g->cap, o.device, S * g->cap * sizeof(orbfe_keypoint), m.s_comm));
+                ORBFE_HIP(hipMemcpyPeerAsync(m.d_desc + at * g->cap * 32, m.device, o.d_desc + at * g->cap * 32, o.device, S * g->cap * 32, m.s_comm));
+            }
+        }
+    }
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_group_allgather(orbfe_group *g)
+{
+    if (!g) return ORBFE_ERR_ARG;
+    GDeviceGuard guard;
+    orbfe_status s;
+    if (g->transport == ORBFE_GROUP_COPY) {
+        s = allgather_copy_enqueue(g);
+    } else {
+        // in-place all-gather of the three padded blocks: every rank's slice sits at rank * shard of the receive buffer
+        ORBFE_NCCL(rccl().GroupStart());
+        s = allgather_rccl_enqueue(g);
+        const ncclResult_t ne = rccl().GroupEnd();  // closed on the error path too: a failure must not leave the group open
+        if (s == ORBFE_OK && ne != ncclSuccess) {
+            orbfe_set_error("ncclGroupEnd failed: %s", rccl().GetErrorString ? rccl().GetErrorString(ne) : "?");
+            s = ORBFE_ERR_HIP;
+        }
+    }
+    if (s != ORBFE_OK) return s;
     for (Member &m : g->mem) {
         ORBFE_HIP(hipSetDevice(m.device));
         ORBFE_HIP(hipEventRecord(m.ev_comm, m.s_comm));
         ORBFE_HIP(hipStreamWaitEvent(m.s_cmp, m.ev_comm, 0));  // consumers on the compute stream see the gathered blocks
     }
-    if (prev >= 0) (void)hipSetDevice(prev);
     return ORBFE_OK;
 }
 
 extern "C" orbfe_status orbfe_group_synchronize(orbfe_group *g)
 {
     if (!g) return ORBFE_ERR_ARG;
-    int prev = -1;
-    (void)hipGetDevice(&prev);
+    GDeviceGuard guard;
     for (Member &m : g->mem) {
         ORBFE_HIP(hipSetDevice(m.device));
         ORBFE_HIP(hipStreamSynchronize(m.s_cmp));
         ORBFE_HIP(hipStreamSynchronize(m.s_comm));
     }
-    if (prev >= 0) (void)hipSetDevice(prev);
     return ORBFE_OK;
 }
 
@@ -406,30 +500,46 @@ extern "C" orbfe_status orbfe_group_blocks(orbfe_group *g, int32_t member, int32
     return ORBFE_OK;
 }
 
-extern "C" orbfe_status orbfe_group_get_frame(orbfe_group *g, int32_t frame, orbfe_keypoint *kps, uint8_t *desc, int32_t cap, int32_t *n_out)
+extern "C" orbfe_status orbfe_group_get_frame_from(orbfe_group *g, int32_t member, int32_t frame, orbfe_keypoint *kps, uint8_t *desc,
+                                                   int32_t cap, int32_t *n_out)
 {
-    if (!g || g->mem.empty() || !n_out || frame < 0 || frame >= g->last_nframes) { orbfe_set_error("bad argument to orbfe_group_get_frame"); return ORBFE_ERR_ARG; }
-    Member &m = g->mem[0];
+    if (!g || member < 0 || member >= (int)g->mem.size() || !n_out || frame < 0 || frame >= g->last_nframes) {
+        orbfe_set_error("bad argument to orbfe_group_get_frame");
+        return ORBFE_ERR_ARG;
+    }
+    Member &m = g->mem[(size_t)member];
     const size_t bi = (size_t)block_index(g, g->last_nframes, frame);
-    int prev = -1;
-    (void)hipGetDevice(&prev);
+    GDeviceGuard guard;
     ORBFE_HIP(hipSetDevice(m.device));
     ORBFE_HIP(hipStreamSynchronize(m.s_cmp));
     ORBFE_HIP(hipStreamSynchronize(m.s_comm));
     int32_t n = 0;
     ORBFE_HIP(hipMemcpy(&n, m.d_n + bi, sizeof(int32_t), hipMemcpyDeviceToHost));
     *n_out = n;
-    orbfe_status s = ORBFE_OK;
-    if (n > cap) s = ORBFE_ERR_CAP;
-    else if (n > 0) {
-        if (!kps || !desc) s = ORBFE_ERR_ARG;
-        else {
-            ORBFE_HIP(hipMemcpy(kps, m.d_kps + bi * g->cap, (size_t)n * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost));
-            ORBFE_HIP(hipMemcpy(desc, m.d_desc + bi * g->cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
-        }
+    if (n > cap) return ORBFE_ERR_CAP;
+    if (n > 0) {
+        if (!kps || !desc) return ORBFE_ERR_ARG;
+        ORBFE_HIP(hipMemcpy(kps, m.d_kps + bi * g->cap, (size_t)n * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost));
+        ORBFE_HIP(hipMemcpy(desc, m.d_desc + bi * g->cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
     }
-    if (prev >= 0) (void)hipSetDevice(prev);
-    return s;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_group_get_counts(orbfe_group *g, int32_t member, int32_t *n_out /* world * shard */)
+{
+    if (!g || member < 0 || member >= (int)g->mem.size() || !n_out) { orbfe_set_error("bad argument to orbfe_group_get_counts"); return ORBFE_ERR_ARG; }
+    Member &m = g->mem[(size_t)member];
+    GDeviceGuard guard;
+    ORBFE_HIP(hipSetDevice(m.device));
+    ORBFE_HIP(hipStreamSynchronize(m.s_cmp));
+    ORBFE_HIP(hipStreamSynchronize(m.s_comm));
+    ORBFE_HIP(hipMemcpy(n_out, m.d_n, (size_t)g->world * g->shard * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_group_get_frame(orbfe_group *g, int32_t frame, orbfe_keypoint *kps, uint8_t *desc, int32_t cap, int32_t *n_out)
+{
+    return orbfe_group_get_frame_from(g, 0, frame, kps, desc, cap, n_out);
 }
 
 // The consumer of the gather (src/LoopClosing.cc:312-342 does this serially per candidate keyframe): pair p matches frame
@@ -445,8 +555,7 @@ extern "C" orbfe_status orbfe_group_match(orbfe_group *g, const int32_t *qframe,
     const int nf = g->last_nframes;
     for (int p = 0; p < npairs; ++p)
         if (qframe[p] < 0 || qframe[p] >= nf || tframe[p] < 0 || tframe[p] >= nf) { orbfe_set_error("pair %d: frame out of range", p); return ORBFE_ERR_ARG; }
-    int prev = -1;
-    (void)hipGetDevice(&prev);
+    GDeviceGuard guard;
     std::vector<int> owner_of((size_t)npairs, -1);
     std::vector<std::vector<int>> mine(g->mem.size());
     for (int p = 0; p < npairs; ++p) {
@@ -492,7 +601,6 @@ extern "C" orbfe_status orbfe_group_match(orbfe_group *g, const int32_t *qframe,
             nmatches[p] = hn[(size_t)i];
         }
     }
-    if (prev >= 0) (void)hipSetDevice(prev);
     return rs;
 }
 
@@ -503,11 +611,8 @@ extern "C" orbfe_status orbfe_group_match_device(orbfe_group *g, int32_t member,
 {
     if (!g || member < 0 || member >= (int)g->mem.size()) return ORBFE_ERR_ARG;
     Member &m = g->mem[(size_t)member];
-    int prev = -1;
-    (void)hipGetDevice(&prev);
+    GDeviceGuard guard;
     ORBFE_HIP(hipSetDevice(m.device));
-    const orbfe_status s = orbfe_match_bf_frames_device(m.mat, m.d_kps, m.d_desc, m.d_n, g->cap, d_qblock, d_tblock, npairs, nnratio, th,
-                                                        check_ori, d_match, d_nmatches, (void *)m.s_cmp);
-    if (prev >= 0) (void)hipSetDevice(prev);
-    return s;
+    return orbfe_match_bf_frames_device(m.mat, m.d_kps, m.d_desc, m.d_n, g->cap, d_qblock, d_tblock, npairs, nnratio, th, check_ori,
+                                        d_match, d_nmatches, (void *)m.s_cmp);
 }

@@ -92,8 +92,10 @@ class KeyframeGroup:
     and the consumer of the gather (own frames against candidate frames anywhere in the batch).  `devices` = the devices
     ONE process drives (ncclCommInitAll); `rank_of_world=(rank, world, id_bytes)` = one process per device."""
 
+    RCCL, COPY = 0, 1   # transports of the exchange step (include/orbfe.h ORBFE_GROUP_RCCL / ORBFE_GROUP_COPY)
+
     def __init__(self, nfeatures, scale_factor, nlevels, ini_th, min_th, max_width, max_height, max_batch, devices=(0,),
-                 rank_of_world=None, device=None):
+                 rank_of_world=None, device=None, transport=None):
         import ctypes as C
         from . import _ffi
         self._ffi, self._C = _ffi, C
@@ -102,7 +104,11 @@ class KeyframeGroup:
         h = C.c_void_p()
         if rank_of_world is None:
             devs = (C.c_int32 * len(devices))(*devices)
-            _ffi.check(L.orbfe_group_create_local(C.byref(p), devs, len(devices), C.byref(h)), "orbfe_group_create_local")
+            if transport is None:   # the C entry point's own default ($ORBFE_GROUP_TRANSPORT, else RCCL)
+                _ffi.check(L.orbfe_group_create_local(C.byref(p), devs, len(devices), C.byref(h)), "orbfe_group_create_local")
+            else:
+                _ffi.check(L.orbfe_group_create_local_ex(C.byref(p), devs, len(devices), int(transport), C.byref(h)),
+                           "orbfe_group_create_local_ex")
         else:
             rank, world, idb = rank_of_world
             buf = (C.c_uint8 * 128).from_buffer_copy(bytes(idb))
@@ -111,6 +117,8 @@ class KeyframeGroup:
         self.handle = h
         self.L = L
         self.world = L.orbfe_group_world(h)
+        self.members = L.orbfe_group_members(h)
+        self.transport = L.orbfe_group_transport(h)
         self.cap = L.orbfe_group_capacity(h)
         self.frames_padded = L.orbfe_group_frames_padded(h)
 
@@ -171,15 +179,31 @@ class KeyframeGroup:
         self._ffi.check(self.L.orbfe_group_blocks(self.handle, member, C.byref(dn), C.byref(dk), C.byref(dd), C.byref(st)), "orbfe_group_blocks")
         return dn.value, dk.value, dd.value, st.value
 
-    def get_frame(self, frame):
+    def get_frame(self, frame, member=0):
         import numpy as np
         C = self._C
         kps = np.zeros(self.cap, self._ffi.KP_DTYPE)
         desc = np.zeros((self.cap, 32), np.uint8)
         n = C.c_int32()
-        self._ffi.check(self.L.orbfe_group_get_frame(self.handle, frame, self._ffi.ptr(kps), self._ffi.ptr(desc), self.cap, C.byref(n)),
-                        "orbfe_group_get_frame")
+        self._ffi.check(self.L.orbfe_group_get_frame_from(self.handle, member, frame, self._ffi.ptr(kps), self._ffi.ptr(desc), self.cap,
+                                                          C.byref(n)), "orbfe_group_get_frame_from")
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def counts(self, member=0):
+        import numpy as np
+        n = np.zeros(self.frames_padded, np.int32)
+        self._ffi.check(self.L.orbfe_group_get_counts(self.handle, member, self._ffi.ptr(n)), "orbfe_group_get_counts")
+        return n
+
+    @staticmethod
+    def owner_rank_c(nframes, world, frame):
+        from . import _ffi
+        return _ffi.lib().orbfe_group_owner_rank(nframes, world, frame)
+
+    @staticmethod
+    def block_index_c(nframes, world, shard, frame):
+        from . import _ffi
+        return _ffi.lib().orbfe_group_block_index_of(nframes, world, shard, frame)
 
     def match_device(self, member, d_qblock_ptr, d_tblock_ptr, npairs, d_match_ptr, d_nm_ptr, nnratio=0.9, th=100, check_ori=True):
         self._ffi.check(self.L.orbfe_group_match_device(self.handle, member, d_qblock_ptr, d_tblock_ptr, npairs, nnratio, th, int(check_ori),

@@ -5,7 +5,11 @@
 cd "$(dirname "$0")/.."
 for flags in "$@" ""; do
     echo "=== flags: '${flags}'"
-    ORBFE_EXTRA_FLAGS="$flags" python -c "from orb_slam2_ssd_semantic_amd import _build; _build.build(force=True)" || exit 1
+    if ! ORBFE_EXTRA_FLAGS="$flags" python -c "from orb_slam2_ssd_semantic_amd import _build; _build.build(force=True)"; then
+        echo "=== build failed for '${flags}': restoring the default build"
+        python -c "from orb_slam2_ssd_semantic_amd import _build; _build.build(force=True)"
+        exit 1
+    fi
     [ -z "$flags" ] && [ $# -gt 0 ] && break
     python tools/stage_times.py
     [ -n "$AB_CFG5" ] && B=128 W=1920 H=1080 NF=4000 python tools/stage_times.py
