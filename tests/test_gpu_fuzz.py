@@ -43,15 +43,21 @@ def test_fuzz_extractor(oracle):
         if rng.random() < 0.2:  # flat regions: empty cells exercise the minTh fallback and tiny trees
             y0, x0 = int(rng.integers(0, h // 2)), int(rng.integers(0, w // 2))
             img[y0:y0 + h // 3, x0:x0 + w // 3] = 128
-        tag = f"case {c}: {w}x{h} nf={nf} nlev={nlev} sf={sf:.2f} th={ini}/{mn} kind={kind}"
+        br = (c >> 1) & 1   # GaussianBlur column rounding: 0 = half-up, 1 = the SSE2 kernel's half-to-even
+        tag = f"case {c}: {w}x{h} nf={nf} nlev={nlev} sf={sf:.2f} th={ini}/{mn} kind={kind} blur_rounding={br}"
         try:
-            e = ORBextractor(nf, sf, nlev, ini, mn, max_width=w, max_height=h)
+            e = ORBextractor(nf, sf, nlev, ini, mn, max_width=w, max_height=h, blur_rounding=br)
             e.set_fast_mode(c & 1)
             gk, gd = e(img)
         except OrbfeError:
             continue  # sizes the boundary rejects (level too small for one cell, > 4 quadtree roots, per-level cap)
-        ok, od = oracle.OracleExtractor(nf, sf, nlev, ini, mn)(img, cap=nf + 16 * nlev + 256)
+        oe = oracle.OracleExtractor(nf, sf, nlev, ini, mn)
+        oe.set_blur_mode(br)
+        ok, od = oe(img, cap=nf + 16 * nlev + 256)
         assert _same(gk, gd, ok, od), tag
+        for l in range(nlev):
+            if len(oe.selected(l)):   # the reference blurs only the levels that hold keypoints (:1090)
+                assert np.array_equal(e.blurred_level(l), oe.blurred(l)), (tag, l)
         assert e.overflow() == 0, tag
         ran += 1
     assert ran >= 0.6 * _n(100), ran
