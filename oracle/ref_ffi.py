@@ -302,6 +302,76 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_SHIMSTEREO = os.path.join(_OUT, "libshim_stereo.so")
+_shimstereo = None
+_STEREO_ARGS = None
+
+
+def _declare_stereo_frame(fn):
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    fn.argtypes = [vp, vp, vp, vp, ci, ci, ci] + [cf] * 7 + [vp] * 7 + [ci, vp, vp, vp, vp]
+    fn.restype = ci
+
+
+def shimstereo_lib():
+    """oracle/_ref/libshim_stereo.so: the reference's stereo Frame constructor (src/Frame.cc:102-168, sliced verbatim with
+    ExtractORB / UndistortKeyPoints / ComputeImageBounds / ComputeStereoMatches / AssignFeaturesToGrid) compiled around the
+    PRODUCT's extractor shim and matcher shim.  Needs a GPU to run."""
+    global _shimstereo
+    if _shimstereo is None:
+        build_shims()
+        if not os.path.exists(_SHIMSTEREO):
+            raise RuntimeError("oracle/_ref/libshim_stereo.so is missing")
+        L = C.CDLL(_SHIMSTEREO)
+        L.shimst_ext_create.restype = C.c_void_p
+        L.shimst_ext_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.shimst_ext_destroy.argtypes = [C.c_void_p]
+        _declare_stereo_frame(L.shimst_stereo_frame)
+        _shimstereo = L
+    return _shimstereo
+
+
+def stereo_frame(left, right, fx, fy, cx, cy, bf, th_depth, mb_before=0.0, nfeatures=1000, scale_factor=1.2, nlevels=8,
+                 ini_th=20, min_th=7, shim=False, extractors=None):
+    """Frame(imLeft, imRight, timeStamp, extractorLeft, extractorRight, voc, K, distCoef = 0, bf, thDepth) -- the reference's
+    stereo constructor body, compiled -- around two reference extractors (shim=False, libref_orb.so) or two of the
+    product's shim extractors + the product's matcher shim (shim=True, libshim_stereo.so).  Returns a dict of what the
+    constructor leaves in the Frame."""
+    left = np.ascontiguousarray(left, np.uint8)
+    right = np.ascontiguousarray(right, np.uint8)
+    h, w = left.shape
+    cap = nfeatures + 4 * nlevels + 256
+    keys, keys_un, keys_r = (np.zeros(cap, KP_DTYPE) for _ in range(3))
+    desc, desc_r = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+    ur, dep = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    cell_off, cell_idx = np.zeros(64 * 48 + 1, np.uint32), np.zeros(cap, np.uint32)
+    scal = np.zeros(8, np.float32)
+    nr = C.c_int()
+    if shim:
+        L = shimstereo_lib()
+        made = extractors is None
+        eL, eR = extractors or (L.shimst_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th),
+                                L.shimst_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th))
+        fn, hL, hR = L.shimst_stereo_frame, eL, eR
+    else:
+        L = lib()
+        _declare_stereo_frame(L.ref_stereo_frame)
+        made = False
+        eL, eR = extractors or (RefExtractor(nfeatures, scale_factor, nlevels, ini_th, min_th),
+                                RefExtractor(nfeatures, scale_factor, nlevels, ini_th, min_th))
+        fn, hL, hR = L.ref_stereo_frame, eL.h, eR.h
+    n = fn(hL, hR, _p(left), _p(right), w, h, left.strides[0], fx, fy, cx, cy, bf, th_depth, mb_before, _p(keys), _p(keys_un),
+           _p(desc), _p(ur), _p(dep), _p(keys_r), _p(desc_r), cap, C.byref(nr), _p(cell_off), _p(cell_idx), _p(scal))
+    if shim and made:
+        L.shimst_ext_destroy(eL)
+        L.shimst_ext_destroy(eR)
+    if n < 0:
+        raise RuntimeError(f"stereo_frame rc={n}")
+    return dict(keys=keys[:n].copy(), keys_un=keys_un[:n].copy(), desc=desc[:n].copy(), u_right=ur[:n].copy(), depth=dep[:n].copy(),
+                keys_right=keys_r[:nr.value].copy(), desc_right=desc_r[:nr.value].copy(), cell_off=cell_off, cell_idx=cell_idx[:n].copy(),
+                scal=scal)
+
+
 def configure(bump=True, canonical_trig=True, blur_mode=0):
     """The two machine-dependent spots of the reference binary and the blur column-rounding variant:
     bump=True           operator new from a bump arena -> the :686 pointer sort breaks ties by creation order

@@ -37,6 +37,7 @@
 #include <set>
 #include <string>
 #include <utility>
+#include <stdexcept>
 #include <vector>
 
 #define CV_PI 3.1415926535897932384626433832795
@@ -337,6 +338,15 @@ class Mat
         return *this;
     }
 
+    /* Mat::reshape(cn): same data, another channel count (continuous matrices only; Frame::UndistortKeyPoints :577-579) */
+    Mat reshape(int cn, int = 0) const
+    {
+        assert(isContinuous() && (cols * channels()) % cn == 0);
+        Mat m(*this);
+        m.cols = cols * channels() / cn;
+        m.flags = CV_MAKETYPE(depth(), cn);
+        return m;
+    }
     Mat rowRange(int startrow, int endrow) const { return Mat(*this, Rect(0, startrow, cols, endrow - startrow)); }
     Mat colRange(int startcol, int endcol) const { return Mat(*this, Rect(startcol, 0, endcol - startcol, rows)); }
     Mat row(int y) const { return Mat(*this, Rect(0, y, cols, 1)); }
@@ -596,6 +606,13 @@ void FAST(InputArray image, std::vector<KeyPoint> &keypoints, int threshold, boo
 void GaussianBlur(InputArray src, OutputArray dst, Size ksize, double sigmaX, double sigmaY = 0,
                   int borderType = BORDER_DEFAULT);
 float fastAtan2(float y, float x);
+
+/* calib3d: referenced by Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:578, :608) only when the
+ * distortion coefficients are non-zero; rectified input (every stereo configuration the reference ships) never calls it */
+inline void undistortPoints(const Mat &, Mat &, const Mat &, const Mat &, const Mat &, const Mat &)
+{
+    throw std::logic_error("cv stub: undistortPoints (calib3d) is not available");
+}
 
 /* referenced only by the dead ComputeKeyPointsOld (ORBextractor.cc:1015,1033), which operator() never calls */
 class KeyPointsFilter

@@ -16,7 +16,7 @@ namespace cvstub
 {
 Tap &tap()
 {
-    static Tap t = {false, {}, {}, 0, 0, 0, 0, 0, 0};
+    static thread_local Tap t = {false, {}, {}, 0, 0, 0, 0, 0, 0}; /* per thread: the stereo Frame constructor extracts on two */
     return t;
 }
 int blur_mode = 0;
@@ -171,24 +171,29 @@ unsigned char *g_arena = 0;
 size_t g_arena_used = 0;
 int g_alloc_mode = 0;
 
+unsigned char *arena_map()
+{
+    void *p = mmap(0, ARENA_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) {
+        fprintf(stderr, "oracle/_ref: arena mmap failed\n");
+        abort();
+    }
+    return (unsigned char *)p;
+}
+
 void *arena_alloc(size_t n)
 {
-    if (!g_arena) {
-        void *p = mmap(0, ARENA_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-        if (p == MAP_FAILED) {
-            fprintf(stderr, "oracle/_ref: arena mmap failed\n");
-            abort();
-        }
-        g_arena = (unsigned char *)p;
-    }
+    static unsigned char *mapped = arena_map(); /* thread-safe one-time mapping */
+    g_arena = mapped;
     n = (n + 15) & ~(size_t)15;
-    if (g_arena_used + n > ARENA_BYTES) {
+    /* atomic: the stereo Frame constructor runs two extractors on two threads (src/Frame.cc:121-124); addresses still
+     * grow with creation order inside each thread, which is all the :686 tie-break needs */
+    const size_t at = __atomic_fetch_add(&g_arena_used, n, __ATOMIC_RELAXED);
+    if (at + n > ARENA_BYTES) {
         fprintf(stderr, "oracle/_ref: bump arena exhausted\n");
         abort();
     }
-    void *r = g_arena + g_arena_used;
-    g_arena_used += n;
-    return r;
+    return g_arena + at;
 }
 inline bool in_arena(void *p) { return g_arena && (unsigned char *)p >= g_arena && (unsigned char *)p < g_arena + ARENA_BYTES; }
 } // namespace

@@ -96,6 +96,9 @@ struct ref_keypoint {
 static_assert(sizeof(ref_keypoint) == sizeof(cv::KeyPoint), "layout");
 
 void ref_config_bump(int bump) { g_bump = bump ? 1 : 0; }
+/* for other glue files that run reference code which calls operator() itself (frame_stereo_api.cpp) */
+void ref_region_enter() { enter(); }
+void ref_region_leave() { leave(); }
 
 /* the reference object behind a handle (for ref_slices.cpp: Frame::ComputeStereoMatches reads its mvImagePyramid) */
 void *ref_ext_object(void *h) { return static_cast<ORB_SLAM2::ORBextractor *>(((RefExt *)h)->ext); }

@@ -32,6 +32,7 @@ namespace ORB_SLAM2
 {
 class KeyFrame;
 class Frame;
+class ORBVocabulary; /* only ever held as a pointer by the code compiled here */
 
 class MapPoint
 {
@@ -112,12 +113,31 @@ class Frame
     static float mfGridElementWidthInv, mfGridElementHeightInv;
     std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
     void ComputeStereoMatches(); /* src/Frame.cc:642-846, sliced */
+    /* the stereo constructor and what it calls (src/Frame.cc:102-168, 337-343, 559-590, 593-626), sliced into
+     * frame_stereo_api.cpp.  The reference reads `mb` in ComputeStereoMatches (:682) BEFORE the constructor assigns it
+     * (:161), i.e. whatever the memory held; here that value is the default member initialiser below. */
+    Frame(const cv::Mat &imLeft, const cv::Mat &imRight, const double &timeStamp, ORBextractor *extractorLeft,
+          ORBextractor *extractorRight, ORBVocabulary *voc, cv::Mat &K, cv::Mat &distCoef, const float &bf, const float &thDepth);
+    void ExtractORB(int flag, const cv::Mat &im);
+    void UndistortKeyPoints();
+    void ComputeImageBounds(const cv::Mat &imLeft);
+    static float s_mb_before_ctor;
+    ORBVocabulary *mpORBvocabulary = 0;
+    double mTimeStamp = 0;
+    cv::Mat mK, mDistCoef;
+    float mThDepth = 0;
+    KeyFrame *mpReferenceKF = 0;
+    long unsigned int mnId = 0;
+    static long unsigned int nNextId;
+    static bool mbInitialComputations;
+    float mfScaleFactor = 1.2f;
+    float invfx = 1, invfy = 1;
     ORBextractor *mpORBextractorLeft, *mpORBextractorRight;
     std::vector<cv::KeyPoint> mvKeysRight;
     cv::Mat mDescriptorsRight;
-    float fx, fy, cx, cy;
-    float mbf, mb;
-    int N;
+    float fx = 1, fy = 1, cx = 0, cy = 0;
+    float mbf = 0, mb = s_mb_before_ctor;
+    int N = 0;
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
     std::vector<float> mvuRight, mvDepth;
     DBoW2::FeatureVector mFeatVec;
@@ -125,8 +145,8 @@ class Frame
     std::vector<MapPoint *> mvpMapPoints;
     std::vector<bool> mvbOutlier;
     cv::Mat mTcw;
-    int mnScaleLevels;
-    float mfLogScaleFactor;
+    int mnScaleLevels = 8;
+    float mfLogScaleFactor = 0.18232156f;
     vector<float> mvScaleFactors, mvInvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
     static float mnMinX, mnMaxX, mnMinY, mnMaxY;
 };

@@ -37,7 +37,7 @@ public:
     // (Frame::ComputeStereoMatches, reference src/Frame.cc:649,761-778): set mbKeepPyramid = true there and every
     // operator() refreshes mvImagePyramid[l] as an ROI of the (w+38)x(h+38) REFLECT_101-padded level.
     std::vector<cv::Mat> mvImagePyramid;
-    bool mbKeepPyramid = false;
+    bool mbKeepPyramid = true;
     void SyncImagePyramid();
 
     int LastStatus() const { return mLastStatus; }  // orbfe_status of the last call (the reference has no error path)

@@ -495,3 +495,31 @@ def test_search_for_triangulation_equals_reference(ref, oracle):
         assert rn == on and np.array_equal(rp, op), (seed, n1, n2, rn, on)
         total += rn
     assert total > 2500
+
+
+def test_reference_stereo_frame_constructor_equals_the_oracle_chain(oracle):
+    """src/Frame.cc:102-168 -- the reference's stereo Frame constructor, sliced verbatim and compiled with its ExtractORB /
+    UndistortKeyPoints / ComputeImageBounds / ComputeStereoMatches / AssignFeaturesToGrid around two compiled reference
+    extractors (two threads, as written) -- against the oracle's chain: two extractions, stereo_matches, assign_grid.
+    `mb` is read by ComputeStereoMatches (:682) before the constructor assigns it (:161): whatever the object's memory held;
+    the harness makes that value an explicit input."""
+    from test_stereo import stereo_pair
+    R.configure(bump=True, canonical_trig=True, blur_mode=0)
+    for seed, fx, bf, mb_before in ((5, 500.0, 40.0, 0.0), (6, 718.856, 386.1448, 0.537)):
+        left, right = stereo_pair(seed)
+        got = R.stereo_frame(left, right, fx, fx + 1, 319.5, 239.5, bf, 35.0, mb_before=mb_before)
+        exL, exR = oracle.OracleExtractor(), oracle.OracleExtractor()
+        kL, dL = exL(left)
+        kR, dR = exR(right)
+        assert np.array_equal(got["keys"].view(np.uint8), kL.view(np.uint8)) and np.array_equal(got["desc"], dL)
+        assert np.array_equal(got["keys_un"].view(np.uint8), kL.view(np.uint8))          # zero distortion: mvKeysUn = mvKeys (:561-565)
+        assert np.array_equal(got["keys_right"].view(np.uint8), kR.view(np.uint8)) and np.array_equal(got["desc_right"], dR)
+        u, dep, _ = oracle.stereo_matches(exL, exR, kL, dL, kR, dR, bf, mb_before)
+        assert np.array_equal(got["u_right"].view(np.uint32), u.view(np.uint32)) and np.array_equal(got["depth"].view(np.uint32), dep.view(np.uint32))
+        assert (got["u_right"] >= 0).sum() > 100
+        minx, maxx, miny, maxy, gwi, ghi, mb, fxo = got["scal"]
+        assert (minx, maxx, miny, maxy) == (0.0, 640.0, 0.0, 480.0) and gwi == np.float32(64) / np.float32(640) and fxo == np.float32(fx)
+        assert mb == np.float32(bf) / np.float32(fx)                                     # :161, after the matches
+        xy = np.stack([kL["x"], kL["y"]], 1).astype(np.float32)
+        off, idx = oracle.assign_grid(xy, minx, miny, gwi, ghi)
+        assert np.array_equal(got["cell_off"], off) and np.array_equal(got["cell_idx"], idx)

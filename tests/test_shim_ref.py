@@ -71,3 +71,30 @@ def test_reference_frame_extractorb_through_the_shim_equals_the_reference_class(
             for l in range(8):
                 assert np.array_equal(shim.level(l), ref.level(l)), l
                 assert np.array_equal(shim.level(l, with_border=True), ref.level(l, with_border=True)), l
+
+
+@pytest.mark.gpu
+def test_reference_stereo_frame_constructor_runs_unchanged_on_the_shims():
+    """The reference's stereo Frame constructor (src/Frame.cc:102-168, sliced verbatim; two ExtractORB threads,
+    UndistortKeyPoints, ComputeStereoMatches reading the extractors' PUBLIC mvImagePyramid at :649 / :761-778,
+    AssignFeaturesToGrid) compiled around the product's extractor shim and matcher shim with NOTHING set on the extractors
+    (mbKeepPyramid defaults to the reference's semantics: mvImagePyramid is valid after every operator())  ==  the same
+    constructor around the reference's own compiled ORBextractor / ORBmatcher: mvKeys, mvKeysUn, mDescriptors, the right
+    image's keypoints, mvuRight and mvDepth bit patterns, the grid, the image bounds."""
+    from test_stereo import stereo_pair
+    R.configure(bump=True, canonical_trig=True, blur_mode=0)
+    L = R.shimstereo_lib()
+    ext = (L.shimst_ext_create(1000, 1.2, 8, 20, 7), L.shimst_ext_create(1000, 1.2, 8, 20, 7))   # reused across frames, like Tracking's
+    matched = 0
+    for seed, fx, bf, mb_before in ((5, 500.0, 40.0, 0.0), (6, 718.856, 386.1448, 0.537), (8, 435.2, 47.9, 0.11)):
+        left, right = stereo_pair(seed)
+        ref = R.stereo_frame(left, right, fx, fx + 1, 319.5, 239.5, bf, 35.0, mb_before=mb_before)
+        got = R.stereo_frame(left, right, fx, fx + 1, 319.5, 239.5, bf, 35.0, mb_before=mb_before, shim=True, extractors=ext)
+        for k in ("keys", "keys_un", "desc", "keys_right", "desc_right", "cell_off", "cell_idx"):
+            assert np.array_equal(got[k].view(np.uint8), ref[k].view(np.uint8)), (seed, k)
+        for k in ("u_right", "depth", "scal"):
+            assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (seed, k)
+        matched += int((ref["u_right"] >= 0).sum())
+    assert matched > 300
+    for e in ext:
+        L.shimst_ext_destroy(e)
