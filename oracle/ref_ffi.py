@@ -323,10 +323,10 @@ def shimstereo_lib():
         if not os.path.exists(_SHIMSTEREO):
             raise RuntimeError("oracle/_ref/libshim_stereo.so is missing")
         L = C.CDLL(_SHIMSTEREO)
-        L.shimst_ext_create.restype = C.c_void_p
-        L.shimst_ext_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
-        L.shimst_ext_destroy.argtypes = [C.c_void_p]
-        _declare_stereo_frame(L.shimst_stereo_frame)
+        L.shim_st_ext_create.restype = C.c_void_p
+        L.shim_st_ext_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.shim_st_ext_destroy.argtypes = [C.c_void_p]
+        _declare_stereo_frame(L.shim_st_stereo_frame)
         _shimstereo = L
     return _shimstereo
 
@@ -350,9 +350,9 @@ def stereo_frame(left, right, fx, fy, cx, cy, bf, th_depth, mb_before=0.0, nfeat
     if shim:
         L = shimstereo_lib()
         made = extractors is None
-        eL, eR = extractors or (L.shimst_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th),
-                                L.shimst_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th))
-        fn, hL, hR = L.shimst_stereo_frame, eL, eR
+        eL, eR = extractors or (L.shim_st_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th),
+                                L.shim_st_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th))
+        fn, hL, hR = L.shim_st_stereo_frame, eL, eR
     else:
         L = lib()
         _declare_stereo_frame(L.ref_stereo_frame)
@@ -363,8 +363,8 @@ def stereo_frame(left, right, fx, fy, cx, cy, bf, th_depth, mb_before=0.0, nfeat
     n = fn(hL, hR, _p(left), _p(right), w, h, left.strides[0], fx, fy, cx, cy, bf, th_depth, mb_before, _p(keys), _p(keys_un),
            _p(desc), _p(ur), _p(dep), _p(keys_r), _p(desc_r), cap, C.byref(nr), _p(cell_off), _p(cell_idx), _p(scal))
     if shim and made:
-        L.shimst_ext_destroy(eL)
-        L.shimst_ext_destroy(eR)
+        L.shim_st_ext_destroy(eL)
+        L.shim_st_ext_destroy(eR)
     if n < 0:
         raise RuntimeError(f"stereo_frame rc={n}")
     return dict(keys=keys[:n].copy(), keys_un=keys_un[:n].copy(), desc=desc[:n].copy(), u_right=ur[:n].copy(), depth=dep[:n].copy(),

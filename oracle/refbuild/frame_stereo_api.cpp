@@ -4,7 +4,7 @@
  * ComputeStereoMatches come from ref_slices.cpp), cut VERBATIM at build time by slice.py and compiled against the mock
  * Frame of ref_mocks.h.  TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Built twice:
  *   -DFS_PREFIX=ref_      into oracle/_ref/libref_orb.so      against the reference's ORBextractor / ORBmatcher
- *   -DFS_PREFIX=shimst_   into oracle/_ref/libshim_stereo.so  against the PRODUCT's shims (shim/ORBextractor.h first on
+ *   -DFS_PREFIX=shim_st_   into oracle/_ref/libshim_stereo.so  against the PRODUCT's shims (shim/ORBextractor.h first on
  *                         the include path, shim/ORBmatcher_orbfe.cc as the ORBmatcher translation unit): the unchanged
  *                         constructor reads the shim's public mvImagePyramid in ComputeStereoMatches (:649, :761-778)
  *                         with nothing set on the extractor -- the drop-in claim of INTEGRATION.md for stereo.

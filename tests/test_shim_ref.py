@@ -84,7 +84,7 @@ def test_reference_stereo_frame_constructor_runs_unchanged_on_the_shims():
     from test_stereo import stereo_pair
     R.configure(bump=True, canonical_trig=True, blur_mode=0)
     L = R.shimstereo_lib()
-    ext = (L.shimst_ext_create(1000, 1.2, 8, 20, 7), L.shimst_ext_create(1000, 1.2, 8, 20, 7))   # reused across frames, like Tracking's
+    ext = (L.shim_st_ext_create(1000, 1.2, 8, 20, 7), L.shim_st_ext_create(1000, 1.2, 8, 20, 7))   # reused across frames, like Tracking's
     matched = 0
     for seed, fx, bf, mb_before in ((5, 500.0, 40.0, 0.0), (6, 718.856, 386.1448, 0.537), (8, 435.2, 47.9, 0.11)):
         left, right = stereo_pair(seed)
@@ -97,4 +97,4 @@ def test_reference_stereo_frame_constructor_runs_unchanged_on_the_shims():
         matched += int((ref["u_right"] >= 0).sum())
     assert matched > 300
     for e in ext:
-        L.shimst_ext_destroy(e)
+        L.shim_st_ext_destroy(e)
