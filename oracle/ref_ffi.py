@@ -856,3 +856,95 @@ def search_for_initialization(f1, f2, prev_matched, window, nnratio=0.9, check_o
     fn = getattr(_pick(shim, perfect), ("shim_" if shim else "ref_") + "search_for_initialization")
     rv = fn(C.byref(a), C.byref(b), _p(pm), int(window), float(nnratio), int(bool(check_ori)), _p(m))
     return m[:a.n], pm[:a.n], rv
+
+
+# ---- the reference's binary map file: Map::Save / Map::Load (perfect/src/Map.cc:143-430, sliced; libref_perfect.so) ----
+def _map_lib():
+    L = perfect_lib()
+    vp, ci = C.c_void_p, C.c_int
+    L.ref_map_save.argtypes = [C.c_char_p, ci, vp, vp, ci] + [vp] * 12
+    L.ref_map_load.restype = vp
+    L.ref_map_load.argtypes = [C.c_char_p]
+    L.ref_map_loaded_free.argtypes = [vp]
+    L.ref_map_loaded_free.restype = None
+    L.ref_map_loaded_counts.argtypes = [vp] * 7
+    L.ref_map_loaded_counts.restype = None
+    L.ref_map_loaded_get.argtypes = [vp] * 20
+    L.ref_map_loaded_get.restype = None
+    return L
+
+
+def map_save(path, mappoints, keyframes):
+    """Map::Save itself on a map built from flat data.  mappoints: [(id, (x, y, z))]; keyframes: dicts with id, timestamp,
+    t_cw, q_cw, kps (KP_DTYPE), desc, mp_index (index into mappoints or ULONG_MAX), parent (keyframe id or None),
+    connections [(keyframe id, weight)].  (The quaternion rides through the mock pose unchanged: Eigen is not vendored.)"""
+    L = _map_lib()
+    nmp, nkf = len(mappoints), len(keyframes)
+    mp_id = np.array([m[0] for m in mappoints] or [0], np.uint64)
+    mp_pos = np.array([m[1] for m in mappoints] or [(0, 0, 0)], np.float32).reshape(-1, 3)
+    idx_of = {kf["id"]: i for i, kf in enumerate(keyframes)}
+    kf_id = np.array([kf["id"] for kf in keyframes] or [0], np.uint64)
+    kf_ts = np.array([kf["timestamp"] for kf in keyframes] or [0], np.float64)
+    kf_t = np.array([kf["t_cw"] for kf in keyframes] or [(0, 0, 0)], np.float32).reshape(-1, 3)
+    kf_q = np.array([kf["q_cw"] for kf in keyframes] or [(0, 0, 0, 1)], np.float32).reshape(-1, 4)
+    kf_n = np.array([len(kf["kps"]) for kf in keyframes] or [0], np.int32)
+    kps = np.concatenate([np.ascontiguousarray(kf["kps"], KP_DTYPE) for kf in keyframes] + [np.zeros(1, KP_DTYPE)])
+    desc = np.concatenate([np.ascontiguousarray(kf["desc"], np.uint8).reshape(-1, 32) for kf in keyframes] + [np.zeros((1, 32), np.uint8)])
+    mpi = np.concatenate([np.where(np.asarray(kf["mp_index"], np.uint64) == np.uint64(0xFFFFFFFFFFFFFFFF), -1,
+                                   np.asarray(kf["mp_index"], np.uint64).astype(np.int64)).astype(np.int64) for kf in keyframes]
+                         + [np.zeros(1, np.int64)])
+    parent = np.array([-1 if kf.get("parent") is None else idx_of[kf["parent"]] for kf in keyframes] or [-1], np.int64)
+    con_off = np.zeros(nkf + 1, np.int32)
+    con_kf, con_w = [], []
+    for i, kf in enumerate(keyframes):
+        for cid, wgt in kf.get("connections", []):
+            con_kf.append(idx_of[cid])
+            con_w.append(wgt)
+        con_off[i + 1] = len(con_kf)
+    con_kf, con_w = np.array(con_kf or [0], np.int32), np.array(con_w or [0], np.int32)
+    rc = L.ref_map_save(str(path).encode(), nmp, _p(mp_id), _p(mp_pos), nkf, _p(kf_id), _p(kf_ts), _p(kf_t), _p(kf_q), _p(kf_n), _p(kps),
+                        _p(desc), _p(mpi), _p(parent), _p(con_off), _p(con_kf), _p(con_w))
+    if rc != 0:
+        raise RuntimeError("Map::Save failed")
+
+
+def map_load(path, bump=True):
+    """Map::Load itself; returns (mappoints, keyframes, info) in FILE order, the same shapes as mapio.load_map plus what the
+    reference did on the way: info = dict(log, next_mp_id, mp_set_rank, mp_nobs, mp_calls).  bump: run it with the bump
+    allocator (heap addresses grow with creation order) -- the reference resolves the stored map-point indices through a
+    std::set<MapPoint*>, so under glibc malloc the links it reads back depend on the heap's history."""
+    L = _map_lib()
+    L.ref_config_bump(int(bump))
+    h = L.ref_map_load(str(path).encode())
+    if not h:
+        raise RuntimeError("Map::Load failed")
+    try:
+        v = [C.c_int() for _ in range(5)]
+        nxt = C.c_uint64()
+        L.ref_map_loaded_counts(h, *[C.byref(x) for x in v], C.byref(nxt))
+        nmp, nkf, nfeat, ncon, loglen = (x.value for x in v)
+        mp_id, mp_pos = np.zeros(max(nmp, 1), np.uint64), np.zeros((max(nmp, 1), 3), np.float32)
+        rank, nobs, calls = np.zeros(max(nmp, 1), np.int32), np.zeros(max(nmp, 1), np.int32), np.zeros((max(nmp, 1), 2), np.int32)
+        kf_id, kf_ts = np.zeros(max(nkf, 1), np.uint64), np.zeros(max(nkf, 1), np.float64)
+        kf_t, kf_q, kf_n = np.zeros((max(nkf, 1), 3), np.float32), np.zeros((max(nkf, 1), 4), np.float32), np.zeros(max(nkf, 1), np.int32)
+        kps, desc = np.zeros(max(nfeat, 1), KP_DTYPE), np.zeros((max(nfeat, 1), 32), np.uint8)
+        kf_mp, urd = np.zeros(max(nfeat, 1), np.int64), np.zeros((max(nfeat, 1), 2), np.float32)
+        par, con_off = np.zeros(max(nkf, 1), np.uint64), np.zeros(nkf + 1, np.int32)
+        con_id, con_w = np.zeros(max(ncon, 1), np.uint64), np.zeros(max(ncon, 1), np.int32)
+        log = C.create_string_buffer(loglen + 1)
+        L.ref_map_loaded_get(h, _p(mp_id), _p(mp_pos), _p(rank), _p(nobs), _p(calls), _p(kf_id), _p(kf_ts), _p(kf_t), _p(kf_q), _p(kf_n),
+                             _p(kps), _p(desc), _p(kf_mp), _p(urd), _p(par), _p(con_off), _p(con_id), _p(con_w), log)
+    finally:
+        L.ref_map_loaded_free(h)
+    mps = [(int(mp_id[i]), tuple(float(c) for c in mp_pos[i])) for i in range(nmp)]
+    kfs, at = [], 0
+    for k in range(nkf):
+        n = int(kf_n[k])
+        kfs.append(dict(id=int(kf_id[k]), timestamp=float(kf_ts[k]), t_cw=kf_t[k].copy(), q_cw=kf_q[k].copy(), kps=kps[at:at + n].copy(),
+                        desc=desc[at:at + n].copy(), mp_id=kf_mp[at:at + n].copy(), u_right=urd[at:at + n, 0].copy(), depth=urd[at:at + n, 1].copy(),
+                        parent=None if par[k] == np.uint64(0xFFFFFFFFFFFFFFFF) else int(par[k]),
+                        connections=[(int(con_id[c]), int(con_w[c])) for c in range(con_off[k], con_off[k + 1])]))
+        at += n
+    info = dict(log=log.raw[:loglen].decode(), next_mp_id=int(nxt.value), mp_set_rank=rank[:nmp].copy(), mp_nobs=nobs[:nmp].copy(),
+                mp_calls=calls[:nmp].copy())
+    return mps, kfs, info

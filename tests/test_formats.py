@@ -167,3 +167,110 @@ def test_device_record_packer_equals_host_writer():
             ref = mapio.write_keyframe(0, 0.0, [0, 0, 0], [0, 0, 0, 1], kps[b, :n[b]], desc[b, :n[b]], mp[b, :n[b]] if with_mp else None)[48:]
             assert got[b, :n[b]].tobytes() == ref, (b, with_mp)
             assert not got[b, n[b]:].any()
+
+
+# ---- pinned to the reference's own writer and reader (perfect/src/Map.cc:143-430, sliced and compiled: oracle/_ref) ----
+def _random_map(seed, nmp=60, sizes=(1004, 0, 333, 1, 57)):
+    rng = np.random.default_rng(seed)
+    mps = [(int(i * 7 + 3), tuple(float(np.float32(v)) for v in rng.normal(0, 5, 3))) for i in range(nmp)]
+    kfs = []
+    for j, n in enumerate(sizes):
+        k, d, _ = _features(seed * 100 + j, n)
+        mp = rng.integers(0, max(nmp, 1), n).astype(np.uint64)
+        mp[rng.random(n) < (0.3 if nmp else 1.0)] = mapio.ULONG_MAX
+        q = rng.normal(0, 1, 4).astype(np.float32)
+        kfs.append(dict(id=100 + 3 * j, timestamp=1341846313.592026 + 0.033 * j, t_cw=rng.normal(0, 2, 3).astype(np.float32),
+                        q_cw=(q / np.linalg.norm(q)).astype(np.float32), kps=k, desc=d, mp_index=mp,
+                        parent=None if j == 0 else 100 + 3 * int(rng.integers(0, j)),
+                        connections=[(100 + 3 * int(c), int(rng.integers(15, 400))) for c in rng.permutation(len(sizes))[:int(rng.integers(0, len(sizes)))] if c != j]))
+    return mps, kfs
+
+
+def _ref():
+    from oracle import ref_ffi as R
+    if not R.available():
+        pytest.skip("oracle/_ref not built and /root/reference absent")
+    return R
+
+
+@pytest.mark.parametrize("seed,nmp,sizes", [(1, 60, (1004, 0, 333, 1, 57)), (2, 0, (5,)), (3, 7, ()), (4, 400, (2031, 1990))])
+def test_map_file_equals_what_the_reference_writer_writes(tmp_path, seed, nmp, sizes):
+    """Map::Save + _WriteMapPoint + _WriteKeyFrame -- the reference's code, compiled -- on a random map vs the product's
+    writer (orbfe_mapio_write_keyframe blocks inside mapio.save_map's container): the two files are byte-identical, and
+    every keyframe block of the reference's file is what orbfe_mapio_write_keyframe returns."""
+    R = _ref()
+    mps, kfs = _random_map(seed, nmp, sizes)
+    ref_path, our_path = os.path.join(tmp_path, "ref.bin"), os.path.join(tmp_path, "orbfe.bin")
+    R.map_save(ref_path, mps, kfs)
+    mapio.save_map(our_path, mps, kfs)
+    blob = open(ref_path, "rb").read()
+    assert blob == open(our_path, "rb").read()
+    off = 8 + 20 * nmp + 8
+    for kf in kfs:
+        blk = mapio.write_keyframe(kf["id"], kf["timestamp"], kf["t_cw"], kf["q_cw"], kf["kps"], kf["desc"], kf["mp_index"])
+        assert blob[off:off + len(blk)] == blk and len(blk) == mapio.keyframe_bytes(len(kf["kps"]))
+        off += len(blk)
+
+
+@pytest.mark.parametrize("seed,nmp,sizes", [(11, 60, (1004, 0, 333, 1, 57)), (12, 3, (9,)), (13, 400, (2031, 1990))])
+def test_reference_reader_reads_our_file_and_we_read_the_reference_file(tmp_path, seed, nmp, sizes):
+    """Map::Load + _ReadMapPoint + _ReadKeyFrame (compiled reference code) on a file the PRODUCT wrote == the map that went in ==
+    what the product's reader returns for the file the REFERENCE wrote.  Also what the reference does around the bytes:
+    the Frame calls per keyframe in order (SetPose, InitializeScaleLevels, UndistortKeyPoints, AssignFeaturesToGrid,
+    ComputeBoW, :167-193), mvuRight / mvDepth = -1 (mono only, :186-187), class_id left at -1, map points gaining one
+    observation per referencing feature, ComputeDistinctiveDescriptors + UpdateNormalAndDepth once per map point."""
+    R = _ref()
+    mps, kfs = _random_map(seed, nmp, sizes)
+    ref_path, our_path = os.path.join(tmp_path, "ref.bin"), os.path.join(tmp_path, "orbfe.bin")
+    mapio.save_map(our_path, mps, kfs)
+    R.map_save(ref_path, mps, kfs)
+    rmps, rkfs, info = R.map_load(our_path)
+    omps, okfs = mapio.load_map(ref_path)
+    f32 = lambda p: tuple(float(np.float32(c)) for c in p)
+    assert rmps == [(i, f32(p)) for i, p in mps] == omps
+    assert len(rkfs) == len(okfs) == len(kfs)
+    # the reference indexes std::set<MapPoint*> (heap-ADDRESS order) with the stored indices (:261): file order under the bump
+    # allocator (addresses grow with creation order), which is the contract the format is pinned under
+    assert np.array_equal(info["mp_set_rank"], np.arange(nmp))
+    for a, r, o in zip(kfs, rkfs, okfs):
+        for b in (r, o):
+            assert b["id"] == a["id"] and b["timestamp"] == a["timestamp"] and b["parent"] == a["parent"] and b["connections"] == a["connections"]
+            assert np.array_equal(b["t_cw"], a["t_cw"]) and np.array_equal(b["q_cw"], a["q_cw"]) and np.array_equal(b["desc"], a["desc"])
+            for f in ("x", "y", "size", "angle", "response", "octave"):
+                assert np.array_equal(b["kps"][f].view(np.uint32), a["kps"][f].view(np.uint32)), f
+            assert (b["kps"]["class_id"] == -1).all()
+        want = np.array([-1 if m == mapio.ULONG_MAX else mps[int(m)][0] for m in a["mp_index"]], np.int64)
+        assert np.array_equal(r["mp_id"], want) and np.array_equal(o["mp_index"], a["mp_index"])
+        assert (r["u_right"] == -1).all() and (r["depth"] == -1).all()
+    per_kf = "SetPose;InitializeScaleLevels;UndistortKeyPoints;AssignFeaturesToGrid;ComputeBoW;"
+    assert info["log"] == per_kf * len(kfs)
+    refs = np.zeros(nmp, np.int64)
+    for a in kfs:
+        for m in a["mp_index"]:
+            if m != mapio.ULONG_MAX:
+                refs[int(m)] += 1
+    assert np.array_equal(info["mp_nobs"], refs) and (info["mp_calls"] == 1).all()
+    assert info["next_mp_id"] == (max(i for i, _ in mps) + 1 if mps else 1)
+
+
+def test_reference_reader_under_glibc_malloc_links_by_heap_address(tmp_path):
+    """Not a property of the format but of the reference's reader: `amp = GetAllMapPoints()` (:261) is a std::set<MapPoint*> in
+    heap-address order, and a feature's stored index m becomes amp[m].  Under glibc malloc that order is whatever the heap's
+    history makes it; the reader is self-consistent with the writer only when it happens to be creation order.  Here: the
+    links the compiled reference reads back are exactly amp[m] in BOTH allocator modes, and equal the file's own order (the
+    product's reading) whenever the set order is the file order."""
+    R = _ref()
+    mps, kfs = _random_map(21, 400, (2031, 777))
+    path = os.path.join(tmp_path, "m.bin")
+    mapio.save_map(path, mps, kfs)
+    for bump in (True, False):
+        _, rkfs, info = R.map_load(path, bump=bump)
+        rank = info["mp_set_rank"]
+        assert sorted(rank.tolist()) == list(range(400))
+        at_rank = np.zeros(400, np.int64)
+        at_rank[rank] = [i for i, _ in mps]                       # amp[m] = the map point whose set position is m
+        for a, r in zip(kfs, rkfs):
+            want = np.array([-1 if m == mapio.ULONG_MAX else at_rank[int(m)] for m in a["mp_index"]], np.int64)
+            assert np.array_equal(r["mp_id"], want), bump
+        if bump:
+            assert np.array_equal(rank, np.arange(400))

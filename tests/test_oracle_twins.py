@@ -234,3 +234,62 @@ def test_full_pipeline_composition(oracle):
     for f in ref.dtype.names:
         assert np.array_equal(ref[f].view(np.uint32), kps[f].view(np.uint32)), f
     assert np.array_equal(np.stack(out_d), desc)
+
+
+def test_fast_as_the_sse2_build_runs_it_on_a_million_neighbourhoods(oracle):
+    """OpenCV 3.2's FAST_t<16> + cornerScore<16> in their SSE2 formulations (saturating `_mm_subs_epu8` / `_mm_adds_epu8`,
+    0x80-xor signed compares, run counting by mask subtraction, the 16-bit min / max ladder that does NOT start from the
+    threshold) against the oracle's cv::FAST restatement: detections, scores, 3x3 NMS and output order on > 10^6 pixel
+    neighbourhoods of five textures, thresholds of both passes (iniThFAST 20, minThFAST 7) and the extremes."""
+    total = 0
+    for seed, (h, w), smooth in ((0, (300, 333), True), (1, (257, 401), True), (2, (240, 320), False), (3, (199, 517), True),
+                                 (4, (311, 290), True)):
+        img = rnd_img(seed, h, w, smooth) if seed != 4 else synth_frame(4, h, w)
+        for thr in (20, 7) + ((0, 1, 100, 255) if seed == 0 else ()):
+            st = {}
+            ref = twins.fast9_sse2(img, thr, True, st)
+            got = oracle.fast9(img, thr, True)
+            assert [(int(k["x"]), int(k["y"]), int(k["response"])) for k in got] == ref, (seed, thr)
+            assert st["missed"] == 0                      # the 4-point pre-test never hides a corner of the full test
+            if thr in (7, 20) and smooth:
+                assert st["blocks"] > 0 and (st["skip16"] + st["skip8"]) > 0 and len(ref) > 50
+            total += (h - 6) * (w - 6)
+        ref = twins.fast9_sse2(img, 20, False)
+        got = oracle.fast9(img, 20, False)
+        assert [(int(k["x"]), int(k["y"])) for k in got] == [(x, y) for x, y, _ in ref], seed
+    assert total > 1_000_000
+
+
+def test_corner_score_sse2_equals_max_arc_threshold_minus_one(oracle):
+    """cornerScore<16> (SSE2 branch) on 200 000 random neighbourhoods == the definition (largest threshold that keeps the
+    pixel a corner, twins.fast_strength - 1) == the oracle's score map, including non-corners and negative strengths."""
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (450, 460), dtype=np.uint8)
+    img[100:300, 50:250] = rnd_img(5, 200, 200, smooth=True)
+    h, w = img.shape
+    ys, xs = np.mgrid[3:h - 3, 3:w - 3]
+    sc = twins.corner_score16_sse2(img, xs.ravel(), ys.ravel()).reshape(h - 6, w - 6)
+    a = twins.fast_strength(img)[3:h - 3, 3:w - 3]
+    assert np.array_equal(sc, a - 1) and sc.size > 200_000
+    assert np.array_equal(oracle.fast_score_map(img)[3:h - 3, 3:w - 3], np.clip(sc, 0, 255))
+
+
+def test_resize_as_the_sse2_build_runs_it_on_a_million_pixels(oracle):
+    """VResizeLinearVec_32s8u's `_mm_mulhi_epi16` form + the scalar tail against orc_resize_linear_u8 on the pyramid's own
+    chain of sizes (640x480 -> 533x400 -> ... -> 179x134, 1920x1080 -> 1600x900) and odd shapes: > 10^6 output pixels; the
+    16-bit packs never saturate and the vector and scalar forms agree on every pixel."""
+    total = 0
+    rng = np.random.default_rng(3)
+    cases = [((480, 640), (400, 533)), ((400, 533), (333, 444)), ((333, 444), (278, 370)), ((278, 370), (231, 309)),
+             ((231, 309), (193, 257)), ((193, 257), (161, 214)), ((161, 214), (134, 179)), ((1080, 1920), (900, 1600)),
+             ((97, 131), (81, 109)), ((50, 41), (42, 34)), ((33, 40), (40, 48)), ((20, 24), (30, 36))]
+    for (sh, sw), (dh, dw) in cases:
+        src = rng.integers(0, 256, (sh, sw), dtype=np.uint8) if (sh * sw) % 2 else rnd_img(sh, sh, sw, smooth=True)
+        src[:3, :5] = 255
+        src[-2:, -7:] = 0
+        st = {}
+        ref = twins.resize_linear_sse2(src, dw, dh, st)
+        assert np.array_equal(oracle.resize_linear(src, dw, dh), ref), ((sh, sw), (dh, dw))
+        assert st["packs_saturated"] == 0 and st["forms_differ"] == 0 and 0 <= dw - st["vector_columns"] <= 4 + (dw < 16) * 16
+        total += dh * dw
+    assert total > 1_000_000

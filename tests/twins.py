@@ -396,3 +396,232 @@ def search_by_bow(descKF, validKF, angKF, fvKF, descF, validF, angF, fvF, nnrati
     if check_ori:
         nm -= _prune(m, bins)
     return m, nm
+
+
+# ---- OpenCV 3.2's SIMD formulations, as executed on an x86-64 build (CV_SSE2) ---------------------------------------
+# Independent of the definition-level twins above AND of the oracle: these emulate, intrinsic by intrinsic, what
+# features2d/src/fast.cpp FAST_t<16> + fast_score.cpp cornerScore<16> and imgproc/src/imgwarp.cpp
+# VResizeLinearVec_32s8u do with their registers (saturating unsigned byte arithmetic, the 0x80 xor that turns unsigned
+# order into signed-compare order, counting by mask subtraction, 16-bit min/max ladders, _mm_mulhi_epi16), so that
+# "the restatement reads the published scalar code right" and "the SIMD build computes the same thing" are two checks.
+def _u8(a):
+    return np.asarray(a).astype(np.uint8)
+
+
+def _adds_epu8(a, b):
+    return np.minimum(a.astype(np.int32) + b.astype(np.int32), 255).astype(np.uint8)
+
+
+def _subs_epu8(a, b):
+    return np.maximum(a.astype(np.int32) - b.astype(np.int32), 0).astype(np.uint8)
+
+
+def _as_epi8(a):
+    return a.astype(np.uint8).view(np.int8)
+
+
+def _cmpgt_epi8(a, b):
+    """signed byte compare -> 0xFF / 0x00 mask"""
+    return np.where(_as_epi8(a) > _as_epi8(b), 0xFF, 0).astype(np.uint8)
+
+
+def _fast_offsets():
+    """makeOffsets: pixel[k] for k < 25 = CIRCLE[k % 16]"""
+    return [CIRCLE[k % 16] for k in range(25)]
+
+
+def corner_score16_sse2(img, xs, ys):
+    """cornerScore<16>, SSE2 branch (fast_score.cpp): d[k] = v - ptr[pixel[k]] as short, k < 25; for k in {0, 8}: eight
+    lanes j hold the arc starting at k + j: a = min(d[k+j+1 .. k+j+8]), b = max(same); q0 = max(q0, min(a, d[k+j]),
+    min(a, d[k+j+9])), q1 = min(q1, max(b, d[k+j]), max(b, d[k+j+9])); q0 = max(q0, 0 - q1); horizontal max; result - 1.
+    Note: unlike the scalar branch the SSE2 branch does not start from `threshold` (q0 = -1000)."""
+    img = img.astype(np.int16)
+    off = _fast_offsets()
+    v = img[ys, xs]
+    d = np.stack([v - img[ys + dy, xs + dx] for dx, dy in off], 1).astype(np.int16)      # (n, 25)
+    n = len(xs)
+    q0 = np.full((n, 8), -1000, np.int16)
+    q1 = np.full((n, 8), 1000, np.int16)
+    lanes = np.arange(8)
+    for k in (0, 8):
+        v0, v1 = d[:, k + 1 + lanes], d[:, k + 2 + lanes]
+        a, b = np.minimum(v0, v1), np.maximum(v0, v1)
+        for t in range(3, 9):
+            v0 = d[:, k + t + lanes]
+            a, b = np.minimum(a, v0), np.maximum(b, v0)
+        v0 = d[:, k + lanes]
+        q0 = np.maximum(q0, np.minimum(a, v0))
+        q1 = np.minimum(q1, np.maximum(b, v0))
+        v0 = d[:, k + 9 + lanes]
+        q0 = np.maximum(q0, np.minimum(a, v0))
+        q1 = np.minimum(q1, np.maximum(b, v0))
+    q0 = np.maximum(q0, (np.int16(0) - q1).astype(np.int16))
+    return (q0.max(1).astype(np.int32) - 1)
+
+
+def fast9_sse2(img, threshold, nonmax=True, stats=None):
+    """cv::FAST(img, kps, threshold, nonmax) as FAST_t<16> runs it with CV_SSE2: per row the 16-pixel SSE2 blocks (with the
+    `mask == 0 -> skip 16`, `(mask & 255) == 0 -> step 8` early-outs of the 4-point pre-test), then the scalar
+    threshold_tab tail for the last < 19 columns; scores by cornerScore<16> (SSE2 branch); NMS over the three row buffers.
+    Returns [(x, y, score)] in OpenCV's output order."""
+    img = _u8(img)
+    h, w = img.shape
+    if h < 7 or w < 7:
+        return []
+    threshold = min(max(int(threshold), 0), 255)
+    t = np.uint8(threshold)
+    off = _fast_offsets()
+    K = 8
+    ys, xs = np.mgrid[3:h - 3, 3:w - 3]
+    v = img[3:h - 3, 3:w - 3]
+    delta = np.uint8(0x80)
+    v1 = _subs_epu8(v, np.full_like(v, t)) ^ delta          # v1 = (v -sat t) ^ 0x80
+    v0 = _adds_epu8(v, np.full_like(v, t)) ^ delta          # v0 = (v +sat t) ^ 0x80
+    ring = [img[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in off]
+    # 4-point pre-test on pixel[0], [4], [8], [12]: x_i = pix - 0x80 (== pix ^ 0x80 as bytes)
+    x = [(ring[q] - delta).astype(np.uint8) for q in (0, 4, 8, 12)]
+    m0 = np.zeros_like(v)
+    m1 = np.zeros_like(v)
+    for i in range(4):
+        a, b = x[i], x[(i + 1) % 4]
+        m0 |= _cmpgt_epi8(a, v0) & _cmpgt_epi8(b, v0)
+        m1 |= _cmpgt_epi8(v1, a) & _cmpgt_epi8(v1, b)
+    pre = (m0 | m1) != 0
+    # full test: counters by mask subtraction, N = 25 positions
+    c0 = np.zeros_like(v)
+    c1 = np.zeros_like(v)
+    max0 = np.zeros_like(v)
+    max1 = np.zeros_like(v)
+    for k in range(25):
+        xk = ring[k] ^ delta
+        mm0 = _cmpgt_epi8(xk, v0)
+        mm1 = _cmpgt_epi8(v1, xk)
+        c0 = ((c0.astype(np.int32) - mm0.astype(np.int32)) & 0xFF).astype(np.uint8) & mm0   # _mm_sub_epi8 wraps: c - 0xFF = c + 1
+        c1 = ((c1.astype(np.int32) - mm1.astype(np.int32)) & 0xFF).astype(np.uint8) & mm1
+        max0 = np.maximum(max0, c0)
+        max1 = np.maximum(max1, c1)
+    sse_corner = _as_epi8(np.maximum(max0, max1)) > np.int8(K)
+    # scalar tail: threshold_tab + run counting
+    d = [ring[k].astype(np.int32) - v.astype(np.int32) for k in range(25)]        # x - v
+    tab = lambda q: np.where(d[q] < -threshold, 1, np.where(d[q] > threshold, 2, 0))
+    dd = tab(0) | tab(8)
+    for q in (2, 4, 6):
+        dd = dd & (tab(q) | tab(q + 8))
+    for q in (1, 3, 5, 7):
+        dd = dd & (tab(q) | tab(q + 8))
+    sc_corner = np.zeros(v.shape, bool)
+    for bit, cond in ((1, lambda q: d[q] < -threshold), (2, lambda q: d[q] > threshold)):
+        cnt = np.zeros(v.shape, np.int32)
+        hit = np.zeros(v.shape, bool)
+        for k in range(25):
+            c = cond(k)
+            cnt = np.where(c, cnt + 1, 0)
+            hit |= cnt > K
+        sc_corner |= hit & ((dd & bit) != 0)
+    # row walk: which pixels each path classifies
+    corner = np.zeros((h, w), bool)
+    nblocks = nskip16 = nskip8 = 0
+    for yy in range(h - 6):
+        j = 3
+        while j < w - 16 - 3:
+            blk = pre[yy, j - 3:j - 3 + 16]
+            if not blk.any():
+                nskip16 += 1
+                j += 16
+                continue
+            if not blk[:8].any():
+                nskip8 += 1
+                j += 8
+                continue
+            corner[yy + 3, j:j + 16] = sse_corner[yy, j - 3:j - 3 + 16]
+            nblocks += 1
+            j += 16
+        corner[yy + 3, j:w - 3] = sc_corner[yy, j - 3:w - 6]
+    if stats is not None:
+        stats.update(blocks=nblocks, skip16=nskip16, skip8=nskip8,
+                     missed=int((sse_corner & ~corner[3:h - 3, 3:w - 3]).sum()))   # corners the early-outs would have hidden
+    cy, cx = np.nonzero(corner)
+    if not nonmax:
+        return [(int(a), int(b), 0) for a, b in zip(cx, cy)]
+    score = np.zeros((h, w), np.int32)
+    if len(cx):
+        score[cy, cx] = corner_score16_sse2(img, cx, cy).astype(np.uint8)        # curr[j] = (uchar)cornerScore
+    res = []
+    p = np.pad(score, 1)
+    for a, b in zip(cx, cy):
+        s = score[b, a]
+        nb = p[b:b + 3, a:a + 3].copy()
+        nb[1, 1] = -1
+        if s > nb.max():
+            res.append((int(a), int(b), int(s)))
+    return res
+
+
+def _packs_epi32(a):
+    return np.clip(a, -32768, 32767).astype(np.int16)
+
+
+def _mulhi_epi16(a, b):
+    return ((a.astype(np.int32) * b.astype(np.int32)) >> 16).astype(np.int16)
+
+
+def _adds_epi16(a, b):
+    return np.clip(a.astype(np.int32) + b.astype(np.int32), -32768, 32767).astype(np.int16)
+
+
+def resize_linear_sse2(src, dw, dh, stats=None):
+    """cv::resize INTER_LINEAR 8UC1 as an x86-64 OpenCV 3.2 build runs it: HResizeLinear<uchar,int,short,2048,HResizeNoVec>
+    (scalar) into int rows, then VResizeLinearVec_32s8u on the first dw - (dw % 4 or 4) .. columns -- `srai 4`,
+    `packs_epi32`, `mulhi_epi16(x, b0) +sat mulhi_epi16(y, b1)`, `+sat 2`, `srai 2`, `packus` -- and the scalar
+    FixedPtCast tail for the rest.  Both forms are evaluated for every pixel and asserted equal where each applies."""
+    src = _u8(src)
+    sh, sw = src.shape
+
+    def axis(ssize, dsize, is_x):
+        scale = 1.0 / (float(dsize) / float(ssize))
+        ofs, c0, c1 = [], [], []
+        for dd in range(dsize):
+            f = F32((dd + 0.5) * scale - 0.5)
+            s = int(math.floor(f))
+            f = F32(f - F32(s))
+            if is_x:
+                if s < 0:
+                    f, s = F32(0), 0
+                if s >= ssize - 1:
+                    f, s = F32(0), ssize - 1
+            ofs.append(s)
+            c0.append(cv_round(F32(F32(1.0) - f) * F32(2048)))
+            c1.append(cv_round(f * F32(2048)))
+        return np.array(ofs), np.array(c0, np.int16), np.array(c1, np.int16)
+
+    xo, a0, a1 = axis(sw, dw, True)
+    yo, b0, b1 = axis(sh, dh, False)
+    s32 = src.astype(np.int32)
+    x1 = np.minimum(xo + 1, sw - 1)
+    H = s32[:, xo] * a0.astype(np.int32) + s32[:, x1] * a1.astype(np.int32)       # int rows (sh, dw)
+    y0 = np.clip(yo, 0, sh - 1)
+    y1 = np.clip(yo + 1, 0, sh - 1)
+    S0, S1 = H[y0], H[y1]                                                            # (dh, dw) int32
+    # SSE2 kernel
+    X = _packs_epi32(S0 >> 4)
+    Y = _packs_epi32(S1 >> 4)
+    if stats is not None:
+        stats["packs_saturated"] = int(((S0 >> 4) > 32767).sum() + ((S1 >> 4) > 32767).sum())
+    r = _adds_epi16(_mulhi_epi16(X, b0[:, None]), _mulhi_epi16(Y, b1[:, None]))
+    r = (_adds_epi16(r, np.int16(2)) >> 2)
+    vec = np.clip(r, 0, 255).astype(np.uint8)                                        # packus_epi16
+    # scalar tail: uchar(( ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2)
+    sc = ((((b0.astype(np.int32)[:, None] * (S0 >> 4)) >> 16) + ((b1.astype(np.int32)[:, None] * (S1 >> 4)) >> 16) + 2) >> 2)
+    sc = (sc & 0xFF).astype(np.uint8)
+    # the vector loops cover x <= width - 16 by 16 and then x < width - 4 by 4; the rest is scalar
+    xv = 0
+    while xv <= dw - 16:
+        xv += 16
+    while xv < dw - 4:
+        xv += 4
+    out = sc.copy()
+    out[:, :xv] = vec[:, :xv]
+    if stats is not None:
+        stats["vector_columns"] = xv
+        stats["forms_differ"] = int((vec != sc).sum())
+    return out
