@@ -277,6 +277,11 @@ orbfe_status orbfe_hamming_csr_device(orbfe_matcher *m, const uint8_t *d_q, int3
 #define ORBFE_GRID_ROWS 48 /* FRAME_GRID_ROWS include/Frame.h:25 */
 orbfe_status orbfe_assign_grid(orbfe_matcher *m, const float *xy, int32_t n, float minx, float miny, float gw_inv,
                                float gh_inv, uint32_t *cell_off, uint32_t *cell_idx, int32_t *n_in_grid);
+/* The same index on the host, without a device or a matcher handle: for hosts that hold the keypoints but not the grid
+ * (KeyFrame::mGrid is protected in the reference, include/KeyFrame.h:223 -- the matcher shim rebuilds it from the public
+ * mvKeysUn with the values Frame::AssignFeaturesToGrid used: Frame::mnMinX / mnMinY, mfGridElement{Width,Height}Inv). */
+orbfe_status orbfe_assign_grid_host(const float *xy, int32_t n, float minx, float miny, float gw_inv, float gh_inv,
+                                    uint32_t *cell_off, uint32_t *cell_idx, int32_t *n_in_grid);
 /* AssignFeaturesToGrid for every frame of an extractor output block, device-resident: frame f's keypoints are
  * d_kps[f * cap .. f * cap + d_n[f]) as orbfe_extract_batch_device wrote them (mvKeysUn == mvKeys: no lens distortion, as
  * for TUM fr3); d_cell_off [nframes][ORBFE_GRID_COLS * ORBFE_GRID_ROWS + 1], d_cell_idx [nframes][cap], d_n_in_grid

@@ -25,6 +25,16 @@
 #define FRAME_GRID_ROWS 48
 #define FRAME_GRID_COLS 64
 
+/* The members below that are `protected:` in the reference's real headers (include/KeyFrame.h:203-241, include/MapPoint.h:
+ * 124-150) are declared behind REF_MOCKS_PROTECTED.  The glue files need them public (they build the mock objects); the
+ * PRODUCT's matcher shim is compiled with -DREF_MOCKS_STRICT, where they ARE protected -- a compile-time check that the shim
+ * reaches the objects only through what the real classes make public. */
+#ifdef REF_MOCKS_STRICT
+#define REF_MOCKS_PROTECTED protected
+#else
+#define REF_MOCKS_PROTECTED public
+#endif
+
 using std::pair; /* include/ORBmatcher.h:82 writes std::vector<pair<size_t,size_t> > without std:: */
 using std::vector;
 
@@ -88,6 +98,7 @@ class MapPoint
     long unsigned int mnFuseCandidateForKF;
 
     /* state under the reference's member names (include/MapPoint.h:118-153) where the sliced bodies touch it */
+  REF_MOCKS_PROTECTED:
     bool mbBad;
     int nObs;
     float mfMinDistance, mfMaxDistance;
@@ -95,6 +106,7 @@ class MapPoint
     cv::Mat world_pos, normal, mDescriptor;
     std::map<KeyFrame *, size_t> mObservations;
     std::mutex mMutexFeatures, mMutexPos;
+  public:
 };
 
 class Frame
@@ -191,12 +203,14 @@ class KeyFrame
     long unsigned int mnId;
     int mnGridCols, mnGridRows;
     float mfGridElementWidthInv, mfGridElementHeightInv;
+  REF_MOCKS_PROTECTED:
     std::vector<std::vector<std::vector<size_t> > > mGrid;
     bool mbBad;
 
     /* mock state */
     std::vector<MapPoint *> mvpMapPoints;
     cv::Mat Ow, Rcw, tcw;
+  public:
 };
 
 } // namespace ORB_SLAM2

@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <new>
 
+#include <vector>
+
 #include "orbfe_common.h"
 #include "orbfe_kernels.h"
 
@@ -1249,6 +1251,38 @@ extern "C" orbfe_status orbfe_assign_grid(orbfe_matcher *m, const float *xy, int
     ORBFE_HIP(hipStreamSynchronize(st));
     if (nin > 0) ORBFE_HIP(hipMemcpy(cell_idx, m->b[2].p, (size_t)nin * 4, hipMemcpyDeviceToHost));
     if (n_in_grid) *n_in_grid = nin;
+    return ORBFE_OK;
+}
+
+// Host form of the same index (no device, no matcher handle): for callers that hold the keypoints but cannot reach the
+// grid itself -- KeyFrame::mGrid is a protected member of the reference (include/KeyFrame.h:223), so the matcher shim
+// rebuilds it from the public mvKeysUn.  Counting sort over the 3072 cells; per cell ascending keypoint index.
+extern "C" orbfe_status orbfe_assign_grid_host(const float *xy, int32_t n, float minx, float miny, float gw_inv, float gh_inv,
+                                               uint32_t *cell_off, uint32_t *cell_idx, int32_t *n_in_grid)
+{
+    if (n < 0 || !cell_off || (n > 0 && (!xy || !cell_idx))) {
+        orbfe_set_error("bad argument to orbfe_assign_grid_host");
+        return ORBFE_ERR_ARG;
+    }
+    auto cell = [&](int i) -> int {
+        // src/Frame.cc:525-526: round() of a float product (no contraction: this file is built with -ffp-contract=off)
+        const float fx = (xy[2 * (size_t)i] - minx) * gw_inv, fy = (xy[2 * (size_t)i + 1] - miny) * gh_inv;
+        const float rx = roundf(fx), ry = roundf(fy);
+        if (!(rx >= 0.f && rx < (float)ORBFE_GRID_COLS && ry >= 0.f && ry < (float)ORBFE_GRID_ROWS)) return -1;
+        return (int)rx * ORBFE_GRID_ROWS + (int)ry;
+    };
+    for (int c = 0; c <= GRID_NC; ++c) cell_off[c] = 0u;
+    for (int i = 0; i < n; ++i) {
+        const int c = cell(i);
+        if (c >= 0) cell_off[c + 1]++;
+    }
+    for (int c = 0; c < GRID_NC; ++c) cell_off[c + 1] += cell_off[c];
+    std::vector<uint32_t> fill(cell_off, cell_off + GRID_NC);
+    for (int i = 0; i < n; ++i) {
+        const int c = cell(i);
+        if (c >= 0) cell_idx[fill[(size_t)c]++] = (uint32_t)i;
+    }
+    if (n_in_grid) *n_in_grid = (int32_t)cell_off[GRID_NC];
     return ORBFE_OK;
 }
 

@@ -33,7 +33,8 @@
 // the matcher concurrently).
 //
 // Built and tested in this repo against the reference's unmodified header with mock KeyFrame / Frame / MapPoint types
-// (oracle/refbuild: libshim_ref.so; tests/test_gpu_shim_ref.py compares it with the compiled reference bodies).
+// (oracle/refbuild: libshim_ref.so / libshim_full.so; tests/test_shim_ref.py and tests/test_projection.py compare it with the
+// compiled reference bodies).
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -143,14 +144,15 @@ struct FrameSide {
             oct[i] = pKF->mvKeysUn[i].octave;
             blocked[i] = vpMatched && (*vpMatched)[i] != NULL;
         }
-        cell_off.reserve(ORBFE_GRID_COLS * ORBFE_GRID_ROWS + 1);
-        cell_off.push_back(0);
-        for (int ix = 0; ix < ORBFE_GRID_COLS; ++ix)
-            for (int iy = 0; iy < ORBFE_GRID_ROWS; ++iy) {
-                const std::vector<size_t> &c = pKF->mGrid[(size_t)ix][(size_t)iy];
-                for (size_t k = 0; k < c.size(); ++k) cell_idx.push_back((uint32_t)c[k]);
-                cell_off.push_back((uint32_t)cell_idx.size());
-            }
+        // KeyFrame::mGrid is PROTECTED in the reference (include/KeyFrame.h:223) and this helper is no friend of the class.
+        // The grid is a pure function of public data: it is the Frame's, built by Frame::AssignFeaturesToGrid from mvKeysUn
+        // with the Frame statics mnMinX / mnMinY (float; KeyFrame keeps truncated int copies) and the cell sizes the
+        // KeyFrame copied; per cell in ascending keypoint order.  orbfe_assign_grid_host restates exactly that.
+        cell_off.resize(ORBFE_GRID_COLS * ORBFE_GRID_ROWS + 1);
+        cell_idx.resize(n);
+        if (orbfe_assign_grid_host(xy.data(), (int32_t)n, ORB_SLAM2::Frame::mnMinX, ORB_SLAM2::Frame::mnMinY, pKF->mfGridElementWidthInv,
+                                   pKF->mfGridElementHeightInv, cell_off.data(), cell_idx.data(), NULL) != ORBFE_OK)
+            throw std::runtime_error(std::string("ORBmatcher (orbfe): orbfe_assign_grid_host: ") + orbfe_last_error());
         desc = Rows(pKF->mDescriptors, tmp);
     }
 };

@@ -238,3 +238,27 @@ def test_gpu_projection_search_chain_device_resident(oracle):
                                 dlv.data_ptr(), nq, c_off.data_ptr(), c_cand.data_ptr(), 100, st)
     torch.cuda.synchronize()
     assert c_off.cpu().numpy().view(np.uint32)[nq] == off[nq] and bool((c_cand == -7).all())
+
+
+def test_host_grid_builder_equals_the_oracle_and_the_sliced_reference():
+    """orbfe_assign_grid_host (what the matcher shim uses to rebuild a KeyFrame's protected mGrid from its public mvKeysUn)
+    == the oracle's AssignFeaturesToGrid == the reference's own sliced Frame::AssignFeaturesToGrid; CPU only, no handle."""
+    import ctypes as C
+    from orb_slam2_ssd_semantic_amd import _ffi
+    from oracle import oracle_ffi as O
+    from oracle import ref_ffi as R
+    L = _ffi.lib()
+    for sd, n in ((1, 0), (2, 1), (3, 1000), (4, 3000), (5, 2000)):
+        xy, octave, minx, miny, gwi, ghi = grid_case(sd, n)
+        if sd == 5:   # lens-distorted bounds: non-integer minimum, points outside the grid on every side
+            minx, miny = np.float32(-7.3), np.float32(-4.9)
+            xy = xy + np.float32([-30.0, -20.0])
+        off, idx = np.zeros(64 * 48 + 1, np.uint32), np.zeros(max(n, 1), np.uint32)
+        nin = C.c_int32()
+        assert L.orbfe_assign_grid_host(_ffi.ptr(np.ascontiguousarray(xy, np.float32)), n, minx, miny, gwi, ghi, _ffi.ptr(off), _ffi.ptr(idx),
+                                        C.byref(nin)) == 0
+        ooff, oidx = O.assign_grid(xy, minx, miny, gwi, ghi)
+        assert np.array_equal(off, ooff) and np.array_equal(idx[:nin.value], oidx) and nin.value == len(oidx)
+        if R.available():
+            roff, ridx = R.assign_grid(xy, minx, miny, gwi, ghi)
+            assert np.array_equal(off, roff) and np.array_equal(idx[:nin.value], ridx)
