@@ -50,7 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from orb_slam2_ssd_semantic_amd.distributed import OverlappedKeyframeGather, all_gather_keyframes, shard_range  # noqa: E402
-from orb_slam2_ssd_semantic_amd.synth import regular_vocabulary, synth_frame, synth_tum_like  # noqa: E402
+from orb_slam2_ssd_semantic_amd.synth import regular_vocabulary, synth_frame, synth_frames_parallel, synth_tum_like  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 N_SIMD = 1024            # 256 CUs x 4 SIMDs
@@ -122,8 +122,7 @@ def base_frames(gen, n, w, h, seed0):
         fr = tum.load_gray_frames(limit=n)
         assert fr.shape[1:] == (h, w), f"TUM frames are {fr.shape[1:]}, bench asked for {(h, w)}"
         return fr
-    make = synth_frame if gen == "S" else synth_tum_like
-    return np.stack([make(seed0 + i, h, w) for i in range(n)])
+    return synth_frames_parallel(gen, n, h, w, seed0)   # n distinct generator seeds, a pool of host processes
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -173,24 +172,33 @@ def cpu_baseline(w, h, nfeat, budget_s=16.0, nframes=200, warmup=20):
             "host_cpus": os.cpu_count()}
 
 
-def cpu_baseline_all_cores(w, h, nfeat, duration_s=6.0, max_procs=64):
-    """One frame stream per core (the reference extractor is serial per call): independent worker processes
-    (oracle/cpu_worker.py, oracle restatement = kind "port"), all started on a common wall-clock tick."""
-    procs = min(os.cpu_count() or 1, max_procs)
-    t_go = time.time() + 8.0
+def cpu_baseline_all_cores(w, h, nfeat, duration_s=6.0, max_procs=None):
+    """One frame stream per host CPU -- ALL of them, as SURVEY 8(d) asks (the reference extractor is serial per call):
+    independent worker processes (oracle/cpu_worker.py), all started on a common wall-clock tick.  kind "reference" when
+    oracle/_ref/libref_orb.so is there (the unmodified reference ORBextractor.cc over the cv stub), else "port"."""
+    procs = os.cpu_count() or 1
+    if max_procs:
+        procs = min(procs, max_procs)
+    kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_orb.so")) else "port"
+    t_go = time.time() + 8.0 + procs / 32.0   # every interpreter has to be up before the tick
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), str(w), str(h), str(nfeat), repr(t_go),
            repr(duration_s)]
+    os.environ["ORBFE_CPU_WORKER_KIND"] = kind
     ps = [subprocess.Popen(cmd + [str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
-    frames = 0
+    frames, late = 0, 0
     for p in ps:
-        out, _ = p.communicate(timeout=duration_s + 120)
+        out, _ = p.communicate(timeout=duration_s + 180)
         try:
-            frames += int(out.strip().split()[-1])
+            tok = out.strip().split()
+            frames += int(tok[-1])
+            late += int(len(tok) > 1 and tok[0] == "late")
         except Exception:
             pass
-    return {"value": round(frames / duration_s, 2), "unit": "frames/s", "cores": procs, "kind": "port",
-            "sample": f"{procs} processes x {duration_s:.0f} s, each its own stream of 640x480 S(seed) frames, extract + BF "
-                      f"match to previous frame, oracle/orb_oracle.c", "host_cpus": os.cpu_count()}
+    return {"value": round(frames / duration_s, 2), "unit": "frames/s", "cores": procs, "kind": kind, "late_starters": late,
+            "sample": f"{procs} processes (one per logical host CPU) x {duration_s:.0f} s, each its own stream of {w}x{h} S(seed) "
+                      f"frames, extract + BF match to previous frame, "
+                      + ("oracle/_ref (unmodified reference ORBextractor.cc, cv stub) + oracle BF match" if kind == "reference"
+                         else "oracle/orb_oracle.c"), "host_cpus": os.cpu_count()}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -351,6 +359,8 @@ def main():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--workload", choices=["S", "S_tum", "TUM"], default="S",
                     help="frames `value` is timed on: S(seed), S_tum(seed), or the TUM sequence at $TUM_FR3_WALKING_XYZ")
+    ap.add_argument("--seeds", type=int, default=1024, help="distinct generator seeds in the resident batch (the rest of the "
+                    "batch are roll / flip transforms of them)")
     ap.add_argument("--fast-mode", type=int, default=0, help="FAST variant of the timed region (0 dense, 1 sparse shortcuts)")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the latency probe")
@@ -410,8 +420,10 @@ def main():
     if not fake:
         for e in getattr(eng, 'exts', [eng.ext]):
             e.set_fast_mode(args.fast_mode)
-    nbase = min(B, 32)
-    base = torch.from_numpy(base_frames(args.workload, nbase, w, h, 10000 + rank * 1000)).to(dev)
+    # the resident batch: `--seeds` DISTINCT generator seeds (default 1024 = one whole launch of different images), expanded to
+    # the B frames of a step by lossless roll / flip transforms of that set (every frame a different image)
+    nbase = min(B, args.seeds)
+    base = torch.from_numpy(base_frames(args.workload, nbase, w, h, 10000 + rank * 4096)).to(dev)
     d_gray = expand_frames(base, B)
     stream = None if fake else torch.cuda.current_stream().cuda_stream
     # (n, kps, desc) order of distributed.all_gather_keyframes
@@ -456,6 +468,23 @@ def main():
     total_frames = B * world * args.steps
     value = total_frames / elapsed
 
+    # The same step with the north star's formulation of the all-pairs matcher (xor + v_bcnt popcount, k_match_popc) instead of
+    # the default exact int8 dot product on the matrix cores (k_match_bf): identical results, reported next to `value`.
+    value_popc = None
+    if not fake and world == 1 and not args.no_match and not args.no_extras:
+        for m in eng.mats:
+            m.set_bf_kernel(1)
+        step()
+        fence()
+        t1 = time.perf_counter()
+        nsteps_popc = max(2, args.steps // 4)
+        for _ in range(nsteps_popc):
+            step()
+        fence()
+        value_popc = B * nsteps_popc / (time.perf_counter() - t1)
+        for m in eng.mats:
+            m.set_bf_kernel(0)
+
     result = None
     if rank == 0:
         result = {
@@ -473,6 +502,12 @@ def main():
                                     B, NL, F, ", asynchronous all-gather of counts/keypoints/descriptors per step" if world > 1 else ""),
                        "frames_per_gpu_per_step": B, "frames_per_launch": F, "width": w, "height": h, "nfeatures": nf,
                        "workload_name": args.workload,
+                       "value_is": "value_hbm_resident (bench contract: inputs resident in HBM when the timed region starts); SURVEY "
+                                   "8(d) row 3 as worded -- host frames in, host results out -- is value_pcie_inclusive",
+                       "match_kernel": None if args.no_match else "mfma_i8 (k_match_bf: exact int8 dot product on the matrix cores; "
+                                       "the north star's xor/popcount formulation k_match_popc gives identical results: "
+                                       "value_match_popc)",
+                       "generator_seeds": int(min(B, args.seeds)),
                        "parallelism": f"frames sharded over {world} GPU(s), one process per GPU",
                        "streams": (f"{eng.P} extractor / matcher handle pairs on {eng.P} streams, sub-batch j on pipe j mod {eng.P}: the "
                                    "VALU-bound FAST pass of one sub-batch shares the chip with the HBM / LDS-bound stages of its "
@@ -481,6 +516,9 @@ def main():
                                    "second stream behind an event, next to the pyramid of sub-batch j+1"
                                    if getattr(eng, "match_stream", None) is not None else "one stream")},
         }
+        result["value_hbm_resident"] = result["value"]
+        if value_popc is not None:
+            result["value_match_popc"] = round(value_popc, 2)
         if fake:
             result["fake"] = True
             result["config"]["workload"] = "FAKE CPU stand-in (spawn-path test), not a measurement"
@@ -688,7 +726,7 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
     # ---- PCIe-inclusive leg (SURVEY 8(d) config 3 as worded): three streams, double buffering ---------------------
     if world == 1:
         result["pcie_inclusive"] = pcie_leg(eng, d_gray[:F], w, h, F)
-        result["pcie_inclusive_frames_per_s"] = result["pcie_inclusive"]["frames_per_s"]
+        result["value_pcie_inclusive"] = result["pcie_inclusive"]["frames_per_s"]
 
     # ---- the other workload, both FAST variants --------------------------------------------------------------------
     if world == 1:
@@ -698,11 +736,16 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
     c4 = config4_leg(args, rank, local_rank, world, fence)
     if rank == 0:
         result["config4"] = c4
+        # one-number summaries at the top level (the driver's record keeps top-level scalars)
+        if isinstance(c4, dict) and "strong" in c4:
+            result["config4_frames_per_s"] = c4["strong"]["frames_per_s"]           # the 1024-frame batch sharded over the ranks
+            result["config4_allgather_bus_GBps"] = c4["strong"]["allgather_bus_GBps"]
 
     if world == 1 and not args.no_cpu_baseline:
         result["projection_chain"] = projection_leg(local_rank)
     if world == 1:
         result["config5"] = config5_leg(args, local_rank, check=not args.no_cpu_baseline)
+        result["config5_frames_per_s"] = result["config5"]["frames_per_s"]
         result["bow_chain"] = bow_leg(args, local_rank)
         result["stereo_chain"] = stereo_leg(args, local_rank)
         result["host_api"] = host_api_leg(args, local_rank, d_gray[:F])

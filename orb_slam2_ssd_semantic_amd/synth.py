@@ -111,3 +111,25 @@ def regular_vocabulary(k=10, L=6, seed=0, zero_frac=0.0):
         weight[rng.random(nodes) < zero_frac] = 0.0
     return dict(child_off=child_off.astype(np.uint32), child_idx=child_idx, node_desc=node_desc, word_id=word_id,
                 weight=weight, L=L)
+
+
+def _gen_chunk(job):
+    """(generator name, first seed, count, h, w) -> uint8 [count, h, w]; module-level so that worker processes can import it"""
+    gen, seed0, count, h, w = job
+    make = synth_frame if gen == "S" else synth_tum_like
+    return np.stack([make(seed0 + i, h, w) for i in range(count)])
+
+
+def synth_frames_parallel(gen, n, h, w, seed0, max_procs=64):
+    """n frames gen(seed0 .. seed0 + n - 1), generated by a pool of worker processes (spawned: safe after a GPU runtime has
+    been initialised in the parent).  The frames are exactly synth_frame / synth_tum_like of those seeds."""
+    import os
+    from concurrent.futures import ProcessPoolExecutor
+    import multiprocessing as mp
+    procs = max(1, min(max_procs, os.cpu_count() or 1, n))
+    if procs == 1 or n < 64:
+        return _gen_chunk((gen, seed0, n, h, w))
+    per = -(-n // (procs * 2))
+    jobs = [(gen, seed0 + a, min(per, n - a), h, w) for a in range(0, n, per)]
+    with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as ex:
+        return np.concatenate(list(ex.map(_gen_chunk, jobs)))
