@@ -362,6 +362,41 @@ orbfe_status orbfe_search_by_projection_chi2(orbfe_matcher *m, const uint8_t *de
                                              int32_t th, float nnratio, int32_t ratio_rule, int32_t *match, int32_t *best,
                                              int32_t *second);
 
+/* HOST-side geometry of the same family (csrc/orbfe_hostgeom.hip; no device, no handle), so that a host shim only flattens
+ * its objects and replays decisions.  Arithmetic order = what the reference's cv::Mat expressions evaluate to: 3x3 * 3x1
+ * products accumulate left to right in float, norms and dot products in double, nothing fused.
+ *
+ * orbfe_project_points: x_c = R * x_w + t (then x_c = R2 * x_c + t2 when R2 != NULL: SearchBySim3's two stages), the depth /
+ * image / distance / viewing-angle gates and the projected coordinates of n map points -- src/ORBmatcher.cc:401-433 (Sim3
+ * projection), :1060-1101 (Fuse), :1224-1255 (Fuse, Sim3), :1389-1424 (SearchBySim3), :1620-1642 (last frame), :1778-1803
+ * (relocalisation).  ok[i] = 1 when point i passed every gate; u, v (and invz, dist, ur = u - bf * invz where non-NULL) are
+ * written for those.  min_dist / max_dist NULL: no distance gate; with them dist = |x_w - Ow| (Ow != NULL) or |x_c|; normal
+ * != NULL adds the viewing-angle gate PO . n < 0.5 * dist -> out.  R, R2 row-major 3x3. */
+#define ORBFE_PJ_SKIP_NEG_DEPTH 1    /* z_c < 0 -> out (:411, :1068, :1234, :1396) */
+#define ORBFE_PJ_SKIP_NEG_INVZ 2     /* 1 / z_c < 0 -> out (:1625) */
+#define ORBFE_PJ_UV_CHAINED 4        /* u = fx * x_c * invz + cx (:1627, :1789) instead of u = fx * (x_c * invz) + cx */
+#define ORBFE_PJ_BOUNDS_CLOSED 8     /* out iff u < minx || u > maxx (Frame statics, :1629) instead of KeyFrame::IsInImage */
+orbfe_status orbfe_project_points(const float *R, const float *t, const float *R2, const float *t2, const float *Ow, float fx,
+                                  float fy, float cx, float cy, float bf, float minx, float maxx, float miny, float maxy,
+                                  int32_t flags, int32_t n, const float *world_pos, const float *normal, const float *min_dist,
+                                  const float *max_dist, float *u, float *v, float *invz, float *dist, float *ur, uint8_t *ok);
+/* the gating of SearchByProjection(Frame&, const vector<MapPoint*>&, th) (:63-93; Tracking::SearchLocalPoints): points with
+ * mbTrackInView and !isBad() become queries (u, v, ur) = proj_uvr[i], r = RadiusByViewingCos(view_cos) [* th] *
+ * scale_factors[level], levels [level - 1, level], right-image gate on, CLAIMS iff obs_gt0; q / src compacted, *nq their count */
+orbfe_status orbfe_proj_queries_local_map(const float *scale_factors, int32_t n, const uint8_t *in_view, const uint8_t *bad,
+                                          const int32_t *level, const float *view_cos, const float *proj_uvr, const uint8_t *obs_gt0,
+                                          float th, orbfe_proj_query *q, int32_t *src, int32_t *nq);
+/* the rotation-consistency check every matcher ends with: match i votes for bin round((angle_a[i] - angle_b[i], + 360 if
+ * negative) * (1 / histo_len)) (:308-313), the three fullest bins stay (ComputeThreeMaxima :1912-1957: an earlier bin wins a
+ * tie, the second / third go when under a tenth of the first); drop[i] = 1 for matches outside them */
+orbfe_status orbfe_rotation_consistency(const float *angle_a, const float *angle_b, int32_t n, int32_t histo_len, uint8_t *drop);
+/* SearchForInitialization's in-order rule (:547-617) on the lists of orbfe_window_distances: query qi takes its closest
+ * candidate among those no earlier query holds at a distance <= its own, accepted when best <= th and best < second * nnratio;
+ * a later query may take a held feature over.  accepted[nq]: the feature a query was accepted with (-1: none) -- whether or
+ * not it was taken over later; holder[n2]: the query that holds a feature at the end (-1: none). */
+orbfe_status orbfe_initialization_resolve(const uint32_t *off, const uint32_t *ent, int32_t nq, int32_t n2, int32_t th, float nnratio,
+                                          int32_t *accepted, int32_t *holder);
+
 /* The window search and the distances alone, as lists: off[nq + 1], ent[off[nq]] with ent = feature | distance << 16 in the
  * reference's candidate order (GetFeaturesInArea's cell walk); flags / ur of the queries are ignored.  ORBFE_ERR_CAP (off[nq] =
  * the size needed) when cap is too small.  ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:523-651) runs its in-order

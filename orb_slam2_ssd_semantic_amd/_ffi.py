@@ -39,7 +39,8 @@ SYMBOLS = (
     "orbfe_group_world", "orbfe_group_capacity", "orbfe_group_frames_padded", "orbfe_group_block_index", "orbfe_group_extract_batch",
     "orbfe_group_extract_shard_device", "orbfe_group_allgather", "orbfe_group_synchronize", "orbfe_group_blocks", "orbfe_group_get_frame",
     "orbfe_group_match", "orbfe_group_match_device", "orbfe_group_owner_rank", "orbfe_group_block_index_of",
-    "orbfe_group_create_local_ex", "orbfe_group_members", "orbfe_group_transport", "orbfe_group_get_frame_from", "orbfe_group_get_counts", "orbfe_assign_grid_host",
+    "orbfe_group_create_local_ex", "orbfe_group_members", "orbfe_group_transport", "orbfe_group_get_frame_from", "orbfe_group_get_counts", "orbfe_assign_grid_host", "orbfe_project_points", "orbfe_proj_queries_local_map", "orbfe_rotation_consistency",
+    "orbfe_initialization_resolve",
 )
 
 
@@ -136,6 +137,10 @@ def lib():
     L.orbfe_hamming_csr_ex.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     L.orbfe_hamming_csr_all.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
     L.orbfe_hamming_csr_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orbfe_project_points.argtypes = [vp] * 5 + [f32] * 9 + [i32, i32] + [vp] * 10
+    L.orbfe_proj_queries_local_map.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp]
+    L.orbfe_rotation_consistency.argtypes = [vp, vp, i32, i32, vp]
+    L.orbfe_initialization_resolve.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp]
     L.orbfe_assign_grid_host.argtypes = [vp, i32, f32, f32, f32, f32, vp, vp, vp]
     L.orbfe_assign_grid.argtypes = [vp, vp, i32, f32, f32, f32, f32, vp, vp, vp]
     L.orbfe_vocabulary_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, i32, vp]

@@ -19,10 +19,15 @@
 // and, with -DORBFE_SHIM_STANDALONE, the rest of the translation unit (constants, constructor, RadiusByViewingCos,
 // CheckDistEpipolarLine, ComputeThreeMaxima), so that src/ORBmatcher.cc can leave the build altogether.
 //
-// One pattern throughout: the pose projection and its gates run here, on cv::Mat, statement for statement as in the
-// reference; the candidate scans (GetFeaturesInArea + Hamming + whatever rule couples the queries) are ONE device call per
-// invocation; the assignments / Replace / AddMapPoint decisions and the rotation histogram are replayed from its result, in
-// the reference's order, on the live objects.  The device call is orbfe_search_by_projection(_chi2) for the four
+// One pattern throughout: this file FLATTENS the objects (poses, map-point positions / normals / distance ranges, keypoints,
+// descriptors), the C-ABI does the work, and the decisions are REPLAYED on the live objects in the reference's order:
+//   orbfe_project_points / orbfe_proj_queries_local_map   the per-point projection and its gates (host, csrc/orbfe_hostgeom.hip)
+//   orbfe_search_by_projection(_chi2) etc.                the candidate scans (GetFeaturesInArea + Hamming + the rule that couples
+//                                                         the queries): ONE device call per invocation
+//   orbfe_rotation_consistency                            the rotation histogram + ComputeThreeMaxima
+// What stays here on cv::Mat are the few POSE-level expressions (-Rcw.t() * tcw, Scw / scw, ...): evaluated through whatever
+// cv::Mat the application links, they are exact in a real OpenCV build (double-accumulating gemm) and in the test stub alike.
+// MapPoint::PredictScale is the application's own member and is called, not restated.  The device call is orbfe_search_by_projection(_chi2) for the four
 // SearchByProjection members (it also resolves the "slot already taken by an earlier query" rule) and for Fuse x2 /
 // SearchBySim3 (independent queries on a KeyFrame's grid; Fuse's reprojection-error gate is ORBFE_PROJ_CHI2_GATE),
 // orbfe_search_for_triangulation, orbfe_search_by_bow, and orbfe_window_distances for SearchForInitialization (whose rule
@@ -41,7 +46,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <functional>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -162,13 +166,10 @@ struct Queries {
     std::vector<uint8_t> desc;
     std::vector<ORB_SLAM2::MapPoint *> mp;
     std::vector<int> src;  // index of the query in the caller's list
-    // flags < 0: the Frame overloads' rule (right-image gate on, the slot is taken iff the point has observations)
-    void Add(ORB_SLAM2::MapPoint *p, int from, float u, float v, float r, int minLevel, int maxLevel, float ur, int flags = -1)
+    void Add(ORB_SLAM2::MapPoint *p, int from, float u, float v, float r, int minLevel, int maxLevel, float ur, int flags)
     {
         orbfe_proj_query e;
-        e.u = u; e.v = v; e.r = r; e.min_level = minLevel; e.max_level = maxLevel; e.ur = ur;
-        e.flags = flags >= 0 ? flags : (ORBFE_PROJ_RIGHT_GATE | (p->Observations() > 0 ? ORBFE_PROJ_CLAIMS : 0));
-        e.pad = 0;
+        e.u = u; e.v = v; e.r = r; e.min_level = minLevel; e.max_level = maxLevel; e.ur = ur; e.flags = flags; e.pad = 0;
         q.push_back(e);
         const cv::Mat d = p->GetDescriptor();
         desc.insert(desc.end(), d.ptr<uint8_t>(0), d.ptr<uint8_t>(0) + 32);
@@ -177,13 +178,78 @@ struct Queries {
     }
 };
 
+// 3x3 / 3x1 CV_32F matrices as the flat arrays the C-ABI takes
+struct Pose {
+    float R[9], t[3];
+    Pose(const cv::Mat &Rm, const cv::Mat &tm)
+    {
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) R[3 * r + c] = Rm.at<float>(r, c);
+            t[r] = tm.at<float>(r);
+        }
+    }
+};
+struct Vec3 {
+    float v[3];
+    explicit Vec3(const cv::Mat &m) { for (int r = 0; r < 3; ++r) v[r] = m.at<float>(r); }
+};
+
+// The map points of one call that passed the object-level filters (null / bad / already found), flattened; Project() runs
+// orbfe_project_points on them: everything per point that the reference computes between GetWorldPos() and PredictScale().
+struct PointList {
+    std::vector<ORB_SLAM2::MapPoint *> mp;
+    std::vector<int> src;
+    std::vector<float> pos, nrm, dmin, dmax;
+    std::vector<float> u, v, invz, dist, ur;
+    std::vector<uint8_t> ok;
+    void Add(ORB_SLAM2::MapPoint *p, int from, bool with_normal, bool with_range)
+    {
+        mp.push_back(p);
+        src.push_back(from);
+        const Vec3 w(p->GetWorldPos());
+        pos.insert(pos.end(), w.v, w.v + 3);
+        if (with_normal) {
+            const Vec3 n(p->GetNormal());
+            nrm.insert(nrm.end(), n.v, n.v + 3);
+        }
+        if (with_range) {
+            dmax.push_back(p->GetMaxDistanceInvariance());
+            dmin.push_back(p->GetMinDistanceInvariance());
+        }
+    }
+    size_t size() const { return mp.size(); }
+    void Project(const Pose &P, const Pose *second, const float *Ow, float fx, float fy, float cx, float cy, float bf, float minx,
+                 float maxx, float miny, float maxy, int flags)
+    {
+        const size_t n = mp.size();
+        u.resize(n); v.resize(n); invz.resize(n); dist.resize(n); ur.resize(n);
+        ok.assign(n, 0);
+        if (n == 0) return;
+        const orbfe_status s = orbfe_project_points(P.R, P.t, second ? second->R : NULL, second ? second->t : NULL, Ow, fx, fy, cx, cy, bf,
+                                                    minx, maxx, miny, maxy, flags, (int32_t)n, pos.data(), nrm.empty() ? NULL : nrm.data(),
+                                                    dmin.empty() ? NULL : dmin.data(), dmax.empty() ? NULL : dmax.data(), u.data(),
+                                                    v.data(), invz.data(), dist.data(), ur.data(), ok.data());
+        if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher (orbfe): orbfe_project_points: ") + orbfe_last_error());
+    }
+};
+
+// rotation-consistency check over the accepted matches (angle pairs in acceptance order): which of them fall outside the
+// three fullest histogram bins (src/ORBmatcher.cc:308-316, :338-360, :1912-1957)
+void RotationOutliers(const std::vector<float> &a, const std::vector<float> &b, int histo_len, std::vector<uint8_t> &drop)
+{
+    drop.assign(a.size(), 0);
+    if (a.empty()) return;
+    if (orbfe_rotation_consistency(a.data(), b.data(), (int32_t)a.size(), histo_len, drop.data()) != ORBFE_OK)
+        throw std::runtime_error(std::string("ORBmatcher (orbfe): orbfe_rotation_consistency: ") + orbfe_last_error());
+}
+
 void RunSearch(ORB_SLAM2::Frame &F, const Queries &qs, int th, float nnratio, int ratio_rule, std::vector<int32_t> &match,
                bool any_point_blocks = false)
 {
     match.assign(qs.q.size(), -1);
     if (qs.q.empty() || F.N == 0) return;
     FrameSide fs(F);
-    if (any_point_blocks)  // :1812 `if(CurrentFrame.mvpMapPoints[i2]) continue;`
+    if (any_point_blocks)  // :1812 a slot holding ANY map point is taken
         for (int i = 0; i < F.N; ++i) fs.blocked[(size_t)i] = F.mvpMapPoints[(size_t)i] != NULL;
     const orbfe_status s = orbfe_search_by_projection(
         t_matcher.get(), fs.desc, fs.xy.data(), fs.oct.data(), F.N, fs.cell_off.data(), fs.cell_idx.data(), ORB_SLAM2::Frame::mnMinX,
@@ -208,37 +274,67 @@ void RunKeyFrameSearch(ORB_SLAM2::KeyFrame *pKF, const Queries &qs, int th, bool
         NULL, NULL);
     if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::") + who + " (orbfe): " + orbfe_last_error());
 }
+
+// the projected points that passed become window queries: level from the application's own MapPoint::PredictScale, search
+// radius th * scale factor of that level, levels [level - 1, level + up]
+template <class Target>
+void LevelQueries(const PointList &pl, Target *where, const std::vector<float> &scale_factors, float th, int up, int flags, bool with_ur,
+                  Queries &qs, std::vector<int> *slot_of_src)
+{
+    for (size_t k = 0; k < pl.size(); ++k) {
+        if (!pl.ok[k]) continue;
+        const int level = pl.mp[k]->PredictScale(pl.dist[k], where);
+        if (slot_of_src) (*slot_of_src)[(size_t)pl.src[k]] = (int)qs.q.size();
+        qs.Add(pl.mp[k], pl.src[k], pl.u[k], pl.v[k], th * scale_factors[(size_t)level], level - 1, level + up, with_ur ? pl.ur[k] : 0.f, flags);
+    }
+}
 }  // namespace
 
 namespace ORB_SLAM2
 {
 
-// src/ORBmatcher.cc:63-157
+// src/ORBmatcher.cc:63-157 (Tracking::SearchLocalPoints)
 int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th)
 {
-    const bool bFactor = th != 1.0;  // :67
+    const size_t n = vpMapPoints.size();
+    std::vector<uint8_t> in_view(n), bad(n), obs(n);
+    std::vector<int32_t> level(n);
+    std::vector<float> view_cos(n), uvr(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        MapPoint *p = vpMapPoints[i];
+        in_view[i] = p->mbTrackInView;
+        bad[i] = p->isBad();
+        obs[i] = p->Observations() > 0;
+        level[i] = p->mnTrackScaleLevel;
+        view_cos[i] = p->mTrackViewCos;
+        uvr[3 * i] = p->mTrackProjX;
+        uvr[3 * i + 1] = p->mTrackProjY;
+        uvr[3 * i + 2] = p->mTrackProjXR;
+    }
     Queries qs;
-    for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {
-        MapPoint *pMP = vpMapPoints[iMP];
-        if (!pMP->mbTrackInView) continue;  // :73
-        if (pMP->isBad()) continue;         // :76
-        const int &nPredictedLevel = pMP->mnTrackScaleLevel;
-        float r = RadiusByViewingCos(pMP->mTrackViewCos);  // :84
-        if (bFactor) r *= th;
-        // :90-91 GetFeaturesInArea(mTrackProjX, mTrackProjY, r * mvScaleFactors[level], level - 1, level); the right-image
-        // gate of :114-119 compares against the same product
-        qs.Add(pMP, (int)iMP, pMP->mTrackProjX, pMP->mTrackProjY, r * F.mvScaleFactors[nPredictedLevel], nPredictedLevel - 1,
-               nPredictedLevel, pMP->mTrackProjXR);
+    qs.q.resize(n);
+    qs.src.resize(n);
+    int32_t nq = 0;
+    if (orbfe_proj_queries_local_map(F.mvScaleFactors.data(), (int32_t)n, in_view.data(), bad.data(), level.data(), view_cos.data(), uvr.data(),
+                                     obs.data(), th, qs.q.data(), qs.src.data(), &nq) != ORBFE_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbfe): ") + orbfe_last_error());
+    qs.q.resize((size_t)nq);
+    qs.src.resize((size_t)nq);
+    for (int k = 0; k < nq; ++k) {
+        MapPoint *p = vpMapPoints[(size_t)qs.src[(size_t)k]];
+        const cv::Mat d = p->GetDescriptor();
+        qs.desc.insert(qs.desc.end(), d.ptr<uint8_t>(0), d.ptr<uint8_t>(0) + 32);
+        qs.mp.push_back(p);
     }
     std::vector<int32_t> match;
     RunSearch(F, qs, TH_HIGH, mfNNratio, 1, match);
-    int nmatches = 0;
+    int found = 0;
     for (size_t k = 0; k < match.size(); ++k)
         if (match[k] >= 0) {  // :150-151
             F.mvpMapPoints[(size_t)match[k]] = qs.mp[k];
-            nmatches++;
+            ++found;
         }
-    return nmatches;
+    return found;
 }
 
 // src/ORBmatcher.cc:1757-1867 (Tracking::Relocalization): the keyframe's MapPoints projected into the current frame; a slot of
@@ -249,101 +345,64 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
     const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
     const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
     const cv::Mat Ow = -Rcw.t() * tcw;
-    const float factor = 1.0f / HISTO_LENGTH;
-    const std::vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
-    Queries qs;
-    for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
-        MapPoint *pMP = vpMPs[i];
-        if (!pMP) continue;
-        if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;  // :1778
-        cv::Mat x3Dw = pMP->GetWorldPos();
-        cv::Mat x3Dc = Rcw * x3Dw + tcw;
-        const float xc = x3Dc.at<float>(0);
-        const float yc = x3Dc.at<float>(1);
-        const float invzc = 1.0 / x3Dc.at<float>(2);
-        const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
-        const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
-        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
-        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
-        cv::Mat PO = x3Dw - Ow;
-        float dist3D = cv::norm(PO);
-        const float maxDistance = pMP->GetMaxDistanceInvariance();
-        const float minDistance = pMP->GetMinDistanceInvariance();
-        if (dist3D < minDistance || dist3D > maxDistance) continue;  // :1799
-        int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
-        const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
-        qs.Add(pMP, (int)i, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, 0.f, ORBFE_PROJ_CLAIMS);  // :1806
+    const std::vector<MapPoint *> kfPoints = pKF->GetMapPointMatches();
+    PointList pl;
+    for (size_t i = 0; i < kfPoints.size(); ++i) {
+        MapPoint *p = kfPoints[i];
+        if (p && !p->isBad() && !sAlreadyFound.count(p)) pl.Add(p, (int)i, false, true);  // :1774-1778
     }
+    const Vec3 centre(Ow);
+    pl.Project(Pose(Rcw, tcw), NULL, centre.v, CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy, 0.f, CurrentFrame.mnMinX,
+               CurrentFrame.mnMaxX, CurrentFrame.mnMinY, CurrentFrame.mnMaxY, ORBFE_PJ_UV_CHAINED | ORBFE_PJ_BOUNDS_CLOSED);
+    Queries qs;
+    LevelQueries(pl, &CurrentFrame, CurrentFrame.mvScaleFactors, th, 1, ORBFE_PROJ_CLAIMS, false, qs, NULL);  // :1803-1806
     std::vector<int32_t> match;
     RunSearch(CurrentFrame, qs, ORBdist, 0.f, 0, match, /*any_point_blocks*/ true);
-    int nmatches = 0;
-    std::vector<int> rotHist[HISTO_LENGTH];
+    std::vector<float> angKF, angF;
+    std::vector<int> hit;
+    int found = 0;
     for (size_t k = 0; k < match.size(); ++k) {
         if (match[k] < 0) continue;
-        const int bestIdx2 = match[k], i = qs.src[k];
-        CurrentFrame.mvpMapPoints[bestIdx2] = qs.mp[k];  // :1826
-        nmatches++;
-        if (mbCheckOrientation) {
-            float rot = pKF->mvKeysUn[i].angle - CurrentFrame.mvKeysUn[bestIdx2].angle;
-            if (rot < 0.0) rot += 360.0f;
-            int bin = round(rot * factor);
-            if (bin == HISTO_LENGTH) bin = 0;
-            rotHist[bin].push_back(bestIdx2);
-        }
+        CurrentFrame.mvpMapPoints[(size_t)match[k]] = qs.mp[k];  // :1826
+        ++found;
+        hit.push_back(match[k]);
+        angKF.push_back(pKF->mvKeysUn[(size_t)qs.src[k]].angle);
+        angF.push_back(CurrentFrame.mvKeysUn[(size_t)match[k]].angle);
     }
     if (mbCheckOrientation) {  // :1846-1863
-        int ind1 = -1, ind2 = -1, ind3 = -1;
-        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-        for (int i = 0; i < HISTO_LENGTH; i++)
-            if (i != ind1 && i != ind2 && i != ind3)
-                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
-                    CurrentFrame.mvpMapPoints[rotHist[i][j]] = NULL;
-                    nmatches--;
-                }
+        std::vector<uint8_t> drop;
+        RotationOutliers(angKF, angF, HISTO_LENGTH, drop);
+        for (size_t e = 0; e < drop.size(); ++e)
+            if (drop[e]) {
+                CurrentFrame.mvpMapPoints[(size_t)hit[e]] = NULL;
+                --found;
+            }
     }
-    return nmatches;
+    return found;
 }
 
 // src/ORBmatcher.cc:378-470 (LoopClosing::ComputeSim3 / SearchAndFuse): map points projected into a keyframe with a Sim3
 int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched,
                                    int th)
 {
-    const float &fx = pKF->fx;
-    const float &fy = pKF->fy;
-    const float &cx = pKF->cx;
-    const float &cy = pKF->cy;
     cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
     const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
     cv::Mat Rcw = sRcw / scw;
     cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
     cv::Mat Ow = -Rcw.t() * tcw;
-    std::set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());  // :393, not updated by the loop
-    spAlreadyFound.erase(static_cast<MapPoint *>(NULL));
-    Queries qs;
-    for (int iMP = 0, iendMP = (int)vpPoints.size(); iMP < iendMP; iMP++) {
-        MapPoint *pMP = vpPoints[iMP];
-        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
-        cv::Mat p3Dw = pMP->GetWorldPos();
-        cv::Mat p3Dc = Rcw * p3Dw + tcw;
-        if (p3Dc.at<float>(2) < 0.0) continue;
-        const float invz = 1 / p3Dc.at<float>(2);
-        const float x = p3Dc.at<float>(0) * invz;
-        const float y = p3Dc.at<float>(1) * invz;
-        const float u = fx * x + cx;
-        const float v = fy * y + cy;
-        if (!pKF->IsInImage(u, v)) continue;
-        const float maxDistance = pMP->GetMaxDistanceInvariance();
-        const float minDistance = pMP->GetMinDistanceInvariance();
-        cv::Mat PO = p3Dw - Ow;
-        const float dist = cv::norm(PO);
-        if (dist < minDistance || dist > maxDistance) continue;
-        cv::Mat Pn = pMP->GetNormal();
-        if (PO.dot(Pn) < 0.5 * dist) continue;
-        int nPredictedLevel = pMP->PredictScale(dist, pKF);
-        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
-        // :434 KeyFrame::GetFeaturesInArea(u, v, radius) + the level test of :447-448 inside the candidate loop
-        qs.Add(pMP, iMP, u, v, radius, nPredictedLevel - 1, nPredictedLevel, 0.f, ORBFE_PROJ_CLAIMS);
+    std::set<MapPoint *> known(vpMatched.begin(), vpMatched.end());  // :393, not updated by the loop
+    known.erase(static_cast<MapPoint *>(NULL));
+    PointList pl;
+    for (size_t i = 0; i < vpPoints.size(); ++i) {
+        MapPoint *p = vpPoints[i];
+        if (!p->isBad() && !known.count(p)) pl.Add(p, (int)i, true, true);  // :403
     }
+    const Vec3 centre(Ow);
+    pl.Project(Pose(Rcw, tcw), NULL, centre.v, pKF->fx, pKF->fy, pKF->cx, pKF->cy, 0.f, (float)pKF->mnMinX, (float)pKF->mnMaxX,
+               (float)pKF->mnMinY, (float)pKF->mnMaxY, ORBFE_PJ_SKIP_NEG_DEPTH);
+    Queries qs;
+    // :434 KeyFrame::GetFeaturesInArea(u, v, radius) + the level test of :447-448 inside the candidate loop: on the device
+    LevelQueries(pl, pKF, pKF->mvScaleFactors, (float)th, 0, ORBFE_PROJ_CLAIMS, false, qs, NULL);
     std::vector<int32_t> match(qs.q.size(), -1);
     if (!qs.q.empty() && !pKF->mvKeysUn.empty()) {
         FrameSide fs(pKF, &vpMatched);
@@ -353,137 +412,123 @@ int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector
             qs.q.data(), qs.desc.data(), (int32_t)qs.q.size(), TH_LOW, 0.f, 0, match.data(), NULL, NULL);
         if (s != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchByProjection (orbfe): ") + orbfe_last_error());
     }
-    int nmatches = 0;
+    int found = 0;
     for (size_t k = 0; k < match.size(); ++k)
         if (match[k] >= 0) {  // :463-464
             vpMatched[(size_t)match[k]] = qs.mp[k];
-            nmatches++;
+            ++found;
         }
-    return nmatches;
+    return found;
 }
 
-// src/ORBmatcher.cc:1578-1724; points_last / points_current: the extra outputs of perfect/src/ORBmatcher.cc:1727-1911
-typedef std::function<void(std::vector<int> *, int &, int &, int &)> ThreeMaxima;  // ORBmatcher::ComputeThreeMaxima is protected
-static int SearchLastFrame(const bool mbCheckOrientation, Frame &CurrentFrame, const Frame &LastFrame, const float th,
-                           const bool bMono, std::vector<cv::Point2f> *points_last, std::vector<cv::Point2f> *points_current,
-                           const ThreeMaxima &three_maxima)
+// src/ORBmatcher.cc:1578-1724 (Tracking::TrackWithMotionModel); points_last / points_current: the extra outputs of
+// perfect/src/ORBmatcher.cc:1727-1911
+static int SearchLastFrame(const bool check_orientation, Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono,
+                           std::vector<cv::Point2f> *points_last, std::vector<cv::Point2f> *points_current)
 {
-    const int HISTO_LENGTH = ORBmatcher::HISTO_LENGTH;
-    const float factor = 1.0f / HISTO_LENGTH;  // :1586
     const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
     const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
     const cv::Mat twc = -Rcw.t() * tcw;
     const cv::Mat Rlw = LastFrame.mTcw.rowRange(0, 3).colRange(0, 3);
     const cv::Mat tlw = LastFrame.mTcw.rowRange(0, 3).col(3);
     const cv::Mat tlc = Rlw * twc + tlw;
-    const bool bForward = tlc.at<float>(2) > CurrentFrame.mb && !bMono;    // :1604
-    const bool bBackward = -tlc.at<float>(2) > CurrentFrame.mb && !bMono;  // :1607
+    const bool forward = tlc.at<float>(2) > CurrentFrame.mb && !bMono;    // :1604
+    const bool backward = -tlc.at<float>(2) > CurrentFrame.mb && !bMono;  // :1607
+    PointList pl;
+    for (int i = 0; i < LastFrame.N; ++i)
+        if (LastFrame.mvpMapPoints[(size_t)i] && !LastFrame.mvbOutlier[(size_t)i]) pl.Add(LastFrame.mvpMapPoints[(size_t)i], i, false, false);
+    pl.Project(Pose(Rcw, tcw), NULL, NULL, CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy, CurrentFrame.mbf,
+               CurrentFrame.mnMinX, CurrentFrame.mnMaxX, CurrentFrame.mnMinY, CurrentFrame.mnMaxY,
+               ORBFE_PJ_SKIP_NEG_INVZ | ORBFE_PJ_UV_CHAINED | ORBFE_PJ_BOUNDS_CLOSED);
     Queries qs;
-    for (int i = 0; i < LastFrame.N; i++) {
-        MapPoint *pMP = LastFrame.mvpMapPoints[i];
-        if (!pMP) continue;
-        if (LastFrame.mvbOutlier[i]) continue;
-        cv::Mat x3Dw = pMP->GetWorldPos();  // :1620-1632
-        cv::Mat x3Dc = Rcw * x3Dw + tcw;
-        const float xc = x3Dc.at<float>(0);
-        const float yc = x3Dc.at<float>(1);
-        const float invzc = 1.0 / x3Dc.at<float>(2);
-        if (invzc < 0) continue;
-        float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
-        float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
-        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
-        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
-        int nLastOctave = LastFrame.mvKeys[i].octave;
-        float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];  // :1642
-        int minLevel, maxLevel;
-        if (bForward) { minLevel = nLastOctave; maxLevel = -1; }            // :1645 GetFeaturesInArea(u, v, radius, nLastOctave)
-        else if (bBackward) { minLevel = 0; maxLevel = nLastOctave; }       // :1647
-        else { minLevel = nLastOctave - 1; maxLevel = nLastOctave + 1; }    // :1649
-        const float ur = u - CurrentFrame.mbf * invzc;                      // :1656
-        qs.Add(pMP, i, u, v, radius, minLevel, maxLevel, ur);
+    for (size_t k = 0; k < pl.size(); ++k) {
+        if (!pl.ok[k]) continue;
+        const int octave = LastFrame.mvKeys[(size_t)pl.src[k]].octave;
+        // :1642-1649 the level window follows the motion: ahead -> finer or equal levels only, backwards -> coarser or equal
+        const int lo = forward ? octave : (backward ? 0 : octave - 1), hi = forward ? -1 : (backward ? octave : octave + 1);
+        MapPoint *p = pl.mp[k];
+        qs.Add(p, pl.src[k], pl.u[k], pl.v[k], th * CurrentFrame.mvScaleFactors[(size_t)octave], lo, hi, pl.ur[k],
+               ORBFE_PROJ_RIGHT_GATE | (p->Observations() > 0 ? ORBFE_PROJ_CLAIMS : 0));
     }
     std::vector<int32_t> match;
     RunSearch(CurrentFrame, qs, ORBmatcher::TH_HIGH, 0.f, 0, match);
-    int nmatches = 0;
-    std::vector<int> rotHist[ORBmatcher::HISTO_LENGTH];
+    std::vector<float> angL, angC;
+    std::vector<int> hit;
+    int found = 0;
     for (size_t k = 0; k < match.size(); ++k) {
         if (match[k] < 0) continue;
-        const int bestIdx2 = match[k], i = qs.src[k];
-        CurrentFrame.mvpMapPoints[bestIdx2] = qs.mp[k];  // :1675-1676
-        nmatches++;
+        const size_t c = (size_t)match[k], l = (size_t)qs.src[k];
+        CurrentFrame.mvpMapPoints[c] = qs.mp[k];  // :1675-1676
+        ++found;
         if (points_last) {
-            points_last->push_back(LastFrame.mvKeys[i].pt);
-            points_current->push_back(CurrentFrame.mvKeys[bestIdx2].pt);
+            points_last->push_back(LastFrame.mvKeys[l].pt);
+            points_current->push_back(CurrentFrame.mvKeys[c].pt);
         }
-        if (mbCheckOrientation) {  // :1679-1689
-            float rot = LastFrame.mvKeysUn[i].angle - CurrentFrame.mvKeysUn[bestIdx2].angle;
-            if (rot < 0.0) rot += 360.0f;
-            int bin = round(rot * factor);
-            if (bin == HISTO_LENGTH) bin = 0;
-            rotHist[bin].push_back(bestIdx2);
-        }
+        hit.push_back(match[k]);
+        angL.push_back(LastFrame.mvKeysUn[l].angle);
+        angC.push_back(CurrentFrame.mvKeysUn[c].angle);
     }
-    if (mbCheckOrientation) {  // :1696-1719
-        int ind1 = -1, ind2 = -1, ind3 = -1;
-        three_maxima(rotHist, ind1, ind2, ind3);  // :1912-1957, the reference's own member
-        for (int i = 0; i < HISTO_LENGTH; i++)
-            if (i != ind1 && i != ind2 && i != ind3)
-                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
-                    CurrentFrame.mvpMapPoints[rotHist[i][j]] = static_cast<MapPoint *>(NULL);
-                    nmatches--;
-                }
+    if (check_orientation) {  // :1696-1719
+        std::vector<uint8_t> drop;
+        RotationOutliers(angL, angC, ORBmatcher::HISTO_LENGTH, drop);
+        for (size_t e = 0; e < drop.size(); ++e)
+            if (drop[e]) {
+                CurrentFrame.mvpMapPoints[(size_t)hit[e]] = NULL;
+                --found;
+            }
     }
-    return nmatches;
+    return found;
 }
 
 int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
 {
-    return SearchLastFrame(mbCheckOrientation, CurrentFrame, LastFrame, th, bMono, NULL, NULL,
-                           [this](std::vector<int> *h, int &a, int &b, int &c) { ComputeThreeMaxima(h, HISTO_LENGTH, a, b, c); });
+    return SearchLastFrame(mbCheckOrientation, CurrentFrame, LastFrame, th, bMono, NULL, NULL);
 }
 
 #ifdef ORBFE_SHIM_PERFECT
 int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono,
                                    std::vector<cv::Point2f> &points_last, std::vector<cv::Point2f> &points_current)
 {
-    return SearchLastFrame(mbCheckOrientation, CurrentFrame, LastFrame, th, bMono, &points_last, &points_current,
-                           [this](std::vector<int> *h, int &a, int &b, int &c) { ComputeThreeMaxima(h, HISTO_LENGTH, a, b, c); });
+    return SearchLastFrame(mbCheckOrientation, CurrentFrame, LastFrame, th, bMono, &points_last, &points_current);
 }
 #endif
 
 // src/ORBmatcher.cc:827-1012 (LocalMapping::CreateNewMapPoints, once per neighbour keyframe): Hamming + epipolar gate of every
 // unmatched keyframe-1 feature against its vocabulary node's keyframe-2 features in ONE orbfe_search_for_triangulation call;
-// the epipole, the eligibility flags and the rotation histogram stay here
+// the eligibility flags and the rotation check are assembled / replayed here
 int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> > &vMatchedPairs,
                                        const bool bOnlyStereo)
 {
-    // :833-843 the epipole of keyframe 1 in keyframe 2
-    cv::Mat Cw = pKF1->GetCameraCenter();
-    cv::Mat R2w = pKF2->GetRotation();
-    cv::Mat t2w = pKF2->GetTranslation();
-    cv::Mat C2 = R2w * Cw + t2w;
-    const float invz = 1.0f / C2.at<float>(2);
-    const float ex = pKF2->fx * C2.at<float>(0) * invz + pKF2->cx;
-    const float ey = pKF2->fy * C2.at<float>(1) * invz + pKF2->cy;
+    // :833-843 the epipole = keyframe 1's camera centre seen by keyframe 2: one point through the projection call, no gates
+    float ex = 0.f, ey = 0.f;
+    {
+        const Vec3 c1(pKF1->GetCameraCenter());
+        const Pose P2(pKF2->GetRotation(), pKF2->GetTranslation());
+        uint8_t ok = 0;
+        const float big = INFINITY;  // closed bounds at +-inf: nothing is gated, whatever the projection yields
+        if (orbfe_project_points(P2.R, P2.t, NULL, NULL, NULL, pKF2->fx, pKF2->fy, pKF2->cx, pKF2->cy, 0.f, -big, big, -big, big,
+                                 ORBFE_PJ_UV_CHAINED | ORBFE_PJ_BOUNDS_CLOSED, 1, c1.v, NULL, NULL, NULL, &ex, &ey, NULL, NULL, NULL, &ok) != ORBFE_OK)
+            throw std::runtime_error(std::string("ORBmatcher::SearchForTriangulation (orbfe): ") + orbfe_last_error());
+    }
     const int n1 = pKF1->N, n2 = pKF2->N;
-    std::vector<int> vMatches12((size_t)n1, -1);
-    int nmatches = 0;
+    std::vector<int32_t> m12((size_t)std::max(n1, 1), -1);
+    int found = 0;
     if (n1 > 0 && n2 > 0) {
         std::vector<float> xy1((size_t)n1 * 2), xy2((size_t)n2 * 2);
         std::vector<int32_t> oct2((size_t)n2);
         std::vector<uint8_t> e1((size_t)n1), s1((size_t)n1), e2((size_t)n2), s2((size_t)n2), t1, t2;
-        for (int i = 0; i < n1; ++i) {
-            xy1[2 * (size_t)i] = pKF1->mvKeysUn[(size_t)i].pt.x;
-            xy1[2 * (size_t)i + 1] = pKF1->mvKeysUn[(size_t)i].pt.y;
-            s1[(size_t)i] = pKF1->mvuRight[(size_t)i] >= 0;                                   // :866
-            e1[(size_t)i] = !pKF1->GetMapPoint((size_t)i) && (!bOnlyStereo || s1[(size_t)i]);  // :860-870
+        for (size_t i = 0; i < (size_t)n1; ++i) {
+            xy1[2 * i] = pKF1->mvKeysUn[i].pt.x;
+            xy1[2 * i + 1] = pKF1->mvKeysUn[i].pt.y;
+            s1[i] = pKF1->mvuRight[i] >= 0;                        // :866
+            e1[i] = !pKF1->GetMapPoint(i) && (!bOnlyStereo || s1[i]);  // :860-870
         }
-        for (int i = 0; i < n2; ++i) {
-            xy2[2 * (size_t)i] = pKF2->mvKeysUn[(size_t)i].pt.x;
-            xy2[2 * (size_t)i + 1] = pKF2->mvKeysUn[(size_t)i].pt.y;
-            oct2[(size_t)i] = pKF2->mvKeysUn[(size_t)i].octave;
-            s2[(size_t)i] = pKF2->mvuRight[(size_t)i] >= 0;                                   // :887
-            e2[(size_t)i] = !pKF2->GetMapPoint((size_t)i) && (!bOnlyStereo || s2[(size_t)i]);  // :881-891 (vbMatched2 is never set)
+        for (size_t i = 0; i < (size_t)n2; ++i) {
+            xy2[2 * i] = pKF2->mvKeysUn[i].pt.x;
+            xy2[2 * i + 1] = pKF2->mvKeysUn[i].pt.y;
+            oct2[i] = pKF2->mvKeysUn[i].octave;
+            s2[i] = pKF2->mvuRight[i] >= 0;                        // :887
+            e2[i] = !pKF2->GetMapPoint(i) && (!bOnlyStereo || s2[i]);  // :881-891 (vbMatched2 is never set)
         }
         Csr c1, c2;
         Flatten(pKF1->mFeatVec, c1);
@@ -491,288 +536,192 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
         float F[9];
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) F[3 * r + c] = F12.at<float>(r, c);
-        std::vector<int32_t> m12((size_t)n1, -1);
         const orbfe_status st = orbfe_search_for_triangulation(
             t_matcher.get(), Rows(pKF1->mDescriptors, t1), xy1.data(), e1.data(), s1.data(), n1, c1.node.data(), c1.off.data(), c1.idx.data(),
             (int)c1.node.size(), Rows(pKF2->mDescriptors, t2), xy2.data(), oct2.data(), e2.data(), s2.data(), n2, c2.node.data(),
             c2.off.data(), c2.idx.data(), (int)c2.node.size(), F, ex, ey, pKF2->mvScaleFactors.data(), pKF2->mvLevelSigma2.data(),
             (int)pKF2->mvScaleFactors.size(), TH_LOW, m12.data());
         if (st != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher::SearchForTriangulation (orbfe): ") + orbfe_last_error());
-        std::vector<int> rotHist[HISTO_LENGTH];
-        const float factor = 1.0f / HISTO_LENGTH;
+        std::vector<float> a1, a2;
+        std::vector<int> hit;
         for (int i = 0; i < n1; ++i) {
-            if (m12[(size_t)i] < 0) continue;
-            vMatches12[(size_t)i] = m12[(size_t)i];  // :917-918
-            nmatches++;
-            if (mbCheckOrientation) {
-                float rot = pKF1->mvKeysUn[(size_t)i].angle - pKF2->mvKeysUn[(size_t)m12[(size_t)i]].angle;
-                if (rot < 0.0) rot += 360.0f;
-                int bin = round(rot * factor);
-                if (bin == HISTO_LENGTH) bin = 0;
-                rotHist[bin].push_back(i);
-            }
+            if (m12[(size_t)i] < 0) continue;  // :917-918
+            ++found;
+            hit.push_back(i);
+            a1.push_back(pKF1->mvKeysUn[(size_t)i].angle);
+            a2.push_back(pKF2->mvKeysUn[(size_t)m12[(size_t)i]].angle);
         }
         if (mbCheckOrientation) {  // :966-985
-            int ind1 = -1, ind2 = -1, ind3 = -1;
-            ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-            for (int i = 0; i < HISTO_LENGTH; i++) {
-                if (i == ind1 || i == ind2 || i == ind3) continue;
-                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
-                    vMatches12[(size_t)rotHist[i][j]] = -1;
-                    nmatches--;
+            std::vector<uint8_t> drop;
+            RotationOutliers(a1, a2, HISTO_LENGTH, drop);
+            for (size_t e = 0; e < drop.size(); ++e)
+                if (drop[e]) {
+                    m12[(size_t)hit[e]] = -1;
+                    --found;
                 }
-            }
         }
     }
     vMatchedPairs.clear();  // :987-997
-    vMatchedPairs.reserve((size_t)std::max(nmatches, 0));
-    for (size_t i = 0, iend = vMatches12.size(); i < iend; i++) {
-        if (vMatches12[i] < 0) continue;
-        vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
-    }
-    return nmatches;
+    vMatchedPairs.reserve((size_t)std::max(found, 0));
+    for (int i = 0; i < n1; ++i)
+        if (m12[(size_t)i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[(size_t)i]));
+    return found;
 }
 
-// src/ORBmatcher.cc:1031-1182
+// src/ORBmatcher.cc:1031-1182 (LocalMapping::SearchInNeighbors)
 int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th)
 {
-    cv::Mat Rcw = pKF->GetRotation();
-    cv::Mat tcw = pKF->GetTranslation();
-    const float &fx = pKF->fx;
-    const float &fy = pKF->fy;
-    const float &cx = pKF->cx;
-    const float &cy = pKF->cy;
-    const float &bf = pKF->mbf;
-    cv::Mat Ow = pKF->GetCameraCenter();
+    const Pose P(pKF->GetRotation(), pKF->GetTranslation());
+    const Vec3 centre(pKF->GetCameraCenter());
     const int nMPs = (int)vpMapPoints.size();
     // ---- phase 1: every gate that does not depend on what the loop mutates (:1060-1101); one query per point that passes ----
+    PointList pl;
+    for (int i = 0; i < nMPs; ++i)
+        if (vpMapPoints[(size_t)i]) pl.Add(vpMapPoints[(size_t)i], i, true, true);
+    pl.Project(P, NULL, centre.v, pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf, (float)pKF->mnMinX, (float)pKF->mnMaxX, (float)pKF->mnMinY,
+               (float)pKF->mnMaxY, ORBFE_PJ_SKIP_NEG_DEPTH);
     Queries qs;
     std::vector<int> slot((size_t)nMPs, -1);  // query index of MapPoint i, -1 = gated out
-    for (int i = 0; i < nMPs; i++) {
-        MapPoint *pMP = vpMapPoints[i];
-        if (!pMP) continue;
-        cv::Mat p3Dw = pMP->GetWorldPos();
-        cv::Mat p3Dc = Rcw * p3Dw + tcw;
-        if (p3Dc.at<float>(2) < 0.0f) continue;  // :1068
-        const float invz = 1 / p3Dc.at<float>(2);
-        const float x = p3Dc.at<float>(0) * invz;
-        const float y = p3Dc.at<float>(1) * invz;
-        const float u = fx * x + cx;
-        const float v = fy * y + cy;
-        if (!pKF->IsInImage(u, v)) continue;  // :1080
-        const float ur = u - bf * invz;  // :1124
-        const float maxDistance = pMP->GetMaxDistanceInvariance();
-        const float minDistance = pMP->GetMinDistanceInvariance();
-        cv::Mat PO = p3Dw - Ow;
-        const float dist3D = cv::norm(PO);
-        if (dist3D < minDistance || dist3D > maxDistance) continue;  // :1090
-        cv::Mat Pn = pMP->GetNormal();
-        if (PO.dot(Pn) < 0.5 * dist3D) continue;  // :1096
-        int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
-        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
-        // :1103 GetFeaturesInArea(u, v, radius), :1119 the level window, :1122-1145 the reprojection-error gate: on the device
-        slot[(size_t)i] = (int)qs.q.size();
-        qs.Add(pMP, i, u, v, radius, nPredictedLevel - 1, nPredictedLevel, ur, ORBFE_PROJ_CHI2_GATE);
-    }
+    // :1103 GetFeaturesInArea(u, v, radius), :1119 the level window, :1122-1145 the reprojection-error gate: on the device
+    LevelQueries(pl, pKF, pKF->mvScaleFactors, th, 0, ORBFE_PROJ_CHI2_GATE, true, qs, &slot);
     // ---- the candidate scans: best candidate per point, first in list order on ties (:1149-1156), accepted at TH_LOW ----
     std::vector<int32_t> bestIdx;
     RunKeyFrameSearch(pKF, qs, TH_LOW, true, bestIdx, "Fuse");
     // ---- phase 2: the loop's decisions, in order, on the live objects (:1049-1056, :1159-1180) ----
-    int nFused = 0;
-    for (int i = 0; i < nMPs; i++) {
-        MapPoint *pMP = vpMapPoints[i];
-        if (!pMP) continue;
+    int fused = 0;
+    for (int i = 0; i < nMPs; ++i) {
+        MapPoint *pMP = vpMapPoints[(size_t)i];
+        if (!pMP || slot[(size_t)i] < 0) continue;
         if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
-        if (slot[(size_t)i] < 0) continue;
-        const int k = slot[(size_t)i];
-        if (bestIdx[(size_t)k] >= 0) {  // :1159 bestDist <= TH_LOW
-            MapPoint *pMPinKF = pKF->GetMapPoint((size_t)bestIdx[(size_t)k]);
-            if (pMPinKF) {
-                if (!pMPinKF->isBad()) {
-                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
-                    else pMPinKF->Replace(pMP);
-                }
-            } else {
-                pMP->AddObservation(pKF, (size_t)bestIdx[(size_t)k]);
-                pKF->AddMapPoint(pMP, (size_t)bestIdx[(size_t)k]);
-            }
-            nFused++;
+        const int32_t at = bestIdx[(size_t)slot[(size_t)i]];
+        if (at < 0) continue;  // :1159 bestDist <= TH_LOW
+        MapPoint *held = pKF->GetMapPoint((size_t)at);
+        if (!held) {
+            pMP->AddObservation(pKF, (size_t)at);
+            pKF->AddMapPoint(pMP, (size_t)at);
+        } else if (!held->isBad()) {
+            if (held->Observations() > pMP->Observations()) pMP->Replace(held);
+            else held->Replace(pMP);
         }
+        ++fused;
     }
-    return nFused;
+    return fused;
 }
 
 // src/ORBmatcher.cc:1198-1299 (LoopClosing::SearchAndFuse): the Sim3 form -- no stereo gate, a hit on an occupied slot is
 // reported in vpReplacePoint instead of replaced; the same two phases as the plain Fuse
 int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint)
 {
-    const float &fx = pKF->fx;
-    const float &fy = pKF->fy;
-    const float &cx = pKF->cx;
-    const float &cy = pKF->cy;
     cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
     const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
     cv::Mat Rcw = sRcw / scw;
     cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
     cv::Mat Ow = -Rcw.t() * tcw;
-    const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();  // :1212, fixed for the whole loop
+    const std::set<MapPoint *> known = pKF->GetMapPoints();  // :1212, fixed for the whole loop
     const int nPoints = (int)vpPoints.size();
+    PointList pl;
+    for (int i = 0; i < nPoints; ++i) {
+        MapPoint *p = vpPoints[(size_t)i];
+        if (p && !p->isBad() && !known.count(p)) pl.Add(p, i, true, true);  // :1224 (neither changes inside the loop)
+    }
+    const Vec3 centre(Ow);
+    pl.Project(Pose(Rcw, tcw), NULL, centre.v, pKF->fx, pKF->fy, pKF->cx, pKF->cy, 0.f, (float)pKF->mnMinX, (float)pKF->mnMaxX,
+               (float)pKF->mnMinY, (float)pKF->mnMaxY, ORBFE_PJ_SKIP_NEG_DEPTH);
     Queries qs;
     std::vector<int> slot((size_t)nPoints, -1);
-    for (int iMP = 0; iMP < nPoints; iMP++) {
-        MapPoint *pMP = vpPoints[iMP];
-        if (!pMP) continue;
-        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;  // :1224 (neither changes inside the loop)
-        cv::Mat p3Dw = pMP->GetWorldPos();
-        cv::Mat p3Dc = Rcw * p3Dw + tcw;
-        if (p3Dc.at<float>(2) < 0.0f) continue;
-        const float invz = 1.0 / p3Dc.at<float>(2);
-        const float x = p3Dc.at<float>(0) * invz;
-        const float y = p3Dc.at<float>(1) * invz;
-        const float u = fx * x + cx;
-        const float v = fy * y + cy;
-        if (!pKF->IsInImage(u, v)) continue;
-        const float maxDistance = pMP->GetMaxDistanceInvariance();
-        const float minDistance = pMP->GetMinDistanceInvariance();
-        cv::Mat PO = p3Dw - Ow;
-        const float dist3D = cv::norm(PO);
-        if (dist3D < minDistance || dist3D > maxDistance) continue;
-        cv::Mat Pn = pMP->GetNormal();
-        if (PO.dot(Pn) < 0.5 * dist3D) continue;
-        int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
-        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
-        // :1257 GetFeaturesInArea(u, v, radius) and the level window of :1268 run on the device
-        slot[(size_t)iMP] = (int)qs.q.size();
-        qs.Add(pMP, iMP, u, v, radius, nPredictedLevel - 1, nPredictedLevel, 0.f, 0);
-    }
+    // :1257 GetFeaturesInArea(u, v, radius) and the level window of :1268 run on the device
+    LevelQueries(pl, pKF, pKF->mvScaleFactors, th, 0, 0, false, qs, &slot);
     std::vector<int32_t> bestIdx;
     RunKeyFrameSearch(pKF, qs, TH_LOW, false, bestIdx, "Fuse");
-    int nFused = 0;
-    for (int iMP = 0; iMP < nPoints; iMP++) {  // :1282-1296 on the live objects, in order
-        if (slot[(size_t)iMP] < 0) continue;
-        const int k = slot[(size_t)iMP];
-        if (bestIdx[(size_t)k] >= 0) {  // :1281 bestDist <= TH_LOW
-            MapPoint *pMP = vpPoints[iMP];
-            MapPoint *pMPinKF = pKF->GetMapPoint((size_t)bestIdx[(size_t)k]);
-            if (pMPinKF) {
-                if (!pMPinKF->isBad()) vpReplacePoint[(size_t)iMP] = pMPinKF;
-            } else {
-                pMP->AddObservation(pKF, (size_t)bestIdx[(size_t)k]);
-                pKF->AddMapPoint(pMP, (size_t)bestIdx[(size_t)k]);
-            }
-            nFused++;
+    int fused = 0;
+    for (int i = 0; i < nPoints; ++i) {  // :1282-1296 on the live objects, in order
+        if (slot[(size_t)i] < 0) continue;
+        const int32_t at = bestIdx[(size_t)slot[(size_t)i]];
+        if (at < 0) continue;  // :1281 bestDist <= TH_LOW
+        MapPoint *held = pKF->GetMapPoint((size_t)at);
+        if (!held) {
+            vpPoints[(size_t)i]->AddObservation(pKF, (size_t)at);
+            pKF->AddMapPoint(vpPoints[(size_t)i], (size_t)at);
+        } else if (!held->isBad()) {
+            vpReplacePoint[(size_t)i] = held;
         }
+        ++fused;
     }
-    return nFused;
+    return fused;
 }
 
 // src/ORBmatcher.cc:1334-1516 (LoopClosing::ComputeSim3): the points of each keyframe are searched in the other one under the
 // candidate similarity, a match is kept when both directions agree.  No decision depends on an earlier one: each direction
-// is one device call (window search on the other keyframe's grid + Hamming).
+// is one projection call + one device call (window search on the other keyframe's grid + Hamming).
 int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12,
                              const cv::Mat &t12, const float th)
 {
-    const float &fx = pKF1->fx;
-    const float &fy = pKF1->fy;
-    const float &cx = pKF1->cx;
-    const float &cy = pKF1->cy;
-    cv::Mat R1w = pKF1->GetRotation();
-    cv::Mat t1w = pKF1->GetTranslation();
-    cv::Mat R2w = pKF2->GetRotation();
-    cv::Mat t2w = pKF2->GetTranslation();
     cv::Mat sR12 = s12 * R12;
     cv::Mat sR21 = (1.0 / s12) * R12.t();
     cv::Mat t21 = -sR21 * t12;
-    const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
-    const int N1 = (int)vpMapPoints1.size();
-    const std::vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
-    const int N2 = (int)vpMapPoints2.size();
-    std::vector<bool> vbAlreadyMatched1((size_t)N1, false), vbAlreadyMatched2((size_t)N2, false);
-    for (int i = 0; i < N1; i++) {
-        MapPoint *pMP = vpMatches12[(size_t)i];
-        if (pMP) {
-            vbAlreadyMatched1[(size_t)i] = true;
-            int idx2 = pMP->GetIndexInKeyFrame(pKF2);
-            if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[(size_t)idx2] = true;
-        }
+    const Pose W1(pKF1->GetRotation(), pKF1->GetTranslation()), W2(pKF2->GetRotation(), pKF2->GetTranslation());
+    const Pose S21(sR21, t21), S12(sR12, t12);
+    const std::vector<MapPoint *> pts1 = pKF1->GetMapPointMatches(), pts2 = pKF2->GetMapPointMatches();
+    const int N1 = (int)pts1.size(), N2 = (int)pts2.size();
+    std::vector<uint8_t> done1((size_t)N1, 0), done2((size_t)N2, 0);
+    for (int i = 0; i < N1; ++i) {  // :1360-1371
+        MapPoint *p = vpMatches12[(size_t)i];
+        if (!p) continue;
+        done1[(size_t)i] = 1;
+        const int at2 = p->GetIndexInKeyFrame(pKF2);
+        if (at2 >= 0 && at2 < N2) done2[(size_t)at2] = 1;
     }
-    // one direction: the points of keyframe A (pose Raw, taw) are taken into keyframe B by (sRba, tba) and looked up there;
-    // GetFeaturesInArea on B's grid, the level window and the Hamming scan are one device call per direction
-    auto search = [&](const std::vector<MapPoint *> &pts, const std::vector<bool> &already, const cv::Mat &Raw, const cv::Mat &taw,
-                      const cv::Mat &sRba, const cv::Mat &tba, KeyFrame *pKFb, std::vector<int> &vnMatch) {
+    // one direction: the points of keyframe A (world -> A by Wa) are taken into keyframe B by the similarity Sba and looked up there
+    auto search = [&](const std::vector<MapPoint *> &pts, const std::vector<uint8_t> &done, const Pose &Wa, const Pose &Sba, KeyFrame *pKFb,
+                      std::vector<int> &found_at) {
+        PointList pl;
+        for (size_t i = 0; i < pts.size(); ++i)
+            if (pts[i] && !done[i] && !pts[i]->isBad()) pl.Add(pts[i], (int)i, false, true);
+        // the reference projects with keyframe 1's intrinsics in BOTH directions (:1337-1340, :1399, :1476)
+        pl.Project(Wa, &Sba, NULL, pKF1->fx, pKF1->fy, pKF1->cx, pKF1->cy, 0.f, (float)pKFb->mnMinX, (float)pKFb->mnMaxX, (float)pKFb->mnMinY,
+                   (float)pKFb->mnMaxY, ORBFE_PJ_SKIP_NEG_DEPTH);
         Queries qs;
-        for (int i = 0; i < (int)pts.size(); i++) {
-            MapPoint *pMP = pts[(size_t)i];
-            if (!pMP || already[(size_t)i]) continue;
-            if (pMP->isBad()) continue;
-            cv::Mat p3Dw = pMP->GetWorldPos();
-            cv::Mat p3Da = Raw * p3Dw + taw;
-            cv::Mat p3Db = sRba * p3Da + tba;
-            if (p3Db.at<float>(2) < 0.0) continue;
-            const float invz = 1.0 / p3Db.at<float>(2);
-            const float x = p3Db.at<float>(0) * invz;
-            const float y = p3Db.at<float>(1) * invz;
-            const float u = fx * x + cx;
-            const float v = fy * y + cy;
-            if (!pKFb->IsInImage(u, v)) continue;
-            const float maxDistance = pMP->GetMaxDistanceInvariance();
-            const float minDistance = pMP->GetMinDistanceInvariance();
-            const float dist3D = cv::norm(p3Db);
-            if (dist3D < minDistance || dist3D > maxDistance) continue;
-            const int nPredictedLevel = pMP->PredictScale(dist3D, pKFb);
-            const float radius = th * pKFb->mvScaleFactors[nPredictedLevel];
-            qs.Add(pMP, i, u, v, radius, nPredictedLevel - 1, nPredictedLevel, 0.f, 0);
-        }
+        LevelQueries(pl, pKFb, pKFb->mvScaleFactors, th, 0, 0, false, qs, NULL);
         std::vector<int32_t> best;
         RunKeyFrameSearch(pKFb, qs, TH_HIGH, false, best, "SearchBySim3");
         for (size_t k = 0; k < best.size(); ++k)
-            if (best[k] >= 0) vnMatch[(size_t)qs.src[k]] = best[k];  // bestDist <= TH_HIGH (:1451, :1527)
+            if (best[k] >= 0) found_at[(size_t)qs.src[k]] = best[k];  // bestDist <= TH_HIGH (:1451, :1527)
     };
-    std::vector<int> vnMatch1((size_t)N1, -1), vnMatch2((size_t)N2, -1);
-    search(vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2, vnMatch1);  // :1380-1453
-    search(vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, pKF1, vnMatch2);  // :1455-1529
-    int nFound = 0;
-    for (int i1 = 0; i1 < N1; i1++) {  // :1532-1545
-        int idx2 = vnMatch1[(size_t)i1];
-        if (idx2 >= 0) {
-            int idx1 = vnMatch2[(size_t)idx2];
-            if (idx1 == i1) {
-                vpMatches12[(size_t)i1] = vpMapPoints2[(size_t)idx2];
-                nFound++;
-            }
+    std::vector<int> in2((size_t)N1, -1), in1((size_t)N2, -1);
+    search(pts1, done1, W1, S21, pKF2, in2);  // :1380-1453
+    search(pts2, done2, W2, S12, pKF1, in1);  // :1455-1529
+    int agreed = 0;
+    for (int i = 0; i < N1; ++i) {  // :1532-1545 both directions have to agree
+        const int j = in2[(size_t)i];
+        if (j >= 0 && in1[(size_t)j] == i) {
+            vpMatches12[(size_t)i] = pts2[(size_t)j];
+            ++agreed;
         }
     }
-    return nFound;
+    return agreed;
 }
 
 // src/ORBmatcher.cc:523-651 (Tracking::MonocularInitialization).  A candidate is skipped when an earlier query already holds
 // it at a distance <= its own (:573), so best / second-best of a query depend on the matches made before it: the device
-// returns every window's candidates with their distances (orbfe_window_distances, one call), the in-order rule runs here.
+// returns every window's candidates with their distances (orbfe_window_distances, one call), orbfe_initialization_resolve runs
+// the in-order rule on those lists, and the outcome is written back here.
 int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize)
 {
-    int nmatches = 0;
-    vnMatches12 = std::vector<int>(F1.mvKeysUn.size(), -1);
-    std::vector<int> rotHist[HISTO_LENGTH];
-    for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
-    const float factor = 1.0f / HISTO_LENGTH;
-    std::vector<int> vMatchedDistance(F2.mvKeysUn.size(), INT_MAX);
-    std::vector<int> vnMatches21(F2.mvKeysUn.size(), -1);
-    const size_t n1 = F1.mvKeysUn.size();
-    // one query per level-0 feature of F1 (:543-545): GetFeaturesInArea(prev.x, prev.y, windowSize, 0, 0) on F2's grid and the
-    // distance of every candidate come back as lists in the reference's candidate order
+    const size_t n1 = F1.mvKeysUn.size(), n2 = F2.mvKeysUn.size();
+    vnMatches12.assign(n1, -1);
+    // one query per level-0 feature of F1 (:543-545): GetFeaturesInArea(prev.x, prev.y, windowSize, 0, 0) on F2's grid
     std::vector<orbfe_proj_query> qs;
     std::vector<uint8_t> qdesc, t1;
-    std::vector<int> slot(n1, -1);
+    std::vector<int> feat_of;  // F1 feature of a query
     const uint8_t *d1 = Rows(F1.mDescriptors, t1);
-    for (size_t i1 = 0; i1 < n1; i1++) {
-        const int level1 = F1.mvKeysUn[i1].octave;
-        if (level1 > 0) continue;
+    for (size_t i = 0; i < n1; ++i) {
+        if (F1.mvKeysUn[i].octave > 0) continue;
         orbfe_proj_query e;
-        e.u = vbPrevMatched[i1].x; e.v = vbPrevMatched[i1].y; e.r = (float)windowSize;
-        e.min_level = level1; e.max_level = level1; e.ur = 0.f; e.flags = 0; e.pad = 0;
-        slot[i1] = (int)qs.size();
+        e.u = vbPrevMatched[i].x; e.v = vbPrevMatched[i].y; e.r = (float)windowSize;
+        e.min_level = 0; e.max_level = 0; e.ur = 0.f; e.flags = 0; e.pad = 0;
+        feat_of.push_back((int)i);
         qs.push_back(e);
-        qdesc.insert(qdesc.end(), d1 + i1 * 32, d1 + i1 * 32 + 32);
+        qdesc.insert(qdesc.end(), d1 + i * 32, d1 + i * 32 + 32);
     }
     const int nq = (int)qs.size();
     std::vector<uint32_t> off((size_t)nq + 1, 0), ent;
@@ -790,60 +739,37 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
             break;
         }
     }
-    for (size_t i1 = 0; i1 < n1; i1++) {  // :538-617 on the device's distances
-        if (slot[i1] < 0) continue;
-        int bestDist = INT_MAX;
-        int bestDist2 = INT_MAX;
-        int bestIdx2 = -1;
-        for (uint32_t k = off[(size_t)slot[i1]]; k < off[(size_t)slot[i1] + 1]; k++) {
-            const size_t i2 = ent[k] & 0xFFFFu;
-            const int d = (int)(ent[k] >> 16);
-            if (vMatchedDistance[i2] <= d) continue;
-            if (d < bestDist) {
-                bestDist2 = bestDist;
-                bestDist = d;
-                bestIdx2 = (int)i2;
-            } else if (d < bestDist2) {
-                bestDist2 = d;
-            }
+    std::vector<int32_t> accepted((size_t)std::max(nq, 1), -1), holder(std::max<size_t>(n2, 1), -1);
+    if (orbfe_initialization_resolve(off.data(), ent.data(), nq, (int32_t)n2, TH_LOW, mfNNratio, accepted.data(), holder.data()) != ORBFE_OK)
+        throw std::runtime_error(std::string("ORBmatcher::SearchForInitialization (orbfe): ") + orbfe_last_error());
+    // a query's match stands while it is still the holder of its feature (:587-592 a later, closer query takes it over)
+    int found = 0;
+    std::vector<float> a1, a2;
+    std::vector<int> voter;  // F1 features in acceptance order: every accepted match votes (:600-608), taken over later or not
+    for (int k = 0; k < nq; ++k) {
+        const int j = accepted[(size_t)k];
+        if (j < 0) continue;
+        const size_t i = (size_t)feat_of[(size_t)k];
+        if (holder[(size_t)j] == k) {
+            vnMatches12[i] = j;
+            ++found;
         }
-        if (bestDist <= TH_LOW) {
-            if (bestDist < (float)bestDist2 * mfNNratio) {
-                if (vnMatches21[(size_t)bestIdx2] >= 0) {
-                    vnMatches12[(size_t)vnMatches21[(size_t)bestIdx2]] = -1;
-                    nmatches--;
-                }
-                vnMatches12[i1] = bestIdx2;
-                vnMatches21[(size_t)bestIdx2] = (int)i1;
-                vMatchedDistance[(size_t)bestIdx2] = bestDist;
-                nmatches++;
-                if (mbCheckOrientation) {
-                    float rot = F1.mvKeysUn[i1].angle - F2.mvKeysUn[(size_t)bestIdx2].angle;
-                    if (rot < 0.0) rot += 360.0f;
-                    int bin = round(rot * factor);
-                    if (bin == HISTO_LENGTH) bin = 0;
-                    rotHist[bin].push_back((int)i1);
-                }
-            }
-        }
+        voter.push_back((int)i);
+        a1.push_back(F1.mvKeysUn[i].angle);
+        a2.push_back(F2.mvKeysUn[(size_t)j].angle);
     }
-    if (mbCheckOrientation) {
-        int ind1 = -1, ind2 = -1, ind3 = -1;
-        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-        for (int i = 0; i < HISTO_LENGTH; i++) {
-            if (i == ind1 || i == ind2 || i == ind3) continue;
-            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
-                int idx1 = rotHist[i][j];
-                if (vnMatches12[(size_t)idx1] >= 0) {
-                    vnMatches12[(size_t)idx1] = -1;
-                    nmatches--;
-                }
+    if (mbCheckOrientation) {  // :621-641
+        std::vector<uint8_t> drop;
+        RotationOutliers(a1, a2, HISTO_LENGTH, drop);
+        for (size_t e = 0; e < drop.size(); ++e)
+            if (drop[e] && vnMatches12[(size_t)voter[e]] >= 0) {
+                vnMatches12[(size_t)voter[e]] = -1;
+                --found;
             }
-        }
     }
-    for (size_t i1 = 0, iend1 = vnMatches12.size(); i1 < iend1; i1++)
-        if (vnMatches12[i1] >= 0) vbPrevMatched[i1] = F2.mvKeysUn[(size_t)vnMatches12[i1]].pt;
-    return nmatches;
+    for (size_t i = 0; i < n1; ++i)  // :644-647
+        if (vnMatches12[i] >= 0) vbPrevMatched[i] = F2.mvKeysUn[(size_t)vnMatches12[i]].pt;
+    return found;
 }
 
 #ifdef ORBFE_SHIM_STANDALONE
