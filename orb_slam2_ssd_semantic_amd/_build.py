@@ -48,15 +48,25 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build_variant(tag, extra_flags):
+    """A variant library next to the default one: ab/liborbfe_<tag>.so built with extra -D flags (ab/ is git-ignored and travels
+    to the GPU box); select it at run time with ORBFE_LIB=<path>.  The default library is not touched."""
+    out = os.path.join(_ROOT, "ab", f"liborbfe_{tag}.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    return build(force=True, out_path=out, extra=list(extra_flags), bdir=os.path.join(_PKG, "build", "ab_" + tag))
+
+
+def build(force=False, verbose=False, out_path=None, extra=None, bdir=None):
+    variant = out_path is not None
+    if not variant and not force and not _stale():
         return LIB
     cc = hipcc()
-    if os.path.exists(FLAGFILE):
+    if not variant and os.path.exists(FLAGFILE):
         os.remove(FLAGFILE)   # no sidecar while a build is in flight: an aborted build is stale
-    extra = os.environ.get("ORBFE_EXTRA_FLAGS", "").split()   # developer A/B builds on the GPU box (e.g. -DQT_MIN_WAVES=7)
+    if extra is None:
+        extra = os.environ.get("ORBFE_EXTRA_FLAGS", "").split()   # developer A/B builds on the GPU box (e.g. -DQT_MIN_WAVES=7)
     objs = []
-    bdir = os.path.join(_PKG, "build")
+    bdir = bdir or os.path.join(_PKG, "build")
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for s in SOURCES:
@@ -72,10 +82,12 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-ldl"]
+    cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out_path or LIB, *objs, "-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    if variant:
+        return out_path
     with open(FLAGFILE, "w") as f:
         f.write(_flagset() + "\n")
     return LIB

@@ -76,7 +76,9 @@ def lib():
         import torch  # noqa: F401  (plumbing only: device memory, streams, torch.distributed)
     except Exception:  # pragma: no cover
         pass
-    path = _build.build()
+    # $ORBFE_LIB: a prebuilt VARIANT of the library (developer A/B runs: kernels compiled with other -D flags, built on the
+    # build machine with _build.build_variant so that the GPU box does not spend its minutes compiling)
+    path = os.environ.get("ORBFE_LIB") or _build.build()
     L = C.CDLL(path)
     vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
     L.orbfe_version.restype = i32

@@ -501,20 +501,37 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         fast_row_steps += mx + 8;
     }
     // blur lane list: every 4-px column of every (balanced, <= ORBFE_ROWS_PER_WAVE rows) row block, single-level waves, no
-    // halos.  Lanes do not talk to each other, so the columns whose 12-byte window [x - 4, x + 8) lies inside the row (no
-    // reflected column: flag bit 1) are packed into waves of their own -- those skip the byte rearrangement of the border
-    // path; the few edge columns (2 - 3 per row block) of a level share separate waves.
+    // halos.  Lanes do not talk to each other, so a wave can hold columns of different row blocks.  Columns whose 12-byte
+    // window [x - 4, x + 8) lies inside the row (flag bit 1: no reflected column) skip the byte rearrangement of the border
+    // path, so they get waves of their own.  Everything is laid out in 64-BYTE PIECES (16 lanes): the left and the right piece
+    // of a row block go to the border waves whole, the pieces between them to the interior waves -- every store instruction
+    // then writes whole 64-byte pieces.  (Border waves holding only the 2 - 3 reflected columns of 20-odd row blocks wrote a
+    // lone dword into 64 different lines per store: WRITE_SIZE was 1.19x the output, profiles/r04_ab_experiments.json;
+    // ORBFE_BLUR_PIECES=0 brings that packing back for the A/B.)
     std::vector<OrbLane> blanes;
+    const bool blur_pieces = !(getenv("ORBFE_BLUR_PIECES") && atoi(getenv("ORBFE_BLUR_PIECES")) == 0);
     for (int l = 0; l < nl; ++l) {
         const OrbLevel &L = P.lv[l];
         if (L.w < 16) { orbfe_set_error("level %d too narrow for the blur kernel", l); return ORBFE_ERR_SIZE; }
         const int brb = rows_per_wave;
         const int ncol = (L.w + 3) / 4, nblk = (L.h + brb - 1) / brb, rb = (L.h + nblk - 1) / nblk;
-        for (int pass = 0; pass < 2; ++pass) {  // 0: interior columns, 1: edge columns
+        // first column of the 64-byte piece that holds the first column whose window reaches past the row's right end
+        const int right0 = (std::min(ncol - 1, std::max(0, (L.w - 8) / 4 + 1)) / 16) * 16;
+        auto dead = [&](bool interior_wave) {
+            OrbLane d;
+            d.x = (uint16_t)(interior_wave ? 4 : 0);
+            d.ys = 0;
+            d.nrows = 0;
+            d.flags = (uint16_t)((l << 8) | 1 | (interior_wave ? 2 : 0));
+            return d;
+        };
+        for (int pass = 0; pass < 2; ++pass) {  // 0: interior waves, 1: border waves
             for (int k = 0; k < nblk; ++k) {
                 const int ys = k * rb, nr = std::min(rb, L.h - ys);
-                for (int c = 0; c < ncol && nr > 0; ++c) {
-                    const bool interior = 4 * c >= 4 && 4 * c + 8 <= L.w;
+                if (nr <= 0) continue;
+                for (int c = 0; c < ncol; ++c) {
+                    const bool no_reflection = 4 * c >= 4 && 4 * c + 8 <= L.w;
+                    const bool interior = blur_pieces ? (no_reflection && c >= 16 && c < right0) : no_reflection;
                     if (interior != (pass == 0)) continue;
                     OrbLane ln;
                     ln.x = (uint16_t)(4 * c);
@@ -522,16 +539,12 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
                     ln.nrows = (uint16_t)nr;
                     ln.flags = (uint16_t)((l << 8) | (interior ? 2 : 0));
                     blanes.push_back(ln);
+                    // the right piece is padded to its 16 slots, so that the next row block's left piece starts a piece again
+                    if (blur_pieces && pass == 1 && c == ncol - 1)
+                        while (blanes.size() % 16) blanes.push_back(dead(false));
                 }
             }
-            while (blanes.size() % 64) {  // dead lanes: shadow a column of the wave's kind, output nothing
-                OrbLane d;
-                d.x = (uint16_t)(pass == 0 ? 4 : 0);
-                d.ys = 0;
-                d.nrows = 0;
-                d.flags = (uint16_t)((l << 8) | 1 | (pass == 0 ? 2 : 0));
-                blanes.push_back(d);
-            }
+            while (blanes.size() % 64) blanes.push_back(dead(pass == 0));  // dead lanes: shadow a column of the wave's kind
         }
     }
     P.nbwaves = (int)(blanes.size() / 64);

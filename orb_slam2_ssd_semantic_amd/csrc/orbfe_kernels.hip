@@ -1898,7 +1898,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     // LDS, pattern and moment weights), so the dependent chain of a workgroup is: this, the key, the pixels.
     struct DescLevel { int32_t sel_off, off, pitch; float scale, patch_size; };
     __shared__ DescLevel s_lv[ORBFE_MAX_LEVELS];
+#ifndef DS_GLOBAL_SAMPLES
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[16][DS_PR * DS_PP];
+#endif
     __shared__ uint2 s_momw[31 * 8];
     __shared__ float4 s_pat[256];  // (x0, y0, x1, y1) of every test pair as floats
 #ifdef DS_EXTRA_LDS   // occupancy probe: dead LDS that costs a workgroup slot per CU
@@ -1993,6 +1995,21 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
+#ifdef DS_GLOBAL_SAMPLES
+    // A/B: no LDS patch -- the 512 rotated samples of a keypoint are byte loads straight from the blurred
+    // level (L1 / L2: the XCD placement keeps a frame in one L2).  No bank conflicts, no 24 KB of LDS per workgroup; every
+    // sample is a 64-address gather instead.
+    typedef const __attribute__((address_space(1))) uint8_t *orb_gptr8;
+    orb_gptr8 gcentre;
+    const int bpitch_g = L.pitch;
+    {
+        const uint64_t bb = (uint64_t)(blur + (int64_t)b * blur_fstride);
+        const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bb);
+        const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bb >> 32));
+        gcentre = (orb_gptr8)(((uint64_t)hi32 << 32) | lo32);
+    }
+    const uint32_t ocentre = (uint32_t)L.off + __umul24((uint32_t)y, (uint32_t)bpitch_g) + (uint32_t)x;
+#else
     // ---- C: blurred patch -> LDS ----
     uint8_t *patch = s_patch[quad];
     {
@@ -2034,11 +2051,14 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
         for (int it = 0; it < 23; ++it) *(uint32_t *)(pl + it * 64) = v[it];
         if (sub < 2) *(uint32_t *)(pl + 23 * 64) = v[23];
     }
+#endif
     float a, bb;
     canon_sincos(angle, &a, &bb);
+#ifndef DS_GLOBAL_SAMPLES
     __syncthreads();
-    uint32_t bits = 0;
     const uint8_t *pc = patch + 18 * DS_PP + 18;
+#endif
+    uint32_t bits = 0;
     // rotated sample positions (:100-106): row = cvRound(x*b + y*a), col = cvRound(x*a - y*b), every product and sum
     // rounded separately.  Two coordinates per packed-fp32 instruction; x*a - y*b == x*a + y*(-b) exactly.
     // cvRound by the 1.5 * 2^23 trick: the fp32 add rounds to the nearest integer, ties to even, and leaves it in
@@ -2052,7 +2072,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
         const orb_f2 p1 = orb_f2{pt.z, pt.z} * ba + orb_f2{pt.w, pt.w} * anb + magic;
         const int r0 = (int)(short)__float_as_int(p0.x), c0 = __float_as_int(p0.y) - 0x4B400000;
         const int r1 = (int)(short)__float_as_int(p1.x), c1 = __float_as_int(p1.y) - 0x4B400000;
+#ifdef DS_GLOBAL_SAMPLES
+        const int t0 = gcentre[ocentre + (uint32_t)(__mul24(r0, bpitch_g) + c0)], t1 = gcentre[ocentre + (uint32_t)(__mul24(r1, bpitch_g) + c1)];
+#else
         const int t0 = pc[r0 * DS_PP + c0], t1 = pc[r1 * DS_PP + c1];
+#endif
         bits |= (uint32_t)(t0 < t1) << i;
     }
     if (live) {
