@@ -615,7 +615,7 @@ __device__ __forceinline__ void fm_flush(uint2 *slist, int32_t *scnt, const uint
 // pixels all fail the compass test skips the arc evaluation, and an NMS row with no strength in its 3-row
 // neighbourhood skips the NMS / emission block.  Results are identical; on corner-saturated frames the tests only cost.
 // -DFM_WAVES_PER_EU=n caps the kernel's occupancy (A/B: leaving register file to a memory-bound kernel on a side stream)
-#ifdef FM_WAVES_PER_EU
+#if defined(FM_WAVES_PER_EU)
 #define FM_OCC __attribute__((amdgpu_waves_per_eu(FM_WAVES_PER_EU, FM_WAVES_PER_EU)))
 #else
 #define FM_OCC
@@ -630,6 +630,15 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
                                                   unsigned long long *__restrict__ fstat)  // {row steps, arc skips, nms skips} or null
 {
     __shared__ uint2 s_buf[4][FM_BUF];
+#ifdef FM_LDS_CONSTS
+    // Per-lane constants of the row loop (the six half-word masks of the cell seams and the four `ord` column parts) parked in
+    // LDS and re-read where they are used: ten registers less in the kernel's peak live set.  At <= 152 registers three of its
+    // waves leave 56 per SIMD lane -- room for one wave of an HBM-bound kernel (k_pyr_walk: 48) beside them, where 160 leave 32
+    // and nothing fits (A/B in profiles/r04_ab_experiments.json).
+    __shared__ uint4 s_lcm[4][64];   // in01, in23, lv01, lv23
+    __shared__ uint2 s_lcr[4][64];   // rv01, rv23
+    __shared__ uint4 s_lco[4][64];   // ordx[0..3]
+#endif
     extern __shared__ uint32_t s_cf[];  // [4][cf_words]: per-wave bitmap of the level's cells with a survivor above iniTh
     int b = blockIdx.y, bx = blockIdx.x;
     xcd_frame_remap(bx, b);
@@ -680,9 +689,20 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
     auto halves = [](int bits, int j) -> uint32_t {
         return (((bits >> j) & 1) ? 0xFFFFu : 0u) | (((bits >> (j + 1)) & 1) ? 0xFFFF0000u : 0u);
     };
+#ifdef FM_LDS_CONSTS
+    s_lcm[wv][lane] = make_uint4(halves(inside, 0), halves(inside, 2), halves(lvalid, 0), halves(lvalid, 2));
+    s_lcr[wv][lane] = make_uint2(halves(rvalid, 0), halves(rvalid, 2));
+    // the address is laundered through an empty asm at every use, so the loads stay where they are written (a loop-invariant
+    // load would be hoisted back into registers)
+    uint32_t lc_m = (uint32_t)(uintptr_t)&s_lcm[wv][lane], lc_r = (uint32_t)(uintptr_t)&s_lcr[wv][lane], lc_o = (uint32_t)(uintptr_t)&s_lco[wv][lane];
+    typedef uint32_t fm_v4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t fm_v2 __attribute__((ext_vector_type(2)));
+#define FM_LC_LOAD(type, addr) ({ asm volatile("" : "+v"(addr)); *(const __attribute__((address_space(3))) type *)(uintptr_t)(addr); })
+#else
     const uint32_t in01 = halves(inside, 0), in23 = halves(inside, 2);
     const uint32_t lv01 = halves(lvalid, 0), lv23 = halves(lvalid, 2);
     const uint32_t rv01 = halves(rvalid, 0), rv23 = halves(rvalid, 2);
+#endif
     // a cell seam between the two pixels of a pair lets BOTH be NMS survivors; at most one pair of a lane has one
     const bool split01 = (inside & 3) == 3 && !(lvalid & 2), split23 = (inside & 12) == 12 && !(lvalid & 8);
     const bool wave_split = orb_ballot(split01 || split23) != 0ull;
@@ -697,6 +717,9 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
         const int cc = rel / wcell;
         ordx[j] = ((uint32_t)cc << 12) | (uint32_t)(rel - cc * wcell);
     }
+#ifdef FM_LDS_CONSTS
+    s_lco[wv][lane] = make_uint4(ordx[0], ordx[1], ordx[2], ordx[3]);
+#endif
     int rmod = (ys - iy0) % hcell;                                  // y_in_cell of the next NMS row (per lane)
     uint32_t ordy = ((uint32_t)(((ys - iy0) / hcell) * L.ncc) << 12) | ((uint32_t)rmod << 6);
     const uint32_t ord_wrap = ((uint32_t)L.ncc << 12) - ((uint32_t)hcell << 6);  // added when a new cell row starts
@@ -746,6 +769,10 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
                 const bool rowok = (uint32_t)(ysrel + s) < hrange;  // iy0 <= rc < iy1
                 const uint32_t tt = rowok ? tzz : 0x03FF03FFu;
                 bool arcs = true;
+#ifdef FM_LDS_CONSTS
+                const fm_v4 lcm = FM_LC_LOAD(fm_v4, lc_m);
+                const uint32_t in01 = lcm.x, in23 = lcm.y;
+#endif
                 if (SPARSE) {
                     const uint32_t p = (fast_compass_pair<0>(rm3, r0, rp3, tt) & in01) |
                                        (fast_compass_pair<2>(rm3, r0, rp3, tt) & in23);
@@ -776,6 +803,11 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
                     continue;
                 }
             }
+#ifdef FM_LDS_CONSTS
+            const fm_v4 lcn = FM_LC_LOAD(fm_v4, lc_m);
+            const fm_v2 lcr = FM_LC_LOAD(fm_v2, lc_r);
+            const uint32_t lv01 = lcn.z, lv23 = lcn.w, rv01 = lcr.x, rv23 = lcr.y;
+#endif
             const uint32_t u01 = up_ok ? S01[ku] : 0u, u23 = up_ok ? S23[ku] : 0u;
             const uint32_t d01 = dn_ok ? S01[k] : 0u, d23 = dn_ok ? S23[k] : 0u;
             const uint32_t m01 = S01[km], m23 = S23[km];
@@ -797,6 +829,10 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
             const unsigned long long b01 = orb_ballot(g01 != 0u) & brow, b23 = orb_ballot(g23 != 0u) & brow;
             const bool has01 = row_out && g01 != 0u, has23 = row_out && g23 != 0u;
             if (b01 | b23) {
+#ifdef FM_LDS_CONSTS
+                const fm_v4 lco = FM_LC_LOAD(fm_v4, lc_o);
+                const uint32_t ordx[4] = {lco.x, lco.y, lco.z, lco.w};
+#endif
                 const uint32_t keyrow = key00 + ((uint32_t)s << 12);
                 const int p01 = __popcll(b01);
                 if (has01) {
