@@ -26,3 +26,22 @@ st = e.stage_ms()
 e.set_profiling(False)
 print("host-to-host ms: median %.4f  p10 %.4f  p90 %.4f" % (np.median(lat) * 1e3, np.percentile(lat, 10) * 1e3, np.percentile(lat, 90) * 1e3))
 print("stage event intervals (ms):", {k: round(v, 4) for k, v in st.items()})
+
+# The C++ shim itself, called the way the reference's Frame calls it (oracle/_ref/libshim_ext.so = shim/ORBextractor.cc +
+# the reference's sliced Frame::ExtractORB): with the reference's semantics (mvImagePyramid refreshed by every call, the
+# shim's default) and with mbKeepPyramid = false (mono / RGB-D opt-out: no pyramid download).
+try:
+    from oracle import ref_ffi as R
+    s = R.ShimExtractor(int(os.environ.get("NF", "1000")), 1.2, 8, 20, 7)
+    for keep in (True, False):
+        for _ in range(20):
+            s.extract_via_frame(img, keep_pyramid=keep)
+        lat = []
+        for _ in range(200):
+            t = time.perf_counter()
+            s.extract_via_frame(img, keep_pyramid=keep)
+            lat.append(time.perf_counter() - t)
+        print("C++ shim operator() via Frame::ExtractORB, mbKeepPyramid = %-5s: median %.4f ms  p10 %.4f  p90 %.4f"
+              % (keep, np.median(lat) * 1e3, np.percentile(lat, 10) * 1e3, np.percentile(lat, 90) * 1e3))
+except Exception as ex:  # the shim libraries are test infrastructure: absent -> only the ctypes figure above
+    print("C++ shim probe skipped:", ex)
