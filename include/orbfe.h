@@ -151,6 +151,11 @@ orbfe_status orbfe_synchronize(orbfe_handle *h);
 orbfe_status orbfe_get_level_size(const orbfe_handle *h, int32_t level, int32_t *w, int32_t *ht);
 orbfe_status orbfe_get_pyramid_level(orbfe_handle *h, int32_t frame, int32_t level, uint8_t *dst,
                                      int32_t dst_stride, int32_t with_border);
+/* The same for ALL levels in one go -- the public mvImagePyramid of the reference (src/ORBextractor.cc:1128-1142): level l of
+ * frame `frame` with its 19-px BORDER_REFLECT_101 frame as a (w_l + 38) x (h_l + 38) block with tight rows (pitch w_l + 38)
+ * at offsets[l] of dst (blocks back to back, each offset a multiple of 64); *total = bytes needed.  dst == NULL: sizes only.
+ * One kernel + ONE device-to-host copy (dst may be pageable).  offsets [nlevels] and total may be NULL. */
+orbfe_status orbfe_get_pyramid_padded(orbfe_handle *h, int32_t frame, uint8_t *dst, size_t cap, size_t *offsets, size_t *total);
 
 /* ---- stage taps of the last extract call (parity tests / debugging; host copies) ---- */
 /* 7x7 sigma-2 blurred level (the private clone of src/ORBextractor.cc:1094-1095) */

@@ -39,7 +39,7 @@ SYMBOLS = (
     "orbfe_group_world", "orbfe_group_capacity", "orbfe_group_frames_padded", "orbfe_group_block_index", "orbfe_group_extract_batch",
     "orbfe_group_extract_shard_device", "orbfe_group_allgather", "orbfe_group_synchronize", "orbfe_group_blocks", "orbfe_group_get_frame",
     "orbfe_group_match", "orbfe_group_match_device", "orbfe_group_owner_rank", "orbfe_group_block_index_of",
-    "orbfe_group_create_local_ex", "orbfe_group_members", "orbfe_group_transport", "orbfe_group_get_frame_from", "orbfe_group_get_counts", "orbfe_assign_grid_host", "orbfe_project_points", "orbfe_proj_queries_local_map", "orbfe_rotation_consistency",
+    "orbfe_group_create_local_ex", "orbfe_group_members", "orbfe_group_transport", "orbfe_group_get_frame_from", "orbfe_group_get_counts", "orbfe_assign_grid_host", "orbfe_get_pyramid_padded", "orbfe_project_points", "orbfe_proj_queries_local_map", "orbfe_rotation_consistency",
     "orbfe_initialization_resolve",
 )
 
@@ -102,6 +102,7 @@ def lib():
     L.orbfe_matcher_get_stream.restype = vp
     L.orbfe_get_level_size.argtypes = [vp, i32, vp, vp]
     L.orbfe_get_pyramid_level.argtypes = [vp, i32, i32, vp, i32, i32]
+    L.orbfe_get_pyramid_padded.argtypes = [vp, i32, vp, sz, vp, vp]
     L.orbfe_tap_blurred_level.argtypes = [vp, i32, i32, vp, i32]
     L.orbfe_tap_candidates.argtypes = [vp, i32, i32, vp, i32, vp]
     L.orbfe_tap_selected.argtypes = [vp, i32, i32, vp, i32, vp]

@@ -66,6 +66,8 @@ struct OrbPyrView {
     int64_t fstride[ORBFE_MAX_LEVELS];  // bytes from a level of one frame of the batch to the same level of the next
     int32_t nframes;                    // frames in the handle's last batch
 };
+// all levels of one frame with their REFLECT_101 frame of ORBFE_EDGE pixels, packed at off[l] (off[nlevels] = total bytes)
+hipError_t orbk_launch_pad_pyramid(const OrbPyrView &v, const uint32_t *off, uint8_t *d_out, hipStream_t st);
 struct orbfe_handle;
 // fills `v` for frame `frame` of the last batch and waits for the handle's own stream; ORBFE_ERR_STATE before any call
 int32_t orbfe_internal_pyramid_view(orbfe_handle *h, int frame, OrbPyrView *v);

@@ -2135,6 +2135,58 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K6  the padded pyramid of ONE frame, all levels in one launch: level l as a (w + 2E) x (h + 2E) block with the
+// BORDER_REFLECT_101 frame copyMakeBorder gives it (src/ORBextractor.cc:1136-1142), rows tight (pitch w + 2E), levels back to
+// back at pad_off[l] -- the memory shape of the reference's public mvImagePyramid, produced for one device-to-host copy.
+// One thread per 4 output bytes.
+// ---------------------------------------------------------------------------------------------------
+struct PadArgs {
+    const uint8_t *src[ORBFE_MAX_LEVELS];
+    int32_t pitch[ORBFE_MAX_LEVELS], w[ORBFE_MAX_LEVELS], h[ORBFE_MAX_LEVELS];
+    uint32_t off[ORBFE_MAX_LEVELS + 1];   // byte offset of a level's block in the output, off[nlevels] = total (multiples of 4)
+    int32_t nlevels;
+};
+__global__ __launch_bounds__(256) void k_pad_pyramid(PadArgs a, uint8_t *__restrict__ out)
+{
+    const uint32_t o = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (o >= a.off[a.nlevels]) return;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < ORBFE_MAX_LEVELS; ++k)
+        if (k < a.nlevels && o >= a.off[k]) l = k;
+    const int W = a.w[l], H = a.h[l], PW = W + 2 * ORBFE_EDGE;
+    const uint32_t rel = o - a.off[l], total = (uint32_t)PW * (uint32_t)(H + 2 * ORBFE_EDGE);
+    uint32_t word = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t r = rel + (uint32_t)j;
+        if (r < total) {   // a block's byte count need not be a multiple of 4: the slack up to the next block stays zero
+            const int py = (int)(r / (uint32_t)PW), px = (int)(r - (uint32_t)py * (uint32_t)PW);
+            const int sy = reflect101(py - ORBFE_EDGE, H), sx = reflect101(px - ORBFE_EDGE, W);
+            word |= (uint32_t)a.src[l][(int64_t)sy * a.pitch[l] + sx] << (8 * j);
+        }
+    }
+    *(uint32_t *)(out + o) = word;
+}
+
+hipError_t orbk_launch_pad_pyramid(const OrbPyrView &v, const uint32_t *off, uint8_t *d_out, hipStream_t st)
+{
+    PadArgs a;
+    a.nlevels = v.nlevels;
+    for (int l = 0; l < v.nlevels; ++l) {
+        a.src[l] = v.ptr[l];
+        a.pitch[l] = v.pitch[l];
+        a.w[l] = v.w[l];
+        a.h[l] = v.h[l];
+        a.off[l] = off[l];
+    }
+    a.off[v.nlevels] = off[v.nlevels];
+    const uint32_t nthreads = (off[v.nlevels] + 3u) / 4u;
+    hipLaunchKernelGGL(k_pad_pyramid, dim3((nthreads + 255u) / 256u), dim3(256), 0, st, a, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------------------------
 static FrameSrc make_src(const OrbLaunch &a)

@@ -144,6 +144,20 @@ class ORBextractor:
               "orbfe_get_pyramid_level")
         return out
 
+    def padded_pyramid(self, frame=0):
+        """every level with its 19-px BORDER_REFLECT_101 frame in ONE device-to-host copy (orbfe_get_pyramid_padded): the memory
+        shape of the reference's public mvImagePyramid; returns the list of (h + 38) x (w + 38) arrays"""
+        off = (C.c_size_t * 16)()
+        total = C.c_size_t()
+        check(self._L.orbfe_get_pyramid_padded(self._h, frame, None, 0, off, C.byref(total)), "orbfe_get_pyramid_padded")
+        buf = np.zeros(total.value, np.uint8)
+        check(self._L.orbfe_get_pyramid_padded(self._h, frame, ptr(buf), total.value, None, None), "orbfe_get_pyramid_padded")
+        out = []
+        for l in range(self.nlevels):
+            w, h = self.level_size(l)
+            out.append(buf[off[l]:off[l] + (w + 38) * (h + 38)].reshape(h + 38, w + 38).copy())
+        return out
+
     @property
     def mvImagePyramid(self):
         return [self.pyramid_level(l) for l in range(self.nlevels)]

@@ -33,9 +33,11 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // The padded pyramid lives on the device.  Mono / RGB-D tracking never reads it; stereo does
-    // (Frame::ComputeStereoMatches, reference src/Frame.cc:649,761-778): set mbKeepPyramid = true there and every
-    // operator() refreshes mvImagePyramid[l] as an ROI of the (w+38)x(h+38) REFLECT_101-padded level.
+    // Reference semantics by default: every operator() leaves mvImagePyramid[l] valid, as an ROI of the (w+38)x(h+38)
+    // REFLECT_101-padded level (src/ORBextractor.cc:1128-1142), so the unchanged stereo Frame::ComputeStereoMatches
+    // (src/Frame.cc:649,761-778) reads what it always read.  The pyramid itself lives on the device; keeping the host copy
+    // costs one kernel + one 1.2 MB device-to-host copy per 640x480 call.  Mono / RGB-D tracking never reads it:
+    // mbKeepPyramid = false after construction skips that (opt-out; SyncImagePyramid() fetches it on demand).
     std::vector<cv::Mat> mvImagePyramid;
     bool mbKeepPyramid = true;
     void SyncImagePyramid();
@@ -58,6 +60,7 @@ private:
     orbfe_handle *mpHandle = nullptr;
     int mPlanW = 0, mPlanH = 0, mLastStatus = 0;
     std::vector<cv::Mat> mvPadded;
+    cv::Mat mPadBlock;  // all padded levels of the last frame, one allocation, one device-to-host copy
     ORBextractor(const ORBextractor &);
     ORBextractor &operator=(const ORBextractor &);
 };

@@ -287,6 +287,19 @@ def test_padded_pyramid_is_reflect101(oracle, ext):
     oe(img)
     for l in (0, 1, 7):
         assert np.array_equal(ext.pyramid_level(l, with_border=True), oracle.copy_make_border101(oe.level(l), 19))
+    # all levels in one device-to-host copy (what the extractor shim's mvImagePyramid is made of)
+    padded = ext.padded_pyramid()
+    for l in range(8):
+        assert np.array_equal(padded[l], oracle.copy_make_border101(oe.level(l), 19)), l
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    e2 = ORBextractor(300, 1.31, 5, 20, 7, max_width=517, max_height=389, max_batch=3)     # odd sizes, frame 2 of a batch
+    frames = np.stack([synth_frame(70 + i, 389, 517) for i in range(3)])
+    e2.extract_batch(frames) if hasattr(e2, "extract_batch") else [e2(f) for f in frames]
+    o2 = oracle.OracleExtractor(300, 1.31, 5, 20, 7)
+    o2(frames[-1])
+    padded = e2.padded_pyramid(frame=2 if hasattr(e2, "extract_batch") else 0)
+    for l in range(5):
+        assert np.array_equal(padded[l], oracle.copy_make_border101(o2.level(l), 19)), l
 
 
 def test_batch_equals_single_and_is_idempotent(oracle, ext):
