@@ -250,6 +250,8 @@ def shimext_lib():
     L.shimext_create.restype = vp
     L.shimext_create.argtypes = [ci, cf, ci, ci, ci]
     L.shimext_destroy.argtypes = [vp]
+    L.shimext_set_blur_rounding.argtypes = [vp, ci]
+    L.shimext_get_blur_rounding.argtypes = [vp]
     L.shimext_extract_via_frame.argtypes = [vp, ci, vp, ci, ci, ci, vp, vp, ci, ci]
     L.shimext_level.argtypes = [vp, ci, ci, vp, ci, vp, vp]
     L.shimext_getters.argtypes = [vp] * 7
@@ -269,6 +271,12 @@ class ShimExtractor:
         if getattr(self, "h", None):
             self.L.shimext_destroy(self.h)
             self.h = None
+
+    def set_blur_rounding(self, mode):
+        self.L.shimext_set_blur_rounding(self.h, int(mode))
+
+    def blur_rounding(self):
+        return self.L.shimext_get_blur_rounding(self.h)
 
     def getters(self):
         n = self.nlevels
@@ -326,6 +334,7 @@ def shimstereo_lib():
         L.shim_st_ext_create.restype = C.c_void_p
         L.shim_st_ext_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         L.shim_st_ext_destroy.argtypes = [C.c_void_p]
+        L.shim_st_ext_set_blur_rounding.argtypes = [C.c_void_p, C.c_int]
         _declare_stereo_frame(L.shim_st_stereo_frame)
         _shimstereo = L
     return _shimstereo

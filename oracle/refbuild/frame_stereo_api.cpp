@@ -56,6 +56,7 @@ void *FS_NAME(ext_create)(int nfeatures, float scale_factor, int nlevels, int in
     return new ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th);
 }
 void FS_NAME(ext_destroy)(void *h) { delete (ORBextractor *)h; }
+void FS_NAME(ext_set_blur_rounding)(void *h, int mode) { ((ORBextractor *)h)->mnBlurRounding = mode; }
 #define FS_ENTER()
 #define FS_LEAVE()
 #endif

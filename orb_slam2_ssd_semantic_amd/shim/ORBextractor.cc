@@ -39,7 +39,7 @@ ORBextractor::~ORBextractor() { orbfe_destroy(mpHandle); }
 
 bool ORBextractor::EnsureHandle(int w, int h)
 {
-    if (mpHandle && w <= mPlanW && h <= mPlanH) return true;
+    if (mpHandle && w <= mPlanW && h <= mPlanH && mPlanBlur == mnBlurRounding) return true;
     orbfe_destroy(mpHandle);
     mpHandle = nullptr;
     orbfe_params p;
@@ -53,6 +53,7 @@ bool ORBextractor::EnsureHandle(int w, int h)
     p.max_height = h > mPlanH ? h : mPlanH;
     p.max_batch = 1;
     p.device = -1;
+    p.blur_rounding = mnBlurRounding;
     mLastStatus = orbfe_create(&p, &mpHandle);
     if (mLastStatus != ORBFE_OK) {
         // The reference has no error path (its operator() cannot fail); a tracker silently fed with empty frames is
@@ -62,6 +63,7 @@ bool ORBextractor::EnsureHandle(int w, int h)
     }
     mPlanW = p.max_width;
     mPlanH = p.max_height;
+    mPlanBlur = mnBlurRounding;
     orbfe_get_scales(mpHandle, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data());
     orbfe_get_features_per_level(mpHandle, mnFeaturesPerLevel.data());
     return true;

@@ -42,6 +42,16 @@ public:
     bool mbKeepPyramid = true;
     void SyncImagePyramid();
 
+    // GaussianBlur's column rounding (SURVEY 9.4 ambiguity A).  The shim stands in for a reference BINARY, and every x86-64
+    // OpenCV <= 3.3 build runs the SSE2 column kernel (SymmColumnVec_32s8u: fp32 sum, cvtps2dq = round half to EVEN on the
+    // columns below width & ~3, half up on the scalar tail): 1 reproduces that, 0 is the generic C++ path's integer formula
+    // (half up everywhere; what an ARM / non-SSE2 build computes and what the C-ABI's zero-initialised params select).  They
+    // differ on about 13 pixels of a 640x480 frame's 8 blurred levels.  Set before the first operator().
+#ifndef ORBFE_SHIM_BLUR_ROUNDING
+#define ORBFE_SHIM_BLUR_ROUNDING 1
+#endif
+    int mnBlurRounding = ORBFE_SHIM_BLUR_ROUNDING;
+
     int LastStatus() const { return mLastStatus; }  // orbfe_status of the last call (the reference has no error path)
     // the C handle, for calls that keep the pyramid on the device (orbfe_stereo_matches); null before the first operator()
     orbfe_handle *handle() const { return mpHandle; }
@@ -58,7 +68,7 @@ protected:
 private:
     bool EnsureHandle(int w, int h);
     orbfe_handle *mpHandle = nullptr;
-    int mPlanW = 0, mPlanH = 0, mLastStatus = 0;
+    int mPlanW = 0, mPlanH = 0, mPlanBlur = -1, mLastStatus = 0;
     std::vector<cv::Mat> mvPadded;
     cv::Mat mPadBlock;  // all padded levels of the last frame, one allocation, one device-to-host copy
     ORBextractor(const ORBextractor &);
