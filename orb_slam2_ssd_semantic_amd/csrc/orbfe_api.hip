@@ -142,7 +142,7 @@ struct orbfe_handle {
     bool plan_valid = false;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
-    DevBuf d_plan, d_tabs, d_flanes, d_blanes;
+    DevBuf d_plan, d_tabs, d_flanes, d_blanes, d_blanesR;
     // per-batch blocks
     DevBuf d_pyr, d_blur, d_skeys, d_scount, d_cflag, d_knode, d_qtbox, d_qtnodes, d_sel, d_nsel, d_nkeys, d_pad;
     // sticky overflow word + FAST sparse-variant statistics: [0] int32 overflow bits, [2..7] 3 x uint64 counters
@@ -178,6 +178,7 @@ struct orbfe_handle {
     // batches that fill the chip (>= 128 frames: 3.71 -> 3.62 ms per 1024 frames, the HBM-bound blur fills the
     // quadtree's idle VALU / memory slots; next to the VALU-bound FAST pass it gains nothing), 0 for small ones
     int overlap = -1;
+    int fuse_blur_pyr = 0;   // 1: blur + pyramid in one chained pass over the levels (ORBFE_FUSE_BLUR_PYR)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -509,6 +510,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     // lone dword into 64 different lines per store: WRITE_SIZE was 1.19x the output, profiles/r04_ab_experiments.json;
     // ORBFE_BLUR_PIECES=0 brings that packing back for the A/B.)
     std::vector<OrbLane> blanes;
+    std::vector<OrbLaneR> blanesR;   // the resize job of every blur lane (fused blur + pyramid pass), same index
     const bool blur_pieces = !(getenv("ORBFE_BLUR_PIECES") && atoi(getenv("ORBFE_BLUR_PIECES")) == 0);
     for (int l = 0; l < nl; ++l) {
         const OrbLevel &L = P.lv[l];
@@ -517,6 +519,31 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         const int ncol = (L.w + 3) / 4, nblk = (L.h + brb - 1) / brb, rb = (L.h + nblk - 1) / nblk;
         // first column of the 64-byte piece that holds the first column whose window reaches past the row's right end
         const int right0 = (std::min(ncol - 1, std::max(0, (L.w - 8) / 4 + 1)) / 16) * 16;
+        P.bwave_off[l] = (int)(blanes.size() / 64);
+        // fused blur + pyramid pass: destination dword j of level l + 1 is carried by the blur lane of source column
+        // floor(j * ncol / ncolD) (injective: the level shrinks), i.e. by a lane whose blur window lies over its source pixels
+        std::vector<int> dword_of_col((size_t)ncol, -1);
+        if (l + 1 < nl) {
+            const int ncolD = (P.lv[l + 1].w + 3) / 4;
+            for (int j = 0; j < ncolD; ++j) {
+                const int c = std::min(ncol - 1, (int)((int64_t)j * ncol / ncolD));
+                if (dword_of_col[(size_t)c] >= 0) { orbfe_set_error("level %d: two destination dwords on one blur column", l); return ORBFE_ERR_SIZE; }
+                dword_of_col[(size_t)c] = j;
+            }
+        }
+        auto resize_job = [&](int c, int ys, int nr) {
+            OrbLaneR r = {0, 0, 0, 0};
+            if (l + 1 >= nl || c < 0 || dword_of_col[(size_t)c] < 0 || nr <= 0) return r;
+            const OrbLevel &D = P.lv[l + 1];
+            int d0 = 0;
+            while (d0 < D.h && tabs[(size_t)D.ytab + d0].s < ys) ++d0;          // first destination row whose upper source row is in the block
+            int d1 = d0;
+            while (d1 < D.h && tabs[(size_t)D.ytab + d1].s < ys + nr) ++d1;
+            r.dj = (uint16_t)dword_of_col[(size_t)c];
+            r.d0 = (uint16_t)d0;
+            r.nd = (uint16_t)(d1 - d0);
+            return r;
+        };
         auto dead = [&](bool interior_wave) {
             OrbLane d;
             d.x = (uint16_t)(interior_wave ? 4 : 0);
@@ -539,13 +566,15 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
                     ln.nrows = (uint16_t)nr;
                     ln.flags = (uint16_t)((l << 8) | (interior ? 2 : 0));
                     blanes.push_back(ln);
+                    blanesR.push_back(resize_job(c, ys, nr));
                     // the right piece is padded to its 16 slots, so that the next row block's left piece starts a piece again
                     if (blur_pieces && pass == 1 && c == ncol - 1)
-                        while (blanes.size() % 16) blanes.push_back(dead(false));
+                        while (blanes.size() % 16) { blanes.push_back(dead(false)); blanesR.push_back(resize_job(-1, 0, 0)); }
                 }
             }
-            while (blanes.size() % 64) blanes.push_back(dead(pass == 0));  // dead lanes: shadow a column of the wave's kind
+            while (blanes.size() % 64) { blanes.push_back(dead(pass == 0)); blanesR.push_back(resize_job(-1, 0, 0)); }  // dead lanes: shadow a column of the wave's kind
         }
+        P.bwave_off[l + 1] = (int)(blanes.size() / 64);
     }
     P.nbwaves = (int)(blanes.size() / 64);
     if (P.ini_th < P.min_th) {
@@ -557,6 +586,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(h->d_tabs.ensure(tabs.size() * sizeof(OrbTab)));
     ORBFE_HIP(h->d_flanes.ensure(std::max<size_t>(flanes.size(), 1) * sizeof(OrbLane)));
     ORBFE_HIP(h->d_blanes.ensure(std::max<size_t>(blanes.size(), 1) * sizeof(OrbLane)));
+    ORBFE_HIP(h->d_blanesR.ensure(std::max<size_t>(blanesR.size(), 1) * sizeof(OrbLaneR)));
     // synchronous copies: plans change rarely (frame size change), never inside the timed region.  Earlier batches may
     // still be in flight on the handle's stream or on the caller's stream of the previous device call: both are drained
     // before the plan tables they read are overwritten.
@@ -568,6 +598,8 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         ORBFE_HIP(hipMemcpy(h->d_flanes.p, flanes.data(), flanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     if (!blanes.empty())
         ORBFE_HIP(hipMemcpy(h->d_blanes.p, blanes.data(), blanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
+    if (!blanesR.empty())
+        ORBFE_HIP(hipMemcpy(h->d_blanesR.p, blanesR.data(), blanesR.size() * sizeof(OrbLaneR), hipMemcpyHostToDevice));
     ORBFE_HIP(orbk_prepare_octree(M, P.max_nini, P.w, P.h, P.max_ncells));
     h->plan = P;
     h->fast_row_steps = fast_row_steps;
@@ -704,6 +736,7 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
             return fail(ORBFE_ERR_HIP);
         }
     if (const char *e = getenv("ORBFE_OVERLAP")) h->overlap = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("ORBFE_FUSE_BLUR_PYR")) h->fuse_blur_pyr = atoi(e) != 0;
     int umax[16];
     host_umax(umax);
     if (orbk_upload_constants(umax) != hipSuccess) {
@@ -729,7 +762,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_cflag, &h->d_knode, &h->d_qtbox, &h->d_qtnodes, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_pad,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_blanesR, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_cflag, &h->d_knode, &h->d_qtbox, &h->d_qtnodes, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_pad,
                       &h->d_stage[0], &h->d_okps[0], &h->d_odesc[0], &h->d_on[0], &h->d_stage[1], &h->d_okps[1], &h->d_odesc[1], &h->d_on[1]};
     for (DevBuf *b : bufs) b->release();
     h->d_misc.release();
@@ -890,6 +923,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_tabs = (const OrbTab *)h->d_tabs.p;
     a.d_flanes = (const OrbLane *)h->d_flanes.p;
     a.d_blanes = (const OrbLane *)h->d_blanes.p;
+    a.d_blanesR = (const OrbLaneR *)h->d_blanesR.p;
     a.nframes = nframes;
     a.d_gray = d_gray;
     a.gray_fstride = (int64_t)frame_stride;
@@ -921,6 +955,36 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     if (h->last_stream_valid && h->last_stream != st) ORBFE_HIP(hipStreamWaitEvent(st, h->ev_last, 0));
     hipEvent_t *ev = h->profiling ? h->ev[h->prof_calls % ORBFE_PROF_RING] : nullptr;
     if (ev) ORBFE_HIP(hipEventRecord(ev[0], st));
+    if (h->fuse_blur_pyr) {
+        // blur(l) and resize(l -> l + 1) in one pass over level l, chained over the levels: level l is read from HBM once for
+        // both.  The stage table then shows the fused chain under "pyramid" and nothing under "blur".
+        ORBFE_HIP(orbk_launch_blur_pyr(a, st));
+        if (ev) {
+            ORBFE_HIP(hipEventRecord(ev[1], st));
+            ORBFE_HIP(hipEventRecord(ev[6], st));
+            ORBFE_HIP(hipEventRecord(ev[7], st));
+        }
+        ORBFE_HIP(orbk_launch_fast(a, st));
+        if (ev) ORBFE_HIP(hipEventRecord(ev[2], st));
+        ORBFE_HIP(orbk_launch_octree(a, st));
+        if (ev) {
+            ORBFE_HIP(hipEventRecord(ev[3], st));
+            ORBFE_HIP(hipEventRecord(ev[4], st));
+        }
+        ORBFE_HIP(orbk_launch_describe(a, st));
+        if (ev) {
+            ORBFE_HIP(hipEventRecord(ev[5], st));
+            h->prof_calls++;
+        }
+        ORBFE_HIP(hipEventRecord(h->ev_last, st));
+        h->last_stream = st;
+        h->last_stream_valid = true;
+        h->last_gray = d_gray;
+        h->last_gray_fstride = (int64_t)frame_stride;
+        h->last_gray_pitch = stride;
+        h->last_nframes = nframes;
+        return ORBFE_OK;
+    }
     ORBFE_HIP(orbk_launch_pyramid(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[1], st));
     const int ov = h->overlap >= 0 ? h->overlap : (nframes >= 128 ? 2 : 0);

@@ -88,6 +88,13 @@ struct OrbLane {
     uint16_t flags;  // bit 0: halo (computes, does not output); bits 8..15: level
 };
 
+// the resize job a blur lane carries in the fused blur + pyramid pass: one destination dword of the next level
+struct OrbLaneR {
+    uint16_t dj;      // destination dword (4 pixels) of level l + 1
+    uint16_t d0, nd;  // destination rows [d0, d0 + nd): those whose upper source row lies in the lane's row block; nd = 0: none
+    uint16_t pad;
+};
+
 struct OrbPlan {
     int32_t nlevels;
     int32_t w, h;              // level-0 size this plan was built for
@@ -103,6 +110,7 @@ struct OrbPlan {
     int32_t dbg;               // developer knob (ORBFE_DEBUG env), 0 in production; 50 = quadtree streaming passes only
     int32_t nfwaves;           // FAST waves per frame (64 lane descriptors each)
     int32_t nbwaves;           // blur waves per frame (64 lane descriptors each)
+    int32_t bwave_off[ORBFE_MAX_LEVELS + 1];  // first blur wave of every level (the lanes of a level are contiguous)
     int64_t pyr_frame_bytes;   // bytes of one frame's pyramid slice (levels 1..n-1; level 0 kept too when owned)
     OrbLevel lv[ORBFE_MAX_LEVELS];
 };

@@ -9,6 +9,7 @@ struct OrbLaunch {
     const OrbTab *d_tabs;
     const OrbLane *d_flanes;
     const OrbLane *d_blanes;
+    const OrbLaneR *d_blanesR;   // the resize job of every blur lane (fused blur + pyramid pass)
     int32_t nframes;
     // input frames (level 0, read in place)
     const uint8_t *d_gray;
@@ -55,6 +56,8 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st);
+// blur of every level and the pyramid in one chained pass (replaces orbk_launch_pyramid + orbk_launch_blur)
+hipError_t orbk_launch_blur_pyr(const OrbLaunch &a, hipStream_t st);
 hipError_t orbk_launch_describe(const OrbLaunch &a, hipStream_t st);
 
 // device view of the pyramid the handle built in its last call (orbfe_api.hip), for kernels outside the extractor

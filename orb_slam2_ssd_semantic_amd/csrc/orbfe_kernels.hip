@@ -1826,6 +1826,251 @@ __global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
     }
 }
 
+// Blur of level l AND the resize l -> l + 1 in one pass over level l (ORBFE_FUSE_BLUR_PYR, one launch per level, chained).
+// A lane keeps its blur job (a 4-pixel column of a row block, k_blur7's code unchanged) and, in the same row walk, produces
+// one 4-pixel destination dword of level l + 1 for the destination rows whose upper source row lies in its row block
+// (k_pyr_walk's arithmetic unchanged: horizontal sums of every source row formed once, a destination row completes in the
+// step of its lower source row).  The resize part fetches its own unaligned 8-byte window per row -- the rows are the ones
+// the workgroup's blur lanes are loading at that moment, so they come from L1 / L2: level l is read from HBM ONCE for both
+// jobs instead of once by k_pyr_walk and once by k_blur7.  Vertical taps of level l + 1 sit in LDS.
+struct BlurPyrArgs {
+    uint8_t *dst;          // level l + 1, frame 0 (null: last level, blur only)
+    int64_t dst_fstride;
+    int32_t dpitch, dh;
+    const OrbTab *xtab, *ytab;
+    int32_t sw, sh;        // size of level l
+    int32_t wave_lo;       // first wave of level l in the blur lane list
+};
+template <int MODE>
+__global__ BL_BOUNDS void k_blur_pyr(const OrbPlan *__restrict__ plan, FrameSrc fs,
+                                     const OrbLane *__restrict__ lanes, const OrbLaneR *__restrict__ lanesR, int nwaves,
+                                     uint8_t *__restrict__ blur, int64_t blur_fstride, int level, BlurPyrArgs pa)
+{
+    extern __shared__ uint2 s_yt[];   // [dh + 8] of level l + 1: .x = b0 | b1 << 16, .y = sy
+    const bool has_next = pa.dst != nullptr;
+    if (has_next)
+        for (int i = threadIdx.x; i < pa.dh + 8; i += 256) s_yt[i] = ((const uint2 *)pa.ytab)[i];
+    __syncthreads();
+    int b = blockIdx.y, bx = blockIdx.x;
+    xcd_frame_remap(bx, b);
+    const int lane = threadIdx.x & 63;
+    const int t = bx * 4 + (threadIdx.x >> 6);
+    if (t >= nwaves) return;
+    const OrbLane ld = lanes[(int64_t)(pa.wave_lo + t) * 64 + lane];
+    const OrbLevel &L = plan->lv[level];
+    // ---- the resize job of this lane: destination dword dj of level l + 1, destination rows [d, dend) ----
+    const OrbLaneR lr = lanesR[(int64_t)(pa.wave_lo + t) * 64 + lane];
+    const bool has_dst = has_next && lr.nd != 0;
+    const int dj4 = has_dst ? 4 * (int)lr.dj : 0;
+    int d = has_dst ? (int)lr.d0 : 0;
+    const int dend = has_dst ? (int)lr.d0 + (int)lr.nd : 0;
+    uint32_t rsel[4] = {0, 0, 0, 0};
+    orb_u2 rcoef[4];
+    int rsx0 = 0;
+    if (has_next) {
+        const uint4 tx01 = *(const uint4 *)(pa.xtab + dj4), tx23 = *(const uint4 *)(pa.xtab + dj4 + 2);
+        const uint32_t xc[4] = {tx01.x, tx01.z, tx23.x, tx23.z};
+        const int xs[4] = {(int)(short)tx01.y, (int)(short)tx01.w, (int)(short)tx23.y, (int)(short)tx23.w};
+        rsx0 = min(xs[0], pa.sw - 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t o = (uint32_t)min(max(xs[j] - rsx0, 0), 7);
+            rsel[j] = 0x0c000c00u | (min(o + 1u, 7u) << 16) | o;
+            rcoef[j] = __builtin_bit_cast(orb_u2, xc[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rcoef[j] = __builtin_bit_cast(orb_u2, 0u);
+    }
+    uint2 rcur = has_next ? s_yt[d] : make_uint2(0u, 0u);
+    uint8_t *rdst = has_next ? pa.dst + (int64_t)b * pa.dst_fstride : nullptr;
+    int pitch;
+    const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
+    uint8_t *dst = blur + (int64_t)b * blur_fstride + L.off;
+    const int W = L.w, H = L.h;
+    const int x = ld.x, y0 = ld.ys, yend = y0 + ld.nrows;
+    const bool active = !(ld.flags & 1);
+    // wave-uniform by construction (the host packs interior and edge columns into separate waves): no reflected column
+    const bool interior = __builtin_amdgcn_readfirstlane((int)(ld.flags & 2)) != 0;
+    const int vec_w = W & ~3;
+    int nsteps = ld.nrows;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps) + 6;  // wave-uniform
+
+    // window pixel i (0..11) is level column reflect101(x - 4 + i); i = 0 and 11 are never used
+    int srcx[12], lo = W;
+#pragma unroll
+    for (int i = 1; i < 11; ++i) {
+        srcx[i] = reflect101(min(x - 4 + i, W + 2), W);
+        lo = min(lo, srcx[i]);
+    }
+    srcx[0] = srcx[1];
+    srcx[11] = srcx[10];
+    // all ten sources lie in [base, base + 12) (checked on the host for every level width); at the right edge the
+    // window is pulled back so that it ends at the last pixel of the row
+    const int base = interior ? x - 4 : min(lo & ~3, W - 12);
+    uint32_t selA[3], selB[3], mskB[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        selA[d] = selB[d] = mskB[d] = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int bi = min(max(srcx[4 * d + k] - base, 0), 11);  // loaded byte index
+            if (bi < 8) selA[d] |= (uint32_t)bi << (8 * k);           // from {w1:w0}
+            else {
+                selB[d] |= (uint32_t)(bi - 8) << (8 * k);             // from w2
+                mskB[d] |= 0xFFu << (8 * k);
+            }
+        }
+    }
+    const bool full = x + 4 <= W;
+    const int dpitch = L.pitch;
+
+    // Row sums are <= 255 * 257 = 65535, i.e. u16: ring slot k holds, per pixel, the pair (row sum of step s-1, row sum of
+    // step s) as two u16 halves, so the vertical pass is three v_dot2_u32_u16 (pairs of taps) plus one multiply-add
+    // for the newest row instead of seven multiply / add steps.
+    uint32_t S[7][4], Sprev[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Sprev[j] = 0u;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[k][j] = 0u;
+
+    // raw rows are fetched BL_PF steps ahead into the same 7-slot ring, so a wave keeps several rows in flight
+    uint32_t Lr[7][3];
+    // A wave none of whose lanes comes within 3 rows of the level's top or bottom (three of four) walks plain rows: the
+    // offset advances by the pitch, no reflected row index per step.
+    const bool plain_rows = orb_ballot(!(y0 >= 3 && y0 - 3 + nsteps + BL_PF <= H)) == 0ull;
+    uint32_t ro = __umul24((uint32_t)max(y0 - 3, 0), (uint32_t)pitch) + (uint32_t)base;
+    auto fetch = [&](int s, uint32_t (&dst3)[3]) {
+        const uint8_t *row;
+        if (plain_rows) {
+            row = src + ro;
+            ro += (uint32_t)pitch;
+        } else {
+            const int yy = reflect101(min(y0 - 3 + s, H + 2), H);
+            row = src + (__umul24((uint32_t)yy, (uint32_t)pitch) + (uint32_t)base);
+        }
+        dst3[0] = *(const uint32_t *)(row);
+        dst3[1] = *(const uint32_t *)(row + 4);
+        dst3[2] = *(const uint32_t *)(row + 8);
+    };
+#pragma unroll
+    for (int k = 0; k < BL_PF; ++k) fetch(k, Lr[k]);
+    // resize rows: source row of step s is y0 - 3 + s, clamped into the level (the virtual row sh repeats row sh - 1, which is
+    // what cv::resize's clamped second tap reads); same prefetch distance, same 7-slot ring
+    uint2 Rr[7];
+    uint32_t Hp[4] = {0u, 0u, 0u, 0u};
+    auto rfetch = [&](int s, uint2 &q) {
+        const int yy = min(max(y0 - 3 + s, 0), H - 1);
+        q = *(const uint2 *)(src + (__umul24((uint32_t)yy, (uint32_t)pitch) + (uint32_t)rsx0));
+    };
+    if (has_next) {
+#pragma unroll
+        for (int k = 0; k < BL_PF; ++k) rfetch(k, Rr[k]);
+    }
+
+    for (int s0 = 0; s0 < nsteps; s0 += 7) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int s = s0 + k;
+            if (s >= nsteps) break;  // wave-uniform
+            const int yin = y0 - 3 + s;
+            fetch(s + BL_PF, Lr[(k + BL_PF) % 7]);  // rows past the run re-read a valid (reflected / clamped) row
+            if (has_next) {   // wave-uniform (kernel argument)
+                rfetch(s + BL_PF, Rr[(k + BL_PF) % 7]);
+                uint32_t Hs[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    Hs[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, __builtin_amdgcn_perm(Rr[k].y, Rr[k].x, rsel[j])), rcoef[j], 0u, false) >> 4;
+                // destination row d completes in the step whose source row is sy(d) + 1 (sy strictly increasing: at most one per step)
+                const bool emit = d < dend && (int)(short)rcur.y + 1 == yin;
+                const uint32_t rb0 = rcur.x & 0xFFFFu, rb1 = rcur.x >> 16;
+                uint32_t ra[4], rbv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ra[j] = __umul24(rb0, Hp[j]);
+                    rbv[j] = __umul24(rb1, Hs[j]) + 0x20000u;
+                }
+                uint32_t t01, t23;
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t01) : "v"(ra[0]), "v"(rbv[0]));
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t01) : "v"(ra[1]), "v"(rbv[1]));
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t23) : "v"(ra[2]), "v"(rbv[2]));
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t23) : "v"(ra[3]), "v"(rbv[3]));
+                const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t01) >> (orb_u2)(2));
+                const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t23) >> (orb_u2)(2));
+                if (emit) {
+                    *(uint32_t *)(rdst + (__umul24((uint32_t)d, (uint32_t)pa.dpitch) + (uint32_t)dj4)) = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
+                    d += 1;
+                    rcur = s_yt[d];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Hp[j] = Hs[j];
+            }
+            const uint32_t l0 = Lr[k][0], l1 = Lr[k][1], l2 = Lr[k][2];
+            uint32_t w[3] = {l0, l1, l2};
+            if (!interior) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const uint32_t ta = __builtin_amdgcn_perm(l1, l0, selA[d]);
+                    const uint32_t tb = __builtin_amdgcn_perm(l2, l2, selB[d]);
+                    w[d] = (tb & mskB[d]) | (ta & ~mskB[d]);
+                }
+            }
+            // horizontal taps as byte dot products against per-(pixel, dword) weight constants
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t h = 0u;
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    if (blur_hw(j, d) != 0u) h = __builtin_amdgcn_udot4(w[d], blur_hw(j, d), h, false);
+                S[k][j] = Sprev[j] | (h << 16);
+                Sprev[j] = h;
+            }
+            if (s >= 6) {
+                const int y = yin - 3;
+                uint32_t tq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // rows y-3 .. y+3 are steps s-6 .. s: pairs (s-6, s-5), (s-4, s-3), (s-2, s-1) sit in the slots written at
+                    // steps s-5, s-3, s-1; the newest row sum is Sprev
+                    uint32_t acc = __umul24(18u, Sprev[j]) + 32768u;  // v_mad_u32_u24
+                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 2) % 7][j]), __builtin_bit_cast(orb_u2, 0x00220012u), acc, false);
+                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 4) % 7][j]), __builtin_bit_cast(orb_u2, 0x00370031u), acc, false);
+                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 6) % 7][j]), __builtin_bit_cast(orb_u2, 0x00220031u), acc, false);
+                    tq[j] = acc;  // (acc >> 16) = value rounded half-up, <= 257
+                }
+                if (MODE == 1) {
+                    // SSE2 half-even: an exact half (low 16 bits zero) rounds to the even value inside the vectorised part of
+                    // the row.  One pixel in 65536 is an exact half, so the test is one wave-uniform branch on the smallest
+                    // low half of the lane's four sums; the per-pixel correction runs only when some lane has one.
+                    const uint32_t lowmin = min(min(tq[0] & 0xFFFFu, tq[1] & 0xFFFFu), min(tq[2] & 0xFFFFu, tq[3] & 0xFFFFu));
+                    if (orb_ballot(lowmin == 0u) != 0ull) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if ((tq[j] & 0xFFFFu) == 0u && (x + j) < vec_w && (tq[j] & 0x10000u)) tq[j] -= 0x10000u;
+                    }
+                }
+                // (acc >> 16) <= 257: the high halves of two sums side by side, saturate_cast<uchar> as one packed u16 min, then
+                // the four low bytes into one dword
+                const uint32_t h01 = pk_min_u16(__builtin_amdgcn_perm(tq[1], tq[0], 0x07060302u), 0x00FF00FFu);
+                const uint32_t h23 = pk_min_u16(__builtin_amdgcn_perm(tq[3], tq[2], 0x07060302u), 0x00FF00FFu);
+                const uint32_t packed = __builtin_amdgcn_perm(h23, h01, 0x06040200u);
+                if (active && y < yend) {
+                    uint8_t *o = dst + (__umul24((uint32_t)y, (uint32_t)dpitch) + (uint32_t)x);
+                    if (full) {
+                        *(uint32_t *)o = packed;
+                    } else {
+                        for (int j = 0; j < 4 && x + j < W; ++j) o[j] = (uint8_t)(packed >> (8 * j));
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K5  IC_Angle + steered BRIEF + keypoint assembly.  One wave per output slot.
 // ---------------------------------------------------------------------------------------------------
@@ -2364,6 +2609,38 @@ hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st)
     else
         hipLaunchKernelGGL(k_blur7<0>, grid, dim3(256), 0, st, a.d_plan, fs, a.d_blanes, a.h_plan->nbwaves, a.d_blur,
                            a.pyr_fstride);
+    return hipGetLastError();
+}
+
+hipError_t orbk_launch_blur_pyr(const OrbLaunch &a, hipStream_t st)
+{
+    const FrameSrc fs = make_src(a);
+    const int nl = a.h_plan->nlevels;
+    for (int l = 0; l < nl; ++l) {
+        const OrbLevel &S = a.h_plan->lv[l];
+        BlurPyrArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.sw = S.w;
+        pa.sh = S.h;
+        pa.wave_lo = a.h_plan->bwave_off[l];
+        size_t lds = 8;
+        if (l + 1 < nl) {
+            const OrbLevel &D = a.h_plan->lv[l + 1];
+            pa.dst = a.d_pyr + D.off;
+            pa.dst_fstride = a.pyr_fstride;
+            pa.dpitch = D.pitch;
+            pa.dh = D.h;
+            pa.xtab = a.d_tabs + D.xtab;
+            pa.ytab = a.d_tabs + D.ytab;
+            lds = (size_t)(D.h + 8) * sizeof(uint2);
+        }
+        const int nw = a.h_plan->bwave_off[l + 1] - a.h_plan->bwave_off[l];
+        dim3 grid((nw + 3) / 4, a.nframes);
+        if (a.h_plan->blur_rounding == 1)
+            hipLaunchKernelGGL(k_blur_pyr<1>, grid, dim3(256), lds, st, a.d_plan, fs, a.d_blanes, a.d_blanesR, nw, a.d_blur, a.pyr_fstride, l, pa);
+        else
+            hipLaunchKernelGGL(k_blur_pyr<0>, grid, dim3(256), lds, st, a.d_plan, fs, a.d_blanes, a.d_blanesR, nw, a.d_blur, a.pyr_fstride, l, pa);
+    }
     return hipGetLastError();
 }
 
