@@ -552,31 +552,106 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             d.flags = (uint16_t)((l << 8) | 1 | (interior_wave ? 2 : 0));
             return d;
         };
+        const int fuse = h->fuse_blur_pyr;   // 0: blur only, 1: every blur lane carries a resize job, 2: resize jobs in waves of their own
+        auto blur_lane = [&](int c, int ys, int nr, bool interior) {
+            OrbLane ln;
+            ln.x = (uint16_t)(4 * c);
+            ln.ys = (uint16_t)ys;
+            ln.nrows = (uint16_t)nr;
+            ln.flags = (uint16_t)((l << 8) | (interior ? 2 : 0));
+            return ln;
+        };
+        auto is_interior = [&](int c) {
+            const bool no_reflection = 4 * c >= 4 && 4 * c + 8 <= L.w;
+            return blur_pieces ? (no_reflection && c >= 16 && c < right0) : no_reflection;
+        };
+        if (fuse == 2 && l + 1 < nl) {
+            // interior blur waves and resize waves of the same row blocks side by side in the wave list (a workgroup is four
+            // consecutive waves): whichever kind touches a source row second finds it in L1 / L2.  Two queues, whole waves of one
+            // kind are emitted as soon as they fill, so neither kind runs more than a row block ahead of the other.
+            std::vector<OrbLane> qb, qr;
+            std::vector<OrbLaneR> qrr;
+            const int ncolD = (P.lv[l + 1].w + 3) / 4;
+            auto flush = [&](bool all) {
+                while (qb.size() >= 64 || qr.size() >= 64 || (all && (!qb.empty() || !qr.empty()))) {
+                    if (qb.size() >= 64 || (all && !qb.empty())) {
+                        const size_t n = std::min<size_t>(64, qb.size());
+                        blanes.insert(blanes.end(), qb.begin(), qb.begin() + n);
+                        blanesR.insert(blanesR.end(), n, OrbLaneR{0, 0, 0, 0});
+                        qb.erase(qb.begin(), qb.begin() + n);
+                        while (blanes.size() % 64) { blanes.push_back(dead(true)); blanesR.push_back(OrbLaneR{0, 0, 0, 0}); }
+                    }
+                    if (qr.size() >= 64 || (all && !qr.empty())) {
+                        const size_t n = std::min<size_t>(64, qr.size());
+                        blanes.insert(blanes.end(), qr.begin(), qr.begin() + n);
+                        blanesR.insert(blanesR.end(), qrr.begin(), qrr.begin() + n);
+                        qr.erase(qr.begin(), qr.begin() + n);
+                        qrr.erase(qrr.begin(), qrr.begin() + n);
+                        while (blanes.size() % 64) {
+                            OrbLane d;
+                            d.x = 0; d.ys = 0; d.nrows = 0;
+                            d.flags = (uint16_t)((l << 8) | 4 | 1);
+                            blanes.push_back(d);
+                            blanesR.push_back(OrbLaneR{0, 0, 0, 0});
+                        }
+                    }
+                }
+            };
+            for (int k = 0; k < nblk; ++k) {
+                const int ys = k * rb, nr = std::min(rb, L.h - ys);
+                if (nr <= 0) continue;
+                for (int c = 0; c < ncol; ++c)
+                    if (is_interior(c)) qb.push_back(blur_lane(c, ys, nr, true));
+                // the destination rows whose upper source row lies in this row block, for every destination dword
+                OrbLaneR rows = resize_job(0, ys, nr);
+                if (dword_of_col[0] < 0) {   // resize_job wants a column that carries a dword: take the row range from any such column
+                    for (int c = 0; c < ncol; ++c)
+                        if (dword_of_col[(size_t)c] >= 0) { rows = resize_job(c, ys, nr); break; }
+                }
+                for (int j = 0; j < ncolD && rows.nd; ++j) {
+                    OrbLane ln;
+                    ln.x = 0; ln.ys = (uint16_t)ys; ln.nrows = 0;
+                    ln.flags = (uint16_t)((l << 8) | 4);
+                    qr.push_back(ln);
+                    qrr.push_back(OrbLaneR{(uint16_t)j, rows.d0, rows.nd, 0});
+                }
+                flush(false);
+            }
+            flush(true);
+            // border blur waves as in the plain layout
+            for (int k = 0; k < nblk; ++k) {
+                const int ys = k * rb, nr = std::min(rb, L.h - ys);
+                if (nr <= 0) continue;
+                for (int c = 0; c < ncol; ++c) {
+                    if (is_interior(c)) continue;
+                    blanes.push_back(blur_lane(c, ys, nr, false));
+                    blanesR.push_back(OrbLaneR{0, 0, 0, 0});
+                    if (blur_pieces && c == ncol - 1)
+                        while (blanes.size() % 16) { blanes.push_back(dead(false)); blanesR.push_back(OrbLaneR{0, 0, 0, 0}); }
+                }
+            }
+            while (blanes.size() % 64) { blanes.push_back(dead(false)); blanesR.push_back(OrbLaneR{0, 0, 0, 0}); }
+        } else
         for (int pass = 0; pass < 2; ++pass) {  // 0: interior waves, 1: border waves
             for (int k = 0; k < nblk; ++k) {
                 const int ys = k * rb, nr = std::min(rb, L.h - ys);
                 if (nr <= 0) continue;
                 for (int c = 0; c < ncol; ++c) {
-                    const bool no_reflection = 4 * c >= 4 && 4 * c + 8 <= L.w;
-                    const bool interior = blur_pieces ? (no_reflection && c >= 16 && c < right0) : no_reflection;
+                    const bool interior = is_interior(c);
                     if (interior != (pass == 0)) continue;
-                    OrbLane ln;
-                    ln.x = (uint16_t)(4 * c);
-                    ln.ys = (uint16_t)ys;
-                    ln.nrows = (uint16_t)nr;
-                    ln.flags = (uint16_t)((l << 8) | (interior ? 2 : 0));
-                    blanes.push_back(ln);
-                    blanesR.push_back(resize_job(c, ys, nr));
+                    blanes.push_back(blur_lane(c, ys, nr, interior));
+                    blanesR.push_back(fuse == 1 ? resize_job(c, ys, nr) : OrbLaneR{0, 0, 0, 0});
                     // the right piece is padded to its 16 slots, so that the next row block's left piece starts a piece again
                     if (blur_pieces && pass == 1 && c == ncol - 1)
-                        while (blanes.size() % 16) { blanes.push_back(dead(false)); blanesR.push_back(resize_job(-1, 0, 0)); }
+                        while (blanes.size() % 16) { blanes.push_back(dead(false)); blanesR.push_back(OrbLaneR{0, 0, 0, 0}); }
                 }
             }
-            while (blanes.size() % 64) { blanes.push_back(dead(pass == 0)); blanesR.push_back(resize_job(-1, 0, 0)); }  // dead lanes: shadow a column of the wave's kind
+            while (blanes.size() % 64) { blanes.push_back(dead(pass == 0)); blanesR.push_back(OrbLaneR{0, 0, 0, 0}); }  // dead lanes: shadow a column of the wave's kind
         }
         P.bwave_off[l + 1] = (int)(blanes.size() / 64);
     }
     P.nbwaves = (int)(blanes.size() / 64);
+    P.blur_split = h->fuse_blur_pyr == 2;
     if (P.ini_th < P.min_th) {
         orbfe_set_error("iniThFAST (%d) must be >= minThFAST (%d)", P.ini_th, P.min_th);
         return ORBFE_ERR_ARG;
@@ -736,7 +811,7 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
             return fail(ORBFE_ERR_HIP);
         }
     if (const char *e = getenv("ORBFE_OVERLAP")) h->overlap = std::max(0, std::min(2, atoi(e)));
-    if (const char *e = getenv("ORBFE_FUSE_BLUR_PYR")) h->fuse_blur_pyr = atoi(e) != 0;
+    if (const char *e = getenv("ORBFE_FUSE_BLUR_PYR")) h->fuse_blur_pyr = std::max(0, std::min(2, atoi(e)));
     int umax[16];
     host_umax(umax);
     if (orbk_upload_constants(umax) != hipSuccess) {

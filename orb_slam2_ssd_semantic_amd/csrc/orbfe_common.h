@@ -111,6 +111,7 @@ struct OrbPlan {
     int32_t nfwaves;           // FAST waves per frame (64 lane descriptors each)
     int32_t nbwaves;           // blur waves per frame (64 lane descriptors each)
     int32_t bwave_off[ORBFE_MAX_LEVELS + 1];  // first blur wave of every level (the lanes of a level are contiguous)
+    int32_t blur_split;        // the blur lane list also holds resize waves (flag bit 2): k_blur_pyr<., 1>; the plain k_blur7 launch skips them
     int64_t pyr_frame_bytes;   // bytes of one frame's pyramid slice (levels 1..n-1; level 0 kept too when owned)
     OrbLevel lv[ORBFE_MAX_LEVELS];
 };

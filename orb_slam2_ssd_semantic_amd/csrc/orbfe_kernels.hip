@@ -1840,14 +1840,16 @@ struct BlurPyrArgs {
     const OrbTab *xtab, *ytab;
     int32_t sw, sh;        // size of level l
     int32_t wave_lo;       // first wave of level l in the blur lane list
+    int32_t split;         // 1: the resize jobs are in waves of their own (lane flag bit 2), the blur lanes only blur
 };
-template <int MODE>
+template <int MODE, int SPLIT>
 __global__ BL_BOUNDS void k_blur_pyr(const OrbPlan *__restrict__ plan, FrameSrc fs,
                                      const OrbLane *__restrict__ lanes, const OrbLaneR *__restrict__ lanesR, int nwaves,
                                      uint8_t *__restrict__ blur, int64_t blur_fstride, int level, BlurPyrArgs pa)
 {
     extern __shared__ uint2 s_yt[];   // [dh + 8] of level l + 1: .x = b0 | b1 << 16, .y = sy
     const bool has_next = pa.dst != nullptr;
+    const bool inlane = has_next && !SPLIT;   // the lane's own resize job (compiled out of the SPLIT instantiation)
     if (has_next)
         for (int i = threadIdx.x; i < pa.dh + 8; i += 256) s_yt[i] = ((const uint2 *)pa.ytab)[i];
     __syncthreads();
@@ -1858,16 +1860,90 @@ __global__ BL_BOUNDS void k_blur_pyr(const OrbPlan *__restrict__ plan, FrameSrc 
     if (t >= nwaves) return;
     const OrbLane ld = lanes[(int64_t)(pa.wave_lo + t) * 64 + lane];
     const OrbLevel &L = plan->lv[level];
-    // ---- the resize job of this lane: destination dword dj of level l + 1, destination rows [d, dend) ----
     const OrbLaneR lr = lanesR[(int64_t)(pa.wave_lo + t) * 64 + lane];
-    const bool has_dst = has_next && lr.nd != 0;
+    if (SPLIT && __builtin_amdgcn_readfirstlane((int)(ld.flags & 4)) != 0) {
+        // ---- a RESIZE wave (pa.split): k_pyr_walk's walk, one destination dword x a run of destination rows per lane; it sits
+        // in the wave list next to the blur waves of the same source rows, so whichever of the two touches a row second finds it
+        // in L1 / L2 ----
+        int pitch;
+        const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
+        uint8_t *dstn = pa.dst + (int64_t)b * pa.dst_fstride;
+        const int dx0 = 4 * (int)lr.dj, y0 = (int)lr.d0, yend = y0 + (int)lr.nd;
+        const uint4 tx01 = *(const uint4 *)(pa.xtab + dx0), tx23 = *(const uint4 *)(pa.xtab + dx0 + 2);
+        const uint32_t xc[4] = {tx01.x, tx01.z, tx23.x, tx23.z};
+        const int xs[4] = {(int)(short)tx01.y, (int)(short)tx01.w, (int)(short)tx23.y, (int)(short)tx23.w};
+        const int sx0 = min(xs[0], pa.sw - 8);
+        uint32_t sel[4];
+        orb_u2 coef[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t o = (uint32_t)min(max(xs[j] - sx0, 0), 7);
+            sel[j] = 0x0c000c00u | (min(o + 1u, 7u) << 16) | o;
+            coef[j] = __builtin_bit_cast(orb_u2, xc[j]);
+        }
+        uint2 cur = s_yt[y0];
+        const int r0 = (int)(short)cur.y;
+        int nsteps = yend > y0 ? (int)(short)s_yt[yend - 1].y + 2 - r0 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
+        nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+        const uint32_t sp = (uint32_t)pitch;
+        const int rlast = pa.sh - 1;
+        auto fetch = [&](int s, uint2 &q) { q = *(const uint2 *)(src + (__umul24((uint32_t)min(r0 + s, rlast), sp) + (uint32_t)sx0)); };
+        auto hsum = [&](const uint2 &q, uint32_t (&h)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, __builtin_amdgcn_perm(q.y, q.x, sel[j])), coef[j], 0u, false) >> 4;
+        };
+        uint2 raw[4];
+        fetch(0, raw[0]);
+        fetch(1, raw[1]);
+        fetch(2, raw[2]);
+        uint32_t Hp[4];
+        hsum(raw[0], Hp);
+        int d = y0;
+        for (int s0 = 1; s0 < nsteps; s0 += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int s = s0 + k;
+                fetch(s + PW_PF, raw[(k + 1 + PW_PF) % 4]);
+                uint32_t Hs[4];
+                hsum(raw[(k + 1) % 4], Hs);
+                const bool emit = d < yend && (int)(short)cur.y + 1 == r0 + s;
+                const uint32_t b0 = cur.x & 0xFFFFu, b1 = cur.x >> 16;
+                uint32_t va[4], vb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    va[j] = __umul24(b0, Hp[j]);
+                    vb[j] = __umul24(b1, Hs[j]) + 0x20000u;
+                }
+                uint32_t t01, t23;
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t01) : "v"(va[0]), "v"(vb[0]));
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t01) : "v"(va[1]), "v"(vb[1]));
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t23) : "v"(va[2]), "v"(vb[2]));
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t23) : "v"(va[3]), "v"(vb[3]));
+                const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t01) >> (orb_u2)(2));
+                const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t23) >> (orb_u2)(2));
+                if (emit) {
+                    *(uint32_t *)(dstn + (__umul24((uint32_t)d, (uint32_t)pa.dpitch) + (uint32_t)dx0)) = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
+                    d += 1;
+                }
+                cur = s_yt[d];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Hp[j] = Hs[j];
+            }
+        }
+        return;
+    }
+    // ---- the resize job of this lane (in-lane fusion, pa.split == 0): destination dword dj of level l + 1, rows [d, dend) ----
+    const bool has_dst = inlane && lr.nd != 0;
     const int dj4 = has_dst ? 4 * (int)lr.dj : 0;
     int d = has_dst ? (int)lr.d0 : 0;
     const int dend = has_dst ? (int)lr.d0 + (int)lr.nd : 0;
     uint32_t rsel[4] = {0, 0, 0, 0};
     orb_u2 rcoef[4];
     int rsx0 = 0;
-    if (has_next) {
+    if (inlane) {
         const uint4 tx01 = *(const uint4 *)(pa.xtab + dj4), tx23 = *(const uint4 *)(pa.xtab + dj4 + 2);
         const uint32_t xc[4] = {tx01.x, tx01.z, tx23.x, tx23.z};
         const int xs[4] = {(int)(short)tx01.y, (int)(short)tx01.w, (int)(short)tx23.y, (int)(short)tx23.w};
@@ -1882,8 +1958,8 @@ __global__ BL_BOUNDS void k_blur_pyr(const OrbPlan *__restrict__ plan, FrameSrc 
 #pragma unroll
         for (int j = 0; j < 4; ++j) rcoef[j] = __builtin_bit_cast(orb_u2, 0u);
     }
-    uint2 rcur = has_next ? s_yt[d] : make_uint2(0u, 0u);
-    uint8_t *rdst = has_next ? pa.dst + (int64_t)b * pa.dst_fstride : nullptr;
+    uint2 rcur = inlane ? s_yt[d] : make_uint2(0u, 0u);
+    uint8_t *rdst = inlane ? pa.dst + (int64_t)b * pa.dst_fstride : nullptr;
     int pitch;
     const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
     uint8_t *dst = blur + (int64_t)b * blur_fstride + L.off;
@@ -1967,7 +2043,7 @@ __global__ BL_BOUNDS void k_blur_pyr(const OrbPlan *__restrict__ plan, FrameSrc 
         const int yy = min(max(y0 - 3 + s, 0), H - 1);
         q = *(const uint2 *)(src + (__umul24((uint32_t)yy, (uint32_t)pitch) + (uint32_t)rsx0));
     };
-    if (has_next) {
+    if (inlane) {
 #pragma unroll
         for (int k = 0; k < BL_PF; ++k) rfetch(k, Rr[k]);
     }
@@ -1979,7 +2055,7 @@ __global__ BL_BOUNDS void k_blur_pyr(const OrbPlan *__restrict__ plan, FrameSrc 
             if (s >= nsteps) break;  // wave-uniform
             const int yin = y0 - 3 + s;
             fetch(s + BL_PF, Lr[(k + BL_PF) % 7]);  // rows past the run re-read a valid (reflected / clamped) row
-            if (has_next) {   // wave-uniform (kernel argument)
+            if (inlane) {   // wave-uniform (kernel argument); absent from the SPLIT instantiation
                 rfetch(s + BL_PF, Rr[(k + BL_PF) % 7]);
                 uint32_t Hs[4];
 #pragma unroll
@@ -2636,10 +2712,16 @@ hipError_t orbk_launch_blur_pyr(const OrbLaunch &a, hipStream_t st)
         }
         const int nw = a.h_plan->bwave_off[l + 1] - a.h_plan->bwave_off[l];
         dim3 grid((nw + 3) / 4, a.nframes);
-        if (a.h_plan->blur_rounding == 1)
-            hipLaunchKernelGGL(k_blur_pyr<1>, grid, dim3(256), lds, st, a.d_plan, fs, a.d_blanes, a.d_blanesR, nw, a.d_blur, a.pyr_fstride, l, pa);
+        pa.split = a.h_plan->blur_split;
+        const int br = a.h_plan->blur_rounding == 1;
+        if (pa.split && br)
+            hipLaunchKernelGGL((k_blur_pyr<1, 1>), grid, dim3(256), lds, st, a.d_plan, fs, a.d_blanes, a.d_blanesR, nw, a.d_blur, a.pyr_fstride, l, pa);
+        else if (pa.split)
+            hipLaunchKernelGGL((k_blur_pyr<0, 1>), grid, dim3(256), lds, st, a.d_plan, fs, a.d_blanes, a.d_blanesR, nw, a.d_blur, a.pyr_fstride, l, pa);
+        else if (br)
+            hipLaunchKernelGGL((k_blur_pyr<1, 0>), grid, dim3(256), lds, st, a.d_plan, fs, a.d_blanes, a.d_blanesR, nw, a.d_blur, a.pyr_fstride, l, pa);
         else
-            hipLaunchKernelGGL(k_blur_pyr<0>, grid, dim3(256), lds, st, a.d_plan, fs, a.d_blanes, a.d_blanesR, nw, a.d_blur, a.pyr_fstride, l, pa);
+            hipLaunchKernelGGL((k_blur_pyr<0, 0>), grid, dim3(256), lds, st, a.d_plan, fs, a.d_blanes, a.d_blanesR, nw, a.d_blur, a.pyr_fstride, l, pa);
     }
     return hipGetLastError();
 }

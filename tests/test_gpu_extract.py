@@ -511,12 +511,14 @@ def test_side_stream_blur_and_grouped_quadtree_equal_the_inline_single_launch_pa
         assert_same_output(k0[i, :n0[i]].copy().view(KP_DTYPE).reshape(-1), d0[i, :n0[i]], ok, od)
 
 
-def test_fused_blur_and_pyramid_pass_equals_the_separate_kernels(oracle, monkeypatch):
-    """ORBFE_FUSE_BLUR_PYR=1: blur(l) and resize(l -> l + 1) in one chained pass over the levels (k_blur_pyr; measured slower than
-    k_pyr_walk + k_blur7 and therefore off by default) -- same pyramid, same blurred levels, same output,
-    in both blur rounding modes and on odd sizes."""
+@pytest.mark.parametrize("fuse", ["1", "2"])
+def test_fused_blur_and_pyramid_pass_equals_the_separate_kernels(oracle, monkeypatch, fuse):
+    """ORBFE_FUSE_BLUR_PYR: blur(l) and resize(l -> l + 1) in one chained pass over the levels (k_blur_pyr): 1 = every blur lane
+    carries a resize job, 2 = resize jobs in waves of their own beside the blur waves of the same rows.  Neither beats k_pyr_walk
+    + k_blur7 on time, so both are off by default -- same pyramid, same blurred levels, same output, in
+    both blur rounding modes and on odd sizes."""
     from orb_slam2_ssd_semantic_amd import ORBextractor
-    monkeypatch.setenv("ORBFE_FUSE_BLUR_PYR", "1")
+    monkeypatch.setenv("ORBFE_FUSE_BLUR_PYR", fuse)
     for (w, h, nf, nlev, sf, mode) in ((640, 480, 1000, 8, 1.2, 0), (517, 389, 700, 6, 1.3, 1), (333, 271, 400, 4, 1.5, 0)):
         e = ORBextractor(nf, sf, nlev, 20, 7, max_width=w, max_height=h, max_batch=3, blur_rounding=mode)
         frames = [synth_frame(500 + i, h, w, sparse=(i == 1)) for i in range(3)]
