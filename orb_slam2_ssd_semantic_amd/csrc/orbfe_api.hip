@@ -251,6 +251,17 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         const int v = atoi(e);
         if (v >= 8 && v <= 512) rows_per_wave = v;
     }
+    // the FAST and the blur walk can take different run lengths (ORBFE_ROWS_FAST / ORBFE_ROWS_BLUR; A/B in
+    // profiles/r04_ab_experiments.json): a longer run amortises the 8 (FAST) / 6 (blur) halo steps, a shorter one balances better
+    int rows_fast = rows_per_wave, rows_blur = rows_per_wave;
+    if (const char *e = getenv("ORBFE_ROWS_FAST")) {
+        const int v = atoi(e);
+        if (v >= 8 && v <= 512) rows_fast = v;
+    }
+    if (const char *e = getenv("ORBFE_ROWS_BLUR")) {
+        const int v = atoi(e);
+        if (v >= 8 && v <= 512) rows_blur = v;
+    }
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
     int64_t off = 0;
@@ -447,7 +458,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             const OrbLevel &L = P.lv[l];
             const int rows = L.iy1 - ORBFE_EDGE, ncol = (L.ix1 - 16 + 3) / 4;
             if (rows <= 0 || ncol <= 0) continue;
-            const int frb = rows_per_wave;
+            const int frb = rows_fast;
             const int nblk = (rows + frb - 1) / frb, rb = (rows + nblk - 1) / nblk;
             for (int k = 0; k < nblk; ++k) {
                 const int ys = ORBFE_EDGE + k * rb, nr = std::min(rb, L.iy1 - ys);
@@ -515,7 +526,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     for (int l = 0; l < nl; ++l) {
         const OrbLevel &L = P.lv[l];
         if (L.w < 16) { orbfe_set_error("level %d too narrow for the blur kernel", l); return ORBFE_ERR_SIZE; }
-        const int brb = rows_per_wave;
+        const int brb = rows_blur;
         const int ncol = (L.w + 3) / 4, nblk = (L.h + brb - 1) / brb, rb = (L.h + nblk - 1) / nblk;
         // first column of the 64-byte piece that holds the first column whose window reaches past the row's right end
         const int right0 = (std::min(ncol - 1, std::max(0, (L.w - 8) / 4 + 1)) / 16) * 16;

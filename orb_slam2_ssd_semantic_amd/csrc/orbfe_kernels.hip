@@ -2311,6 +2311,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
         if (sub < 7) ((uint32_t *)kp)[sub] = 0u;
         if (sub < 8) ((uint32_t *)dd)[sub] = 0u;
     }
+    // A workgroup whose 16 slots all lie behind the frame's last keypoint has only padding to write (cap is nfeatures + margin:
+    // about 5 of 68 workgroups per frame at 1000 features): done.  Workgroup-uniform, before the second barrier.
+    if (bx * 16 >= total) return;
     const int lv = live ? level : 0;
     const DescLevel L = s_lv[lv];
     uint32_t key = 0;
