@@ -767,6 +767,9 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
         result["cpu_baseline"] = cb
         result["speedup_vs_cpu_1thread"] = round(value / cb["value"], 1)
         result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(w, h, nf)
+        # one process per PHYSICAL core as well (logical CPUs / 2 on these SMT-2 hosts): the all-logical-CPU figure above is the
+        # lower of the two -- the second hardware thread of a core adds contention, not throughput, to this integer code
+        result["cpu_baseline_half_of_logical_cpus"] = cpu_baseline_all_cores(w, h, nf, max_procs=max(1, (os.cpu_count() or 2) // 2))
 
 
 def pcie_leg(eng, d_src, w, h, F, nbatches=48):
