@@ -22,7 +22,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1]
-bench_args = sys.argv[2:] or ["--no-extras", "--launches", "2", "--steps", "4", "--warmup", "2"]
+bench_args = sys.argv[2:] or ["--no-extras", "--launches", "2", "--steps", "4", "--warmup", "2", "--seeds", "32"]   # 32 seeds: made in-process (no worker pool under the profiler)
 cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
 # the per-kernel passes run the step on ONE stream (ORBFE_BENCH_PIPES=1): with the default pipes, kernels of several
 # sub-batches share the CUs and a kernel's begin-to-end interval is not its own duration; the default command gets one more
@@ -105,7 +105,7 @@ shutil.rmtree(os.path.join(OUT, f"{tag}_trace"), ignore_errors=True)
 # the default command: several sub-batches in flight (intervals overlap; Calls and TotalDuration are what to read)
 env_p = dict(os.environ, TMPDIR="/tmp")
 env_p.pop("ORBFE_BENCH_PIPES", None)
-cmd_p = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-extras", "--steps", "4", "--warmup", "2"] if len(sys.argv) <= 2 else cmd
+cmd_p = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-extras", "--steps", "4", "--warmup", "2", "--seeds", "32"] if len(sys.argv) <= 2 else cmd
 d, line_p, _ = rocprof(["--kernel-trace", "--stats"], "trace_pipes", env=env_p, cmd=cmd_p)
 st = glob.glob(os.path.join(d, "*", "*kernel_stats.csv"))
 if st:
