@@ -114,22 +114,44 @@ def regular_vocabulary(k=10, L=6, seed=0, zero_frac=0.0):
 
 
 def _gen_chunk(job):
-    """(generator name, first seed, count, h, w) -> uint8 [count, h, w]; module-level so that worker processes can import it"""
+    """(generator name, first seed, count, h, w) -> uint8 [count, h, w]"""
     gen, seed0, count, h, w = job
     make = synth_frame if gen == "S" else synth_tum_like
     return np.stack([make(seed0 + i, h, w) for i in range(count)])
 
 
 def synth_frames_parallel(gen, n, h, w, seed0, max_procs=64):
-    """n frames gen(seed0 .. seed0 + n - 1), generated by a pool of worker processes (spawned: safe after a GPU runtime has
-    been initialised in the parent).  The frames are exactly synth_frame / synth_tum_like of those seeds."""
+    """n frames gen(seed0 .. seed0 + n - 1), generated by worker PROCESSES started as `python -m ...synth` (plain interpreters
+    that import numpy and this module only -- a multiprocessing pool would re-import the caller's main module, i.e. torch,
+    in every worker; and nothing is forked from a process that has a GPU runtime open).  Each worker writes its chunk as a
+    raw file into a temporary directory.  The frames are exactly synth_frame / synth_tum_like of those seeds."""
     import os
-    from concurrent.futures import ProcessPoolExecutor
-    import multiprocessing as mp
-    procs = max(1, min(max_procs, os.cpu_count() or 1, n))
-    if procs == 1 or n < 64:
+    import subprocess
+    import sys
+    import tempfile
+    world = max(1, int(os.environ.get("WORLD_SIZE", "1")))   # ranks of one node share the host's cores
+    procs = max(1, min(max_procs, (os.cpu_count() or 1) // world, n // 16))
+    if procs == 1:
         return _gen_chunk((gen, seed0, n, h, w))
-    per = -(-n // (procs * 2))
-    jobs = [(gen, seed0 + a, min(per, n - a), h, w) for a in range(0, n, per)]
-    with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as ex:
-        return np.concatenate(list(ex.map(_gen_chunk, jobs)))
+    per = -(-n // procs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = np.empty((n, h, w), np.uint8)
+    with tempfile.TemporaryDirectory(prefix="orbfe_synth_") as td:
+        jobs = []
+        for k, a in enumerate(range(0, n, per)):
+            cnt = min(per, n - a)
+            path = os.path.join(td, f"{k}.raw")
+            p = subprocess.Popen([sys.executable, "-m", "orb_slam2_ssd_semantic_amd.synth", gen, str(seed0 + a), str(cnt), str(h), str(w), path],
+                                 cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", "")))
+            jobs.append((a, cnt, path, p))
+        for a, cnt, path, p in jobs:
+            if p.wait() != 0:
+                raise RuntimeError("frame generator worker failed")
+            out[a:a + cnt] = np.fromfile(path, np.uint8).reshape(cnt, h, w)
+    return out
+
+
+if __name__ == "__main__":   # worker: gen seed0 count h w outfile
+    import sys
+    _g, _s, _c, _h, _w, _o = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    _gen_chunk((_g, _s, _c, _h, _w)).tofile(_o)
