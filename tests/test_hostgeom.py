@@ -55,10 +55,11 @@ def twin_project(R, t, pos, K, bounds, flags, R2=None, t2=None, Ow=None, normal=
         if flags & PJ_NEG_INVZ and iz < 0:
             out.append(None)
             continue
-        if flags & PJ_CHAINED:
-            u, v = F32(F32(fx * pc[0]) * iz) + cx, F32(F32(fy * pc[1]) * iz) + cy
-        else:
-            u, v = F32(fx * F32(pc[0] * iz)) + cx, F32(fy * F32(pc[1] * iz)) + cy
+        with np.errstate(all="ignore"):   # a point at the camera centre: inf * 0
+            if flags & PJ_CHAINED:
+                u, v = F32(F32(fx * pc[0]) * iz) + cx, F32(F32(fy * pc[1]) * iz) + cy
+            else:
+                u, v = F32(fx * F32(pc[0] * iz)) + cx, F32(fy * F32(pc[1] * iz)) + cy
         inside = (not (u < minx or u > maxx or v < miny or v > maxy)) if flags & PJ_CLOSED else (minx <= u < maxx and miny <= v < maxy)
         if not inside:
             out.append(None)
