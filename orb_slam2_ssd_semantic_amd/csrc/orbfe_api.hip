@@ -144,7 +144,7 @@ struct orbfe_handle {
     std::vector<OrbTab> tabs;
     DevBuf d_plan, d_tabs, d_flanes, d_blanes, d_blanesR;
     // per-batch blocks
-    DevBuf d_pyr, d_blur, d_skeys, d_scount, d_cflag, d_knode, d_qtbox, d_qtnodes, d_sel, d_nsel, d_nkeys, d_pad;
+    DevBuf d_pyr, d_blur, d_skeys, d_scount, d_knode, d_qtbox, d_qtnodes, d_sel, d_nsel, d_nkeys, d_pad;
     // sticky overflow word + FAST sparse-variant statistics: [0] int32 overflow bits, [2..7] 3 x uint64 counters
     DevBuf d_misc;
     int fast_mode = 0;            // 0 dense, 1 sparse shortcuts (orbfe_set_fast_mode)
@@ -848,7 +848,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_blanesR, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_cflag, &h->d_knode, &h->d_qtbox, &h->d_qtnodes, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_pad,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_blanesR, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_qtbox, &h->d_qtnodes, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_pad,
                       &h->d_stage[0], &h->d_okps[0], &h->d_odesc[0], &h->d_on[0], &h->d_stage[1], &h->d_okps[1], &h->d_odesc[1], &h->d_on[1]};
     for (DevBuf *b : bufs) b->release();
     h->d_misc.release();
