@@ -2242,7 +2242,13 @@ hipError_t orbk_upload_moment_weights(const int *umax16)
     return hipMemcpyToSymbol(HIP_SYMBOL(c_momw), h, sizeof(h));
 }
 
-__global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restrict__ plan, FrameSrc fs,
+// Keypoints per workgroup (16 lanes each).  The pattern and moment-weight tables (6 KB) are per workgroup and a keypoint's
+// blurred patch takes 1480 B of LDS: 16 keypoints -> 30 KB, 5 workgroups = 80 keypoints per CU; 32 keypoints -> 53 KB, 3
+// workgroups = 96 keypoints per CU (A/B: profiles/r04_ab_experiments.json).
+#ifndef DS_KPW
+#define DS_KPW 16
+#endif
+__global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *__restrict__ plan, FrameSrc fs,
                                                          const uint8_t *__restrict__ blur, int64_t blur_fstride,
                                                          const uint32_t *__restrict__ sel,
                                                          const int32_t *__restrict__ nsel,
@@ -2256,7 +2262,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     struct DescLevel { int32_t sel_off, off, pitch; float scale, patch_size; };
     __shared__ DescLevel s_lv[ORBFE_MAX_LEVELS];
 #ifndef DS_GLOBAL_SAMPLES
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[16][DS_PR * DS_PP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[DS_KPW][DS_PR * DS_PP];
 #endif
     __shared__ uint2 s_momw[31 * 8];
     __shared__ float4 s_pat[256];  // (x0, y0, x1, y1) of every test pair as floats
@@ -2270,7 +2276,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     b = __builtin_amdgcn_readfirstlane(b);  // workgroup-uniform: frame offsets are scalar 64-bit products
     bx = __builtin_amdgcn_readfirstlane(bx);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int sub = lane & 15, quad = tid >> 4;  // quad 0..15 inside the workgroup = one keypoint
+    const int sub = lane & 15, quad = tid >> 4;  // quad 0..DS_KPW-1 inside the workgroup = one keypoint
     int32_t cnt[ORBFE_MAX_LEVELS];
     {
         const int32_t *ns = nsel + b * nl;
@@ -2281,8 +2287,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
         const OrbLevel &Lt = plan->lv[tid];
         s_lv[tid] = DescLevel{Lt.sel_off, Lt.off, Lt.pitch, Lt.scale, Lt.patch_size};
     }
-    for (int i = tid; i < 31 * 8; i += 256) s_momw[i] = c_momw[i];
-    {
+    for (int i = tid; i < 31 * 8; i += DS_KPW * 16) s_momw[i] = c_momw[i];
+    if (tid < 256) {
         const uint32_t pt = ((const uint32_t *)c_pattern)[tid];
         // pair p = 16 * sub + i is stored at [i][sub]: the 16 lanes of a keypoint read consecutive float4s
         s_pat[(tid & 15) * 16 + (tid >> 4)] = make_float4((float)(int8_t)(pt & 0xFF), (float)(int8_t)((pt >> 8) & 0xFF),
@@ -2290,7 +2296,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     }
     __syncthreads();
 
-    const int slot = bx * 16 + quad;
+    const int slot = bx * DS_KPW + quad;
     int level = -1, idx = slot, total = 0;
 #pragma unroll
     for (int l = 0; l < ORBFE_MAX_LEVELS; ++l) {
@@ -2313,7 +2319,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const OrbPlan *__restri
     }
     // A workgroup whose 16 slots all lie behind the frame's last keypoint has only padding to write (cap is nfeatures + margin:
     // about 5 of 68 workgroups per frame at 1000 features): done.  Workgroup-uniform, before the second barrier.
-    if (bx * 16 >= total) return;
+    if (bx * DS_KPW >= total) return;
     const int lv = live ? level : 0;
     const DescLevel L = s_lv[lv];
     uint32_t key = 0;
@@ -2732,8 +2738,8 @@ hipError_t orbk_launch_blur_pyr(const OrbLaunch &a, hipStream_t st)
 hipError_t orbk_launch_describe(const OrbLaunch &a, hipStream_t st)
 {
     const FrameSrc fs = make_src(a);
-    dim3 grid((a.cap + 15) / 16, a.nframes);
-    hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, st, a.d_plan, fs, a.d_blur, a.pyr_fstride, a.d_sel,
+    dim3 grid((a.cap + DS_KPW - 1) / DS_KPW, a.nframes);
+    hipLaunchKernelGGL(k_orient_describe, grid, dim3(DS_KPW * 16), 0, st, a.d_plan, fs, a.d_blur, a.pyr_fstride, a.d_sel,
                        a.d_nsel, a.d_kps, a.d_desc, a.cap, a.d_n_out, a.h_plan->nlevels, a.h_plan->sel_per_frame,
                        a.d_ovf);
     return hipGetLastError();
