@@ -178,6 +178,9 @@ struct orbfe_handle {
     // batches that fill the chip (>= 128 frames: 3.71 -> 3.62 ms per 1024 frames, the HBM-bound blur fills the
     // quadtree's idle VALU / memory slots; next to the VALU-bound FAST pass it gains nothing), 0 for small ones
     int overlap = -1;
+    int fuse_fast_pyr = 0;   // 1 / 2: FAST(l) + resize(l -> l + 1) in one launch per level (ORBFE_FUSE_FAST_PYR; 2 = the two kinds of
+                             // workgroups dealt out proportionally over the grid, 1 = resize workgroups first)
+    int fuse_fast_pyr_levels = ORBFE_MAX_LEVELS;   // levels fused that way; the rest: plain resizes + one FAST launch
     int fuse_blur_pyr = 0;   // 1: blur + pyramid in one chained pass over the levels (ORBFE_FUSE_BLUR_PYR)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -476,9 +479,11 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             return (a.flags >> 8) == (b2.flags >> 8) && a.ys == b2.ys && b2.x == a.x + 4;
         };
         size_t i = 0;
+        for (int l = 0; l <= ORBFE_MAX_LEVELS; ++l) P.fwave_off[l] = -1;
         while (i < stream.size()) {
             const int lvl = stream[i].flags >> 8;
             const size_t w0 = flanes.size();
+            if (P.fwave_off[lvl] < 0) P.fwave_off[lvl] = (int)(w0 / 64);
             if (i > 0 && same_strip(stream[i - 1], stream[i])) {  // continuing a cut strip: left halo first
                 OrbLane hl = stream[i - 1];
                 hl.flags |= 1;
@@ -506,6 +511,10 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         }
     }
     P.nfwaves = (int)(flanes.size() / 64);
+    P.fwave_off[nl] = P.nfwaves;
+    for (int l = ORBFE_MAX_LEVELS; l > nl; --l) P.fwave_off[l] = P.nfwaves;
+    for (int l = nl - 1; l >= 0; --l)
+        if (P.fwave_off[l] < 0) P.fwave_off[l] = P.fwave_off[l + 1];   // a level without FAST rows
     int64_t fast_row_steps = 0;  // wave row steps one frame costs k_fast_map (VALU model of bench.py's roofline)
     for (int wv = 0; wv < P.nfwaves; ++wv) {
         int mx = 0;
@@ -823,6 +832,9 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
         }
     if (const char *e = getenv("ORBFE_OVERLAP")) h->overlap = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("ORBFE_FUSE_BLUR_PYR")) h->fuse_blur_pyr = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("ORBFE_FUSE_FAST_PYR")) h->fuse_fast_pyr = std::max(0, std::min(3, atoi(e)));
+    if (const char *e = getenv("ORBFE_FUSE_FAST_PYR_LEVELS")) h->fuse_fast_pyr_levels = std::max(1, std::min((int)ORBFE_MAX_LEVELS, atoi(e)));
+    if (h->fuse_fast_pyr) h->fuse_blur_pyr = 0;   // one fusion at a time
     int umax[16];
     host_umax(umax);
     if (orbk_upload_constants(umax) != hipSuccess) {
@@ -1071,9 +1083,23 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
         h->last_nframes = nframes;
         return ORBFE_OK;
     }
-    ORBFE_HIP(orbk_launch_pyramid(a, st));
+    // ORBFE_FUSE_FAST_PYR: FAST(l) and resize(l -> l + 1) in one launch per level (k_fast_pyr); the stage table then shows the
+    // whole chain under "fast" and nothing under "pyramid"
+    // ORBFE_FUSE_FAST_PYR=3: no fused kernel -- FAST of level 0, which needs no pyramid, runs on the side stream BESIDE the pyramid
+    // chain (two FAST waves leave room for four resize waves on a SIMD), FAST of the other levels after both
+    const bool ffp = h->fuse_fast_pyr == 1 || h->fuse_fast_pyr == 2;
+    const bool fside = h->fuse_fast_pyr == 3;
+    if (fside) {
+        ORBFE_HIP(orbk_launch_fast_levels(a, 0, 0, 1, st));   // the clear only
+        ORBFE_HIP(hipEventRecord(h->ev_fork, st));
+        ORBFE_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        ORBFE_HIP(orbk_launch_fast_levels(a, 0, 1, 0, h->side));
+        ORBFE_HIP(hipEventRecord(h->ev_join, h->side));
+    }
+    if (!ffp) ORBFE_HIP(orbk_launch_pyramid(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[1], st));
-    const int ov = h->overlap >= 0 ? h->overlap : (nframes >= 128 ? 2 : 0);
+    int ov = h->overlap >= 0 ? h->overlap : (nframes >= 128 ? 2 : 0);
+    if ((ffp || fside) && ov == 1) ov = 2;   // the blur needs the whole pyramid, which the fused chain finishes last
     auto fork_blur = [&]() -> hipError_t {
         hipError_t e = hipEventRecord(h->ev_fork, st);
         if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->ev_fork, 0);
@@ -1084,7 +1110,11 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
         return e;
     };
     if (ov == 1) ORBFE_HIP(fork_blur());
-    ORBFE_HIP(orbk_launch_fast(a, st));
+    if (ffp) ORBFE_HIP(orbk_launch_fast_pyr(a, h->fuse_fast_pyr_levels, h->fuse_fast_pyr == 2, st));
+    else if (fside) {
+        ORBFE_HIP(orbk_launch_fast_levels(a, 1, h->plan.nlevels, 0, st));
+        ORBFE_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    } else ORBFE_HIP(orbk_launch_fast(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[2], st));
     if (ov == 2) ORBFE_HIP(fork_blur());
     ORBFE_HIP(orbk_launch_octree(a, st));

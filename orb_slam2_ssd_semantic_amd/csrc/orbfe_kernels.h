@@ -44,6 +44,10 @@ struct OrbLaunch {
     unsigned long long *d_fstat;
 };
 
+// FAST(l) + resize(l -> l + 1) in one launch per level for the levels below `nfused`, the remaining pyramid levels and one
+// FAST launch over the remaining waves after them (replaces orbk_launch_pyramid + orbk_launch_fast); spread: see k_fast_pyr
+hipError_t orbk_launch_fast_pyr(const OrbLaunch &a, int nfused, int spread, hipStream_t st);
+hipError_t orbk_launch_fast_levels(const OrbLaunch &a, int l0, int l1, int clear, hipStream_t st);
 hipError_t orbk_upload_constants(const int *umax16);
 size_t orbk_octree_lds_bytes(int node_cap, int max_nini, int w, int h, int ncells);
 size_t orbk_octree_box_bytes(int node_cap);

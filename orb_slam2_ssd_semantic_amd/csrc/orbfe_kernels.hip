@@ -137,17 +137,18 @@ struct PyrArgs {
 // vertical taps sit in LDS as well.  The level pitch is a multiple of 64: the last column group stores its whole dword.
 #define PW_PF 2
 #define PW_ROWS 16  // destination rows per lane run (8, 24, 32 measured slower)
-__global__ __launch_bounds__(256) void k_pyr_walk(PyrArgs a)
+// (the body is shared with k_fast_pyr, whose workgroups are either FAST or resize workgroups; bxi / b = the workgroup's index
+// among the resize workgroups of its frame / its frame)
+__device__ __forceinline__ void pyr_walk_body(const PyrArgs &a, const int bxi, const int b)
 {
     extern __shared__ uint2 s_dyn[];
     uint2 *s_yt = s_dyn;                                   // [dh + 8]: .x = b0 | b1 << 16, .y = sy (low half)
     uint32_t *s_out = (uint32_t *)(s_dyn + (a.dh + 8));    // [rb][256]
-    const int b = blockIdx.y;
     const int W = a.dw, H = a.dh;
     for (int i = threadIdx.x; i < H + 8; i += 256) s_yt[i] = ((const uint2 *)a.ytab)[i];
     const int ncol4 = (W + 3) >> 2;
     const int nlanes = ncol4 * a.nrblk;
-    const int fl = min((int)(blockIdx.x * 256 + threadIdx.x), nlanes - 1);  // surplus lanes repeat the last lane's work
+    const int fl = min((int)(bxi * 256 + threadIdx.x), nlanes - 1);  // surplus lanes repeat the last lane's work
     const int rblk = fl / ncol4;
     const int dx0 = (fl - rblk * ncol4) * 4;
     const int y0 = rblk * a.rb, yend = min(y0 + a.rb, H);
@@ -239,6 +240,8 @@ __global__ __launch_bounds__(256) void k_pyr_walk(PyrArgs a)
             if (i0 + i < nrows) *(uint32_t *)(dst + (oofs + (uint32_t)(i0 + i) * (uint32_t)a.dpitch)) = v[i];
     }
 }
+
+__global__ __launch_bounds__(256) void k_pyr_walk(PyrArgs a) { pyr_walk_body(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 // Two levels per launch.  The workgroup owns a tile of level B = l: p2_gx column groups x p2_gy runs of a.rb rows, produced
 // from level A = l - 1 exactly as k_pyr_walk does (same row walk, same arithmetic); the finished tile stays in LDS
@@ -620,14 +623,16 @@ __device__ __forceinline__ void fm_flush(uint2 *slist, int32_t *scnt, const uint
 #else
 #define FM_OCC
 #endif
+// t = the wave's index in the lane list, b = its frame (both wave-uniform); the body is shared by k_fast_map (one launch over
+// the waves of all levels) and k_fast_pyr (one launch per level, resize workgroups beside the FAST workgroups)
 template <int SPARSE>
-__global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restrict__ plan, FrameSrc fs,
-                                                  const OrbLane *__restrict__ lanes, int nwaves,
-                                                  uint2 *__restrict__ skeys,      // [B][keys_per_frame] {key, ord}
-                                                  int32_t *__restrict__ scount,   // [B][nlevels] * NK_STRIDE, zeroed
-                                                  uint32_t *__restrict__ cflags,  // [B][nlevels][cf_words], zeroed
-                                                  int32_t cf_words,
-                                                  unsigned long long *__restrict__ fstat)  // {row steps, arc skips, nms skips} or null
+__device__ __forceinline__ void fast_map_body(const OrbPlan *__restrict__ plan, const FrameSrc &fs,
+                                              const OrbLane *__restrict__ lanes, const int t, const int b,
+                                              uint2 *__restrict__ skeys,      // [B][keys_per_frame] {key, ord}
+                                              int32_t *__restrict__ scount,   // [B][nlevels] * NK_STRIDE, zeroed
+                                              uint32_t *__restrict__ cflags,  // [B][nlevels][cf_words], zeroed
+                                              const int32_t cf_words,
+                                              unsigned long long *__restrict__ fstat)  // {row steps, arc skips, nms skips} or null
 {
     __shared__ uint2 s_buf[4][FM_BUF];
 #ifdef FM_LDS_CONSTS
@@ -640,12 +645,8 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
     __shared__ uint4 s_lco[4][64];   // ordx[0..3]
 #endif
     extern __shared__ uint32_t s_cf[];  // [4][cf_words]: per-wave bitmap of the level's cells with a survivor above iniTh
-    int b = blockIdx.y, bx = blockIdx.x;
-    xcd_frame_remap(bx, b);
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int t = bx * (blockDim.x >> 6) + wv;
-    if (t >= nwaves) return;
     uint32_t *lflag = s_cf + wv * cf_words;
     for (int i = lane; i < cf_words; i += 64) lflag[i] = 0u;  // wave-private: its own DS operations execute in order
     // Work is described per LANE: a 4-pixel column, a run of rows, "halo" (contributes neighbour strengths only).
@@ -879,6 +880,50 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
         atomicAdd(&fstat[1], (unsigned long long)st_arc);
         atomicAdd(&fstat[2], (unsigned long long)st_nms);
     }
+}
+
+template <int SPARSE>
+__global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restrict__ plan, FrameSrc fs,
+                                                  const OrbLane *__restrict__ lanes, int nwaves, uint2 *__restrict__ skeys,
+                                                  int32_t *__restrict__ scount, uint32_t *__restrict__ cflags, int32_t cf_words,
+                                                  unsigned long long *__restrict__ fstat)
+{
+    int b = blockIdx.y, bx = blockIdx.x;
+    xcd_frame_remap(bx, b);
+    const int t = bx * 4 + (int)(threadIdx.x >> 6);
+    if (t >= nwaves) return;
+    fast_map_body<SPARSE>(plan, fs, lanes, t, b, skeys, scount, cflags, cf_words, fstat);
+}
+
+// FAST on level l and cv::resize l -> l + 1 in ONE launch, the launches chained over the levels ("pyramid inside
+// the FAST pass").  FAST's live set leaves no register for a second job in its lanes (157 of the 168 that three waves per SIMD
+// allow), so the fusion is by WORKGROUP ROLE: `npyr` of the launch's workgroups per frame are resize workgroups
+// (k_pyr_walk's walk, unchanged), the others FAST workgroups over the wave range [wave_lo, wave_lo + nwaves) of the lane list.
+// Both read level l, FAST is VALU-bound and the walk HBM-bound, and the two kinds are dealt out proportionally over the block
+// index (spread = 1), so a CU holds both at any time and the second reader of a row finds it in L2; spread = 0 puts the resize
+// workgroups first.  npyr = 0 on the last level.
+template <int SPARSE>
+__global__ __launch_bounds__(256) void k_fast_pyr(const OrbPlan *__restrict__ plan, FrameSrc fs, const OrbLane *__restrict__ lanes,
+                                                  int wave_lo, int nwaves, uint2 *__restrict__ skeys, int32_t *__restrict__ scount,
+                                                  uint32_t *__restrict__ cflags, int32_t cf_words,
+                                                  unsigned long long *__restrict__ fstat, PyrArgs pa, int npyr, int spread)
+{
+    int b = blockIdx.y, bx = blockIdx.x;
+    xcd_frame_remap(bx, b);
+    int before = min(bx, npyr);              // resize workgroups in front of this one
+    bool is_pyr = bx < npyr;
+    if (spread) {
+        const int T = (int)gridDim.x;
+        before = (int)(((uint32_t)bx * (uint32_t)npyr) / (uint32_t)T);
+        is_pyr = (int)(((uint32_t)(bx + 1) * (uint32_t)npyr) / (uint32_t)T) > before;
+    }
+    if (is_pyr) {
+        pyr_walk_body(pa, before, b);
+        return;
+    }
+    const int t = (bx - before) * 4 + (int)(threadIdx.x >> 6);
+    if (t >= nwaves) return;
+    fast_map_body<SPARSE>(plan, fs, lanes, wave_lo + t, b, skeys, scount, cflags, cf_words, fstat);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2622,6 +2667,76 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
     else
         hipLaunchKernelGGL(k_fast_map<0>, grid, dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
                            a.d_scount, a.d_cflag, a.cf_words, (unsigned long long *)nullptr);
+    return hipGetLastError();
+}
+
+static hipError_t fast_clear(const OrbLaunch &a, hipStream_t st)
+{
+    // the survivor counts and, right behind them, the cell flags of this call's frames: one clear
+    const int nl = a.h_plan->nlevels;
+    if ((const char *)a.d_cflag != (const char *)a.d_scount + sizeof(int32_t) * (size_t)a.nframes * nl * ORBFE_NK_STRIDE)
+        return hipErrorInvalidValue;
+    return hipMemsetAsync(a.d_scount, 0, sizeof(int32_t) * (size_t)a.nframes * nl * ORBFE_NK_STRIDE +
+                                             sizeof(uint32_t) * (size_t)a.nframes * nl * a.cf_words, st);
+}
+
+// one k_fast_pyr launch: FAST waves [w0, w1) of the lane list + the resize to level lpyr (0: none)
+static void fast_pyr_one(const OrbLaunch &a, int w0, int w1, int lpyr, int spread, hipStream_t st)
+{
+    const FrameSrc fs = make_src(a);
+    const OrbPlan &P = *a.h_plan;
+    unsigned long long *fstat = a.fast_sparse ? a.d_fstat : (unsigned long long *)nullptr;
+    PyrArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    int npyr = 0;
+    size_t lds = (size_t)a.cf_words * 16;
+    if (lpyr > 0) {
+        pyr_args(a, lpyr, pa);
+        npyr = (((P.lv[lpyr].w + 3) / 4) * pa.nrblk + 255) / 256;
+        lds = std::max(lds, orbk_pyramid_lds_bytes(P.lv[lpyr].h));
+    }
+    dim3 grid((w1 - w0 + 3) / 4 + npyr, a.nframes);
+    if (grid.x == 0) return;
+    if (a.fast_sparse)
+        hipLaunchKernelGGL(k_fast_pyr<1>, grid, dim3(256), lds, st, a.d_plan, fs, a.d_flanes, w0, w1 - w0, a.d_skeys, a.d_scount,
+                           a.d_cflag, a.cf_words, fstat, pa, npyr, spread);
+    else
+        hipLaunchKernelGGL(k_fast_pyr<0>, grid, dim3(256), lds, st, a.d_plan, fs, a.d_flanes, w0, w1 - w0, a.d_skeys, a.d_scount,
+                           a.d_cflag, a.cf_words, fstat, pa, npyr, spread);
+}
+
+hipError_t orbk_launch_fast_pyr(const OrbLaunch &a, int nfused, int spread, hipStream_t st)
+{
+    const OrbPlan &P = *a.h_plan;
+    const int nl = P.nlevels;
+    hipError_t e = fast_clear(a, st);
+    if (e != hipSuccess) return e;
+    nfused = std::max(1, std::min(nfused, nl));
+    for (int l = 0; l < nfused; ++l) fast_pyr_one(a, P.fwave_off[l], P.fwave_off[l + 1], l + 1 < nl ? l + 1 : 0, spread, st);
+    if (nfused < nl) {
+        // levels nfused + 1 .. nl - 1 as plain resize launches, then FAST over all remaining levels in one launch
+        for (int l = nfused + 1; l < nl; ++l) {
+            PyrArgs pa;
+            pyr_args(a, l, pa);
+            const int nlanes = ((P.lv[l].w + 3) / 4) * pa.nrblk;
+            hipLaunchKernelGGL(k_pyr_walk, dim3((nlanes + 255) / 256, a.nframes), dim3(256), orbk_pyramid_lds_bytes(P.lv[l].h), st, pa);
+        }
+        fast_pyr_one(a, P.fwave_off[nfused], P.nfwaves, 0, 0, st);
+    }
+    return hipGetLastError();
+}
+
+// FAST over the levels [l0, l1) of the lane list (no resize workgroups); clear = zero the survivor counts / cell flags first
+hipError_t orbk_launch_fast_levels(const OrbLaunch &a, int l0, int l1, int clear, hipStream_t st)
+{
+    const OrbPlan &P = *a.h_plan;
+    if (clear) {
+        hipError_t e = fast_clear(a, st);
+        if (e != hipSuccess) return e;
+    }
+    l0 = std::max(0, std::min(l0, (int)P.nlevels));
+    l1 = std::max(l0, std::min(l1, (int)P.nlevels));
+    fast_pyr_one(a, P.fwave_off[l0], P.fwave_off[l1], 0, 0, st);
     return hipGetLastError();
 }
 

@@ -532,3 +532,35 @@ def test_fused_blur_and_pyramid_pass_equals_the_separate_kernels(oracle, monkeyp
                 if len(oe.selected(l)):
                     assert np.array_equal(e.blurred_level(l), oe.blurred(l)), (w, l)
             assert_same_output(gk, gd, ok, od)
+
+
+@pytest.mark.parametrize("fuse,levels", [("1", None), ("2", None), ("2", "3"), ("1", "1"), ("3", None)])
+def test_fused_fast_and_pyramid_pass_equals_the_separate_kernels(oracle, monkeypatch, fuse, levels):
+    """ORBFE_FUSE_FAST_PYR ("pyramid inside the FAST pass"): FAST(l) and resize(l -> l + 1) in ONE launch per
+    level (k_fast_pyr), the two jobs in workgroups of their own -- 1 = resize workgroups first, 2 = dealt out proportionally;
+    ORBFE_FUSE_FAST_PYR_LEVELS = k fuses the first k levels only (plain resizes + one FAST launch for the rest); 3 = no fused
+    kernel, FAST of level 0 on the side stream beside the pyramid chain.  Same pyramid,
+    same candidate lists, same output as k_pyr_walk x 7 + k_fast_map, single frames and batches, odd sizes, both FAST variants."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    monkeypatch.setenv("ORBFE_FUSE_FAST_PYR", fuse)
+    if levels:
+        monkeypatch.setenv("ORBFE_FUSE_FAST_PYR_LEVELS", levels)
+    for (w, h, nf, nlev, sf) in ((640, 480, 1000, 8, 1.2), (517, 389, 700, 6, 1.3), (333, 271, 400, 4, 1.5), (128, 112, 100, 3, 1.2)):
+        e = ORBextractor(nf, sf, nlev, 20, 7, max_width=w, max_height=h, max_batch=16)
+        frames = [synth_frame(700 + i, h, w, sparse=(i % 3 == 1)) for i in range(16)]
+        oe = oracle.OracleExtractor(nf, sf, nlev, 20, 7)
+        outs = []
+        for img in frames[:3]:
+            ok, od = oe(img)
+            outs.append((ok, od))
+            gk, gd = e(img)
+            for l in range(nlev):
+                assert np.array_equal(e.pyramid_level(l), oe.level(l)), (w, l)
+            assert_same_output(gk, gd, ok, od)
+        # a batch (a multiple of 8 frames: the frame -> XCD remap of the grid is active) == the single calls
+        res = e.extract_batch(np.stack(frames))
+        for i in (0, 1, 2):
+            gk, gd = res[i]
+            assert_same_output(gk, gd, outs[i][0], outs[i][1])
+        ok, od = oe(frames[15])
+        assert_same_output(res[15][0], res[15][1], ok, od)
