@@ -49,6 +49,7 @@ import torch.distributed as dist  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+CTL = {}   # control-plane process groups of a multi-GPU run (see main) and the `abandon` flag of the guarded group leg
 from orb_slam2_ssd_semantic_amd.distributed import OverlappedKeyframeGather, all_gather_keyframes, shard_range  # noqa: E402
 from orb_slam2_ssd_semantic_amd.synth import regular_vocabulary, synth_frame, synth_frames_parallel, synth_tum_like  # noqa: E402
 
@@ -222,9 +223,16 @@ class HipEngine:
         self.exts = [self.ext] + [ORBextractor(nfeatures, 1.2, 8, 20, 7, max_width=self.w, max_height=self.h, max_batch=self.F,
                                                device=local_rank) for _ in range(self.P - 1)]
         self.pipe_streams = [None] + [torch.cuda.Stream(device=local_rank) for _ in range(self.P - 1)]
+        if os.environ.get("ORBFE_BENCH_PRIO"):   # experiment: stream priorities of the pipes, e.g. "-1,0,1"
+            pr = [int(x) for x in os.environ["ORBFE_BENCH_PRIO"].split(",")]
+            self.pipe_streams = [torch.cuda.Stream(device=local_rank, priority=pr[i % len(pr)]) for i in range(self.P)]
         self.mat = ORBmatcher(0.9, True, device=local_rank)
         self.mats = [self.mat] + [ORBmatcher(0.9, True, device=local_rank) for _ in range(self.P - 1)]
         self.one_pipe = False   # True: everything on pipe 0 (the exclusive stage times of the report)
+        # One GPU: nothing consumes a step's outputs before the timed region's closing fence, and sub-batch j of every step runs on
+        # the same pipe (its slices are stream-ordered), so the pipes are not joined at step boundaries -- 24 sub-batches, then
+        # the next 24, back to back.  With N > 1 the gather consumes every step: the pipes join the current stream at its end.
+        self.free_run = world == 1 and os.environ.get("ORBFE_BENCH_STEP_JOIN", "0") != "1"
         self.cap = self.ext.capacity()
         B = self.F * self.nl
         self.B = B
@@ -270,7 +278,7 @@ class HipEngine:
         lo = j * F
         cur = torch.cuda.current_stream()
         st = self.pipe_streams[p] or cur
-        if j < self.P and st is not cur:
+        if j < self.P and st is not cur and not self.free_run:
             st.wait_stream(cur)   # the step starts after what the current stream held (previous step's consumers)
         self.exts[p].extract_batch_device(d_gray[lo].data_ptr(), F, w, h, w, w * h, kps[lo].data_ptr(), desc[lo].data_ptr(),
                                           self.cap, n[lo:].data_ptr(), st.cuda_stream)
@@ -283,8 +291,11 @@ class HipEngine:
 
     def end_step(self):
         """everything of the step is ordered before what follows on the current stream (gather, the next use of the set)"""
+        if self.free_run:
+            return
         for st in self.pipe_streams[1:]:
-            torch.cuda.current_stream().wait_stream(st)
+            if st is not None:
+                torch.cuda.current_stream().wait_stream(st)
         if self.match and self.match_stream is not None:
             torch.cuda.current_stream().wait_stream(self.match_stream)
 
@@ -392,6 +403,11 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # two CPU-side control groups for the guarded config-4 leg (config4_group_guarded): one for the main thread, one for
+            # the worker thread that drives the library's own RCCL communicator
+            from datetime import timedelta
+            CTL["main"] = dist.new_group(backend="gloo", timeout=timedelta(seconds=900))
+            CTL["leg"] = dist.new_group(backend="gloo", timeout=timedelta(seconds=300))
     dev = "cpu" if fake else "cuda"
 
     def fence():
@@ -511,7 +527,10 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), one process per GPU",
                        "streams": (f"{eng.P} extractor / matcher handle pairs on {eng.P} streams, sub-batch j on pipe j mod {eng.P}: the "
                                    "VALU-bound FAST pass of one sub-batch shares the chip with the HBM / LDS-bound stages of its "
-                                   "neighbours (ORBFE_BENCH_PIPES)" if getattr(eng, "P", 1) > 1 else
+                                   "neighbours (ORBFE_BENCH_PIPES)" + ("; the pipes run the K steps back to back, joined by the closing "
+                                   "fence only (one GPU: no consumer between steps)" if getattr(eng, "free_run", False) else
+                                   "; the pipes join the launch stream at the end of every step (the gather consumes it)")
+                                   if getattr(eng, "P", 1) > 1 else
                                    "extractor on the launch stream (blur on the library's side stream), matcher of sub-batch j on a "
                                    "second stream behind an event, next to the pyramid of sub-batch j+1"
                                    if getattr(eng, "match_stream", None) is not None else "one stream")},
@@ -535,6 +554,12 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)   # anything a native library left in the C stdout buffer goes out BEFORE the line
         print(json.dumps(result), flush=True)
+    if CTL.get("abandon"):
+        # a rank's worker thread is stuck inside the group leg's communicator: the line above is complete and says so; tearing
+        # the process groups down would wait for that thread, so every rank leaves directly
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if world > 1:
         with c_stdout_to_stderr():
             dist.barrier()
@@ -1219,22 +1244,23 @@ def config5_leg(args, local_rank, nframes=512, nfeat=4000, w=1920, h=1080, warmu
     return out
 
 
-def config4_group(args, rank, local_rank, world, fence, allf, lo, hi, global_batch, nfeat, steps, ncand=8):
+def config4_group(args, rank, local_rank, world, uid, allf, lo, hi, global_batch, nfeat, steps, ncand=8):
     """Config 4 through the C-ABI's own multi-device layer (include/orbfe.h orbfe_group_*, one rank per process): extract the
     shard into its slice of the padded blocks, ONE in-place ncclAllGather (RCCL, loaded by liborbfe.so itself) and the
     consumer of the gather (src/LoopClosing.cc:312-342): every own frame is brute-force matched against `ncand`
-    candidate frames spread over the whole gathered batch, i.e. over the other ranks' shards."""
+    candidate frames spread over the whole gathered batch, i.e. over the other ranks' shards.  Runs in a worker thread when
+    world > 1 (config4_group_guarded): no torch collective in here, ranks meet on the CPU-side group CTL["leg"]."""
     from orb_slam2_ssd_semantic_amd.distributed import KeyframeGroup
     w, h = args.width, args.height
-    idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-    if rank == 0:
-        with c_stdout_to_stderr():
-            idt.copy_(torch.frombuffer(bytearray(KeyframeGroup.unique_id()), dtype=torch.uint8))
-    if world > 1:
-        dist.broadcast(idt, 0)
+    torch.cuda.set_device(local_rank)   # the current device is per thread
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(group=CTL["leg"])
+
     with c_stdout_to_stderr():
-        g = KeyframeGroup(nfeat, 1.2, 8, 20, 7, w, h, global_batch, rank_of_world=(rank, world, bytes(idt.cpu().numpy().tobytes())),
-                          device=local_rank)
+        g = KeyframeGroup(nfeat, 1.2, 8, 20, 7, w, h, global_batch, rank_of_world=(rank, world, uid), device=local_rank)
     shard = allf[lo:hi].contiguous()
     nloc = hi - lo
     qf = np.repeat(np.arange(lo, hi), ncand)
@@ -1260,8 +1286,8 @@ def config4_group(args, rank, local_rank, world, fence, allf, lo, hi, global_bat
     fence()
     dt = time.perf_counter() - t
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=CTL["leg"])
         dt = float(tt[0])
     nm = d_nm.cpu().numpy()
     res = {"frames_per_s": round(global_batch * steps / dt, 1), "pairs_per_rank": int(len(qf)), "candidates_per_frame": ncand,
@@ -1279,6 +1305,46 @@ def config4_group(args, rank, local_rank, world, fence, allf, lo, hi, global_bat
         res["exact_checked"] = True
     g.close()
     return res
+
+
+def config4_group_guarded(args, rank, local_rank, world, allf, lo, hi, global_batch, nfeat, steps, timeout_s=240.0):
+    """config4_group behind a watchdog.  With world > 1 the library's own RCCL communicator runs here for the first time on a
+    given node; a rank that fails or stalls inside it must cost this leg, not the line: the leg runs in a worker thread, every
+    rank waits `timeout_s` for its own, and the ranks then agree on the CPU-side group CTL["main"] whether all finished.  If one
+    did not, the leg is reported as such and every rank leaves through os._exit after rank 0 has printed the line (main)."""
+    import threading
+    from orb_slam2_ssd_semantic_amd.distributed import KeyframeGroup
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        with c_stdout_to_stderr():
+            uid.copy_(torch.frombuffer(bytearray(KeyframeGroup.unique_id()), dtype=torch.uint8))
+    if world > 1:
+        dist.broadcast(uid, 0, group=CTL["main"])
+    uid = bytes(uid.numpy().tobytes())
+    threaded = world > 1 or os.environ.get("ORBFE_BENCH_GUARD_THREAD") == "1"   # the env: exercise the worker-thread path on one GPU
+    if not threaded:
+        return config4_group(args, rank, local_rank, world, uid, allf, lo, hi, global_batch, nfeat, steps)
+    box = {}
+
+    def work():
+        try:
+            box["res"] = config4_group(args, rank, local_rank, world, uid, allf, lo, hi, global_batch, nfeat, steps)
+        except BaseException as e:   # noqa: BLE001 -- reported, see below
+            box["err"] = f"{type(e).__name__}: {e}"
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    stuck = th.is_alive()
+    flags = torch.tensor([0 if (stuck or "err" in box) else 1, 0 if stuck else 1], dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=CTL["main"])
+    if int(flags[1]) == 0:
+        CTL["abandon"] = True
+    if int(flags[0]) == 1:
+        return box["res"]
+    return {"error": box.get("err") or ("this rank did not finish within %.0f s" % timeout_s if stuck else "another rank failed or stalled"),
+            "abandoned": bool(CTL.get("abandon"))}
 
 
 def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2000, steps=10):
@@ -1337,7 +1403,7 @@ def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2
     run(allf[lo:hi].contiguous(), hi - lo, "strong")
     run(allf, global_batch, "weak")
     try:
-        out["cabi_group"] = config4_group(args, rank, local_rank, world, fence, allf, lo, hi, global_batch, nfeat, steps)
+        out["cabi_group"] = config4_group_guarded(args, rank, local_rank, world, allf, lo, hi, global_batch, nfeat, steps)
     except Exception as e:   # a second communicator next to torch's: report, never lose the line over it
         out["cabi_group"] = {"error": f"{type(e).__name__}: {e}"}
     out["nfeatures"], out["global_batch"], out["cap"], out["n_gpus"] = nfeat, global_batch, cap, world

@@ -137,111 +137,12 @@ struct PyrArgs {
 // vertical taps sit in LDS as well.  The level pitch is a multiple of 64: the last column group stores its whole dword.
 #define PW_PF 2
 #define PW_ROWS 16  // destination rows per lane run (8, 24, 32 measured slower)
-// (the body is shared with k_fast_pyr, whose workgroups are either FAST or resize workgroups; bxi / b = the workgroup's index
-// among the resize workgroups of its frame / its frame)
-__device__ __forceinline__ void pyr_walk_body(const PyrArgs &a, const int bxi, const int b)
+__global__ __launch_bounds__(256) void k_pyr_walk(PyrArgs a)
 {
-    extern __shared__ uint2 s_dyn[];
-    uint2 *s_yt = s_dyn;                                   // [dh + 8]: .x = b0 | b1 << 16, .y = sy (low half)
-    uint32_t *s_out = (uint32_t *)(s_dyn + (a.dh + 8));    // [rb][256]
-    const int W = a.dw, H = a.dh;
-    for (int i = threadIdx.x; i < H + 8; i += 256) s_yt[i] = ((const uint2 *)a.ytab)[i];
-    const int ncol4 = (W + 3) >> 2;
-    const int nlanes = ncol4 * a.nrblk;
-    const int fl = min((int)(bxi * 256 + threadIdx.x), nlanes - 1);  // surplus lanes repeat the last lane's work
-    const int rblk = fl / ncol4;
-    const int dx0 = (fl - rblk * ncol4) * 4;
-    const int y0 = rblk * a.rb, yend = min(y0 + a.rb, H);
-    const uint8_t *src = a.src + (int64_t)b * a.src_fstride;
-    uint8_t *dst = a.dst + (int64_t)b * a.dst_fstride;
-
-    const uint4 tx01 = *(const uint4 *)(a.xtab + dx0), tx23 = *(const uint4 *)(a.xtab + dx0 + 2);
-    const uint32_t xc[4] = {tx01.x, tx01.z, tx23.x, tx23.z};
-    const int xs[4] = {(int)(short)tx01.y, (int)(short)tx01.w, (int)(short)tx23.y, (int)(short)tx23.w};
-    const int sx0 = min(xs[0], a.sw - 8);
-    uint32_t sel[4];
-    orb_u2 coef[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t o = (uint32_t)min(max(xs[j] - sx0, 0), 7);
-        sel[j] = 0x0c000c00u | (min(o + 1u, 7u) << 16) | o;
-        coef[j] = __builtin_bit_cast(orb_u2, xc[j]);
-    }
-    __syncthreads();
-    uint2 cur = s_yt[y0];
-    const int r0 = (int)(short)cur.y;
-    int nsteps = (int)(short)s_yt[yend - 1].y + 2 - r0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
-    nsteps = __builtin_amdgcn_readfirstlane(nsteps);
-    const uint32_t sp = (uint32_t)a.spitch;
-    const int rlast = a.sh - 1;
-    // uniform base + 32-bit per-lane offset (global_load with an SGPR base)
-    auto fetch = [&](int s, uint2 &q) { q = *(const uint2 *)(src + (__umul24((uint32_t)min(r0 + s, rlast), sp) + (uint32_t)sx0)); };
-    auto hsum = [&](const uint2 &q, uint32_t (&h)[4]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, __builtin_amdgcn_perm(q.y, q.x, sel[j])), coef[j], 0u, false) >> 4;
-    };
-    uint2 raw[4];
-    fetch(0, raw[0]);
-    fetch(1, raw[1]);
-    fetch(2, raw[2]);
-    uint32_t Hp[4];
-    hsum(raw[0], Hp);  // step 0: source row sy(y0), completes nothing
-    int d = y0;
-    uint32_t *park = s_out + threadIdx.x;
-    // steps run in groups of four (static ring indices, no exit inside a group): surplus steps re-read the clamped last
-    // row and complete nothing
-    for (int s0 = 1; s0 < nsteps; s0 += 4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int s = s0 + k;
-            fetch(s + PW_PF, raw[(k + 1 + PW_PF) % 4]);
-            uint32_t Hs[4];
-            hsum(raw[(k + 1) % 4], Hs);
-            const bool emit = d < yend && (int)(short)cur.y + 1 == r0 + s;
-            // ((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2: the "+ 2" rides in the second product (+ 2 << 16, no carry
-            // into it from below), the two ">> 16" are the SDWA word selects of one add, whose result lands in the low /
-            // high half of a pair register; ">> 2" is then one packed shift per pixel pair
-            const uint32_t b0 = cur.x & 0xFFFFu, b1 = cur.x >> 16;
-            uint32_t pa[4], pb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pa[j] = __umul24(b0, Hp[j]);
-                pb[j] = __umul24(b1, Hs[j]) + 0x20000u;
-            }
-            uint32_t t01, t23;
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t01) : "v"(pa[0]), "v"(pb[0]));
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t01) : "v"(pa[1]), "v"(pb[1]));
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t23) : "v"(pa[2]), "v"(pb[2]));
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t23) : "v"(pa[3]), "v"(pb[3]));
-            const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t01) >> (orb_u2)(2));
-            const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t23) >> (orb_u2)(2));
-            if (emit) {
-                *park = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
-                park += 256;
-                d += 1;
-            }
-            cur = s_yt[d];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Hp[j] = Hs[j];
-        }
-    }
-    // burst store of the run (every lane reads back its own LDS column: no barrier)
-    uint32_t oofs = __umul24((uint32_t)y0, (uint32_t)a.dpitch) + (uint32_t)dx0;
-    const int nrows = yend - y0;
-    for (int i0 = 0; i0 < a.rb; i0 += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = s_out[min(i0 + i, a.rb - 1) * 256 + threadIdx.x];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i0 + i < nrows) *(uint32_t *)(dst + (oofs + (uint32_t)(i0 + i) * (uint32_t)a.dpitch)) = v[i];
-    }
+    const int b = blockIdx.y;
+    const uint32_t bxi = blockIdx.x;
+#include "orbfe_pyr_body.inc"
 }
-
-__global__ __launch_bounds__(256) void k_pyr_walk(PyrArgs a) { pyr_walk_body(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 // Two levels per launch.  The workgroup owns a tile of level B = l: p2_gx column groups x p2_gy runs of a.rb rows, produced
 // from level A = l - 1 exactly as k_pyr_walk does (same row walk, same arithmetic); the finished tile stays in LDS
@@ -623,276 +524,40 @@ __device__ __forceinline__ void fm_flush(uint2 *slist, int32_t *scnt, const uint
 #else
 #define FM_OCC
 #endif
-// t = the wave's index in the lane list, b = its frame (both wave-uniform); the body is shared by k_fast_map (one launch over
-// the waves of all levels) and k_fast_pyr (one launch per level, resize workgroups beside the FAST workgroups)
-template <int SPARSE>
-__device__ __forceinline__ void fast_map_body(const OrbPlan *__restrict__ plan, const FrameSrc &fs,
-                                              const OrbLane *__restrict__ lanes, const int t, const int b,
-                                              uint2 *__restrict__ skeys,      // [B][keys_per_frame] {key, ord}
-                                              int32_t *__restrict__ scount,   // [B][nlevels] * NK_STRIDE, zeroed
-                                              uint32_t *__restrict__ cflags,  // [B][nlevels][cf_words], zeroed
-                                              const int32_t cf_words,
-                                              unsigned long long *__restrict__ fstat)  // {row steps, arc skips, nms skips} or null
-{
-    __shared__ uint2 s_buf[4][FM_BUF];
+#define FM_SHARED_DECLS                                                                                             \
+    __shared__ uint2 s_buf[4][FM_BUF];                                                                              \
+    extern __shared__ uint32_t s_cf[]; /* [4][cf_words]: per-wave bitmap of the level's cells with a survivor above iniTh */
 #ifdef FM_LDS_CONSTS
-    // Per-lane constants of the row loop (the six half-word masks of the cell seams and the four `ord` column parts) parked in
-    // LDS and re-read where they are used: ten registers less in the kernel's peak live set.  At <= 152 registers three of its
-    // waves leave 56 per SIMD lane -- room for one wave of an HBM-bound kernel (k_pyr_walk: 48) beside them, where 160 leave 32
-    // and nothing fits (A/B in profiles/r04_ab_experiments.json).
-    __shared__ uint4 s_lcm[4][64];   // in01, in23, lv01, lv23
-    __shared__ uint2 s_lcr[4][64];   // rv01, rv23
-    __shared__ uint4 s_lco[4][64];   // ordx[0..3]
-#endif
-    extern __shared__ uint32_t s_cf[];  // [4][cf_words]: per-wave bitmap of the level's cells with a survivor above iniTh
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    uint32_t *lflag = s_cf + wv * cf_words;
-    for (int i = lane; i < cf_words; i += 64) lflag[i] = 0u;  // wave-private: its own DS operations execute in order
-    // Work is described per LANE: a 4-pixel column, a run of rows, "halo" (contributes neighbour strengths only).
-    // The host packs the column strips of all row blocks of one level back to back into 64-lane waves, so narrow
-    // levels do not leave lanes idle; neighbouring lanes are neighbouring columns inside one strip.
-    const OrbLane ld = lanes[(int64_t)t * 64 + lane];
-    const int level = __builtin_amdgcn_readfirstlane((int)(ld.flags >> 8));
-    const OrbLevel &L = plan->lv[level];
-    int pitch;
-    const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
-    uint2 *slist = skeys + (int64_t)b * plan->keys_per_frame + L.key_off;
-    int32_t *scnt = scount + (b * plan->nlevels + level) * ORBFE_NK_STRIDE;
-    uint32_t *cflag = cflags + (int64_t)(b * plan->nlevels + level) * cf_words;
-    const int ini_th = plan->ini_th;
-    uint2 *sbuf = s_buf[wv];
-    int nbuf = 0;  // wave-uniform fill of sbuf
-    int st_rows = 0, st_arc = 0, st_nms = 0;  // SPARSE statistics (wave-uniform)
-    const int H = L.h, key_cap = L.key_cap;
-    const int ix0 = ORBFE_EDGE, iy0 = ORBFE_EDGE, ix1 = L.ix1, iy1 = L.iy1;
-    const int wcell = L.wcell, hcell = L.hcell;
-    const int x = ld.x;                 // first pixel of this lane (16 <= x < ix1: the 12-byte row window is in the image)
-    const int ys = ld.ys;
-    int nsteps = ld.nrows;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
-    nsteps = __builtin_amdgcn_readfirstlane(nsteps) + 8;  // wave-uniform, and the compiler knows it
-    const int tz = max(plan->min_th, 1);
-
-    // per-lane column masks: bit j = pixel j inside the interior / has a valid left / right neighbour in its cell
-    int inside = 0, lvalid = 0, rvalid = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int xx = x + j;
-        if (xx >= ix0 && xx < ix1) {
-            const int m = (xx - ix0) % wcell;
-            inside |= 1 << j;
-            if (m != 0) lvalid |= 1 << j;
-            if (m != wcell - 1 && xx + 1 < ix1) rvalid |= 1 << j;
-        }
-    }
-    auto halves = [](int bits, int j) -> uint32_t {
-        return (((bits >> j) & 1) ? 0xFFFFu : 0u) | (((bits >> (j + 1)) & 1) ? 0xFFFF0000u : 0u);
-    };
-#ifdef FM_LDS_CONSTS
-    s_lcm[wv][lane] = make_uint4(halves(inside, 0), halves(inside, 2), halves(lvalid, 0), halves(lvalid, 2));
-    s_lcr[wv][lane] = make_uint2(halves(rvalid, 0), halves(rvalid, 2));
-    // the address is laundered through an empty asm at every use, so the loads stay where they are written (a loop-invariant
-    // load would be hoisted back into registers)
-    uint32_t lc_m = (uint32_t)(uintptr_t)&s_lcm[wv][lane], lc_r = (uint32_t)(uintptr_t)&s_lcr[wv][lane], lc_o = (uint32_t)(uintptr_t)&s_lco[wv][lane];
-    typedef uint32_t fm_v4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t fm_v2 __attribute__((ext_vector_type(2)));
-#define FM_LC_LOAD(type, addr) ({ asm volatile("" : "+v"(addr)); *(const __attribute__((address_space(3))) type *)(uintptr_t)(addr); })
+// Per-lane constants of the row loop (the six half-word masks of the cell seams and the four `ord` column parts) parked in
+// LDS and re-read where they are used: ten registers less in the kernel's peak live set.  At <= 152 registers three of its
+// waves leave 56 per SIMD lane -- room for one wave of an HBM-bound kernel (k_pyr_walk: 48) beside them, where 160 leave 32
+// and nothing fits (A/B in profiles/r04_ab_experiments.json).
+#define FM_LDS_DECLS                                                             \
+    __shared__ uint4 s_lcm[4][64]; /* in01, in23, lv01, lv23 */                  \
+    __shared__ uint2 s_lcr[4][64]; /* rv01, rv23 */                              \
+    __shared__ uint4 s_lco[4][64]; /* ordx[0..3] */
 #else
-    const uint32_t in01 = halves(inside, 0), in23 = halves(inside, 2);
-    const uint32_t lv01 = halves(lvalid, 0), lv23 = halves(lvalid, 2);
-    const uint32_t rv01 = halves(rvalid, 0), rv23 = halves(rvalid, 2);
+#define FM_LDS_DECLS
 #endif
-    // a cell seam between the two pixels of a pair lets BOTH be NMS survivors; at most one pair of a lane has one
-    const bool split01 = (inside & 3) == 3 && !(lvalid & 2), split23 = (inside & 12) == 12 && !(lvalid & 8);
-    const bool wave_split = orb_ballot(split01 || split23) != 0ull;
-    const bool out_lane = !(ld.flags & 1) && inside != 0;
-    const int nrows_out = out_lane ? (int)ld.nrows : 0;
-    // per-pixel part of `ord`, the rank key of the reference's candidate order (cell-row-major, raster inside a cell):
-    // ord = (cell_row * ncc + cell_col) << 12 | y_in_cell << 6 | x_in_cell
-    uint32_t ordx[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rel = max(x + j - ix0, 0);
-        const int cc = rel / wcell;
-        ordx[j] = ((uint32_t)cc << 12) | (uint32_t)(rel - cc * wcell);
-    }
-#ifdef FM_LDS_CONSTS
-    s_lco[wv][lane] = make_uint4(ordx[0], ordx[1], ordx[2], ordx[3]);
-#endif
-    int rmod = (ys - iy0) % hcell;                                  // y_in_cell of the next NMS row (per lane)
-    uint32_t ordy = ((uint32_t)(((ys - iy0) / hcell) * L.ncc) << 12) | ((uint32_t)rmod << 6);
-    const uint32_t ord_wrap = ((uint32_t)L.ncc << 12) - ((uint32_t)hcell << 6);  // added when a new cell row starts
-    const uint32_t tzz = (uint32_t)tz * 0x00010001u;
-    const uint32_t resp0 = (uint32_t)(tz - 1);
-    const int ysrel = ys - 7 - iy0;                                 // strength row of step s, relative to iy0, minus s
-    const uint32_t hrange = (uint32_t)(iy1 - iy0);
-    // key of pixel 0 in the NMS row of step 0 (detection-window coordinates = level - 16, reference :831-832)
-    const uint32_t key00 = (uint32_t)(x - ORBFE_MINB) + ((uint32_t)(ys - 8 - ORBFE_MINB) << 12);
-
-    // 8-slot ring of unpacked rows (7 live), statically indexed under the 8-fold unroll; the raw row of the next step is
-    // fetched one step ahead into one of two 12-byte buffers
-    uint32_t R[8][FM_NE], Raw[2][3];
-    uint32_t S01[8], S23[8];  // S of the pixel pairs (0,1), (2,3) for the strength row computed in ring slot k
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        S01[k] = S23[k] = 0u;
-#pragma unroll
-        for (int i = 0; i < FM_NE; ++i) R[k][i] = 0u;
-    }
-    auto fetch = [&](int s, uint32_t (&dst3)[3]) {
-        const int r = ys - 4 + s;  // image row of step s (lanes past their run re-read a valid row)
-        const uint8_t *row = src + (__umul24((uint32_t)min(r, H - 1), (uint32_t)pitch) + (uint32_t)x);
-        dst3[0] = *(const uint32_t *)(row - 4);
-        dst3[1] = *(const uint32_t *)(row);
-        dst3[2] = *(const uint32_t *)(row + 4);
-    };
-    fetch(0, Raw[0]);
-
-    for (int s0 = 0; s0 < nsteps; s0 += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int s = s0 + k;
-            if (s >= nsteps) break;    // wave-uniform
-            fetch(s + 1, Raw[(k + 1) % 2]);
-            fast_unpack_row(Raw[k % 2], R[k]);
-            if (s < 6) continue;
-            // ---- strength row rc = r - 3 (newest ring slot k is row rc+3, slot (k+2)%8 is row rc-3) ----
-            {
-                const uint32_t(&rm3)[FM_NE] = R[(k + 2) % 8];
-                const uint32_t(&rm2)[FM_NE] = R[(k + 3) % 8];
-                const uint32_t(&rm1)[FM_NE] = R[(k + 4) % 8];
-                const uint32_t(&r0)[FM_NE] = R[(k + 5) % 8];
-                const uint32_t(&rp1)[FM_NE] = R[(k + 6) % 8];
-                const uint32_t(&rp2)[FM_NE] = R[(k + 7) % 8];
-                const uint32_t(&rp3)[FM_NE] = R[k];
-                const bool rowok = (uint32_t)(ysrel + s) < hrange;  // iy0 <= rc < iy1
-                const uint32_t tt = rowok ? tzz : 0x03FF03FFu;
-                bool arcs = true;
-#ifdef FM_LDS_CONSTS
-                const fm_v4 lcm = FM_LC_LOAD(fm_v4, lc_m);
-                const uint32_t in01 = lcm.x, in23 = lcm.y;
-#endif
-                if (SPARSE) {
-                    const uint32_t p = (fast_compass_pair<0>(rm3, r0, rp3, tt) & in01) |
-                                       (fast_compass_pair<2>(rm3, r0, rp3, tt) & in23);
-                    arcs = orb_ballot(p != 0u) != 0ull;  // wave-uniform
-                    if (fstat) { st_rows++; st_arc += arcs ? 0 : 1; }
-                }
-                if (arcs) {
-                    S01[k] = fast_strength_pair<0>(rm3, rm2, rm1, r0, rp1, rp2, rp3, tt) & in01;
-                    S23[k] = fast_strength_pair<2>(rm3, rm2, rm1, r0, rp1, rp2, rp3, tt) & in23;
-                } else {
-                    S01[k] = S23[k] = 0u;
-                }
-            }
-            if (s < 8) continue;
-            // ---- 3x3 strict NMS of row rn = rc - 1 on packed pairs: rows U = S[k-2], M = S[k-1], D = S[k] ----
-            const int ku = (k + 6) % 8, km = (k + 7) % 8;
-            const bool up_ok = rmod != 0;            // neighbours outside the own cell count as 0
-            const bool dn_ok = rmod != hcell - 1;    // (the row at iy1 is already all zero)
-            const uint32_t ord_row = ordy;
-            {
-                const bool wrap = rmod == hcell - 1;
-                rmod = wrap ? 0 : rmod + 1;
-                ordy += wrap ? 64u + ord_wrap : 64u;
-            }
-            if (SPARSE) {  // no strength in the row being suppressed -> nothing can survive (wave-uniform)
-                if (orb_ballot((S01[km] | S23[km]) != 0u) == 0ull) {
-                    if (fstat) st_nms++;
-                    continue;
-                }
-            }
-#ifdef FM_LDS_CONSTS
-            const fm_v4 lcn = FM_LC_LOAD(fm_v4, lc_m);
-            const fm_v2 lcr = FM_LC_LOAD(fm_v2, lc_r);
-            const uint32_t lv01 = lcn.z, lv23 = lcn.w, rv01 = lcr.x, rv23 = lcr.y;
-#endif
-            const uint32_t u01 = up_ok ? S01[ku] : 0u, u23 = up_ok ? S23[ku] : 0u;
-            const uint32_t d01 = dn_ok ? S01[k] : 0u, d23 = dn_ok ? S23[k] : 0u;
-            const uint32_t m01 = S01[km], m23 = S23[km];
-            const uint32_t v01 = pk_max_u16(u01, d01), v23 = pk_max_u16(u23, d23);   // vertical neighbours
-            const uint32_t c01 = pk_max_u16(v01, m01), c23 = pk_max_u16(v23, m23);   // column maxima
-            // neighbour lanes by DPP wave shifts (lane 0 / 63 read back 0: they have no such neighbour)
-            const uint32_t cL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c23, 0x138, 0xF, 0xF, true);  // wave_shr:1, .hi = column x-1
-            const uint32_t cR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c01, 0x130, 0xF, 0xF, true);  // wave_shl:1, .lo = column x+4
-            const uint32_t l01 = __builtin_amdgcn_alignbit(c01, cL, 16) & lv01;      // columns (x-1, x)
-            const uint32_t x12 = __builtin_amdgcn_alignbit(c23, c01, 16);            // columns (x+1, x+2)
-            const uint32_t r23 = __builtin_amdgcn_alignbit(cR, c23, 16) & rv23;      // columns (x+3, x+4)
-            const uint32_t n01 = pk_max3(l01, x12 & rv01, v01);
-            const uint32_t n23 = pk_max3(x12 & lv23, r23, v23);
-            const uint32_t g01 = pk_subsat_u16(m01, n01), g23 = pk_subsat_u16(m23, n23);  // != 0 <=> survivor
-            const bool row_out = s - 8 < nrows_out;  // per lane
-            // ballots of the plain compares, combined on the scalar side (a ballot of a combined predicate is lowered through a
-            // VGPR: select 0 / 1, compare again)
-            const unsigned long long brow = orb_ballot(row_out);
-            const unsigned long long b01 = orb_ballot(g01 != 0u) & brow, b23 = orb_ballot(g23 != 0u) & brow;
-            const bool has01 = row_out && g01 != 0u, has23 = row_out && g23 != 0u;
-            if (b01 | b23) {
-#ifdef FM_LDS_CONSTS
-                const fm_v4 lco = FM_LC_LOAD(fm_v4, lc_o);
-                const uint32_t ordx[4] = {lco.x, lco.y, lco.z, lco.w};
-#endif
-                const uint32_t keyrow = key00 + ((uint32_t)s << 12);
-                const int p01 = __popcll(b01);
-                if (has01) {
-                    const bool hi = g01 > 0xFFFFu;
-                    const uint32_t a = hi ? m01 >> 16 : m01 & 0xFFFFu;
-                    sbuf[nbuf + lanes_below(b01)] = make_uint2(keyrow + (hi ? 1u : 0u) + ((a + resp0) << 24),
-                                                               ord_row + (hi ? ordx[1] : ordx[0]));
-                }
-                if (has23) {
-                    const bool hi = g23 > 0xFFFFu;
-                    const uint32_t a = hi ? m23 >> 16 : m23 & 0xFFFFu;
-                    sbuf[nbuf + p01 + lanes_below(b23)] = make_uint2(keyrow + (hi ? 3u : 2u) + ((a + resp0) << 24),
-                                                                     ord_row + (hi ? ordx[3] : ordx[2]));
-                }
-                nbuf += p01 + __popcll(b23);
-                if (wave_split) {  // both pixels of a seam pair survived: the low one is still to be written
-                    const uint32_t gs = split01 ? g01 : (split23 ? g23 : 0u);
-                    const bool dbl = row_out && (gs & 0xFFFFu) != 0u && gs > 0xFFFFu;
-                    const unsigned long long bd = orb_ballot(dbl);
-                    if (bd) {
-                        if (dbl) {
-                            const uint32_t a = (split23 ? m23 : m01) & 0xFFFFu;
-                            sbuf[nbuf + lanes_below(bd)] = make_uint2(keyrow + (split23 ? 2u : 0u) + ((a + resp0) << 24),
-                                                                      ord_row + (split23 ? ordx[2] : ordx[0]));
-                        }
-                        nbuf += __popcll(bd);
-                    }
-                }
-                if (nbuf > FM_BUF - FM_ROW_MAX) {
-                    fm_flush(slist, scnt, sbuf, nbuf, key_cap, lane, lflag, ini_th);
-                    nbuf = 0;
-                }
-            }
-        }
-    }
-    if (nbuf > 0) fm_flush(slist, scnt, sbuf, nbuf, key_cap, lane, lflag, ini_th);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    for (int i = lane; i < cf_words; i += 64) {
-        const uint32_t v = lflag[i];
-        if (v) atomicOr(&cflag[i], v);
-    }
-    if (SPARSE && fstat && lane == 0) {
-        atomicAdd(&fstat[0], (unsigned long long)st_rows);
-        atomicAdd(&fstat[1], (unsigned long long)st_arc);
-        atomicAdd(&fstat[2], (unsigned long long)st_nms);
-    }
-}
 
 template <int SPARSE>
 __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restrict__ plan, FrameSrc fs,
-                                                  const OrbLane *__restrict__ lanes, int nwaves, uint2 *__restrict__ skeys,
-                                                  int32_t *__restrict__ scount, uint32_t *__restrict__ cflags, int32_t cf_words,
-                                                  unsigned long long *__restrict__ fstat)
+                                                  const OrbLane *__restrict__ lanes, int nwaves,
+                                                  uint2 *__restrict__ skeys,      // [B][keys_per_frame] {key, ord}
+                                                  int32_t *__restrict__ scount,   // [B][nlevels] * NK_STRIDE, zeroed
+                                                  uint32_t *__restrict__ cflags,  // [B][nlevels][cf_words], zeroed
+                                                  int32_t cf_words,
+                                                  unsigned long long *__restrict__ fstat)  // {row steps, arc skips, nms skips} or null
 {
+    FM_SHARED_DECLS
+    FM_LDS_DECLS
     int b = blockIdx.y, bx = blockIdx.x;
     xcd_frame_remap(bx, b);
-    const int t = bx * 4 + (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int t = bx * (blockDim.x >> 6) + wv;
     if (t >= nwaves) return;
-    fast_map_body<SPARSE>(plan, fs, lanes, t, b, skeys, scount, cflags, cf_words, fstat);
+#include "orbfe_fast_body.inc"
 }
 
 // FAST on level l and cv::resize l -> l + 1 in ONE launch, the launches chained over the levels ("pyramid inside
@@ -908,6 +573,8 @@ __global__ __launch_bounds__(256) void k_fast_pyr(const OrbPlan *__restrict__ pl
                                                   uint32_t *__restrict__ cflags, int32_t cf_words,
                                                   unsigned long long *__restrict__ fstat, PyrArgs pa, int npyr, int spread)
 {
+    FM_SHARED_DECLS
+    FM_LDS_DECLS
     int b = blockIdx.y, bx = blockIdx.x;
     xcd_frame_remap(bx, b);
     int before = min(bx, npyr);              // resize workgroups in front of this one
@@ -918,12 +585,16 @@ __global__ __launch_bounds__(256) void k_fast_pyr(const OrbPlan *__restrict__ pl
         is_pyr = (int)(((uint32_t)(bx + 1) * (uint32_t)npyr) / (uint32_t)T) > before;
     }
     if (is_pyr) {
-        pyr_walk_body(pa, before, b);
+        const PyrArgs &a = pa;
+        const uint32_t bxi = (uint32_t)before;
+#include "orbfe_pyr_body.inc"
         return;
     }
-    const int t = (bx - before) * 4 + (int)(threadIdx.x >> 6);
-    if (t >= nwaves) return;
-    fast_map_body<SPARSE>(plan, fs, lanes, wave_lo + t, b, skeys, scount, cflags, cf_words, fstat);
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    if ((bx - before) * 4 + wv >= nwaves) return;
+    const int t = wave_lo + (bx - before) * 4 + wv;
+#include "orbfe_fast_body.inc"
 }
 
 // ---------------------------------------------------------------------------------------------------
