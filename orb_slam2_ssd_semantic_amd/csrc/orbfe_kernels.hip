@@ -1384,61 +1384,44 @@ __host__ __device__ constexpr uint32_t blur_hw(int j, int d)
 #else
 #define BL_BOUNDS __launch_bounds__(256)
 #endif
-template <int MODE>
-__global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
-                                               const OrbLane *__restrict__ lanes, int nwaves,
-                                               uint8_t *__restrict__ blur, int64_t blur_fstride)
+// the row walk of one lane; INTERIOR (wave-uniform, compile-time): the 12-byte window holds no reflected column
+template <int MODE, bool INTERIOR>
+__device__ __forceinline__ void blur7_walk(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int pitch, const int dpitch,
+                                           const int W, const int H, const int x, const int y0, const int yend, const bool active,
+                                           const int nsteps, const int vec_w)
 {
-    int b = blockIdx.y, bx = blockIdx.x;
-    xcd_frame_remap(bx, b);
-    const int lane = threadIdx.x & 63;
-    const int t = bx * 4 + (threadIdx.x >> 6);
-    if (t >= nwaves) return;
-    const OrbLane ld = lanes[(int64_t)t * 64 + lane];
-    const int level = __builtin_amdgcn_readfirstlane((int)(ld.flags >> 8));
-    const OrbLevel &L = plan->lv[level];
-    int pitch;
-    const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
-    uint8_t *dst = blur + (int64_t)b * blur_fstride + L.off;
-    const int W = L.w, H = L.h;
-    const int x = ld.x, y0 = ld.ys, yend = y0 + ld.nrows;
-    const bool active = !(ld.flags & 1);
-    // wave-uniform by construction (the host packs interior and edge columns into separate waves): no reflected column
-    const bool interior = __builtin_amdgcn_readfirstlane((int)(ld.flags & 2)) != 0;
-    const int vec_w = W & ~3;
-    int nsteps = ld.nrows;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
-    nsteps = __builtin_amdgcn_readfirstlane(nsteps) + 6;  // wave-uniform
-
     // window pixel i (0..11) is level column reflect101(x - 4 + i); i = 0 and 11 are never used
+    // (interior waves -- no reflected column, the host packs them apart -- take their 12-byte window as it lies: no selectors)
     int srcx[12], lo = W;
+    if (!INTERIOR) {
 #pragma unroll
-    for (int i = 1; i < 11; ++i) {
-        srcx[i] = reflect101(min(x - 4 + i, W + 2), W);
-        lo = min(lo, srcx[i]);
+        for (int i = 1; i < 11; ++i) {
+            srcx[i] = reflect101(min(x - 4 + i, W + 2), W);
+            lo = min(lo, srcx[i]);
+        }
+        srcx[0] = srcx[1];
+        srcx[11] = srcx[10];
     }
-    srcx[0] = srcx[1];
-    srcx[11] = srcx[10];
     // all ten sources lie in [base, base + 12) (checked on the host for every level width); at the right edge the
     // window is pulled back so that it ends at the last pixel of the row
-    const int base = interior ? x - 4 : min(lo & ~3, W - 12);
+    const int base = INTERIOR ? x - 4 : min(lo & ~3, W - 12);
     uint32_t selA[3], selB[3], mskB[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         selA[d] = selB[d] = mskB[d] = 0u;
+        if (!INTERIOR) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int bi = min(max(srcx[4 * d + k] - base, 0), 11);  // loaded byte index
-            if (bi < 8) selA[d] |= (uint32_t)bi << (8 * k);           // from {w1:w0}
-            else {
-                selB[d] |= (uint32_t)(bi - 8) << (8 * k);             // from w2
-                mskB[d] |= 0xFFu << (8 * k);
+            for (int k = 0; k < 4; ++k) {
+                const int bi = min(max(srcx[4 * d + k] - base, 0), 11);  // loaded byte index
+                if (bi < 8) selA[d] |= (uint32_t)bi << (8 * k);           // from {w1:w0}
+                else {
+                    selB[d] |= (uint32_t)(bi - 8) << (8 * k);             // from w2
+                    mskB[d] |= 0xFFu << (8 * k);
+                }
             }
         }
     }
     const bool full = x + 4 <= W;
-    const int dpitch = L.pitch;
 
     // Row sums are <= 255 * 257 = 65535, i.e. u16: ring slot k holds, per pixel, the pair (row sum of step s-1, row sum of
     // step s) as two u16 halves, so the vertical pass is three v_dot2_u32_u16 (pairs of taps) plus one multiply-add
@@ -1482,7 +1465,7 @@ __global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
             fetch(s + BL_PF, Lr[(k + BL_PF) % 7]);  // rows past the run re-read a valid (reflected / clamped) row
             const uint32_t l0 = Lr[k][0], l1 = Lr[k][1], l2 = Lr[k][2];
             uint32_t w[3] = {l0, l1, l2};
-            if (!interior) {
+            if (!INTERIOR) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     const uint32_t ta = __builtin_amdgcn_perm(l1, l0, selA[d]);
@@ -1540,6 +1523,38 @@ __global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
             }
         }
     }
+}
+
+template <int MODE>
+__global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
+                                               const OrbLane *__restrict__ lanes, int nwaves,
+                                               uint8_t *__restrict__ blur, int64_t blur_fstride)
+{
+    int b = blockIdx.y, bx = blockIdx.x;
+    xcd_frame_remap(bx, b);
+    const int lane = threadIdx.x & 63;
+    const int t = bx * 4 + (threadIdx.x >> 6);
+    if (t >= nwaves) return;
+    const OrbLane ld = lanes[(int64_t)t * 64 + lane];
+    const int level = __builtin_amdgcn_readfirstlane((int)(ld.flags >> 8));
+    const OrbLevel &L = plan->lv[level];
+    int pitch;
+    const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
+    uint8_t *dst = blur + (int64_t)b * blur_fstride + L.off;
+    const int W = L.w, H = L.h;
+    const int x = ld.x, y0 = ld.ys, yend = y0 + ld.nrows;
+    const bool active = !(ld.flags & 1);
+    // wave-uniform by construction (the host packs interior and edge columns into separate waves): no reflected column
+    const bool interior = __builtin_amdgcn_readfirstlane((int)(ld.flags & 2)) != 0;
+    const int vec_w = W & ~3;
+    int nsteps = ld.nrows;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps) + 6;  // wave-uniform
+    if (interior)
+        blur7_walk<MODE, true>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
+    else
+        blur7_walk<MODE, false>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
 }
 
 // Blur of level l AND the resize l -> l + 1 in one pass over level l (ORBFE_FUSE_BLUR_PYR, one launch per level, chained).
