@@ -532,6 +532,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     std::vector<OrbLane> blanes;
     std::vector<OrbLaneR> blanesR;   // the resize job of every blur lane (fused blur + pyramid pass), same index
     const bool blur_pieces = !(getenv("ORBFE_BLUR_PIECES") && atoi(getenv("ORBFE_BLUR_PIECES")) == 0);
+    const int blur_updown = getenv("ORBFE_BLUR_UPDOWN") ? std::max(0, std::min(2, atoi(getenv("ORBFE_BLUR_UPDOWN")))) : 1;
     for (int l = 0; l < nl; ++l) {
         const OrbLevel &L = P.lv[l];
         if (L.w < 16) { orbfe_set_error("level %d too narrow for the blur kernel", l); return ORBFE_ERR_SIZE; }
@@ -653,20 +654,42 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             while (blanes.size() % 64) { blanes.push_back(dead(false)); blanesR.push_back(OrbLaneR{0, 0, 0, 0}); }
         } else
         for (int pass = 0; pass < 2; ++pass) {  // 0: interior waves, 1: border waves
-            for (int k = 0; k < nblk; ++k) {
-                const int ys = k * rb, nr = std::min(rb, L.h - ys);
-                if (nr <= 0) continue;
-                for (int c = 0; c < ncol; ++c) {
-                    const bool interior = is_interior(c);
-                    if (interior != (pass == 0)) continue;
-                    blanes.push_back(blur_lane(c, ys, nr, interior));
-                    blanesR.push_back(fuse == 1 ? resize_job(c, ys, nr) : OrbLaneR{0, 0, 0, 0});
-                    // the right piece is padded to its 16 slots, so that the next row block's left piece starts a piece again
-                    if (blur_pieces && pass == 1 && c == ncol - 1)
-                        while (blanes.size() % 16) { blanes.push_back(dead(false)); blanesR.push_back(OrbLaneR{0, 0, 0, 0}); }
+            // Odd row blocks walk UPWARDS (flag bit 3, wave-uniform: the even blocks' lanes come first, then the odd blocks'; the
+            // kernel is vertically symmetric).  Two neighbouring row blocks then read the rows around their common boundary at the
+            // same end of their walks -- both at the start or both at the end; all waves of a frame are in flight together -- and
+            // the second reader finds the halo rows in L2 instead of HBM: FETCH_SIZE of the kernel -18 % when every level does it.
+            // Keeping the two directions in waves of their own can cost a level one more (partly filled) wave, i.e. instructions,
+            // which is what the pipeline as a whole is bound by: a (level, pass) is split only where the wave count stays the same
+            // (ORBFE_BLUR_UPDOWN=0: never, =2: always; the fused blur + pyramid passes walk downwards only).
+            auto emit = [&](int nparity, std::vector<OrbLane> &ol, std::vector<OrbLaneR> &orr) {
+                for (int par = 0; par < nparity; ++par) {
+                    const uint16_t upflag = par ? 8 : 0;
+                    for (int k = 0; k < nblk; ++k) {
+                        if (nparity == 2 && (k & 1) != par) continue;
+                        const int ys = k * rb, nr = std::min(rb, L.h - ys);
+                        if (nr <= 0) continue;
+                        for (int c = 0; c < ncol; ++c) {
+                            const bool interior = is_interior(c);
+                            if (interior != (pass == 0)) continue;
+                            ol.push_back(blur_lane(c, ys, nr, interior));
+                            ol.back().flags |= upflag;
+                            orr.push_back(fuse == 1 ? resize_job(c, ys, nr) : OrbLaneR{0, 0, 0, 0});
+                            // the right piece is padded to its 16 slots, so that the next row block's left piece starts a piece again
+                            if (blur_pieces && pass == 1 && c == ncol - 1)
+                                while (ol.size() % 16) { ol.push_back(dead(false)); ol.back().flags |= upflag; orr.push_back(OrbLaneR{0, 0, 0, 0}); }
+                        }
+                    }
+                    // dead lanes: shadow a column of the wave's kind
+                    while (ol.size() % 64) { ol.push_back(dead(pass == 0)); ol.back().flags |= upflag; orr.push_back(OrbLaneR{0, 0, 0, 0}); }
                 }
-            }
-            while (blanes.size() % 64) { blanes.push_back(dead(pass == 0)); blanesR.push_back(OrbLaneR{0, 0, 0, 0}); }  // dead lanes: shadow a column of the wave's kind
+            };
+            std::vector<OrbLane> l1, l2;
+            std::vector<OrbLaneR> r1, r2;
+            emit(1, l1, r1);
+            if (fuse == 0 && blur_updown) emit(2, l2, r2);
+            const bool split = fuse == 0 && blur_updown && (blur_updown == 2 || l2.size() == l1.size());
+            blanes.insert(blanes.end(), (split ? l2 : l1).begin(), (split ? l2 : l1).end());
+            blanesR.insert(blanesR.end(), (split ? r2 : r1).begin(), (split ? r2 : r1).end());
         }
         P.bwave_off[l + 1] = (int)(blanes.size() / 64);
     }

@@ -1384,12 +1384,14 @@ __host__ __device__ constexpr uint32_t blur_hw(int j, int d)
 #else
 #define BL_BOUNDS __launch_bounds__(256)
 #endif
-// the row walk of one lane; INTERIOR (wave-uniform, compile-time): the 12-byte window holds no reflected column
-template <int MODE, bool INTERIOR>
+// the row walk of one lane; INTERIOR (wave-uniform, compile-time): the 12-byte window holds no reflected column; UP (wave-uniform,
+// compile-time): the walk goes from the bottom of the row block to its top
+template <int MODE, bool INTERIOR, bool UP>
 __device__ __forceinline__ void blur7_walk(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int pitch, const int dpitch,
                                            const int W, const int H, const int x, const int y0, const int yend, const bool active,
                                            const int nsteps, const int vec_w)
 {
+    constexpr bool up = UP;
     // window pixel i (0..11) is level column reflect101(x - 4 + i); i = 0 and 11 are never used
     // (interior waves -- no reflected column, the host packs them apart -- take their 12-byte window as it lies: no selectors)
     int srcx[12], lo = W;
@@ -1438,15 +1440,21 @@ __device__ __forceinline__ void blur7_walk(const uint8_t *__restrict__ src, uint
     uint32_t Lr[7][3];
     // A wave none of whose lanes comes within 3 rows of the level's top or bottom (three of four) walks plain rows: the
     // offset advances by the pitch, no reflected row index per step.
-    const bool plain_rows = orb_ballot(!(y0 >= 3 && y0 - 3 + nsteps + BL_PF <= H)) == 0ull;
-    uint32_t ro = __umul24((uint32_t)max(y0 - 3, 0), (uint32_t)pitch) + (uint32_t)base;
+    // A lane walks its rows downwards from y0 - 3 or (flag bit 3, odd row blocks) upwards from yend + 2: the taps are symmetric,
+    // the sums are the same integers.  Row of step s: ystart + dir * s; the output row of step s lies 3 * dir behind it.
+    const int dir = up ? -1 : 1;
+    const int ystart = up ? yend + 2 : y0 - 3;
+    const int ylast = ystart + dir * (nsteps + BL_PF - 1);   // last row the walk asks for (incl. the prefetch past its end)
+    const bool plain_rows = orb_ballot(!(min(ystart, ylast) >= 0 && max(ystart, ylast) < H)) == 0ull;
+    uint32_t ro = __umul24((uint32_t)min(max(ystart, 0), H - 1), (uint32_t)pitch) + (uint32_t)base;
+    const uint32_t rstep = up ? 0u - (uint32_t)pitch : (uint32_t)pitch;
     auto fetch = [&](int s, uint32_t (&dst3)[3]) {
         const uint8_t *row;
         if (plain_rows) {
             row = src + ro;
-            ro += (uint32_t)pitch;
+            ro += rstep;
         } else {
-            const int yy = reflect101(min(y0 - 3 + s, H + 2), H);
+            const int yy = reflect101(max(min(ystart + dir * s, H + 2), -3), H);
             row = src + (__umul24((uint32_t)yy, (uint32_t)pitch) + (uint32_t)base);
         }
         dst3[0] = *(const uint32_t *)(row);
@@ -1461,7 +1469,7 @@ __device__ __forceinline__ void blur7_walk(const uint8_t *__restrict__ src, uint
         for (int k = 0; k < 7; ++k) {
             const int s = s0 + k;
             if (s >= nsteps) break;  // wave-uniform
-            const int yin = y0 - 3 + s;
+            const int yin = ystart + dir * s;
             fetch(s + BL_PF, Lr[(k + BL_PF) % 7]);  // rows past the run re-read a valid (reflected / clamped) row
             const uint32_t l0 = Lr[k][0], l1 = Lr[k][1], l2 = Lr[k][2];
             uint32_t w[3] = {l0, l1, l2};
@@ -1484,7 +1492,7 @@ __device__ __forceinline__ void blur7_walk(const uint8_t *__restrict__ src, uint
                 Sprev[j] = h;
             }
             if (s >= 6) {
-                const int y = yin - 3;
+                const int y = yin - 3 * dir;
                 uint32_t tq[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1512,7 +1520,7 @@ __device__ __forceinline__ void blur7_walk(const uint8_t *__restrict__ src, uint
                 const uint32_t h01 = pk_min_u16(__builtin_amdgcn_perm(tq[1], tq[0], 0x07060302u), 0x00FF00FFu);
                 const uint32_t h23 = pk_min_u16(__builtin_amdgcn_perm(tq[3], tq[2], 0x07060302u), 0x00FF00FFu);
                 const uint32_t packed = __builtin_amdgcn_perm(h23, h01, 0x06040200u);
-                if (active && y < yend) {
+                if (active && (uint32_t)(y - y0) < (uint32_t)(yend - y0)) {
                     uint8_t *o = dst + (__umul24((uint32_t)y, (uint32_t)dpitch) + (uint32_t)x);
                     if (full) {
                         *(uint32_t *)o = packed;
@@ -1551,10 +1559,14 @@ __global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
     nsteps = __builtin_amdgcn_readfirstlane(nsteps) + 6;  // wave-uniform
-    if (interior)
-        blur7_walk<MODE, true>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
-    else
-        blur7_walk<MODE, false>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
+    const bool up = __builtin_amdgcn_readfirstlane((int)(ld.flags & 8)) != 0;   // wave-uniform by construction, like `interior`
+    if (interior) {
+        if (up) blur7_walk<MODE, true, true>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
+        else blur7_walk<MODE, true, false>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
+    } else {
+        if (up) blur7_walk<MODE, false, true>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
+        else blur7_walk<MODE, false, false>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
+    }
 }
 
 // Blur of level l AND the resize l -> l + 1 in one pass over level l (ORBFE_FUSE_BLUR_PYR, one launch per level, chained).
@@ -1749,15 +1761,22 @@ __global__ BL_BOUNDS void k_blur_pyr(const OrbPlan *__restrict__ plan, FrameSrc 
     uint32_t Lr[7][3];
     // A wave none of whose lanes comes within 3 rows of the level's top or bottom (three of four) walks plain rows: the
     // offset advances by the pitch, no reflected row index per step.
-    const bool plain_rows = orb_ballot(!(y0 >= 3 && y0 - 3 + nsteps + BL_PF <= H)) == 0ull;
-    uint32_t ro = __umul24((uint32_t)max(y0 - 3, 0), (uint32_t)pitch) + (uint32_t)base;
+    // A lane walks its rows downwards from y0 - 3 or (flag bit 3, odd row blocks) upwards from yend + 2: the taps are symmetric,
+    // the sums are the same integers.  Row of step s: ystart + dir * s; the output row of step s lies 3 * dir behind it.
+    const bool up = false;   // the fused pass walks every row block downwards (its resize jobs complete rows top to bottom)
+    const int dir = up ? -1 : 1;
+    const int ystart = up ? yend + 2 : y0 - 3;
+    const int ylast = ystart + dir * (nsteps + BL_PF - 1);   // last row the walk asks for (incl. the prefetch past its end)
+    const bool plain_rows = orb_ballot(!(min(ystart, ylast) >= 0 && max(ystart, ylast) < H)) == 0ull;
+    uint32_t ro = __umul24((uint32_t)min(max(ystart, 0), H - 1), (uint32_t)pitch) + (uint32_t)base;
+    const uint32_t rstep = up ? 0u - (uint32_t)pitch : (uint32_t)pitch;
     auto fetch = [&](int s, uint32_t (&dst3)[3]) {
         const uint8_t *row;
         if (plain_rows) {
             row = src + ro;
-            ro += (uint32_t)pitch;
+            ro += rstep;
         } else {
-            const int yy = reflect101(min(y0 - 3 + s, H + 2), H);
+            const int yy = reflect101(max(min(ystart + dir * s, H + 2), -3), H);
             row = src + (__umul24((uint32_t)yy, (uint32_t)pitch) + (uint32_t)base);
         }
         dst3[0] = *(const uint32_t *)(row);
@@ -1784,7 +1803,7 @@ __global__ BL_BOUNDS void k_blur_pyr(const OrbPlan *__restrict__ plan, FrameSrc 
         for (int k = 0; k < 7; ++k) {
             const int s = s0 + k;
             if (s >= nsteps) break;  // wave-uniform
-            const int yin = y0 - 3 + s;
+            const int yin = ystart + dir * s;
             fetch(s + BL_PF, Lr[(k + BL_PF) % 7]);  // rows past the run re-read a valid (reflected / clamped) row
             if (inlane) {   // wave-uniform (kernel argument); absent from the SPLIT instantiation
                 rfetch(s + BL_PF, Rr[(k + BL_PF) % 7]);
