@@ -564,3 +564,30 @@ def test_fused_fast_and_pyramid_pass_equals_the_separate_kernels(oracle, monkeyp
             assert_same_output(gk, gd, outs[i][0], outs[i][1])
         ok, od = oe(frames[15])
         assert_same_output(res[15][0], res[15][1], ok, od)
+
+
+@pytest.mark.parametrize("updown", ["0", "2"])
+def test_blur_row_walk_directions_give_the_same_levels(oracle, monkeypatch, updown):
+    """ORBFE_BLUR_UPDOWN: odd row blocks of k_blur7 walk upwards (the 7 x 7 kernel is vertically symmetric) so that neighbouring
+    blocks read their shared halo rows at the same time; default 1 = only where it adds no wave, 2 = everywhere, 0 = nowhere.
+    Every setting gives the oracle's blurred levels byte for byte, in both rounding modes, on sizes whose last row block is short
+    and on single frames (short runs) as well as batches (40-row runs)."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    monkeypatch.setenv("ORBFE_BLUR_UPDOWN", updown)
+    for (w, h, nf, nlev, sf, mode, mb) in ((640, 480, 1000, 8, 1.2, 0, 16), (517, 389, 700, 6, 1.3, 1, 16), (333, 271, 400, 4, 1.5, 0, 1),
+                                           (752, 480, 1200, 8, 1.2, 1, 9)):
+        e = ORBextractor(nf, sf, nlev, 20, 7, max_width=w, max_height=h, max_batch=mb, blur_rounding=mode)
+        oe = oracle.OracleExtractor(nf, sf, nlev, 20, 7)
+        oe.set_blur_mode(mode)
+        frames = [synth_frame(900 + i, h, w, sparse=(i == 1)) for i in range(min(mb, 3))]
+        res = e.extract_batch(np.stack(frames)) if mb > 1 else [e(frames[0])]
+        for i, img in enumerate(frames):
+            ok, od = oe(img)
+            assert_same_output(res[i][0], res[i][1], ok, od)
+        # blurred levels of frame 0 of a fresh single call
+        gk, gd = e(frames[0])
+        ok, od = oe(frames[0])
+        for l in range(nlev):
+            if len(oe.selected(l)):
+                assert np.array_equal(e.blurred_level(l), oe.blurred(l)), (w, l, updown)
+        assert_same_output(gk, gd, ok, od)
