@@ -2027,12 +2027,9 @@ __global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *
     bx = __builtin_amdgcn_readfirstlane(bx);
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = lane & 15, quad = tid >> 4;  // quad 0..DS_KPW-1 inside the workgroup = one keypoint
-    int32_t cnt[ORBFE_MAX_LEVELS];
-    {
-        const int32_t *ns = nsel + b * nl;
-#pragma unroll
-        for (int l = 0; l < ORBFE_MAX_LEVELS; ++l) cnt[l] = l < nl ? ns[l] : 0;
-    }
+    // lane `sub` of every 16-lane group holds the selection count of level `sub` (ORBFE_MAX_LEVELS == 16 == the group width)
+    static_assert(ORBFE_MAX_LEVELS == 16, "level look-up: one level per lane of a 16-lane group");
+    const int cnt_l = sub < nl ? nsel[b * nl + sub] : 0;
     if (tid < nl) {
         const OrbLevel &Lt = plan->lv[tid];
         s_lv[tid] = DescLevel{Lt.sel_off, Lt.off, Lt.pitch, Lt.scale, Lt.patch_size};
@@ -2047,14 +2044,20 @@ __global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *
     __syncthreads();
 
     const int slot = bx * DS_KPW + quad;
-    int level = -1, idx = slot, total = 0;
-#pragma unroll
-    for (int l = 0; l < ORBFE_MAX_LEVELS; ++l) {
-        const int c = cnt[l];
-        if (level < 0 && idx < c) level = l;
-        if (level < 0) idx -= c;
-        total += c;
-    }
+    // The keypoint of slot `slot` (level-major slots, :1103-1112): inclusive prefix sums of the level counts across the group's
+    // lanes (four DPP row shifts), the level = number of levels whose prefix is <= slot (one ballot, the group's 16 bits of it),
+    // the index inside the level = slot - prefix of the level before.
+    int incl = cnt_l;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1 (lanes without a source add 0)
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
+    const unsigned long long below = orb_ballot(incl <= slot);
+    const int nbelow = __popc((uint32_t)(below >> (lane & 48)) & 0xFFFFu);  // levels that end at or before the slot
+    const int total = __builtin_amdgcn_readfirstlane(__shfl(incl, (lane & 48) | 15, 64));   // the same in every group: scalar
+    const int before = __shfl(incl, (lane & 48) | max(nbelow - 1, 0), 64);
+    const int level = nbelow < nl ? nbelow : -1;
+    const int idx = slot - (nbelow > 0 ? before : 0);
     if (slot == 0 && sub == 0) {
         n_out[b] = total;
         if (total > cap) atomicOr(ovf, 4);  // n_out holds the required count; slots >= cap are not written
