@@ -2090,9 +2090,14 @@ __global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *
         // rows r0, r0 + 2, ...; the 16th row of the odd lanes (31) is clamped to 30 and not used
         const uint8_t *p = img + (__umul24((uint32_t)(y - 15 + r0), (uint32_t)pitch) + (uint32_t)(x - 15 + 4 * k));
         uint32_t w[16];
+        // unaligned dwords; the pointer advances by two rows per load (one 64-bit add each instead of a multiply and an add);
+        // the last step of the odd lanes is one row (row 30, clamped)
+        const uint32_t step2 = 2u * (uint32_t)pitch, step_last = __umul24((uint32_t)(2 - r0), (uint32_t)pitch);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)  // unaligned dwords; explicit 24-bit multiplies (left alone by the compiler)
-            w[i] = *(const uint32_t *)(p + __umul24(i < 15 ? (uint32_t)(2 * i) : (uint32_t)(30 - r0), (uint32_t)pitch));
+        for (int i = 0; i < 16; ++i) {
+            w[i] = *(const uint32_t *)p;
+            p += i < 14 ? step2 : step_last;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = r0 + 2 * i;
@@ -2150,7 +2155,10 @@ __global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *
         // "+ 64 * it" rides in the load's immediate offset: three VALU operations per load (the incremental carry logic this
         // replaces took ten).
         static_assert(DS_PR == 37 && DS_PP == 40, "patch staging: LDS pitch == patch bytes");
-        const uint32_t s205 = (uint32_t)sub * 205u;
+        uint32_t s205 = (uint32_t)sub * 205u;
+        // kept as a value of its own: folded into a multiply-add with the step's constant, every load pays a register move for that
+        // constant (the multiply-add cannot take a literal next to its scalar operand); as an addend it takes the literal directly
+        asm volatile("" : "+v"(s205));
         const uint32_t bp40 = (uint32_t)bpitch - 40u;
         // uniform base + one 32-bit per-lane offset + immediate: a global_load with an SGPR base, no 64-bit address arithmetic
         const uint32_t o4 = (uint32_t)L.off + __umul24((uint32_t)(y - 18), (uint32_t)bpitch) + (uint32_t)(x - 18 + 4 * sub);
