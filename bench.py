@@ -173,11 +173,73 @@ def cpu_baseline(w, h, nfeat, budget_s=16.0, nframes=200, warmup=20):
             "host_cpus": os.cpu_count()}
 
 
+def host_cpu_report():
+    """what the CPU figures ran on: logical CPUs, the CPUs this process may run on, the cgroup quota"""
+    rep = {"logical_cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            rep["cgroup_" + os.path.basename(path)] = open(path).read().strip()
+        except OSError:
+            pass
+    try:
+        model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")]
+        rep["cpu_model"] = model[0] if model else None
+    except OSError:
+        pass
+    q = rep.get("cgroup_cpu.max", "max").split()
+    rep["usable_cpus"] = rep["affinity_cpus"] or rep["logical_cpus"]
+    if q and q[0] != "max" and len(q) == 2:
+        rep["usable_cpus"] = max(1, min(rep["usable_cpus"], int(float(q[0]) / float(q[1]))))
+    return rep
+
+
+def cpu_baseline_vectorised(w, h, nfeat, budget_s=8.0, nframes=120, warmup=10):
+    """The same measurement as cpu_baseline on oracle/_ref/libref_orb_vec.so: the same unmodified reference ORBextractor.cc and the
+    same five OpenCV stand-ins, built -O3 -mavx2 (auto-vectorised, -ffp-contract=off) -- the nearest thing to "the reference
+    over a real SIMD OpenCV" this box allows.  Its outputs are asserted equal to the -O2 build's before it is timed."""
+    from oracle import oracle_ffi as O
+    try:
+        from oracle import ref_ffi as R
+        if not (R.vectorised_available() and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_orb.so"))):
+            return None
+    except Exception:
+        return None
+    frames = [synth_frame(10000 + i, h, w) for i in range(8)]
+    R.configure(bump=True, canonical_trig=True, blur_mode=0)
+    k0, d0 = R.RefExtractor(nfeat, 1.2, 8, 20, 7)(frames[0])
+    with R.use_vectorised():
+        R.configure(bump=True, canonical_trig=True, blur_mode=0)
+        e = R.RefExtractor(nfeat, 1.2, 8, 20, 7)
+        k1, d1 = e(frames[0])
+        if not (np.array_equal(k0.view(np.uint8), k1.view(np.uint8)) and np.array_equal(d0, d1)):
+            raise SystemExit("bench.py: the -O3 -mavx2 build of the reference differs from the -O2 build")
+        prev, times, n = None, [], 0
+        t_start = time.perf_counter()
+        while len(times) < nframes and time.perf_counter() - t_start < budget_s:
+            t0 = time.perf_counter()
+            k, d = e(frames[n % len(frames)])
+            if prev is not None:
+                O.match_bf(d, prev[1], k["angle"], prev[0]["angle"], 0.9, 100, True)
+            dt = time.perf_counter() - t0
+            prev = (k, d)
+            n += 1
+            if n > warmup:
+                times.append(dt)
+        del e
+    med = float(np.median(times))
+    return {"value": round(1.0 / med, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+            "sample": f"median per-frame time of {len(times)} synthetic {w}x{h} frames S(seed) after {warmup} warm-up frames, {nfeat} features, "
+                      "extract + BF match to previous frame, oracle/_ref/libref_orb_vec.so (unmodified reference ORBextractor.cc + the cv "
+                      "stub's OpenCV stand-ins, g++ -O3 -mavx2 -ffp-contract=off; outputs asserted identical to the -O2 build) + oracle BF "
+                      "match, single thread", "host": host_cpu_report()}
+
+
 def cpu_baseline_all_cores(w, h, nfeat, duration_s=6.0, max_procs=None):
     """One frame stream per host CPU -- ALL of them, as SURVEY 8(d) asks (the reference extractor is serial per call):
     independent worker processes (oracle/cpu_worker.py), all started on a common wall-clock tick.  kind "reference" when
     oracle/_ref/libref_orb.so is there (the unmodified reference ORBextractor.cc over the cv stub), else "port"."""
-    procs = os.cpu_count() or 1
+    host = host_cpu_report()
+    procs = host["usable_cpus"] or os.cpu_count() or 1   # the CPUs this process may actually use (affinity mask, cgroup quota)
     if max_procs:
         procs = min(procs, max_procs)
     kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_orb.so")) else "port"
@@ -196,7 +258,8 @@ def cpu_baseline_all_cores(w, h, nfeat, duration_s=6.0, max_procs=None):
         except Exception:
             pass
     return {"value": round(frames / duration_s, 2), "unit": "frames/s", "cores": procs, "kind": kind, "late_starters": late,
-            "sample": f"{procs} processes (one per logical host CPU) x {duration_s:.0f} s, each its own stream of {w}x{h} S(seed) "
+            "per_process_frames_per_s": round(frames / duration_s / procs, 3), "host": host,
+            "sample": f"{procs} processes (one per CPU this process may use: affinity mask / cgroup quota, see host) x {duration_s:.0f} s, each its own stream of {w}x{h} S(seed) "
                       f"frames, extract + BF match to previous frame, "
                       + ("oracle/_ref (unmodified reference ORBextractor.cc, cv stub) + oracle BF match" if kind == "reference"
                          else "oracle/orb_oracle.c"), "host_cpus": os.cpu_count()}
@@ -206,98 +269,59 @@ def cpu_baseline_all_cores(w, h, nfeat, duration_s=6.0, max_procs=None):
 # the engines: HIP (the product) and the CPU stand-in used by the spawn-path test
 # ----------------------------------------------------------------------------------------------------------------
 class HipEngine:
-    """Owns the extractor / matcher handles, the output sets and the launch sequence of one step."""
+    """One step = ONE call of the library's sequence pipeline (include/orbfe.h orbfe_pipeline_extract_match_device): the B
+    resident frames of the step are a sequence; the library cuts it into sub-batches of F frames on P pipes (extractor +
+    matcher + stream each), matches frame k against frame k - 1 across sub-batch boundaries, and -- ORBFE_PIPE_CONTINUE --
+    frame 0 of a step against the last frame of the previous step.  Nothing of the pipeline lives in this file."""
 
-    def __init__(self, args, local_rank, nfeatures, frames_per_launch, launches, world):
-        from orb_slam2_ssd_semantic_amd import ORBextractor, ORBmatcher, _ffi
+    def __init__(self, args, local_rank, nfeatures, frames_per_launch, launches, world, device=None):
+        from orb_slam2_ssd_semantic_amd import FramePipeline, _ffi
         self.ffi = _ffi
         self.L = _ffi.lib()
         self.w, self.h, self.F, self.nl = args.width, args.height, frames_per_launch, launches
         self.match = not args.no_match
-        self.ext = ORBextractor(nfeatures, 1.2, 8, 20, 7, max_width=self.w, max_height=self.h, max_batch=self.F,
-                                device=local_rank)
-        # ORBFE_BENCH_PIPES=P: P extractor handles (each with its own pyramids / candidate buffers) on P streams, sub-batch j on
-        # pipe j % P, so that the VALU-bound FAST pass of one sub-batch can share the chip with the HBM/LDS-bound stages of
-        # its neighbour
-        self.P = max(1, int(os.environ.get("ORBFE_BENCH_PIPES", "3")))
-        self.exts = [self.ext] + [ORBextractor(nfeatures, 1.2, 8, 20, 7, max_width=self.w, max_height=self.h, max_batch=self.F,
-                                               device=local_rank) for _ in range(self.P - 1)]
-        self.pipe_streams = [None] + [torch.cuda.Stream(device=local_rank) for _ in range(self.P - 1)]
-        if os.environ.get("ORBFE_BENCH_PRIO"):   # experiment: stream priorities of the pipes, e.g. "-1,0,1"
-            pr = [int(x) for x in os.environ["ORBFE_BENCH_PRIO"].split(",")]
-            self.pipe_streams = [torch.cuda.Stream(device=local_rank, priority=pr[i % len(pr)]) for i in range(self.P)]
-        self.mat = ORBmatcher(0.9, True, device=local_rank)
-        self.mats = [self.mat] + [ORBmatcher(0.9, True, device=local_rank) for _ in range(self.P - 1)]
-        self.one_pipe = False   # True: everything on pipe 0 (the exclusive stage times of the report)
-        # One GPU: nothing consumes a step's outputs before the timed region's closing fence, and sub-batch j of every step runs on
-        # the same pipe (its slices are stream-ordered), so the pipes are not joined at step boundaries -- 24 sub-batches, then
-        # the next 24, back to back.  With N > 1 the gather consumes every step: the pipes join the current stream at its end.
-        self.free_run = world == 1 and os.environ.get("ORBFE_BENCH_STEP_JOIN", "0") != "1"
-        self.cap = self.ext.capacity()
+        dev = local_rank if device is None else device
+        self.P = max(1, args.pipes)
+        self.pl = FramePipeline(nfeatures, 1.2, 8, 20, 7, max_width=self.w, max_height=self.h, sub_batch=self.F, npipes=self.P,
+                                device=dev, blur_rounding=args.blur_rounding, nnratio=0.9, th=100, check_ori=True)
+        self.exts, self.mats = self.pl.extractors, self.pl.matchers
+        self.ext, self.mat = self.exts[0], self.mats[0]
+        # One GPU: nothing consumes a step's outputs before the timed region's closing fence, so the steps run back to back
+        # (ORBFE_PIPE_NO_JOIN: the pipes are not drained at step boundaries; the library orders the re-use of the output blocks
+        # with events).  With N > 1 the gather consumes every step: the call joins the launch stream.
+        self.free_run = world == 1 and not args.step_join
+        self.cap = self.pl.capacity()
         B = self.F * self.nl
         self.B = B
         nsets = 2 if world > 1 else 1   # with N > 1 the gather of step k overlaps the kernels of step k+1
         self.outs = [(torch.zeros((B, self.cap, 7), dtype=torch.int32, device="cuda"),
                       torch.zeros((B, self.cap, 32), dtype=torch.uint8, device="cuda"),
                       torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(nsets)]
-        self.qf = torch.arange(0, self.F, dtype=torch.int32, device="cuda")
-        self.tf = (torch.arange(0, self.F, dtype=torch.int32, device="cuda") + (self.F - 1)) % self.F  # predecessor
         self.d_match = torch.zeros((B, self.cap), dtype=torch.int32, device="cuda")
         self.d_nm = torch.zeros(B, dtype=torch.int32, device="cuda")
-        # The matcher of sub-batch j only reads what the extractor wrote for j and writes its own slices, so it runs on a
-        # stream of its own behind an event: its matrix-core / VALU work then overlaps the HBM-bound pyramid of sub-batch
-        # j + 1 instead of standing in line (ORBFE_BENCH_MATCH_STREAM=0 puts it back on the extractor's stream).
-        self.match_stream = torch.cuda.Stream(device=local_rank) if os.environ.get("ORBFE_BENCH_MATCH_STREAM", "1") != "0" else None
-        self.ev = [torch.cuda.Event() for _ in range(4)]
+        # pairs (i, i - 1) of one sub-batch, for the matcher-alone timing of the stage table
+        self.qf = torch.arange(1, self.F, dtype=torch.int32, device="cuda")
+        self.tf = self.qf - 1
 
-    def launch(self, d_gray, j, out_set, stream):
-        """sub-batch j of the resident batch d_gray [B, h, w] -> slices j of the output set"""
+    def step(self, d_gray, out_set, stream, nframes=None, flags=None):
+        """the whole resident batch d_gray [B, h, w] -> output set `out_set` (+ match rows)"""
         kps, desc, n = self.outs[out_set]
-        F, w, h = self.F, self.w, self.h
-        lo = j * F
-        p = j % self.P
-        if self.P > 1 and not self.one_pipe:
-            return self.launch_pipe(d_gray, j, out_set, p)
-        self.ext.extract_batch_device(d_gray[lo].data_ptr(), F, w, h, w, w * h, kps[lo].data_ptr(), desc[lo].data_ptr(),
-                                      self.cap, n[lo:].data_ptr(), stream)
-        if self.match:
-            ms = stream
-            if self.match_stream is not None:
-                ev = self.ev[j % len(self.ev)]
-                ev.record(torch.cuda.current_stream())   # `stream` is the current stream's handle
-                self.match_stream.wait_event(ev)
-                ms = self.match_stream.cuda_stream
-            rc = self.L.orbfe_match_bf_frames_device(self.mat.handle, kps[lo].data_ptr(), desc[lo].data_ptr(),
-                                                     n[lo:].data_ptr(), self.cap, self.qf.data_ptr(), self.tf.data_ptr(), F,
-                                                     0.9, 100, 1, self.d_match[lo].data_ptr(), self.d_nm[lo:].data_ptr(), ms)
-            self.ffi.check(rc, "orbfe_match_bf_frames_device")
+        B = self.B if nframes is None else nframes
+        if flags is None:
+            flags = self.pl.CONTINUE | (self.pl.NO_JOIN if self.free_run else 0)
+        self.pl.extract_match_device(d_gray.data_ptr(), B, self.w, self.h, self.w, self.w * self.h, kps.data_ptr(), desc.data_ptr(),
+                                     self.cap, n.data_ptr(), self.d_match.data_ptr() if self.match else None,
+                                     self.d_nm.data_ptr() if self.match else None, flags=flags, stream=stream)
 
-    def launch_pipe(self, d_gray, j, out_set, p):
-        kps, desc, n = self.outs[out_set]
+    def one_pipe_pass(self, d_gray, stream):
+        """every sub-batch of the step through pipe 0's extractor ALONE on `stream` (nothing beside it on the chip): the
+        exclusive stage times of the report"""
+        kps, desc, n = self.outs[0]
         F, w, h = self.F, self.w, self.h
-        lo = j * F
-        cur = torch.cuda.current_stream()
-        st = self.pipe_streams[p] or cur
-        if j < self.P and st is not cur and not self.free_run:
-            st.wait_stream(cur)   # the step starts after what the current stream held (previous step's consumers)
-        self.exts[p].extract_batch_device(d_gray[lo].data_ptr(), F, w, h, w, w * h, kps[lo].data_ptr(), desc[lo].data_ptr(),
-                                          self.cap, n[lo:].data_ptr(), st.cuda_stream)
-        if self.match:
-            rc = self.L.orbfe_match_bf_frames_device(self.mats[p].handle, kps[lo].data_ptr(), desc[lo].data_ptr(),
-                                                     n[lo:].data_ptr(), self.cap, self.qf.data_ptr(), self.tf.data_ptr(), F,
-                                                     0.9, 100, 1, self.d_match[lo].data_ptr(), self.d_nm[lo:].data_ptr(),
-                                                     st.cuda_stream)
-            self.ffi.check(rc, "orbfe_match_bf_frames_device")
-
-    def end_step(self):
-        """everything of the step is ordered before what follows on the current stream (gather, the next use of the set)"""
-        if self.free_run:
-            return
-        for st in self.pipe_streams[1:]:
-            if st is not None:
-                torch.cuda.current_stream().wait_stream(st)
-        if self.match and self.match_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.match_stream)
+        for j in range(self.nl):
+            lo = j * F
+            self.ext.extract_batch_device(d_gray[lo].data_ptr(), F, w, h, w, w * h, kps[lo].data_ptr(), desc[lo].data_ptr(), self.cap,
+                                          n[lo:].data_ptr(), stream)
 
 
 class FakeEngine:
@@ -312,13 +336,12 @@ class FakeEngine:
         self.outs = [(torch.zeros((self.B, self.cap, 7), dtype=torch.int32), torch.zeros((self.B, self.cap, 32), dtype=torch.uint8),
                       torch.zeros(self.B, dtype=torch.int32)) for _ in range(nsets)]
 
-    def launch(self, d_gray, j, out_set, stream):
+    def step(self, d_gray, out_set, stream):
         kps, desc, n = self.outs[out_set]
-        lo = j * self.F
-        s = d_gray[lo:lo + self.F].reshape(self.F, -1)[:, :self.cap].to(torch.int32)
-        n[lo:lo + self.F] = 1 + (s[:, 0] % (self.cap - 1))
-        kps[lo:lo + self.F, :, 0] = s
-        desc[lo:lo + self.F, :, 0] = s.to(torch.uint8)
+        s = d_gray.reshape(self.B, -1)[:, :self.cap].to(torch.int32)
+        n[:] = 1 + (s[:, 0] % (self.cap - 1))
+        kps[:, :, 0] = s
+        desc[:, :, 0] = s.to(torch.uint8)
 
 
 class c_stdout_to_stderr:
@@ -362,9 +385,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per launch (sub-batch) per GPU")
-    ap.add_argument("--launches", type=int, default=24, help="sub-batches per step: a step covers frames x launches "
-                    "resident frames per GPU (default 24 576: twenty steps are > 2 s of GPU work)")
+    ap.add_argument("--frames", type=int, default=1024, help="frames per sub-batch of the library's pipeline")
+    ap.add_argument("--launches", type=int, default=24, help="sub-batches per step: a step is ONE pipeline call over frames x "
+                    "launches resident frames per GPU (default 24 576: twenty steps are > 1.5 s of GPU work)")
+    ap.add_argument("--pipes", type=int, default=int(os.environ.get("ORBFE_BENCH_PIPES", "3")), help="pipes of the pipeline")
+    ap.add_argument("--step-join", action="store_true", help="join the launch stream after every step even on one GPU")
+    ap.add_argument("--blur-rounding", type=int, default=0, help="GaussianBlur column rounding: 0 canonical half-up, 1 = the x86 "
+                    "SSE2 kernel's (what an x86-64 OpenCV <= 3.3 binary computes); value_blur_mode1 reports the other one")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
@@ -381,6 +408,10 @@ def main():
                     help="bow: print the line of the device-resident ComputeBoW -> SearchByBoW chain instead; config5: the "
                          "line of BASELINE config 5 (512 resident 1920x1080 frames, 4000 features, one batched call)")
     ap.add_argument("--fake", action="store_true", help="CPU stand-in over gloo (spawn-path test only)")
+    ap.add_argument("--same-device", action="store_true", help="TEST MODE: all ranks of an N > 1 run share GPU 0 (the exchange goes "
+                    "through a host-staged gloo group, RCCL refuses two ranks per device).  Exercises every N > 1 code path with "
+                    "real kernels on a one-GPU box; the line says same_device: true and is never a scaling figure")
+    ap.add_argument("--config4-batch", type=int, default=1024, help="global batch of the config-4 leg (tests: an uneven 1023)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -393,19 +424,28 @@ def main():
               f"wrong number of GPUs", file=sys.stderr)
         sys.exit(2)
     fake = args.fake
+    same = bool(args.same_device) and world > 1 and not fake
+    if same:
+        local_rank = 0
+    args.same = same
     if not fake:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
         torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from datetime import timedelta
         if fake:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        elif same:
+            # every rank on device 0: CPU-side groups only; "gather" is used by the gather worker thread alone
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=900))
+            CTL["gather"] = dist.new_group(backend="gloo", timeout=timedelta(seconds=900))
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if not fake:
             # two CPU-side control groups for the guarded config-4 leg (config4_group_guarded): one for the main thread, one for
             # the worker thread that drives the library's own RCCL communicator
-            from datetime import timedelta
             CTL["main"] = dist.new_group(backend="gloo", timeout=timedelta(seconds=900))
             CTL["leg"] = dist.new_group(backend="gloo", timeout=timedelta(seconds=300))
     dev = "cpu" if fake else "cuda"
@@ -434,16 +474,16 @@ def main():
     Engine = FakeEngine if fake else HipEngine
     eng = Engine(args, local_rank, nf, F, NL, world)
     if not fake:
-        for e in getattr(eng, 'exts', [eng.ext]):
-            e.set_fast_mode(args.fast_mode)
-    # the resident batch: `--seeds` DISTINCT generator seeds (default 1024 = one whole launch of different images), expanded to
+        eng.pl.set_fast_mode(args.fast_mode)
+    # the resident batch: `--seeds` DISTINCT generator seeds (default 1024 = one whole sub-batch of different images), expanded to
     # the B frames of a step by lossless roll / flip transforms of that set (every frame a different image)
     nbase = min(B, args.seeds)
     base = torch.from_numpy(base_frames(args.workload, nbase, w, h, 10000 + rank * 4096)).to(dev)
     d_gray = expand_frames(base, B)
     stream = None if fake else torch.cuda.current_stream().cuda_stream
     # (n, kps, desc) order of distributed.all_gather_keyframes
-    gather = OverlappedKeyframeGather([(o[2], o[0], o[1]) for o in eng.outs]) if world > 1 else None
+    gather = (OverlappedKeyframeGather([(o[2], o[0], o[1]) for o in eng.outs], group=CTL.get("gather"), host_staged=same)
+              if world > 1 else None)
     counter = [0]
 
     def step():
@@ -451,55 +491,35 @@ def main():
         counter[0] += 1
         if gather:
             gather.acquire(k)  # set k is free once its previous gather (two steps ago) has read it (stream-level wait)
-        for j in range(NL):
-            eng.launch(d_gray, j, k, stream)
-        if hasattr(eng, "end_step"):
-            eng.end_step()
+        eng.step(d_gray, k, stream)   # ONE call of the library's pipeline; with N > 1 it joins the launch stream
         if gather:
             # the one exchange step of the batched keyframe mode, asynchronous: RCCL runs on its own stream after the
             # kernels above and overlaps the next step's kernels
             gather.launch(k)
 
+    def timed(nsteps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        if not fake and world == 1:
+            eng.pl.synchronize()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (fake or same) else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     for _ in range(args.warmup):
         step()
-    fence()
-    if not fake:
-        eng.ext.set_profiling(True)  # HIP events on the launch stream around every stage of the timed calls
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(args.steps)
     if gather:  # retire the work handles of the last gathers (already complete: fence() synchronised the device)
         for k in range(len(eng.outs)):
             gather.acquire(k)
-    stage = None
-    if not fake:
-        stage = eng.ext.stage_ms()
-        eng.ext.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     total_frames = B * world * args.steps
     value = total_frames / elapsed
-
-    # The same step with the north star's formulation of the all-pairs matcher (xor + v_bcnt popcount, k_match_popc) instead of
-    # the default exact int8 dot product on the matrix cores (k_match_bf): identical results, reported next to `value`.
-    value_popc = None
-    if not fake and world == 1 and not args.no_match and not args.no_extras:
-        for m in eng.mats:
-            m.set_bf_kernel(1)
-        step()
-        fence()
-        t1 = time.perf_counter()
-        nsteps_popc = max(2, args.steps // 4)
-        for _ in range(nsteps_popc):
-            step()
-        fence()
-        value_popc = B * nsteps_popc / (time.perf_counter() - t1)
-        for m in eng.mats:
-            m.set_bf_kernel(0)
 
     result = None
     if rank == 0:
@@ -509,15 +529,18 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("BASELINE config 3 shape, HBM-RESIDENT inputs (the PCIe-inclusive rate of the same pipeline "
-                                    "is `pcie_inclusive`): %dx%d synthetic frames %s(seed) (S / S_tum: no TUM data on the box), %d "
-                                    "features, 8 levels, %s; %d frames per GPU per step in %d launches of %d%s; exactness is "
+                                    "is `value_pcie_inclusive`): %dx%d synthetic frames %s(seed) (S / S_tum: no TUM data on the box), %d "
+                                    "features, 8 levels, %s; a step = ONE call of the library's sequence pipeline "
+                                    "(orbfe_pipeline_extract_match_device) over %d resident frames per GPU = %d sub-batches of %d on %d "
+                                    "pipes, frame k matched against frame k - 1 across sub-batches and steps%s; exactness is "
                                     "checked against the in-repo oracle, which is pinned to the compiled reference "
                                     "(tests/test_ref_pin.py)") %
                                    (w, h, args.workload, nf, "extract only" if args.no_match else
-                                    "extract + brute-force Hamming match to previous frame (nnratio 0.9, TH_HIGH 100, rot. hist.)",
-                                    B, NL, F, ", asynchronous all-gather of counts/keypoints/descriptors per step" if world > 1 else ""),
+                                    "extract + brute-force Hamming match to the previous frame (nnratio 0.9, TH_HIGH 100, rot. hist.)",
+                                    B, NL, F, getattr(eng, "P", 1),
+                                    ", asynchronous all-gather of counts/keypoints/descriptors per step" if world > 1 else ""),
                        "frames_per_gpu_per_step": B, "frames_per_launch": F, "width": w, "height": h, "nfeatures": nf,
-                       "workload_name": args.workload,
+                       "workload_name": args.workload, "pipes": getattr(eng, "P", 1), "blur_rounding": args.blur_rounding,
                        "value_is": "value_hbm_resident (bench contract: inputs resident in HBM when the timed region starts); SURVEY "
                                    "8(d) row 3 as worded -- host frames in, host results out -- is value_pcie_inclusive",
                        "match_kernel": None if args.no_match else "mfma_i8 (k_match_bf: exact int8 dot product on the matrix cores; "
@@ -525,19 +548,17 @@ def main():
                                        "value_match_popc)",
                        "generator_seeds": int(min(B, args.seeds)),
                        "parallelism": f"frames sharded over {world} GPU(s), one process per GPU",
-                       "streams": (f"{eng.P} extractor / matcher handle pairs on {eng.P} streams, sub-batch j on pipe j mod {eng.P}: the "
-                                   "VALU-bound FAST pass of one sub-batch shares the chip with the HBM / LDS-bound stages of its "
-                                   "neighbours (ORBFE_BENCH_PIPES)" + ("; the pipes run the K steps back to back, joined by the closing "
-                                   "fence only (one GPU: no consumer between steps)" if getattr(eng, "free_run", False) else
-                                   "; the pipes join the launch stream at the end of every step (the gather consumes it)")
-                                   if getattr(eng, "P", 1) > 1 else
-                                   "extractor on the launch stream (blur on the library's side stream), matcher of sub-batch j on a "
-                                   "second stream behind an event, next to the pyramid of sub-batch j+1"
-                                   if getattr(eng, "match_stream", None) is not None else "one stream")},
+                       "streams": ("the library's pipeline: %d pipes (extractor + matcher + stream each), sub-batch j on pipe j mod %d; %s"
+                                   % (getattr(eng, "P", 1), getattr(eng, "P", 1),
+                                      "steps run back to back (ORBFE_PIPE_NO_JOIN), joined by the closing fence only (one GPU: no consumer "
+                                      "between steps)" if getattr(eng, "free_run", False) else
+                                      "every step joins the launch stream (the gather consumes it)"))},
         }
         result["value_hbm_resident"] = result["value"]
-        if value_popc is not None:
-            result["value_match_popc"] = round(value_popc, 2)
+        if same:
+            result["same_device"] = True
+            result["config"]["workload"] = ("SAME-DEVICE TEST MODE -- %d ranks share ONE GPU, host-staged gloo exchange: exercises the N > 1 "
+                                            "code paths with real kernels, NOT a scaling measurement.  " % world) + result["config"]["workload"]
         if fake:
             result["fake"] = True
             result["config"]["workload"] = "FAKE CPU stand-in (spawn-path test), not a measurement"
@@ -548,8 +569,14 @@ def main():
             result["exact_checked"] = False   # profiling runs: no oracle in the process
         else:
             result.update(self_check(eng, d_gray, (counter[0] - 1) % len(eng.outs), nf))
+    if not fake and world > 1 and not args.no_extras:
+        chk = gathered_check(eng, gather, d_gray, (counter[0] - 1) % len(eng.outs), nf, rank, world)
+        if rank == 0:
+            result.update(chk)
     if not fake:
-        extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fence)
+        extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, step, timed)
+    if gather:
+        gather.close()
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)   # anything a native library left in the C stdout buffer goes out BEFORE the line
@@ -567,16 +594,54 @@ def main():
     os.dup2(2, 1)   # nothing may follow the JSON line on stdout (buffers flushed at exit by native libraries)
 
 
-def self_check(eng, d_gray, out_set, nf, seed=2026):
+def gathered_check(eng, gather, d_gray, out_set, nf, rank, world):
+    """N > 1: frames of ANOTHER rank's shard, as they arrived through the all-gather, against the oracle.  Every rank sends
+    rank 0 two of its input frames (CPU-side group); rank 0 extracts them with the oracle and compares them with the rows of
+    the gathered blocks that belong to that rank."""
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE
+    B = eng.B
+    n_all, k_all, d_all = gather.result(out_set)
+    torch.cuda.synchronize()
+    picks = [0, B // 2 + 7]
+    mine = torch.stack([d_gray[f] for f in picks]).cpu()
+    bucket = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, bucket, dst=0, group=CTL.get("main"))
+    if rank != 0:
+        return {}
+    from oracle import oracle_ffi as O
+    oe = O.OracleExtractor(nf, 1.2, 8, 20, 7)
+    checked = []
+    for r in range(world):
+        if r == 0 and world > 1:
+            continue
+        for i, f in enumerate(picks):
+            ok, od = oe(bucket[r][i].numpy())
+            row = r * B + f
+            nd = int(n_all[row].item())
+            gk = k_all[row, :nd].cpu().numpy().copy().view(KP_DTYPE).reshape(-1)
+            if not (nd == len(ok) and np.array_equal(gk.view(np.uint8), ok.view(np.uint8)) and np.array_equal(d_all[row, :nd].cpu().numpy(), od)):
+                raise SystemExit(f"bench.py: frame {f} of rank {r}, read from the gathered blocks on rank 0, differs from the oracle")
+            checked.append({"rank": r, "frame": f, "keypoints": nd})
+    return {"gathered_exact_checked": True, "gathered_exact_checked_frames": checked}
+
+
+def self_check(eng, d_gray, out_set, nf, seed=2026, blur_mode=None, nrandom=8):
     """The output of the TIMED region itself against the oracle (pinned to the compiled reference, tests/test_ref_pin.py):
-    frame 0 and one random frame of the last timed step's output set -- count, every keypoint field bit pattern, every
-    descriptor byte, order -- and their brute-force matches against the predecessor frame.  Checker use of oracle/ only."""
+    a dozen frames of the last timed step's output set -- count, every keypoint field bit pattern, every descriptor byte,
+    order -- and their brute-force matches against the predecessor frame, including the pairs that straddle a sub-batch
+    boundary and the step boundary.  Checker use of oracle/ only."""
     from oracle import oracle_ffi as O
     from orb_slam2_ssd_semantic_amd import KP_DTYPE
     kps, desc, n = eng.outs[out_set]
     F, B = eng.F, eng.B
     oe = O.OracleExtractor(nf, 1.2, 8, 20, 7)
-    frames = [0, int(np.random.default_rng(seed).integers(1, B))] if B > 1 else [0]
+    bm = getattr(getattr(eng, "pl", None), "blur_rounding", 0) if blur_mode is None else blur_mode
+    if bm:
+        oe.set_blur_mode(bm)
+    # frame 0 (its predecessor is the LAST frame of the previous step: ORBFE_PIPE_CONTINUE), the first frames of two sub-batches
+    # (predecessor extracted on another pipe), the last frame, and eight random ones
+    frames = sorted(set([0, B - 1] + [j * F for j in (1, 2) if j * F < B] +
+                        [int(v) for v in np.random.default_rng(seed).integers(1, B, nrandom)])) if B > 1 else [0]
     cache = {}
 
     def oracle_frame(f):
@@ -595,8 +660,7 @@ def self_check(eng, d_gray, out_set, nf, seed=2026):
                              f"({nd} vs {len(ok)} keypoints)")
         row = {"frame": f, "keypoints": nd}
         if eng.match:
-            lo = (f // F) * F
-            pf = lo + (f - lo + F - 1) % F
+            pf = (f - 1) % B   # a real sequence; the steps repeat the same resident batch, so frame 0 follows frame B - 1
             pk, pd = oracle_frame(pf)
             rm, _, _, rn = O.match_bf(od, pd, ok["angle"], pk["angle"], 0.9, 100, True)
             gm = eng.d_match[f, :nd].cpu().numpy()
@@ -621,7 +685,10 @@ def stage_report(ext, stage, mean_kp, w, h, nf, F, workload, local_rank):
         return tab[name] * F / (stage_k[name] * 1e-3) / 1e9 if stage_k[name] > 0 else 0.0
     kname = {"pyramid": "k_pyr_walk (7 launches)", "fast": "k_fast_map", "octree": "k_octree",
              "blur": "k_blur7", "describe": "k_orient_describe"}
-    roof = {"bound": "hbm", "kernel": kname[dom], "achieved": round(gbs(dom), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # k_fast_map is bound by VALU issue (VALUBusy 0.92: profiles/*_pmc_valubusy.json), not by HBM: the label says so; achieved /
+    # peak / frac stay the HBM figures the contract defines (algorithmic bytes / kernel time against 8 TB/s), valu_frac beside them
+    roof = {"bound": "valu" if dom == "fast" else "hbm", "frac_is": "hbm: achieved / peak", "kernel": kname[dom],
+            "achieved": round(gbs(dom), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs(dom) / HBM_PEAK_GBS, 5), "traffic": None,
             "algorithmic_bytes_per_launch": int(ab[dom] * F), "launch_ms": round(stage_k[dom], 4),
             "frames_per_launch": F}
@@ -648,6 +715,7 @@ def stage_report(ext, stage, mean_kp, w, h, nf, F, workload, local_rank):
             vc["lane_valu_insts_per_pixel"] = round(nv * 64 / (F * sum(P)), 2)
             vc["clk_per_wave_valu_inst_per_simd"] = round(stage_k[dom] * 1e-3 * clk * N_SIMD / nv, 3)
         roof["valu_ceiling"] = vc
+        roof["valu_frac"] = vc["valu_busy_frac"]
     name, pj = profile_for_shape("_pmc_hbm.json", shape)
     if pj and kn in pj.get("FETCH_SIZE_KB", {}):
         # gfx950: FETCH_SIZE reports half of the read bytes (calibrated on this repo's access shapes,
@@ -680,100 +748,167 @@ def stage_report(ext, stage, mean_kp, w, h, nf, F, workload, local_rank):
     return roof, stages, ncand
 
 
-def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fence):
-    """Everything besides the timed region: stage table + roofline, PCIe-inclusive leg, S_tum leg, config 4, CPU legs."""
-    from orb_slam2_ssd_semantic_amd import ORBextractor
-    w, h, F, NL, nf = args.width, args.height, args.frames, args.launches, args.nfeatures
-    stream = torch.cuda.current_stream().cuda_stream
+def exclusive_stage_pass(eng, d_gray, stream, local_rank):
+    """ONE table of stage times, ONE mode: every sub-batch of a step through pipe 0's extractor alone, ORBFE_OPT_OVERLAP = 0
+    (every kernel in line on one stream, nothing beside it on the chip), the library's HIP events on that stream around every
+    stage, averaged over the step's sub-batches; then the matcher alone on the same stream.  ms per sub-batch of F frames."""
     ext = eng.ext
-    n_host = eng.outs[0][2].cpu().numpy()
-
-    # matcher kernel time (torch's current stream = the launch stream, so torch events bracket it correctly)
+    ext.set_option("overlap", 0)
+    eng.one_pipe_pass(d_gray, stream)       # warm-up in this mode
+    torch.cuda.synchronize()
+    ext.set_profiling(True)
+    eng.one_pipe_pass(d_gray, stream)
+    torch.cuda.synchronize()
+    st = ext.stage_ms()
+    ext.set_profiling(False)
+    ext.set_option("overlap", -1)
     match_ms = 0.0
     if eng.match:
         kps, desc, n = eng.outs[0]
+        F = eng.F
         m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         m0.record()
-        for _ in range(5):
+        for _ in range(5):   # F - 1 pairs (i, i - 1) of one sub-batch
             eng.L.orbfe_match_bf_frames_device(eng.mat.handle, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), eng.cap,
-                                               eng.qf.data_ptr(), eng.tf.data_ptr(), F, 0.9, 100, 1, eng.d_match.data_ptr(),
-                                               eng.d_nm.data_ptr(), stream)
+                                               eng.qf.data_ptr(), eng.tf.data_ptr(), F - 1, 0.9, 100, 1, eng.d_match[1].data_ptr(),
+                                               eng.d_nm[1:].data_ptr(), stream)
         m1.record()
         torch.cuda.synchronize()
         match_ms = m0.elapsed_time(m1) / 5
+    st["match"] = match_ms
+    return st
+
+
+def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, step, timed):
+    """Everything besides the timed region: stage table + roofline, PCIe-inclusive leg, S_tum leg, config 4, CPU legs."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    w, h, F, NL, nf = args.width, args.height, args.frames, args.launches, args.nfeatures
+    B = F * NL
+    stream = torch.cuda.current_stream().cuda_stream
+    ext = eng.ext
+    torch.cuda.synchronize()
+    n_host = eng.outs[0][2].cpu().numpy()
 
     if rank == 0:
-        # one more launch so the taps (candidate lists) belong to frame 0 of sub-batch 0
-        eng.launch(d_gray, 0, 0, stream)
-        torch.cuda.synchronize()
-        assert ext.overflow() == 0, "device-side capacity overflow during the timed region"
+        stage = exclusive_stage_pass(eng, d_gray, stream, local_rank)
+        # the taps (candidate lists) now belong to frame 0 of the LAST sub-batch pipe 0's extractor ran
+        assert eng.pl.overflow() == 0, "device-side capacity overflow during the timed region"
         roof, stages, ncand = stage_report(ext, stage, float(n_host.mean()), w, h, nf, F, args.workload, local_rank)
-        stages["match_ms"] = round(match_ms, 4)
-        if match_ms > 0:
+        stages["match_ms"] = round(stage["match"], 4)
+        if stage["match"] > 0:
             nn = n_host[:F].astype(np.float64)
-            stages["match_Gdist_per_s"] = round(float((nn * np.roll(nn, 1)).sum()) / (match_ms * 1e-3) / 1e9, 2)
-        if getattr(eng, "P", 1) > 1:
-            # In the timed region the kernels of P sub-batches share the chip, so a stage's event interval there contains
-            # other pipes' work.  One more pass on pipe 0 alone gives each stage's own duration.
-            eng.one_pipe = True
-            ext.set_profiling(True)
-            for j in range(NL):
-                eng.launch(d_gray, j, 0, stream)
-            eng.end_step()
-            torch.cuda.synchronize()
-            stage1 = ext.stage_ms()
-            ext.set_profiling(False)
-            eng.one_pipe = False
-            roof1, stages1, _ = stage_report(ext, stage1, float(n_host.mean()), w, h, nf, F, args.workload, local_rank)
-            roof1["launch_ms_in_timed_region"] = roof["launch_ms"]
-            roof1["achieved_in_timed_region"] = roof["achieved"]
-            roof1["note"] = (f"In the timed region {eng.P} sub-batches are in flight on as many streams and share the CUs, so the "
-                             "event interval of a kernel there (launch_ms_in_timed_region) contains other kernels' work and is not "
-                             "the kernel's own duration.  launch_ms / achieved / frac are the same kernel on the same data with "
-                             f"nothing beside it: one more pass of the step ({NL} launches) on one stream, HIP events on the launch "
-                             "stream, in this process right after the timed region.  The rocprofv3 summary to compare with is the "
-                             "one taken with ORBFE_BENCH_PIPES=1 (profiles/*_kernel_stats.csv); *_kernel_stats_pipes.csv is the "
-                             "default command.")
-            result["stages_in_timed_region"] = stages
-            for k in ("match_ms", "match_Gdist_per_s"):
-                if k in stages:
-                    stages1[k] = stages[k]
-            roof, stages = roof1, stages1
+            stages["match_Gdist_per_s"] = round(float((nn[1:] * nn[:-1]).sum()) / (stage["match"] * 1e-3) / 1e9, 2)
+        stages["mode"] = ("exclusive: one stream, ORBFE_OPT_OVERLAP = 0, pipe 0's extractor alone on the chip, HIP events of the library "
+                          f"around every stage, mean over the {NL} sub-batches of a step; the matcher alone on the same stream.  Sum = the "
+                          "one-pipe in-line cost of a sub-batch; the timed region overlaps stages of different sub-batches, so "
+                          "ms_per_step / launches is smaller than the sum")
         result["roofline"] = roof
         result["stages"] = stages
+        # the driver's record keeps top-level scalars: the table once more, flat
+        for k in ("pyramid", "fast", "octree", "blur", "describe"):
+            result[f"stage_ms_exclusive_{k}"] = round(stage[k], 4)
+        result["stage_ms_exclusive_match"] = round(stage["match"], 4)
+        result["stage_ms_exclusive_sum"] = round(sum(stage[k] for k in ("pyramid", "fast", "octree", "blur", "describe", "match")), 4)
+        result["stage_ms_per_sub_batch_in_timed_region"] = round(result["ms_per_step"] / NL, 4)
+        vc = roof.get("valu_ceiling") or {}
+        result["valu_frac_fast"] = vc.get("valu_busy_frac")
+        result["roofline_frac_hbm"] = roof["frac"]
         result["config"]["mean_keypoints_per_frame"] = round(float(n_host.mean()), 1)
         result["config"]["fast_candidates_frame0"] = ncand
 
     if args.no_extras:
         return
 
+    if world == 1:
+        # ---- the same step in the other modes, each timed like `value` (fence, K steps back to back, fence) -------------------
+        nsteps = max(2, args.steps // 4)
+
+        def rate(run_step, nst=nsteps):
+            run_step()
+            torch.cuda.synchronize()
+            eng.pl.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nst):
+                run_step()
+            eng.pl.synchronize()
+            torch.cuda.synchronize()
+            return B * nst / (time.perf_counter() - t1)
+
+        if eng.match:
+            # the north star's formulation of the all-pairs matcher (xor + v_bcnt popcount, k_match_popc): identical results
+            eng.pl.set_bf_kernel(1)
+            result["value_match_popc"] = round(rate(step), 2)
+            eng.pl.set_bf_kernel(0)
+            # BASELINE config 2: extract only
+            eng.match = False
+            result["value_extract_only"] = round(rate(step), 2)
+            eng.match = True
+        # joined steps (what a consumer between the steps costs)
+        fr = eng.free_run
+        eng.free_run = not fr
+        result["value_step_joined" if fr else "value_free_run"] = round(rate(step), 2)
+        eng.free_run = fr
+        # the other blur rounding: blur_rounding = 1 is what an x86-64 OpenCV <= 3.3 BINARY computes (SSE2 column kernel), 0 the
+        # canonical integer formula (DESIGN.md section 2); a second pipeline, same step
+        import copy
+        a2 = copy.copy(args)
+        a2.blur_rounding = 1 - args.blur_rounding
+        outs_saved = eng.outs
+        eng2 = HipEngine(a2, local_rank, nf, F, NL, world)
+        eng2.pl.set_fast_mode(args.fast_mode)
+        result["value_blur_mode%d" % a2.blur_rounding] = round(rate(lambda: eng2.step(d_gray, 0, stream)), 2)
+        if not args.no_cpu_baseline:
+            result["blur_mode%d_exact_checked" % a2.blur_rounding] = self_check(eng2, d_gray, 0, nf, blur_mode=a2.blur_rounding,
+                                                                                nrandom=2)["exact_checked"]
+        eng2.pl.close()
+        del eng2
+        torch.cuda.empty_cache()
+        eng.outs = outs_saved
+        # camera-like frames: the same step on S_tum(seed) (256 distinct seeds, expanded like the main batch)
+        other = "S_tum" if args.workload == "S" else "S"
+        d_other = expand_frames(torch.from_numpy(base_frames(other, min(B, 256), w, h, 10000)).cuda(), B)
+        result["value_%s" % other.lower()] = round(rate(lambda: eng.step(d_other, 0, stream)), 2)
+        eng.pl.set_fast_mode(1)
+        result["value_%s_fast_mode1" % other.lower()] = round(rate(lambda: eng.step(d_other, 0, stream)), 2)
+        eng.pl.set_fast_mode(args.fast_mode)
+        result["workloads"] = workload_legs(args, eng, d_gray[:F], d_other[:F], local_rank)
+        del d_other
+        eng.pl.reset_sequence()
+        step()   # the resident batch's results back in the output set
+        eng.pl.synchronize()
+
     # ---- PCIe-inclusive leg (SURVEY 8(d) config 3 as worded): three streams, double buffering ---------------------
     if world == 1:
         result["pcie_inclusive"] = pcie_leg(eng, d_gray[:F], w, h, F)
         result["value_pcie_inclusive"] = result["pcie_inclusive"]["frames_per_s"]
 
-    # ---- the other workload, both FAST variants --------------------------------------------------------------------
-    if world == 1:
-        result["workloads"] = workload_legs(args, eng, d_gray[:F], local_rank)
-
     # ---- config 4: 2000 features, a 1024-frame batch sharded over the ranks + all-gather ---------------------------
-    c4 = config4_leg(args, rank, local_rank, world, fence)
+    c4 = config4_leg(args, rank, local_rank, world, fence, global_batch=args.config4_batch)
     if rank == 0:
         result["config4"] = c4
         # one-number summaries at the top level (the driver's record keeps top-level scalars)
         if isinstance(c4, dict) and "strong" in c4:
             result["config4_frames_per_s"] = c4["strong"]["frames_per_s"]           # the 1024-frame batch sharded over the ranks
+            result["config4_weak_frames_per_s"] = c4["weak"]["frames_per_s"]
+            result["config4_allgather_ms"] = c4["strong"]["allgather_ms"]
             result["config4_allgather_bus_GBps"] = c4["strong"]["allgather_bus_GBps"]
+            cg = c4.get("cabi_group") or {}
+            result["config4_cabi_group_frames_per_s"] = cg.get("frames_per_s")
+            result["config4_cabi_group_status"] = "ok" if "frames_per_s" in cg else ("error: " + str(cg.get("error")))
 
     if world == 1 and not args.no_cpu_baseline:
         result["projection_chain"] = projection_leg(local_rank)
     if world == 1:
         result["config5"] = config5_leg(args, local_rank, check=not args.no_cpu_baseline)
         result["config5_frames_per_s"] = result["config5"]["frames_per_s"]
+        result["config5_roofline_frac_hbm"] = result["config5"]["roofline"]["frac"]
         result["bow_chain"] = bow_leg(args, local_rank)
+        result["bow_search_pairs_per_s"] = round(1e6 / result["bow_chain"]["search_by_bow_us_per_pair"], 1)
         result["stereo_chain"] = stereo_leg(args, local_rank)
+        result["stereo_pairs_per_s"] = result["stereo_chain"]["stereo_pairs_per_s"]
         result["host_api"] = host_api_leg(args, local_rank, d_gray[:F])
+        result["host_api_frames_per_s"] = result["host_api"]["frames_per_s"]
 
     if world == 1 and not args.no_cpu_baseline:
         # online (single-frame, host buffers in / out) latency of ORBextractor::operator(): replicas-only path
@@ -791,14 +926,18 @@ def extras(args, eng, d_gray, stage, value, result, rank, local_rank, world, fen
         cb = cpu_baseline(w, h, nf)
         result["cpu_baseline"] = cb
         result["speedup_vs_cpu_1thread"] = round(value / cb["value"], 1)
+        cv = cpu_baseline_vectorised(w, h, nf)
+        if cv is not None:
+            result["cpu_baseline_vectorised"] = cv
+            result["cpu_baseline_vectorised_frames_per_s"] = cv["value"]
+            result["speedup_vs_cpu_1thread_vectorised"] = round(value / cv["value"], 1)
         result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(w, h, nf)
-        # one process per PHYSICAL core as well (logical CPUs / 2 on these SMT-2 hosts): the all-logical-CPU figure above is the
-        # lower of the two -- the second hardware thread of a core adds contention, not throughput, to this integer code
-        result["cpu_baseline_half_of_logical_cpus"] = cpu_baseline_all_cores(w, h, nf, max_procs=max(1, (os.cpu_count() or 2) // 2))
+        result["cpu_baseline_all_cores_frames_per_s"] = result["cpu_baseline_all_cores"]["value"]
 
 
 def pcie_leg(eng, d_src, w, h, F, nbatches=48):
-    """Host frames in, host results out: pinned buffers, H2D / kernels / D2H on three streams, two buffer sets."""
+    """Host frames in, host results out: pinned buffers, H2D / kernels / D2H on three streams, two buffer sets.  Every batch of F
+    frames is one call of the library's pipeline on the compute stream (ORBFE_PIPE_CONTINUE: the batches form one sequence)."""
     pin_in = d_src.cpu().pin_memory()
     cap = eng.cap
     d_in = [torch.empty_like(d_src) for _ in range(2)]
@@ -811,6 +950,8 @@ def pcie_leg(eng, d_src, w, h, F, nbatches=48):
     ev_in = [torch.cuda.Event() for _ in range(2)]
     ev_cmp = [torch.cuda.Event() for _ in range(2)]
     ev_out = [torch.cuda.Event() for _ in range(2)]
+    eng.pl.synchronize()
+    eng.pl.reset_sequence()
 
     def link_rate(fn, nbytes, reps=12):
         for _ in range(3):   # first touches of the pinned pages / warm-up of the copy engines
@@ -838,12 +979,9 @@ def pcie_leg(eng, d_src, w, h, F, nbatches=48):
             if i >= 2:
                 s_cmp.wait_event(ev_out[k])         # the results of batch i-2 have left output set k
             kk, dd, nn, mm, nm = d_out[k]
-            eng.ext.extract_batch_device(d_in[k].data_ptr(), F, w, h, w, w * h, kk.data_ptr(), dd.data_ptr(), cap,
-                                         nn.data_ptr(), s_cmp.cuda_stream)
-            if eng.match:
-                eng.L.orbfe_match_bf_frames_device(eng.mat.handle, kk.data_ptr(), dd.data_ptr(), nn.data_ptr(), cap,
-                                                   eng.qf.data_ptr(), eng.tf.data_ptr(), F, 0.9, 100, 1, mm.data_ptr(),
-                                                   nm.data_ptr(), s_cmp.cuda_stream)
+            eng.pl.extract_match_device(d_in[k].data_ptr(), F, w, h, w, w * h, kk.data_ptr(), dd.data_ptr(), cap, nn.data_ptr(),
+                                        mm.data_ptr() if eng.match else None, nm.data_ptr() if eng.match else None,
+                                        flags=eng.pl.CONTINUE, stream=s_cmp.cuda_stream)
             ev_cmp[k].record(s_cmp)
             with torch.cuda.stream(s_out):
                 s_out.wait_event(ev_cmp[k])
@@ -861,17 +999,16 @@ def pcie_leg(eng, d_src, w, h, F, nbatches=48):
     return {"frames_per_s": round(fps, 2), "h2d_GBps_measured": round(h2d, 2), "d2h_GBps_measured": round(d2h, 2),
             "bytes_in_per_frame": w * h, "bytes_out_per_frame": int(out_bytes // F),
             "link_bound_frames_per_s": round(link_fps, 1), "frac_of_link_bound": round(fps / link_fps, 4),
-            "sample": f"{nbatches} batches of {F} frames: pinned host frames -> H2D -> extract + match -> D2H of counts, "
-                      f"padded keypoints / descriptors / matches; H2D, kernels and D2H on three streams, two buffer sets"}
+            "sample": f"{nbatches} batches of {F} frames: pinned host frames -> H2D -> extract + match (one pipeline call per batch) -> "
+                      f"D2H of counts, padded keypoints / descriptors / matches; H2D, kernels and D2H on three streams, two buffer sets"}
 
 
-def workload_legs(args, eng, d_S, local_rank):
-    """Stage times and rate of one launch of F frames on S and on S_tum, dense and sparse FAST variants."""
+def workload_legs(args, eng, d_S, d_other, local_rank):
+    """Stage times (overlap as shipped, one pipe) and rate of one sub-batch of F frames on both workloads, dense and sparse FAST."""
     w, h, F = args.width, args.height, args.frames
     stream = torch.cuda.current_stream().cuda_stream
-    base_t = torch.from_numpy(base_frames("S_tum" if args.workload == "S" else "S", min(F, 32), w, h, 10000)).cuda()
-    other = expand_frames(base_t, F)
-    sets = {args.workload: d_S, ("S_tum" if args.workload == "S" else "S"): other}
+    other = "S_tum" if args.workload == "S" else "S"
+    sets = {args.workload: d_S, other: d_other}
     out = {}
     kps, desc, n = eng.outs[0]
     for name in sets:
@@ -898,8 +1035,8 @@ def workload_legs(args, eng, d_S, local_rank):
                                              n.data_ptr(), stream)
                 if eng.match:
                     eng.L.orbfe_match_bf_frames_device(eng.mat.handle, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), eng.cap,
-                                                       eng.qf.data_ptr(), eng.tf.data_ptr(), F, 0.9, 100, 1,
-                                                       eng.d_match.data_ptr(), eng.d_nm.data_ptr(), stream)
+                                                       eng.qf.data_ptr(), eng.tf.data_ptr(), F - 1, 0.9, 100, 1,
+                                                       eng.d_match[1].data_ptr(), eng.d_nm[1:].data_ptr(), stream)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t
             sm = eng.ext.stage_ms()
@@ -908,6 +1045,7 @@ def workload_legs(args, eng, d_S, local_rank):
             row[f"stage_ms_{label}"] = {k: round(sm[k], 4) for k in ("pyramid", "fast", "octree", "blur", "describe")}
         row["fast_candidates_frame0"] = int(sum(len(eng.ext.candidates(l, frame=0)) for l in range(8)))
         row["mean_keypoints_per_frame"] = round(float(n[:F].float().mean().item()), 1)
+        row["note"] = "one pipe, blur beside the quadtree as shipped (ORBFE_OPT_OVERLAP built-in): stage intervals here overlap"
         out[name] = row
     eng.ext.set_fast_mode(args.fast_mode)
     return out
@@ -1307,13 +1445,15 @@ def config4_group(args, rank, local_rank, world, uid, allf, lo, hi, global_batch
     return res
 
 
-def config4_group_guarded(args, rank, local_rank, world, allf, lo, hi, global_batch, nfeat, steps, timeout_s=240.0):
+def config4_group_guarded(args, rank, local_rank, world, allf, lo, hi, global_batch, nfeat, steps, timeout_s=None):
     """config4_group behind a watchdog.  With world > 1 the library's own RCCL communicator runs here for the first time on a
     given node; a rank that fails or stalls inside it must cost this leg, not the line: the leg runs in a worker thread, every
     rank waits `timeout_s` for its own, and the ranks then agree on the CPU-side group CTL["main"] whether all finished.  If one
     did not, the leg is reported as such and every rank leaves through os._exit after rank 0 has printed the line (main)."""
     import threading
     from orb_slam2_ssd_semantic_amd.distributed import KeyframeGroup
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("ORBFE_BENCH_GROUP_TIMEOUT", "240"))
     uid = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         with c_stdout_to_stderr():
@@ -1357,8 +1497,11 @@ def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2
     ext = ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=global_batch, device=local_rank)
     cap = ext.capacity()
     stream = torch.cuda.current_stream().cuda_stream
-    base = torch.from_numpy(base_frames("S", 32, w, h, 10000)).cuda()
-    allf = expand_frames(base, global_batch)   # every rank builds the same global batch and takes its shard
+    # S(10000 + i), i < 1024 -- every frame its own generator seed; every rank builds the same global batch
+    # and takes its shard
+    allf = torch.from_numpy(base_frames("S", global_batch, w, h, 10000)).cuda()
+    same = bool(getattr(args, "same", False))
+    red_dev = "cpu" if same else "cuda"   # the default group is CPU-only (gloo) when the ranks share one device
     out = {}
 
     def run(frames, nfr, tag):
@@ -1370,7 +1513,7 @@ def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2
             ext.extract_batch_device(frames.data_ptr(), nfr, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap,
                                      n.data_ptr(), stream)
             return all_gather_keyframes(n[:S] if tag == "strong" else n, kps[:S] if tag == "strong" else kps,
-                                        desc[:S] if tag == "strong" else desc)
+                                        desc[:S] if tag == "strong" else desc, host_staged=same)
         for _ in range(3):
             one()
         fence()
@@ -1384,11 +1527,11 @@ def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2
         t2 = time.perf_counter()
         for _ in range(steps):
             all_gather_keyframes(n[:S] if tag == "strong" else n, kps[:S] if tag == "strong" else kps,
-                                 desc[:S] if tag == "strong" else desc)
+                                 desc[:S] if tag == "strong" else desc, host_staged=same)
         fence()
         dtg = (time.perf_counter() - t2) / steps
         if world > 1:
-            tt = torch.tensor([dt, dtg], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt, dtg], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt, dtg = float(tt[0]), float(tt[1])
         rows = S if tag == "strong" else nfr
@@ -1398,6 +1541,22 @@ def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2
                     "allgather_ms": round(dtg * 1e3, 4), "allgather_bytes_per_rank": int(per_rank),
                     "allgather_bus_GBps": round(per_rank * (world - 1) / dtg / 1e9, 2) if world > 1 else None,
                     "gathered_frames": int(g[0].shape[0])}
+        if tag == "strong" and rank == 0 and not args.no_cpu_baseline:
+            # frames of the LAST rank's shard (and one of the own), read from the gathered blocks on rank 0, against the oracle
+            from oracle import oracle_ffi as O
+            from orb_slam2_ssd_semantic_amd import KP_DTYPE
+            oe = O.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+            lo_l, hi_l = shard_range(global_batch, world - 1, world)
+            torch.cuda.synchronize()
+            for owner, f in ((world - 1, lo_l), (world - 1, hi_l - 1), (0, hi - 1)):
+                lo_o, _ = shard_range(global_batch, owner, world)
+                row = owner * S + (f - lo_o)
+                ok, od = oe(allf[f].cpu().numpy())
+                nd = int(g[0][row].item())
+                gk = g[1][row, :nd].cpu().numpy().copy().view(KP_DTYPE).reshape(-1)
+                if not (nd == len(ok) and np.array_equal(gk.view(np.uint8), ok.view(np.uint8)) and np.array_equal(g[2][row, :nd].cpu().numpy(), od)):
+                    raise SystemExit(f"bench.py config 4: frame {f} (rank {owner}'s shard) read from the gathered blocks differs from the oracle")
+            out["gathered_exact_checked"] = True
         del kps, desc, n
 
     run(allf[lo:hi].contiguous(), hi - lo, "strong")
@@ -1407,8 +1566,9 @@ def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2
     except Exception as e:   # a second communicator next to torch's: report, never lose the line over it
         out["cabi_group"] = {"error": f"{type(e).__name__}: {e}"}
     out["nfeatures"], out["global_batch"], out["cap"], out["n_gpus"] = nfeat, global_batch, cap, world
-    out["note"] = ("strong: the 1024-frame batch sharded in contiguous blocks (SURVEY 8(d) row 4); weak: 1024 frames on every "
-                   "rank.  The all-gather is synchronous here (its cost is visible); the main timed region overlaps it.")
+    out["note"] = (f"strong: the {global_batch}-frame batch S(10000 + i) sharded in contiguous blocks (SURVEY 8(d) row 4); weak: "
+                   f"{global_batch} frames on every rank.  The all-gather is synchronous here (its cost is visible); the main timed "
+                   "region overlaps it." + ("  SAME-DEVICE TEST MODE: host-staged gloo exchange, not a bandwidth figure." if same else ""))
     assert ext.overflow() == 0
     return out
 

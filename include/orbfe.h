@@ -140,6 +140,31 @@ orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[3], int32_t rese
 /* work model of the FAST kernel for the current frame size: out[0] = wave row steps per frame (one step = 64 lanes x 4
  * pixels of one row, halo rows included), out[1] = waves per frame.  bench.py prices its VALU ceiling with it. */
 orbfe_status orbfe_get_work_counts(const orbfe_handle *h, int64_t out[2]);
+/* Launch-shape and A/B options of a handle.  The release library takes them ONLY through this call -- it reads no tuning
+ * knob from the process environment (a library inside a SLAM process must not change algorithm because of the host's
+ * environment).  Every setting gives byte-identical results; 0 (ORBFE_OPT_OVERLAP: -1) restores the built-in choice.
+ * Options marked [dev] select kernel variants that were measured slower than the default and are compiled only into a
+ * developer build (-DORBFE_DEVELOPER, tools/ab_build.sh; such a build also honours $ORBFE_<NAME> at orbfe_create): a
+ * release build answers ORBFE_ERR_STATE to a non-zero value.  Call between extract calls, not concurrently with one. */
+enum {
+    ORBFE_OPT_OVERLAP = 1,        /* blur on the side stream: 0 never, 1 from before FAST, 2 beside the quadtree, -1 by batch size */
+    ORBFE_OPT_ROWS = 2,           /* rows a FAST / blur wave walks (8..512) */
+    ORBFE_OPT_ROWS_FAST = 3,      /* ... FAST only */
+    ORBFE_OPT_ROWS_BLUR = 4,      /* ... blur only */
+    ORBFE_OPT_BLUR_PIECES = 5,    /* 1 (default): blur lanes laid out in 64-byte pieces */
+    ORBFE_OPT_BLUR_UPDOWN = 6,    /* odd row blocks of the blur walk upwards: 0 never, 1 where it adds no wave (default), 2 always */
+    ORBFE_OPT_PYR_ROWS = 7,       /* destination rows per lane run of the pyramid kernel (2..16) */
+    ORBFE_OPT_QT_THREADS_0 = 8,   /* threads per workgroup of the quadtree's three level groups (64..512, multiple of 64) */
+    ORBFE_OPT_QT_THREADS_1 = 9,
+    ORBFE_OPT_QT_THREADS_2 = 10,
+    ORBFE_OPT_DEBUG = 11,         /* forces production code paths that ordinary frames rarely take (tests): 50 = quadtree by
+                                   * streaming key passes only (the deep-tree path), 51 = generic node passes only */
+    ORBFE_OPT_PYR_FUSE = 12,      /* [dev] 1: two pyramid levels per launch */
+    ORBFE_OPT_FUSE_BLUR_PYR = 13, /* [dev] 1 / 2: blur + resize in one chained pass */
+    ORBFE_OPT_FUSE_FAST_PYR = 14, /* [dev] 1 / 2: FAST + resize in one launch per level, 3: FAST of level 0 beside the pyramid */
+    ORBFE_OPT_FUSE_FAST_PYR_LEVELS = 15
+};
+orbfe_status orbfe_set_option(orbfe_handle *h, int32_t option, int32_t value);
 /* the handle's own non-blocking stream (hipStream_t as void*): the host-buffer entry points run on it */
 void *orbfe_get_stream(orbfe_handle *h);
 /* block until everything enqueued by this handle on its own stream has finished */
@@ -228,6 +253,14 @@ orbfe_status orbfe_match_bf_frames_device(orbfe_matcher *m, const orbfe_keypoint
                                           const int32_t *d_tframe, int32_t npairs, float nnratio, int32_t th,
                                           int32_t check_ori, int32_t *d_match_q2t /* npairs*cap */,
                                           int32_t *d_nmatches /* npairs */, void *stream);
+
+/* the same with queries and train frames taken from two DIFFERENT output blocks of the same `cap` (e.g. the frames of this
+ * batch against frames of the previous batch): d_qframe indexes (d_qkps, d_qdesc, d_qn), d_tframe indexes (d_tkps, d_tdesc, d_tn) */
+orbfe_status orbfe_match_bf_blocks_device(orbfe_matcher *m, const orbfe_keypoint *d_qkps, const uint8_t *d_qdesc,
+                                          const int32_t *d_qn, const orbfe_keypoint *d_tkps, const uint8_t *d_tdesc,
+                                          const int32_t *d_tn, int32_t cap, const int32_t *d_qframe, const int32_t *d_tframe,
+                                          int32_t npairs, float nnratio, int32_t th, int32_t check_ori,
+                                          int32_t *d_match_q2t /* npairs*cap */, int32_t *d_nmatches /* npairs */, void *stream);
 
 /* ORBmatcher::SearchByBoW (KeyFrame*, Frame&, ...) src/ORBmatcher.cc:217-363   [strict_lt = 0, validF = NULL]
  * ORBmatcher::SearchByBoW (KeyFrame*, KeyFrame*, ...) src/ORBmatcher.cc:665-812 [strict_lt = 1]
@@ -393,7 +426,9 @@ orbfe_status orbfe_proj_queries_local_map(const float *scale_factors, int32_t n,
                                           float th, orbfe_proj_query *q, int32_t *src, int32_t *nq);
 /* the rotation-consistency check every matcher ends with: match i votes for bin round((angle_a[i] - angle_b[i], + 360 if
  * negative) * (1 / histo_len)) (:308-313), the three fullest bins stay (ComputeThreeMaxima :1912-1957: an earlier bin wins a
- * tie, the second / third go when under a tenth of the first); drop[i] = 1 for matches outside them */
+ * tie, the second / third go when under a tenth of the first); drop[i] = 1 for matches outside them.  A match whose bin is
+ * not in [0, histo_len] (NaN, an angle outside [0, 360), or histo_len < 19 with ordinary angles) is what the reference asserts
+ * against (:314): ORBFE_ERR_ARG, nothing written */
 orbfe_status orbfe_rotation_consistency(const float *angle_a, const float *angle_b, int32_t n, int32_t histo_len, uint8_t *drop);
 /* SearchForInitialization's in-order rule (:547-617) on the lists of orbfe_window_distances: query qi takes its closest
  * candidate among those no earlier query holds at a distance <= its own, accepted when best <= th and best < second * nnratio;
@@ -513,6 +548,53 @@ orbfe_status orbfe_search_by_bow_batch_device(orbfe_matcher *m, const orbfe_keyp
                                               int32_t *d_nmatches, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Sequence pipeline: the frame loop of the reference's drivers (perfect/Examples/RGB-D/rgbd_tum.cc:77-119: every frame of
+ * the sequence through the Frame constructor = ORBextractor::operator(), then matched against its predecessor -- BASELINE
+ * config 3) for a device-resident SEQUENCE in one call.
+ *
+ * A pipeline owns `npipes` pipes; a pipe = one extractor handle + one matcher handle + one stream.  A call cuts its
+ * nframes into sub-batches of p->max_batch frames (the last one may be shorter) and runs sub-batch j on pipe j mod npipes,
+ * so that the VALU-bound FAST pass of one sub-batch shares the chip with the HBM / LDS-bound stages of its neighbours
+ * (one pipe 273 k, three pipes 302 k frames/s at 1024-frame sub-batches).  Frame k is matched against frame
+ * k - 1 as orbfe_match_bf does (best <= th, ratio, rotation histogram) ACROSS sub-batch boundaries; frame 0 of a call is
+ * matched against the last frame of the previous call when ORBFE_PIPE_CONTINUE is set (the pipeline keeps its own copy of
+ * that frame, the caller may re-use its buffers), otherwise -- and on the first call or after
+ * orbfe_pipeline_reset_sequence -- it has no predecessor: its match row is -1, its count 0.
+ *   d_gray / d_kps / d_desc / cap / d_n_out   exactly as orbfe_extract_batch_device, for all nframes
+ *   d_match [nframes][cap], d_nmatches [nframes]   row k = matches of frame k into frame k - 1 (train index or -1);
+ *                                                  d_match == NULL: extract only (BASELINE config 2)
+ * The call only enqueues.  The pipes start behind what `stream` holds at the time of the call; unless ORBFE_PIPE_NO_JOIN
+ * is set, `stream` is made to wait for all pipes before the call returns, so that anything enqueued on it afterwards sees
+ * the results.  With ORBFE_PIPE_NO_JOIN consecutive calls run back to back without draining the chip in between (a
+ * throughput loop whose results are consumed later): call orbfe_pipeline_join(pl, stream) or orbfe_pipeline_synchronize(pl)
+ * before touching the outputs.  Buffers re-used by the next call are protected inside the pipeline (events).
+ * A pipeline is used by one thread at a time.  orbfe_pipeline_extractor / _matcher give the pipes' handles for the per-handle
+ * settings (orbfe_set_fast_mode, orbfe_set_profiling, orbfe_matcher_set_bf_kernel) and taps.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct orbfe_pipeline orbfe_pipeline;
+#define ORBFE_PIPE_CONTINUE 1 /* frame 0 continues the sequence of the previous call */
+#define ORBFE_PIPE_NO_JOIN 2  /* do not order `stream` behind the pipes at the end of the call */
+orbfe_status orbfe_pipeline_create(const orbfe_params *p /* max_batch = frames per sub-batch */, int32_t npipes, orbfe_pipeline **out);
+void orbfe_pipeline_destroy(orbfe_pipeline *pl);
+int32_t orbfe_pipeline_pipes(const orbfe_pipeline *pl);
+int32_t orbfe_pipeline_capacity(const orbfe_pipeline *pl);   /* = orbfe_keypoint_capacity of its handles */
+int32_t orbfe_pipeline_sub_batch(const orbfe_pipeline *pl);
+orbfe_handle *orbfe_pipeline_extractor(orbfe_pipeline *pl, int32_t pipe);
+orbfe_matcher *orbfe_pipeline_matcher(orbfe_pipeline *pl, int32_t pipe);
+orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, const uint8_t *d_gray, int32_t nframes, int32_t w, int32_t ht,
+                                                 int32_t stride, size_t frame_stride, orbfe_keypoint *d_kps, uint8_t *d_desc,
+                                                 int32_t cap, int32_t *d_n_out, int32_t *d_match, int32_t *d_nmatches,
+                                                 float nnratio, int32_t th, int32_t check_ori, int32_t flags, void *stream);
+/* `stream` waits (at stream level) for everything the pipes hold */
+orbfe_status orbfe_pipeline_join(orbfe_pipeline *pl, void *stream);
+/* the host waits for the pipes */
+orbfe_status orbfe_pipeline_synchronize(orbfe_pipeline *pl);
+/* the next call starts a new sequence even with ORBFE_PIPE_CONTINUE */
+orbfe_status orbfe_pipeline_reset_sequence(orbfe_pipeline *pl);
+/* OR of orbfe_get_overflow over the pipes' extractors (waits for them) */
+orbfe_status orbfe_pipeline_get_overflow(orbfe_pipeline *pl, int32_t *flags);
+
+/* ---------------------------------------------------------------------------------------------
  * Batched keyframe mode over several devices (north star: "shards independent frames across the 8 GPUs of one
  * node with an RCCL all-gather of descriptors over xGMI", host stays C++).
  *
@@ -537,7 +619,7 @@ orbfe_status orbfe_search_by_bow_batch_device(orbfe_matcher *m, const orbfe_keyp
  * ordered by events); orbfe_group_synchronize / _get_frame / _match wait.
  *
  * Transport of the exchange step.  ORBFE_GROUP_RCCL (default): ncclAllGather.  ORBFE_GROUP_COPY (local groups only,
- * orbfe_group_create_local_ex or $ORBFE_GROUP_TRANSPORT=copy): every member pulls the other members' slices with
+ * orbfe_group_create_local_ex): every member pulls the other members' slices with
  * hipMemcpyAsync / hipMemcpyPeerAsync on its communication stream behind the same events -- same bytes at the same offsets.
  * It needs no communicator, so `devices` may name one device several times: several members on ONE GPU, which is how the
  * multi-member paths are tested on a one-GPU box (RCCL refuses two ranks on one device).

@@ -86,6 +86,45 @@ def perfect_lib():
     return _perfect
 
 
+_VEC = os.path.join(_OUT, "libref_orb_vec.so")
+_vec = None
+
+
+def vectorised_available():
+    """oracle/_ref/libref_orb_vec.so exists and this host's CPUs have AVX2 (it is built -O3 -mavx2)"""
+    if not os.path.exists(_VEC):
+        return False
+    try:
+        return " avx2" in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
+def vectorised_lib():
+    global _vec
+    if _vec is None:
+        if not vectorised_available():
+            raise RuntimeError("oracle/_ref/libref_orb_vec.so is missing or this CPU has no AVX2")
+        _vec = _declare(C.CDLL(_VEC))
+    return _vec
+
+
+class use_vectorised:
+    """with use_vectorised(): every ref_* call goes to libref_orb_vec.so -- the same unmodified reference sources and stub
+    stand-ins as libref_orb.so, built -O3 -mavx2 -ffp-contract=off (bit-identical results, tests/test_ref_pin.py)"""
+
+    def __enter__(self):
+        global _lib
+        self.prev = lib()
+        _lib = vectorised_lib()
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
 def lib():
     global _lib
     if _lib is not None:

@@ -339,12 +339,19 @@ class Mat
     }
 
     /* Mat::reshape(cn): same data, another channel count (continuous matrices only; Frame::UndistortKeyPoints :577-579) */
-    Mat reshape(int cn, int = 0) const
+    Mat reshape(int cn, int new_rows = 0) const
     {
         assert(isContinuous() && (cols * channels()) % cn == 0);
         Mat m(*this);
         m.cols = cols * channels() / cn;
         m.flags = CV_MAKETYPE(depth(), cn);
+        if (new_rows > 0 && new_rows != rows) { /* core/matrix.cpp Mat::reshape: total elements kept, rows changed */
+            const size_t total = (size_t)rows * m.cols;
+            assert(total % (size_t)new_rows == 0);
+            m.rows = new_rows;
+            m.cols = (int)(total / (size_t)new_rows);
+            m.step = (size_t)m.cols * m.elemSize();
+        }
         return m;
     }
     Mat rowRange(int startrow, int endrow) const { return Mat(*this, Rect(0, startrow, cols, endrow - startrow)); }

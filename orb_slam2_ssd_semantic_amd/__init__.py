@@ -8,6 +8,7 @@ from .matcher import FrameGrid, ORBVocabulary, ORBmatcher, feature_vector_to_csr
 from ._ffi import KP_DTYPE, OrbfeError  # noqa: F401
 from . import mapio  # noqa: F401
 from .mapio import VocabularyFile  # noqa: F401
+from .pipeline import FramePipeline  # noqa: F401
 
-__all__ = ["ORBextractor", "ORBmatcher", "FrameGrid", "ORBVocabulary", "VocabularyFile", "mapio", "feature_vector_to_csr",
+__all__ = ["ORBextractor", "ORBmatcher", "FramePipeline", "FrameGrid", "ORBVocabulary", "VocabularyFile", "mapio", "feature_vector_to_csr",
            "KP_DTYPE", "OrbfeError"]

@@ -40,8 +40,16 @@ SYMBOLS = (
     "orbfe_group_extract_shard_device", "orbfe_group_allgather", "orbfe_group_synchronize", "orbfe_group_blocks", "orbfe_group_get_frame",
     "orbfe_group_match", "orbfe_group_match_device", "orbfe_group_owner_rank", "orbfe_group_block_index_of",
     "orbfe_group_create_local_ex", "orbfe_group_members", "orbfe_group_transport", "orbfe_group_get_frame_from", "orbfe_group_get_counts", "orbfe_assign_grid_host", "orbfe_get_pyramid_padded", "orbfe_project_points", "orbfe_proj_queries_local_map", "orbfe_rotation_consistency",
-    "orbfe_initialization_resolve",
+    "orbfe_initialization_resolve", "orbfe_set_option", "orbfe_match_bf_blocks_device",
+    "orbfe_pipeline_create", "orbfe_pipeline_destroy", "orbfe_pipeline_pipes", "orbfe_pipeline_capacity", "orbfe_pipeline_sub_batch",
+    "orbfe_pipeline_extractor", "orbfe_pipeline_matcher", "orbfe_pipeline_extract_match_device", "orbfe_pipeline_join",
+    "orbfe_pipeline_synchronize", "orbfe_pipeline_reset_sequence", "orbfe_pipeline_get_overflow",
 )
+
+# orbfe_set_option (include/orbfe.h ORBFE_OPT_*)
+OPTIONS = dict(overlap=1, rows=2, rows_fast=3, rows_blur=4, blur_pieces=5, blur_updown=6, pyr_rows=7, qt_threads_0=8, qt_threads_1=9,
+               qt_threads_2=10, debug=11, pyr_fuse=12, fuse_blur_pyr=13, fuse_fast_pyr=14, fuse_fast_pyr_levels=15)
+PIPE_CONTINUE, PIPE_NO_JOIN = 1, 2
 
 
 PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
@@ -79,7 +87,18 @@ def lib():
     # $ORBFE_LIB: a prebuilt VARIANT of the library (developer A/B runs: kernels compiled with other -D flags, built on the
     # build machine with _build.build_variant so that the GPU box does not spend its minutes compiling)
     path = os.environ.get("ORBFE_LIB") or _build.build()
-    L = C.CDLL(path)
+    _lib = _configure(C.CDLL(path))
+    return _lib
+
+
+def load_variant(path):
+    """A second, separately built liborbfe (e.g. ab/liborbfe_dev.so, the -DORBFE_DEVELOPER build) next to the default one in
+    the same process: ORBextractor(..., lib=load_variant(path)).  Tests of the developer-only kernel variants use it."""
+    lib()   # torch / HIP runtime first, as for the default library
+    return _configure(C.CDLL(path))
+
+
+def _configure(L):
     vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
     L.orbfe_version.restype = i32
     L.orbfe_strerror.restype = C.c_char_p
@@ -187,11 +206,25 @@ def lib():
     L.orbfe_group_get_counts.argtypes = [vp, i32, vp]
     L.orbfe_group_match.argtypes = [vp, vp, vp, i32, f32, i32, i32, vp, vp]
     L.orbfe_group_match_device.argtypes = [vp, i32, vp, vp, i32, f32, i32, i32, vp, vp]
+    L.orbfe_set_option.argtypes = [vp, i32, i32]
+    L.orbfe_match_bf_blocks_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, f32, i32, i32, vp, vp, vp]
+    L.orbfe_pipeline_create.argtypes = [C.POINTER(OrbfeParams), i32, C.POINTER(vp)]
+    L.orbfe_pipeline_destroy.argtypes = [vp]
+    L.orbfe_pipeline_destroy.restype = None
+    for nm in ("orbfe_pipeline_pipes", "orbfe_pipeline_capacity", "orbfe_pipeline_sub_batch", "orbfe_pipeline_synchronize",
+               "orbfe_pipeline_reset_sequence"):
+        getattr(L, nm).argtypes = [vp]
+    L.orbfe_pipeline_extractor.argtypes = [vp, i32]
+    L.orbfe_pipeline_extractor.restype = vp
+    L.orbfe_pipeline_matcher.argtypes = [vp, i32]
+    L.orbfe_pipeline_matcher.restype = vp
+    L.orbfe_pipeline_extract_match_device.argtypes = [vp, vp, i32, i32, i32, i32, sz, vp, vp, i32, vp, vp, vp, f32, i32, i32, i32, vp]
+    L.orbfe_pipeline_join.argtypes = [vp, vp]
+    L.orbfe_pipeline_get_overflow.argtypes = [vp, vp]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int:  # default -> orbfe_status / int32
             f.restype = i32
-    _lib = L
     return L
 
 

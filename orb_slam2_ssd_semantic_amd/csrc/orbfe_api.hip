@@ -184,6 +184,11 @@ struct orbfe_handle {
     int fuse_blur_pyr = 0;   // 1: blur + pyramid in one chained pass over the levels (ORBFE_FUSE_BLUR_PYR)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;   // the side-stream FAST of ORBFE_OPT_FUSE_FAST_PYR = 3 (developer builds)
+    // tuning options (orbfe_set_option; 0 / -1 = built-in choice).  The plan-shaping ones invalidate the plan.
+    int opt_rows = 0, opt_rows_fast = 0, opt_rows_blur = 0;
+    int opt_blur_pieces = 1, opt_blur_updown = 1, opt_debug = 0;
+    OrbOpts kopts = {0, 0, {0, 0, 0}};
 };
 
 // waits until the last batched call of the handle has finished, on whichever stream it ran
@@ -244,27 +249,18 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     P.ini_th = std::min(255, std::max(0, h->prm.ini_th_fast));
     P.min_th = std::min(255, std::max(0, h->prm.min_th_fast));
     P.blur_rounding = h->prm.blur_rounding;
-    P.dbg = getenv("ORBFE_DEBUG") ? atoi(getenv("ORBFE_DEBUG")) : 0;
+    P.dbg = h->opt_debug;
     // Rows a FAST / blur wave walks.  Long runs amortise the 8 (FAST) / 6 (blur) halo rows -- right for batches, whose waves
     // fill the chip anyway.  A handle made for the online call (a frame or a few per call) is latency-bound instead: one wave's
     // walk IS the kernel's duration, so it takes short runs and more waves: single 640x480 frame, FAST 41 -> 25 -> 21 us and blur
-    // 19 -> 11 -> 9 us with 40 -> 16 -> 8 rows (ORBFE_ROWS overrides, 8..512).
+    // 19 -> 11 -> 9 us with 40 -> 16 -> 8 rows (ORBFE_OPT_ROWS overrides, 8..512).
     int rows_per_wave = h->prm.max_batch <= 2 ? 8 : (h->prm.max_batch <= 8 ? 16 : ORBFE_ROWS_PER_WAVE);
-    if (const char *e = getenv("ORBFE_ROWS")) {
-        const int v = atoi(e);
-        if (v >= 8 && v <= 512) rows_per_wave = v;
-    }
-    // the FAST and the blur walk can take different run lengths (ORBFE_ROWS_FAST / ORBFE_ROWS_BLUR; A/B in
+    if (h->opt_rows >= 8 && h->opt_rows <= 512) rows_per_wave = h->opt_rows;
+    // the FAST and the blur walk can take different run lengths (ORBFE_OPT_ROWS_FAST / ORBFE_OPT_ROWS_BLUR; A/B in
     // profiles/r04_ab_experiments.json): a longer run amortises the 8 (FAST) / 6 (blur) halo steps, a shorter one balances better
     int rows_fast = rows_per_wave, rows_blur = rows_per_wave;
-    if (const char *e = getenv("ORBFE_ROWS_FAST")) {
-        const int v = atoi(e);
-        if (v >= 8 && v <= 512) rows_fast = v;
-    }
-    if (const char *e = getenv("ORBFE_ROWS_BLUR")) {
-        const int v = atoi(e);
-        if (v >= 8 && v <= 512) rows_blur = v;
-    }
+    if (h->opt_rows_fast >= 8 && h->opt_rows_fast <= 512) rows_fast = h->opt_rows_fast;
+    if (h->opt_rows_blur >= 8 && h->opt_rows_blur <= 512) rows_blur = h->opt_rows_blur;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
     int64_t off = 0;
@@ -387,9 +383,10 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             return ORBFE_ERR_SIZE;
         }
     }
-    // Two pyramid levels per launch: for B = 1, 3, 5, ... with a level C = B + 1 above it, the tiling of B and the first
-    // C column / row every tile column / row owns (C pixel (x2, y2) belongs to the tile that holds its top-left tap
-    // (sx(x2), sy(y2)) in its own -- non-overlap -- part).
+#ifdef ORBFE_DEVELOPER
+    // Two pyramid levels per launch (ORBFE_OPT_PYR_FUSE, developer builds): for B = 1, 3, 5, ... with a level C = B + 1 above
+    // it, the tiling of B and the first C column / row every tile column / row owns (C pixel (x2, y2) belongs to the tile that
+    // holds its top-left tap (sx(x2), sy(y2)) in its own -- non-overlap -- part).
     for (int l = 1; l + 1 < nl; l += 2) {
         OrbLevel &B = P.lv[l];
         const OrbLevel &C = P.lv[l + 1];
@@ -427,6 +424,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         B.p2_cxs = add_i32(cxs);
         B.p2_cys = add_i32(cys);
     }
+#endif
     P.ncells = (int)cells.size();
     P.cell_cap = cell_cap;
     P.max_ncells = 1;
@@ -528,11 +526,11 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     // of a row block go to the border waves whole, the pieces between them to the interior waves -- every store instruction
     // then writes whole 64-byte pieces.  (Border waves holding only the 2 - 3 reflected columns of 20-odd row blocks wrote a
     // lone dword into 64 different lines per store: WRITE_SIZE was 1.19x the output, profiles/r04_ab_experiments.json;
-    // ORBFE_BLUR_PIECES=0 brings that packing back for the A/B.)
+    // ORBFE_OPT_BLUR_PIECES = 0 brings that packing back for the A/B.)
     std::vector<OrbLane> blanes;
     std::vector<OrbLaneR> blanesR;   // the resize job of every blur lane (fused blur + pyramid pass), same index
-    const bool blur_pieces = !(getenv("ORBFE_BLUR_PIECES") && atoi(getenv("ORBFE_BLUR_PIECES")) == 0);
-    const int blur_updown = getenv("ORBFE_BLUR_UPDOWN") ? std::max(0, std::min(2, atoi(getenv("ORBFE_BLUR_UPDOWN")))) : 1;
+    const bool blur_pieces = h->opt_blur_pieces != 0;
+    const int blur_updown = std::max(0, std::min(2, h->opt_blur_updown));
     for (int l = 0; l < nl; ++l) {
         const OrbLevel &L = P.lv[l];
         if (L.w < 16) { orbfe_set_error("level %d too narrow for the blur kernel", l); return ORBFE_ERR_SIZE; }
@@ -660,7 +658,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
             // the second reader finds the halo rows in L2 instead of HBM: FETCH_SIZE of the kernel -18 % when every level does it.
             // Keeping the two directions in waves of their own can cost a level one more (partly filled) wave, i.e. instructions,
             // which is what the pipeline as a whole is bound by: a (level, pass) is split only where the wave count stays the same
-            // (ORBFE_BLUR_UPDOWN=0: never, =2: always; the fused blur + pyramid passes walk downwards only).
+            // (ORBFE_OPT_BLUR_UPDOWN = 0: never, 2: always; the fused blur + pyramid passes walk downwards only).
             auto emit = [&](int nparity, std::vector<OrbLane> &ol, std::vector<OrbLaneR> &orr) {
                 for (int par = 0; par < nparity; ++par) {
                     const uint16_t upflag = par ? 8 : 0;
@@ -853,11 +851,30 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
             orbfe_set_error("pipeline event creation failed");
             return fail(ORBFE_ERR_HIP);
         }
-    if (const char *e = getenv("ORBFE_OVERLAP")) h->overlap = std::max(0, std::min(2, atoi(e)));
-    if (const char *e = getenv("ORBFE_FUSE_BLUR_PYR")) h->fuse_blur_pyr = std::max(0, std::min(2, atoi(e)));
-    if (const char *e = getenv("ORBFE_FUSE_FAST_PYR")) h->fuse_fast_pyr = std::max(0, std::min(3, atoi(e)));
-    if (const char *e = getenv("ORBFE_FUSE_FAST_PYR_LEVELS")) h->fuse_fast_pyr_levels = std::max(1, std::min((int)ORBFE_MAX_LEVELS, atoi(e)));
-    if (h->fuse_fast_pyr) h->fuse_blur_pyr = 0;   // one fusion at a time
+    if (hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) != hipSuccess) {
+        orbfe_set_error("event creation failed");
+        return fail(ORBFE_ERR_HIP);
+    }
+#ifdef ORBFE_DEVELOPER
+    // a developer build (-DORBFE_DEVELOPER; tools/ab_build.sh) also honours the A/B knobs from the environment, under the
+    // names of the options (ORBFE_OPT_OVERLAP -> $ORBFE_OVERLAP ...); the release library takes them through orbfe_set_option only
+    {
+        static const struct { const char *env; int opt; } kEnv[] = {
+            {"ORBFE_OVERLAP", ORBFE_OPT_OVERLAP}, {"ORBFE_ROWS", ORBFE_OPT_ROWS}, {"ORBFE_ROWS_FAST", ORBFE_OPT_ROWS_FAST},
+            {"ORBFE_ROWS_BLUR", ORBFE_OPT_ROWS_BLUR}, {"ORBFE_BLUR_PIECES", ORBFE_OPT_BLUR_PIECES},
+            {"ORBFE_BLUR_UPDOWN", ORBFE_OPT_BLUR_UPDOWN}, {"ORBFE_PW_ROWS", ORBFE_OPT_PYR_ROWS}, {"ORBFE_PYR_FUSE", ORBFE_OPT_PYR_FUSE},
+            {"ORBFE_DEBUG", ORBFE_OPT_DEBUG}, {"ORBFE_FUSE_BLUR_PYR", ORBFE_OPT_FUSE_BLUR_PYR},
+            {"ORBFE_FUSE_FAST_PYR", ORBFE_OPT_FUSE_FAST_PYR}, {"ORBFE_FUSE_FAST_PYR_LEVELS", ORBFE_OPT_FUSE_FAST_PYR_LEVELS}};
+        for (const auto &k : kEnv)
+            if (const char *e = getenv(k.env)) (void)orbfe_set_option(h, k.opt, atoi(e));
+        if (const char *e = getenv("ORBFE_QT")) {
+            int v[3];
+            if (sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3)
+                for (int i = 0; i < 3; ++i) (void)orbfe_set_option(h, ORBFE_OPT_QT_THREADS_0 + i, v[i]);
+        }
+    }
+#endif
     int umax[16];
     host_umax(umax);
     if (orbk_upload_constants(umax) != hipSuccess) {
@@ -904,6 +921,8 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
+    if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1003,6 +1022,59 @@ extern "C" orbfe_status orbfe_internal_read_misc(orbfe_handle *h, void *out, int
     return ORBFE_OK;
 }
 
+extern "C" orbfe_status orbfe_set_option(orbfe_handle *h, int32_t option, int32_t value)
+{
+    if (!h) return ORBFE_ERR_ARG;
+    auto in = [&](int lo, int hi) { return value >= lo && value <= hi; };
+    auto developer_only = [&]() {
+#ifdef ORBFE_DEVELOPER
+        return false;
+#else
+        if (value == 0) return false;   // "off" is always accepted
+        orbfe_set_error("option %d selects a kernel variant that is compiled into developer builds (-DORBFE_DEVELOPER) only", option);
+        return true;
+#endif
+    };
+    bool replan = false;
+    switch (option) {
+    case ORBFE_OPT_OVERLAP: if (!in(-1, 2)) return ORBFE_ERR_ARG; h->overlap = value; break;
+    case ORBFE_OPT_ROWS: if (value && !in(8, 512)) return ORBFE_ERR_ARG; h->opt_rows = value; replan = true; break;
+    case ORBFE_OPT_ROWS_FAST: if (value && !in(8, 512)) return ORBFE_ERR_ARG; h->opt_rows_fast = value; replan = true; break;
+    case ORBFE_OPT_ROWS_BLUR: if (value && !in(8, 512)) return ORBFE_ERR_ARG; h->opt_rows_blur = value; replan = true; break;
+    case ORBFE_OPT_BLUR_PIECES: if (!in(0, 1)) return ORBFE_ERR_ARG; h->opt_blur_pieces = value; replan = true; break;
+    case ORBFE_OPT_BLUR_UPDOWN: if (!in(0, 2)) return ORBFE_ERR_ARG; h->opt_blur_updown = value; replan = true; break;
+    case ORBFE_OPT_PYR_ROWS: if (value && !in(2, ORBFE_PW_ROWS)) return ORBFE_ERR_ARG; h->kopts.pw_rows = value; break;
+    case ORBFE_OPT_QT_THREADS_0:
+    case ORBFE_OPT_QT_THREADS_1:
+    case ORBFE_OPT_QT_THREADS_2:
+        if (value && (!in(64, 512) || value % 64)) return ORBFE_ERR_ARG;
+        h->kopts.qt[option - ORBFE_OPT_QT_THREADS_0] = value;
+        break;
+    case ORBFE_OPT_DEBUG: if (value != 0 && value != 50 && value != 51) return ORBFE_ERR_ARG; h->opt_debug = value; replan = true; break;
+    case ORBFE_OPT_PYR_FUSE: if (!in(0, 1)) return ORBFE_ERR_ARG; if (developer_only()) return ORBFE_ERR_STATE; h->kopts.pyr_fuse = value; break;
+    case ORBFE_OPT_FUSE_BLUR_PYR:
+        if (!in(0, 2)) return ORBFE_ERR_ARG;
+        if (developer_only()) return ORBFE_ERR_STATE;
+        h->fuse_blur_pyr = value;
+        if (value) h->fuse_fast_pyr = 0;   // one fusion at a time
+        replan = true;
+        break;
+    case ORBFE_OPT_FUSE_FAST_PYR:
+        if (!in(0, 3)) return ORBFE_ERR_ARG;
+        if (developer_only()) return ORBFE_ERR_STATE;
+        h->fuse_fast_pyr = value;
+        if (value && h->fuse_blur_pyr) { h->fuse_blur_pyr = 0; replan = true; }
+        break;
+    case ORBFE_OPT_FUSE_FAST_PYR_LEVELS:
+        if (!in(1, ORBFE_MAX_LEVELS)) return ORBFE_ERR_ARG;
+        h->fuse_fast_pyr_levels = value;
+        break;
+    default: orbfe_set_error("unknown option %d", option); return ORBFE_ERR_ARG;
+    }
+    if (replan) h->plan_valid = false;   // rebuilt (behind the handle's outstanding work) by the next call
+    return ORBFE_OK;
+}
+
 extern "C" orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32_t collect_stats)
 {
     if (!h || mode < 0 || mode > 1) return ORBFE_ERR_ARG;
@@ -1039,6 +1111,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     s = ensure_batch_buffers(h, nframes);
     if (s != ORBFE_OK) return s;
     OrbLaunch a;
+    a.opts = h->kopts;
     a.h_plan = &h->plan;
     a.d_plan = (const OrbPlan *)h->d_plan.p;
     a.d_tabs = (const OrbTab *)h->d_tabs.p;
@@ -1076,9 +1149,26 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     if (h->last_stream_valid && h->last_stream != st) ORBFE_HIP(hipStreamWaitEvent(st, h->ev_last, 0));
     hipEvent_t *ev = h->profiling ? h->ev[h->prof_calls % ORBFE_PROF_RING] : nullptr;
     if (ev) ORBFE_HIP(hipEventRecord(ev[0], st));
+    auto finish = [&]() -> orbfe_status {   // common tail: profiling bookkeeping, the "last call" state of the handle
+        if (ev) {
+            ORBFE_HIP(hipEventRecord(ev[5], st));
+            h->prof_calls++;
+        }
+        ORBFE_HIP(hipEventRecord(h->ev_last, st));
+        h->last_stream = st;
+        h->last_stream_valid = true;
+        h->last_gray = d_gray;
+        h->last_gray_fstride = (int64_t)frame_stride;
+        h->last_gray_pitch = stride;
+        h->last_nframes = nframes;
+        return ORBFE_OK;
+    };
+    int ov = h->overlap >= 0 ? h->overlap : (nframes >= 128 ? 2 : 0);
+#ifdef ORBFE_DEVELOPER
     if (h->fuse_blur_pyr) {
         // blur(l) and resize(l -> l + 1) in one pass over level l, chained over the levels: level l is read from HBM once for
-        // both.  The stage table then shows the fused chain under "pyramid" and nothing under "blur".
+        // both.  The stage table then shows the fused chain under "pyramid" and nothing under "blur"; `overlap` does not apply
+        // (there is no separate blur to put beside anything).
         ORBFE_HIP(orbk_launch_blur_pyr(a, st));
         if (ev) {
             ORBFE_HIP(hipEventRecord(ev[1], st));
@@ -1093,36 +1183,27 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
             ORBFE_HIP(hipEventRecord(ev[4], st));
         }
         ORBFE_HIP(orbk_launch_describe(a, st));
-        if (ev) {
-            ORBFE_HIP(hipEventRecord(ev[5], st));
-            h->prof_calls++;
-        }
-        ORBFE_HIP(hipEventRecord(h->ev_last, st));
-        h->last_stream = st;
-        h->last_stream_valid = true;
-        h->last_gray = d_gray;
-        h->last_gray_fstride = (int64_t)frame_stride;
-        h->last_gray_pitch = stride;
-        h->last_nframes = nframes;
-        return ORBFE_OK;
+        return finish();
     }
-    // ORBFE_FUSE_FAST_PYR: FAST(l) and resize(l -> l + 1) in one launch per level (k_fast_pyr); the stage table then shows the
-    // whole chain under "fast" and nothing under "pyramid"
-    // ORBFE_FUSE_FAST_PYR=3: no fused kernel -- FAST of level 0, which needs no pyramid, runs on the side stream BESIDE the pyramid
-    // chain (two FAST waves leave room for four resize waves on a SIMD), FAST of the other levels after both
+    // ORBFE_OPT_FUSE_FAST_PYR 1 / 2: FAST(l) and resize(l -> l + 1) in one launch per level (k_fast_pyr); the stage table then
+    // shows the whole chain under "fast" and nothing under "pyramid".  3: no fused kernel -- FAST of level 0, which needs no
+    // pyramid, runs on the side stream BESIDE the pyramid chain (two FAST waves leave room for four resize waves on a SIMD),
+    // FAST of the other levels after both; it has its own event pair (ev_fork2 / ev_join2), the blur fork keeps ev_fork / ev_join
     const bool ffp = h->fuse_fast_pyr == 1 || h->fuse_fast_pyr == 2;
     const bool fside = h->fuse_fast_pyr == 3;
     if (fside) {
         ORBFE_HIP(orbk_launch_fast_levels(a, 0, 0, 1, st));   // the clear only
-        ORBFE_HIP(hipEventRecord(h->ev_fork, st));
-        ORBFE_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        ORBFE_HIP(hipEventRecord(h->ev_fork2, st));
+        ORBFE_HIP(hipStreamWaitEvent(h->side, h->ev_fork2, 0));
         ORBFE_HIP(orbk_launch_fast_levels(a, 0, 1, 0, h->side));
-        ORBFE_HIP(hipEventRecord(h->ev_join, h->side));
+        ORBFE_HIP(hipEventRecord(h->ev_join2, h->side));
     }
+    if ((ffp || fside) && ov == 1) ov = 2;   // the blur needs the whole pyramid, which the fused chain finishes last
+#else
+    const bool ffp = false, fside = false;
+#endif
     if (!ffp) ORBFE_HIP(orbk_launch_pyramid(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[1], st));
-    int ov = h->overlap >= 0 ? h->overlap : (nframes >= 128 ? 2 : 0);
-    if ((ffp || fside) && ov == 1) ov = 2;   // the blur needs the whole pyramid, which the fused chain finishes last
     auto fork_blur = [&]() -> hipError_t {
         hipError_t e = hipEventRecord(h->ev_fork, st);
         if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->ev_fork, 0);
@@ -1133,11 +1214,14 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
         return e;
     };
     if (ov == 1) ORBFE_HIP(fork_blur());
+#ifdef ORBFE_DEVELOPER
     if (ffp) ORBFE_HIP(orbk_launch_fast_pyr(a, h->fuse_fast_pyr_levels, h->fuse_fast_pyr == 2, st));
     else if (fside) {
         ORBFE_HIP(orbk_launch_fast_levels(a, 1, h->plan.nlevels, 0, st));
-        ORBFE_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
-    } else ORBFE_HIP(orbk_launch_fast(a, st));
+        ORBFE_HIP(hipStreamWaitEvent(st, h->ev_join2, 0));
+    } else
+#endif
+        ORBFE_HIP(orbk_launch_fast(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[2], st));
     if (ov == 2) ORBFE_HIP(fork_blur());
     ORBFE_HIP(orbk_launch_octree(a, st));
@@ -1151,18 +1235,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     }
     if (ev) ORBFE_HIP(hipEventRecord(ev[4], st));
     ORBFE_HIP(orbk_launch_describe(a, st));
-    if (ev) {
-        ORBFE_HIP(hipEventRecord(ev[5], st));
-        h->prof_calls++;
-    }
-    ORBFE_HIP(hipEventRecord(h->ev_last, st));
-    h->last_stream = st;
-    h->last_stream_valid = true;
-    h->last_gray = d_gray;
-    h->last_gray_fstride = (int64_t)frame_stride;
-    h->last_gray_pitch = stride;
-    h->last_nframes = nframes;
-    return ORBFE_OK;
+    return finish();
 }
 
 extern "C" orbfe_status orbfe_extract_batch_device(orbfe_handle *h, const uint8_t *d_gray, int32_t nframes,

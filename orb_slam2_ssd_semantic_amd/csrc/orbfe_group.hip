@@ -162,6 +162,15 @@ extern "C" orbfe_status orbfe_group_unique_id(uint8_t id[128])
     return ORBFE_OK;
 }
 
+static void drain_members(orbfe_group *g)
+{
+    for (Member &m : g->mem) {
+        if (m.device >= 0) (void)hipSetDevice(m.device);
+        if (m.s_cmp) (void)hipStreamSynchronize(m.s_cmp);
+        if (m.s_comm) (void)hipStreamSynchronize(m.s_comm);
+    }
+}
+
 static void destroy_member(Member &m)
 {
     if (m.device >= 0) (void)hipSetDevice(m.device);
@@ -184,6 +193,9 @@ extern "C" void orbfe_group_destroy(orbfe_group *g)
 {
     if (!g) return;
     GDeviceGuard guard;
+    // under the copy transport every member pulls the OTHER members' slices on its own communication stream: all streams of
+    // all members are drained before the first block is freed
+    drain_members(g);
     for (Member &m : g->mem) destroy_member(m);
     delete g;
 }
@@ -275,9 +287,7 @@ extern "C" orbfe_status orbfe_group_create_local_ex(const orbfe_params *p, const
 
 extern "C" orbfe_status orbfe_group_create_local(const orbfe_params *p, const int32_t *devices, int32_t ndevices, orbfe_group **out)
 {
-    // $ORBFE_GROUP_TRANSPORT = "copy" selects the copy transport for groups made through this entry point
-    const char *t = getenv("ORBFE_GROUP_TRANSPORT");
-    return orbfe_group_create_local_ex(p, devices, ndevices, t && !strcmp(t, "copy") ? ORBFE_GROUP_COPY : ORBFE_GROUP_RCCL, out);
+    return orbfe_group_create_local_ex(p, devices, ndevices, ORBFE_GROUP_RCCL, out);
 }
 
 extern "C" orbfe_status orbfe_group_create_rank(const orbfe_params *p, int32_t device, int32_t rank, int32_t world, const uint8_t id[128],

@@ -131,7 +131,15 @@ extern "C" orbfe_status orbfe_rotation_consistency(const float *angle_a, const f
     for (int i = 0; i < n; ++i) {
         float d = angle_a[i] - angle_b[i];
         if (d < 0.0f) d += 360.0f;
-        int b = (int)roundf(d * inv);
+        const float fb = roundf(d * inv);
+        // the reference asserts bin >= 0 && bin < HISTO_LENGTH (src/ORBmatcher.cc:314); here an angle pair whose bin falls outside
+        // the histogram (NaN, angles outside [0, 360), or a histo_len below 19 with ordinary angles) is an argument error
+        if (!(fb >= 0.0f && fb <= (float)histo_len)) {
+            orbfe_set_error("orbfe_rotation_consistency: match %d (angles %g, %g) falls into bin %g of %d", i, (double)angle_a[i],
+                            (double)angle_b[i], (double)fb, histo_len);
+            return ORBFE_ERR_ARG;
+        }
+        int b = (int)fb;
         if (b == histo_len) b = 0;
         bin_of[(size_t)i] = b;
         count[(size_t)b]++;

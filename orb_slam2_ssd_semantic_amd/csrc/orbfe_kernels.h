@@ -2,8 +2,16 @@
 #pragma once
 #include "orbfe_common.h"
 
+// launch-shape options of a handle (orbfe_set_option); 0 = the built-in choice
+struct OrbOpts {
+    int32_t pw_rows;   // destination rows per lane run of the pyramid kernels (2..ORBFE_PW_ROWS)
+    int32_t pyr_fuse;  // 1: two pyramid levels per launch (k_pyr_walk2; developer builds)
+    int32_t qt[3];     // threads per workgroup of the quadtree's three level groups
+};
+
 // everything one batched extractor call needs on the device
 struct OrbLaunch {
+    OrbOpts opts;
     const OrbPlan *h_plan;  // host copy
     const OrbPlan *d_plan;  // device copy
     const OrbTab *d_tabs;

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void k_pyr_walk(PyrArgs a)
 #include "orbfe_pyr_body.inc"
 }
 
+#ifdef ORBFE_DEVELOPER   // measured slower than the default chain; compiled only into developer builds
 // Two levels per launch.  The workgroup owns a tile of level B = l: p2_gx column groups x p2_gy runs of a.rb rows, produced
 // from level A = l - 1 exactly as k_pyr_walk does (same row walk, same arithmetic); the finished tile stays in LDS
 // ([row][p2_gx] dwords), is stored to B in a burst, and level C = l + 1 is then resized from the LDS tile: every C pixel whose
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(256) void k_pyr_walk2(Pyr2Args p)
         }
     }
 }
+#endif  // ORBFE_DEVELOPER
 
 // ---------------------------------------------------------------------------------------------------
 // K2  FAST-9/16 with the reference's per-cell semantics: corner at t <=> A > t for the arc strength
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
 #include "orbfe_fast_body.inc"
 }
 
+#ifdef ORBFE_DEVELOPER   // measured slower than the default chain; compiled only into developer builds
 // FAST on level l and cv::resize l -> l + 1 in ONE launch, the launches chained over the levels ("pyramid inside
 // the FAST pass").  FAST's live set leaves no register for a second job in its lanes (157 of the 168 that three waves per SIMD
 // allow), so the fusion is by WORKGROUP ROLE: `npyr` of the launch's workgroups per frame are resize workgroups
@@ -596,6 +599,7 @@ __global__ __launch_bounds__(256) void k_fast_pyr(const OrbPlan *__restrict__ pl
     const int t = wave_lo + (bx - before) * 4 + wv;
 #include "orbfe_fast_body.inc"
 }
+#endif  // ORBFE_DEVELOPER
 
 // ---------------------------------------------------------------------------------------------------
 // K3  DistributeOctTree on the device.  One workgroup per (frame, level).
@@ -1569,6 +1573,7 @@ __global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
     }
 }
 
+#ifdef ORBFE_DEVELOPER   // measured slower than the default chain; compiled only into developer builds
 // Blur of level l AND the resize l -> l + 1 in one pass over level l (ORBFE_FUSE_BLUR_PYR, one launch per level, chained).
 // A lane keeps its blur job (a 4-pixel column of a row block, k_blur7's code unchanged) and, in the same row walk, produces
 // one 4-pixel destination dword of level l + 1 for the destination rows whose upper source row lies in its row block
@@ -1896,6 +1901,7 @@ __global__ BL_BOUNDS void k_blur_pyr(const OrbPlan *__restrict__ plan, FrameSrc 
         }
     }
 }
+#endif  // ORBFE_DEVELOPER
 
 // ---------------------------------------------------------------------------------------------------
 // K5  IC_Angle + steered BRIEF + keypoint assembly.  One wave per output slot.
@@ -2293,7 +2299,9 @@ static FrameSrc make_src(const OrbLaunch &a)
 
 size_t orbk_pyramid_lds_bytes(int dh) { return (size_t)(dh + 8) * sizeof(uint2) + (size_t)PW_ROWS * 256 * 4; }
 
+#ifdef ORBFE_DEVELOPER
 size_t orbk_pyramid2_lds_bytes(int gx, int gy) { return (size_t)(gy * PW_ROWS + 8) * sizeof(uint2) + (size_t)gy * PW_ROWS * gx * 4; }
+#endif
 
 static void pyr_args(const OrbLaunch &a, int l, PyrArgs &pa)
 {
@@ -2317,10 +2325,7 @@ static void pyr_args(const OrbLaunch &a, int l, PyrArgs &pa)
     // rows per lane run: PW_ROWS for batches; a call with a few frames is bound by the length of ONE lane's walk, so it takes
     // short runs and more lanes (ORBFE_PW_ROWS overrides, 2..PW_ROWS)
     int rows = a.nframes <= 8 ? 2 : PW_ROWS;
-    if (const char *e = getenv("ORBFE_PW_ROWS")) {
-        const int v = atoi(e);
-        if (v >= 2 && v <= PW_ROWS) rows = v;
-    }
+    if (a.opts.pw_rows >= 2 && a.opts.pw_rows <= PW_ROWS) rows = a.opts.pw_rows;   // ORBFE_OPT_PYR_ROWS
     const int nb = (D.h + rows - 1) / rows;
     pa.rb = (D.h + nb - 1) / nb;               // balanced run length
     pa.nrblk = (D.h + pa.rb - 1) / pa.rb;      // no empty run
@@ -2328,7 +2333,7 @@ static void pyr_args(const OrbLaunch &a, int l, PyrArgs &pa)
 
 hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
 {
-    // Level l reads level l-1 (:1134): one launch per level.  ORBFE_PYR_FUSE=1 selects the two-levels-per-launch form instead
+    // Level l reads level l-1 (:1134): one launch per level.  ORBFE_OPT_PYR_FUSE (developer builds) selects the two-levels-per-launch form instead
     // (k_pyr_walk2: level l from l-1 in tiles, level l+1 from the tile while it is in LDS -- the odd levels are not re-read
     // from HBM, an 8-level pyramid takes 4 launches).  It is byte-exact and tested, and it is SLOWER on this part: 0.574 vs
     // 0.505 ms per 1024 640x480 frames, 0.424 vs 0.397 ms per 128 1080p frames (profiles/r03_ab_experiments.json) -- the
@@ -2337,14 +2342,13 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
     // of a frame in one launch (a 1024-thread workgroup per frame, workgroup barriers between levels) -- 0.66 ms against
     // 0.63 ms per 1024 frames; with an agent-scope fence between the levels 4.8 ms.
     // (For a single frame the fused form does not win either: 49 us against 48 us for the seven chained launches.)
-    const char *fe = getenv("ORBFE_PYR_FUSE");
-    const bool fuse = fe && atoi(fe) == 1;
     const int nl = a.h_plan->nlevels;
     for (int l = 1; l < nl; ++l) {
         const OrbLevel &D = a.h_plan->lv[l];
         PyrArgs pa;
         pyr_args(a, l, pa);
-        if (fuse && l + 1 < nl && D.p2_tx > 0) {
+#ifdef ORBFE_DEVELOPER
+        if (a.opts.pyr_fuse == 1 && l + 1 < nl && D.p2_tx > 0) {
             const OrbLevel &C = a.h_plan->lv[l + 1];
             Pyr2Args p2;
             p2.ab = pa;
@@ -2360,6 +2364,7 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
             ++l;
             continue;
         }
+#endif
         const int nlanes = ((D.w + 3) / 4) * pa.nrblk;
         dim3 grid((nlanes + 255) / 256, a.nframes);
         hipLaunchKernelGGL(k_pyr_walk, grid, dim3(256), orbk_pyramid_lds_bytes(D.h), st, pa);
@@ -2396,6 +2401,7 @@ static hipError_t fast_clear(const OrbLaunch &a, hipStream_t st)
                                              sizeof(uint32_t) * (size_t)a.nframes * nl * a.cf_words, st);
 }
 
+#ifdef ORBFE_DEVELOPER
 // one k_fast_pyr launch: FAST waves [w0, w1) of the lane list + the resize to level lpyr (0: none)
 static void fast_pyr_one(const OrbLaunch &a, int w0, int w1, int lpyr, int spread, hipStream_t st)
 {
@@ -2455,6 +2461,7 @@ hipError_t orbk_launch_fast_levels(const OrbLaunch &a, int l0, int l1, int clear
     fast_pyr_one(a, P.fwave_off[l0], P.fwave_off[l1], 0, 0, st);
     return hipGetLastError();
 }
+#endif  // ORBFE_DEVELOPER
 
 hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
 {
@@ -2470,12 +2477,8 @@ hipError_t orbk_launch_octree(const OrbLaunch &a, hipStream_t st)
     const bool grouped = a.nframes >= 128;
     const int cut[4] = {0, grouped ? std::max(1, nl / 8) : nl, grouped ? std::max(1, nl / 2) : nl, nl};
     int qts[3] = {512, 256, 128};
-    if (const char *e = getenv("ORBFE_QT")) {  // developer knob: threads per workgroup of the three level groups
-        int v[3];
-        if (sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3)
-            for (int i = 0; i < 3; ++i)
-                if (v[i] >= 64 && v[i] <= QT_MAX && v[i] % 64 == 0) qts[i] = v[i];
-    }
+    for (int i = 0; i < 3; ++i)   // ORBFE_OPT_QT_THREADS_0..2: threads per workgroup of the three level groups
+        if (a.opts.qt[i] >= 64 && a.opts.qt[i] <= QT_MAX && a.opts.qt[i] % 64 == 0) qts[i] = a.opts.qt[i];
     for (int gi = 0; gi < 3; ++gi) {
         const int l0 = cut[gi], l1 = std::min(cut[gi + 1], nl);
         if (l1 <= l0) continue;
@@ -2528,6 +2531,7 @@ hipError_t orbk_launch_blur(const OrbLaunch &a, hipStream_t st)
     return hipGetLastError();
 }
 
+#ifdef ORBFE_DEVELOPER
 hipError_t orbk_launch_blur_pyr(const OrbLaunch &a, hipStream_t st)
 {
     const FrameSrc fs = make_src(a);
@@ -2565,6 +2569,7 @@ hipError_t orbk_launch_blur_pyr(const OrbLaunch &a, hipStream_t st)
     }
     return hipGetLastError();
 }
+#endif  // ORBFE_DEVELOPER
 
 hipError_t orbk_launch_describe(const OrbLaunch &a, hipStream_t st)
 {

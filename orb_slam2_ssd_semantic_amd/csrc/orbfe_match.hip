@@ -114,6 +114,7 @@ __device__ __forceinline__ uint2 bm_expand_byte(uint32_t v, uint32_t mag)
 __global__ __launch_bounds__(BM_WAVES * 64, 2) void k_match_bf(const uint8_t *__restrict__ q_base,
                                                                const uint8_t *__restrict__ t_base,
                                                                const int32_t *__restrict__ n_arr,  // per-frame counts or NULL
+                                                               const int32_t *__restrict__ tn_arr, // counts of the train block
                                                                const int32_t *__restrict__ qframe,
                                                                const int32_t *__restrict__ tframe, int cap, int nq_s,
                                                                int nt_s, float nnratio, int th,
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(BM_WAVES * 64, 2) void k_match_bf(const uint8_t *__
         q = q_base + (int64_t)qf * cap * 32;
         t = t_base + (int64_t)tf * cap * 32;
         nq = min(n_arr[qf], cap);
-        nt = min(n_arr[tf], cap);
+        nt = min(tn_arr[tf], cap);
         out0 = (int64_t)pair * cap;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -309,7 +310,8 @@ __global__ __launch_bounds__(BM_WAVES * 64, 2) void k_match_bf(const uint8_t *__
 // ---------------------------------------------------------------------------------------------------
 #define BP_TILE 128
 __global__ __launch_bounds__(256) void k_match_popc(const uint8_t *__restrict__ q_base, const uint8_t *__restrict__ t_base,
-                                                    const int32_t *__restrict__ n_arr, const int32_t *__restrict__ qframe,
+                                                    const int32_t *__restrict__ n_arr, const int32_t *__restrict__ tn_arr,
+                                                    const int32_t *__restrict__ qframe,
                                                     const int32_t *__restrict__ tframe, int cap, int nq_s, int nt_s,
                                                     float nnratio, int th, int32_t *__restrict__ match,
                                                     int32_t *__restrict__ best_o, int32_t *__restrict__ second_o)
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void k_match_popc(const uint8_t *__restrict__ 
         q = q_base + (int64_t)qf * cap * 32;
         t = t_base + (int64_t)tf * cap * 32;
         nq = min(n_arr[qf], cap);
-        nt = min(n_arr[tf], cap);
+        nt = min(tn_arr[tf], cap);
         out0 = (int64_t)pair * cap;
     }
     const int tid = threadIdx.x;
@@ -757,12 +759,12 @@ static orbfe_status launch_bf(int kernel, const uint8_t *d_q, int nq, const uint
     if (nq > 0) {
         if (kernel == 1)
             hipLaunchKernelGGL(k_match_popc, dim3((nq + 255) / 256, 1), dim3(256), 0, st, d_q, d_t, (const int32_t *)nullptr,
-                               (const int32_t *)nullptr, (const int32_t *)nullptr, 0, nq, nt, nnratio, th, d_match, d_best,
-                               d_second);
+                               (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0, nq, nt, nnratio, th,
+                               d_match, d_best, d_second);
         else
             hipLaunchKernelGGL(k_match_bf, dim3((nq + BM_QW - 1) / BM_QW, 1), dim3(BM_WAVES * 64), 0, st, d_q, d_t,
-                               (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0, nq, nt,
-                               nnratio, th, d_match, d_best, d_second);
+                               (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                               (const int32_t *)nullptr, 0, nq, nt, nnratio, th, d_match, d_best, d_second);
         ORBFE_HIP(hipGetLastError());
     }
     const int ori = (check_ori && d_qa && d_ta) ? 1 : 0;
@@ -832,33 +834,43 @@ extern "C" orbfe_status orbfe_match_bf(orbfe_matcher *m, const uint8_t *q, int32
     return ORBFE_OK;
 }
 
-extern "C" orbfe_status orbfe_match_bf_frames_device(orbfe_matcher *m, const orbfe_keypoint *d_kps,
-                                                     const uint8_t *d_desc, const int32_t *d_n, int32_t cap,
-                                                     const int32_t *d_qframe, const int32_t *d_tframe, int32_t npairs,
-                                                     float nnratio, int32_t th, int32_t check_ori,
-                                                     int32_t *d_match_q2t, int32_t *d_nmatches, void *stream)
+extern "C" orbfe_status orbfe_match_bf_blocks_device(orbfe_matcher *m, const orbfe_keypoint *d_qkps, const uint8_t *d_qdesc,
+                                                     const int32_t *d_qn, const orbfe_keypoint *d_tkps, const uint8_t *d_tdesc,
+                                                     const int32_t *d_tn, int32_t cap, const int32_t *d_qframe,
+                                                     const int32_t *d_tframe, int32_t npairs, float nnratio, int32_t th,
+                                                     int32_t check_ori, int32_t *d_match_q2t, int32_t *d_nmatches, void *stream)
 {
-    if (!m || !d_kps || !d_desc || !d_n || !d_qframe || !d_tframe || !d_match_q2t || !d_nmatches || cap < 1 ||
-        cap > BM_MAX_NT || npairs < 0) {
-        orbfe_set_error("bad argument to orbfe_match_bf_frames_device (cap 1..%d)", BM_MAX_NT);
+    if (!m || !d_qkps || !d_qdesc || !d_qn || !d_tkps || !d_tdesc || !d_tn || !d_qframe || !d_tframe || !d_match_q2t ||
+        !d_nmatches || cap < 1 || cap > BM_MAX_NT || npairs < 0) {
+        orbfe_set_error("bad argument to orbfe_match_bf_blocks_device / _frames_device (cap 1..%d)", BM_MAX_NT);
         return ORBFE_ERR_ARG;
     }
     if (npairs == 0) return ORBFE_OK;
     MDeviceGuard g(m->device);
     hipStream_t st = (hipStream_t)stream;
     if (m->bf_kernel == 1)
-        hipLaunchKernelGGL(k_match_popc, dim3((cap + 255) / 256, npairs), dim3(256), 0, st, d_desc, d_desc, d_n, d_qframe,
+        hipLaunchKernelGGL(k_match_popc, dim3((cap + 255) / 256, npairs), dim3(256), 0, st, d_qdesc, d_tdesc, d_qn, d_tn, d_qframe,
                            d_tframe, cap, 0, 0, nnratio, th, d_match_q2t, (int32_t *)nullptr, (int32_t *)nullptr);
     else
-        hipLaunchKernelGGL(k_match_bf, dim3((cap + BM_QW - 1) / BM_QW, npairs), dim3(BM_WAVES * 64), 0, st, d_desc, d_desc,
-                           d_n, d_qframe, d_tframe, cap, 0, 0, nnratio, th, d_match_q2t, (int32_t *)nullptr,
+        hipLaunchKernelGGL(k_match_bf, dim3((cap + BM_QW - 1) / BM_QW, npairs), dim3(BM_WAVES * 64), 0, st, d_qdesc, d_tdesc,
+                           d_qn, d_tn, d_qframe, d_tframe, cap, 0, 0, nnratio, th, d_match_q2t, (int32_t *)nullptr,
                            (int32_t *)nullptr);
     ORBFE_HIP(hipGetLastError());
-    const float *ang = &d_kps->angle;  // orbfe_keypoint.angle, stride 7 floats
-    hipLaunchKernelGGL(k_rot_prune, dim3(npairs), dim3(256), 0, st, d_match_q2t, ang, ang, 7, d_n, d_qframe, d_tframe,
-                       cap, 0, check_ori ? 1 : 0, d_nmatches);
+    // orbfe_keypoint.angle, stride 7 floats
+    hipLaunchKernelGGL(k_rot_prune, dim3(npairs), dim3(256), 0, st, d_match_q2t, &d_qkps->angle, &d_tkps->angle, 7, d_qn, d_qframe,
+                       d_tframe, cap, 0, check_ori ? 1 : 0, d_nmatches);
     ORBFE_HIP(hipGetLastError());
     return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_match_bf_frames_device(orbfe_matcher *m, const orbfe_keypoint *d_kps,
+                                                     const uint8_t *d_desc, const int32_t *d_n, int32_t cap,
+                                                     const int32_t *d_qframe, const int32_t *d_tframe, int32_t npairs,
+                                                     float nnratio, int32_t th, int32_t check_ori,
+                                                     int32_t *d_match_q2t, int32_t *d_nmatches, void *stream)
+{
+    return orbfe_match_bf_blocks_device(m, d_kps, d_desc, d_n, d_kps, d_desc, d_n, cap, d_qframe, d_tframe, npairs, nnratio, th,
+                                        check_ori, d_match_q2t, d_nmatches, stream);
 }
 
 static bool csr_ok(const uint32_t *node, const uint32_t *off, const uint32_t *idx, int nn, int nfeat,

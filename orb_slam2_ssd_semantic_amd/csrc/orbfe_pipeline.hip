@@ -1,0 +1,314 @@
+// orbfe_pipeline.hip -- the throughput pipeline of the ORB front-end as a product feature (include/orbfe.h "Pipeline").
+//
+// What it stands for in the reference: the frame loop of perfect/Examples/RGB-D/rgbd_tum.cc:77-119 -- one frame after the
+// other through ORBextractor::operator() (Frame constructor) and a match against the previous frame.  Here a whole resident
+// SEQUENCE goes through in one call: it is cut into sub-batches of `max_batch` frames, sub-batch j runs on pipe j mod P -- a
+// pipe = one extractor handle + one matcher handle + one stream, so that the VALU-bound FAST pass of one sub-batch shares the
+// chip with the HBM / LDS-bound stages of its neighbours -- and frame k is matched against frame k - 1 ACROSS sub-batch
+// boundaries and across calls (the last frame of a call is carried over), i.e. a real sequence.
+//
+// Host code only: every kernel is launched through the extractor / matcher entry points of this library.
+#include <new>
+#include <vector>
+
+#include "orbfe_common.h"
+
+struct PipeGuard {
+    int prev = -1, dev = -1;
+    explicit PipeGuard(int d) : dev(d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~PipeGuard()
+    {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+
+struct orbfe_pipeline {
+    orbfe_params prm;
+    int device = 0;
+    int P = 1;     // pipes
+    int F = 1;     // frames per sub-batch (prm.max_batch)
+    int cap = 0;   // keypoint slots per frame
+    std::vector<orbfe_handle *> ext;
+    std::vector<orbfe_matcher *> mat;
+    std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> ev_end;    // per pipe: behind the pipe's last launch of the most recent call
+    std::vector<hipEvent_t> ev_ext;    // per sub-batch index: extraction finished (most recent call)
+    std::vector<hipEvent_t> ev_match;  // per sub-batch index: matcher finished (most recent call)
+    std::vector<char> ev_match_valid;
+    hipEvent_t ev_fork = nullptr;
+    // seq[i] = i - 1: qframe = seq + q0 + 1 (q0, q0 + 1, ...), tframe = seq + q0 (q0 - 1, q0, ...)
+    int32_t *d_seq = nullptr;
+    int seq_len = 0;
+    // the last frame of the previous call (keypoints, descriptors, count): two slots, written alternately
+    orbfe_keypoint *d_ckps[2] = {nullptr, nullptr};
+    uint8_t *d_cdesc[2] = {nullptr, nullptr};
+    int32_t *d_cn[2] = {nullptr, nullptr};
+    hipEvent_t ev_carry[2] = {nullptr, nullptr};
+    int carry_cur = 0;          // slot the NEXT call reads
+    bool have_carry = false;
+    bool joined = true;
+};
+
+static orbfe_status ensure_events(orbfe_pipeline *pl, int nsub)
+{
+    while ((int)pl->ev_ext.size() < nsub) {
+        hipEvent_t a = nullptr, b = nullptr;
+        ORBFE_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        pl->ev_ext.push_back(a);
+        ORBFE_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        pl->ev_match.push_back(b);
+        pl->ev_match_valid.push_back(0);
+    }
+    return ORBFE_OK;
+}
+
+static orbfe_status ensure_seq(orbfe_pipeline *pl, int nframes)
+{
+    if (nframes + 1 <= pl->seq_len) return ORBFE_OK;
+    // the index table is about to be replaced: no launch of an earlier call may still read it
+    for (hipStream_t s : pl->st) ORBFE_HIP(hipStreamSynchronize(s));
+    if (pl->d_seq) ORBFE_HIP(hipFree(pl->d_seq));
+    pl->d_seq = nullptr;
+    pl->seq_len = 0;
+    const int len = std::max(nframes + 1, 4096);
+    std::vector<int32_t> h((size_t)len);
+    for (int i = 0; i < len; ++i) h[(size_t)i] = i - 1;
+    ORBFE_HIP(hipMalloc((void **)&pl->d_seq, (size_t)len * sizeof(int32_t)));
+    ORBFE_HIP(hipMemcpy(pl->d_seq, h.data(), (size_t)len * sizeof(int32_t), hipMemcpyHostToDevice));
+    pl->seq_len = len;
+    return ORBFE_OK;
+}
+
+extern "C" void orbfe_pipeline_destroy(orbfe_pipeline *pl)
+{
+    if (!pl) return;
+    PipeGuard g(pl->device);
+    for (hipStream_t s : pl->st)
+        if (s) (void)hipStreamSynchronize(s);
+    for (orbfe_handle *h : pl->ext) orbfe_destroy(h);
+    for (orbfe_matcher *m : pl->mat) orbfe_matcher_destroy(m);
+    for (hipEvent_t e : pl->ev_end)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : pl->ev_ext)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : pl->ev_match)
+        if (e) (void)hipEventDestroy(e);
+    if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
+    for (int k = 0; k < 2; ++k) {
+        if (pl->ev_carry[k]) (void)hipEventDestroy(pl->ev_carry[k]);
+        if (pl->d_ckps[k]) (void)hipFree(pl->d_ckps[k]);
+        if (pl->d_cdesc[k]) (void)hipFree(pl->d_cdesc[k]);
+        if (pl->d_cn[k]) (void)hipFree(pl->d_cn[k]);
+    }
+    if (pl->d_seq) (void)hipFree(pl->d_seq);
+    for (hipStream_t s : pl->st)
+        if (s) (void)hipStreamDestroy(s);
+    delete pl;
+}
+
+extern "C" orbfe_status orbfe_pipeline_create(const orbfe_params *p, int32_t npipes, orbfe_pipeline **out)
+{
+    if (!p || !out || npipes < 1 || npipes > 16) {
+        orbfe_set_error("bad argument to orbfe_pipeline_create (1..16 pipes)");
+        return ORBFE_ERR_ARG;
+    }
+    *out = nullptr;
+    orbfe_pipeline *pl = new (std::nothrow) orbfe_pipeline();
+    if (!pl) return ORBFE_ERR_NOMEM;
+    pl->prm = *p;
+    pl->P = npipes;
+    pl->F = p->max_batch;
+    auto fail = [&](orbfe_status s) {
+        orbfe_pipeline_destroy(pl);
+        return s;
+    };
+    for (int i = 0; i < npipes; ++i) {
+        orbfe_handle *h = nullptr;
+        orbfe_status s = orbfe_create(p, &h);   // validates the parameter set, fails with ORBFE_ERR_NODEVICE without a GPU
+        if (s != ORBFE_OK) return fail(s);
+        pl->ext.push_back(h);
+        if (i == 0) {
+            // the device the first handle resolved (p->device may be -1 = current)
+            int dev = p->device;
+            if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+            pl->device = dev;
+            pl->prm.device = dev;
+        }
+        orbfe_matcher *m = nullptr;
+        s = orbfe_matcher_create(pl->device, &m);
+        if (s != ORBFE_OK) return fail(s);
+        pl->mat.push_back(m);
+    }
+    PipeGuard g(pl->device);
+    pl->cap = orbfe_keypoint_capacity(pl->ext[0]);
+    for (int i = 0; i < npipes; ++i) {
+        hipStream_t s = nullptr;
+        hipEvent_t e = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { orbfe_set_error("pipeline stream creation failed"); return fail(ORBFE_ERR_HIP); }
+        pl->st.push_back(s);
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { orbfe_set_error("pipeline event creation failed"); return fail(ORBFE_ERR_HIP); }
+        pl->ev_end.push_back(e);
+    }
+    if (hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess) { orbfe_set_error("pipeline event creation failed"); return fail(ORBFE_ERR_HIP); }
+    for (int k = 0; k < 2; ++k) {
+        if (hipEventCreateWithFlags(&pl->ev_carry[k], hipEventDisableTiming) != hipSuccess ||
+            hipMalloc((void **)&pl->d_ckps[k], (size_t)pl->cap * sizeof(orbfe_keypoint)) != hipSuccess ||
+            hipMalloc((void **)&pl->d_cdesc[k], (size_t)pl->cap * 32) != hipSuccess ||
+            hipMalloc((void **)&pl->d_cn[k], 64) != hipSuccess) {
+            orbfe_set_error("pipeline carry buffers: %s", hipGetErrorString(hipGetLastError()));
+            return fail(ORBFE_ERR_NOMEM);
+        }
+        (void)hipMemset(pl->d_cn[k], 0, 64);
+    }
+    orbfe_status s = ensure_seq(pl, 4095);
+    if (s != ORBFE_OK) return fail(s);
+    *out = pl;
+    return ORBFE_OK;
+}
+
+extern "C" int32_t orbfe_pipeline_pipes(const orbfe_pipeline *pl) { return pl ? pl->P : 0; }
+extern "C" int32_t orbfe_pipeline_capacity(const orbfe_pipeline *pl) { return pl ? pl->cap : 0; }
+extern "C" int32_t orbfe_pipeline_sub_batch(const orbfe_pipeline *pl) { return pl ? pl->F : 0; }
+extern "C" orbfe_handle *orbfe_pipeline_extractor(orbfe_pipeline *pl, int32_t pipe)
+{
+    return (pl && pipe >= 0 && pipe < pl->P) ? pl->ext[(size_t)pipe] : nullptr;
+}
+extern "C" orbfe_matcher *orbfe_pipeline_matcher(orbfe_pipeline *pl, int32_t pipe)
+{
+    return (pl && pipe >= 0 && pipe < pl->P) ? pl->mat[(size_t)pipe] : nullptr;
+}
+
+extern "C" orbfe_status orbfe_pipeline_reset_sequence(orbfe_pipeline *pl)
+{
+    if (!pl) return ORBFE_ERR_ARG;
+    pl->have_carry = false;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_pipeline_join(orbfe_pipeline *pl, void *stream)
+{
+    if (!pl) return ORBFE_ERR_ARG;
+    PipeGuard g(pl->device);
+    for (int p = 0; p < pl->P; ++p) ORBFE_HIP(hipStreamWaitEvent((hipStream_t)stream, pl->ev_end[(size_t)p], 0));
+    pl->joined = true;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_pipeline_synchronize(orbfe_pipeline *pl)
+{
+    if (!pl) return ORBFE_ERR_ARG;
+    PipeGuard g(pl->device);
+    for (hipStream_t s : pl->st) ORBFE_HIP(hipStreamSynchronize(s));
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_pipeline_get_overflow(orbfe_pipeline *pl, int32_t *flags)
+{
+    if (!pl || !flags) return ORBFE_ERR_ARG;
+    *flags = 0;
+    for (orbfe_handle *h : pl->ext) {
+        int32_t f = 0;
+        const orbfe_status s = orbfe_get_overflow(h, &f);
+        if (s != ORBFE_OK) return s;
+        *flags |= f;
+    }
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, const uint8_t *d_gray, int32_t nframes, int32_t w,
+                                                            int32_t ht, int32_t stride, size_t frame_stride, orbfe_keypoint *d_kps,
+                                                            uint8_t *d_desc, int32_t cap, int32_t *d_n_out, int32_t *d_match,
+                                                            int32_t *d_nmatches, float nnratio, int32_t th, int32_t check_ori,
+                                                            int32_t flags, void *stream)
+{
+    if (!pl || !d_gray || !d_kps || !d_desc || !d_n_out || nframes < 1 || cap < 1 || (d_match && !d_nmatches)) {
+        orbfe_set_error("bad argument to orbfe_pipeline_extract_match_device");
+        return ORBFE_ERR_ARG;
+    }
+    PipeGuard g(pl->device);
+    const int F = pl->F, P = pl->P;
+    const int nsub = (nframes + F - 1) / F;
+    orbfe_status s = ensure_events(pl, nsub + 1);
+    if (s != ORBFE_OK) return s;
+    s = ensure_seq(pl, nframes);
+    if (s != ORBFE_OK) return s;
+    hipStream_t cs = (hipStream_t)stream;
+    const bool match = d_match != nullptr;
+    const bool cont = (flags & ORBFE_PIPE_CONTINUE) != 0 && pl->have_carry && match;
+    const int rd = pl->carry_cur, wr = pl->carry_cur ^ 1;
+
+    // fork: the pipes start behind whatever the caller's stream holds (the producer of d_gray, the consumer of the output
+    // blocks of an earlier call)
+    ORBFE_HIP(hipEventRecord(pl->ev_fork, cs));
+    for (int p = 0; p < P; ++p) ORBFE_HIP(hipStreamWaitEvent(pl->st[(size_t)p], pl->ev_fork, 0));
+    // The output blocks may be the ones of the previous call (a host that re-uses its buffers): the copy of that call's last
+    // frame into the carry slot must have read it before any pipe overwrites it.
+    if (pl->have_carry)
+        for (int p = 0; p < std::min(P, nsub); ++p) ORBFE_HIP(hipStreamWaitEvent(pl->st[(size_t)p], pl->ev_carry[rd], 0));
+
+    for (int j = 0; j < nsub; ++j) {
+        const int p = j % P;
+        hipStream_t st = pl->st[(size_t)p];
+        const int lo = j * F, nf = std::min(F, nframes - lo);
+        // same reason, per sub-batch: the matcher of sub-batch j + 1 of the PREVIOUS call read the last frame of slice j on
+        // another pipe's stream
+        if (j + 1 < (int)pl->ev_match_valid.size() && pl->ev_match_valid[(size_t)j + 1])
+            ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_match[(size_t)j + 1], 0));
+        s = orbfe_extract_batch_device(pl->ext[(size_t)p], d_gray + (size_t)lo * frame_stride, nf, w, ht, stride, frame_stride,
+                                       d_kps + (size_t)lo * cap, d_desc + (size_t)lo * cap * 32, cap, d_n_out + lo, (void *)st);
+        if (s != ORBFE_OK) return s;
+        ORBFE_HIP(hipEventRecord(pl->ev_ext[(size_t)j], st));
+        if (!match) continue;
+        if (j > 0) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_ext[(size_t)j - 1], 0));   // frame lo - 1 comes from the neighbour pipe
+        const int q0 = lo == 0 ? 1 : lo;
+        const int np = lo + nf - q0;
+        if (np > 0) {
+            s = orbfe_match_bf_blocks_device(pl->mat[(size_t)p], d_kps, d_desc, d_n_out, d_kps, d_desc, d_n_out, cap, pl->d_seq + q0 + 1,
+                                             pl->d_seq + q0, np, nnratio, th, check_ori, d_match + (size_t)q0 * cap, d_nmatches + q0,
+                                             (void *)st);
+            if (s != ORBFE_OK) return s;
+        }
+        if (lo == 0) {
+            if (cont) {
+                ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_carry[rd], 0));
+                // query = frame 0 of this call, train = the carried frame (frame 0 of the carry block)
+                s = orbfe_match_bf_blocks_device(pl->mat[(size_t)p], d_kps, d_desc, d_n_out, pl->d_ckps[rd], pl->d_cdesc[rd], pl->d_cn[rd], cap,
+                                                 pl->d_seq + 1, pl->d_seq + 1, 1, nnratio, th, check_ori, d_match, d_nmatches, (void *)st);
+                if (s != ORBFE_OK) return s;
+            } else {  // the first frame of a sequence has no predecessor
+                ORBFE_HIP(hipMemsetAsync(d_match, 0xFF, (size_t)cap * sizeof(int32_t), st));
+                ORBFE_HIP(hipMemsetAsync(d_nmatches, 0, sizeof(int32_t), st));
+            }
+        }
+        ORBFE_HIP(hipEventRecord(pl->ev_match[(size_t)j], st));
+        pl->ev_match_valid[(size_t)j] = 1;
+    }
+    for (size_t j = (size_t)nsub; j < pl->ev_match_valid.size(); ++j) pl->ev_match_valid[j] = 0;
+    if (!match)
+        for (int j = 0; j < nsub; ++j) pl->ev_match_valid[(size_t)j] = 0;
+
+    // carry: the last frame of this call, for the first frame of the next one.  Slot `wr` was read by the previous call's
+    // frame-0 match on pipe 0: this call's work on pipe 0 is ordered behind it, and the copy waits for this call's first
+    // sub-batch (ev_ext[0], recorded on pipe 0 after it).
+    {
+        const int jl = nsub - 1;
+        hipStream_t st = pl->st[(size_t)(jl % P)];
+        const size_t last = (size_t)nframes - 1;
+        if (jl % P != 0) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_ext[0], 0));
+        ORBFE_HIP(hipMemcpyAsync(pl->d_ckps[wr], d_kps + last * cap, (size_t)std::min(cap, pl->cap) * sizeof(orbfe_keypoint),
+                                 hipMemcpyDeviceToDevice, st));
+        ORBFE_HIP(hipMemcpyAsync(pl->d_cdesc[wr], d_desc + last * cap * 32, (size_t)std::min(cap, pl->cap) * 32, hipMemcpyDeviceToDevice, st));
+        ORBFE_HIP(hipMemcpyAsync(pl->d_cn[wr], d_n_out + last, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        ORBFE_HIP(hipEventRecord(pl->ev_carry[wr], st));
+        pl->carry_cur = wr;
+        pl->have_carry = true;
+    }
+    for (int p = 0; p < P; ++p) ORBFE_HIP(hipEventRecord(pl->ev_end[(size_t)p], pl->st[(size_t)p]));
+    pl->joined = false;
+    if (!(flags & ORBFE_PIPE_NO_JOIN)) return orbfe_pipeline_join(pl, stream);
+    return ORBFE_OK;
+}

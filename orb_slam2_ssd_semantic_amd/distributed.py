@@ -21,7 +21,7 @@ def max_shard(nframes, world):
     return -(-nframes // world)
 
 
-def all_gather_keyframes(n, kps, desc, nframes_total=None, group=None):
+def all_gather_keyframes(n, kps, desc, nframes_total=None, group=None, host_staged=False):
     """All-gather per-rank results.
 
     n    : int32 [S]            keypoint counts of this rank's S frames (S = max_shard; unused slots 0)
@@ -29,6 +29,8 @@ def all_gather_keyframes(n, kps, desc, nframes_total=None, group=None):
     desc : uint8 [S, cap, 32]
     Returns (n_all [W*S], kps_all [W*S, cap, 7], desc_all [W*S, cap, 32]) in rank-major order; with
     `nframes_total` the padding slots of uneven shards are removed so the result is in frame order.
+    host_staged: device tensors over a CPU-only backend (gloo) -- D2H, gather, H2D.  This is how several ranks that share ONE
+    GPU exchange their blocks (RCCL refuses two ranks per device): a test transport, never a measurement.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
@@ -36,8 +38,14 @@ def all_gather_keyframes(n, kps, desc, nframes_total=None, group=None):
     else:
         out = []
         for t in (n, kps, desc):
-            g = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(g, t.contiguous(), group=group)
+            src = t.contiguous()
+            if host_staged and src.is_cuda:
+                hg = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+                dist.all_gather_into_tensor(hg, src.cpu(), group=group)
+                g = hg.to(t.device)
+            else:
+                g = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                dist.all_gather_into_tensor(g, src, group=group)
             out.append(g)
         out = tuple(out)
     if nframes_total is None:
@@ -51,6 +59,24 @@ def all_gather_keyframes(n, kps, desc, nframes_total=None, group=None):
     return tuple(t.index_select(0, idx) for t in out)
 
 
+class _HostStagedWork:
+    """the pending gather of one tensor on the host-staged transport: wait() = host waits for the worker thread, then the
+    CURRENT stream waits (stream level) for the upload of the gathered block"""
+
+    def __init__(self):
+        import threading
+        self.done = threading.Event()
+        self.uploaded = None
+        self.error = None
+
+    def wait(self):
+        self.done.wait()
+        if self.error is not None:
+            raise self.error
+        if self.uploaded is not None:
+            torch.cuda.current_stream().wait_event(self.uploaded)
+
+
 class OverlappedKeyframeGather:
     """Double-buffered, asynchronous form of `all_gather_keyframes` for a steady stream of batches.
 
@@ -58,15 +84,57 @@ class OverlappedKeyframeGather:
     the gather that last read set k has finished (stream-level on RCCL, host-level on gloo), `launch(k)` starts the
     all-gather of set k after the work already enqueued on the current stream; it then overlaps whatever is enqueued
     next.  `result(k)` waits for and returns the gathered (n, kps, desc) of set k in rank-major order.
+
+    host_staged=True: device blocks over a CPU-only group (gloo).  A worker thread waits for an event recorded behind the
+    producer's launches, copies the blocks to pinned host memory, gathers them over `group`, uploads the result on a side stream.
+    The producer keeps enqueuing the next step meanwhile, exactly as with the asynchronous RCCL collective -- this is the
+    transport for several ranks on ONE device (tests; RCCL refuses two ranks per GPU).  `group` must then be a group used by
+    nobody else (the worker thread issues its collectives in launch order on every rank).
     """
 
-    def __init__(self, sets, group=None):
+    def __init__(self, sets, group=None, host_staged=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.sets = sets
         self.pending = [[] for _ in sets]
         self.gathered = [tuple(torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
                                            device=t.device) for t in s) for s in sets]
+        self.host_staged = bool(host_staged) and self.world > 1
+        if self.host_staged:
+            import queue
+            import threading
+            self.h_src = [tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in s) for s in sets]
+            self.h_dst = [tuple(torch.empty(g.shape, dtype=g.dtype).pin_memory() for g in gs) for gs in self.gathered]
+            self.side = torch.cuda.Stream()
+            self.device = torch.cuda.current_device()
+            self.q = queue.Queue()
+            self.thread = threading.Thread(target=self._worker, daemon=True)
+            self.thread.start()
+
+    def _worker(self):
+        torch.cuda.set_device(self.device)   # the current device is per thread
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            k, ready, work = job
+            try:
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ready)
+                    for hs, src in zip(self.h_src[k], self.sets[k]):
+                        hs.copy_(src, non_blocking=True)
+                    self.side.synchronize()
+                    for hd, hs in zip(self.h_dst[k], self.h_src[k]):
+                        dist.all_gather_into_tensor(hd, hs, group=self.group)
+                    for dst, hd in zip(self.gathered[k], self.h_dst[k]):
+                        dst.copy_(hd, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                    self.side.synchronize()   # the pinned blocks are re-used by the next job
+                work.uploaded = ev
+            except BaseException as e:   # noqa: BLE001 -- surfaced by wait()
+                work.error = e
+            work.done.set()
 
     def acquire(self, k):
         for w in self.pending[k]:
@@ -78,12 +146,25 @@ class OverlappedKeyframeGather:
             for dst, src in zip(self.gathered[k], self.sets[k]):
                 dst.copy_(src)
             return
+        if self.host_staged:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            work = _HostStagedWork()
+            self.pending[k].append(work)
+            self.q.put((k, ready, work))
+            return
         for dst, src in zip(self.gathered[k], self.sets[k]):
             self.pending[k].append(dist.all_gather_into_tensor(dst, src.contiguous(), group=self.group, async_op=True))
 
     def result(self, k):
         self.acquire(k)
         return self.gathered[k]
+
+    def close(self):
+        if self.host_staged and self.thread is not None:
+            self.q.put(None)
+            self.thread.join(timeout=60)
+            self.thread = None
 
 
 class KeyframeGroup:
@@ -104,7 +185,7 @@ class KeyframeGroup:
         h = C.c_void_p()
         if rank_of_world is None:
             devs = (C.c_int32 * len(devices))(*devices)
-            if transport is None:   # the C entry point's own default ($ORBFE_GROUP_TRANSPORT, else RCCL)
+            if transport is None:   # the C entry point's own default (RCCL)
                 _ffi.check(L.orbfe_group_create_local(C.byref(p), devs, len(devices), C.byref(h)), "orbfe_group_create_local")
             else:
                 _ffi.check(L.orbfe_group_create_local_ex(C.byref(p), devs, len(devices), int(transport), C.byref(h)),

@@ -17,12 +17,20 @@ class ORBextractor:
     HARRIS_SCORE, FAST_SCORE = 0, 1  # declared, unused by the reference too (include/ORBextractor.h:39)
 
     def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, *,
-                 max_width=640, max_height=480, max_batch=1, device=-1, blur_rounding=0):
-        self._L = _ffi.lib()
+                 max_width=640, max_height=480, max_batch=1, device=-1, blur_rounding=0, options=None, lib=None, _borrow=None):
+        """options: {name: value} for orbfe_set_option (names: _ffi.OPTIONS), applied before the first call.  lib: another
+        build of liborbfe (_ffi.load_variant), e.g. the developer build that holds the measured-slower kernel variants."""
+        self._L = lib or _ffi.lib()
         self._h = C.c_void_p()
-        p = OrbfeParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width, max_height, max_batch,
-                        device, blur_rounding)
-        check(self._L.orbfe_create(C.byref(p), C.byref(self._h)), "orbfe_create")
+        self._owned = _borrow is None
+        if _borrow is not None:   # a handle owned by someone else (a pipe of orbfe_pipeline): never destroyed here
+            self._h = C.c_void_p(_borrow)
+        else:
+            p = OrbfeParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width, max_height, max_batch,
+                            device, blur_rounding)
+            check(self._L.orbfe_create(C.byref(p), C.byref(self._h)), "orbfe_create")
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
         self.nfeatures, self.scaleFactor, self.nlevels = nfeatures, float(np.float32(scaleFactor)), nlevels
         self.iniThFAST, self.minThFAST = iniThFAST, minThFAST
         self.max_batch = max_batch
@@ -34,8 +42,14 @@ class ORBextractor:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.orbfe_destroy(self._h)
+            if self._owned:
+                self._L.orbfe_destroy(self._h)
             self._h = None
+
+    def set_option(self, name, value):
+        """orbfe_set_option by name (overlap, rows, rows_fast, rows_blur, blur_pieces, blur_updown, pyr_rows, qt_threads_0..2,
+        debug, and -- developer builds only -- pyr_fuse, fuse_blur_pyr, fuse_fast_pyr, fuse_fast_pyr_levels)"""
+        check(self._L.orbfe_set_option(self._h, _ffi.OPTIONS[name], int(value)), f"orbfe_set_option({name}, {value})")
 
     def __del__(self):
         self.close()

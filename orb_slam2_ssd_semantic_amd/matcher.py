@@ -30,16 +30,21 @@ class ORBmatcher:
     TH_LOW = 50        # src/ORBmatcher.cc:40
     HISTO_LENGTH = 30  # src/ORBmatcher.cc:41
 
-    def __init__(self, nnratio=0.6, checkOri=True, device=-1):
+    def __init__(self, nnratio=0.6, checkOri=True, device=-1, _borrow=None):
         self._L = _ffi.lib()
         self._m = C.c_void_p()
-        check(self._L.orbfe_matcher_create(device, C.byref(self._m)), "orbfe_matcher_create")
+        self._owned = _borrow is None
+        if _borrow is not None:   # a matcher owned by a pipeline
+            self._m = C.c_void_p(_borrow)
+        else:
+            check(self._L.orbfe_matcher_create(device, C.byref(self._m)), "orbfe_matcher_create")
         self.mfNNratio = float(nnratio)
         self.mbCheckOrientation = bool(checkOri)
 
     def close(self):
         if getattr(self, "_m", None):
-            self._L.orbfe_matcher_destroy(self._m)
+            if self._owned:
+                self._L.orbfe_matcher_destroy(self._m)
             self._m = None
 
     def __del__(self):

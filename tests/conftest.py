@@ -37,3 +37,14 @@ def oracle():
 @pytest.fixture(scope="session")
 def have_gpu():
     return _gpu_present()
+
+
+@pytest.fixture(scope="session")
+def dev_lib():
+    """The -DORBFE_DEVELOPER build of liborbfe (ab/liborbfe_dev.so, built by __graft_entry__.build()): the release library plus
+    the measured-slower kernel variants (k_pyr_walk2, k_fast_pyr, k_blur_pyr) that the release build compiles out."""
+    from orb_slam2_ssd_semantic_amd import _build, _ffi
+    path = os.path.join(ROOT, "ab", "liborbfe_dev.so")
+    if not os.path.exists(path):
+        _build.build_variant("dev", ["-DORBFE_DEVELOPER"])
+    return _ffi.load_variant(path)

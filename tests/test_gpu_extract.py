@@ -156,18 +156,17 @@ def test_clustered_corners_deep_quadtree(oracle, ext, seed, box):
 
 
 def test_streaming_quadtree_passes_only(oracle):
-    """ORBFE_DEBUG=50 disables the histogram passes: every pass streams over the keys (the deep-tree code path)."""
+    """ORBFE_OPT_DEBUG = 50 disables the histogram passes: every pass streams over the keys (the deep-tree code path)."""
     from orb_slam2_ssd_semantic_amd import ORBextractor
-    os.environ["ORBFE_DEBUG"] = "50"
-    try:
-        e = ORBextractor(1000, 1.2, 8, 20, 7)
-        for seed, sparse in ((0, False), (2, True)):
-            img = synth_frame(seed, sparse=sparse)
-            ok, od = oracle.OracleExtractor()(img)
-            gk, gd = e(img)
-            assert_same_output(gk, gd, ok, od)
-    finally:
-        del os.environ["ORBFE_DEBUG"]
+    e = ORBextractor(1000, 1.2, 8, 20, 7, options={"debug": 50})
+    for seed, sparse in ((0, False), (2, True)):
+        img = synth_frame(seed, sparse=sparse)
+        ok, od = oracle.OracleExtractor()(img)
+        gk, gd = e(img)
+        assert_same_output(gk, gd, ok, od)
+    e.set_option("debug", 0)   # back to the default passes on the same handle (the plan is rebuilt)
+    gk, gd = e(img)
+    assert_same_output(gk, gd, ok, od)
 
 
 @pytest.mark.parametrize("nf,h,w", [(3000, 480, 640), (10000, 480, 640), (20000, 1080, 1920)])
@@ -200,44 +199,36 @@ def test_large_nfeatures_node_arrays_beyond_the_lds(oracle, nf, h, w):
         assert_same_output(kps[b, :n[b]].copy().view(KP_DTYPE).reshape(-1), desc[b, :n[b]], *ref[b])
 
 
-def test_two_pyramid_levels_per_launch(oracle):
-    """ORBFE_PYR_FUSE=1: k_pyr_walk2 produces level l in LDS tiles and level l+1 from the tile (the odd levels are not
+def test_two_pyramid_levels_per_launch(oracle, dev_lib):
+    """ORBFE_OPT_PYR_FUSE = 1 (developer build): k_pyr_walk2 produces level l in LDS tiles and level l+1 from the tile (the odd levels are not
     re-read from HBM).  Not the default (it is slower on this part, see the launcher), but byte-exact: every level of odd
     and even sized frames, 8 and 5 levels, scale factors 1.2 and 1.35, against the oracle."""
     from orb_slam2_ssd_semantic_amd import ORBextractor
-    os.environ["ORBFE_PYR_FUSE"] = "1"
-    try:
-        for (h, w, nl, sf, seed) in ((480, 640, 8, 1.2, 1), (389, 517, 8, 1.2, 7), (1080, 1920, 8, 1.2, 3), (301, 1203, 5, 1.35, 9),
-                                     (600, 431, 7, 1.2, 4)):
-            img = synth_frame(seed, h, w)
-            oe = oracle.OracleExtractor(700, sf, nl, 20, 7)
-            ok, od = oe(img, cap=1200)
-            e = ORBextractor(700, sf, nl, 20, 7, max_width=w, max_height=h)
-            gk, gd = e(img)
-            for l in range(nl):
-                assert np.array_equal(e.pyramid_level(l), oe.level(l)), (h, w, l)
-            assert_same_output(gk, gd, ok, od)
-    finally:
-        del os.environ["ORBFE_PYR_FUSE"]
+    for (h, w, nl, sf, seed) in ((480, 640, 8, 1.2, 1), (389, 517, 8, 1.2, 7), (1080, 1920, 8, 1.2, 3), (301, 1203, 5, 1.35, 9),
+                                 (600, 431, 7, 1.2, 4)):
+        img = synth_frame(seed, h, w)
+        oe = oracle.OracleExtractor(700, sf, nl, 20, 7)
+        ok, od = oe(img, cap=1200)
+        e = ORBextractor(700, sf, nl, 20, 7, max_width=w, max_height=h, lib=dev_lib, options={"pyr_fuse": 1})
+        gk, gd = e(img)
+        for l in range(nl):
+            assert np.array_equal(e.pyramid_level(l), oe.level(l)), (h, w, l)
+        assert_same_output(gk, gd, ok, od)
 
 
 def test_generic_quadtree_passes_only(oracle):
-    """ORBFE_DEBUG=51 disables the fused breadth-first pass of the histogram mode: every pass goes through the generic node
+    """ORBFE_OPT_DEBUG = 51 disables the fused breadth-first pass of the histogram mode: every pass goes through the generic node
     phase (the one the largest-first passes and the deep trees use) and must give the same trees."""
     from orb_slam2_ssd_semantic_amd import ORBextractor
-    os.environ["ORBFE_DEBUG"] = "51"
-    try:
-        e = ORBextractor(1000, 1.2, 8, 20, 7)
-        for seed, sparse in ((0, False), (2, True), (5, False)):
-            img = synth_frame(seed, sparse=sparse)
-            oe = oracle.OracleExtractor()
-            ok, od = oe(img)
-            gk, gd = e(img)
-            for l in range(8):
-                assert np.array_equal(e.selected(l), cand_array(oe.selected(l))), f"quadtree level {l}"
-            assert_same_output(gk, gd, ok, od)
-    finally:
-        del os.environ["ORBFE_DEBUG"]
+    e = ORBextractor(1000, 1.2, 8, 20, 7, options={"debug": 51})
+    for seed, sparse in ((0, False), (2, True), (5, False)):
+        img = synth_frame(seed, sparse=sparse)
+        oe = oracle.OracleExtractor()
+        ok, od = oe(img)
+        gk, gd = e(img)
+        for l in range(8):
+            assert np.array_equal(e.selected(l), cand_array(oe.selected(l))), f"quadtree level {l}"
+        assert_same_output(gk, gd, ok, od)
 
 
 def test_edge_cases(oracle, ext):
@@ -475,8 +466,8 @@ def test_hip_path_equals_the_compiled_reference_directly():
 
 def test_side_stream_blur_and_grouped_quadtree_equal_the_inline_single_launch_path(oracle, monkeypatch):
     """Batches of >= 128 frames run the blur on the handle's side stream next to the quadtree and launch the quadtree per
-    level group; smaller batches (and ORBFE_OVERLAP=0) keep one stream / one launch.  All of it must be invisible:
-    136 frames through the large-batch path == the same frames in chunks of 8 through the small-batch path == ORBFE_OVERLAP=0,
+    level group; smaller batches (and ORBFE_OPT_OVERLAP = 0) keep one stream / one launch.  All of it must be invisible:
+    136 frames through the large-batch path == the same frames in chunks of 8 through the small-batch path == overlap 0 / 1,
     and a sample of them == the oracle."""
     import torch
     from orb_slam2_ssd_semantic_amd import KP_DTYPE, ORBextractor
@@ -485,11 +476,8 @@ def test_side_stream_blur_and_grouped_quadtree_equal_the_inline_single_launch_pa
     dg = torch.from_numpy(frames).cuda()
 
     def run(chunk, env):
-        if env is None:
-            monkeypatch.delenv("ORBFE_OVERLAP", raising=False)
-        else:
-            monkeypatch.setenv("ORBFE_OVERLAP", env)
-        e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=chunk)
+        e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=chunk,
+                         options=None if env is None else {"overlap": int(env)})
         cap = e.capacity()
         dk = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
         dd = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
@@ -512,15 +500,15 @@ def test_side_stream_blur_and_grouped_quadtree_equal_the_inline_single_launch_pa
 
 
 @pytest.mark.parametrize("fuse", ["1", "2"])
-def test_fused_blur_and_pyramid_pass_equals_the_separate_kernels(oracle, monkeypatch, fuse):
-    """ORBFE_FUSE_BLUR_PYR: blur(l) and resize(l -> l + 1) in one chained pass over the levels (k_blur_pyr): 1 = every blur lane
+def test_fused_blur_and_pyramid_pass_equals_the_separate_kernels(oracle, dev_lib, fuse):
+    """ORBFE_OPT_FUSE_BLUR_PYR (developer build): blur(l) and resize(l -> l + 1) in one chained pass over the levels (k_blur_pyr): 1 = every blur lane
     carries a resize job, 2 = resize jobs in waves of their own beside the blur waves of the same rows.  Neither beats k_pyr_walk
     + k_blur7 on time, so both are off by default -- same pyramid, same blurred levels, same output, in
     both blur rounding modes and on odd sizes."""
     from orb_slam2_ssd_semantic_amd import ORBextractor
-    monkeypatch.setenv("ORBFE_FUSE_BLUR_PYR", fuse)
     for (w, h, nf, nlev, sf, mode) in ((640, 480, 1000, 8, 1.2, 0), (517, 389, 700, 6, 1.3, 1), (333, 271, 400, 4, 1.5, 0)):
-        e = ORBextractor(nf, sf, nlev, 20, 7, max_width=w, max_height=h, max_batch=3, blur_rounding=mode)
+        e = ORBextractor(nf, sf, nlev, 20, 7, max_width=w, max_height=h, max_batch=3, blur_rounding=mode, lib=dev_lib,
+                         options={"fuse_blur_pyr": int(fuse)})
         frames = [synth_frame(500 + i, h, w, sparse=(i == 1)) for i in range(3)]
         oe = oracle.OracleExtractor(nf, sf, nlev, 20, 7)
         oe.set_blur_mode(mode)
@@ -535,18 +523,18 @@ def test_fused_blur_and_pyramid_pass_equals_the_separate_kernels(oracle, monkeyp
 
 
 @pytest.mark.parametrize("fuse,levels", [("1", None), ("2", None), ("2", "3"), ("1", "1"), ("3", None)])
-def test_fused_fast_and_pyramid_pass_equals_the_separate_kernels(oracle, monkeypatch, fuse, levels):
-    """ORBFE_FUSE_FAST_PYR ("pyramid inside the FAST pass"): FAST(l) and resize(l -> l + 1) in ONE launch per
+def test_fused_fast_and_pyramid_pass_equals_the_separate_kernels(oracle, dev_lib, fuse, levels):
+    """ORBFE_OPT_FUSE_FAST_PYR (developer build; VERDICT r03 #3, "pyramid inside the FAST pass"): FAST(l) and resize(l -> l + 1) in ONE launch per
     level (k_fast_pyr), the two jobs in workgroups of their own -- 1 = resize workgroups first, 2 = dealt out proportionally;
     ORBFE_FUSE_FAST_PYR_LEVELS = k fuses the first k levels only (plain resizes + one FAST launch for the rest); 3 = no fused
     kernel, FAST of level 0 on the side stream beside the pyramid chain.  Same pyramid,
     same candidate lists, same output as k_pyr_walk x 7 + k_fast_map, single frames and batches, odd sizes, both FAST variants."""
     from orb_slam2_ssd_semantic_amd import ORBextractor
-    monkeypatch.setenv("ORBFE_FUSE_FAST_PYR", fuse)
+    opts = {"fuse_fast_pyr": int(fuse)}
     if levels:
-        monkeypatch.setenv("ORBFE_FUSE_FAST_PYR_LEVELS", levels)
+        opts["fuse_fast_pyr_levels"] = int(levels)
     for (w, h, nf, nlev, sf) in ((640, 480, 1000, 8, 1.2), (517, 389, 700, 6, 1.3), (333, 271, 400, 4, 1.5), (128, 112, 100, 3, 1.2)):
-        e = ORBextractor(nf, sf, nlev, 20, 7, max_width=w, max_height=h, max_batch=16)
+        e = ORBextractor(nf, sf, nlev, 20, 7, max_width=w, max_height=h, max_batch=16, lib=dev_lib, options=opts)
         frames = [synth_frame(700 + i, h, w, sparse=(i % 3 == 1)) for i in range(16)]
         oe = oracle.OracleExtractor(nf, sf, nlev, 20, 7)
         outs = []
@@ -567,16 +555,16 @@ def test_fused_fast_and_pyramid_pass_equals_the_separate_kernels(oracle, monkeyp
 
 
 @pytest.mark.parametrize("updown", ["0", "2"])
-def test_blur_row_walk_directions_give_the_same_levels(oracle, monkeypatch, updown):
-    """ORBFE_BLUR_UPDOWN: odd row blocks of k_blur7 walk upwards (the 7 x 7 kernel is vertically symmetric) so that neighbouring
+def test_blur_row_walk_directions_give_the_same_levels(oracle, updown):
+    """ORBFE_OPT_BLUR_UPDOWN: odd row blocks of k_blur7 walk upwards (the 7 x 7 kernel is vertically symmetric) so that neighbouring
     blocks read their shared halo rows at the same time; default 1 = only where it adds no wave, 2 = everywhere, 0 = nowhere.
     Every setting gives the oracle's blurred levels byte for byte, in both rounding modes, on sizes whose last row block is short
     and on single frames (short runs) as well as batches (40-row runs)."""
     from orb_slam2_ssd_semantic_amd import ORBextractor
-    monkeypatch.setenv("ORBFE_BLUR_UPDOWN", updown)
     for (w, h, nf, nlev, sf, mode, mb) in ((640, 480, 1000, 8, 1.2, 0, 16), (517, 389, 700, 6, 1.3, 1, 16), (333, 271, 400, 4, 1.5, 0, 1),
                                            (752, 480, 1200, 8, 1.2, 1, 9)):
-        e = ORBextractor(nf, sf, nlev, 20, 7, max_width=w, max_height=h, max_batch=mb, blur_rounding=mode)
+        e = ORBextractor(nf, sf, nlev, 20, 7, max_width=w, max_height=h, max_batch=mb, blur_rounding=mode,
+                         options={"blur_updown": int(updown)})
         oe = oracle.OracleExtractor(nf, sf, nlev, 20, 7)
         oe.set_blur_mode(mode)
         frames = [synth_frame(900 + i, h, w, sparse=(i == 1)) for i in range(min(mb, 3))]

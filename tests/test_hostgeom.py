@@ -172,6 +172,28 @@ def test_rotation_consistency_equals_bins_plus_three_maxima(oracle):
         assert np.array_equal(drop[:n].astype(bool), np.array([bb not in keep for bb in bins], bool)), case
 
 
+def test_rotation_consistency_rejects_bins_outside_the_histogram():
+    """histo_len < 19 with ordinary angles, NaN and angles outside [0, 360) index past the histogram in the
+    reference (it asserts, src/ORBmatcher.cc:314); the C-ABI returns ORBFE_ERR_ARG and writes nothing."""
+    L = _ffi.lib()
+    a = np.array([350.0, 10.0, 20.0], F32)
+    b = np.array([0.0, 10.0, 20.0], F32)
+    drop = np.full(3, 7, np.uint8)
+    assert L.orbfe_rotation_consistency(ptr(a), ptr(b), 3, 5, ptr(drop)) == _ffi.ORBFE_ERR_ARG   # round(350 / 5) = 70 >= 5
+    assert np.all(drop == 7)
+    assert L.orbfe_rotation_consistency(ptr(a), ptr(b), 3, 19, ptr(drop)) == 0                   # round(350 / 19) = 18 < 19
+    for bad in (np.nan, np.inf, -np.inf, 1.0e6, -1.0e6):
+        a2 = a.copy()
+        a2[1] = bad
+        drop[:] = 7
+        assert L.orbfe_rotation_consistency(ptr(a2), ptr(b), 3, 30, ptr(drop)) == _ffi.ORBFE_ERR_ARG, bad
+        assert np.all(drop == 7)
+    # histo_len == bin (360 / 1 at histo_len 360 -> bin 1; d = 360 - eps at histo_len 19 -> bin 19 -> wraps to 0)
+    a3 = np.array([359.99], F32)
+    b3 = np.array([0.0], F32)
+    assert L.orbfe_rotation_consistency(ptr(a3), ptr(b3), 1, 19, ptr(drop)) == 0 and drop[0] == 0
+
+
 def test_initialization_resolve_equals_the_sequential_rule():
     """pure-Python transcription of the rule's MEANING (not of the reference's statements): queries in order; a candidate held
     by an earlier query at a distance <= the own one is invisible; accept best <= th and best < second * nnratio; take over."""

@@ -523,3 +523,24 @@ def test_reference_stereo_frame_constructor_equals_the_oracle_chain(oracle):
         xy = np.stack([kL["x"], kL["y"]], 1).astype(np.float32)
         off, idx = oracle.assign_grid(xy, minx, miny, gwi, ghi)
         assert np.array_equal(got["cell_off"], off) and np.array_equal(got["cell_idx"], idx)
+
+
+@pytest.mark.skipif(not R.vectorised_available(), reason="oracle/_ref/libref_orb_vec.so not built or no AVX2 on this host")
+def test_vectorised_build_of_the_reference_is_bit_identical(ref, oracle):
+    """oracle/_ref/libref_orb_vec.so (bench.py's cpu_baseline_vectorised): the same unmodified reference sources and stub
+    stand-ins as libref_orb.so, built -O3 -mavx2 -ffp-contract=off.  Auto-vectorisation must not change a bit: frames of
+    three sizes, both blur roundings, against the -O2 build and the oracle."""
+    for seed, (h, w), nf, mode in ((1, (480, 640), 1000, 0), (2, (480, 640), 2000, 1), (3, (389, 517), 700, 0), (4, (1080, 1920), 4000, 0)):
+        img = synth_frame(seed, h, w, sparse=(seed == 3))
+        R.configure(bump=True, canonical_trig=True, blur_mode=mode)
+        k0, d0 = R.RefExtractor(nf, 1.2, 8, 20, 7)(img, cap=nf + 512)
+        with R.use_vectorised():
+            R.configure(bump=True, canonical_trig=True, blur_mode=mode)
+            k1, d1 = R.RefExtractor(nf, 1.2, 8, 20, 7)(img, cap=nf + 512)
+        oe = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+        oe.set_blur_mode(mode)
+        ok, od = oe(img, cap=nf + 512)
+        assert len(k0) == len(k1) == len(ok) > 0
+        assert np.array_equal(k0.view(np.uint8), k1.view(np.uint8)) and np.array_equal(d0, d1), (seed, "vec vs -O2")
+        assert np.array_equal(k1.view(np.uint8), ok.view(np.uint8)) and np.array_equal(d1, od), (seed, "vec vs oracle")
+    R.configure(bump=True, canonical_trig=True, blur_mode=0)
