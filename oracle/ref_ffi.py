@@ -420,6 +420,60 @@ def stereo_frame(left, right, fx, fy, cx, cy, bf, th_depth, mb_before=0.0, nfeat
                 scal=scal)
 
 
+def _declare_frame_ctor(fn):
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    fn.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci] + [cf] * 6 + [vp] * 5 + [ci, vp, vp, vp]
+    fn.restype = ci
+
+
+FRAME_RGBD, FRAME_MONO, FRAME_MASKED = 0, 1, 2
+
+
+def frame_ctor(kind, gray, depth_img=None, mask=None, fx=535.4, fy=539.2, cx=320.1, cy=247.6, bf=40.0, th_depth=40.0, nfeatures=1000,
+               scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, shim=False, extractor=None, blur_rounding=None):
+    """The reference's constructors of the TUM path, compiled (sliced verbatim):
+      FRAME_RGBD    Frame(imGray, imDepth, ts, extractor, voc, K, distCoef, bf, thDepth)          src/Frame.cc:176-245
+      FRAME_MONO    Frame(imGray, ts, extractor, voc, K, distCoef, bf, thDepth)                   src/Frame.cc:247-311
+      FRAME_MASKED  Frame(imGray, imDepth, imMask, ts, extractor, voc, K, distCoef, bf, thDepth)  perfect/src/Frame.cc:328-420
+    around the reference's extractor (shim=False, libref_orb.so) or the PRODUCT's extractor shim (shim=True, libshim_stereo.so;
+    needs a GPU).  depth_img: float32 [h, w] (metres, as Tracking hands it over), mask: uint8 [h, w] of 0 / 1."""
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    dimg = None if depth_img is None else np.ascontiguousarray(depth_img, np.float32)
+    mimg = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    cap = nfeatures + 4 * nlevels + 256
+    keys, keys_un = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    ur, dep = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    cell_off, cell_idx = np.zeros(64 * 48 + 1, np.uint32), np.zeros(cap, np.uint32)
+    scal = np.zeros(8, np.float32)
+    made = False
+    if shim:
+        L = shimstereo_lib()
+        _declare_frame_ctor(L.shim_st_frame_ctor)
+        fn = L.shim_st_frame_ctor
+        if extractor is None:
+            made = True
+            extractor = L.shim_st_ext_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+            if blur_rounding is not None:
+                L.shim_st_ext_set_blur_rounding(extractor, int(blur_rounding))
+        hE = extractor
+    else:
+        L = lib()
+        _declare_frame_ctor(L.ref_frame_ctor)
+        fn = L.ref_frame_ctor
+        extractor = extractor or RefExtractor(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        hE = extractor.h
+    n = fn(hE, int(kind), _p(gray), None if dimg is None else _p(dimg), None if mimg is None else _p(mimg), w, h, gray.strides[0], fx, fy,
+           cx, cy, bf, th_depth, _p(keys), _p(keys_un), _p(desc), _p(ur), _p(dep), cap, _p(cell_off), _p(cell_idx), _p(scal))
+    if made:
+        L.shim_st_ext_destroy(extractor)
+    if n < 0:
+        raise RuntimeError(f"frame_ctor rc={n}")
+    return dict(keys=keys[:n].copy(), keys_un=keys_un[:n].copy(), desc=desc[:n].copy(), u_right=ur[:n].copy(), depth=dep[:n].copy(),
+                cell_off=cell_off, cell_idx=cell_idx[:int(cell_off[-1])].copy(), scal=scal, N=n)
+
+
 def configure(bump=True, canonical_trig=True, blur_mode=0):
     """The two machine-dependent spots of the reference binary and the blur column-rounding variant:
     bump=True           operator new from a bump arena -> the :686 pointer sort breaks ties by creation order

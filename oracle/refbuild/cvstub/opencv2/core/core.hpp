@@ -75,10 +75,14 @@ static inline int cvCeil(double value)
     return i + (i < value);
 }
 
-namespace cv
-{
+/* OpenCV declares these at GLOBAL scope (core/hal/interface.h); perfect/src/Frame.cc:366 writes at<uchar> inside ORB_SLAM2 */
 typedef unsigned char uchar;
 typedef unsigned short ushort;
+
+namespace cv
+{
+using ::uchar;
+using ::ushort;
 
 template <typename T> static inline T saturate_cast(float v) { return (T)v; }
 template <> inline int saturate_cast<int>(float v) { return cvRound(v); }
@@ -354,6 +358,24 @@ class Mat
         }
         return m;
     }
+    /* Mat::push_back(const Mat&) (core/matrix.cpp): an empty matrix becomes a copy of m, otherwise m's rows are appended
+     * (same type and width); perfect/src/Frame.cc:372 collects the descriptor rows of the unmasked keypoints with it */
+    void push_back(const Mat &m)
+    {
+        if (m.rows == 0) return;
+        if (!data || rows == 0) {
+            Mat c;
+            m.copyTo(c);
+            *this = c;
+            return;
+        }
+        assert(m.type() == type() && m.cols == cols);
+        Mat grown(rows + m.rows, cols, type());
+        for (int y = 0; y < rows; y++) memcpy(grown.data + (size_t)y * grown.step.v, data + (size_t)y * step.v, (size_t)cols * elemSize());
+        for (int y = 0; y < m.rows; y++)
+            memcpy(grown.data + (size_t)(rows + y) * grown.step.v, m.data + (size_t)y * m.step.v, (size_t)cols * elemSize());
+        *this = grown;
+    }
     Mat rowRange(int startrow, int endrow) const { return Mat(*this, Rect(0, startrow, cols, endrow - startrow)); }
     Mat colRange(int startcol, int endcol) const { return Mat(*this, Rect(startcol, 0, endcol - startcol, rows)); }
     Mat row(int y) const { return Mat(*this, Rect(0, y, cols, 1)); }
@@ -501,8 +523,40 @@ inline void Mat::convertTo(Mat &dst, int rtype) const
 namespace stubdetail
 {
 inline Mat newf(int r, int c) { return Mat(r, c, CV_32F); }
+
 inline float gf(const Mat &m, int y, int x) { return m.at<float>(y, x); }
 } // namespace stubdetail
+
+/* cv::Scalar and cv::sum (core/stat.cpp: per-channel sums as doubles); perfect/src/Frame.cc:360 sums the 0 / 1 dynamic mask */
+template <typename T> class Scalar_
+{
+  public:
+    Scalar_() { val[0] = val[1] = val[2] = val[3] = 0; }
+    Scalar_(T v0, T v1 = 0, T v2 = 0, T v3 = 0) { val[0] = v0; val[1] = v1; val[2] = v2; val[3] = v3; }
+    T val[4];
+    const T &operator[](int i) const { return val[i]; }
+    T &operator[](int i) { return val[i]; }
+};
+typedef Scalar_<double> Scalar;
+inline Scalar sum(const Mat &m)
+{
+    Scalar s;
+    const int cn = m.channels();
+    assert(cn <= 4);
+    for (int y = 0; y < m.rows; y++)
+        for (int x = 0; x < m.cols; x++)
+            for (int c = 0; c < cn; c++) {
+                double v = 0;
+                switch (m.depth()) {
+                case CV_8U: v = m.ptr<uchar>(y)[x * cn + c]; break;
+                case CV_32F: v = m.ptr<float>(y)[x * cn + c]; break;
+                case CV_32S: v = m.ptr<int>(y)[x * cn + c]; break;
+                default: assert(!"cv stub: sum() of this depth");
+                }
+                s.val[c] += v;
+            }
+    return s;
+}
 inline Mat Mat::t() const
 {
     Mat r = stubdetail::newf(cols, rows);

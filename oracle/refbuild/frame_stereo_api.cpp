@@ -9,6 +9,10 @@
  *                         constructor reads the shim's public mvImagePyramid in ComputeStereoMatches (:649, :761-778)
  *                         with nothing set on the extractor -- the drop-in claim of INTEGRATION.md for stereo.
  * The constructor runs its two ExtractORB calls on two threads, as written (:121-124).
+ *
+ * The same translation unit carries the callers of the TUM path (BASELINE configs 1-3 are RGB-D): the RGB-D constructor
+ * (src/Frame.cc:176-245) with ComputeStereoFromRGBD (:850-874), the monocular constructor (:247-311), and perfect/'s RGB-D
+ * constructor with the dynamic-object mask (perfect/src/Frame.cc:328-420), behind FS_NAME(frame_ctor).
  */
 #include <algorithm>
 #include <climits>
@@ -33,6 +37,7 @@ float Frame::mnMinX = 0, Frame::mnMaxX = 640, Frame::mnMinY = 0, Frame::mnMaxY =
 float Frame::mfGridElementWidthInv = 0.1f, Frame::mfGridElementHeightInv = 0.1f;
 #endif
 #include "gen_frame_stereo_ctor.inc"
+#include "gen_frame_masked_ctor.inc"
 } // namespace ORB_SLAM2
 
 using namespace ORB_SLAM2;
@@ -112,6 +117,67 @@ int FS_NAME(stereo_frame)(void *extL, void *extR, const uint8_t *left, const uin
         scal[0] = Frame::mnMinX; scal[1] = Frame::mnMaxX; scal[2] = Frame::mnMinY; scal[3] = Frame::mnMaxY;
         scal[4] = Frame::mfGridElementWidthInv; scal[5] = Frame::mfGridElementHeightInv; scal[6] = f.mb; scal[7] = f.fx;
         rc = n;
+    } catch (const std::length_error &) {
+        rc = -2;
+    } catch (const std::exception &) {
+        rc = -3;
+    }
+    FS_LEAVE();
+    return rc;
+}
+
+/* kind 0: Frame(imGray, imDepth, ts, ext, voc, K, distCoef, bf, thDepth)          src/Frame.cc:176-245
+ * kind 1: Frame(imGray, ts, ext, voc, K, distCoef, bf, thDepth)                   src/Frame.cc:247-311
+ * kind 2: Frame(imGray, imDepth, imMask, ts, ext, voc, K, distCoef, bf, thDepth)  perfect/src/Frame.cc:328-420
+ * depth_img: w x h floats (the caller converted it, src/Tracking.cc:355-356), mask: w x h bytes 0 / 1.  Outputs as
+ * FS_NAME(stereo_frame); scal[8] = {mnMinX, mnMaxX, mnMinY, mnMaxY, grid width inv, grid height inv, mb, fx}. */
+int FS_NAME(frame_ctor)(void *ext, int kind, const uint8_t *gray, const float *depth_img, const uint8_t *mask, int w, int h, int stride,
+                        float fx, float fy, float cx, float cy, float bf, float th_depth, fs_kp *keys, fs_kp *keys_un, uint8_t *desc,
+                        float *u_right, float *depth, int cap, uint32_t *cell_off, uint32_t *cell_idx, float *scal)
+{
+    cv::Mat im(h, w, CV_8UC1, (void *)gray, (size_t)stride);
+    cv::Mat imD, imM;
+    if (depth_img) imD = cv::Mat(h, w, CV_32F, (void *)depth_img, (size_t)w * sizeof(float));
+    if (mask) imM = cv::Mat(h, w, CV_8UC1, (void *)mask, (size_t)w);
+    cv::Mat K = cv::Mat::eye(3, 3, CV_32F);
+    K.at<float>(0, 0) = fx;
+    K.at<float>(1, 1) = fy;
+    K.at<float>(0, 2) = cx;
+    K.at<float>(1, 2) = cy;
+    cv::Mat dist = cv::Mat::zeros(4, 1, CV_32F);
+    Frame::mbInitialComputations = true;
+    FS_ENTER();
+    int rc;
+    try {
+        Frame *pf = 0;
+        if (kind == 0) pf = new Frame(im, imD, 0.0, FS_EXT(ext), (ORBVocabulary *)0, K, dist, bf, th_depth);
+        else if (kind == 1) pf = new Frame(im, 0.0, FS_EXT(ext), (ORBVocabulary *)0, K, dist, bf, th_depth);
+        else pf = new Frame(im, imD, imM, 0.0, FS_EXT(ext), (ORBVocabulary *)0, K, dist, bf, th_depth);
+        Frame &f = *pf;
+        const int n = f.N;
+        if (n > cap) { delete pf; throw std::length_error("cap"); }
+        if ((int)f.mvKeys.size() != n || (n && ((int)f.mvKeysUn.size() != n || f.mDescriptors.rows != n || (int)f.mvuRight.size() != n ||
+                                                (int)f.mvDepth.size() != n))) { delete pf; throw std::logic_error("sizes"); }
+        if (n) {
+            memcpy(keys, f.mvKeys.data(), sizeof(cv::KeyPoint) * (size_t)n);
+            memcpy(keys_un, f.mvKeysUn.data(), sizeof(cv::KeyPoint) * (size_t)n);
+        }
+        for (int i = 0; i < n; i++) {
+            memcpy(desc + (size_t)i * 32, f.mDescriptors.ptr(i), 32);
+            u_right[i] = f.mvuRight[(size_t)i];
+            depth[i] = f.mvDepth[(size_t)i];
+        }
+        uint32_t k = 0;
+        for (int ix = 0; ix < FRAME_GRID_COLS; ix++)
+            for (int iy = 0; iy < FRAME_GRID_ROWS; iy++) {
+                cell_off[ix * FRAME_GRID_ROWS + iy] = k;
+                for (size_t j = 0; j < f.mGrid[ix][iy].size(); j++) cell_idx[k++] = (uint32_t)f.mGrid[ix][iy][j];
+            }
+        cell_off[FRAME_GRID_COLS * FRAME_GRID_ROWS] = k;
+        scal[0] = Frame::mnMinX; scal[1] = Frame::mnMaxX; scal[2] = Frame::mnMinY; scal[3] = Frame::mnMaxY;
+        scal[4] = Frame::mfGridElementWidthInv; scal[5] = Frame::mfGridElementHeightInv; scal[6] = f.mb; scal[7] = f.fx;
+        rc = n;
+        delete pf;
     } catch (const std::length_error &) {
         rc = -2;
     } catch (const std::exception &) {

@@ -130,6 +130,17 @@ class Frame
      * (:161), i.e. whatever the memory held; here that value is the default member initialiser below. */
     Frame(const cv::Mat &imLeft, const cv::Mat &imRight, const double &timeStamp, ORBextractor *extractorLeft,
           ORBextractor *extractorRight, ORBVocabulary *voc, cv::Mat &K, cv::Mat &distCoef, const float &bf, const float &thDepth);
+    /* the RGB-D constructor (src/Frame.cc:176-245; BASELINE configs 1-3), the monocular one (:247-311), the depth look-up
+     * they call (:850-874) and perfect/'s RGB-D constructor with the dynamic-object mask (perfect/src/Frame.cc:328-420), all
+     * sliced into frame_stereo_api.cpp */
+    Frame(const cv::Mat &imGray, const cv::Mat &imDepth, const double &timeStamp, ORBextractor *extractor, ORBVocabulary *voc,
+          cv::Mat &K, cv::Mat &distCoef, const float &bf, const float &thDepth);
+    Frame(const cv::Mat &imGray, const double &timeStamp, ORBextractor *extractor, ORBVocabulary *voc, cv::Mat &K,
+          cv::Mat &distCoef, const float &bf, const float &thDepth);
+    Frame(const cv::Mat &imGray, const cv::Mat &imDepth, const cv::Mat &imMask, const double &timeStamp, ORBextractor *extractor,
+          ORBVocabulary *voc, cv::Mat &K, cv::Mat &distCoef, const float &bf, const float &thDepth);
+    void ComputeStereoFromRGBD(const cv::Mat &imDepth);
+    cv::Mat mImDepth, mImDynm_mask; /* perfect/include/Frame.h:164-166 */
     void ExtractORB(int flag, const cv::Mat &im);
     void UndistortKeyPoints();
     void ComputeImageBounds(const cv::Mat &imLeft);

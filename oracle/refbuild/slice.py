@@ -28,6 +28,17 @@ SLICES = {
         "void Frame::ExtractORB(int flag, const cv::Mat &im)",
         "void Frame::UndistortKeyPoints()",
         "void Frame::ComputeImageBounds(const cv::Mat &imLeft)",
+        # the RGB-D constructor (BASELINE configs 1-3 are RGB-D: src/Frame.cc:176-245), the monocular one (:247-...) and the
+        # depth look-up they call (:850)
+        ("Frame::Frame(const cv::Mat &imGray, const cv::Mat &imDepth, const double &timeStamp, ORBextractor* extractor,ORBVocabulary* voc, cv::Mat &K, cv::Mat &distCoef, const float &bf, const float &thDepth)",
+         "Frame::Frame(const cv::Mat &imGray, const cv::Mat &imDepth, \n"),   # perfect/src/Frame.cc: three lines, + mImDepth(imDepth)
+        "Frame::Frame(const cv::Mat &imGray, const double &timeStamp, ORBextractor* extractor,ORBVocabulary* voc, cv::Mat &K, cv::Mat &distCoef, const float &bf, const float &thDepth)",
+        "void Frame::ComputeStereoFromRGBD(const cv::Mat &imDepth)",
+    ]),
+    # perfect/ only: the RGB-D constructor with the dynamic-object mask (perfect/src/Frame.cc:328-420): keypoints whose mask
+    # pixel is not 1 are dropped after extraction.  Always cut from the perfect copy, whichever root this run was given.
+    "gen_frame_masked_ctor.inc": (("perfect/src/Frame.cc", "src/Frame.cc"), [
+        "Frame::Frame(const cv::Mat &imGray, const cv::Mat &imDepth,\n",
     ]),
     "gen_mappoint.inc": ("src/MapPoint.cc", [
         "void MapPoint::ComputeDistinctiveDescriptors()",
@@ -76,6 +87,8 @@ def main():
     os.makedirs(out, exist_ok=True)
     for name, entry in SLICES.items():
         src, sigs = entry[0], entry[1]
+        if not isinstance(src, str):   # alternative locations: the first that exists under this root
+            src = [c for c in src if os.path.exists(os.path.join(ref, c))][0]
         text = open(os.path.join(ref, src), encoding="utf-8", errors="replace").read()
         if len(entry) > 2 and entry[2] == "optional" and all(text.count(s if isinstance(s, str) else s[0]) == 0 for s in sigs):
             continue  # this copy of the reference does not have these functions at all

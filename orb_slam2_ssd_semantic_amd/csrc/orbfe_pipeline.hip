@@ -50,6 +50,10 @@ struct orbfe_pipeline {
     hipEvent_t ev_carry[2] = {nullptr, nullptr};
     int carry_cur = 0;          // slot the NEXT call reads
     bool have_carry = false;
+    // where the carried frame was copied FROM (the caller's blocks of the previous call): a sub-batch of the next call that
+    // writes over these addresses waits for the copy, the others do not (no drain at the call boundary)
+    const void *carry_src[3] = {nullptr, nullptr, nullptr};
+    size_t carry_src_bytes[3] = {0, 0, 0};
     bool joined = true;
 };
 
@@ -245,10 +249,10 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
     // blocks of an earlier call)
     ORBFE_HIP(hipEventRecord(pl->ev_fork, cs));
     for (int p = 0; p < P; ++p) ORBFE_HIP(hipStreamWaitEvent(pl->st[(size_t)p], pl->ev_fork, 0));
-    // The output blocks may be the ones of the previous call (a host that re-uses its buffers): the copy of that call's last
-    // frame into the carry slot must have read it before any pipe overwrites it.
-    if (pl->have_carry)
-        for (int p = 0; p < std::min(P, nsub); ++p) ORBFE_HIP(hipStreamWaitEvent(pl->st[(size_t)p], pl->ev_carry[rd], 0));
+    auto overlaps = [](const void *a, size_t na, const void *b, size_t nb) {
+        const char *pa = (const char *)a, *pb = (const char *)b;
+        return a && b && pa < pb + nb && pb < pa + na;
+    };
 
     for (int j = 0; j < nsub; ++j) {
         const int p = j % P;
@@ -258,6 +262,13 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
         // another pipe's stream
         if (j + 1 < (int)pl->ev_match_valid.size() && pl->ev_match_valid[(size_t)j + 1])
             ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_match[(size_t)j + 1], 0));
+        // ... and the copy of the previous call's last frame into the carry slot must have read it before this sub-batch
+        // writes over it (only the sub-batch whose output slices cover those addresses waits: no drain at the call boundary)
+        if (pl->have_carry &&
+            (overlaps(pl->carry_src[0], pl->carry_src_bytes[0], d_kps + (size_t)lo * cap, (size_t)nf * cap * sizeof(orbfe_keypoint)) ||
+             overlaps(pl->carry_src[1], pl->carry_src_bytes[1], d_desc + (size_t)lo * cap * 32, (size_t)nf * cap * 32) ||
+             overlaps(pl->carry_src[2], pl->carry_src_bytes[2], d_n_out + lo, (size_t)nf * sizeof(int32_t))))
+            ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_carry[rd], 0));
         s = orbfe_extract_batch_device(pl->ext[(size_t)p], d_gray + (size_t)lo * frame_stride, nf, w, ht, stride, frame_stride,
                                        d_kps + (size_t)lo * cap, d_desc + (size_t)lo * cap * 32, cap, d_n_out + lo, (void *)st);
         if (s != ORBFE_OK) return s;
@@ -306,6 +317,12 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
         ORBFE_HIP(hipEventRecord(pl->ev_carry[wr], st));
         pl->carry_cur = wr;
         pl->have_carry = true;
+        pl->carry_src[0] = d_kps + last * cap;
+        pl->carry_src_bytes[0] = (size_t)std::min(cap, pl->cap) * sizeof(orbfe_keypoint);
+        pl->carry_src[1] = d_desc + last * cap * 32;
+        pl->carry_src_bytes[1] = (size_t)std::min(cap, pl->cap) * 32;
+        pl->carry_src[2] = d_n_out + last;
+        pl->carry_src_bytes[2] = sizeof(int32_t);
     }
     for (int p = 0; p < P; ++p) ORBFE_HIP(hipEventRecord(pl->ev_end[(size_t)p], pl->st[(size_t)p]));
     pl->joined = false;

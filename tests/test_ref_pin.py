@@ -544,3 +544,78 @@ def test_vectorised_build_of_the_reference_is_bit_identical(ref, oracle):
         assert np.array_equal(k0.view(np.uint8), k1.view(np.uint8)) and np.array_equal(d0, d1), (seed, "vec vs -O2")
         assert np.array_equal(k1.view(np.uint8), ok.view(np.uint8)) and np.array_equal(d1, od), (seed, "vec vs oracle")
     R.configure(bump=True, canonical_trig=True, blur_mode=0)
+
+
+def tum_like_depth_and_mask(seed, h=480, w=640, masked_frac=0.2):
+    """a depth image as Tracking hands it to the Frame constructor (float32 metres, 0 = no reading: src/Tracking.cc:355-356)
+    and a dynamic-object mask of 0 / 1 (perfect/src/Frame.cc:330: 1 = keep)"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    depth = (1.5 + 2.5 * (xx / w) + 1.2 * np.sin(yy / 37.0) ** 2).astype(np.float32)
+    depth += rng.normal(0, 0.01, (h, w)).astype(np.float32)
+    for _ in range(12):                                    # holes: no depth reading
+        y0, x0 = int(rng.integers(0, h - 40)), int(rng.integers(0, w - 60))
+        depth[y0:y0 + int(rng.integers(8, 40)), x0:x0 + int(rng.integers(8, 60))] = 0.0
+    mask = np.ones((h, w), np.uint8)
+    mh = int(h * np.sqrt(masked_frac))
+    mw = int(w * np.sqrt(masked_frac))
+    y0, x0 = int(rng.integers(0, h - mh + 1)), int(rng.integers(0, w - mw + 1))
+    mask[y0:y0 + mh, x0:x0 + mw] = 0
+    return depth, mask
+
+
+def expected_frame(oracle, kind, gray, depth, mask, bf, nf=1000, blur_mode=0):
+    """what the three constructors leave in the Frame, from the oracle's extraction and the reference's arithmetic restated in
+    numpy: mvKeysUn = mvKeys (zero distortion, :561-565); depth look-up at the TRUNCATED keypoint position (at<float>(v, u)
+    converts the float coordinates to int, :862), mvuRight = kpU.pt.x - mbf / d in float (:867); the mask rule of
+    perfect/src/Frame.cc:360-377 (applied only when more than 65 % of the mask is 1)"""
+    oe = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    if blur_mode:
+        oe.set_blur_mode(blur_mode)
+    k, d = oe(gray)
+    if kind == R.FRAME_MASKED and float(mask.astype(np.float64).sum()) > mask.shape[0] * mask.shape[1] * 0.65:
+        keep = mask[k["y"].astype(np.int32), k["x"].astype(np.int32)] == 1
+        k, d = k[keep], d[keep]
+    n = len(k)
+    ur, dep = np.full(n, -1, np.float32), np.full(n, -1, np.float32)
+    if kind != R.FRAME_MONO:
+        dv = depth[k["y"].astype(np.int32), k["x"].astype(np.int32)]
+        ok = dv > 0
+        dep[ok] = dv[ok]
+        ur[ok] = k["x"][ok] - np.float32(bf) / dv[ok]
+    return k, d, ur, dep
+
+
+def check_frame(oracle, got, exp, fx, bf, h=480, w=640):
+    k, d, ur, dep = exp
+    assert got["N"] == len(k) > 0
+    assert np.array_equal(got["keys"].view(np.uint8), k.view(np.uint8)) and np.array_equal(got["keys_un"].view(np.uint8), k.view(np.uint8))
+    assert np.array_equal(got["desc"], d)
+    assert np.array_equal(got["u_right"].view(np.uint32), ur.view(np.uint32)) and np.array_equal(got["depth"].view(np.uint32), dep.view(np.uint32))
+    minx, maxx, miny, maxy, gwi, ghi, mb, fxo = got["scal"]
+    assert (minx, maxx, miny, maxy) == (0.0, float(w), 0.0, float(h)) and fxo == np.float32(fx) and mb == np.float32(bf) / np.float32(fx)
+    off, idx = oracle.assign_grid(np.stack([k["x"], k["y"]], 1).astype(np.float32), minx, miny, gwi, ghi)
+    assert np.array_equal(got["cell_off"], off) and np.array_equal(got["cell_idx"], idx)
+
+
+def test_reference_rgbd_mono_and_masked_frame_constructors_equal_the_oracle_chain(oracle):
+    """The callers of the TUM path (BASELINE configs 1-3 are RGB-D), sliced verbatim and compiled around the compiled reference
+    extractor: Frame(imGray, imDepth, ...) src/Frame.cc:176-245 + ComputeStereoFromRGBD :850-874, the monocular constructor
+    :247-311, and perfect/'s constructor with the dynamic-object mask perfect/src/Frame.cc:328-420 -- against the oracle's
+    extraction plus the constructors' own arithmetic restated in numpy.  TUM3.yaml intrinsics (fx 535.4, bf 40)."""
+    R.configure(bump=True, canonical_trig=True, blur_mode=0)
+    fx, fy, cx, cy, bf = 535.4, 539.2, 320.1, 247.6, 40.0
+    ext = R.RefExtractor(1000, 1.2, 8, 20, 7)
+    for seed in (11, 12, 13):
+        gray = synth_frame(100 + seed, sparse=(seed == 13))
+        depth, mask = tum_like_depth_and_mask(seed, masked_frac=0.2 if seed != 12 else 0.5)   # 0.5: the 65 % rule switches the filter off
+        for kind in (R.FRAME_RGBD, R.FRAME_MONO, R.FRAME_MASKED):
+            got = R.frame_ctor(kind, gray, depth if kind != R.FRAME_MONO else None, mask if kind == R.FRAME_MASKED else None,
+                               fx, fy, cx, cy, bf, 40.0, extractor=ext)
+            exp = expected_frame(oracle, kind, gray, depth, mask, bf)
+            check_frame(oracle, got, exp, fx, bf)
+            if kind == R.FRAME_RGBD:
+                assert (got["depth"] > 0).sum() > 700 and (got["depth"] < 0).sum() > 5      # holes in the depth image exist and count
+            if kind == R.FRAME_MASKED:
+                full = R.frame_ctor(R.FRAME_RGBD, gray, depth, None, fx, fy, cx, cy, bf, 40.0, extractor=ext)["N"]
+                assert (got["N"] < full - 50) if seed != 12 else (got["N"] == full)

@@ -107,3 +107,40 @@ def test_reference_stereo_frame_constructor_runs_unchanged_on_the_shims():
     for e in ext:
         L.shim_st_ext_destroy(e)
     R.configure(bump=True, canonical_trig=True, blur_mode=0)
+
+
+@pytest.mark.gpu
+def test_reference_rgbd_mono_and_masked_frame_constructors_run_unchanged_on_the_shim():
+    """the callers of the TUM path -- Frame(imGray, imDepth, ...) src/Frame.cc:176-245 with
+    ComputeStereoFromRGBD :850-874, the monocular constructor :247-311, perfect/'s constructor with the dynamic-object mask
+    perfect/src/Frame.cc:328-420 -- sliced verbatim and compiled around the PRODUCT's extractor shim (libshim_stereo.so), one
+    extractor object re-used over the frames like Tracking's  ==  the same compiled constructors around the reference's own
+    ORBextractor: mvKeys, mvKeysUn, mvuRight, mvDepth, mDescriptors and mGrid bit patterns, the image bounds.  Synthetic depth
+    (with holes) and mask; S frames, a sparse one and camera-like S_tum frames; both blur roundings."""
+    from orb_slam2_ssd_semantic_amd.synth import synth_frame, synth_tum_like
+    from test_ref_pin import tum_like_depth_and_mask
+    fx, fy, cx, cy, bf = 535.4, 539.2, 320.1, 247.6, 40.0
+    L = R.shimstereo_lib()
+    total = 0
+    for mode in (1, 0):   # 1 = the shim's default (what an x86-64 OpenCV 3.2 binary computes)
+        R.configure(bump=True, canonical_trig=True, blur_mode=mode)
+        ext = L.shim_st_ext_create(1000, 1.2, 8, 20, 7)
+        if mode == 0:
+            L.shim_st_ext_set_blur_rounding(ext, 0)
+        rext = R.RefExtractor(1000, 1.2, 8, 20, 7)
+        frames = [synth_frame(500), synth_tum_like(501), synth_frame(502, sparse=True), synth_tum_like(503)]
+        for i, gray in enumerate(frames):
+            depth, mask = tum_like_depth_and_mask(40 + i, masked_frac=0.5 if i == 3 else 0.25)
+            for kind in (R.FRAME_RGBD, R.FRAME_MONO, R.FRAME_MASKED):
+                args = (kind, gray, depth if kind != R.FRAME_MONO else None, mask if kind == R.FRAME_MASKED else None, fx, fy, cx, cy, bf, 40.0)
+                ref = R.frame_ctor(*args, extractor=rext)
+                got = R.frame_ctor(*args, shim=True, extractor=ext)
+                assert got["N"] == ref["N"] > 0, (mode, i, kind)
+                for k in ("keys", "keys_un", "desc", "cell_off", "cell_idx"):
+                    assert np.array_equal(got[k].view(np.uint8), ref[k].view(np.uint8)), (mode, i, kind, k)
+                for k in ("u_right", "depth", "scal"):
+                    assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (mode, i, kind, k)
+                total += got["N"]
+        L.shim_st_ext_destroy(ext)
+    assert total > 15000
+    R.configure(bump=True, canonical_trig=True, blur_mode=0)
