@@ -1050,3 +1050,78 @@ def map_load(path, bump=True):
     info = dict(log=log.raw[:loglen].decode(), next_mp_id=int(nxt.value), mp_set_rank=rank[:nmp].copy(), mp_nobs=nobs[:nmp].copy(),
                 mp_calls=calls[:nmp].copy())
     return mps, kfs, info
+
+
+# ---- the DBoW2 twin (oracle/refbuild/dbow2_twin: TemplatedVocabulary / FORB / BowVector / FeatureVector in DBoW2's class shape) ----
+_TWIN = os.path.join(_OUT, "libdbow2_twin.so")
+TEXT2BINARY = os.path.join(_OUT, "text2binary")   # the reference's tool/text2binary.cc, compiled UNCHANGED against the twin
+_twin = None
+
+
+def twin_available():
+    return (os.path.exists(_TWIN) and os.path.exists(TEXT2BINARY)) or have_reference()
+
+
+def twin_lib():
+    global _twin
+    if _twin is None:
+        if have_reference():
+            _make("twin")
+        if not os.path.exists(_TWIN):
+            raise RuntimeError("oracle/_ref/libdbow2_twin.so is missing and /root/reference is not available to build it")
+        L = C.CDLL(_TWIN)
+        vp, ci = C.c_void_p, C.c_int
+        L.twin_voc_load.restype = vp
+        L.twin_voc_load.argtypes = [C.c_char_p, ci]
+        L.twin_voc_free.argtypes = [vp]
+        L.twin_voc_save_binary.argtypes = [vp, C.c_char_p]
+        L.twin_voc_info.argtypes = [vp] * 7
+        L.twin_voc_arrays.argtypes = [vp] * 6
+        L.twin_voc_transform.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+        L.twin_voc_score.restype = C.c_double
+        L.twin_voc_score.argtypes = [vp, vp, vp, ci, vp, vp, ci]
+        _twin = L
+    return _twin
+
+
+class TwinVocabulary:
+    """ORB_SLAM2::ORBVocabulary (the reference's typedef, include/ORBVocabulary.h:16-17) instantiated over the DBoW2 twin"""
+
+    def __init__(self, path, binary=False):
+        self.L = twin_lib()
+        self.h = self.L.twin_voc_load(str(path).encode(), int(binary))
+        if not self.h:
+            raise RuntimeError(f"twin vocabulary: cannot load {path}")
+        v = [C.c_int() for _ in range(6)]
+        self.L.twin_voc_info(self.h, *[C.byref(x) for x in v])
+        self.k, self.depth, self.nnodes, self.nwords, self.scoring, self.weighting = (x.value for x in v)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.twin_voc_free(self.h)
+            self.h = None
+
+    def save_binary(self, path):
+        self.L.twin_voc_save_binary(self.h, str(path).encode())
+
+    def arrays(self):
+        nn = self.nnodes
+        parent, leaf, desc = np.zeros(nn, np.uint32), np.zeros(nn, np.uint8), np.zeros((nn, 32), np.uint8)
+        weight, word = np.zeros(nn, np.float64), np.zeros(nn, np.uint32)
+        self.L.twin_voc_arrays(self.h, _p(parent), _p(leaf), _p(desc), _p(weight), _p(word))
+        return dict(parent=parent, is_leaf=leaf, node_desc=desc, weight=weight, word_id=word)
+
+    def transform(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        m = max(n, 1)
+        bid, bval, nb = np.zeros(m, np.uint32), np.zeros(m, np.float64), C.c_int()
+        fvn, fvo, fvi, nf = np.zeros(m, np.uint32), np.zeros(m + 1, np.uint32), np.zeros(m, np.uint32), C.c_int()
+        self.L.twin_voc_transform(self.h, _p(desc), n, levelsup, _p(bid), _p(bval), C.byref(nb), _p(fvn), _p(fvo), _p(fvi), C.byref(nf))
+        return dict(bow_id=bid[:nb.value].copy(), bow_val=bval[:nb.value].copy(), fv_node=fvn[:nf.value].copy(),
+                    fv_off=fvo[:nf.value + 1].copy(), fv_idx=fvi[:int(fvo[nf.value])].copy())
+
+    def score(self, a, b):
+        ia, va = np.ascontiguousarray(a[0], np.uint32), np.ascontiguousarray(a[1], np.float64)
+        ib, vb = np.ascontiguousarray(b[0], np.uint32), np.ascontiguousarray(b[1], np.float64)
+        return float(self.L.twin_voc_score(self.h, _p(ia), _p(va), len(ia), _p(ib), _p(vb), len(ib)))

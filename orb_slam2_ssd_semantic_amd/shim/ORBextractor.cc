@@ -104,10 +104,10 @@ void ORBextractor::SyncImagePyramid()
     if (!mpHandle) return;
     const int E = 19;  // EDGE_THRESHOLD
     // ONE device kernel frames every level with its 19-px BORDER_REFLECT_101 border and ONE copy brings the blocks over
-    // (orbfe_get_pyramid_padded); mvImagePyramid[l] is then the ROI inside the padded (w + 38) x (h + 38) buffer, the
-    // reference's memory shape (:1128, :1136-1142).  Like the reference, which allocates `temp` anew for every level of every
-    // call (:1126), each call gets a FRESH block and the per-level matrices are reference-counted views of it: a cv::Mat copy
-    // of mvImagePyramid[l] a caller kept stays valid and unchanged after the next operator().
+    // (orbfe_get_pyramid_padded) into a staging block; every level then gets its OWN freshly allocated (w + 38) x (h + 38) matrix,
+    // exactly the reference's memory shape -- `Mat temp(wholeSize, ...)` per level per call (:1126), mvImagePyramid[l] its ROI
+    // (:1128, :1136-1142): Mat::adjustROI / locateROI on a level behave as on the reference's, and a cv::Mat copy of
+    // mvImagePyramid[l] a caller kept stays valid and unchanged after the next operator() (reference-counted, never re-used).
     // Every failure is loud (the reference cannot fail here; a stale pyramid under ComputeStereoMatches would be silent).
     auto fail = [&](const char *what) {
         throw std::runtime_error(std::string("ORBextractor (orbfe): ") + what + " failed: " + orbfe_strerror(mLastStatus) + " (" +
@@ -116,7 +116,7 @@ void ORBextractor::SyncImagePyramid()
     size_t off[16] = {0}, total = 0;
     mLastStatus = orbfe_get_pyramid_padded(mpHandle, 0, NULL, 0, off, &total);
     if (mLastStatus != ORBFE_OK) fail("orbfe_get_pyramid_padded (sizes)");
-    mPadBlock = cv::Mat(1, (int)total, CV_8U);
+    mPadBlock.create(1, (int)total, CV_8U);   // staging only: re-used while the frame size stays
     mLastStatus = orbfe_get_pyramid_padded(mpHandle, 0, mPadBlock.ptr<uint8_t>(0), total, NULL, NULL);
     if (mLastStatus != ORBFE_OK) fail("orbfe_get_pyramid_padded");
     mvPadded.resize(nlevels);
@@ -125,11 +125,12 @@ void ORBextractor::SyncImagePyramid()
         mLastStatus = orbfe_get_level_size(mpHandle, l, &w, &h);
         if (mLastStatus != ORBFE_OK) fail("orbfe_get_level_size");
         const int pw = w + 2 * E, ph = h + 2 * E;
+        cv::Mat pad(ph, pw, CV_8U);   // a new allocation: tight rows (pitch w + 38), like the staging block's
+        memcpy(pad.ptr<uint8_t>(0), mPadBlock.ptr<uint8_t>(0) + off[l], (size_t)pw * ph);
+        mvPadded[l] = pad;
 #ifdef ORBFE_WITH_OPENCV
-        mvPadded[l] = mPadBlock.colRange((int)off[l], (int)off[l] + pw * ph).reshape(1, ph);  // shares mPadBlock's refcount
         mvImagePyramid[l] = mvPadded[l](cv::Rect(E, E, w, h));  // ROI inside the padded buffer (:1128)
 #else
-        mvPadded[l] = mPadBlock.view(off[l], ph, pw);
         mvImagePyramid[l] = mvPadded[l].roi(E, E, w, h);
 #endif
     }

@@ -46,8 +46,6 @@ public:
     const uint8_t *ptr(int r = 0) const { return data + (size_t)r * step; }
     Mat row(int r) const { Mat m; m.rows = 1; m.cols = cols; m.step = step; m.data = data + (size_t)r * step; m.own_ = own_; return m; }
     Mat roi(int x, int y, int w, int h) const { Mat m; m.rows = h; m.cols = w; m.step = step; m.data = data + (size_t)y * step + x; m.own_ = own_; return m; }
-    // rows x cols tight-row view at byte `off` of a continuous matrix, sharing its buffer (what colRange(...).reshape(1, rows) is in OpenCV)
-    Mat view(size_t off, int r, int c) const { Mat m; m.rows = r; m.cols = c; m.step = (size_t)c; m.data = data + off; m.own_ = own_; return m; }
     Mat getMat() const { return *this; }
 private:
     std::shared_ptr<std::vector<uint8_t>> own_;

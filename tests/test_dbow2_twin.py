@@ -1,0 +1,108 @@
+"""SURVEY 8(f).3, as far as it goes.  DBoW2 is NOT in /root/reference (perfect/Thirdparty/DBoW2 holds a
+readme only), so nothing of it can be compiled as a pin: parity of the vocabulary path stays "published algorithm".  What
+the tree does hold is ONE DBoW2 client, tool/text2binary.cc (loadFromTextFile -> saveToBinaryFile -> loadFromBinaryFile on
+ORB_SLAM2::ORBVocabulary).  oracle/refbuild/dbow2_twin restates TemplatedVocabulary / FORB / BowVector / FeatureVector a SECOND
+time, in C++ and in DBoW2's class shape (the first restatement is the oracle's C / the product's HIP), and
+
+  * oracle/_ref/text2binary = the reference's tool/text2binary.cc compiled UNCHANGED against the twin: its main() runs on a
+    Vocabulary/ORBvoc.txt and the ORBvoc.bin it writes is byte-identical to orbfe_vocfile_save_binary's;
+  * the product's loaders (orbfe_vocfile_load, both layouts) yield the twin class's tree, node for node;
+  * ORBVocabulary::transform(features, BowVector, FeatureVector, 4) of the twin == the oracle (CPU) == orbfe_bow_transform
+    (GPU): word ids, L1-normalised values (bit patterns), node ids, feature lists, on TF_IDF / L1 trees incl. zero-weight
+    (stopped) words."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import ref_ffi as R
+from orb_slam2_ssd_semantic_amd import VocabularyFile
+from orb_slam2_ssd_semantic_amd.synth import regular_vocabulary
+from test_formats import _write_voc_text
+
+pytestmark = pytest.mark.skipif(not R.twin_available(), reason="oracle/_ref twin not built and /root/reference absent")
+
+
+def _voc_dir(tmp_path, k, L, seed, zero_frac=0.05):
+    voc = regular_vocabulary(k, L, seed=seed, zero_frac=zero_frac)
+    d = os.path.join(tmp_path, f"run_{k}_{L}_{seed}")
+    os.makedirs(os.path.join(d, "Vocabulary"))
+    txt = os.path.join(d, "Vocabulary", "ORBvoc.txt")
+    _write_voc_text(txt, voc, k, L)
+    return voc, d, txt, os.path.join(d, "Vocabulary", "ORBvoc.bin")
+
+
+@pytest.mark.parametrize("k,L,seed", [(4, 3, 1), (10, 3, 2), (3, 5, 3), (7, 2, 4)])
+def test_reference_text2binary_main_runs_on_the_twin_and_writes_our_bytes(tmp_path, k, L, seed):
+    R.twin_lib()
+    voc, d, txt, binp = _voc_dir(tmp_path, k, L, seed)
+    r = subprocess.run([R.TEXT2BINARY], cwd=d, capture_output=True, text=True, timeout=120)   # main() of tool/text2binary.cc, unchanged
+    assert r.returncode == 0, r.stderr
+    assert "BoW load/save benchmark" in r.stdout and "Loading from text" in r.stdout and "Loading from binary" in r.stdout
+    blob = open(binp, "rb").read()
+    ours = os.path.join(d, "ours.bin")
+    vf = VocabularyFile(txt)
+    vf.save_binary(ours)
+    assert blob == open(ours, "rb").read()                      # saveToBinaryFile (twin class) == orbfe_vocfile_save_binary
+    # both loaders of the product against both loaders of the twin class, node for node
+    for path, binary in ((txt, False), (binp, True)):
+        tw = R.TwinVocabulary(path, binary=binary)
+        pv = VocabularyFile(path)
+        assert (tw.k, tw.depth, tw.nnodes, tw.nwords, tw.scoring, tw.weighting) == (pv.k, pv.L, pv.nnodes, pv.nwords, pv.scoring, pv.weighting)
+        ta = tw.arrays()
+        pa, pe = pv.arrays()
+        assert np.array_equal(ta["parent"], pe["parent"]) and np.array_equal(ta["is_leaf"], pe["is_leaf"])
+        assert np.array_equal(ta["node_desc"][1:], pa["node_desc"][1:])
+        assert np.array_equal(ta["weight"][1:].view(np.uint64), pa["weight"][1:].view(np.uint64))
+        leaf = ta["is_leaf"].astype(bool)
+        assert np.array_equal(ta["word_id"][leaf], pa["word_id"][leaf])
+
+
+def _same_transform(a, b, values_exact=True):
+    for key in ("bow_id", "fv_node", "fv_off", "fv_idx"):
+        assert np.array_equal(a[key], b[key]), key
+    if values_exact:
+        assert np.array_equal(np.asarray(a["bow_val"]).view(np.uint64), np.asarray(b["bow_val"]).view(np.uint64))
+    else:
+        assert np.allclose(a["bow_val"], b["bow_val"], rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("k,L,seed,levelsup", [(10, 3, 5, 1), (4, 4, 6, 2), (5, 3, 7, 4), (10, 2, 8, 1), (3, 6, 9, 4)])
+def test_twin_transform_equals_the_oracle(oracle, tmp_path, k, L, seed, levelsup):
+    voc, d, txt, _ = _voc_dir(tmp_path, k, L, seed, zero_frac=0.15)
+    tw = R.TwinVocabulary(txt)
+    arr, _ = VocabularyFile(txt).arrays()
+    rng = np.random.default_rng(seed)
+    for n in (0, 1, 37, 1000):
+        desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        if n >= 37:   # descriptors near the node descriptors: ties and real descents
+            pick = rng.integers(1, len(voc["node_desc"]), n // 2)
+            desc[: n // 2] = voc["node_desc"][pick] ^ (rng.random((n // 2, 32)) < 0.02).astype(np.uint8)
+        _same_transform(tw.transform(desc, levelsup), oracle.bow_transform(arr, desc, levelsup))
+    # ORBVocabulary::score (src/LoopClosing.cc:156) of the twin: symmetric, 1 for identical vectors, in [0, 1]
+    a = tw.transform(rng.integers(0, 256, (500, 32), dtype=np.uint8), levelsup)
+    b = tw.transform(rng.integers(0, 256, (500, 32), dtype=np.uint8), levelsup)
+    va, vb = (a["bow_id"], a["bow_val"]), (b["bow_id"], b["bow_val"])
+    assert abs(tw.score(va, va) - 1.0) < 1e-12 and abs(tw.score(va, vb) - tw.score(vb, va)) < 1e-15 and 0.0 <= tw.score(va, vb) <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,L,seed,levelsup", [(10, 3, 15, 1), (4, 4, 16, 2), (10, 4, 17, 4)])
+def test_product_transform_equals_the_twin_class(tmp_path, k, L, seed, levelsup):
+    """orbfe_vocfile_load -> orbfe_vocabulary_create_from_file -> orbfe_bow_transform (HIP)  ==  the twin's
+    loadFromTextFile -> transform(features, BowVector, FeatureVector, levelsup)"""
+    from orb_slam2_ssd_semantic_amd import ORBmatcher
+    voc, d, txt, binp = _voc_dir(tmp_path, k, L, seed, zero_frac=0.1)
+    assert subprocess.run([R.TEXT2BINARY], cwd=d, capture_output=True, timeout=120).returncode == 0
+    m = ORBmatcher(0.7, True)
+    rng = np.random.default_rng(seed)
+    for path, binary in ((txt, False), (binp, True)):
+        tw = R.TwinVocabulary(path, binary=binary)
+        V = VocabularyFile(path).to_device(m)
+        for n in (1, 64, 1000, 2000):
+            desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            pick = rng.integers(1, len(voc["node_desc"]), n // 2)
+            desc[: n // 2] = voc["node_desc"][pick] ^ (rng.random((n // 2, 32)) < 0.02).astype(np.uint8)
+            got = V.transform(desc, levelsup)
+            _same_transform(tw.transform(desc, levelsup), got)
