@@ -399,7 +399,7 @@ def main():
                     help="frames `value` is timed on: S(seed), S_tum(seed), or the TUM sequence at $TUM_FR3_WALKING_XYZ")
     ap.add_argument("--seeds", type=int, default=1024, help="distinct generator seeds in the resident batch (the rest of the "
                     "batch are roll / flip transforms of them)")
-    ap.add_argument("--fast-mode", type=int, default=0, help="FAST variant of the timed region (0 dense, 1 sparse shortcuts)")
+    ap.add_argument("--fast-mode", type=int, default=0, help="FAST variant of the timed region (0 dense, 1 sparse shortcuts, 2 lane-compacting, 3 auto)")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the latency probe")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (rocprof runs): no PCIe leg, no "
@@ -869,8 +869,8 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
         other = "S_tum" if args.workload == "S" else "S"
         d_other = expand_frames(torch.from_numpy(base_frames(other, min(B, 256), w, h, 10000)).cuda(), B)
         result["value_%s" % other.lower()] = round(rate(lambda: eng.step(d_other, 0, stream)), 2)
-        eng.pl.set_fast_mode(1)
-        result["value_%s_fast_mode1" % other.lower()] = round(rate(lambda: eng.step(d_other, 0, stream)), 2)
+        eng.pl.set_fast_mode(3)   # auto: lane-compacting FAST where few pixel pairs pass the necessary test, else dense
+        result["value_%s_fast_auto" % other.lower()] = round(rate(lambda: eng.step(d_other, 0, stream)), 2)
         eng.pl.set_fast_mode(args.fast_mode)
         result["workloads"] = workload_legs(args, eng, d_gray[:F], d_other[:F], local_rank)
         del d_other
@@ -1014,9 +1014,9 @@ def workload_legs(args, eng, d_S, d_other, local_rank):
     for name in sets:
         g = sets[name]
         row = {}
-        for mode, label in ((0, "dense"), (1, "sparse")):
-            eng.ext.set_fast_mode(mode, collect_stats=(mode == 1))
-            if mode == 1:
+        for mode, label in ((0, "dense"), (1, "sparse"), (2, "compact")):
+            eng.ext.set_fast_mode(mode, collect_stats=(mode >= 1))
+            if mode >= 1:
                 eng.ext.fast_stats(reset=True)
             for _ in range(2):
                 eng.ext.extract_batch_device(g.data_ptr(), F, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), eng.cap,
@@ -1027,6 +1027,11 @@ def workload_legs(args, eng, d_S, d_other, local_rank):
                 row["sparse_arc_skip_frac"] = round(st["arc_skips"] / max(st["row_steps"], 1), 4)
                 row["sparse_nms_skip_frac"] = round(st["nms_skips"] / max(st["row_steps"], 1), 4)
                 eng.ext.set_fast_mode(1, collect_stats=False)
+            if mode == 2:   # {row steps, batches, parked pairs} of the sampled waves
+                st = eng.ext.fast_stats(reset=True)
+                row["compact_pass_rate"] = round(st["parked_pairs"] / max(128.0 * st["row_steps"], 1), 4)
+                row["compact_batch_fill"] = round(st["parked_pairs"] / max(64.0 * st["batches"], 1), 4)
+                eng.ext.set_fast_mode(2, collect_stats=False)
             eng.ext.set_profiling(True)
             t = time.perf_counter()
             reps = 8

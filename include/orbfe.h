@@ -132,9 +132,17 @@ orbfe_status orbfe_extract_batch_device(orbfe_handle *h, const uint8_t *d_gray, 
  * clears the word: bit 0 = a level's FAST survivor list overflowed, bit 1 = a level's quadtree selection overflowed,
  * bit 2 = a frame produced more keypoints than `cap` (d_n_out holds the required count). */
 orbfe_status orbfe_get_overflow(orbfe_handle *h, int32_t *flags);
-/* FAST kernel variant: 0 = dense (default), 1 = wave-uniform shortcuts for frames with sparse corners (skips the arc
- * evaluation of 256-pixel row pieces that fail a 4-point necessary test, and the suppression of rows without
- * strength).  Results are identical in both modes.  collect_stats != 0 counts {row steps, arc skips, NMS skips}. */
+/* FAST kernel variant.  Results are identical in every mode.
+ *   0  dense (default): the 16 nine-arcs of every pixel
+ *   1  dense with wave-uniform shortcuts (skips the arc evaluation of 256-pixel row pieces that fail a 4-point necessary
+ *      test, and the suppression of rows without strength)
+ *   2  lane-compacting: every pixel pair takes the 4-point necessary test; the pairs that pass are gathered, 64 at a time,
+ *      from all over the wave's strip and evaluated one per lane -- cheaper than dense when few pairs pass (measured break-even
+ *      near 14 %: low-texture / low-contrast frames; -18 % at 2 %), dearer when more do (+4 % at the 19 % of the camera-like
+ *      synthetic frames S_tum, +45 % at the 85 % of the corner-saturated frames S)
+ *   3  auto: 2, and 0 for the next 64 calls whenever the compacting kernel reported more than 14 % passing pairs
+ * collect_stats != 0 counts {row steps, arc skips, NMS skips} (mode 1) / {row steps, batches, parked pairs} of a sample of the
+ * waves (mode 2); in mode 3 orbfe_get_fast_stats returns the counters of the last probe that completed. */
 orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32_t collect_stats);
 orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[3], int32_t reset);
 /* work model of the FAST kernel for the current frame size: out[0] = wave row steps per frame (one step = 64 lanes x 4

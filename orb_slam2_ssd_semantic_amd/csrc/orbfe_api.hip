@@ -129,6 +129,10 @@ struct PinBuf {
 // event marks of one profiled call: 0 start, 1 pyramid done, 2 FAST done, 3 quadtree done, 4 describe start, 5 end (launch
 // stream); 6 / 7 around the blur (on whichever stream it ran)
 #define ORBFE_EV_N 8
+// auto FAST mode: above this share of pixel pairs passing the necessary test the dense form is the cheaper one.  Measured per
+// 1024 frames of 640x480 (tools/fast_floor.py, profiles/r05_fast_floor.json): pass rate 0.85 (S) dense 1.48 / compacting 2.15 ms;
+// 0.187 (S_tum) 1.33 / 1.38; 0.111 1.28 / 1.23; 0.083 1.26 / 1.19; 0.053 1.25 / 1.11; 0.021 1.21 / 1.00 -- break-even near 0.14
+#define ORBFE_AUTO_DENSE_RATE 0.14
 
 struct orbfe_handle {
     orbfe_params prm;
@@ -147,8 +151,15 @@ struct orbfe_handle {
     DevBuf d_pyr, d_blur, d_skeys, d_scount, d_knode, d_qtbox, d_qtnodes, d_sel, d_nsel, d_nkeys, d_pad;
     // sticky overflow word + FAST sparse-variant statistics: [0] int32 overflow bits, [2..7] 3 x uint64 counters
     DevBuf d_misc;
-    int fast_mode = 0;            // 0 dense, 1 sparse shortcuts (orbfe_set_fast_mode)
+    int fast_mode = 0;            // 0 dense, 1 sparse shortcuts, 2 lane-compacting, 3 auto: 2 or 0 by the observed pass rate (orbfe_set_fast_mode)
     bool fast_stats = false;
+    // auto mode: the lane-compacting kernel reports {row steps, batches, parked pairs} of a sample of its waves; the counters are
+    // copied to pinned host memory behind the kernel and looked at -- without waiting -- by a later call
+    PinBuf h_auto;                // 3 x uint64
+    hipEvent_t ev_auto = nullptr;
+    bool auto_pending = false;
+    int auto_dense_left = 0;      // calls still to run dense before the pass rate is probed again
+    uint64_t auto_last[3] = {0, 0, 0};
     int64_t fast_row_steps = 0;
     // The most recent batched call: its stream (only compared, never dereferenced: the caller may have destroyed it) and an
     // event recorded behind its last launch.  All calls of a handle share the scratch blocks, so a call on another stream
@@ -852,6 +863,7 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
             return fail(ORBFE_ERR_HIP);
         }
     if (hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_auto, hipEventDisableTiming) != hipSuccess || h->h_auto.ensure(64) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) != hipSuccess) {
         orbfe_set_error("event creation failed");
         return fail(ORBFE_ERR_HIP);
@@ -922,6 +934,8 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
+    if (h->ev_auto) (void)hipEventDestroy(h->ev_auto);
+    h->h_auto.release();
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1050,7 +1064,15 @@ extern "C" orbfe_status orbfe_set_option(orbfe_handle *h, int32_t option, int32_
         if (value && (!in(64, 512) || value % 64)) return ORBFE_ERR_ARG;
         h->kopts.qt[option - ORBFE_OPT_QT_THREADS_0] = value;
         break;
-    case ORBFE_OPT_DEBUG: if (value != 0 && value != 50 && value != 51) return ORBFE_ERR_ARG; h->opt_debug = value; replan = true; break;
+    case ORBFE_OPT_DEBUG:
+#ifdef ORBFE_DEVELOPER
+        if (value != 0 && value != 50 && value != 51 && value != 60) return ORBFE_ERR_ARG;   // 60: timing-only, FAST without arcs
+#else
+        if (value != 0 && value != 50 && value != 51) return ORBFE_ERR_ARG;
+#endif
+        h->opt_debug = value;
+        replan = true;
+        break;
     case ORBFE_OPT_PYR_FUSE: if (!in(0, 1)) return ORBFE_ERR_ARG; if (developer_only()) return ORBFE_ERR_STATE; h->kopts.pyr_fuse = value; break;
     case ORBFE_OPT_FUSE_BLUR_PYR:
         if (!in(0, 2)) return ORBFE_ERR_ARG;
@@ -1077,9 +1099,10 @@ extern "C" orbfe_status orbfe_set_option(orbfe_handle *h, int32_t option, int32_
 
 extern "C" orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32_t collect_stats)
 {
-    if (!h || mode < 0 || mode > 1) return ORBFE_ERR_ARG;
+    if (!h || mode < 0 || mode > 3) return ORBFE_ERR_ARG;
     h->fast_mode = mode;
     h->fast_stats = collect_stats != 0;
+    h->auto_dense_left = 0;
     return ORBFE_OK;
 }
 
@@ -1090,6 +1113,14 @@ extern "C" orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[3], i
     if (!h->d_misc.p) return ORBFE_OK;
     DeviceGuard g(h->device);
     ORBFE_HIP(wait_last_call(h));
+    if (h->fast_mode == 3) {   // auto: the counters belong to the mode selection; report its last completed probe
+        if (h->auto_pending && hipEventQuery(h->ev_auto) == hipSuccess) {
+            memcpy(h->auto_last, h->h_auto.p, sizeof(h->auto_last));
+            h->auto_pending = false;
+        }
+        for (int i = 0; i < 3; ++i) out[i] = h->auto_last[i];
+        return ORBFE_OK;
+    }
     ORBFE_HIP(hipMemcpy(out, (char *)h->d_misc.p + 16, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (reset) ORBFE_HIP(hipMemset((char *)h->d_misc.p + 16, 0, 3 * sizeof(uint64_t)));
     return ORBFE_OK;
@@ -1142,8 +1173,28 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.cap = cap;
     a.d_n_out = d_n_out;
     a.d_ovf = (int32_t *)h->d_misc.p;
-    a.fast_sparse = h->fast_mode;
-    a.d_fstat = h->fast_stats ? (unsigned long long *)((char *)h->d_misc.p + 16) : nullptr;
+    // FAST form of this call.  Auto (3): lane-compacting unless the last probe found more than ORBFE_AUTO_DENSE_RATE of the
+    // pixel pairs passing the necessary test -- then dense for the next 64 calls, after which one compacting call probes again.
+    int fmode = h->fast_mode;
+    bool auto_probe = false;
+    if (fmode == 3) {
+        if (h->auto_pending && hipEventQuery(h->ev_auto) == hipSuccess) {   // never waits
+            memcpy(h->auto_last, h->h_auto.p, sizeof(h->auto_last));
+            h->auto_pending = false;
+            if (h->auto_last[0] > 0 && (double)h->auto_last[2] > ORBFE_AUTO_DENSE_RATE * 128.0 * (double)h->auto_last[0]) h->auto_dense_left = 64;
+        } else {
+            (void)hipGetLastError();   // hipErrorNotReady is not an error of ours
+        }
+        if (h->auto_dense_left > 0) {
+            h->auto_dense_left--;
+            fmode = 0;
+        } else {
+            fmode = 2;
+            auto_probe = !h->auto_pending;
+        }
+    }
+    a.fast_sparse = fmode;
+    a.d_fstat = (h->fast_stats || auto_probe) ? (unsigned long long *)((char *)h->d_misc.p + 16) : nullptr;
     // every call of a handle uses the same scratch blocks (pyramid, blur, survivor lists, selections): a call on another
     // stream than its predecessor's waits, at stream level, for that predecessor to finish
     if (h->last_stream_valid && h->last_stream != st) ORBFE_HIP(hipStreamWaitEvent(st, h->ev_last, 0));
@@ -1222,6 +1273,12 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     } else
 #endif
         ORBFE_HIP(orbk_launch_fast(a, st));
+    if (auto_probe) {   // the sampled counters of this launch -> pinned host memory; a later call looks at them
+        ORBFE_HIP(hipMemcpyAsync(h->h_auto.p, (char *)h->d_misc.p + 16, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        ORBFE_HIP(hipMemsetAsync((char *)h->d_misc.p + 16, 0, 3 * sizeof(uint64_t), st));
+        ORBFE_HIP(hipEventRecord(h->ev_auto, st));
+        h->auto_pending = true;
+    }
     if (ev) ORBFE_HIP(hipEventRecord(ev[2], st));
     if (ov == 2) ORBFE_HIP(fork_blur());
     ORBFE_HIP(orbk_launch_octree(a, st));

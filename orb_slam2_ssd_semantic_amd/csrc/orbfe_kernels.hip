@@ -489,6 +489,58 @@ __device__ __forceinline__ uint32_t fast_compass_pair(const uint32_t (&rm3)[FM_N
     return pk_subsat_u16(pk_max_u16(pk_subsat_u16(mb, v), pk_subsat_u16(v, md)), t);
 }
 
+// The lane-compacting form (orbfe_fast_body_c.inc) splits fast_strength_pair in two: the 16 circle pixel pairs + centre of the
+// pair (J, J+1) as values (gather), and the network on values (strength_from) -- the same operations in the same order.
+template <int J>
+__device__ __forceinline__ void fast_gather_pair(const uint32_t (&rm3)[FM_NE], const uint32_t (&rm2)[FM_NE],
+                                                 const uint32_t (&rm1)[FM_NE], const uint32_t (&r0)[FM_NE],
+                                                 const uint32_t (&rp1)[FM_NE], const uint32_t (&rp2)[FM_NE],
+                                                 const uint32_t (&rp3)[FM_NE], uint32_t (&c)[16], uint32_t &v)
+{
+    c[0] = rp3[3 + J];
+    c[1] = rp3[4 + J];
+    c[2] = rp2[5 + J];
+    c[3] = rp1[6 + J];
+    c[4] = r0[6 + J];
+    c[5] = rm1[6 + J];
+    c[6] = rm2[5 + J];
+    c[7] = rm3[4 + J];
+    c[8] = rm3[3 + J];
+    c[9] = rm3[2 + J];
+    c[10] = rm2[1 + J];
+    c[11] = rm1[0 + J];
+    c[12] = r0[0 + J];
+    c[13] = rp1[0 + J];
+    c[14] = rp2[1 + J];
+    c[15] = rp3[2 + J];
+    v = r0[3 + J];
+}
+__device__ __forceinline__ uint32_t fast_strength_from(const uint32_t (&c)[16], uint32_t v, uint32_t t)
+{
+    uint32_t P[8], Q[8], ex[8], en[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        P[i] = pk_min_u16(c[2 * i + 1], c[(2 * i + 2) & 15]);
+        Q[i] = pk_max_u16(c[2 * i + 1], c[(2 * i + 2) & 15]);
+        ex[i] = pk_max_u16(c[2 * i], c[(2 * i + 9) & 15]);
+        en[i] = pk_min_u16(c[2 * i], c[(2 * i + 9) & 15]);
+    }
+    uint32_t Wb[8], Wd[8];
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const uint32_t ab = pk_min3(P[i], P[(i + 1) & 7], P[(i + 2) & 7]);
+        const uint32_t ad = pk_max3(Q[i], Q[(i + 1) & 7], Q[(i + 2) & 7]);
+        Wb[i] = pk_min3(ab, P[(i + 3) & 7], ex[i]);
+        Wd[i] = pk_max3(ad, Q[(i + 3) & 7], en[i]);
+        Wb[(i + 7) & 7] = pk_min3(P[(i + 7) & 7], ab, ex[(i + 7) & 7]);
+        Wd[(i + 7) & 7] = pk_max3(Q[(i + 7) & 7], ad, en[(i + 7) & 7]);
+    }
+    const uint32_t maxmin = pk_max_u16(pk_max3(pk_max3(pk_max3(Wb[0], Wb[1], Wb[2]), Wb[3], Wb[4]), Wb[5], Wb[6]), Wb[7]);
+    const uint32_t minmax = pk_min_u16(pk_min3(pk_min3(pk_min3(Wd[0], Wd[1], Wd[2]), Wd[3], Wd[4]), Wd[5], Wd[6]), Wd[7]);
+    const uint32_t m = pk_max3(pk_subsat_u16(v, minmax), pk_subsat_u16(maxmin, v), t);
+    return pk_sub_u16(m, t);
+}
+
 __device__ __forceinline__ int lanes_below(unsigned long long m)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -560,6 +612,32 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
     const int t = bx * (blockDim.x >> 6) + wv;
     if (t >= nwaves) return;
 #include "orbfe_fast_body.inc"
+}
+
+// The lane-compacting form of the same pass (orbfe_fast_body_c.inc): per wave a queue of FC_QCAP parked pixel pairs (18 dwords each,
+// odd stride: conflict-free), four strength rows in flight, a smaller survivor staging buffer -- 13 KB per wave, three
+// workgroups per CU as for the dense form (whose 157 registers allow three waves per SIMD).
+#define FC_QCAP 128      // items (power of two); a push of <= 64 always finds room once the fill is <= FC_QCAP - 64
+#define FC_ISTRIDE 19    // dwords per item: c[0..15], v, tag; odd = bank-conflict-free for consecutive items
+#define FC_LAG 3         // rows the suppression runs behind the front: an item never waits longer
+#define FC_BUF 192       // survivor staging (FM_ROW_MAX = 140 per row at most)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_fast_map_c(const OrbPlan *__restrict__ plan, FrameSrc fs,
+                                                    const OrbLane *__restrict__ lanes, int nwaves,
+                                                    uint2 *__restrict__ skeys, int32_t *__restrict__ scount,
+                                                    uint32_t *__restrict__ cflags, int32_t cf_words,
+                                                    unsigned long long *__restrict__ fstat)  // {row steps, batches, parked pairs} of sampled waves, or null
+{
+    __shared__ uint32_t s_q[4][FC_QCAP * FC_ISTRIDE];
+    __shared__ uint32_t s_srow[4][4 * 64 * 2];
+    __shared__ uint2 s_buf[4][FC_BUF];
+    extern __shared__ uint32_t s_cf[];
+    int b = blockIdx.y, bx = blockIdx.x;
+    xcd_frame_remap(bx, b);
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int t = bx * (blockDim.x >> 6) + wv;
+    if (t >= nwaves) return;
+#include "orbfe_fast_body_c.inc"
 }
 
 #ifdef ORBFE_DEVELOPER   // measured slower than the default chain; compiled only into developer builds
@@ -2382,7 +2460,10 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
                                                      sizeof(uint32_t) * (size_t)a.nframes * a.h_plan->nlevels * a.cf_words, st);
     if (e != hipSuccess) return e;
     dim3 grid((a.h_plan->nfwaves + 3) / 4, a.nframes);
-    if (a.fast_sparse)
+    if (a.fast_sparse == 2)
+        hipLaunchKernelGGL(k_fast_map_c, grid, dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
+                           a.d_scount, a.d_cflag, a.cf_words, a.d_fstat);
+    else if (a.fast_sparse)
         hipLaunchKernelGGL(k_fast_map<1>, grid, dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
                            a.d_scount, a.d_cflag, a.cf_words, a.d_fstat);
     else

@@ -116,8 +116,8 @@ extern "C" void orbfe_pipeline_destroy(orbfe_pipeline *pl)
 
 extern "C" orbfe_status orbfe_pipeline_create(const orbfe_params *p, int32_t npipes, orbfe_pipeline **out)
 {
-    if (!p || !out || npipes < 1 || npipes > 16) {
-        orbfe_set_error("bad argument to orbfe_pipeline_create (1..16 pipes)");
+    if (!p || !out || npipes < 1 || npipes > 64) {
+        orbfe_set_error("bad argument to orbfe_pipeline_create (1..64 pipes)");
         return ORBFE_ERR_ARG;
     }
     *out = nullptr;

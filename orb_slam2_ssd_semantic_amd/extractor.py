@@ -139,7 +139,8 @@ class ORBextractor:
     def fast_stats(self, reset=True):
         out = np.zeros(3, np.uint64)
         check(self._L.orbfe_get_fast_stats(self._h, ptr(out), int(reset)), "orbfe_get_fast_stats")
-        return dict(row_steps=int(out[0]), arc_skips=int(out[1]), nms_skips=int(out[2]))
+        # mode 1: {row steps, arc skips, NMS skips}; modes 2 / 3: {row steps, batches, parked pairs} of the sampled waves
+        return dict(row_steps=int(out[0]), arc_skips=int(out[1]), nms_skips=int(out[2]), batches=int(out[1]), parked_pairs=int(out[2]))
 
     def synchronize(self):
         check(self._L.orbfe_synchronize(self._h), "orbfe_synchronize")

@@ -104,5 +104,5 @@ def test_product_transform_equals_the_twin_class(tmp_path, k, L, seed, levelsup)
             desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
             pick = rng.integers(1, len(voc["node_desc"]), n // 2)
             desc[: n // 2] = voc["node_desc"][pick] ^ (rng.random((n // 2, 32)) < 0.02).astype(np.uint8)
-            got = V.transform(desc, levelsup)
-            _same_transform(tw.transform(desc, levelsup), got)
+            (bid, bval), (fvn, fvo, fvi) = V.transform(desc, levelsup)
+            _same_transform(tw.transform(desc, levelsup), dict(bow_id=bid, bow_val=bval, fv_node=fvn, fv_off=fvo, fv_idx=fvi))

@@ -47,7 +47,7 @@ def test_fuzz_extractor(oracle):
         tag = f"case {c}: {w}x{h} nf={nf} nlev={nlev} sf={sf:.2f} th={ini}/{mn} kind={kind} blur_rounding={br}"
         try:
             e = ORBextractor(nf, sf, nlev, ini, mn, max_width=w, max_height=h, blur_rounding=br)
-            e.set_fast_mode(c & 1)
+            e.set_fast_mode(c & 3)   # dense / sparse shortcuts / lane-compacting / auto
             gk, gd = e(img)
         except OrbfeError:
             continue  # sizes the boundary rejects (level too small for one cell, > 4 quadtree roots, per-level cap)
@@ -175,7 +175,7 @@ def test_fuzz_device_api(oracle):
             e = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
         except Exception:
             continue
-        e.set_fast_mode(c & 1)
+        e.set_fast_mode(c & 3)
         res, _ = _device_batch(e, buf, B, w, h, stride, fstride)
         oe = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
         for i in sorted(set([0, B - 1, int(rng.integers(0, B))])):
@@ -188,8 +188,9 @@ def test_fuzz_device_api(oracle):
 @pytest.mark.parametrize("gen,nframes", [("S", 200), ("S_tum", 96)])
 def test_sequence_batched_device_call(oracle, gen, nframes):
     """BASELINE config 2 on the synthetic stand-in for the TUM sequence: N frames through ONE batched device call, every
-    frame's count, keypoint bit patterns, descriptor bytes and order against the oracle -- in both FAST variants, whose
-    padded output buffers must also be identical byte for byte."""
+    frame's count, keypoint bit patterns, descriptor bytes and order against the oracle -- in every FAST variant (dense, sparse
+    shortcuts, lane-compacting, auto), whose padded output buffers must also be identical byte for byte; the compacting kernel's
+    pass-rate statistics separate the two workloads (S: most pixel pairs pass the necessary test, S_tum: under half)."""
     from orb_slam2_ssd_semantic_amd import ORBextractor
     B = _n(nframes)
     w, h = 640, 480
@@ -199,8 +200,10 @@ def test_sequence_batched_device_call(oracle, gen, nframes):
     oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
     expect = [oe(f) for f in frames]
     raws = []
-    for mode in (0, 1):
-        e.set_fast_mode(mode, collect_stats=True)
+    rate = None
+    for it, mode in enumerate((0, 1, 2, 3, 3)):   # dense, sparse shortcuts, lane-compacting, auto (the first call probes, the second follows the probe)
+        if it < 4:
+            e.set_fast_mode(mode, collect_stats=True)
         res, raw = _device_batch(e, frames.reshape(-1), B, w, h, w, w * h)
         for i in range(B):
             assert _same(res[i][0], res[i][1], expect[i][0], expect[i][1]), (gen, mode, i)
@@ -208,8 +211,15 @@ def test_sequence_batched_device_call(oracle, gen, nframes):
         st = e.fast_stats()
         if mode == 1:
             assert st["row_steps"] > 0
-    for a, b in zip(raws[0], raws[1]):
-        assert np.array_equal(a, b)
+        if mode == 2:   # {row steps, batches, parked pairs} of the sampled waves: the share of pixel pairs passing the necessary test
+            assert st["row_steps"] > 0 and st["arc_skips"] > 0
+            rate = st["nms_skips"] / (128.0 * st["row_steps"])
+            assert (rate > 0.6) if gen == "S" else (0.05 < rate < 0.45), rate   # S ~0.85, S_tum ~0.19
+    for r in raws[1:]:
+        for a, b in zip(raws[0], r):
+            assert np.array_equal(a, b)
+    st = e.fast_stats()   # auto mode: the last probe that completed
+    assert st["row_steps"] > 0 and abs(st["nms_skips"] / (128.0 * st["row_steps"]) - rate) < 0.05
     ncand = [sum(len(oe.candidates(l)) for l in range(8))]
     assert (ncand[0] > 20000) if gen == "S" else (1000 < ncand[0] < 12000)
 
