@@ -388,7 +388,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1024, help="frames per sub-batch of the library's pipeline")
     ap.add_argument("--launches", type=int, default=24, help="sub-batches per step: a step is ONE pipeline call over frames x "
                     "launches resident frames per GPU (default 24 576: twenty steps are > 1.5 s of GPU work)")
-    ap.add_argument("--pipes", type=int, default=int(os.environ.get("ORBFE_BENCH_PIPES", "3")), help="pipes of the pipeline")
+    ap.add_argument("--pipes", type=int, default=int(os.environ.get("ORBFE_BENCH_PIPES", "12")), help="pipes of the pipeline (measured: 1: 277 k, 3: 296 k, 6: 306 k, 12: 316 k, 16-32: 311-313 k frames/s)")
     ap.add_argument("--step-join", action="store_true", help="join the launch stream after every step even on one GPU")
     ap.add_argument("--blur-rounding", type=int, default=0, help="GaussianBlur column rounding: 0 canonical half-up, 1 = the x86 "
                     "SSE2 kernel's (what an x86-64 OpenCV <= 3.3 binary computes); value_blur_mode1 reports the other one")
@@ -935,21 +935,21 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
         result["cpu_baseline_all_cores_frames_per_s"] = result["cpu_baseline_all_cores"]["value"]
 
 
-def pcie_leg(eng, d_src, w, h, F, nbatches=48):
-    """Host frames in, host results out: pinned buffers, H2D / kernels / D2H on three streams, two buffer sets.  Every batch of F
-    frames is one call of the library's pipeline on the compute stream (ORBFE_PIPE_CONTINUE: the batches form one sequence)."""
+def pcie_leg(eng, d_src, w, h, F, nbatches=24):
+    """Host frames in, host results out -- BASELINE config 3 as SURVEY 8(d) words it -- through the PRODUCT's host entry point
+    orbfe_pipeline_extract_match: page-locked frames -> H2D -> pipes -> D2H of counts, padded keypoints / descriptors / matches, the
+    three overlapped inside liborbfe.so (three device buffer sets, two copy streams, chunks of one sub-batch taking turns on the
+    pipes).  One blocking call over nbatches x F frames; nothing of the pipeline lives in this file."""
+    import ctypes as C
     pin_in = d_src.cpu().pin_memory()
     cap = eng.cap
-    d_in = [torch.empty_like(d_src) for _ in range(2)]
-    kps, desc, n = eng.outs[0]
-    d_out = [(kps[i * F:(i + 1) * F], desc[i * F:(i + 1) * F], n[i * F:(i + 1) * F], eng.d_match[i * F:(i + 1) * F],
-              eng.d_nm[i * F:(i + 1) * F]) for i in range(2)]
-    h_out = [tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in d_out[i]) for i in range(2)]
-    s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
-    s_cmp = torch.cuda.current_stream()
-    ev_in = [torch.cuda.Event() for _ in range(2)]
-    ev_cmp = [torch.cuda.Event() for _ in range(2)]
-    ev_out = [torch.cuda.Event() for _ in range(2)]
+    N = nbatches * F
+    hk = torch.empty((N, cap, 7), dtype=torch.int32, pin_memory=True)
+    hd = torch.empty((N, cap, 32), dtype=torch.uint8, pin_memory=True)
+    hn = torch.empty(N, dtype=torch.int32, pin_memory=True)
+    hm = torch.empty((N, cap), dtype=torch.int32, pin_memory=True)
+    hnm = torch.empty(N, dtype=torch.int32, pin_memory=True)
+    ptrs = (C.c_void_p * N)(*[pin_in[i % F].data_ptr() for i in range(N)])
     eng.pl.synchronize()
     eng.pl.reset_sequence()
 
@@ -963,44 +963,33 @@ def pcie_leg(eng, d_src, w, h, F, nbatches=48):
         torch.cuda.synchronize()
         return nbytes * reps / (time.perf_counter() - t) / 1e9
 
-    h2d = link_rate(lambda: d_in[0].copy_(pin_in, non_blocking=True), pin_in.numel())
-    out_bytes = sum(t.numel() * t.element_size() for t in d_out[0])
-    d2h = link_rate(lambda: [hh.copy_(dd, non_blocking=True) for hh, dd in zip(h_out[0], d_out[0])], out_bytes)
+    d_tmp = torch.empty_like(d_src)
+    h2d = link_rate(lambda: d_tmp.copy_(pin_in, non_blocking=True), pin_in.numel())
+    kps, desc, n = eng.outs[0]
+    d_out = (kps[:F], desc[:F], n[:F], eng.d_match[:F], eng.d_nm[:F])
+    h_out = (hk[:F], hd[:F], hn[:F], hm[:F], hnm[:F])
+    out_bytes = sum(t.numel() * t.element_size() for t in d_out)
+    d2h = link_rate(lambda: [hh.copy_(dd, non_blocking=True) for hh, dd in zip(h_out, d_out)], out_bytes)
 
-    def run(nb):
-        for i in range(nb):
-            k = i & 1
-            with torch.cuda.stream(s_in):
-                if i >= 2:
-                    s_in.wait_event(ev_cmp[k])      # the kernels of batch i-2 have consumed input buffer k
-                d_in[k].copy_(pin_in, non_blocking=True)
-                ev_in[k].record(s_in)
-            s_cmp.wait_event(ev_in[k])
-            if i >= 2:
-                s_cmp.wait_event(ev_out[k])         # the results of batch i-2 have left output set k
-            kk, dd, nn, mm, nm = d_out[k]
-            eng.pl.extract_match_device(d_in[k].data_ptr(), F, w, h, w, w * h, kk.data_ptr(), dd.data_ptr(), cap, nn.data_ptr(),
-                                        mm.data_ptr() if eng.match else None, nm.data_ptr() if eng.match else None,
-                                        flags=eng.pl.CONTINUE, stream=s_cmp.cuda_stream)
-            ev_cmp[k].record(s_cmp)
-            with torch.cuda.stream(s_out):
-                s_out.wait_event(ev_cmp[k])
-                for hh, dv in zip(h_out[k], d_out[k]):
-                    hh.copy_(dv, non_blocking=True)
-                ev_out[k].record(s_out)
-        torch.cuda.synchronize()
+    def run(nfr):
+        eng.pl.extract_match(ptrs, nfr, w, h, w, hk.data_ptr(), hd.data_ptr(), cap, hn.data_ptr(),
+                             hm.data_ptr() if eng.match else None, hnm.data_ptr() if eng.match else None)
 
-    run(4)
+    run(4 * F)
     t = time.perf_counter()
-    run(nbatches)
+    run(N)
     dt = time.perf_counter() - t
-    fps = nbatches * F / dt
+    fps = N / dt
     link_fps = h2d * 1e9 / (w * h)
-    return {"frames_per_s": round(fps, 2), "h2d_GBps_measured": round(h2d, 2), "d2h_GBps_measured": round(d2h, 2),
-            "bytes_in_per_frame": w * h, "bytes_out_per_frame": int(out_bytes // F),
-            "link_bound_frames_per_s": round(link_fps, 1), "frac_of_link_bound": round(fps / link_fps, 4),
-            "sample": f"{nbatches} batches of {F} frames: pinned host frames -> H2D -> extract + match (one pipeline call per batch) -> "
-                      f"D2H of counts, padded keypoints / descriptors / matches; H2D, kernels and D2H on three streams, two buffer sets"}
+    res = {"frames_per_s": round(fps, 2), "h2d_GBps_measured": round(h2d, 2), "d2h_GBps_measured": round(d2h, 2),
+           "bytes_in_per_frame": w * h, "bytes_out_per_frame": int(out_bytes // F),
+           "link_bound_frames_per_s": round(link_fps, 1), "frac_of_link_bound": round(fps / link_fps, 4),
+           "sample": f"ONE orbfe_pipeline_extract_match call over {nbatches} x {F} page-locked host frames: H2D -> extract + match -> D2H of "
+                     f"counts, padded keypoints / descriptors / matches, overlapped inside the library"}
+    # the host results of the call against the device-resident pipeline's on the same frames (frames F .. 2F - 1 repeat 0 .. F - 1)
+    torch.cuda.synchronize()
+    res["host_equals_resident_counts"] = bool(torch.equal(hn[:F], hn[F:2 * F]))
+    return res
 
 
 def workload_legs(args, eng, d_S, d_other, local_rank):

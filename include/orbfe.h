@@ -593,6 +593,17 @@ orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, const uint8
                                                  int32_t stride, size_t frame_stride, orbfe_keypoint *d_kps, uint8_t *d_desc,
                                                  int32_t cap, int32_t *d_n_out, int32_t *d_match, int32_t *d_nmatches,
                                                  float nnratio, int32_t th, int32_t check_ori, int32_t flags, void *stream);
+/* The same with HOST buffers -- the frame loop as the reference's drivers run it (images from the host, results to the host;
+ * BASELINE config 3 as SURVEY 8(d) words it): grays[i] = frame i (w x ht, row pitch stride), results into kps [nframes][cap],
+ * desc [nframes][cap][32], n_out [nframes] and, with match != NULL, match [nframes][cap] / nmatches [nframes]; cap >=
+ * orbfe_pipeline_capacity().  Chunks of one sub-batch: the H2D copy of chunk c + 1, the pipes of chunk c and the D2H copies of
+ * chunk c - 1 overlap (three device buffer sets, two copy streams); consecutive chunks take turns on the pipes.  Page-locked
+ * frames / result arrays (hipHostMalloc, hipHostRegister, torch pin_memory) are copied asynchronously as they are; pageable
+ * memory works, more slowly.  Blocking: returns when the results are on the host.  ORBFE_PIPE_CONTINUE as above. */
+orbfe_status orbfe_pipeline_extract_match(orbfe_pipeline *pl, const uint8_t *const *grays, int32_t nframes, int32_t w, int32_t ht,
+                                          int32_t stride, orbfe_keypoint *kps, uint8_t *desc, int32_t cap, int32_t *n_out,
+                                          int32_t *match, int32_t *nmatches, float nnratio, int32_t th, int32_t check_ori,
+                                          int32_t flags);
 /* `stream` waits (at stream level) for everything the pipes hold */
 orbfe_status orbfe_pipeline_join(orbfe_pipeline *pl, void *stream);
 /* the host waits for the pipes */

@@ -55,6 +55,17 @@ struct orbfe_pipeline {
     const void *carry_src[3] = {nullptr, nullptr, nullptr};
     size_t carry_src_bytes[3] = {0, 0, 0};
     bool joined = true;
+    int rot = 0;                // pipe of sub-batch 0 of the next call: consecutive short calls take turns on the pipes
+    // host entry point (orbfe_pipeline_extract_match): device input / output sets, copy streams
+    static const int NSETS = 3;
+    uint8_t *d_in[NSETS] = {nullptr, nullptr, nullptr};
+    orbfe_keypoint *d_okps[NSETS] = {nullptr, nullptr, nullptr};
+    uint8_t *d_odesc[NSETS] = {nullptr, nullptr, nullptr};
+    int32_t *d_on[NSETS] = {nullptr, nullptr, nullptr}, *d_om[NSETS] = {nullptr, nullptr, nullptr}, *d_onm[NSETS] = {nullptr, nullptr, nullptr};
+    size_t in_bytes = 0;
+    int out_frames = 0;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_out[NSETS] = {nullptr, nullptr, nullptr};
 };
 
 static orbfe_status ensure_events(orbfe_pipeline *pl, int nsub)
@@ -109,6 +120,16 @@ extern "C" void orbfe_pipeline_destroy(orbfe_pipeline *pl)
         if (pl->d_cn[k]) (void)hipFree(pl->d_cn[k]);
     }
     if (pl->d_seq) (void)hipFree(pl->d_seq);
+    if (pl->s_in) (void)hipStreamSynchronize(pl->s_in);
+    if (pl->s_out) (void)hipStreamSynchronize(pl->s_out);
+    for (int k = 0; k < orbfe_pipeline::NSETS; ++k) {
+        void *bufs[] = {pl->d_in[k], pl->d_okps[k], pl->d_odesc[k], pl->d_on[k], pl->d_om[k], pl->d_onm[k]};
+        for (void *b : bufs)
+            if (b) (void)hipFree(b);
+        if (pl->ev_out[k]) (void)hipEventDestroy(pl->ev_out[k]);
+    }
+    if (pl->s_in) (void)hipStreamDestroy(pl->s_in);
+    if (pl->s_out) (void)hipStreamDestroy(pl->s_out);
     for (hipStream_t s : pl->st)
         if (s) (void)hipStreamDestroy(s);
     delete pl;
@@ -255,7 +276,7 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
     };
 
     for (int j = 0; j < nsub; ++j) {
-        const int p = j % P;
+        const int p = (pl->rot + j) % P;
         hipStream_t st = pl->st[(size_t)p];
         const int lo = j * F, nf = std::min(F, nframes - lo);
         // same reason, per sub-batch: the matcher of sub-batch j + 1 of the PREVIOUS call read the last frame of slice j on
@@ -307,9 +328,9 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
     // sub-batch (ev_ext[0], recorded on pipe 0 after it).
     {
         const int jl = nsub - 1;
-        hipStream_t st = pl->st[(size_t)(jl % P)];
+        hipStream_t st = pl->st[(size_t)((pl->rot + jl) % P)];
         const size_t last = (size_t)nframes - 1;
-        if (jl % P != 0) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_ext[0], 0));
+        if (jl != 0) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_ext[0], 0));
         ORBFE_HIP(hipMemcpyAsync(pl->d_ckps[wr], d_kps + last * cap, (size_t)std::min(cap, pl->cap) * sizeof(orbfe_keypoint),
                                  hipMemcpyDeviceToDevice, st));
         ORBFE_HIP(hipMemcpyAsync(pl->d_cdesc[wr], d_desc + last * cap * 32, (size_t)std::min(cap, pl->cap) * 32, hipMemcpyDeviceToDevice, st));
@@ -326,6 +347,102 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
     }
     for (int p = 0; p < P; ++p) ORBFE_HIP(hipEventRecord(pl->ev_end[(size_t)p], pl->st[(size_t)p]));
     pl->joined = false;
+    pl->rot = (pl->rot + nsub) % P;
     if (!(flags & ORBFE_PIPE_NO_JOIN)) return orbfe_pipeline_join(pl, stream);
+    return ORBFE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host frames in, host results out: chunks of one sub-batch, H2D / pipes / D2H overlapped over three device buffer sets
+// ---------------------------------------------------------------------------------------------------
+static orbfe_status ensure_host_sets(orbfe_pipeline *pl, int w, int ht)
+{
+    const size_t need = (size_t)pl->F * w * ht;
+    if (need <= pl->in_bytes && pl->out_frames == pl->F) return ORBFE_OK;
+    if (!pl->s_in) ORBFE_HIP(hipStreamCreateWithFlags(&pl->s_in, hipStreamNonBlocking));
+    if (!pl->s_out) ORBFE_HIP(hipStreamCreateWithFlags(&pl->s_out, hipStreamNonBlocking));
+    ORBFE_HIP(hipStreamSynchronize(pl->s_in));
+    ORBFE_HIP(hipStreamSynchronize(pl->s_out));
+    for (hipStream_t st : pl->st) ORBFE_HIP(hipStreamSynchronize(st));
+    const size_t F = (size_t)pl->F, cap = (size_t)pl->cap;
+    for (int k = 0; k < orbfe_pipeline::NSETS; ++k) {
+        if (pl->d_in[k]) ORBFE_HIP(hipFree(pl->d_in[k]));
+        pl->d_in[k] = nullptr;
+        ORBFE_HIP(hipMalloc((void **)&pl->d_in[k], need + 64));
+        if (!pl->ev_out[k]) ORBFE_HIP(hipEventCreateWithFlags(&pl->ev_out[k], hipEventDisableTiming));
+        if (!pl->d_okps[k]) {
+            ORBFE_HIP(hipMalloc((void **)&pl->d_okps[k], F * cap * sizeof(orbfe_keypoint)));
+            ORBFE_HIP(hipMalloc((void **)&pl->d_odesc[k], F * cap * 32));
+            ORBFE_HIP(hipMalloc((void **)&pl->d_on[k], F * sizeof(int32_t)));
+            ORBFE_HIP(hipMalloc((void **)&pl->d_om[k], F * cap * sizeof(int32_t)));
+            ORBFE_HIP(hipMalloc((void **)&pl->d_onm[k], F * sizeof(int32_t)));
+        }
+    }
+    pl->in_bytes = need;
+    pl->out_frames = pl->F;
+    return ORBFE_OK;
+}
+
+extern "C" orbfe_status orbfe_pipeline_extract_match(orbfe_pipeline *pl, const uint8_t *const *grays, int32_t nframes, int32_t w, int32_t ht,
+                                                     int32_t stride, orbfe_keypoint *kps, uint8_t *desc, int32_t cap, int32_t *n_out,
+                                                     int32_t *match, int32_t *nmatches, float nnratio, int32_t th, int32_t check_ori,
+                                                     int32_t flags)
+{
+    if (!pl || !grays || !kps || !desc || !n_out || nframes < 1 || w < 1 || ht < 1 || stride < w || (match && !nmatches)) {
+        orbfe_set_error("bad argument to orbfe_pipeline_extract_match");
+        return ORBFE_ERR_ARG;
+    }
+    if (cap < pl->cap) {
+        orbfe_set_error("orbfe_pipeline_extract_match: cap %d below orbfe_pipeline_capacity() = %d", cap, pl->cap);
+        return ORBFE_ERR_CAP;
+    }
+    PipeGuard g(pl->device);
+    orbfe_status s = ensure_host_sets(pl, w, ht);
+    if (s != ORBFE_OK) return s;
+    const int F = pl->F, pc = pl->cap;
+    const size_t fbytes = (size_t)w * ht;
+    const int nchunks = (nframes + F - 1) / F;
+    for (int c = 0; c < nchunks; ++c) {
+        const int k = c % orbfe_pipeline::NSETS, lo = c * F, nf = std::min(F, nframes - lo);
+        // set k is free once the results of chunk c - NSETS have left it
+        if (c >= orbfe_pipeline::NSETS) ORBFE_HIP(hipStreamWaitEvent(pl->s_in, pl->ev_out[k], 0));
+        bool contiguous = stride == w;
+        for (int f = 1; f < nf && contiguous; ++f) contiguous = grays[lo + f] == grays[lo + f - 1] + fbytes;
+        if (contiguous) {
+            ORBFE_HIP(hipMemcpyAsync(pl->d_in[k], grays[lo], fbytes * nf, hipMemcpyHostToDevice, pl->s_in));
+        } else {
+            for (int f = 0; f < nf; ++f)
+                ORBFE_HIP(hipMemcpy2DAsync(pl->d_in[k] + fbytes * f, (size_t)w, grays[lo + f], (size_t)stride, (size_t)w, (size_t)ht,
+                                           hipMemcpyHostToDevice, pl->s_in));
+        }
+        // the pipes start behind the copy (the call forks from s_in) and are not joined: the next chunk's copy and pipes follow at once
+        const int fl = ((c > 0 || (flags & ORBFE_PIPE_CONTINUE)) ? ORBFE_PIPE_CONTINUE : 0) | ORBFE_PIPE_NO_JOIN;
+        s = orbfe_pipeline_extract_match_device(pl, pl->d_in[k], nf, w, ht, w, fbytes, pl->d_okps[k], pl->d_odesc[k], pc, pl->d_on[k],
+                                                match ? pl->d_om[k] : nullptr, match ? pl->d_onm[k] : nullptr, nnratio, th, check_ori, fl,
+                                                (void *)pl->s_in);
+        if (s != ORBFE_OK) return s;
+        s = orbfe_pipeline_join(pl, (void *)pl->s_out);   // everything submitted so far, i.e. this chunk and older ones
+        if (s != ORBFE_OK) return s;
+        // padded blocks straight into the caller's arrays (row pitch cap >= pc)
+        ORBFE_HIP(hipMemcpyAsync(n_out + lo, pl->d_on[k], (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, pl->s_out));
+        ORBFE_HIP(hipMemcpy2DAsync(kps + (size_t)lo * cap, (size_t)cap * sizeof(orbfe_keypoint), pl->d_okps[k], (size_t)pc * sizeof(orbfe_keypoint),
+                                   (size_t)pc * sizeof(orbfe_keypoint), (size_t)nf, hipMemcpyDeviceToHost, pl->s_out));
+        ORBFE_HIP(hipMemcpy2DAsync(desc + (size_t)lo * cap * 32, (size_t)cap * 32, pl->d_odesc[k], (size_t)pc * 32, (size_t)pc * 32, (size_t)nf,
+                                   hipMemcpyDeviceToHost, pl->s_out));
+        if (match) {
+            ORBFE_HIP(hipMemcpy2DAsync(match + (size_t)lo * cap, (size_t)cap * sizeof(int32_t), pl->d_om[k], (size_t)pc * sizeof(int32_t),
+                                       (size_t)pc * sizeof(int32_t), (size_t)nf, hipMemcpyDeviceToHost, pl->s_out));
+            ORBFE_HIP(hipMemcpyAsync(nmatches + lo, pl->d_onm[k], (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, pl->s_out));
+        }
+        ORBFE_HIP(hipEventRecord(pl->ev_out[k], pl->s_out));
+    }
+    ORBFE_HIP(hipStreamSynchronize(pl->s_out));
+    int32_t ovf = 0;
+    s = orbfe_pipeline_get_overflow(pl, &ovf);
+    if (s != ORBFE_OK) return s;
+    if (ovf) {
+        orbfe_set_error("device-side capacity overflow %d in orbfe_pipeline_extract_match", ovf);
+        return ORBFE_ERR_CAP;
+    }
     return ORBFE_OK;
 }

@@ -53,6 +53,13 @@ class FramePipeline:
                                                           d_match, d_nmatches, self.nnratio, self.th, int(self.check_ori), flags,
                                                           stream), "orbfe_pipeline_extract_match_device")
 
+    def extract_match(self, frame_ptrs, nframes, w, h, stride, kps_ptr, desc_ptr, cap, n_ptr, match_ptr=None, nmatches_ptr=None, flags=0):
+        """host frames in, host results out (orbfe_pipeline_extract_match): frame_ptrs = ctypes array of nframes host pointers;
+        the other arguments are host addresses (ints).  Blocking."""
+        check(self._L.orbfe_pipeline_extract_match(self._p, frame_ptrs, nframes, w, h, stride, kps_ptr, desc_ptr, cap, n_ptr, match_ptr,
+                                                   nmatches_ptr, self.nnratio, self.th, int(self.check_ori), flags),
+              "orbfe_pipeline_extract_match")
+
     def join(self, stream=None):
         check(self._L.orbfe_pipeline_join(self._p, stream), "orbfe_pipeline_join")
 

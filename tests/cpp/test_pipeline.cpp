@@ -1,7 +1,9 @@
 // test_pipeline.cpp -- a C++ host driving the sequence pipeline of the C-ABI (include/orbfe.h orbfe_pipeline_*), the shape
 // of the reference's frame loop (perfect/Examples/RGB-D/rgbd_tum.cc:77-119: every frame through the extractor, then a match
 // against the previous frame).  No Python, no torch: HIP runtime + liborbfe.so only.
-//   usage: test_pipeline in.raw W H nframes nfeatures sub_batch npipes calls out.bin [no_join]
+//   usage: test_pipeline in.raw W H nframes nfeatures sub_batch npipes calls out.bin [no_join [host]]
+// host != 0: the calls go through orbfe_pipeline_extract_match -- plain host buffers in and out (malloc'ed, pageable), the
+// copies overlapped inside the library -- instead of the device entry point.
 // The sequence of `nframes` frames is pushed through in `calls` consecutive calls (ORBFE_PIPE_CONTINUE from the second on),
 // every call re-using the SAME device output blocks (the pipeline protects them); results are copied to the host after each
 // call.  out.bin: per frame  int32 n | n x 28 B keypoints | n x 32 B descriptors | int32 nmatches | n x int32 match row.
@@ -40,6 +42,7 @@ int main(int argc, char **argv)
     const int W = atoi(argv[2]), H = atoi(argv[3]), N = atoi(argv[4]), nf = atoi(argv[5]), F = atoi(argv[6]), P = atoi(argv[7]);
     const int calls = atoi(argv[8]);
     const bool no_join = argc > 10 && atoi(argv[10]) != 0;
+    const bool host_mode = argc > 11 && atoi(argv[11]) != 0;
     if (N < 1 || calls < 1 || calls > N) return 2;
     std::vector<uint8_t> frames((size_t)W * H * N);
     FILE *fi = fopen(argv[1], "rb");
@@ -76,6 +79,12 @@ int main(int argc, char **argv)
     for (int c = 0, lo = 0; lo < N; ++c, lo += per_call) {
         const int nfr = per_call < N - lo ? per_call : N - lo;
         const int flags = (c > 0 ? ORBFE_PIPE_CONTINUE : 0) | (no_join ? ORBFE_PIPE_NO_JOIN : 0);
+        if (host_mode) {
+            std::vector<const uint8_t *> ptrs((size_t)nfr);
+            for (int f = 0; f < nfr; ++f) ptrs[(size_t)f] = frames.data() + (size_t)(lo + f) * W * H;
+            CHECK_ORB(orbfe_pipeline_extract_match(pl, ptrs.data(), nfr, W, H, W, kps.data(), desc.data(), cap, n.data(), match.data(),
+                                                   nm.data(), 0.9f, ORBFE_TH_HIGH, 1, c > 0 ? ORBFE_PIPE_CONTINUE : 0));
+        } else {
         CHECK_ORB(orbfe_pipeline_extract_match_device(pl, d_gray + (size_t)lo * W * H, nfr, W, H, W, (size_t)W * H, d_kps, d_desc, cap, d_n,
                                                       d_match, d_nm, 0.9f, ORBFE_TH_HIGH, 1, flags, (void *)st));
         if (no_join) CHECK_ORB(orbfe_pipeline_join(pl, (void *)st));   // the copies below run on `st`
@@ -85,6 +94,7 @@ int main(int argc, char **argv)
         CHECK_HIP(hipMemcpyAsync(desc.data(), d_desc, (size_t)nfr * cap * 32, hipMemcpyDeviceToHost, st));
         CHECK_HIP(hipMemcpyAsync(match.data(), d_match, (size_t)nfr * cap * 4, hipMemcpyDeviceToHost, st));
         CHECK_HIP(hipStreamSynchronize(st));
+        }
         for (int f = 0; f < nfr; ++f) {
             const int k = n[(size_t)f];
             if (k < 0 || k > cap) { fprintf(stderr, "frame %d: count %d outside [0, %d]\n", lo + f, k, cap); return 5; }

@@ -237,3 +237,63 @@ def test_cpp_host_drives_a_3000_frame_sequence(oracle, tmp_path):
             rm, _, _, rn = oracle.match_bf(od, pd, ok["angle"], pk["angle"], 0.9, 100, True)
             assert nm == rn and np.array_equal(gm, rm), ("matches", k)
     assert pos == len(blob)
+
+
+def _read_host_dump(blob, nframes, KP):
+    pos, out = 0, []
+    for _ in range(nframes):
+        n = struct.unpack_from("<i", blob, pos)[0]
+        pos += 4
+        gk = np.frombuffer(blob, KP, n, pos)
+        pos += 28 * n
+        gd = np.frombuffer(blob, np.uint8, 32 * n, pos).reshape(n, 32)
+        pos += 32 * n
+        nm = struct.unpack_from("<i", blob, pos)[0]
+        pos += 4
+        gm = np.frombuffer(blob, np.int32, n, pos)
+        pos += 4 * n
+        out.append((gk, gd, nm, gm))
+    assert pos == len(blob)
+    return out
+
+
+@pytest.mark.gpu
+def test_host_entry_point_from_cpp_and_python(oracle, tmp_path):
+    """orbfe_pipeline_extract_match: host frames in, host results out (BASELINE config 3 as SURVEY 8(d) words it), copies and
+    pipes overlapped inside the library.  (a) a C++ host with plain malloc'ed (pageable) buffers, 2 calls x 150 frames, 4 pipes x
+    32-frame chunks; (b) the ctypes mirror with strided page-locked frames and a `cap` larger than the pipeline's.  Every frame and
+    every match row against the oracle."""
+    import ctypes as C
+    import torch
+    from orb_slam2_ssd_semantic_amd import KP_DTYPE, FramePipeline
+    exe = build_host()
+    w, h, nf, N = 640, 480, 1000, 300
+    frames = np.stack([synth_frame(9700 + i, h, w, sparse=(i % 7 == 2)) for i in range(N)])
+    ref = oracle_sequence(frames, nf)
+    raw, out = tmp_path / "h.raw", tmp_path / "h.out"
+    frames.tofile(raw)
+    r = subprocess.run([exe, str(raw), str(w), str(h), str(N), str(nf), "32", "4", "2", str(out), "0", "1"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k, ((gk, gd, nm, gm), (ok, od)) in enumerate(zip(_read_host_dump(open(out, "rb").read(), N, oracle.KP_DTYPE), ref)):
+        assert len(gk) == len(ok) and np.array_equal(gk.view(np.uint8), ok.view(np.uint8)) and np.array_equal(gd, od), ("frame", k)
+        if k == 0:
+            assert nm == 0 and np.all(gm == -1)
+        else:
+            rm, _, _, rn = oracle.match_bf(od, ref[k - 1][1], ok["angle"], ref[k - 1][0]["angle"], 0.9, 100, True)
+            assert nm == rn and np.array_equal(gm, rm), ("matches", k)
+    # (b) ctypes, frames with a row pitch of w + 64 in page-locked memory, cap = capacity + 64
+    pl = FramePipeline(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, sub_batch=16, npipes=3)
+    M, stride = 70, w + 64
+    buf = torch.zeros((M, h, stride), dtype=torch.uint8).pin_memory()
+    buf[:, :, :w] = torch.from_numpy(frames[:M])
+    cap = pl.capacity() + 64
+    hk = torch.zeros((M, cap, 7), dtype=torch.int32).pin_memory()
+    hd = torch.zeros((M, cap, 32), dtype=torch.uint8).pin_memory()
+    hn, hnm = torch.zeros(M, dtype=torch.int32).pin_memory(), torch.zeros(M, dtype=torch.int32).pin_memory()
+    hm = torch.zeros((M, cap), dtype=torch.int32).pin_memory()
+    ptrs = (C.c_void_p * M)(*[buf[i].data_ptr() for i in range(M)])
+    pl.extract_match(ptrs, M, w, h, stride, hk.data_ptr(), hd.data_ptr(), cap, hn.data_ptr(), hm.data_ptr(), hnm.data_ptr())
+    pc = pl.capacity()   # the library fills the pipeline's own capacity of every row; the caller's extra columns stay untouched
+    check_sequence(oracle, ref[:M], hn.numpy(), hk.numpy(), hd.numpy(), hm.numpy()[:, :pc], hnm.numpy(), label="host, strided")
+    assert not hm.numpy()[:, pc:].any() and not hk.numpy()[:, pc:].any()
