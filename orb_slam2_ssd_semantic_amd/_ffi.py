@@ -43,7 +43,7 @@ SYMBOLS = (
     "orbfe_initialization_resolve", "orbfe_set_option", "orbfe_match_bf_blocks_device",
     "orbfe_pipeline_create", "orbfe_pipeline_destroy", "orbfe_pipeline_pipes", "orbfe_pipeline_capacity", "orbfe_pipeline_sub_batch",
     "orbfe_pipeline_extractor", "orbfe_pipeline_matcher", "orbfe_pipeline_extract_match_device", "orbfe_pipeline_join",
-    "orbfe_pipeline_synchronize", "orbfe_pipeline_reset_sequence", "orbfe_pipeline_get_overflow", "orbfe_pipeline_extract_match",
+    "orbfe_pipeline_synchronize", "orbfe_pipeline_reset_sequence", "orbfe_pipeline_get_overflow", "orbfe_pipeline_extract_match", "orbfe_pipeline_set_host_pipes",
 )
 
 # orbfe_set_option (include/orbfe.h ORBFE_OPT_*)
@@ -220,6 +220,7 @@ def _configure(L):
     L.orbfe_pipeline_matcher.restype = vp
     L.orbfe_pipeline_extract_match_device.argtypes = [vp, vp, i32, i32, i32, i32, sz, vp, vp, i32, vp, vp, vp, f32, i32, i32, i32, vp]
     L.orbfe_pipeline_join.argtypes = [vp, vp]
+    L.orbfe_pipeline_set_host_pipes.argtypes = [vp, i32]
     L.orbfe_pipeline_extract_match.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, f32, i32, i32, i32]
     L.orbfe_pipeline_get_overflow.argtypes = [vp, vp]
     for name in SYMBOLS:

@@ -138,6 +138,8 @@ struct orbfe_handle {
     orbfe_params prm;
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;      // false: the stream belongs to a pipeline (orbfe_internal_create_on_stream); no host copy streams then
+    bool own_side = true;        // false: the side stream (blur) is one the pipeline shares among its pipes
     // constructor tables (src/ORBextractor.cc:404-439)
     float scale[ORBFE_MAX_LEVELS], inv_scale[ORBFE_MAX_LEVELS], sigma2[ORBFE_MAX_LEVELS], inv_sigma2[ORBFE_MAX_LEVELS];
     int feat[ORBFE_MAX_LEVELS];
@@ -780,7 +782,17 @@ static orbfe_status read_overflow(orbfe_handle *h, int32_t *flags)
 // ---------------------------------------------------------------------------------------------------
 // create / destroy / getters
 // ---------------------------------------------------------------------------------------------------
-extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
+static orbfe_status create_impl(const orbfe_params *p, hipStream_t borrowed, hipStream_t borrowed_side, bool borrow, orbfe_handle **out);
+extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out) { return create_impl(p, nullptr, nullptr, false, out); }
+// A handle for a pipe of orbfe_pipeline: `st` (the pipe's stream) serves as the handle's own stream and stays the pipeline's;
+// the copy streams of the host entry points are not created (orbfe_extract / orbfe_extract_batch answer ORBFE_ERR_STATE).  Every
+// stream a process creates is multiplexed onto a few hardware queues: a pipeline of 12 pipes made 74 of them this way, 26 now.
+orbfe_status orbfe_internal_create_on_stream(const orbfe_params *p, void *st, void *side, orbfe_handle **out)
+{
+    return create_impl(p, (hipStream_t)st, (hipStream_t)side, true, out);
+}
+
+static orbfe_status create_impl(const orbfe_params *p, hipStream_t borrowed, hipStream_t borrowed_side, bool borrow, orbfe_handle **out)
 {
     if (!p || !out) { orbfe_set_error("null argument"); return ORBFE_ERR_ARG; }
     *out = nullptr;
@@ -833,7 +845,10 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
         orbfe_destroy(h);
         return s;
     };
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (borrow) {
+        h->stream = borrowed;
+        h->own_stream = false;
+    } else if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         orbfe_set_error("hipStreamCreate failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(ORBFE_ERR_HIP);
     }
@@ -843,15 +858,19 @@ extern "C" orbfe_status orbfe_create(const orbfe_params *p, orbfe_handle **out)
     for (int r = 0; r < ORBFE_PROF_RING; ++r)
         for (int i = 0; i < ORBFE_EV_N; ++i)
             if (hipEventCreate(&h->ev[r][i]) != hipSuccess) { orbfe_set_error("hipEventCreate failed"); return fail(ORBFE_ERR_HIP); }
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+    if (borrow && borrowed_side) {
+        h->side = borrowed_side;
+        h->own_side = false;
+    }
+    if ((h->own_side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
         orbfe_set_error("side stream / event creation failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(ORBFE_ERR_HIP);
     }
-    if (hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess) {
+    if (h->own_stream && (hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess ||
+                          hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess)) {
         orbfe_set_error("copy stream creation failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(ORBFE_ERR_HIP);
     }
@@ -937,8 +956,8 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (h->ev_auto) (void)hipEventDestroy(h->ev_auto);
     h->h_auto.release();
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
-    if (h->side) (void)hipStreamDestroy(h->side);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->side && h->own_side) (void)hipStreamDestroy(h->side);
+    if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -1328,6 +1347,10 @@ static bool is_pinned_host(const void *p)
 static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, int nframes, int w, int ht,
                                  int stride, orbfe_keypoint *kps, uint8_t *desc, int cap, int32_t *n_out)
 {
+    if (!h->own_stream) {
+        orbfe_set_error("this extractor is a pipe of an orbfe_pipeline: use orbfe_pipeline_extract_match for host buffers");
+        return ORBFE_ERR_STATE;
+    }
     DeviceGuard g(h->device);
     const int chunk_max = h->prm.max_batch;
     const int nchunks = (nframes + chunk_max - 1) / chunk_max;

@@ -655,6 +655,7 @@ struct orbfe_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
     MDevBuf b[16];
+    bool own_stream = true;  // false: the stream belongs to a pipeline (orbfe_internal_matcher_create_on_stream)
     int bf_kernel = 0;  // 0 = k_match_bf (int8 dot product on the matrix cores), 1 = k_match_popc (xor / popcount)
     // Device entry points that use the scratch blocks b[] run on the CALLER's stream: one that arrives on another stream
     // than its predecessor waits (at stream level) for the event recorded behind that predecessor's last launch.
@@ -702,7 +703,15 @@ extern "C" int32_t orbfe_hamming(const uint8_t a[32], const uint8_t b[32])
     return d;
 }
 
-extern "C" orbfe_status orbfe_matcher_create(int32_t device, orbfe_matcher **out)
+static orbfe_status matcher_create_impl(int32_t device, hipStream_t borrowed, bool borrow, orbfe_matcher **out);
+extern "C" orbfe_status orbfe_matcher_create(int32_t device, orbfe_matcher **out) { return matcher_create_impl(device, nullptr, false, out); }
+// a matcher for a pipe of orbfe_pipeline: `st` (the pipe's stream) is its own stream and stays the pipeline's
+orbfe_status orbfe_internal_matcher_create_on_stream(int32_t device, void *st, orbfe_matcher **out)
+{
+    return matcher_create_impl(device, (hipStream_t)st, true, out);
+}
+
+static orbfe_status matcher_create_impl(int32_t device, hipStream_t borrowed, bool borrow, orbfe_matcher **out)
 {
     if (!out) return ORBFE_ERR_ARG;
     *out = nullptr;
@@ -718,10 +727,12 @@ extern "C" orbfe_status orbfe_matcher_create(int32_t device, orbfe_matcher **out
     if (!m) return ORBFE_ERR_NOMEM;
     m->device = device;
     MDeviceGuard g(device);
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+    m->own_stream = !borrow;
+    if (borrow) m->stream = borrowed;
+    if ((!borrow && hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreateWithFlags(&m->ev_scratch, hipEventDisableTiming) != hipSuccess) {
         orbfe_set_error("hipStreamCreate / hipEventCreate failed");
-        if (m->stream) (void)hipStreamDestroy(m->stream);
+        if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
         delete m;
         return ORBFE_ERR_HIP;
     }
@@ -748,7 +759,7 @@ extern "C" void orbfe_matcher_destroy(orbfe_matcher *m)
     m->pin_in.release();
     m->pin_out.release();
     if (m->ev_scratch) (void)hipEventDestroy(m->ev_scratch);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
 

@@ -13,6 +13,14 @@
 
 #include "orbfe_common.h"
 
+// csrc/orbfe_api.hip / orbfe_match.hip: handles that live on a stream of the pipeline instead of creating their own
+orbfe_status orbfe_internal_create_on_stream(const orbfe_params *p, void *st, void *side, orbfe_handle **out);
+orbfe_status orbfe_internal_matcher_create_on_stream(int32_t device, void *st, orbfe_matcher **out);
+
+#ifndef ORBFE_PIPE_SIDE_STREAMS
+#define ORBFE_PIPE_SIDE_STREAMS 1   // side streams of a pipeline, shared by its pipes (A/B -DORBFE_PIPE_SIDE_STREAMS=n, 12 pipes: 1: 314-315 k frames/s resident and 0.91 of the PCIe link through the host entry point; 2: 312-313 k / 0.87; 4: 299-301 k; one per pipe: 310 k / 0.90)
+#endif
+
 struct PipeGuard {
     int prev = -1, dev = -1;
     explicit PipeGuard(int d) : dev(d)
@@ -35,6 +43,7 @@ struct orbfe_pipeline {
     std::vector<orbfe_handle *> ext;
     std::vector<orbfe_matcher *> mat;
     std::vector<hipStream_t> st;
+    std::vector<hipStream_t> side;     // side streams (the extractors' blur), shared: pipe i uses side[i % side.size()]
     std::vector<hipEvent_t> ev_end;    // per pipe: behind the pipe's last launch of the most recent call
     std::vector<hipEvent_t> ev_ext;    // per sub-batch index: extraction finished (most recent call)
     std::vector<hipEvent_t> ev_match;  // per sub-batch index: matcher finished (most recent call)
@@ -56,6 +65,7 @@ struct orbfe_pipeline {
     size_t carry_src_bytes[3] = {0, 0, 0};
     bool joined = true;
     int rot = 0;                // pipe of sub-batch 0 of the next call: consecutive short calls take turns on the pipes
+    int host_pipes = 1;         // pipes the host entry point deals its chunks to (orbfe_pipeline_set_host_pipes)
     // host entry point (orbfe_pipeline_extract_match): device input / output sets, copy streams
     static const int NSETS = 3;
     uint8_t *d_in[NSETS] = {nullptr, nullptr, nullptr};
@@ -132,6 +142,8 @@ extern "C" void orbfe_pipeline_destroy(orbfe_pipeline *pl)
     if (pl->s_out) (void)hipStreamDestroy(pl->s_out);
     for (hipStream_t s : pl->st)
         if (s) (void)hipStreamDestroy(s);
+    for (hipStream_t s : pl->side)
+        if (s) (void)hipStreamDestroy(s);
     delete pl;
 }
 
@@ -151,33 +163,49 @@ extern "C" orbfe_status orbfe_pipeline_create(const orbfe_params *p, int32_t npi
         orbfe_pipeline_destroy(pl);
         return s;
     };
-    for (int i = 0; i < npipes; ++i) {
-        orbfe_handle *h = nullptr;
-        orbfe_status s = orbfe_create(p, &h);   // validates the parameter set, fails with ORBFE_ERR_NODEVICE without a GPU
-        if (s != ORBFE_OK) return fail(s);
-        pl->ext.push_back(h);
-        if (i == 0) {
-            // the device the first handle resolved (p->device may be -1 = current)
-            int dev = p->device;
-            if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
-            pl->device = dev;
-            pl->prm.device = dev;
+    {   // the device the handles will resolve (p->device may be -1 = current); without a device the first create fails below
+        int dev = p->device;
+        if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+        pl->device = dev;
+        pl->prm.device = dev;
+    }
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+            (void)hipGetLastError();
+            orbfe_set_error("no HIP device visible; liborbfe has no CPU fallback");
+            return fail(ORBFE_ERR_NODEVICE);
         }
-        orbfe_matcher *m = nullptr;
-        s = orbfe_matcher_create(pl->device, &m);
-        if (s != ORBFE_OK) return fail(s);
-        pl->mat.push_back(m);
+        if (pl->device >= ndev) { orbfe_set_error("device %d out of range (%d visible)", pl->device, ndev); return fail(ORBFE_ERR_ARG); }
     }
     PipeGuard g(pl->device);
-    pl->cap = orbfe_keypoint_capacity(pl->ext[0]);
+    // One stream per pipe, shared by the pipe's extractor and matcher handles (which then create none of their own but the
+    // extractor's side stream): the runtime multiplexes all streams of a process onto a few hardware queues, and every idle
+    // stream less is a copy stream that does not have to share its queue with a kernel stream.
     for (int i = 0; i < npipes; ++i) {
-        hipStream_t s = nullptr;
+        hipStream_t st = nullptr;
         hipEvent_t e = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { orbfe_set_error("pipeline stream creation failed"); return fail(ORBFE_ERR_HIP); }
-        pl->st.push_back(s);
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { orbfe_set_error("pipeline stream creation failed"); return fail(ORBFE_ERR_HIP); }
+        pl->st.push_back(st);
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { orbfe_set_error("pipeline event creation failed"); return fail(ORBFE_ERR_HIP); }
         pl->ev_end.push_back(e);
     }
+    for (int i = 0; i < std::min(npipes, ORBFE_PIPE_SIDE_STREAMS); ++i) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { orbfe_set_error("pipeline stream creation failed"); return fail(ORBFE_ERR_HIP); }
+        pl->side.push_back(st);
+    }
+    for (int i = 0; i < npipes; ++i) {
+        orbfe_handle *h = nullptr;
+        orbfe_status s = orbfe_internal_create_on_stream(&pl->prm, (void *)pl->st[(size_t)i], (void *)pl->side[(size_t)i % pl->side.size()], &h);
+        if (s != ORBFE_OK) return fail(s);
+        pl->ext.push_back(h);
+        orbfe_matcher *m = nullptr;
+        s = orbfe_internal_matcher_create_on_stream(pl->device, (void *)pl->st[(size_t)i], &m);
+        if (s != ORBFE_OK) return fail(s);
+        pl->mat.push_back(m);
+    }
+    pl->cap = orbfe_keypoint_capacity(pl->ext[0]);
     if (hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess) { orbfe_set_error("pipeline event creation failed"); return fail(ORBFE_ERR_HIP); }
     for (int k = 0; k < 2; ++k) {
         if (hipEventCreateWithFlags(&pl->ev_carry[k], hipEventDisableTiming) != hipSuccess ||
@@ -205,6 +233,13 @@ extern "C" orbfe_handle *orbfe_pipeline_extractor(orbfe_pipeline *pl, int32_t pi
 extern "C" orbfe_matcher *orbfe_pipeline_matcher(orbfe_pipeline *pl, int32_t pipe)
 {
     return (pl && pipe >= 0 && pipe < pl->P) ? pl->mat[(size_t)pipe] : nullptr;
+}
+
+extern "C" orbfe_status orbfe_pipeline_set_host_pipes(orbfe_pipeline *pl, int32_t n)
+{
+    if (!pl || n < 1) return ORBFE_ERR_ARG;
+    pl->host_pipes = std::min(n, pl->P);
+    return ORBFE_OK;
 }
 
 extern "C" orbfe_status orbfe_pipeline_reset_sequence(orbfe_pipeline *pl)
@@ -359,6 +394,7 @@ static orbfe_status ensure_host_sets(orbfe_pipeline *pl, int w, int ht)
 {
     const size_t need = (size_t)pl->F * w * ht;
     if (need <= pl->in_bytes && pl->out_frames == pl->F) return ORBFE_OK;
+    // (measured and rejected: copy streams at the highest stream priority -- 159 k frames/s with 3 pipes, 41 k with 12)
     if (!pl->s_in) ORBFE_HIP(hipStreamCreateWithFlags(&pl->s_in, hipStreamNonBlocking));
     if (!pl->s_out) ORBFE_HIP(hipStreamCreateWithFlags(&pl->s_out, hipStreamNonBlocking));
     ORBFE_HIP(hipStreamSynchronize(pl->s_in));
@@ -417,6 +453,7 @@ extern "C" orbfe_status orbfe_pipeline_extract_match(orbfe_pipeline *pl, const u
         }
         // the pipes start behind the copy (the call forks from s_in) and are not joined: the next chunk's copy and pipes follow at once
         const int fl = ((c > 0 || (flags & ORBFE_PIPE_CONTINUE)) ? ORBFE_PIPE_CONTINUE : 0) | ORBFE_PIPE_NO_JOIN;
+        pl->rot = c % std::max(1, std::min(pl->host_pipes, pl->P));   // the chunk is one sub-batch: this is its pipe
         s = orbfe_pipeline_extract_match_device(pl, pl->d_in[k], nf, w, ht, w, fbytes, pl->d_okps[k], pl->d_odesc[k], pc, pl->d_on[k],
                                                 match ? pl->d_om[k] : nullptr, match ? pl->d_onm[k] : nullptr, nnratio, th, check_ori, fl,
                                                 (void *)pl->s_in);
@@ -425,13 +462,14 @@ extern "C" orbfe_status orbfe_pipeline_extract_match(orbfe_pipeline *pl, const u
         if (s != ORBFE_OK) return s;
         // padded blocks straight into the caller's arrays (row pitch cap >= pc)
         ORBFE_HIP(hipMemcpyAsync(n_out + lo, pl->d_on[k], (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, pl->s_out));
-        ORBFE_HIP(hipMemcpy2DAsync(kps + (size_t)lo * cap, (size_t)cap * sizeof(orbfe_keypoint), pl->d_okps[k], (size_t)pc * sizeof(orbfe_keypoint),
-                                   (size_t)pc * sizeof(orbfe_keypoint), (size_t)nf, hipMemcpyDeviceToHost, pl->s_out));
-        ORBFE_HIP(hipMemcpy2DAsync(desc + (size_t)lo * cap * 32, (size_t)cap * 32, pl->d_odesc[k], (size_t)pc * 32, (size_t)pc * 32, (size_t)nf,
-                                   hipMemcpyDeviceToHost, pl->s_out));
+        auto rows_out = [&](void *dst, const void *src, size_t elem) -> hipError_t {   // nf rows of pc elements, host pitch cap
+            if (cap == pc) return hipMemcpyAsync(dst, src, (size_t)nf * pc * elem, hipMemcpyDeviceToHost, pl->s_out);   // one linear copy
+            return hipMemcpy2DAsync(dst, (size_t)cap * elem, src, (size_t)pc * elem, (size_t)pc * elem, (size_t)nf, hipMemcpyDeviceToHost, pl->s_out);
+        };
+        ORBFE_HIP(rows_out(kps + (size_t)lo * cap, pl->d_okps[k], sizeof(orbfe_keypoint)));
+        ORBFE_HIP(rows_out(desc + (size_t)lo * cap * 32, pl->d_odesc[k], 32));
         if (match) {
-            ORBFE_HIP(hipMemcpy2DAsync(match + (size_t)lo * cap, (size_t)cap * sizeof(int32_t), pl->d_om[k], (size_t)pc * sizeof(int32_t),
-                                       (size_t)pc * sizeof(int32_t), (size_t)nf, hipMemcpyDeviceToHost, pl->s_out));
+            ORBFE_HIP(rows_out(match + (size_t)lo * cap, pl->d_om[k], sizeof(int32_t)));
             ORBFE_HIP(hipMemcpyAsync(nmatches + lo, pl->d_onm[k], (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, pl->s_out));
         }
         ORBFE_HIP(hipEventRecord(pl->ev_out[k], pl->s_out));

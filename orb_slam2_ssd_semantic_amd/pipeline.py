@@ -60,6 +60,9 @@ class FramePipeline:
                                                    nmatches_ptr, self.nnratio, self.th, int(self.check_ori), flags),
               "orbfe_pipeline_extract_match")
 
+    def set_host_pipes(self, n):
+        check(self._L.orbfe_pipeline_set_host_pipes(self._p, int(n)), "orbfe_pipeline_set_host_pipes")
+
     def join(self, stream=None):
         check(self._L.orbfe_pipeline_join(self._p, stream), "orbfe_pipeline_join")
 
