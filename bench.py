@@ -891,6 +891,7 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
         if isinstance(c4, dict) and "strong" in c4:
             result["config4_frames_per_s"] = c4["strong"]["frames_per_s"]           # the 1024-frame batch sharded over the ranks
             result["config4_weak_frames_per_s"] = c4["weak"]["frames_per_s"]
+            result["config4_pipeline_frames_per_s"] = c4.get("pipeline_frames_per_s")
             result["config4_allgather_ms"] = c4["strong"]["allgather_ms"]
             result["config4_allgather_bus_GBps"] = c4["strong"]["allgather_bus_GBps"]
             cg = c4.get("cabi_group") or {}
@@ -902,6 +903,7 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
     if world == 1:
         result["config5"] = config5_leg(args, local_rank, check=not args.no_cpu_baseline)
         result["config5_frames_per_s"] = result["config5"]["frames_per_s"]
+        result["config5_pipeline_frames_per_s"] = result["config5"]["frames_per_s_pipeline"]
         result["config5_roofline_frac_hbm"] = result["config5"]["roofline"]["frac"]
         result["bow_chain"] = bow_leg(args, local_rank)
         result["bow_search_pairs_per_s"] = round(1e6 / result["bow_chain"]["search_by_bow_us_per_pair"], 1)
@@ -1374,6 +1376,29 @@ def config5_leg(args, local_rank, nframes=512, nfeat=4000, w=1920, h=1080, warmu
            "width": w, "height": h, "nfeatures": nfeat, "cap": cap, "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
            "fast_candidates_frame0": ncand, "resident_input_bytes": int(frames.numel()), "warmup": warmup, "reps": reps,
            "roofline": roof, "stages": stages}
+    # the same 512 frames through ONE call of the sequence pipeline (extract only): 8 pipes x sub-batches of 64 frames
+    from orb_slam2_ssd_semantic_amd import FramePipeline
+    k1, d1, n1 = kps.clone(), desc.clone(), n.clone()
+    pl = FramePipeline(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, sub_batch=max(1, nframes // 8), npipes=8, device=local_rank)
+
+    def onep():
+        pl.extract_match_device(frames.data_ptr(), nframes, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr(), None, None,
+                                flags=pl.NO_JOIN, stream=stream)
+    for _ in range(warmup):
+        onep()
+    pl.synchronize()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        onep()
+    pl.synchronize()
+    torch.cuda.synchronize()
+    out["frames_per_s_pipeline"] = round(nframes * reps / (time.perf_counter() - t), 1)
+    out["pipeline"] = "one orbfe_pipeline_extract_match_device call (extract only), 8 pipes x sub-batches of %d frames" % max(1, nframes // 8)
+    out["pipeline_equals_one_call"] = bool(torch.equal(kps, k1) and torch.equal(desc, d1) and torch.equal(n, n1))
+    assert pl.overflow() == 0
+    pl.close()
+    del pl, k1, d1, n1
     if check:   # two frames of the timed call's output against the oracle (count, keypoint bit patterns, descriptors, order)
         from oracle import oracle_ffi as O
         oe = O.OracleExtractor(nfeat, 1.2, 8, 20, 7)
@@ -1576,6 +1601,32 @@ def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2
 
     run(allf[lo:hi].contiguous(), hi - lo, "strong")
     run(allf, global_batch, "weak")
+    if world == 1:   # the shard through ONE call of the sequence pipeline (extract only): 4 pipes x sub-batches of a quarter shard
+        from orb_slam2_ssd_semantic_amd import FramePipeline
+        nfr = hi - lo
+        pl = FramePipeline(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, sub_batch=max(1, -(-nfr // 4)), npipes=4, device=local_rank)
+        kps = torch.zeros((nfr, cap, 7), dtype=torch.int32, device="cuda")
+        desc = torch.zeros((nfr, cap, 32), dtype=torch.uint8, device="cuda")
+        n = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+        shard = allf[lo:hi].contiguous()
+
+        def onep():
+            pl.extract_match_device(shard.data_ptr(), nfr, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr(), None, None,
+                                    flags=pl.NO_JOIN, stream=stream)
+        for _ in range(3):
+            onep()
+        pl.synchronize()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            onep()
+        pl.synchronize()
+        torch.cuda.synchronize()
+        out["pipeline_frames_per_s"] = round(nfr * steps / (time.perf_counter() - t), 1)
+        out["pipeline"] = "one orbfe_pipeline_extract_match_device call per batch (extract only), 4 pipes"
+        assert pl.overflow() == 0
+        pl.close()
+        del pl, kps, desc, n
     try:
         out["cabi_group"] = config4_group_guarded(args, rank, local_rank, world, allf, lo, hi, global_batch, nfeat, steps)
     except Exception as e:   # a second communicator next to torch's: report, never lose the line over it
