@@ -285,9 +285,10 @@ class HipEngine:
         self.pl = FramePipeline(nfeatures, 1.2, 8, 20, 7, max_width=self.w, max_height=self.h, sub_batch=self.F, npipes=self.P,
                                 device=dev, blur_rounding=args.blur_rounding, nnratio=0.9, th=100, check_ori=True)
         self.exts, self.mats = self.pl.extractors, self.pl.matchers
-        if getattr(args, "overlap", None) is not None:
-            for e in self.exts:
-                e.set_option("overlap", args.overlap)
+        for opt in ("overlap", "rows_fast", "rows_blur"):
+            if getattr(args, opt, None) is not None:
+                for e in self.exts:
+                    e.set_option(opt, getattr(args, opt))
         self.ext, self.mat = self.exts[0], self.mats[0]
         # One GPU: nothing consumes a step's outputs before the timed region's closing fence, so the steps run back to back
         # (ORBFE_PIPE_NO_JOIN: the pipes are not drained at step boundaries; the library orders the re-use of the output blocks
@@ -393,6 +394,8 @@ def main():
                     "launches resident frames per GPU (default 24 576: twenty steps are > 1.5 s of GPU work)")
     ap.add_argument("--pipes", type=int, default=int(os.environ.get("ORBFE_BENCH_PIPES", "12")), help="pipes of the pipeline (measured: 1: 277 k, 3: 296 k, 6: 306 k, 12: 316 k, 16-32: 311-313 k frames/s)")
     ap.add_argument("--step-join", action="store_true", help="join the launch stream after every step even on one GPU")
+    ap.add_argument("--rows-fast", type=int, default=None, help="ORBFE_OPT_ROWS_FAST of the pipes' extractors (rows a FAST wave walks)")
+    ap.add_argument("--rows-blur", type=int, default=None, help="ORBFE_OPT_ROWS_BLUR of the pipes' extractors")
     ap.add_argument("--overlap", type=int, default=None, help="ORBFE_OPT_OVERLAP of the pipes' extractors (blur on the handle's side "
                     "stream: 0 never, 1 / 2 beside FAST / the quadtree; default: the library's choice)")
     ap.add_argument("--blur-rounding", type=int, default=0, help="GaussianBlur column rounding: 0 canonical half-up, 1 = the x86 "

@@ -57,6 +57,8 @@ struct orbfe_pipeline {
     uint8_t *d_cdesc[2] = {nullptr, nullptr};
     int32_t *d_cn[2] = {nullptr, nullptr};
     hipEvent_t ev_carry[2] = {nullptr, nullptr};
+    hipEvent_t ev_m0[2] = {nullptr, nullptr};   // behind the frame-0 match of a call that READ carry slot k (recorded on that call's pipe)
+    bool m0_valid[2] = {false, false};
     int carry_cur = 0;          // slot the NEXT call reads
     bool have_carry = false;
     // where the carried frame was copied FROM (the caller's blocks of the previous call): a sub-batch of the next call that
@@ -125,6 +127,7 @@ extern "C" void orbfe_pipeline_destroy(orbfe_pipeline *pl)
     if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
     for (int k = 0; k < 2; ++k) {
         if (pl->ev_carry[k]) (void)hipEventDestroy(pl->ev_carry[k]);
+        if (pl->ev_m0[k]) (void)hipEventDestroy(pl->ev_m0[k]);
         if (pl->d_ckps[k]) (void)hipFree(pl->d_ckps[k]);
         if (pl->d_cdesc[k]) (void)hipFree(pl->d_cdesc[k]);
         if (pl->d_cn[k]) (void)hipFree(pl->d_cn[k]);
@@ -209,6 +212,7 @@ extern "C" orbfe_status orbfe_pipeline_create(const orbfe_params *p, int32_t npi
     if (hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess) { orbfe_set_error("pipeline event creation failed"); return fail(ORBFE_ERR_HIP); }
     for (int k = 0; k < 2; ++k) {
         if (hipEventCreateWithFlags(&pl->ev_carry[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&pl->ev_m0[k], hipEventDisableTiming) != hipSuccess ||
             hipMalloc((void **)&pl->d_ckps[k], (size_t)pl->cap * sizeof(orbfe_keypoint)) != hipSuccess ||
             hipMalloc((void **)&pl->d_cdesc[k], (size_t)pl->cap * 32) != hipSuccess ||
             hipMalloc((void **)&pl->d_cn[k], 64) != hipSuccess) {
@@ -346,6 +350,8 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
                 s = orbfe_match_bf_blocks_device(pl->mat[(size_t)p], d_kps, d_desc, d_n_out, pl->d_ckps[rd], pl->d_cdesc[rd], pl->d_cn[rd], cap,
                                                  pl->d_seq + 1, pl->d_seq + 1, 1, nnratio, th, check_ori, d_match, d_nmatches, (void *)st);
                 if (s != ORBFE_OK) return s;
+                ORBFE_HIP(hipEventRecord(pl->ev_m0[rd], st));   // slot rd has been read: the NEXT call may write it
+                pl->m0_valid[rd] = true;
             } else {  // the first frame of a sequence has no predecessor
                 ORBFE_HIP(hipMemsetAsync(d_match, 0xFF, (size_t)cap * sizeof(int32_t), st));
                 ORBFE_HIP(hipMemsetAsync(d_nmatches, 0, sizeof(int32_t), st));
@@ -358,14 +364,17 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
     if (!match)
         for (int j = 0; j < nsub; ++j) pl->ev_match_valid[(size_t)j] = 0;
 
-    // carry: the last frame of this call, for the first frame of the next one.  Slot `wr` was read by the previous call's
-    // frame-0 match on pipe 0: this call's work on pipe 0 is ordered behind it, and the copy waits for this call's first
-    // sub-batch (ev_ext[0], recorded on pipe 0 after it).
+    // carry: the last frame of this call, for the first frame of the next one.  Slot `wr` was read by the PREVIOUS call's
+    // frame-0 match, on whatever pipe that call's sub-batch 0 ran (the pipes take turns): the copy waits for that match's own
+    // event.
     {
         const int jl = nsub - 1;
         hipStream_t st = pl->st[(size_t)((pl->rot + jl) % P)];
         const size_t last = (size_t)nframes - 1;
-        if (jl != 0) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_ext[0], 0));
+        if (pl->m0_valid[wr]) {
+            ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_m0[wr], 0));
+            pl->m0_valid[wr] = false;
+        }
         ORBFE_HIP(hipMemcpyAsync(pl->d_ckps[wr], d_kps + last * cap, (size_t)std::min(cap, pl->cap) * sizeof(orbfe_keypoint),
                                  hipMemcpyDeviceToDevice, st));
         ORBFE_HIP(hipMemcpyAsync(pl->d_cdesc[wr], d_desc + last * cap * 32, (size_t)std::min(cap, pl->cap) * 32, hipMemcpyDeviceToDevice, st));

@@ -297,3 +297,38 @@ def test_host_entry_point_from_cpp_and_python(oracle, tmp_path):
     pc = pl.capacity()   # the library fills the pipeline's own capacity of every row; the caller's extra columns stay untouched
     check_sequence(oracle, ref[:M], hn.numpy(), hk.numpy(), hd.numpy(), hm.numpy()[:, :pc], hnm.numpy(), label="host, strided")
     assert not hm.numpy()[:, pc:].any() and not hk.numpy()[:, pc:].any()
+
+
+@pytest.mark.gpu
+def test_many_short_continuing_calls_take_turns_on_the_pipes(oracle):
+    """40 calls of 1 - 7 frames (sub-batch 4, 3 pipes: consecutive calls start on different pipes), each continuing the sequence
+    and each writing into the SAME output slots, nothing synchronised between the calls but the final read-back of each call's
+    rows on the launch stream: the carried last frame, the frame-0 match against it and the re-use of the caller's blocks are
+    ordered by the pipeline's events alone."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import FramePipeline
+    w, h, nf = 640, 480, 1000
+    rng = np.random.default_rng(5)
+    sizes = [int(v) for v in rng.integers(1, 8, 40)]
+    N = sum(sizes)
+    frames = np.stack([synth_frame(8800 + i, h, w, sparse=(i % 4 == 1)) for i in range(N)])
+    ref = oracle_sequence(frames, nf)
+    pl = FramePipeline(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, sub_batch=4, npipes=3)
+    cap = pl.capacity()
+    dg = torch.from_numpy(frames).cuda()
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")  # noqa: E731
+    dk, dd, dn, dm, dnm = z((8, cap, 7), torch.int32), z((8, cap, 32), torch.uint8), z(8, torch.int32), z((8, cap), torch.int32), z(8, torch.int32)
+    st = torch.cuda.current_stream().cuda_stream
+    got, lo = [], 0
+    for c, n in enumerate(sizes):
+        pl.extract_match_device(dg[lo].data_ptr(), n, w, h, w, w * h, dk.data_ptr(), dd.data_ptr(), cap, dn.data_ptr(), dm.data_ptr(), dnm.data_ptr(),
+                                flags=pl.CONTINUE if c else 0, stream=st)
+        # asynchronous copies on the launch stream (ordered behind the call's join); the next call overwrites the blocks at once
+        got.append(tuple(t[:n].to("cpu", non_blocking=False).numpy().copy() for t in (dn, dk, dd, dm, dnm)))
+        lo += n
+    lo = 0
+    for c, n in enumerate(sizes):
+        cn, ck, cd, cm, cnm = got[c]
+        check_sequence(oracle, ref[lo:lo + n], cn, ck, cd, cm, cnm, first_has_pred=ref[lo - 1] if c else None, label=f"call {c} ({n} frames)")
+        lo += n
+    assert pl.overflow() == 0
