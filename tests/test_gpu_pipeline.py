@@ -332,3 +332,36 @@ def test_many_short_continuing_calls_take_turns_on_the_pipes(oracle):
         check_sequence(oracle, ref[lo:lo + n], cn, ck, cd, cm, cnm, first_has_pred=ref[lo - 1] if c else None, label=f"call {c} ({n} frames)")
         lo += n
     assert pl.overflow() == 0
+
+
+@pytest.mark.gpu
+def test_pipeline_at_config5_and_config4_shapes_equals_one_batched_call():
+    """BASELINE config 5 (1920x1080, 4000 features) and config 4 (640x480, 2000 features) through the pipeline, extract only:
+    byte-identical to one batched call on one handle (which tests/test_gpu_extract.py pins to the oracle at these shapes)."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import FramePipeline, ORBextractor
+    for (w, h, nf, N, sub, pipes) in ((1920, 1080, 4000, 40, 8, 3), (640, 480, 2000, 100, 16, 4)):
+        frames = np.stack([synth_frame(9900 + i, h, w, sparse=(i % 6 == 5)) for i in range(N)])
+        dg = torch.from_numpy(frames).cuda()
+        e = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=N)
+        pl = FramePipeline(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, sub_batch=sub, npipes=pipes)
+        cap = e.capacity()
+        assert pl.capacity() == cap
+        st = torch.cuda.current_stream().cuda_stream
+        outs = []
+        for use_pl in (False, True):
+            k = torch.zeros((N, cap, 7), dtype=torch.int32, device="cuda")
+            d = torch.zeros((N, cap, 32), dtype=torch.uint8, device="cuda")
+            n = torch.zeros(N, dtype=torch.int32, device="cuda")
+            if use_pl:
+                pl.extract_match_device(dg.data_ptr(), N, w, h, w, w * h, k.data_ptr(), d.data_ptr(), cap, n.data_ptr(), None, None, stream=st)
+            else:
+                e.extract_batch_device(dg.data_ptr(), N, w, h, w, w * h, k.data_ptr(), d.data_ptr(), cap, n.data_ptr(), st)
+            torch.cuda.synchronize()
+            outs.append((k, d, n))
+        assert e.overflow() == 0 and pl.overflow() == 0
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), (w, h)
+        assert int(outs[0][2].min()) > 0.9 * nf
+        pl.close()
+        e.close()
