@@ -48,6 +48,7 @@ struct orbfe_pipeline {
     std::vector<hipEvent_t> ev_ext;    // per sub-batch index: extraction finished (most recent call)
     std::vector<hipEvent_t> ev_match;  // per sub-batch index: matcher finished (most recent call)
     std::vector<char> ev_match_valid;
+    std::vector<char> ev_ext_valid;
     hipEvent_t ev_fork = nullptr;
     // seq[i] = i - 1: qframe = seq + q0 + 1 (q0, q0 + 1, ...), tframe = seq + q0 (q0 - 1, q0, ...)
     int32_t *d_seq = nullptr;
@@ -89,6 +90,7 @@ static orbfe_status ensure_events(orbfe_pipeline *pl, int nsub)
         ORBFE_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
         pl->ev_match.push_back(b);
         pl->ev_match_valid.push_back(0);
+        pl->ev_ext_valid.push_back(0);
     }
     return ORBFE_OK;
 }
@@ -318,8 +320,12 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
         const int p = (pl->rot + j) % P;
         hipStream_t st = pl->st[(size_t)p];
         const int lo = j * F, nf = std::min(F, nframes - lo);
-        // same reason, per sub-batch: the matcher of sub-batch j + 1 of the PREVIOUS call read the last frame of slice j on
-        // another pipe's stream
+        // The output blocks may be the ones of the previous call (a host that re-uses its buffers), and the pipes take turns: what
+        // the PREVIOUS call did with slices j happened on other pipes' streams.  This sub-batch overwrites them only after that
+        // call's extraction of sub-batch j (write after write), its matcher of sub-batch j (queries) and its matcher of
+        // sub-batch j + 1 (whose first pair reads the last frame of slice j) have finished.  (Events of finished work cost nothing.)
+        if (pl->ev_ext_valid[(size_t)j]) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_ext[(size_t)j], 0));
+        if (pl->ev_match_valid[(size_t)j]) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_match[(size_t)j], 0));
         if (j + 1 < (int)pl->ev_match_valid.size() && pl->ev_match_valid[(size_t)j + 1])
             ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_match[(size_t)j + 1], 0));
         // ... and the copy of the previous call's last frame into the carry slot must have read it before this sub-batch
@@ -333,6 +339,7 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
                                        d_kps + (size_t)lo * cap, d_desc + (size_t)lo * cap * 32, cap, d_n_out + lo, (void *)st);
         if (s != ORBFE_OK) return s;
         ORBFE_HIP(hipEventRecord(pl->ev_ext[(size_t)j], st));
+        pl->ev_ext_valid[(size_t)j] = 1;
         if (!match) continue;
         if (j > 0) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_ext[(size_t)j - 1], 0));   // frame lo - 1 comes from the neighbour pipe
         const int q0 = lo == 0 ? 1 : lo;
@@ -360,9 +367,8 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
         ORBFE_HIP(hipEventRecord(pl->ev_match[(size_t)j], st));
         pl->ev_match_valid[(size_t)j] = 1;
     }
-    for (size_t j = (size_t)nsub; j < pl->ev_match_valid.size(); ++j) pl->ev_match_valid[j] = 0;
-    if (!match)
-        for (int j = 0; j < nsub; ++j) pl->ev_match_valid[(size_t)j] = 0;
+    // (the events of sub-batch indices this call did not use keep their last record: a later, longer call still orders itself
+    // behind whatever touched those slices last)
 
     // carry: the last frame of this call, for the first frame of the next one.  Slot `wr` was read by the PREVIOUS call's
     // frame-0 match, on whatever pipe that call's sub-batch 0 ran (the pipes take turns): the copy waits for that match's own
