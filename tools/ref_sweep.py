@@ -1,7 +1,7 @@
 """Direct sweep on the GPU box: B frames (S, sparse S, S_tum; 1000 and 2000 features; both blur roundings) through one batched
 device call each, every frame compared with oracle/_ref -- the UNMODIFIED reference ORBextractor.cc compiled against the cv
 stub (bump allocator, canonical cos/sin) -- without the oracle in between.  The reference side runs in a process pool.
-usage: python tools/ref_sweep.py [B=320] [seed0=5000] [procs=32]"""
+usage: python tools/ref_sweep.py [B=320] [seed0=5000] [procs=32] [fast_mode=0]     (fast_mode: orbfe_set_fast_mode, 2 = lane-compacting)"""
 import multiprocessing as mp
 import os
 import sys
@@ -34,6 +34,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 320
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     procs = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    fast_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     pool = mp.get_context("spawn").Pool(procs)   # spawned before torch touches the GPU
     import torch
     from oracle import ref_ffi as R
@@ -44,6 +45,7 @@ def main():
     for nf in (1000, 2000):
         for mode in (0, 1):
             e = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B, blur_rounding=mode)
+            e.set_fast_mode(fast_mode)
             cap = e.capacity()
             dg = torch.from_numpy(frames).cuda()
             dk = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
@@ -63,7 +65,7 @@ def main():
                 total += 1
             print("nfeatures", nf, "blur_rounding", mode, "frames", B, "mismatching frames so far", bad,
                   "ref time %.1f s on %d processes" % (time.time() - t0, procs), flush=True)
-    print("TOTAL extractions", total, "mismatches", bad)
+    print("TOTAL extractions", total, "mismatches", bad, "fast_mode", fast_mode)
     pool.close()
     return 1 if bad else 0
 
