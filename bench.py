@@ -858,21 +858,19 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
         result["value_step_joined" if fr else "value_free_run"] = round(rate(step), 2)
         eng.free_run = fr
         # the other blur rounding: blur_rounding = 1 is what an x86-64 OpenCV <= 3.3 BINARY computes (SSE2 column kernel), 0 the
-        # canonical integer formula; a second pipeline, same step
-        import copy
-        a2 = copy.copy(args)
-        a2.blur_rounding = 1 - args.blur_rounding
-        outs_saved = eng.outs
-        eng2 = HipEngine(a2, local_rank, nf, F, NL, world)
-        eng2.pl.set_fast_mode(args.fast_mode)
-        result["value_blur_mode%d" % a2.blur_rounding] = round(rate(lambda: eng2.step(d_gray, 0, stream)), 2)
+        # canonical integer formula; the same pipeline, switched with ORBFE_OPT_BLUR_ROUNDING
+        other_mode = 1 - args.blur_rounding
+        for e in eng.exts:
+            e.set_option("blur_rounding", other_mode)
+        eng.pl.blur_rounding = other_mode
+        eng.pl.reset_sequence()
+        result["value_blur_mode%d" % other_mode] = round(rate(step), 2)
         if not args.no_cpu_baseline:
-            result["blur_mode%d_exact_checked" % a2.blur_rounding] = self_check(eng2, d_gray, 0, nf, blur_mode=a2.blur_rounding,
-                                                                                nrandom=2)["exact_checked"]
-        eng2.pl.close()
-        del eng2
-        torch.cuda.empty_cache()
-        eng.outs = outs_saved
+            result["blur_mode%d_exact_checked" % other_mode] = self_check(eng, d_gray, 0, nf, blur_mode=other_mode, nrandom=2)["exact_checked"]
+        for e in eng.exts:
+            e.set_option("blur_rounding", args.blur_rounding)
+        eng.pl.blur_rounding = args.blur_rounding
+        eng.pl.reset_sequence()
         # camera-like frames: the same step on S_tum(seed) (256 distinct seeds, expanded like the main batch)
         other = "S_tum" if args.workload == "S" else "S"
         d_other = expand_frames(torch.from_numpy(base_frames(other, min(B, 256), w, h, 10000)).cuda(), B)

@@ -170,7 +170,8 @@ enum {
     ORBFE_OPT_PYR_FUSE = 12,      /* [dev] 1: two pyramid levels per launch */
     ORBFE_OPT_FUSE_BLUR_PYR = 13, /* [dev] 1 / 2: blur + resize in one chained pass */
     ORBFE_OPT_FUSE_FAST_PYR = 14, /* [dev] 1 / 2: FAST + resize in one launch per level, 3: FAST of level 0 beside the pyramid */
-    ORBFE_OPT_FUSE_FAST_PYR_LEVELS = 15
+    ORBFE_OPT_FUSE_FAST_PYR_LEVELS = 15,
+    ORBFE_OPT_BLUR_ROUNDING = 16  /* orbfe_params.blur_rounding of an existing handle (0 / 1); this one changes RESULTS */
 };
 orbfe_status orbfe_set_option(orbfe_handle *h, int32_t option, int32_t value);
 /* the handle's own non-blocking stream (hipStream_t as void*): the host-buffer entry points run on it */

@@ -48,7 +48,7 @@ SYMBOLS = (
 
 # orbfe_set_option (include/orbfe.h ORBFE_OPT_*)
 OPTIONS = dict(overlap=1, rows=2, rows_fast=3, rows_blur=4, blur_pieces=5, blur_updown=6, pyr_rows=7, qt_threads_0=8, qt_threads_1=9,
-               qt_threads_2=10, debug=11, pyr_fuse=12, fuse_blur_pyr=13, fuse_fast_pyr=14, fuse_fast_pyr_levels=15)
+               qt_threads_2=10, debug=11, pyr_fuse=12, fuse_blur_pyr=13, fuse_fast_pyr=14, fuse_fast_pyr_levels=15, blur_rounding=16)
 PIPE_CONTINUE, PIPE_NO_JOIN = 1, 2
 
 

@@ -1110,6 +1110,7 @@ extern "C" orbfe_status orbfe_set_option(orbfe_handle *h, int32_t option, int32_
         if (!in(1, ORBFE_MAX_LEVELS)) return ORBFE_ERR_ARG;
         h->fuse_fast_pyr_levels = value;
         break;
+    case ORBFE_OPT_BLUR_ROUNDING: if (!in(0, 1)) return ORBFE_ERR_ARG; h->prm.blur_rounding = value; replan = true; break;
     default: orbfe_set_error("unknown option %d", option); return ORBFE_ERR_ARG;
     }
     if (replan) h->plan_valid = false;   // rebuilt (behind the handle's outstanding work) by the next call

@@ -195,3 +195,26 @@ def test_natural_halves_over_a_sequence_both_modes(oracle):
         for l in range(8):
             ndiff += int((res[0][i][l] != res[1][i][l]).sum())
     assert nties > 0 and 0 < ndiff <= nties, (nties, ndiff)
+
+
+def test_blur_rounding_switched_on_an_existing_handle(oracle):
+    """ORBFE_OPT_BLUR_ROUNDING: the rounding mode of an existing handle (the plan is rebuilt behind the outstanding work);
+    a handle switched 0 -> 1 -> 0 gives what fresh handles of those modes give, on a frame with constructed exact halves
+    (where the two modes differ) -- blurred levels, keypoints and descriptors."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    img = frame_with_halves(91, 640, 480)[0]
+    e = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=2)
+    outs = {}
+    for mode in (0, 1, 0):
+        e.set_option("blur_rounding", mode)
+        gk, gd = e(img)
+        oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+        oe.set_blur_mode(mode)
+        ok, od = oe(img)
+        assert _same(gk, gd, ok, od), mode
+        for l in range(8):
+            if len(oe.selected(l)):
+                assert np.array_equal(e.blurred_level(l), oe.blurred(l)), (mode, l)
+        outs.setdefault(mode, []).append(e.blurred_level(0))
+    assert not np.array_equal(outs[0][0], outs[1][0])          # the constructed halves make the modes differ
+    assert np.array_equal(outs[0][0], outs[0][1])
