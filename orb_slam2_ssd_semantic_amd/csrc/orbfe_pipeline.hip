@@ -453,6 +453,17 @@ extern "C" orbfe_status orbfe_pipeline_extract_match(orbfe_pipeline *pl, const u
     const int F = pl->F, pc = pl->cap;
     const size_t fbytes = (size_t)w * ht;
     const int nchunks = (nframes + F - 1) / F;
+    // Whatever way the loop is left, copies that read the caller's frames or write its arrays may be in flight: every exit
+    // drains the copy streams and the pipes first.
+    struct Drain {
+        orbfe_pipeline *pl;
+        ~Drain()
+        {
+            if (pl->s_in) (void)hipStreamSynchronize(pl->s_in);
+            for (hipStream_t st : pl->st) (void)hipStreamSynchronize(st);
+            if (pl->s_out) (void)hipStreamSynchronize(pl->s_out);
+        }
+    } drain{pl};
     for (int c = 0; c < nchunks; ++c) {
         const int k = c % orbfe_pipeline::NSETS, lo = c * F, nf = std::min(F, nframes - lo);
         // set k is free once the results of chunk c - NSETS have left it
