@@ -148,7 +148,7 @@ struct orbfe_handle {
     bool plan_valid = false;
     std::vector<OrbCell> cells;
     std::vector<OrbTab> tabs;
-    DevBuf d_plan, d_tabs, d_flanes, d_blanes, d_blanesR;
+    DevBuf d_plan, d_tabs, d_flanes, d_flanes_c, d_blanes, d_blanesR;
     // per-batch blocks
     DevBuf d_pyr, d_blur, d_skeys, d_scount, d_knode, d_qtbox, d_qtnodes, d_sel, d_nsel, d_nkeys, d_pad;
     // sticky overflow word + FAST sparse-variant statistics: [0] int32 overflow bits, [2..7] 3 x uint64 counters
@@ -465,7 +465,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     // FAST lane list: per level, per (balanced) row block of <= ORBFE_ROWS_PER_WAVE rows, the 4-px columns x = 16, 20, ... < ix1 form a
     // strip; strips are packed back to back into single-level waves of 64 lanes.  Where a wave boundary falls inside a
     // strip, each side gets one halo lane (computes neighbour strengths, outputs nothing).
-    std::vector<OrbLane> flanes;
+    std::vector<OrbLane> flanes, clanes;
     {
         std::vector<OrbLane> stream;
         for (int l = 0; l < nl; ++l) {
@@ -520,8 +520,47 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
                 flanes.push_back(d);
             }
         }
+    // Lane list of the lane-compacting form (k_fast_map_c): the same strips, but EVERY piece of a strip inside a wave is closed by a halo
+    // lane on both sides (the 4-px column before / behind it, flag bit 0) -- its lanes take their left / right neighbour pixels from
+    // the neighbouring lanes, not from memory.  At the image's side borders the halo is the column outside the detectable interior
+    // (x = 12 / the column behind the last one: real pixels, nothing inside, nothing output).
+    {
+        size_t i = 0;
+        while (i < stream.size()) {
+            const int lvl = stream[i].flags >> 8;
+            const size_t w0 = clanes.size();
+            while (i < stream.size() && (stream[i].flags >> 8) == lvl && 64 - (clanes.size() - w0) >= 3) {
+                OrbLane hl = stream[i];
+                hl.x = (uint16_t)(hl.x - 4);
+                hl.flags |= 1;
+                clanes.push_back(hl);
+                size_t room = 64 - (clanes.size() - w0) - 1;   // the right halo takes the last slot
+                OrbLane last = stream[i];
+                while (room > 0) {
+                    last = stream[i];
+                    clanes.push_back(last);
+                    ++i;
+                    --room;
+                    if (!(i < stream.size() && same_strip(last, stream[i]))) break;
+                }
+                OrbLane hr = last;
+                hr.x = (uint16_t)(hr.x + 4);
+                hr.flags |= 1;
+                clanes.push_back(hr);
+            }
+            while (clanes.size() - w0 < 64) {  // dead lanes
+                OrbLane d;
+                d.x = 16;
+                d.ys = ORBFE_EDGE;
+                d.nrows = 0;
+                d.flags = (uint16_t)((lvl << 8) | 1);
+                clanes.push_back(d);
+            }
+        }
+    }
     }
     P.nfwaves = (int)(flanes.size() / 64);
+    P.nfwaves_c = (int)(clanes.size() / 64);
     P.fwave_off[nl] = P.nfwaves;
     for (int l = ORBFE_MAX_LEVELS; l > nl; --l) P.fwave_off[l] = P.nfwaves;
     for (int l = nl - 1; l >= 0; --l)
@@ -714,6 +753,7 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(h->d_plan.ensure(sizeof(OrbPlan)));
     ORBFE_HIP(h->d_tabs.ensure(tabs.size() * sizeof(OrbTab)));
     ORBFE_HIP(h->d_flanes.ensure(std::max<size_t>(flanes.size(), 1) * sizeof(OrbLane)));
+    ORBFE_HIP(h->d_flanes_c.ensure(std::max<size_t>(clanes.size(), 1) * sizeof(OrbLane)));
     ORBFE_HIP(h->d_blanes.ensure(std::max<size_t>(blanes.size(), 1) * sizeof(OrbLane)));
     ORBFE_HIP(h->d_blanesR.ensure(std::max<size_t>(blanesR.size(), 1) * sizeof(OrbLaneR)));
     // synchronous copies: plans change rarely (frame size change), never inside the timed region.  Earlier batches may
@@ -725,6 +765,8 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     ORBFE_HIP(hipMemcpy(h->d_tabs.p, tabs.data(), tabs.size() * sizeof(OrbTab), hipMemcpyHostToDevice));
     if (!flanes.empty())
         ORBFE_HIP(hipMemcpy(h->d_flanes.p, flanes.data(), flanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
+    if (!clanes.empty())
+        ORBFE_HIP(hipMemcpy(h->d_flanes_c.p, clanes.data(), clanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     if (!blanes.empty())
         ORBFE_HIP(hipMemcpy(h->d_blanes.p, blanes.data(), blanes.size() * sizeof(OrbLane), hipMemcpyHostToDevice));
     if (!blanesR.empty())
@@ -931,7 +973,7 @@ extern "C" void orbfe_destroy(orbfe_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->s_in) (void)hipStreamSynchronize(h->s_in);
     if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_blanes, &h->d_blanesR, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_qtbox, &h->d_qtnodes, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_pad,
+    DevBuf *bufs[] = {&h->d_plan, &h->d_tabs, &h->d_flanes, &h->d_flanes_c, &h->d_blanes, &h->d_blanesR, &h->d_pyr, &h->d_blur, &h->d_skeys, &h->d_scount, &h->d_knode, &h->d_qtbox, &h->d_qtnodes, &h->d_sel, &h->d_nsel, &h->d_nkeys, &h->d_pad,
                       &h->d_stage[0], &h->d_okps[0], &h->d_odesc[0], &h->d_on[0], &h->d_stage[1], &h->d_okps[1], &h->d_odesc[1], &h->d_on[1]};
     for (DevBuf *b : bufs) b->release();
     h->d_misc.release();
@@ -1167,6 +1209,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.d_plan = (const OrbPlan *)h->d_plan.p;
     a.d_tabs = (const OrbTab *)h->d_tabs.p;
     a.d_flanes = (const OrbLane *)h->d_flanes.p;
+    a.d_flanes_c = (const OrbLane *)h->d_flanes_c.p;
     a.d_blanes = (const OrbLane *)h->d_blanes.p;
     a.d_blanesR = (const OrbLaneR *)h->d_blanesR.p;
     a.nframes = nframes;
@@ -1272,6 +1315,7 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     if ((ffp || fside) && ov == 1) ov = 2;   // the blur needs the whole pyramid, which the fused chain finishes last
 #else
     const bool ffp = false, fside = false;
+    (void)fside;
 #endif
     if (!ffp) ORBFE_HIP(orbk_launch_pyramid(a, st));
     if (ev) ORBFE_HIP(hipEventRecord(ev[1], st));

@@ -16,6 +16,7 @@ struct OrbLaunch {
     const OrbPlan *d_plan;  // device copy
     const OrbTab *d_tabs;
     const OrbLane *d_flanes;
+    const OrbLane *d_flanes_c;   // lane list of k_fast_map_c
     const OrbLane *d_blanes;
     const OrbLaneR *d_blanesR;   // the resize job of every blur lane (fused blur + pyramid pass)
     int32_t nframes;

@@ -489,32 +489,8 @@ __device__ __forceinline__ uint32_t fast_compass_pair(const uint32_t (&rm3)[FM_N
     return pk_subsat_u16(pk_max_u16(pk_subsat_u16(mb, v), pk_subsat_u16(v, md)), t);
 }
 
-// The lane-compacting form (orbfe_fast_body_c.inc) splits fast_strength_pair in two: the 16 circle pixel pairs + centre of the
-// pair (J, J+1) as values (gather), and the network on values (strength_from) -- the same operations in the same order.
-template <int J>
-__device__ __forceinline__ void fast_gather_pair(const uint32_t (&rm3)[FM_NE], const uint32_t (&rm2)[FM_NE],
-                                                 const uint32_t (&rm1)[FM_NE], const uint32_t (&r0)[FM_NE],
-                                                 const uint32_t (&rp1)[FM_NE], const uint32_t (&rp2)[FM_NE],
-                                                 const uint32_t (&rp3)[FM_NE], uint32_t (&c)[16], uint32_t &v)
-{
-    c[0] = rp3[3 + J];
-    c[1] = rp3[4 + J];
-    c[2] = rp2[5 + J];
-    c[3] = rp1[6 + J];
-    c[4] = r0[6 + J];
-    c[5] = rm1[6 + J];
-    c[6] = rm2[5 + J];
-    c[7] = rm3[4 + J];
-    c[8] = rm3[3 + J];
-    c[9] = rm3[2 + J];
-    c[10] = rm2[1 + J];
-    c[11] = rm1[0 + J];
-    c[12] = r0[0 + J];
-    c[13] = rp1[0 + J];
-    c[14] = rp2[1 + J];
-    c[15] = rp3[2 + J];
-    v = r0[3 + J];
-}
+// the network of fast_strength_pair on values -- the same operations in the same order (the lane-compacting form,
+// orbfe_fast_body_c.inc, gathers the 16 circle pixel pairs + centre of an item from its LDS pixel ring)
 __device__ __forceinline__ uint32_t fast_strength_from(const uint32_t (&c)[16], uint32_t v, uint32_t t)
 {
     uint32_t P[8], Q[8], ex[8], en[8];
@@ -614,20 +590,33 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
 #include "orbfe_fast_body.inc"
 }
 
-// The lane-compacting form of the same pass (orbfe_fast_body_c.inc): per wave a queue of FC_QCAP parked pixel pairs (18 dwords each,
-// odd stride: conflict-free), four strength rows in flight, a smaller survivor staging buffer -- 13 KB per wave, three
-// workgroups per CU as for the dense form (whose 157 registers allow three waves per SIMD).
-#define FC_QCAP 128      // items (power of two); a push of <= 64 always finds room once the fill is <= FC_QCAP - 64
-#define FC_ISTRIDE 19    // dwords per item: c[0..15], v, tag; odd = bank-conflict-free for consecutive items
+// The lane-compacting form of the same pass (orbfe_fast_body_c.inc): per wave a ring of the pixel rows its lanes fetched (one dword
+// per lane and row, 2 x FC_PN slots of FC_PW dwords), a queue of FC_QCAP one-dword tags of parked pixel pairs, four strength rows
+// in flight and the survivor staging buffer -- 10 KB per wave, four workgroups per CU.
+#define FC_QCAP 256      // tags (power of two); a push of <= 64 always finds room once the fill is <= FC_QCAP - 64
 #define FC_LAG 3         // rows the suppression runs behind the front: an item never waits longer
+#define FC_PN 10         // rows the pixel ring holds: the 7 of an item + FC_LAG
+#define FC_PW 66         // dwords per ring slot: the 64 lanes + a pad on both sides
 #define FC_BUF 192       // survivor staging (FM_ROW_MAX = 140 per row at most)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_fast_map_c(const OrbPlan *__restrict__ plan, FrameSrc fs,
+#ifndef FC_OCC
+#define FC_OCC
+#endif
+static_assert(FC_PN >= 7 + FC_LAG, "pixel ring: the first row of an item parked at step s is overwritten at step s - 6 + FC_PN");
+// fast_compass_pair on values: the four compass pixel pairs and the centre pair of one pixel pair
+__device__ __forceinline__ uint32_t fast_compass_from(uint32_t c0, uint32_t c8, uint32_t c4, uint32_t c12, uint32_t v, uint32_t t)
+{
+    const uint32_t mb = pk_min_u16(pk_max_u16(c0, c8), pk_max_u16(c4, c12));
+    const uint32_t md = pk_max_u16(pk_min_u16(c0, c8), pk_min_u16(c4, c12));
+    return pk_subsat_u16(pk_max_u16(pk_subsat_u16(mb, v), pk_subsat_u16(v, md)), t);
+}
+__global__ __launch_bounds__(256) FC_OCC void k_fast_map_c(const OrbPlan *__restrict__ plan, FrameSrc fs,
                                                     const OrbLane *__restrict__ lanes, int nwaves,
                                                     uint2 *__restrict__ skeys, int32_t *__restrict__ scount,
                                                     uint32_t *__restrict__ cflags, int32_t cf_words,
                                                     unsigned long long *__restrict__ fstat)  // {row steps, batches, parked pairs} of sampled waves, or null
 {
-    __shared__ uint32_t s_q[4][FC_QCAP * FC_ISTRIDE];
+    __shared__ uint32_t s_pix[4][2 * FC_PN * FC_PW];
+    __shared__ uint32_t s_q[4][FC_QCAP];
     __shared__ uint32_t s_srow[4][4 * 64 * 2];
     __shared__ uint2 s_buf[4][FC_BUF];
     extern __shared__ uint32_t s_cf[];
@@ -2461,8 +2450,8 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
     if (e != hipSuccess) return e;
     dim3 grid((a.h_plan->nfwaves + 3) / 4, a.nframes);
     if (a.fast_sparse == 2)
-        hipLaunchKernelGGL(k_fast_map_c, grid, dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
-                           a.d_scount, a.d_cflag, a.cf_words, a.d_fstat);
+        hipLaunchKernelGGL(k_fast_map_c, dim3((a.h_plan->nfwaves_c + 3) / 4, a.nframes), dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs,
+                           a.d_flanes_c, a.h_plan->nfwaves_c, a.d_skeys, a.d_scount, a.d_cflag, a.cf_words, a.d_fstat);
     else if (a.fast_sparse)
         hipLaunchKernelGGL(k_fast_map<1>, grid, dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
                            a.d_scount, a.d_cflag, a.cf_words, a.d_fstat);
@@ -2472,6 +2461,7 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
     return hipGetLastError();
 }
 
+#ifdef ORBFE_DEVELOPER
 static hipError_t fast_clear(const OrbLaunch &a, hipStream_t st)
 {
     // the survivor counts and, right behind them, the cell flags of this call's frames: one clear
@@ -2482,7 +2472,6 @@ static hipError_t fast_clear(const OrbLaunch &a, hipStream_t st)
                                              sizeof(uint32_t) * (size_t)a.nframes * nl * a.cf_words, st);
 }
 
-#ifdef ORBFE_DEVELOPER
 // one k_fast_pyr launch: FAST waves [w0, w1) of the lane list + the resize to level lpyr (0: none)
 static void fast_pyr_one(const OrbLaunch &a, int w0, int w1, int lpyr, int spread, hipStream_t st)
 {

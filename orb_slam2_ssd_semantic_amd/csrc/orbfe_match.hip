@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void k_match_popc(const uint8_t *__restrict__ 
     const int tid = threadIdx.x;
     const int qi = blockIdx.x * 256 + tid;
     const int nslots = n_arr ? cap : nq;
-    if (blockIdx.x * 256 >= nslots) return;
+    if ((int)blockIdx.x * 256 >= nslots) return;
     uint32_t qw[8];
     {
         const uint4 *pq = (const uint4 *)(q + (int64_t)min(qi, max(nq - 1, 0)) * 32);
@@ -2729,7 +2729,7 @@ __global__ __launch_bounds__(256) void k_search_by_bow_rows(BowBatch a)
         // chunk 0 of the F list stays in registers
         Desc8 d0;
         uint32_t rf0 = 0;
-        bool ok0 = lane16 < nFb;
+        bool ok0 = lane16 < (int)nFb;
         if (ok0) {
             rf0 = idxF[f0 + lane16];
             if (validF && !validF[rf0]) ok0 = false;
