@@ -130,9 +130,10 @@ struct PinBuf {
 // stream); 6 / 7 around the blur (on whichever stream it ran)
 #define ORBFE_EV_N 8
 // auto FAST mode: above this share of pixel pairs passing the necessary test the dense form is the cheaper one.  Measured per
-// 1024 frames of 640x480 (tools/fast_floor.py, profiles/r05_fast_floor.json): pass rate 0.85 (S) dense 1.48 / compacting 2.15 ms;
-// 0.187 (S_tum) 1.33 / 1.38; 0.111 1.28 / 1.23; 0.083 1.26 / 1.19; 0.053 1.25 / 1.11; 0.021 1.21 / 1.00 -- break-even near 0.14
-#define ORBFE_AUTO_DENSE_RATE 0.14
+// 1024 frames of 640x480 (tools/compact_ab.py, profiles/r05_compact_ab.json; dense / lane-compacting, ms): pass rate 0.84 (S)
+// 1.47 / 2.14; 0.43 1.40 / 1.62; 0.38 1.42 / 1.55; 0.29 1.36 / 1.39; 0.18 (S_tum) 1.33 / 1.12; 0.076 1.26 / 0.92;
+// 0.02 1.22 / 0.74 -- break-even near 0.27
+#define ORBFE_AUTO_DENSE_RATE 0.25
 
 struct orbfe_handle {
     orbfe_params prm;

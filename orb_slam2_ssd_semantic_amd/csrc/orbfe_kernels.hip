@@ -592,12 +592,15 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
 
 // The lane-compacting form of the same pass (orbfe_fast_body_c.inc): per wave a ring of the pixel rows its lanes fetched (one dword
 // per lane and row, 2 x FC_PN slots of FC_PW dwords), a queue of FC_QCAP one-dword tags of parked pixel pairs, four strength rows
-// in flight and the survivor staging buffer -- 10 KB per wave, four workgroups per CU.
-#define FC_QCAP 256      // tags (power of two); a push of <= 64 always finds room once the fill is <= FC_QCAP - 64
+// in flight (a byte per pixel) and the survivor staging buffer -- 8 KB per wave; the 117 registers allow four waves per SIMD.
+#define FC_QCAP 128      // tags (power of two); a push of <= 64 always finds room once the fill is <= FC_QCAP - 64
+#ifndef FC_LAG
 #define FC_LAG 3         // rows the suppression runs behind the front: an item never waits longer
-#define FC_PN 10         // rows the pixel ring holds: the 7 of an item + FC_LAG
+#endif
+#define FC_PN (7 + FC_LAG)   // rows the pixel ring holds: the 7 of an item + FC_LAG
 #define FC_PW 66         // dwords per ring slot: the 64 lanes + a pad on both sides
-#define FC_BUF 192       // survivor staging (FM_ROW_MAX = 140 per row at most)
+#define FC_SEAMS 16      // lanes of a wave whose pixel pair straddles a cell seam (cells are >= 30 px wide: <= 9)
+#define FC_BUF (128 + FC_SEAMS)   // survivor staging: one row's worth; flushed when the next row might not fit
 #ifndef FC_OCC
 #define FC_OCC
 #endif
@@ -616,8 +619,13 @@ __global__ __launch_bounds__(256) FC_OCC void k_fast_map_c(const OrbPlan *__rest
                                                     unsigned long long *__restrict__ fstat)  // {row steps, batches, parked pairs} of sampled waves, or null
 {
     __shared__ uint32_t s_pix[4][2 * FC_PN * FC_PW];
+#ifdef FC_EXTRA_LDS   // occupancy probe: dead LDS that costs a workgroup slot per CU
+    __shared__ uint32_t s_fcpad[FC_EXTRA_LDS / 4];
+    if (nwaves < 0) s_fcpad[threadIdx.x] = 1u;
+    if (nwaves < -1) scount[0] = (int32_t)s_fcpad[threadIdx.x ^ 1];
+#endif
     __shared__ uint32_t s_q[4][FC_QCAP];
-    __shared__ uint32_t s_srow[4][4 * 64 * 2];
+    __shared__ uint32_t s_srow[4][4 * 64];
     __shared__ uint2 s_buf[4][FC_BUF];
     extern __shared__ uint32_t s_cf[];
     int b = blockIdx.y, bx = blockIdx.x;
