@@ -407,7 +407,8 @@ def main():
                     help="frames `value` is timed on: S(seed), S_tum(seed), or the TUM sequence at $TUM_FR3_WALKING_XYZ")
     ap.add_argument("--seeds", type=int, default=1024, help="distinct generator seeds in the resident batch (the rest of the "
                     "batch are roll / flip transforms of them)")
-    ap.add_argument("--fast-mode", type=int, default=0, help="FAST variant of the timed region (0 dense, 1 sparse shortcuts, 2 lane-compacting, 3 auto)")
+    ap.add_argument("--fast-mode", type=int, default=3, help="FAST variant of the timed region (3 auto = the library's default: dense or "
+                    "lane-compacting per launch by the pass rate the kernel reports; 0 dense, 1 sparse shortcuts, 2 lane-compacting)")
     ap.add_argument("--no-match", action="store_true", help="extract only (BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines and the latency probe")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (rocprof runs): no PCIe leg, no "
@@ -483,6 +484,7 @@ def main():
     eng = Engine(args, local_rank, nf, F, NL, world)
     if not fake:
         eng.pl.set_fast_mode(args.fast_mode)
+        eng.fast_mode = args.fast_mode
     # the resident batch: `--seeds` DISTINCT generator seeds (default 1024 = one whole sub-batch of different images), expanded to
     # the B frames of a step by lossless roll / flip transforms of that set (every frame a different image)
     nbase = min(B, args.seeds)
@@ -549,6 +551,9 @@ def main():
                                     ", asynchronous all-gather of counts/keypoints/descriptors per step" if world > 1 else ""),
                        "frames_per_gpu_per_step": B, "frames_per_launch": F, "width": w, "height": h, "nfeatures": nf,
                        "workload_name": args.workload, "pipes": getattr(eng, "P", 1), "blur_rounding": args.blur_rounding,
+                       "fast_mode": {0: "dense", 1: "dense + wave-uniform shortcuts", 2: "lane-compacting",
+                                     3: "auto (library default): lane-compacting or dense per launch from the pass rate the kernel reports; "
+                                        "dense on these frames after the first probe (value_fast_dense: the same step pinned to dense)"}[args.fast_mode],
                        "value_is": "value_hbm_resident (bench contract: inputs resident in HBM when the timed region starts); SURVEY "
                                    "8(d) row 3 as worded -- host frames in, host results out -- is value_pcie_inclusive",
                        "match_kernel": None if args.no_match else "mfma_i8 (k_match_bf: exact int8 dot product on the matrix cores; "
@@ -762,6 +767,11 @@ def exclusive_stage_pass(eng, d_gray, stream, local_rank):
     stage, averaged over the step's sub-batches; then the matcher alone on the same stream.  ms per sub-batch of F frames."""
     ext = eng.ext
     ext.set_option("overlap", 0)
+    form = getattr(eng, "fast_mode", 0)
+    if form == 3:   # auto: the table is taken in the form the mode has settled on for these frames (no probe call inside it)
+        ps = ext.fast_stats()
+        form = 0 if ps["parked_pairs"] > 0.25 * 128.0 * max(ps["row_steps"], 1) else 2
+        ext.set_fast_mode(form)
     eng.one_pipe_pass(d_gray, stream)       # warm-up in this mode
     torch.cuda.synchronize()
     ext.set_profiling(True)
@@ -770,6 +780,9 @@ def exclusive_stage_pass(eng, d_gray, stream, local_rank):
     st = ext.stage_ms()
     ext.set_profiling(False)
     ext.set_option("overlap", -1)
+    if getattr(eng, "fast_mode", 0) == 3:
+        ext.set_fast_mode(3)
+    st["fast_form"] = {0: "dense", 1: "dense + shortcuts", 2: "lane-compacting"}[form]
     match_ms = 0.0
     if eng.match:
         kps, desc, n = eng.outs[0]
@@ -817,6 +830,7 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
         for k in ("pyramid", "fast", "octree", "blur", "describe"):
             result[f"stage_ms_exclusive_{k}"] = round(stage[k], 4)
         result["stage_ms_exclusive_match"] = round(stage["match"], 4)
+        result["stage_table_fast_form"] = stage.get("fast_form")
         result["stage_ms_exclusive_sum"] = round(sum(stage[k] for k in ("pyramid", "fast", "octree", "blur", "describe", "match")), 4)
         result["stage_ms_per_sub_batch_in_timed_region"] = round(result["ms_per_step"] / NL, 4)
         vc = roof.get("valu_ceiling") or {}
@@ -874,9 +888,14 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
         # camera-like frames: the same step on S_tum(seed) (256 distinct seeds, expanded like the main batch)
         other = "S_tum" if args.workload == "S" else "S"
         d_other = expand_frames(torch.from_numpy(base_frames(other, min(B, 256), w, h, 10000)).cuda(), B)
+        eng.pl.set_fast_mode(args.fast_mode)   # another workload: the auto mode starts over (its dense runs last up to 256 calls)
         result["value_%s" % other.lower()] = round(rate(lambda: eng.step(d_other, 0, stream)), 2)
-        eng.pl.set_fast_mode(3)   # auto: lane-compacting FAST where few pixel pairs pass the necessary test, else dense
-        result["value_%s_fast_auto" % other.lower()] = round(rate(lambda: eng.step(d_other, 0, stream)), 2)
+        # the same two workloads with the FAST form pinned to dense (what rounds 1-4 shipped): the library's default, auto, picks
+        # the lane-compacting kernel where few pixel pairs pass the necessary test (S_tum: 18 %) and dense elsewhere (S: 84 %)
+        eng.pl.set_fast_mode(0)
+        result["value_%s_fast_dense" % other.lower()] = round(rate(lambda: eng.step(d_other, 0, stream)), 2)
+        eng.pl.reset_sequence()
+        result["value_fast_dense"] = round(rate(step), 2)
         eng.pl.set_fast_mode(args.fast_mode)
         result["workloads"] = workload_legs(args, eng, d_gray[:F], d_other[:F], local_rank)
         del d_other

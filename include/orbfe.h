@@ -133,16 +133,18 @@ orbfe_status orbfe_extract_batch_device(orbfe_handle *h, const uint8_t *d_gray, 
  * bit 2 = a frame produced more keypoints than `cap` (d_n_out holds the required count). */
 orbfe_status orbfe_get_overflow(orbfe_handle *h, int32_t *flags);
 /* FAST kernel variant.  Results are identical in every mode.
- *   0  dense (default): the 16 nine-arcs of every pixel
+ *   0  dense: the 16 nine-arcs of every pixel
  *   1  dense with wave-uniform shortcuts (skips the arc evaluation of 256-pixel row pieces that fail a 4-point necessary
  *      test, and the suppression of rows without strength)
- *   2  lane-compacting: every pixel pair takes the 4-point necessary test; the pairs that pass are gathered, 64 at a time,
- *      from all over the wave's strip and evaluated one per lane -- cheaper than dense when few pairs pass (measured break-even
- *      near 14 %: low-texture / low-contrast frames; -18 % at 2 %), dearer when more do (+4 % at the 19 % of the camera-like
- *      synthetic frames S_tum, +45 % at the 85 % of the corner-saturated frames S)
- *   3  auto: 2, and 0 for the next 64 calls whenever the compacting kernel reported more than 14 % passing pairs
+ *   2  lane-compacting: every pixel pair takes the 4-point necessary test; the pairs that pass leave a tag in a queue and are
+ *      evaluated, 64 at a time, one per lane, from a ring of the pixel rows the wave holds in LDS -- cheaper than dense when few
+ *      pairs pass (FAST stage of 1024 frames of 640x480: -16 % at the 18 % of the camera-like synthetic frames S_tum, -28 % at
+ *      8 %, -40 % at 2 %; break-even near 27 %), dearer when more do (+45 % at the 84 % of the corner-saturated frames S), and
+ *      dearer for calls that do not fill the GPU (its waves are longer: +15 % on one frame)
+ *   3  auto (the default): 0 for calls of fewer than 32 frames; otherwise 2, and 0 for the next 16 calls (doubling up to 256 while
+ *      it keeps happening) whenever the compacting kernel reported more than 25 % passing pairs
  * collect_stats != 0 counts {row steps, arc skips, NMS skips} (mode 1) / {row steps, batches, parked pairs} of a sample of the
- * waves (mode 2); in mode 3 orbfe_get_fast_stats returns the counters of the last probe that completed. */
+ * waves (mode 2); in mode 3 orbfe_get_fast_stats returns the counters of the last probe that completed (zeros before one has). */
 orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32_t collect_stats);
 orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[3], int32_t reset);
 /* work model of the FAST kernel for the current frame size: out[0] = wave row steps per frame (one step = 64 lanes x 4

@@ -134,6 +134,13 @@ struct PinBuf {
 // 1.47 / 2.14; 0.43 1.40 / 1.62; 0.38 1.42 / 1.55; 0.29 1.36 / 1.39; 0.18 (S_tum) 1.33 / 1.12; 0.076 1.26 / 0.92;
 // 0.02 1.22 / 0.74 -- break-even near 0.27
 #define ORBFE_AUTO_DENSE_RATE 0.25
+// ... and below this many frames per call dense is the form with the shorter wave: a launch that does not fill the GPU is bound by
+// its longest wave, not by issue slots (FAST stage of ONE frame: 18 us dense / 21 us compacting on S_tum, 20 / 26 on S; 8 frames:
+// 29 / 34 and 31 / 44 -- tools/fast_mode_latency.py)
+#define ORBFE_AUTO_MIN_FRAMES 32
+#define ORBFE_AUTO_HOLD_MIN 16    // dense calls after a probe above the rate; doubles with every such probe in a row ...
+#define ORBFE_AUTO_HOLD_MAX 256   // ... up to this (a probe call on corner-saturated frames costs +45 % of its FAST stage)
+#define ORBFE_AUTO_PROBE_EVERY 8  // compacting calls between two looks at the pass rate
 
 struct orbfe_handle {
     orbfe_params prm;
@@ -154,7 +161,7 @@ struct orbfe_handle {
     DevBuf d_pyr, d_blur, d_skeys, d_scount, d_knode, d_qtbox, d_qtnodes, d_sel, d_nsel, d_nkeys, d_pad;
     // sticky overflow word + FAST sparse-variant statistics: [0] int32 overflow bits, [2..7] 3 x uint64 counters
     DevBuf d_misc;
-    int fast_mode = 0;            // 0 dense, 1 sparse shortcuts, 2 lane-compacting, 3 auto: 2 or 0 by the observed pass rate (orbfe_set_fast_mode)
+    int fast_mode = 3;            // 0 dense, 1 sparse shortcuts, 2 lane-compacting, 3 auto (default): 2 or 0 by batch size and observed pass rate (orbfe_set_fast_mode)
     bool fast_stats = false;
     // auto mode: the lane-compacting kernel reports {row steps, batches, parked pairs} of a sample of its waves; the counters are
     // copied to pinned host memory behind the kernel and looked at -- without waiting -- by a later call
@@ -162,6 +169,9 @@ struct orbfe_handle {
     hipEvent_t ev_auto = nullptr;
     bool auto_pending = false;
     int auto_dense_left = 0;      // calls still to run dense before the pass rate is probed again
+    int auto_hold = ORBFE_AUTO_HOLD_MIN;   // length of the next dense run
+    int auto_since = 0;           // compacting calls since the last probe
+    int auto_form = 2;            // the form the last probe chose (before the first answer: compacting, the probe's own form)
     uint64_t auto_last[3] = {0, 0, 0};
     int64_t fast_row_steps = 0;
     // The most recent batched call: its stream (only compared, never dereferenced: the caller may have destroyed it) and an
@@ -1166,6 +1176,9 @@ extern "C" orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32
     h->fast_mode = mode;
     h->fast_stats = collect_stats != 0;
     h->auto_dense_left = 0;
+    h->auto_hold = ORBFE_AUTO_HOLD_MIN;
+    h->auto_since = 0;
+    h->auto_form = 2;
     return ORBFE_OK;
 }
 
@@ -1237,26 +1250,53 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.cap = cap;
     a.d_n_out = d_n_out;
     a.d_ovf = (int32_t *)h->d_misc.p;
-    // FAST form of this call.  Auto (3): lane-compacting unless the last probe found more than ORBFE_AUTO_DENSE_RATE of the
-    // pixel pairs passing the necessary test -- then dense for the next 64 calls, after which one compacting call probes again.
+    // FAST form of this call.  Auto (3, the default): dense for calls of fewer than ORBFE_AUTO_MIN_FRAMES frames; otherwise
+    // lane-compacting unless the last probe found more than ORBFE_AUTO_DENSE_RATE of the pixel pairs passing the necessary test --
+    // then dense for the next auto_hold calls (16, doubling up to 256 while the probes keep saying so), after which one compacting
+    // call probes again.
     int fmode = h->fast_mode;
     bool auto_probe = false;
-    if (fmode == 3) {
+    if (fmode == 3 && nframes < ORBFE_AUTO_MIN_FRAMES) {
+        fmode = 0;
+    } else if (fmode == 3) {
         if (h->auto_pending && hipEventQuery(h->ev_auto) == hipSuccess) {   // never waits
             memcpy(h->auto_last, h->h_auto.p, sizeof(h->auto_last));
             h->auto_pending = false;
-            if (h->auto_last[0] > 0 && (double)h->auto_last[2] > ORBFE_AUTO_DENSE_RATE * 128.0 * (double)h->auto_last[0]) h->auto_dense_left = 64;
+            if (h->auto_last[0] > 0 && (double)h->auto_last[2] > ORBFE_AUTO_DENSE_RATE * 128.0 * (double)h->auto_last[0]) {
+                h->auto_form = 0;
+                h->auto_dense_left = h->auto_hold;
+                h->auto_hold = std::min(2 * h->auto_hold, ORBFE_AUTO_HOLD_MAX);
+            } else {
+                h->auto_form = 2;
+                h->auto_hold = ORBFE_AUTO_HOLD_MIN;
+                h->auto_since = 1;
+            }
         } else {
             (void)hipGetLastError();   // hipErrorNotReady is not an error of ours
         }
-        if (h->auto_dense_left > 0) {
-            h->auto_dense_left--;
-            fmode = 0;
+        // A host that runs ahead of the GPU enqueues many calls before a probe's answer arrives: those follow the LAST answer
+        // (auto_form), only the probe call itself is compacting when that answer was "dense".
+        if (h->auto_form == 0) {
+            if (h->auto_dense_left > 0) {
+                h->auto_dense_left--;
+                fmode = 0;
+            } else if (!h->auto_pending) {
+                fmode = 2;
+                auto_probe = true;
+            } else {
+                fmode = 0;
+            }
         } else {
             fmode = 2;
-            auto_probe = !h->auto_pending;
+            auto_probe = !h->auto_pending && (h->auto_since++ % ORBFE_AUTO_PROBE_EVERY) == 0;
         }
     }
+#ifdef ORBFE_DEVELOPER
+    if (h->fuse_fast_pyr && fmode >= 2) {   // the fused FAST + pyramid kernels exist in the dense forms only
+        fmode = 0;
+        auto_probe = false;
+    }
+#endif
     a.fast_sparse = fmode;
     a.d_fstat = (h->fast_stats || auto_probe) ? (unsigned long long *)((char *)h->d_misc.p + 16) : nullptr;
     // every call of a handle uses the same scratch blocks (pyramid, blur, survivor lists, selections): a call on another

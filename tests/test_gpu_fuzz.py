@@ -185,6 +185,32 @@ def test_fuzz_device_api(oracle):
     assert ran >= 0.6 * _n(30)
 
 
+@pytest.mark.gpu
+def test_auto_fast_mode_is_the_default_small_batches_stay_dense(oracle):
+    """orbfe_set_fast_mode 3 is what a fresh handle runs: calls of fewer than 32 frames take the dense form (no probe: the counters
+    stay zero); a larger batch of camera-like frames runs the lane-compacting form and leaves the pass rate of a sample of its
+    waves behind; results equal the oracle's either way."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    w, h = 640, 480
+    B = 40
+    frames = np.stack([synth_tum_like(900 + s, h, w) for s in range(B)])
+    oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)   # no set_fast_mode: the default
+    res, _ = _device_batch(e, frames[:8].reshape(-1), 8, w, h, w, w * h)
+    for i in (0, 7):
+        ok, od = oe(frames[i])
+        assert _same(res[i][0], res[i][1], ok, od)
+    assert e.fast_stats(reset=False)["row_steps"] == 0          # small call: dense, nothing probed
+    for _ in range(2):                                          # the first large call probes, the second reads the probe
+        res, _ = _device_batch(e, frames.reshape(-1), B, w, h, w, w * h)
+    for i in (0, 17, B - 1):
+        ok, od = oe(frames[i])
+        assert _same(res[i][0], res[i][1], ok, od)
+    st = e.fast_stats(reset=False)
+    assert st["row_steps"] > 0 and 0.05 < st["parked_pairs"] / (128.0 * st["row_steps"]) < 0.45, st
+    e.close()
+
+
 @pytest.mark.parametrize("gen,nframes", [("S", 200), ("S_tum", 96)])
 def test_sequence_batched_device_call(oracle, gen, nframes):
     """BASELINE config 2 on the synthetic stand-in for the TUM sequence: N frames through ONE batched device call, every
