@@ -592,19 +592,19 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
 
 // The lane-compacting form of the same pass (orbfe_fast_body_c.inc): per wave a ring of the pixel rows its lanes fetched (one dword
 // per lane and row, 2 x FC_PN slots of FC_PW dwords), a queue of FC_QCAP one-dword tags of parked pixel pairs, four strength rows
-// in flight (a byte per pixel) and the survivor staging buffer -- 8 KB per wave; the 117 registers allow four waves per SIMD.
+// in flight (a byte per pixel) and the survivor staging buffer -- 7.4 KB per wave and 96 registers: five waves per SIMD.
 #define FC_QCAP 128      // tags (power of two); a push of <= 64 always finds room once the fill is <= FC_QCAP - 64
 #ifndef FC_LAG
 #define FC_LAG 3         // rows the suppression runs behind the front: an item never waits longer
 #endif
-#define FC_PN (7 + FC_LAG)   // rows the pixel ring holds: the 7 of an item + FC_LAG
+#define FC_PN (6 + FC_LAG)   // rows the pixel ring holds: what step s parked is evaluated before the row of step s + FC_LAG is written
 #define FC_PW 66         // dwords per ring slot: the 64 lanes + a pad on both sides
 #define FC_SEAMS 16      // lanes of a wave whose pixel pair straddles a cell seam (cells are >= 30 px wide: <= 9)
 #define FC_BUF (128 + FC_SEAMS)   // survivor staging: one row's worth; flushed when the next row might not fit
 #ifndef FC_OCC
 #define FC_OCC
 #endif
-static_assert(FC_PN >= 7 + FC_LAG, "pixel ring: the first row of an item parked at step s is overwritten at step s - 6 + FC_PN");
+static_assert(FC_PN >= 6 + FC_LAG && FC_PN >= 7, "pixel ring: the first row of an item parked at step s is overwritten at step s - 6 + FC_PN");
 // fast_compass_pair on values: the four compass pixel pairs and the centre pair of one pixel pair
 __device__ __forceinline__ uint32_t fast_compass_from(uint32_t c0, uint32_t c8, uint32_t c4, uint32_t c12, uint32_t v, uint32_t t)
 {
