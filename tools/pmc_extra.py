@@ -1,7 +1,7 @@
 """Supplementary counters of the bench command, one rocprofv3 --kernel-trace --pmc pass per counter group (never together
 with another trace domain): LDS bank conflicts, LDS wait, memory-unit stall, occupancy, L2 hit rate -- the evidence behind
 "LDS-latency bound" (quadtree) and "line-traffic bound" (describe) in DESIGN.md.
-usage (GPU box):  python tools/pmc_extra.py <tag>      ->  gpurun_out/<tag>_pmc_extra.json"""
+usage (GPU box):  python tools/pmc_extra.py <tag> [more bench args]     ->  gpurun_out/<tag>_pmc_extra.json"""
 import collections
 import csv
 import glob
@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1]
-bench_args = ["--no-extras", "--launches", "2", "--steps", "4", "--warmup", "2"]
+bench_args = ["--no-extras", "--launches", "2", "--steps", "4", "--warmup", "2"] + sys.argv[2:]   # e.g. --workload S_tum --seeds 32
 cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
 env = dict(os.environ, TMPDIR="/tmp")
 GROUPS = [["LDSBankConflict"], ["MemUnitStalled"], ["OccupancyPercent"], ["SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES"],
