@@ -141,7 +141,7 @@ orbfe_status orbfe_get_overflow(orbfe_handle *h, int32_t *flags);
  *      pairs pass (FAST stage of 1024 frames of 640x480: -16 % at the 18 % of the camera-like synthetic frames S_tum, -28 % at
  *      8 %, -40 % at 2 %; break-even near 27 %), dearer when more do (+45 % at the 84 % of the corner-saturated frames S), and
  *      dearer for calls that do not fill the GPU (its waves are longer: +15 % on one frame)
- *   3  auto (the default): 0 for calls of fewer than 32 frames; otherwise 2, and 0 for the next 16 calls (doubling up to 256 while
+ *   3  auto (the default): 0 for calls that do not fill the GPU (less work than about 29 frames of 640x480); otherwise 2, and 0 for the next 16 calls (doubling up to 256 while
  *      it keeps happening) whenever the compacting kernel reported more than 25 % passing pairs
  * collect_stats != 0 counts {row steps, arc skips, NMS skips} (mode 1) / {row steps, batches, parked pairs} of a sample of the
  * waves (mode 2); in mode 3 orbfe_get_fast_stats returns the counters of the last probe that completed (zeros before one has). */

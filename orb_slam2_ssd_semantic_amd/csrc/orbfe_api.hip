@@ -134,10 +134,10 @@ struct PinBuf {
 // 1.47 / 2.14; 0.43 1.40 / 1.62; 0.38 1.42 / 1.55; 0.29 1.36 / 1.39; 0.18 (S_tum) 1.33 / 1.12; 0.076 1.26 / 0.92;
 // 0.02 1.22 / 0.74 -- break-even near 0.27
 #define ORBFE_AUTO_DENSE_RATE 0.25
-// ... and below this many frames per call dense is the form with the shorter wave: a launch that does not fill the GPU is bound by
-// its longest wave, not by issue slots (FAST stage of ONE frame: 18 us dense / 21 us compacting on S_tum, 20 / 26 on S; 8 frames:
-// 29 / 34 and 31 / 44 -- tools/fast_mode_latency.py)
-#define ORBFE_AUTO_MIN_FRAMES 32
+// ... and a launch that does not fill the GPU is bound by its longest wave, not by issue slots, and the dense form has the shorter
+// wave (FAST stage of ONE 640x480 frame: 18 us dense / 21 us compacting on S_tum, 20 / 26 on S; 8 frames: 29 / 34 and 31 / 44 --
+// tools/fast_mode_latency.py): below this many wave row steps per call (about 29 frames of 640x480 with 8 levels: 4 890 each) auto is dense
+#define ORBFE_AUTO_MIN_ROW_STEPS 140000
 #define ORBFE_AUTO_HOLD_MIN 16    // dense calls after a probe above the rate; doubles with every such probe in a row ...
 #define ORBFE_AUTO_HOLD_MAX 256   // ... up to this (a probe call on corner-saturated frames costs +45 % of its FAST stage)
 #define ORBFE_AUTO_PROBE_EVERY 8  // compacting calls between two looks at the pass rate
@@ -1250,13 +1250,14 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
     a.cap = cap;
     a.d_n_out = d_n_out;
     a.d_ovf = (int32_t *)h->d_misc.p;
-    // FAST form of this call.  Auto (3, the default): dense for calls of fewer than ORBFE_AUTO_MIN_FRAMES frames; otherwise
+    // FAST form of this call.  Auto (3, the default): dense for calls of fewer than ORBFE_AUTO_MIN_ROW_STEPS wave row steps (about 29
+    // VGA frames); otherwise
     // lane-compacting unless the last probe found more than ORBFE_AUTO_DENSE_RATE of the pixel pairs passing the necessary test --
     // then dense for the next auto_hold calls (16, doubling up to 256 while the probes keep saying so), after which one compacting
     // call probes again.
     int fmode = h->fast_mode;
     bool auto_probe = false;
-    if (fmode == 3 && nframes < ORBFE_AUTO_MIN_FRAMES) {
+    if (fmode == 3 && (int64_t)nframes * h->fast_row_steps < ORBFE_AUTO_MIN_ROW_STEPS) {
         fmode = 0;
     } else if (fmode == 3) {
         if (h->auto_pending && hipEventQuery(h->ev_auto) == hipSuccess) {   // never waits

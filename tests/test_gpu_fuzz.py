@@ -187,7 +187,7 @@ def test_fuzz_device_api(oracle):
 
 @pytest.mark.gpu
 def test_auto_fast_mode_is_the_default_small_batches_stay_dense(oracle):
-    """orbfe_set_fast_mode 3 is what a fresh handle runs: calls of fewer than 32 frames take the dense form (no probe: the counters
+    """orbfe_set_fast_mode 3 is what a fresh handle runs: calls that do not fill the GPU (8 VGA frames here) take the dense form (no probe: the counters
     stay zero); a larger batch of camera-like frames runs the lane-compacting form and leaves the pass rate of a sample of its
     waves behind; results equal the oracle's either way."""
     from orb_slam2_ssd_semantic_amd import ORBextractor
