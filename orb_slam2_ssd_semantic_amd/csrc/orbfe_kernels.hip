@@ -2079,7 +2079,21 @@ hipError_t orbk_upload_moment_weights(const int *umax16)
 #ifndef DS_KPW
 #define DS_KPW 16
 #endif
-__global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *__restrict__ plan, FrameSrc fs,
+// Launch geometry: a workgroup belongs to ONE level (its DS_KPW keypoints are consecutive entries of that level's selection), so
+// the address of a keypoint's key follows from the block index and the kernel arguments alone -- no count, no plan in memory in
+// front of it.  The dependent chain of a workgroup is then TWO round trips: {all level counts, the keys}, then {the 16 moment
+// dwords and the 24 blurred-patch dwords of every lane, requested back to back}; it used to be four (counts + plan, key, moment
+// pixels, patch pixels), and with a wave's 2.9 k cycles of arithmetic against tens of thousands of cycles of waiting the chain
+// length is part of what the kernel's time follows (-7 %).  The output slot of a keypoint (level-major, :1103-1112) needs the
+// counts of the levels before its own: they arrive with the key and are used only by the stores at the very end.
+struct DescLevelArg { int32_t sel_off, off, pitch, wg0; float scale, patch_size; int32_t pad[2]; };   // wg0: first workgroup of the level
+struct DescArgs {
+    int32_t wg0[ORBFE_MAX_LEVELS];   // the same, side by side: one scalar load for the level scan (levels past the last: INT_MAX)
+    int32_t nwg;                     // workgroups that belong to a level: sum over the levels of ceil(sel_cap / DS_KPW)
+    int32_t pad[3];
+    DescLevelArg lv[ORBFE_MAX_LEVELS];
+};
+__global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(DescArgs da, FrameSrc fs,
                                                          const uint8_t *__restrict__ blur, int64_t blur_fstride,
                                                          const uint32_t *__restrict__ sel,
                                                          const int32_t *__restrict__ nsel,
@@ -2088,13 +2102,7 @@ __global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *
                                                          int32_t *__restrict__ n_out, int32_t nl,
                                                          int32_t sel_per_frame, int32_t *__restrict__ ovf)
 {
-    // Everything the keypoint look-up needs is requested in ONE round trip (level counts, per-level constants into
-    // LDS, pattern and moment weights), so the dependent chain of a workgroup is: this, the key, the pixels.
-    struct DescLevel { int32_t sel_off, off, pitch; float scale, patch_size; };
-    __shared__ DescLevel s_lv[ORBFE_MAX_LEVELS];
-#ifndef DS_GLOBAL_SAMPLES
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[DS_KPW][DS_PR * DS_PP];
-#endif
     __shared__ uint2 s_momw[31 * 8];
     __shared__ float4 s_pat[256];  // (x0, y0, x1, y1) of every test pair as floats
 #ifdef DS_EXTRA_LDS   // occupancy probe: dead LDS that costs a workgroup slot per CU
@@ -2108,115 +2116,83 @@ __global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *
     bx = __builtin_amdgcn_readfirstlane(bx);
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = lane & 15, quad = tid >> 4;  // quad 0..DS_KPW-1 inside the workgroup = one keypoint
-    // lane `sub` of every 16-lane group holds the selection count of level `sub` (ORBFE_MAX_LEVELS == 16 == the group width)
-    static_assert(ORBFE_MAX_LEVELS == 16, "level look-up: one level per lane of a 16-lane group");
-    const int cnt_l = sub < nl ? nsel[b * nl + sub] : 0;
-    if (tid < nl) {
-        const OrbLevel &Lt = plan->lv[tid];
-        s_lv[tid] = DescLevel{Lt.sel_off, Lt.off, Lt.pitch, Lt.scale, Lt.patch_size};
+    // the level of this workgroup (scalar scan of the kernel arguments); workgroups behind the levels' only pad the output
+    int level = -1;
+    if (bx < da.nwg) {
+        level = 0;
+#pragma unroll
+        for (int j = 1; j < ORBFE_MAX_LEVELS; ++j) level += bx >= da.wg0[j] ? 1 : 0;   // ascending; INT_MAX past the last level
     }
-    for (int i = tid; i < 31 * 8; i += DS_KPW * 16) s_momw[i] = c_momw[i];
+    const int lv = max(level, 0);
+    const DescLevelArg L = da.lv[lv];
+    const int idx = (bx - L.wg0) * DS_KPW + quad;   // index inside the level's selection
+    // ---- round trip 1: the counts of all levels (lane `sub` of every 16-lane group holds level `sub`'s) and the key ----
+    static_assert(ORBFE_MAX_LEVELS == 16, "level counts: one level per lane of a 16-lane group");
+    const int cnt_l = sub < nl ? nsel[b * nl + sub] : 0;
+    uint32_t key = 0;
+    // entries behind the level's count are stale but inside its slice of the scratch (sel_cap rounded up to 64): read, not used
+    if (level >= 0) key = sel[(int64_t)b * sel_per_frame + L.sel_off + idx];
+    // ... and the two tables, requested in the same round trip (both loads before either LDS store: the load counter is in order)
+    static_assert(DS_KPW * 16 >= 256, "table fill: one pattern entry and one moment-weight entry per thread");
+    const uint2 mw = c_momw[min(tid, 31 * 8 - 1)];
+    const uint32_t pt = ((const uint32_t *)c_pattern)[tid & 255];
+    if (tid < 31 * 8) s_momw[tid] = mw;
     if (tid < 256) {
-        const uint32_t pt = ((const uint32_t *)c_pattern)[tid];
         // pair p = 16 * sub + i is stored at [i][sub]: the 16 lanes of a keypoint read consecutive float4s
         s_pat[(tid & 15) * 16 + (tid >> 4)] = make_float4((float)(int8_t)(pt & 0xFF), (float)(int8_t)((pt >> 8) & 0xFF),
                                                          (float)(int8_t)((pt >> 16) & 0xFF), (float)(int8_t)(pt >> 24));
     }
-    __syncthreads();
-
-    const int slot = bx * DS_KPW + quad;
-    // The keypoint of slot `slot` (level-major slots, :1103-1112): inclusive prefix sums of the level counts across the group's
-    // lanes (four DPP row shifts), the level = number of levels whose prefix is <= slot (one ballot, the group's 16 bits of it),
-    // the index inside the level = slot - prefix of the level before.
+    // inclusive prefix sums of the level counts across the group's lanes (four DPP row shifts)
     int incl = cnt_l;
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1 (lanes without a source add 0)
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
-    const unsigned long long below = orb_ballot(incl <= slot);
-    const int nbelow = __popc((uint32_t)(below >> (lane & 48)) & 0xFFFFu);  // levels that end at or before the slot
-    const int total = __builtin_amdgcn_readfirstlane(__shfl(incl, (lane & 48) | 15, 64));   // the same in every group: scalar
-    const int before = __shfl(incl, (lane & 48) | max(nbelow - 1, 0), 64);
-    const int level = nbelow < nl ? nbelow : -1;
-    const int idx = slot - (nbelow > 0 ? before : 0);
-    if (slot == 0 && sub == 0) {
+    const int total = __builtin_amdgcn_readlane(incl, 15);                 // the same in every group: scalar
+    const int mine = __builtin_amdgcn_readlane(cnt_l, lv);                 // keypoints of this workgroup's level
+    const int before = lv > 0 ? __builtin_amdgcn_readlane(incl, max(lv - 1, 0)) : 0;   // keypoints of the levels in front of it
+    if (bx == 0 && tid == 0) {
         n_out[b] = total;
         if (total > cap) atomicOr(ovf, 4);  // n_out holds the required count; slots >= cap are not written
     }
-    const bool in_cap = slot < cap;
+    {   // zero-fill the padding so the buffers can be all-gathered as they are: workgroup g takes slots total + 16 g ...
+        // (the grid has at least cap / DS_KPW workgroups)
+        const int zs = total + bx * DS_KPW + quad;
+        if (zs < cap) {
+            if (sub < 7) ((uint32_t *)(kps + (int64_t)b * cap + zs))[sub] = 0u;
+            if (sub < 8) ((uint32_t *)(desc + ((int64_t)b * cap + zs) * 32))[sub] = 0u;
+        }
+    }
+    // A workgroup behind its level's last keypoint (the levels' capacities are what the grid covers), or behind the levels: done.
+    // Workgroup-uniform, before the barriers.
+    if (level < 0 || (bx - L.wg0) * DS_KPW >= mine) return;
+    const int slot = before + idx;
+    const bool live = idx < mine && slot < cap;
     orbfe_keypoint *kp = kps + (int64_t)b * cap + slot;
     uint8_t *dd = desc + ((int64_t)b * cap + slot) * 32;
-    const bool live = in_cap && level >= 0;
-    if (in_cap && level < 0) {  // zero-fill the padding so the buffers can be all-gathered as they are
-        if (sub < 7) ((uint32_t *)kp)[sub] = 0u;
-        if (sub < 8) ((uint32_t *)dd)[sub] = 0u;
-    }
-    // A workgroup whose 16 slots all lie behind the frame's last keypoint has only padding to write (cap is nfeatures + margin:
-    // about 5 of 68 workgroups per frame at 1000 features): done.  Workgroup-uniform, before the second barrier.
-    if (bx * DS_KPW >= total) return;
-    const int lv = live ? level : 0;
-    const DescLevel L = s_lv[lv];
-    uint32_t key = 0;
-    if (live) key = sel[(int64_t)b * sel_per_frame + L.sel_off + idx];
     // dead quads shadow a valid position so that every lane can run the same loads
     const int x = live ? orb_key_x(key) : ORBFE_EDGE, y = live ? orb_key_y(key) : ORBFE_EDGE;
     const int pitch = lv == 0 ? fs.l0_pitch : L.pitch;
     const uint8_t *img = lv == 0 ? fs.l0 + (int64_t)b * fs.l0_fstride : fs.pyr + (int64_t)b * fs.pyr_fstride + L.off;
 
-    // ---- A: moments ----
-    int m10 = 0, rs15 = 0, m01 = 0;
+    // ---- round trip 2: the moment dwords (unblurred level) and the blurred patch of every lane, requested back to back ----
+    const int mk = sub & 7, mr0 = sub >> 3;
+    uint32_t w[16];
     {
-        const int k = sub & 7, r0 = sub >> 3;
         // 32-bit offsets from 24-bit multiplies (the 32-bit multiply and the 64-bit multiply-add are quarter rate):
         // rows r0, r0 + 2, ...; the 16th row of the odd lanes (31) is clamped to 30 and not used
-        const uint8_t *p = img + (__umul24((uint32_t)(y - 15 + r0), (uint32_t)pitch) + (uint32_t)(x - 15 + 4 * k));
-        uint32_t w[16];
+        const uint8_t *p = img + (__umul24((uint32_t)(y - 15 + mr0), (uint32_t)pitch) + (uint32_t)(x - 15 + 4 * mk));
         // unaligned dwords; the pointer advances by two rows per load (one 64-bit add each instead of a multiply and an add);
         // the last step of the odd lanes is one row (row 30, clamped)
-        const uint32_t step2 = 2u * (uint32_t)pitch, step_last = __umul24((uint32_t)(2 - r0), (uint32_t)pitch);
+        const uint32_t step2 = 2u * (uint32_t)pitch, step_last = __umul24((uint32_t)(2 - mr0), (uint32_t)pitch);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             w[i] = *(const uint32_t *)p;
             p += i < 14 ? step2 : step_last;
         }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = r0 + 2 * i;
-            if (row <= 30) {
-                const uint2 wt = s_momw[row * 8 + k];
-                const uint32_t a = __builtin_amdgcn_udot4(w[i], wt.x, 0u, false);  // sum (u+15) * I
-                const uint32_t s1 = __builtin_amdgcn_udot4(w[i], wt.y, 0u, false); // sum I
-                m10 += (int)a;
-                rs15 += (int)s1;
-                m01 += __mul24(row - 15, (int)s1);  // |row - 15| <= 15, s1 <= 1020
-            }
-        }
-        m10 -= 15 * rs15;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o, 64);
-            m01 += __shfl_xor(m01, o, 64);
-        }
     }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-#ifdef DS_GLOBAL_SAMPLES
-    // A/B: no LDS patch -- the 512 rotated samples of a keypoint are byte loads straight from the blurred
-    // level (L1 / L2: the XCD placement keeps a frame in one L2).  No bank conflicts, no 24 KB of LDS per workgroup; every
-    // sample is a 64-address gather instead.
-    typedef const __attribute__((address_space(1))) uint8_t *orb_gptr8;
-    orb_gptr8 gcentre;
-    const int bpitch_g = L.pitch;
-    {
-        const uint64_t bb = (uint64_t)(blur + (int64_t)b * blur_fstride);
-        const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bb);
-        const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bb >> 32));
-        gcentre = (orb_gptr8)(((uint64_t)hi32 << 32) | lo32);
-    }
-    const uint32_t ocentre = (uint32_t)L.off + __umul24((uint32_t)y, (uint32_t)bpitch_g) + (uint32_t)x;
-#else
-    // ---- C: blurred patch -> LDS ----
     uint8_t *patch = s_patch[quad];
+    uint32_t v[24];
     {
         const int bpitch = L.pitch;
         // uniform base (frame b of the blurred pyramid) + a 32-bit per-lane offset that advances by additions
@@ -2243,7 +2219,6 @@ __global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *
         const uint32_t bp40 = (uint32_t)bpitch - 40u;
         // uniform base + one 32-bit per-lane offset + immediate: a global_load with an SGPR base, no 64-bit address arithmetic
         const uint32_t o4 = (uint32_t)L.off + __umul24((uint32_t)(y - 18), (uint32_t)bpitch) + (uint32_t)(x - 18 + 4 * sub);
-        uint32_t v[24];
 #pragma unroll
         for (int it = 0; it < 23; ++it) {
             const uint32_t row = (s205 + (uint32_t)(it * 16 * 205)) >> 11;
@@ -2254,18 +2229,42 @@ __global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *
             const uint32_t fl = 368u + (uint32_t)min(sub, 1);
             v[23] = *(orb_gptr32)(bbase + ((uint32_t)L.off + __umul24((uint32_t)(y + 18), (uint32_t)bpitch) + (uint32_t)(x - 18) + 4u * (fl - 360u)));
         }
+    }
+    __syncthreads();   // the tables (moment weights, pattern) are in LDS
+    // ---- A: moments ----
+    int m10 = 0, rs15 = 0, m01 = 0;
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = mr0 + 2 * i;
+            if (row <= 30) {
+                const uint2 wt = s_momw[row * 8 + mk];
+                const uint32_t a = __builtin_amdgcn_udot4(w[i], wt.x, 0u, false);  // sum (u+15) * I
+                const uint32_t s1 = __builtin_amdgcn_udot4(w[i], wt.y, 0u, false); // sum I
+                m10 += (int)a;
+                rs15 += (int)s1;
+                m01 += __mul24(row - 15, (int)s1);  // |row - 15| <= 15, s1 <= 1020
+            }
+        }
+        m10 -= 15 * rs15;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o, 64);
+            m01 += __shfl_xor(m01, o, 64);
+        }
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // ---- C: blurred patch -> LDS ----
+    {
         uint8_t *pl = patch + 4 * sub;
 #pragma unroll
         for (int it = 0; it < 23; ++it) *(uint32_t *)(pl + it * 64) = v[it];
         if (sub < 2) *(uint32_t *)(pl + 23 * 64) = v[23];
     }
-#endif
     float a, bb;
     canon_sincos(angle, &a, &bb);
-#ifndef DS_GLOBAL_SAMPLES
     __syncthreads();
     const uint8_t *pc = patch + 18 * DS_PP + 18;
-#endif
     uint32_t bits = 0;
     // rotated sample positions (:100-106): row = cvRound(x*b + y*a), col = cvRound(x*a - y*b), every product and sum
     // rounded separately.  Two coordinates per packed-fp32 instruction; x*a - y*b == x*a + y*(-b) exactly.
@@ -2280,11 +2279,7 @@ __global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(const OrbPlan *
         const orb_f2 p1 = orb_f2{pt.z, pt.z} * ba + orb_f2{pt.w, pt.w} * anb + magic;
         const int r0 = (int)(short)__float_as_int(p0.x), c0 = __float_as_int(p0.y) - 0x4B400000;
         const int r1 = (int)(short)__float_as_int(p1.x), c1 = __float_as_int(p1.y) - 0x4B400000;
-#ifdef DS_GLOBAL_SAMPLES
-        const int t0 = gcentre[ocentre + (uint32_t)(__mul24(r0, bpitch_g) + c0)], t1 = gcentre[ocentre + (uint32_t)(__mul24(r1, bpitch_g) + c1)];
-#else
         const int t0 = pc[r0 * DS_PP + c0], t1 = pc[r1 * DS_PP + c1];
-#endif
         bits |= (uint32_t)(t0 < t1) << i;
     }
     if (live) {
@@ -2652,9 +2647,20 @@ hipError_t orbk_launch_blur_pyr(const OrbLaunch &a, hipStream_t st)
 hipError_t orbk_launch_describe(const OrbLaunch &a, hipStream_t st)
 {
     const FrameSrc fs = make_src(a);
-    dim3 grid((a.cap + DS_KPW - 1) / DS_KPW, a.nframes);
-    hipLaunchKernelGGL(k_orient_describe, grid, dim3(DS_KPW * 16), 0, st, a.d_plan, fs, a.d_blur, a.pyr_fstride, a.d_sel,
-                       a.d_nsel, a.d_kps, a.d_desc, a.cap, a.d_n_out, a.h_plan->nlevels, a.h_plan->sel_per_frame,
-                       a.d_ovf);
+    const OrbPlan &P = *a.h_plan;
+    DescArgs da;
+    int wg = 0;
+    for (int l = 0; l < ORBFE_MAX_LEVELS; ++l) {
+        const OrbLevel &L = P.lv[l < P.nlevels ? l : 0];
+        da.lv[l] = DescLevelArg{L.sel_off, L.off, L.pitch, wg, L.scale, L.patch_size, {0, 0}};
+        da.wg0[l] = l < P.nlevels ? wg : 0x7FFFFFFF;
+        if (l < P.nlevels) wg += (L.sel_cap + DS_KPW - 1) / DS_KPW;
+    }
+    da.nwg = wg;
+    da.pad[0] = da.pad[1] = da.pad[2] = 0;
+    // the workgroups of the levels; at least cap / DS_KPW of them: workgroup g also zero-fills the output slots total + 16 g ...
+    dim3 grid(std::max(wg, (a.cap + DS_KPW - 1) / DS_KPW), a.nframes);
+    hipLaunchKernelGGL(k_orient_describe, grid, dim3(DS_KPW * 16), 0, st, da, fs, a.d_blur, a.pyr_fstride, a.d_sel,
+                       a.d_nsel, a.d_kps, a.d_desc, a.cap, a.d_n_out, P.nlevels, P.sel_per_frame, a.d_ovf);
     return hipGetLastError();
 }
