@@ -152,7 +152,10 @@ orbfe_status orbfe_get_fast_stats(orbfe_handle *h, uint64_t out[3], int32_t rese
 orbfe_status orbfe_get_work_counts(const orbfe_handle *h, int64_t out[2]);
 /* Launch-shape and A/B options of a handle.  The release library takes them ONLY through this call -- it reads no tuning
  * knob from the process environment (a library inside a SLAM process must not change algorithm because of the host's
- * environment).  Every setting gives byte-identical results; 0 (ORBFE_OPT_OVERLAP: -1) restores the built-in choice.
+ * environment).  Every setting gives byte-identical results (ORBFE_OPT_BLUR_ROUNDING excepted).  Built-in choices, i.e. the value that
+ * restores the default: OVERLAP -1; ROWS / ROWS_FAST / ROWS_BLUR / PYR_ROWS / QT_THREADS_* 0; BLUR_PIECES 1 (0 = the older packing, an
+ * A/B variant); BLUR_UPDOWN 1 (0 = never, 2 = always); DEBUG 0; the [dev] fusions 0; FUSE_FAST_PYR_LEVELS 0 (= all levels; 1..8 = that
+ * many); REUSE_IDENTICAL_INPUT 0.
  * Options marked [dev] select kernel variants that were measured slower than the default and are compiled only into a
  * developer build (-DORBFE_DEVELOPER, tools/ab_build.sh; such a build also honours $ORBFE_<NAME> at orbfe_create): a
  * release build answers ORBFE_ERR_STATE to a non-zero value.  Call between extract calls, not concurrently with one. */
@@ -173,9 +176,17 @@ enum {
     ORBFE_OPT_FUSE_BLUR_PYR = 13, /* [dev] 1 / 2: blur + resize in one chained pass */
     ORBFE_OPT_FUSE_FAST_PYR = 14, /* [dev] 1 / 2: FAST + resize in one launch per level, 3: FAST of level 0 beside the pyramid */
     ORBFE_OPT_FUSE_FAST_PYR_LEVELS = 15,
-    ORBFE_OPT_BLUR_ROUNDING = 16  /* orbfe_params.blur_rounding of an existing handle (0 / 1); this one changes RESULTS */
+    ORBFE_OPT_BLUR_ROUNDING = 16, /* orbfe_params.blur_rounding of an existing handle (0 / 1); this one changes RESULTS */
+    ORBFE_OPT_REUSE_IDENTICAL_INPUT = 17 /* single-frame host calls (orbfe_extract; orbfe_extract_batch with one frame), default 0.  1: a call whose
+                                   * pixels equal those of the previous such call of this handle (same w, ht, cap; compared on the host against the pinned
+                                   * staging copy, stride-independent) returns that call's keypoints / descriptors without
+                                   * touching the GPU; pyramid and taps stay those of that frame.  For callers that extract the
+                                   * same image twice: perfect/src/Tracking.cc:685 and :716 build two Frames from one mImGray.
+                                   * Bit-exact by construction.  Any other use of the handle in between drops the cached frame. */
 };
 orbfe_status orbfe_set_option(orbfe_handle *h, int32_t option, int32_t value);
+/* 1 when the last orbfe_extract call of the handle was answered from the previous call's results (ORBFE_OPT_REUSE_IDENTICAL_INPUT) */
+int32_t orbfe_last_call_reused(const orbfe_handle *h);
 /* the handle's own non-blocking stream (hipStream_t as void*): the host-buffer entry points run on it */
 void *orbfe_get_stream(orbfe_handle *h);
 /* block until everything enqueued by this handle on its own stream has finished */
@@ -249,6 +260,11 @@ void *orbfe_matcher_get_stream(orbfe_matcher *m);
 /* all-pairs kernel behind the three orbfe_match_bf* calls: 0 (default) = exact int8 dot product on the matrix cores
  * (dot = 128 * (128 - hamming)), 1 = xor / popcount.  Results are identical; see DESIGN.md for the measured A/B. */
 orbfe_status orbfe_matcher_set_bf_kernel(orbfe_matcher *m, int32_t kernel);
+/* orbfe_search_by_projection(_chi2): 0 (default) = the whole search in ONE launch (k_proj_fused: per-query slabs, round 0 of the
+ * relaxation decided while the candidates are written, the last workgroup finishes the rounds, results stored straight into
+ * page-locked host memory), falling back to 1 = count -> scan -> fill -> resolve when a query has more than 512 candidates or
+ * the tables exceed 64 KB of LDS.  Identical results. */
+orbfe_status orbfe_matcher_set_projection_kernel(orbfe_matcher *m, int32_t kernel);
 /* same, DEVICE buffers, enqueued on `stream` (NULL = HIP's default stream, see orbfe_extract_batch_device;
  * orbfe_matcher_get_stream(m) = the matcher's own stream), no synchronisation;
  * d_nmatches is one int32 in device memory */
@@ -578,7 +594,9 @@ orbfe_status orbfe_search_by_bow_batch_device(orbfe_matcher *m, const orbfe_keyp
  * is set, `stream` is made to wait for all pipes before the call returns, so that anything enqueued on it afterwards sees
  * the results.  With ORBFE_PIPE_NO_JOIN consecutive calls run back to back without draining the chip in between (a
  * throughput loop whose results are consumed later): call orbfe_pipeline_join(pl, stream) or orbfe_pipeline_synchronize(pl)
- * before touching the outputs.  Buffers re-used by the next call are protected inside the pipeline (events).
+ * before touching the outputs.  Output blocks re-used by a later call are protected inside the pipeline: every sub-batch records the address ranges
+ * it writes, and a later sub-batch waits for the extraction and the matchers of every recorded range that overlaps its own (by
+ * address, not by position in the call: shifted base pointers and other call sizes are ordered too).
  * A pipeline is used by one thread at a time.  orbfe_pipeline_extractor / _matcher give the pipes' handles for the per-handle
  * settings (orbfe_set_fast_mode, orbfe_set_profiling, orbfe_matcher_set_bf_kernel) and taps.
  * ------------------------------------------------------------------------------------------- */

@@ -317,6 +317,16 @@ class ShimExtractor:
     def blur_rounding(self):
         return self.L.shimext_get_blur_rounding(self.h)
 
+    def set_reuse(self, on):
+        """mbReuseIdenticalInput of the shim (before the first call)"""
+        self.L.shimext_set_reuse.argtypes = [C.c_void_p, C.c_int]
+        self.L.shimext_set_reuse(self.h, int(on))
+
+    def reused_calls(self):
+        self.L.shimext_reused_calls.argtypes = [C.c_void_p]
+        self.L.shimext_reused_calls.restype = C.c_long
+        return int(self.L.shimext_reused_calls(self.h))
+
     def getters(self):
         n = self.nlevels
         lv, sf = C.c_int(), C.c_float()
@@ -374,6 +384,10 @@ def shimstereo_lib():
         L.shim_st_ext_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         L.shim_st_ext_destroy.argtypes = [C.c_void_p]
         L.shim_st_ext_set_blur_rounding.argtypes = [C.c_void_p, C.c_int]
+        L.shim_st_ext_set_reuse.argtypes = [C.c_void_p, C.c_int]
+        L.shim_st_ext_set_keep_pyramid.argtypes = [C.c_void_p, C.c_int]
+        L.shim_st_ext_reused_calls.argtypes = [C.c_void_p]
+        L.shim_st_ext_reused_calls.restype = C.c_long
         _declare_stereo_frame(L.shim_st_stereo_frame)
         _shimstereo = L
     return _shimstereo

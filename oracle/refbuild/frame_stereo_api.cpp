@@ -62,6 +62,9 @@ void *FS_NAME(ext_create)(int nfeatures, float scale_factor, int nlevels, int in
 }
 void FS_NAME(ext_destroy)(void *h) { delete (ORBextractor *)h; }
 void FS_NAME(ext_set_blur_rounding)(void *h, int mode) { ((ORBextractor *)h)->mnBlurRounding = mode; }
+void FS_NAME(ext_set_reuse)(void *h, int on) { ((ORBextractor *)h)->mbReuseIdenticalInput = on != 0; }
+long FS_NAME(ext_reused_calls)(void *h) { return ((ORBextractor *)h)->mnReusedCalls; }
+void FS_NAME(ext_set_keep_pyramid)(void *h, int on) { ((ORBextractor *)h)->mbKeepPyramid = on != 0; }
 #define FS_ENTER()
 #define FS_LEAVE()
 #endif

@@ -40,6 +40,8 @@ void *shimext_create(int nfeatures, float scale_factor, int nlevels, int ini_th,
 void shimext_destroy(void *h) { delete (ORBextractor *)h; }
 void shimext_set_blur_rounding(void *h, int mode) { ((ORBextractor *)h)->mnBlurRounding = mode; }
 int shimext_get_blur_rounding(void *h) { return ((ORBextractor *)h)->mnBlurRounding; }
+void shimext_set_reuse(void *h, int on) { ((ORBextractor *)h)->mbReuseIdenticalInput = on != 0; }
+long shimext_reused_calls(void *h) { return ((ORBextractor *)h)->mnReusedCalls; }
 
 /* left = 1: (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors) through Frame::ExtractORB(0, im); else the right
  * extractor / mvKeysRight.  Returns the keypoint count, -2 if cap is too small, -3 if the shim threw. */

@@ -40,7 +40,7 @@ SYMBOLS = (
     "orbfe_group_extract_shard_device", "orbfe_group_allgather", "orbfe_group_synchronize", "orbfe_group_blocks", "orbfe_group_get_frame",
     "orbfe_group_match", "orbfe_group_match_device", "orbfe_group_owner_rank", "orbfe_group_block_index_of",
     "orbfe_group_create_local_ex", "orbfe_group_members", "orbfe_group_transport", "orbfe_group_get_frame_from", "orbfe_group_get_counts", "orbfe_assign_grid_host", "orbfe_get_pyramid_padded", "orbfe_project_points", "orbfe_proj_queries_local_map", "orbfe_rotation_consistency",
-    "orbfe_initialization_resolve", "orbfe_set_option", "orbfe_match_bf_blocks_device",
+    "orbfe_initialization_resolve", "orbfe_set_option", "orbfe_last_call_reused", "orbfe_matcher_set_projection_kernel", "orbfe_match_bf_blocks_device",
     "orbfe_pipeline_create", "orbfe_pipeline_destroy", "orbfe_pipeline_pipes", "orbfe_pipeline_capacity", "orbfe_pipeline_sub_batch",
     "orbfe_pipeline_extractor", "orbfe_pipeline_matcher", "orbfe_pipeline_extract_match_device", "orbfe_pipeline_join",
     "orbfe_pipeline_synchronize", "orbfe_pipeline_reset_sequence", "orbfe_pipeline_get_overflow", "orbfe_pipeline_extract_match", "orbfe_pipeline_set_host_pipes",
@@ -48,7 +48,7 @@ SYMBOLS = (
 
 # orbfe_set_option (include/orbfe.h ORBFE_OPT_*)
 OPTIONS = dict(overlap=1, rows=2, rows_fast=3, rows_blur=4, blur_pieces=5, blur_updown=6, pyr_rows=7, qt_threads_0=8, qt_threads_1=9,
-               qt_threads_2=10, debug=11, pyr_fuse=12, fuse_blur_pyr=13, fuse_fast_pyr=14, fuse_fast_pyr_levels=15, blur_rounding=16)
+               qt_threads_2=10, debug=11, pyr_fuse=12, fuse_blur_pyr=13, fuse_fast_pyr=14, fuse_fast_pyr_levels=15, blur_rounding=16, reuse_identical_input=17)
 PIPE_CONTINUE, PIPE_NO_JOIN = 1, 2
 
 
@@ -127,6 +127,7 @@ def _configure(L):
     L.orbfe_tap_selected.argtypes = [vp, i32, i32, vp, i32, vp]
     L.orbfe_get_work_counts.argtypes = [vp, vp]
     L.orbfe_matcher_set_bf_kernel.argtypes = [vp, i32]
+    L.orbfe_matcher_set_projection_kernel.argtypes = [vp, i32]
     L.orbfe_mapio_keyframe_bytes.restype = sz
     L.orbfe_mapio_keyframe_bytes.argtypes = [i32]
     L.orbfe_mapio_write_keyframe.argtypes = [vp, sz, C.c_uint64, C.c_double, vp, vp, vp, vp, vp, i32, vp]
@@ -207,6 +208,8 @@ def _configure(L):
     L.orbfe_group_match.argtypes = [vp, vp, vp, i32, f32, i32, i32, vp, vp]
     L.orbfe_group_match_device.argtypes = [vp, i32, vp, vp, i32, f32, i32, i32, vp, vp]
     L.orbfe_set_option.argtypes = [vp, i32, i32]
+    L.orbfe_last_call_reused.argtypes = [vp]
+    L.orbfe_last_call_reused.restype = C.c_int32
     L.orbfe_match_bf_blocks_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, f32, i32, i32, vp, vp, vp]
     L.orbfe_pipeline_create.argtypes = [C.POINTER(OrbfeParams), i32, C.POINTER(vp)]
     L.orbfe_pipeline_destroy.argtypes = [vp]

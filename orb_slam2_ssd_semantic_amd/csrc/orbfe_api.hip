@@ -213,6 +213,13 @@ struct orbfe_handle {
     int opt_rows = 0, opt_rows_fast = 0, opt_rows_blur = 0;
     int opt_blur_pieces = 1, opt_blur_updown = 1, opt_debug = 0;
     OrbOpts kopts = {0, 0, {0, 0, 0}};
+    // ORBFE_OPT_REUSE_IDENTICAL_INPUT (orbfe_extract only): the frame of the last single-frame host call is still in the pinned
+    // staging block h_stage[0] and its results in h_okps[0]; a call that brings the same pixels gets those results back without
+    // touching the GPU.  reuse_valid is dropped by every other use of the handle (run_batch) and by every option change.
+    int opt_reuse = 0;
+    bool reuse_valid = false, last_reused = false;
+    int reuse_w = 0, reuse_h = 0, reuse_cap = 0;
+    int64_t reuse_hits = 0;
 };
 
 // waits until the last batched call of the handle has finished, on whichever stream it ran
@@ -1159,16 +1166,21 @@ extern "C" orbfe_status orbfe_set_option(orbfe_handle *h, int32_t option, int32_
         h->fuse_fast_pyr = value;
         if (value && h->fuse_blur_pyr) { h->fuse_blur_pyr = 0; replan = true; }
         break;
-    case ORBFE_OPT_FUSE_FAST_PYR_LEVELS:
-        if (!in(1, ORBFE_MAX_LEVELS)) return ORBFE_ERR_ARG;
-        h->fuse_fast_pyr_levels = value;
+    case ORBFE_OPT_FUSE_FAST_PYR_LEVELS:   // matters for the developer-only variant ORBFE_OPT_FUSE_FAST_PYR alone; 0 = all levels (the default)
+        if (!in(0, ORBFE_MAX_LEVELS)) return ORBFE_ERR_ARG;
+        if (developer_only()) return ORBFE_ERR_STATE;
+        h->fuse_fast_pyr_levels = value ? value : ORBFE_MAX_LEVELS;
         break;
     case ORBFE_OPT_BLUR_ROUNDING: if (!in(0, 1)) return ORBFE_ERR_ARG; h->prm.blur_rounding = value; replan = true; break;
+    case ORBFE_OPT_REUSE_IDENTICAL_INPUT: if (!in(0, 1)) return ORBFE_ERR_ARG; h->opt_reuse = value; break;
     default: orbfe_set_error("unknown option %d", option); return ORBFE_ERR_ARG;
     }
     if (replan) h->plan_valid = false;   // rebuilt (behind the handle's outstanding work) by the next call
+    h->reuse_valid = false;
     return ORBFE_OK;
 }
+
+extern "C" int32_t orbfe_last_call_reused(const orbfe_handle *h) { return h && h->last_reused ? 1 : 0; }
 
 extern "C" orbfe_status orbfe_set_fast_mode(orbfe_handle *h, int32_t mode, int32_t collect_stats)
 {
@@ -1213,6 +1225,8 @@ static orbfe_status run_batch(orbfe_handle *h, const uint8_t *d_gray, int nframe
         orbfe_set_error("frame %dx%d larger than planned %dx%d", w, ht, h->prm.max_width, h->prm.max_height);
         return ORBFE_ERR_SIZE;
     }
+    h->reuse_valid = false;   // the scratch blocks and taps belong to this call from here on
+    h->last_reused = false;
     orbfe_status s = build_plan(h, w, ht);
     if (s != ORBFE_OK) return s;
     s = ensure_batch_buffers(h, nframes);
@@ -1457,6 +1471,28 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
     const size_t kb = (sizeof(orbfe_keypoint) * (size_t)cap * nbmax + 255) & ~(size_t)255;
     const size_t db = ((size_t)32 * cap * nbmax + 255) & ~(size_t)255;
     const size_t cb = (sizeof(int32_t) * nbmax + 255) & ~(size_t)255;
+    // ORBFE_OPT_REUSE_IDENTICAL_INPUT: perfect/src/Tracking.cc:685 and :716 build two Frames from the SAME mImGray with the same
+    // extractor (the second with the dynamic-object mask, which operator() ignores): the second extraction is the first one's
+    // result.  The previous frame sits in the pinned staging block (pitch-aligned rows) and its results in the pinned result
+    // block; one pass of memcmp over the rows decides, and a hit touches neither the link nor the GPU (pyramid, taps and the
+    // device-side state of the handle are still those of that frame).  Bit-exact by construction.
+    if (h->opt_reuse && nframes == 1 && h->reuse_valid && h->reuse_w == w && h->reuse_h == ht && h->reuse_cap == cap && h->plan_valid) {
+        const uint8_t *prev = (const uint8_t *)h->h_stage[0].p, *src = grays[0];
+        bool same = true;
+        if (stride == w && pitch == w) same = memcmp(prev, src, fbytes) == 0;
+        else
+            for (int y = 0; y < ht && same; ++y) same = memcmp(prev + (size_t)y * pitch, src + (size_t)y * stride, (size_t)w) == 0;
+        if (same) {
+            const uint8_t *hb = (const uint8_t *)h->h_okps[0].p;   // keypoints | descriptors | counts of that call
+            const int n = ((const int32_t *)(hb + kb + db))[0];
+            n_out[0] = n;
+            memcpy(kps, hb, sizeof(orbfe_keypoint) * (size_t)n);
+            memcpy(desc, hb + kb, (size_t)32 * n);
+            h->last_reused = true;
+            h->reuse_hits++;
+            return ORBFE_OK;
+        }
+    }
     uint8_t *d_ok[2] = {nullptr, nullptr}, *d_od[2] = {nullptr, nullptr}, *d_oc[2] = {nullptr, nullptr};
     for (int k = 0; k < nset; ++k) {
         if (!direct) ORBFE_HIP(h->h_stage[k].ensure(fbytes * nbmax));
@@ -1589,6 +1625,12 @@ static orbfe_status extract_host(orbfe_handle *h, const uint8_t *const *grays, i
         }
     }
     if (worst == ORBFE_ERR_CAP) orbfe_set_error("cap=%d too small; n_out holds the required counts", cap);
+    if (worst == ORBFE_OK && nframes == 1 && !direct && !direct_out) {   // what a later identical frame can be answered from
+        h->reuse_valid = true;
+        h->reuse_w = w;
+        h->reuse_h = ht;
+        h->reuse_cap = cap;
+    }
     return worst;
 }
 

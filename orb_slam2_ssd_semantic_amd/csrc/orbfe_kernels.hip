@@ -604,6 +604,7 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
 #ifndef FC_OCC
 #define FC_OCC
 #endif
+static_assert(FC_LAG >= 1 && FC_LAG <= 3, "the strength-row ring (srow / snap, 4 slots) is re-used by the front half of step s + 4: the back half of step s must have read it, i.e. lag <= 3");
 static_assert(FC_PN >= 6 + FC_LAG && FC_PN >= 7, "pixel ring: the first row of an item parked at step s is overwritten at step s - 6 + FC_PN");
 // fast_compass_pair on values: the four compass pixel pairs and the centre pair of one pixel pair
 __device__ __forceinline__ uint32_t fast_compass_from(uint32_t c0, uint32_t c8, uint32_t c4, uint32_t c12, uint32_t v, uint32_t t)

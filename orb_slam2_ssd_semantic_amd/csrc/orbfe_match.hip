@@ -663,6 +663,8 @@ struct orbfe_matcher {
     bool scratch_used = false;
     hipEvent_t ev_scratch = nullptr;
     MPinBuf pin_in, pin_out;  // page-locked staging of the latency-bound per-frame calls (orbfe_search_by_projection)
+    bool proj_fused = true;   // orbfe_search_by_projection: the one-launch form (k_proj_fused); false = the four-kernel path (tests)
+    MDevBuf proj_done;        // k_proj_fused's arrival counter / overflow word (zero between calls)
 };
 
 static hipError_t scratch_acquire(orbfe_matcher *m, hipStream_t st)
@@ -749,6 +751,13 @@ extern "C" orbfe_status orbfe_matcher_set_bf_kernel(orbfe_matcher *m, int32_t ke
     return ORBFE_OK;
 }
 
+extern "C" orbfe_status orbfe_matcher_set_projection_kernel(orbfe_matcher *m, int32_t kernel)
+{
+    if (!m || kernel < 0 || kernel > 1) return ORBFE_ERR_ARG;
+    m->proj_fused = kernel == 0;
+    return ORBFE_OK;
+}
+
 extern "C" void orbfe_matcher_destroy(orbfe_matcher *m)
 {
     if (!m) return;
@@ -756,6 +765,7 @@ extern "C" void orbfe_matcher_destroy(orbfe_matcher *m)
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->scratch_used) (void)hipEventSynchronize(m->ev_scratch);
     for (auto &b : m->b) b.release();
+    m->proj_done.release();
     m->pin_in.release();
     m->pin_out.release();
     if (m->ev_scratch) (void)hipEventDestroy(m->ev_scratch);
@@ -1614,6 +1624,223 @@ __global__ __launch_bounds__(PJ_T) void k_proj_resolve(ProjArgs a)
     if (tid == 0) a.status[1] = round + 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The search in TWO launches instead of four and a copy (the per-frame members of Tracking are launch-bound: count -> scan -> fill ->
+// resolve plus a result copy cost more than their kernels).  Same arithmetic, same fixed point:
+//   * every query's wave walks its cell rectangle twice inside the launch (count, then fill -- the second walk finds its lines
+//     in the cache) and writes its entries into a fixed slab of PJ_SLAB slots at i * PJ_SLAB: no scan over the queries, no
+//     second launch.  A query with more candidates raises need[] and the host takes the four-kernel path (below) instead.
+//   * while it fills, the wave already reduces the two smallest keys: round 0 of the relaxation (owner table empty) is decided
+//     here, spread over the chip, for every query at once.
+//   * a second, one-workgroup launch (k_proj_rounds) runs the remaining rounds.  A query re-scans its entries in
+//     a round only if it has to: when the slot of its best or of its second-best candidate is now owned by an earlier query, or
+//     when it ever skipped an owned slot (that slot may have been freed).  Every other query's two smallest free keys are what
+//     they were, so its choice is what a full re-scan would return: the rounds and their results are those of k_proj_resolve.
+//     On real frames a few dozen of ~800 queries re-scan.
+//   * results go straight to page-locked host memory (match | best | second | status): two launches, no copy back, one wait.
+// ---------------------------------------------------------------------------------------------------
+#define PJ_SLAB 512
+#define PJ_FT 256                // threads per workgroup: one wave per query in the fill, 16 lanes per query in the rounds
+struct ProjFusedArgs {
+    ProjArgs a;
+    int32_t *f12;                // [2 * nq] feature of the best / second-best free candidate (-1: none)
+    uint8_t *constrained;        // [nq] the query skipped an owned slot in its last scan
+    uint32_t *done;              // [1] largest candidate count above PJ_SLAB (0: none); reset by k_proj_rounds
+    int32_t *h_out;              // mapped host: match[nq] | best[nq] | second[nq] | status[2]
+};
+
+// the decision of :128-148 / :1673 from the two smallest keys of the free candidates and their features
+__device__ __forceinline__ int proj_decide(const ProjArgs &a, uint32_t k1, uint32_t k2, int f1, int f2, int &bestDist, int &bestDist2)
+{
+    bestDist = k1 == PJ_NOKEY ? 256 : (int)(k1 >> 16);
+    bestDist2 = k2 == PJ_NOKEY ? 256 : (int)(k2 >> 16);
+    if (bestDist > a.th) return -1;
+    if (a.ratio_rule) {
+        const int bestLevel = a.octF[(size_t)a.os * f1];
+        const int bestLevel2 = k2 == PJ_NOKEY ? -1 : a.octF[(size_t)a.os * f2];
+        if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2)) return -1;
+    }
+    return f1;
+}
+
+// merge (k1, f1, k2, f2) with a partner's over `width` lanes: the two smallest keys and their features
+template <int WIDTH>
+__device__ __forceinline__ void proj_reduce2(uint32_t &k1, int &f1, uint32_t &k2, int &f2)
+{
+#pragma unroll
+    for (int s = WIDTH / 2; s > 0; s >>= 1) {
+        const uint32_t o1 = __shfl_xor(k1, s, WIDTH), o2 = __shfl_xor(k2, s, WIDTH);
+        const int g1 = __shfl_xor(f1, s, WIDTH), g2 = __shfl_xor(f2, s, WIDTH);
+        // keys are unique inside a query (the position is part of them), NOKEY excepted
+        uint32_t hi;
+        int fh;
+        if (o1 < k1) { hi = k1; fh = f1; k1 = o1; f1 = g1; } else { hi = o1; fh = g1; }
+        const uint32_t m2 = min(k2, o2);
+        const int fm = k2 <= o2 ? f2 : g2;
+        if (hi <= m2) { k2 = hi; f2 = fh; } else { k2 = m2; f2 = fm; }
+    }
+}
+
+__global__ __launch_bounds__(PJ_FT) void k_proj_fused(ProjFusedArgs p)
+{
+    const ProjArgs &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nq = a.nq;
+    {
+        const int i = blockIdx.x * (PJ_FT / 64) + wv;
+        if (i < nq) {   // wave-uniform
+            const orbfe_proj_query Q = a.q[i];
+            ProjRect R;
+            const bool any = proj_rect(a, Q, R);
+            int n = 0;
+            if (any) proj_walk(a, Q, R, lane, [&](uint32_t) { ++n; });
+            const int incl = wave_incl_scan_m(n);
+            const int tot = __shfl(incl, 63, 64);
+            uint32_t k1 = PJ_NOKEY, k2 = PJ_NOKEY;
+            int f1 = -1, f2 = -1;
+            if (tot > PJ_SLAB) {
+                if (lane == 0) atomicMax(&p.done[1], (uint32_t)tot);
+            } else if (tot > 0) {
+                uint32_t o = (uint32_t)(incl - n);
+                uint32_t *ent = a.ent + (size_t)i * PJ_SLAB;
+                Desc8 dq;
+                const uint32_t *pq = (const uint32_t *)(a.qdesc + (int64_t)i * 32);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dq.w[k] = pq[k];
+                const bool gate = (Q.flags & ORBFE_PROJ_RIGHT_GATE) && a.uRight;
+                const bool chi2 = (Q.flags & ORBFE_PROJ_CHI2_GATE) && a.inv_sigma2;
+                proj_walk(a, Q, R, lane, [&](uint32_t f) {
+                    bool skip = a.blocked && a.blocked[f];
+                    if (!skip && gate) {
+                        const float ur = a.uRight[f];
+                        skip = ur > 0.f && fabsf(__fsub_rn(Q.ur, ur)) > Q.r;
+                    }
+                    if (!skip && chi2) {
+                        const float ex = __fsub_rn(Q.u, a.xyF[(size_t)a.xs * f]), ey = __fsub_rn(Q.v, a.xyF[(size_t)a.xs * f + 1]);
+                        float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                        const float kr = a.uRight ? a.uRight[f] : -1.f;
+                        const int lv = min(max(a.octF[(size_t)a.os * f], 0), a.nlevels - 1);
+                        double bound = 5.99;
+                        if (kr >= 0.f) {
+                            const float er = __fsub_rn(Q.ur, kr);
+                            e2 = __fadd_rn(e2, __fmul_rn(er, er));
+                            bound = 7.8;
+                        }
+                        skip = (double)__fmul_rn(e2, a.inv_sigma2[lv]) > bound;
+                    }
+                    const uint32_t d = skip ? PJ_SKIP : (uint32_t)hamming8(dq, (const uint32_t *)(a.descF + (int64_t)f * 32));
+                    ent[o] = f | (d << 16);
+                    if (!skip) {
+                        const uint32_t key = (d << 16) | o;
+                        if (key < k1) { k2 = k1; f2 = f1; k1 = key; f1 = (int)f; }
+                        else if (key < k2) { k2 = key; f2 = (int)f; }
+                    }
+                    ++o;
+                });
+                proj_reduce2<64>(k1, f1, k2, f2);
+            }
+            if (lane == 0) {
+                int bd, bd2;
+                a.match[i] = proj_decide(a, k1, k2, f1, f2, bd, bd2);   // round 0: every slot free
+                a.best[i] = bd;
+                a.second[i] = bd2;
+                a.cnt[i] = (uint32_t)min(tot, PJ_SLAB);
+                p.f12[2 * i] = f1;
+                p.f12[2 * i + 1] = f2;
+                p.constrained[i] = 0;
+            }
+        }
+    }
+}
+
+// the remaining rounds, ONE workgroup, launched behind k_proj_fused (the launch boundary makes the slabs visible; an in-kernel
+// hand-over to "the last workgroup to arrive" was measured: the agent-scope fences cost more than the launch, 95 against 82 us)
+__global__ __launch_bounds__(PJ_FT) void k_proj_rounds(ProjFusedArgs p)
+{
+    extern __shared__ int32_t s_dyn[];     // [nF] owner table, then [nq] the queries that re-scan
+    __shared__ int s_changed, s_nlist;
+    const ProjArgs &a = p.a;
+    const int tid = threadIdx.x;
+    const int nq = a.nq, nF = a.nF;
+    int32_t *s_owner = s_dyn, *s_list = s_dyn + nF;
+    const uint32_t need = p.done[1];
+    int round = 1;
+    if (need == 0) {
+        for (; round <= nq + 2; ++round) {
+            for (int f = tid; f < nF; f += PJ_FT) s_owner[f] = 0x7FFFFFFF;
+            if (tid == 0) { s_changed = 0; s_nlist = 0; }
+            __syncthreads();
+            for (int i = tid; i < nq; i += PJ_FT) {
+                const int mt = a.match[i];
+                if (mt >= 0 && (a.q[i].flags & ORBFE_PROJ_CLAIMS)) atomicMin(&s_owner[mt], i);
+            }
+            __syncthreads();
+            for (int i = tid; i < nq; i += PJ_FT) {
+                const int f1 = p.f12[2 * i], f2 = p.f12[2 * i + 1];
+                if (p.constrained[i] || (f1 >= 0 && s_owner[f1] < i) || (f2 >= 0 && s_owner[f2] < i)) s_list[atomicAdd(&s_nlist, 1)] = i;
+            }
+            __syncthreads();
+            const int nl = s_nlist;
+            if (nl == 0) break;               // workgroup-uniform
+            const int sub = tid % PJ_L, grp = tid / PJ_L;
+            bool changed = false;
+            for (int l0 = 0; l0 < nl; l0 += PJ_FT / PJ_L) {
+                const int li = l0 + grp;
+                const int i = li < nl ? s_list[li] : -1;
+                uint32_t k1 = PJ_NOKEY, k2 = PJ_NOKEY;
+                int f1 = -1, f2 = -1;
+                bool skipped = false;
+                if (i >= 0) {
+                    const uint32_t *ent = a.ent + (size_t)i * PJ_SLAB;
+                    const uint32_t e = a.cnt[i];
+                    for (uint32_t k = sub; k < e; k += PJ_L) {
+                        const uint32_t en = ent[k];
+                        const uint32_t f = en & 0xFFFFu, d = en >> 16;
+                        if (d == PJ_SKIP) continue;
+                        if (s_owner[f] < i) { skipped = true; continue; }   // taken by an earlier query of this call
+                        const uint32_t key = (d << 16) | k;
+                        if (key < k1) { k2 = k1; f2 = f1; k1 = key; f1 = (int)f; }
+                        else if (key < k2) { k2 = key; f2 = (int)f; }
+                    }
+                }
+                proj_reduce2<PJ_L>(k1, f1, k2, f2);
+#pragma unroll
+                for (int s = PJ_L / 2; s > 0; s >>= 1) skipped = skipped || __shfl_xor((int)skipped, s, PJ_L) != 0;
+                if (i >= 0 && sub == 0) {
+                    int bd, bd2;
+                    const int mt = proj_decide(a, k1, k2, f1, f2, bd, bd2);
+                    if (mt != a.match[i]) {
+                        a.match[i] = mt;
+                        changed = true;
+                    }
+                    a.best[i] = bd;
+                    a.second[i] = bd2;
+                    p.f12[2 * i] = f1;
+                    p.f12[2 * i + 1] = f2;
+                    p.constrained[i] = skipped ? 1 : 0;
+                }
+            }
+            if (changed) s_changed = 1;
+            __syncthreads();
+            if (!s_changed) break;            // workgroup-uniform
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // results to the host; the counters back to zero for the next call
+    for (int i = tid; i < nq; i += PJ_FT) {
+        p.h_out[i] = a.match[i];
+        p.h_out[nq + i] = a.best[i];
+        p.h_out[2 * (size_t)nq + i] = a.second[i];
+    }
+    if (tid == 0) {
+        p.h_out[3 * (size_t)nq] = (int32_t)need;   // > 0: some query has that many candidates; nothing above is valid
+        p.h_out[3 * (size_t)nq + 1] = round + 1;
+        p.done[1] = 0u;
+    }
+}
+
 extern "C" orbfe_status orbfe_search_by_projection_chi2(orbfe_matcher *m, const uint8_t *descF, const float *xyF, const int32_t *octF,
                                                         int32_t nF, const uint32_t *cell_off, const uint32_t *cell_idx, float minx,
                                                         float miny, float gw_inv, float gh_inv, const float *uRight,
@@ -1686,9 +1913,40 @@ extern "C" orbfe_status orbfe_search_by_projection_chi2(orbfe_matcher *m, const 
     a.cnt = (uint32_t *)m->b[2].p;
     a.lcnt = (uint16_t *)m->b[3].p;
     a.off = (uint32_t *)m->b[4].p;
+    const int32_t *hout = (const int32_t *)m->pin_out.p;
+    // ONE launch (k_proj_fused) when the owner table and the re-scan list fit the LDS and no query overflows its slab; else (or on
+    // overflow, reported in status[0]) the four-kernel path below
+    const size_t fused_lds = ((size_t)std::max(nF, 1) + (size_t)nq) * 4;
+    if (m->proj_fused && fused_lds <= 64 * 1024) {
+        ORBFE_HIP(m->b[5].ensure((size_t)nq * PJ_SLAB * 4));
+        ORBFE_HIP(m->b[6].ensure((size_t)nq * 8));
+        ORBFE_HIP(m->b[7].ensure((size_t)nq));
+        if (!m->proj_done.p) {
+            ORBFE_HIP(m->proj_done.ensure(256));
+            ORBFE_HIP(hipMemsetAsync(m->proj_done.p, 0, 256, st));   // the kernel leaves its counters at zero
+        }
+        ProjFusedArgs fa;
+        fa.a = a;
+        fa.a.ent = (uint32_t *)m->b[5].p;
+        fa.a.ent_cap = 0xFFFFFFFFu;
+        fa.f12 = (int32_t *)m->b[6].p;
+        fa.constrained = (uint8_t *)m->b[7].p;
+        fa.done = (uint32_t *)m->proj_done.p;
+        fa.h_out = (int32_t *)m->pin_out.p;   // page-locked and mapped: the kernel stores the results there
+        const int nwg = (nq + PJ_FT / 64 - 1) / (PJ_FT / 64);
+        hipLaunchKernelGGL(k_proj_fused, dim3(nwg), dim3(PJ_FT), 0, st, fa);
+        hipLaunchKernelGGL(k_proj_rounds, dim3(1), dim3(PJ_FT), fused_lds, st, fa);
+        ORBFE_HIP(hipGetLastError());
+        ORBFE_HIP(hipStreamSynchronize(st));
+        if (hout[3 * (size_t)nq] == 0) {
+            memcpy(match, hout, (size_t)nq * 4);
+            if (best) memcpy(best, hout + nq, (size_t)nq * 4);
+            if (second) memcpy(second, hout + 2 * (size_t)nq, (size_t)nq * 4);
+            return ORBFE_OK;
+        }
+    }
     const int ngrp = (nq * PJ_LC + 255) / 256;
     size_t ent_cap = std::max<size_t>((size_t)nq * 96, 1 << 16);
-    const int32_t *hout = (const int32_t *)m->pin_out.p;
     for (int attempt = 0; attempt < 2; ++attempt) {
         ORBFE_HIP(m->b[5].ensure(ent_cap * 4));
         a.ent = (uint32_t *)m->b[5].p;

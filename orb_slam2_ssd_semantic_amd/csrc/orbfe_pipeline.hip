@@ -49,6 +49,10 @@ struct orbfe_pipeline {
     std::vector<hipEvent_t> ev_match;  // per sub-batch index: matcher finished (most recent call)
     std::vector<char> ev_match_valid;
     std::vector<char> ev_ext_valid;
+    // the output slices the events of index j stand for (keypoint block, descriptor block, counts): a later call that lays its
+    // sub-batches over other addresses (shifted base pointer, another call size) is ordered by ADDRESS, not by index
+    struct Slice { const char *k = nullptr, *d = nullptr, *n = nullptr; size_t kb = 0, db = 0, nb = 0; };
+    std::vector<Slice> ev_slice;
     hipEvent_t ev_fork = nullptr;
     // seq[i] = i - 1: qframe = seq + q0 + 1 (q0, q0 + 1, ...), tframe = seq + q0 (q0 - 1, q0, ...)
     int32_t *d_seq = nullptr;
@@ -60,6 +64,7 @@ struct orbfe_pipeline {
     hipEvent_t ev_carry[2] = {nullptr, nullptr};
     hipEvent_t ev_m0[2] = {nullptr, nullptr};   // behind the frame-0 match of a call that READ carry slot k (recorded on that call's pipe)
     bool m0_valid[2] = {false, false};
+    bool carry_written[2] = {false, false};
     int carry_cur = 0;          // slot the NEXT call reads
     bool have_carry = false;
     // where the carried frame was copied FROM (the caller's blocks of the previous call): a sub-batch of the next call that
@@ -91,6 +96,7 @@ static orbfe_status ensure_events(orbfe_pipeline *pl, int nsub)
         pl->ev_match.push_back(b);
         pl->ev_match_valid.push_back(0);
         pl->ev_ext_valid.push_back(0);
+        pl->ev_slice.push_back(orbfe_pipeline::Slice());
     }
     return ORBFE_OK;
 }
@@ -210,7 +216,16 @@ extern "C" orbfe_status orbfe_pipeline_create(const orbfe_params *p, int32_t npi
         if (s != ORBFE_OK) return fail(s);
         pl->mat.push_back(m);
     }
-    pl->cap = orbfe_keypoint_capacity(pl->ext[0]);
+    // Slots per frame of the host sets and the carry blocks: the extractor's capacity for the planned max_width x max_height, and
+    // never less than what ANY frame size can ask for -- a level's selection holds max(N_l + 2, 4 * roots) keypoints and the root
+    // count follows the frame's aspect ratio (at most ORBFE_MAX_ROOTS): a later call with another w / ht finds room.
+    {
+        int32_t feat[ORBFE_MAX_LEVELS];
+        int worst = 0;
+        if (orbfe_get_features_per_level(pl->ext[0], feat) == ORBFE_OK)
+            for (int l = 0; l < pl->prm.nlevels; ++l) worst += std::max(feat[l] + 2, 4 * ORBFE_MAX_ROOTS);
+        pl->cap = std::max(orbfe_keypoint_capacity(pl->ext[0]), (worst + 63) & ~63);
+    }
     if (hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess) { orbfe_set_error("pipeline event creation failed"); return fail(ORBFE_ERR_HIP); }
     for (int k = 0; k < 2; ++k) {
         if (hipEventCreateWithFlags(&pl->ev_carry[k], hipEventDisableTiming) != hipSuccess ||
@@ -311,6 +326,15 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
     // blocks of an earlier call)
     ORBFE_HIP(hipEventRecord(pl->ev_fork, cs));
     for (int p = 0; p < P; ++p) ORBFE_HIP(hipStreamWaitEvent(pl->st[(size_t)p], pl->ev_fork, 0));
+    // An error in the middle of the loop leaves launches of this call in flight and the event / carry bookkeeping half
+    // updated: drain the pipes and start the sequence over (the next call has no predecessor frame), then report.
+    auto bail = [&](orbfe_status e) {
+        for (hipStream_t x : pl->st) (void)hipStreamSynchronize(x);
+        pl->have_carry = false;
+        pl->m0_valid[0] = pl->m0_valid[1] = false;
+        pl->joined = true;
+        return e;
+    };
     auto overlaps = [](const void *a, size_t na, const void *b, size_t nb) {
         const char *pa = (const char *)a, *pb = (const char *)b;
         return a && b && pa < pb + nb && pb < pa + na;
@@ -324,10 +348,25 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
         // the PREVIOUS call did with slices j happened on other pipes' streams.  This sub-batch overwrites them only after that
         // call's extraction of sub-batch j (write after write), its matcher of sub-batch j (queries) and its matcher of
         // sub-batch j + 1 (whose first pair reads the last frame of slice j) have finished.  (Events of finished work cost nothing.)
-        if (pl->ev_ext_valid[(size_t)j]) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_ext[(size_t)j], 0));
-        if (pl->ev_match_valid[(size_t)j]) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_match[(size_t)j], 0));
-        if (j + 1 < (int)pl->ev_match_valid.size() && pl->ev_match_valid[(size_t)j + 1])
-            ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_match[(size_t)j + 1], 0));
+        {
+            const char *ok = (const char *)(d_kps + (size_t)lo * cap), *od = (const char *)(d_desc + (size_t)lo * cap * 32), *on = (const char *)(d_n_out + lo);
+            const size_t okb = (size_t)nf * cap * sizeof(orbfe_keypoint), odb = (size_t)nf * cap * 32, onb = (size_t)nf * sizeof(int32_t);
+            auto wait_index = [&](size_t i) -> hipError_t {   // everything that wrote or read the slices recorded under index i
+                hipError_t e = hipSuccess;
+                if (pl->ev_ext_valid[i]) e = hipStreamWaitEvent(st, pl->ev_ext[i], 0);
+                if (e == hipSuccess && pl->ev_match_valid[i]) e = hipStreamWaitEvent(st, pl->ev_match[i], 0);
+                if (e == hipSuccess && i + 1 < pl->ev_match_valid.size() && pl->ev_match_valid[i + 1]) e = hipStreamWaitEvent(st, pl->ev_match[i + 1], 0);
+                return e;
+            };
+            // index j (its events are about to be re-recorded), and every other index whose recorded slices overlap this sub-batch's:
+            // with the usual re-use of the same buffers and call size that is index j alone
+            ORBFE_HIP(wait_index((size_t)j));
+            for (size_t i = 0; i < pl->ev_slice.size(); ++i) {
+                const orbfe_pipeline::Slice &si = pl->ev_slice[i];
+                if ((int)i != j && si.k && (overlaps(si.k, si.kb, ok, okb) || overlaps(si.d, si.db, od, odb) || overlaps(si.n, si.nb, on, onb)))
+                    ORBFE_HIP(wait_index(i));
+            }
+        }
         // ... and the copy of the previous call's last frame into the carry slot must have read it before this sub-batch
         // writes over it (only the sub-batch whose output slices cover those addresses waits: no drain at the call boundary)
         if (pl->have_carry &&
@@ -337,9 +376,15 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
             ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_carry[rd], 0));
         s = orbfe_extract_batch_device(pl->ext[(size_t)p], d_gray + (size_t)lo * frame_stride, nf, w, ht, stride, frame_stride,
                                        d_kps + (size_t)lo * cap, d_desc + (size_t)lo * cap * 32, cap, d_n_out + lo, (void *)st);
-        if (s != ORBFE_OK) return s;
+        if (s != ORBFE_OK) return bail(s);
         ORBFE_HIP(hipEventRecord(pl->ev_ext[(size_t)j], st));
         pl->ev_ext_valid[(size_t)j] = 1;
+        {
+            orbfe_pipeline::Slice &sj = pl->ev_slice[(size_t)j];
+            sj.k = (const char *)(d_kps + (size_t)lo * cap); sj.kb = (size_t)nf * cap * sizeof(orbfe_keypoint);
+            sj.d = (const char *)(d_desc + (size_t)lo * cap * 32); sj.db = (size_t)nf * cap * 32;
+            sj.n = (const char *)(d_n_out + lo); sj.nb = (size_t)nf * sizeof(int32_t);
+        }
         if (!match) continue;
         if (j > 0) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_ext[(size_t)j - 1], 0));   // frame lo - 1 comes from the neighbour pipe
         const int q0 = lo == 0 ? 1 : lo;
@@ -348,7 +393,7 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
             s = orbfe_match_bf_blocks_device(pl->mat[(size_t)p], d_kps, d_desc, d_n_out, d_kps, d_desc, d_n_out, cap, pl->d_seq + q0 + 1,
                                              pl->d_seq + q0, np, nnratio, th, check_ori, d_match + (size_t)q0 * cap, d_nmatches + q0,
                                              (void *)st);
-            if (s != ORBFE_OK) return s;
+            if (s != ORBFE_OK) return bail(s);
         }
         if (lo == 0) {
             if (cont) {
@@ -356,7 +401,7 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
                 // query = frame 0 of this call, train = the carried frame (frame 0 of the carry block)
                 s = orbfe_match_bf_blocks_device(pl->mat[(size_t)p], d_kps, d_desc, d_n_out, pl->d_ckps[rd], pl->d_cdesc[rd], pl->d_cn[rd], cap,
                                                  pl->d_seq + 1, pl->d_seq + 1, 1, nnratio, th, check_ori, d_match, d_nmatches, (void *)st);
-                if (s != ORBFE_OK) return s;
+                if (s != ORBFE_OK) return bail(s);
                 ORBFE_HIP(hipEventRecord(pl->ev_m0[rd], st));   // slot rd has been read: the NEXT call may write it
                 pl->m0_valid[rd] = true;
             } else {  // the first frame of a sequence has no predecessor
@@ -381,11 +426,15 @@ extern "C" orbfe_status orbfe_pipeline_extract_match_device(orbfe_pipeline *pl, 
             ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_m0[wr], 0));
             pl->m0_valid[wr] = false;
         }
+        // ... and behind the previous WRITER of the slot (two calls ago, possibly on another pipe's stream): calls without a frame-0
+        // match (extract only, no CONTINUE) record no ev_m0, and nothing else would order the two copies
+        if (pl->carry_written[wr]) ORBFE_HIP(hipStreamWaitEvent(st, pl->ev_carry[wr], 0));
         ORBFE_HIP(hipMemcpyAsync(pl->d_ckps[wr], d_kps + last * cap, (size_t)std::min(cap, pl->cap) * sizeof(orbfe_keypoint),
                                  hipMemcpyDeviceToDevice, st));
         ORBFE_HIP(hipMemcpyAsync(pl->d_cdesc[wr], d_desc + last * cap * 32, (size_t)std::min(cap, pl->cap) * 32, hipMemcpyDeviceToDevice, st));
         ORBFE_HIP(hipMemcpyAsync(pl->d_cn[wr], d_n_out + last, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         ORBFE_HIP(hipEventRecord(pl->ev_carry[wr], st));
+        pl->carry_written[wr] = true;
         pl->carry_cur = wr;
         pl->have_carry = true;
         pl->carry_src[0] = d_kps + last * cap;

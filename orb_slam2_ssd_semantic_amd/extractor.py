@@ -51,6 +51,10 @@ class ORBextractor:
         debug, and -- developer builds only -- pyr_fuse, fuse_blur_pyr, fuse_fast_pyr, fuse_fast_pyr_levels)"""
         check(self._L.orbfe_set_option(self._h, _ffi.OPTIONS[name], int(value)), f"orbfe_set_option({name}, {value})")
 
+    def last_call_reused(self):
+        """True when the last __call__ was answered from the previous call's results (option reuse_identical_input)"""
+        return bool(self._L.orbfe_last_call_reused(self._h))
+
     def __del__(self):
         self.close()
 

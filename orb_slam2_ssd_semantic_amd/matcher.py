@@ -110,6 +110,10 @@ class ORBmatcher:
         """0 = matrix-core int8 dot product (default), 1 = xor / popcount: same results (orbfe_matcher_set_bf_kernel)"""
         check(self._L.orbfe_matcher_set_bf_kernel(self._m, int(kernel)), "orbfe_matcher_set_bf_kernel")
 
+    def set_projection_kernel(self, kernel):
+        """0 = the projection search in one launch (default), 1 = the four-kernel path: same results (orbfe_matcher_set_projection_kernel)"""
+        check(self._L.orbfe_matcher_set_projection_kernel(self._m, int(kernel)), "orbfe_matcher_set_projection_kernel")
+
     def SearchByBoW_batch_device(self, d_kps, d_desc, cap, d_valid, d_fv_node, d_fv_off, d_fv_idx, d_counts, d_kf, d_f,
                                  npairs, d_match, d_nmatches, kf_kf=False, th_low=None, stream=None):
         """SearchByBoW for a batch of (KeyFrame, Frame) pairs taken from device-resident extractor / BoW blocks

@@ -64,6 +64,7 @@ bool ORBextractor::EnsureHandle(int w, int h)
     mPlanW = p.max_width;
     mPlanH = p.max_height;
     mPlanBlur = mnBlurRounding;
+    if (mbReuseIdenticalInput) orbfe_set_option(mpHandle, ORBFE_OPT_REUSE_IDENTICAL_INPUT, 1);
     orbfe_get_scales(mpHandle, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data());
     orbfe_get_features_per_level(mpHandle, mnFeaturesPerLevel.data());
     return true;
@@ -96,7 +97,11 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
         cv::Mat out = _descriptors.getMat();
         for (int i = 0; i < n; ++i) memcpy(out.ptr<uint8_t>(i), desc.ptr<uint8_t>(i), 32);
     }
-    if (mbKeepPyramid) SyncImagePyramid();
+    // a call answered from the previous one's results left the device pyramid as it was: the host copy made then is still it
+    const bool reused = orbfe_last_call_reused(mpHandle) != 0;
+    if (reused) ++mnReusedCalls;
+    if (mbKeepPyramid && !(reused && mbPyramidSynced)) SyncImagePyramid();
+    if (!mbKeepPyramid && !reused) mbPyramidSynced = false;
 }
 
 void ORBextractor::SyncImagePyramid()
@@ -134,6 +139,7 @@ void ORBextractor::SyncImagePyramid()
         mvImagePyramid[l] = mvPadded[l].roi(E, E, w, h);
 #endif
     }
+    mbPyramidSynced = true;
 }
 
 }  // namespace ORB_SLAM2

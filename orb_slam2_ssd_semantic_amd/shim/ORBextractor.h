@@ -52,6 +52,20 @@ public:
 #endif
     int mnBlurRounding = ORBFE_SHIM_BLUR_ROUNDING;
 
+    // perfect/src/Tracking.cc:685 and :716 construct two Frames from the SAME mImGray with the same extractor (the second with the
+    // dynamic-object mask, which operator() ignores): with this flag the second operator() is answered from the first one's
+    // results (ORBFE_OPT_REUSE_IDENTICAL_INPUT: a host compare against the staged previous frame, no GPU work, no pyramid copy).
+    // On in a -DORBFE_SHIM_PERFECT build (the tree that has that call pattern), off otherwise.  Set before the first operator().
+#ifndef ORBFE_SHIM_REUSE_IDENTICAL_INPUT
+#ifdef ORBFE_SHIM_PERFECT
+#define ORBFE_SHIM_REUSE_IDENTICAL_INPUT 1
+#else
+#define ORBFE_SHIM_REUSE_IDENTICAL_INPUT 0
+#endif
+#endif
+    bool mbReuseIdenticalInput = ORBFE_SHIM_REUSE_IDENTICAL_INPUT != 0;
+    long mnReusedCalls = 0;   // operator() calls answered that way
+
     int LastStatus() const { return mLastStatus; }  // orbfe_status of the last call (the reference has no error path)
     // the C handle, for calls that keep the pyramid on the device (orbfe_stereo_matches); null before the first operator()
     orbfe_handle *handle() const { return mpHandle; }
@@ -69,6 +83,7 @@ private:
     bool EnsureHandle(int w, int h);
     orbfe_handle *mpHandle = nullptr;
     int mPlanW = 0, mPlanH = 0, mPlanBlur = -1, mLastStatus = 0;
+    bool mbPyramidSynced = false;   // mvImagePyramid holds the frame the handle's device pyramid holds
     std::vector<cv::Mat> mvPadded;
     cv::Mat mPadBlock;  // all padded levels of the last frame, one allocation, one device-to-host copy
     ORBextractor(const ORBextractor &);

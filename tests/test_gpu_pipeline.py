@@ -365,3 +365,54 @@ def test_pipeline_at_config5_and_config4_shapes_equals_one_batched_call():
         assert int(outs[0][2].min()) > 0.9 * nf
         pl.close()
         e.close()
+
+
+@pytest.mark.gpu
+def test_unjoined_calls_over_shifted_and_differently_sized_slices_are_ordered_by_address(oracle):
+    """ORBFE_PIPE_NO_JOIN calls whose output slices do not line up with the previous call's sub-batch indices: a ring of
+    output slots written by calls of varying size at a moving offset -- slices recorded under index i of one call are overwritten
+    under index j != i of a later one -- and extract-only calls in between (no frame-0 match: the carry slot's write-after-write).
+    Nothing is joined until the end of a lap; every frame's rows must be the oracle's, whichever call wrote them last."""
+    import torch
+    from orb_slam2_ssd_semantic_amd import FramePipeline
+    w, h, nf, sub = 640, 480, 1000, 4
+    rng = np.random.default_rng(9)
+    N = 48
+    frames = np.stack([synth_frame(9100 + i, h, w, sparse=(i % 3 == 1)) for i in range(N)])
+    ref = oracle_sequence(frames, nf)
+    pl = FramePipeline(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, sub_batch=sub, npipes=3)
+    cap = pl.capacity()
+    dg = torch.from_numpy(frames).cuda()
+    R = 20   # ring of output slots
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")  # noqa: E731
+    dk, dd, dn, dm, dnm = z((R, cap, 7), torch.int32), z((R, cap, 32), torch.uint8), z(R, torch.int32), z((R, cap), torch.int32), z(R, torch.int32)
+    st = torch.cuda.current_stream().cuda_stream
+    for lap in range(3):
+        owner = {}          # ring slot -> (frame index, has match row, predecessor frame or None)
+        lo, off, c = 0, int(rng.integers(0, R)), 0
+        pl.reset_sequence()
+        while lo < N:
+            n = min(int(rng.integers(1, 11)), N - lo)
+            if off + n > R:
+                off = int(rng.integers(0, 3))          # wrap: the new slices straddle old ones at another alignment
+            with_match = (c % 4) != 2                  # every fourth call is extract only
+            pl.extract_match_device(dg[lo].data_ptr(), n, w, h, w, w * h, dk[off].data_ptr(), dd[off].data_ptr(), cap, dn[off:].data_ptr(),
+                                    dm[off].data_ptr() if with_match else None, dnm[off:].data_ptr() if with_match else None,
+                                    flags=pl.NO_JOIN | (pl.CONTINUE if c else 0), stream=st)
+            for i in range(n):
+                prev = lo + i - 1
+                # a call behind an extract-only call has no carried predecessor for its frame 0?  No: the carry is the previous
+                # call's last frame whether or not that call matched; only the very first call of the lap has none
+                owner[off + i] = (lo + i, with_match, prev if prev >= 0 else None)
+            lo += n
+            off += n
+            c += 1
+        pl.synchronize()
+        torch.cuda.synchronize()
+        hn, hk, hd, hm, hnm = (t.cpu().numpy() for t in (dn, dk, dd, dm, dnm))
+        for slot, (f, with_match, prev) in owner.items():
+            pred = ref[prev] if prev is not None else None
+            check_sequence(oracle, [ref[f]], hn[slot:slot + 1], hk[slot:slot + 1], hd[slot:slot + 1], hm[slot:slot + 1] if with_match else None,
+                           hnm[slot:slot + 1] if with_match else None, first_has_pred=pred, label=f"lap {lap} slot {slot} frame {f}")
+        assert pl.overflow() == 0
+    pl.close()

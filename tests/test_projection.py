@@ -21,10 +21,14 @@ def _core_both(mat, cur, q, qdesc, th, nnratio, rule):
     return (om, ob, os_), (gm, gb, gs)
 
 
-@pytest.fixture(scope="module")
-def mat():
+@pytest.fixture(scope="module", params=[0, 1], ids=["one-launch", "four-kernel"])
+def mat(request):
+    """both forms of the device core: k_proj_fused (default; falls back by itself when a query has > 512 candidates -- the tight
+    cluster of test_core_long_dependency_chains does that) and count -> scan -> fill -> resolve"""
     from orb_slam2_ssd_semantic_amd import ORBmatcher
-    return ORBmatcher(0.9, True)
+    m = ORBmatcher(0.9, True)
+    m.set_projection_kernel(request.param)
+    return m
 
 
 @pytest.mark.gpu

@@ -19,11 +19,16 @@ q, valid = O.proj_queries_last_frame(cur["Tcw"], last["Tcw"], cur["K"], cur["bou
 sel = valid.astype(bool)
 ci = PC.core_inputs(cur)
 qq, qd = q[sel], last["mpdesc"][sel]
-for _ in range(5):
-    mat.SearchByProjectionCore(queries=qq, qdesc=qd, th=100, nnratio=0.0, ratio_rule=0, **ci)
-t = []
-for _ in range(50):
-    t0 = time.perf_counter()
-    mat.SearchByProjectionCore(queries=qq, qdesc=qd, th=100, nnratio=0.0, ratio_rule=0, **ci)
-    t.append(time.perf_counter() - t0)
-print("queries", len(qq), "median call ms", round(float(np.median(t)) * 1e3, 4), "min", round(min(t) * 1e3, 4))
+res = {}
+for kernel, name in ((0, "one-launch (k_proj_fused)"), (1, "four-kernel"), (0, "one-launch (k_proj_fused) again")):
+    mat.set_projection_kernel(kernel)
+    for _ in range(5):
+        out = mat.SearchByProjectionCore(queries=qq, qdesc=qd, th=100, nnratio=0.0, ratio_rule=0, **ci)
+    t = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        mat.SearchByProjectionCore(queries=qq, qdesc=qd, th=100, nnratio=0.0, ratio_rule=0, **ci)
+        t.append(time.perf_counter() - t0)
+    res[name] = out
+    print(name, "queries", len(qq), "median call ms", round(float(np.median(t)) * 1e3, 4), "min", round(min(t) * 1e3, 4))
+assert all(np.array_equal(a, b) for a, b in zip(res["one-launch (k_proj_fused)"], res["four-kernel"]))
