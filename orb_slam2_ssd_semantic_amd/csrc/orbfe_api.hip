@@ -597,6 +597,29 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
     // then writes whole 64-byte pieces.  (Border waves holding only the 2 - 3 reflected columns of 20-odd row blocks wrote a
     // lone dword into 64 different lines per store: WRITE_SIZE was 1.19x the output, profiles/r04_ab_experiments.json;
     // ORBFE_OPT_BLUR_PIECES = 0 brings that packing back for the A/B.)
+    // k_blur7's border lanes: folded horizontal weights per (level, lane type) -- tap t of output pixel c sits on column
+    // reflect101(c - 3 + t), and taps that land on the same column add up (at most 49 + 49: a byte)
+    for (int l = 0; l < nl; ++l) {
+        const OrbLevel &L = P.lv[l];
+        if (L.w < 16) { orbfe_set_error("level %d too narrow for the blur kernel", l); return ORBFE_ERR_SIZE; }
+        const int kern[7] = {18, 34, 49, 55, 49, 34, 18};
+        const int xlast = ((L.w - 1) / 4) * 4;
+        const int xs[4] = {4, 0, xlast - 4, xlast};   // a lane of every type
+        for (int ty = 0; ty < 4; ++ty) {
+            const int x = xs[ty], base = std::min(std::max(x - 4, 0), L.w - 12);
+            for (int j = 0; j < 4; ++j) {
+                const int c = std::min(x + j, L.w - 1);   // output pixels past the row's end are computed and not stored
+                for (int t = 0; t < 7; ++t) {
+                    int col = c - 3 + t;
+                    if (col < 0) col = -col;
+                    if (col >= L.w) col = 2 * L.w - 2 - col;
+                    const int bi = col - base;
+                    if (bi < 0 || bi > 11) { orbfe_set_error("level %d: blur window of column %d does not hold column %d", l, x, col); return ORBFE_ERR_SIZE; }
+                    P.blur_wt[l][ty][3 * j + bi / 4] += (uint32_t)kern[t] << (8 * (bi % 4));
+                }
+            }
+        }
+    }
     std::vector<OrbLane> blanes;
     std::vector<OrbLaneR> blanesR;   // the resize job of every blur lane (fused blur + pyramid pass), same index
     const bool blur_pieces = h->opt_blur_pieces != 0;

@@ -116,6 +116,10 @@ struct OrbPlan {
     int32_t blur_split;        // the blur lane list also holds resize waves (flag bit 2): k_blur_pyr<., 1>; the plain k_blur7 launch skips them
     int64_t pyr_frame_bytes;   // bytes of one frame's pyramid slice (levels 1..n-1; level 0 kept too when owned)
     OrbLevel lv[ORBFE_MAX_LEVELS];
+    // k_blur7, border waves: the horizontal taps of a lane with BORDER_REFLECT_101 folded into them.  [level][lane type][3 * j + d] =
+    // weight bytes of window dword d for the lane's output pixel j; lane type 0: no reflected column (window = x - 4 .. x + 7), 1: x = 0,
+    // 2: 4 < w - x <= 8, 3: w - x <= 4 (window pulled back to end at the row's last pixel)
+    uint32_t blur_wt[ORBFE_MAX_LEVELS][4][12];
 };
 
 // packed FAST candidate: x (12 bit) | y (12 bit) << 12 | response (8 bit) << 24, detection-window coords

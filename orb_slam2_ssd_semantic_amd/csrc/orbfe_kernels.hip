@@ -1457,7 +1457,7 @@ __host__ __device__ constexpr uint32_t blur_hw(int j, int d)
 // covers all (reflected) source pixels of its 12-byte window and rearranges them with per-lane byte selectors
 // (identity for interior lanes); row borders are a per-lane reflected row index.
 #ifndef BL_PF
-#define BL_PF 2  // prefetch distance in rows
+#define BL_PF 4  // prefetch distance in rows (2 .. 6 measured: profiles/r06_ab_blur.json)
 #endif
 #ifdef BL_MIN_WAVES
 #define BL_BOUNDS __launch_bounds__(256, BL_MIN_WAVES)
@@ -1465,69 +1465,66 @@ __host__ __device__ constexpr uint32_t blur_hw(int j, int d)
 #define BL_BOUNDS __launch_bounds__(256)
 #endif
 // the row walk of one lane; INTERIOR (wave-uniform, compile-time): the 12-byte window holds no reflected column; UP (wave-uniform,
-// compile-time): the walk goes from the bottom of the row block to its top
+// compile-time): the walk goes from the bottom of the row block to its top.
+//
+// Instruction budget of a row step (4 pixels per lane): 10 v_dot4 horizontal taps (border waves: 12, below), the vertical taps on
+// u16 row-sum PAIRS -- a pair (row 2m, row 2m + 1) is formed once, on the odd step (4 v_lshl_or every other step), and the seven
+// rows of an output are three pairs and one single row on even steps, the high half of a pair and three pairs on odd ones, i.e.
+// four v_dot2 per pixel either way -- saturate_cast<uchar> by the dot products' own clamp (the accumulator starts at
+// 0xFF000000 + the rounding constant, so a value >= 256 runs into 0xFFFFFFFF and byte 2 IS the saturated pixel), three v_perm to
+// gather the four bytes, one compare against the lane's row count, one add each for the load and the store offset.
+//
+// Border waves (reflected columns): BORDER_REFLECT_101 folds the taps that fall outside the row onto pixels inside it, so a
+// border lane reads its 12-byte window as it lies (pulled inside the row) and applies FOLDED weights: twelve per-lane weight
+// dwords from the plan's table (OrbPlan::blur_wt, four lane types per level) instead of byte selectors -- no v_perm per row.
 template <int MODE, bool INTERIOR, bool UP>
 __device__ __forceinline__ void blur7_walk(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int pitch, const int dpitch,
-                                           const int W, const int H, const int x, const int y0, const int yend, const bool active,
-                                           const int nsteps, const int vec_w)
+                                           const int W, const int H, const int x, const int y0, const int nrows_lane, const bool active,
+                                           const int nsteps, const int vec_w, const uint32_t *__restrict__ wtab)
 {
     constexpr bool up = UP;
-    // window pixel i (0..11) is level column reflect101(x - 4 + i); i = 0 and 11 are never used
-    // (interior waves -- no reflected column, the host packs them apart -- take their 12-byte window as it lies: no selectors)
-    int srcx[12], lo = W;
+    // all sources of the lane's ten window pixels lie in [base, base + 12) (checked on the host for every level width); at the
+    // right edge the window is pulled back so that it ends at the last pixel of the row
+    const int base = INTERIOR ? x - 4 : min(max(x - 4, 0), W - 12);
+    uint32_t wt[4][3];
     if (!INTERIOR) {
-#pragma unroll
-        for (int i = 1; i < 11; ++i) {
-            srcx[i] = reflect101(min(x - 4 + i, W + 2), W);
-            lo = min(lo, srcx[i]);
-        }
-        srcx[0] = srcx[1];
-        srcx[11] = srcx[10];
-    }
-    // all ten sources lie in [base, base + 12) (checked on the host for every level width); at the right edge the
-    // window is pulled back so that it ends at the last pixel of the row
-    const int base = INTERIOR ? x - 4 : min(lo & ~3, W - 12);
-    uint32_t selA[3], selB[3], mskB[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        selA[d] = selB[d] = mskB[d] = 0u;
-        if (!INTERIOR) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int bi = min(max(srcx[4 * d + k] - base, 0), 11);  // loaded byte index
-                if (bi < 8) selA[d] |= (uint32_t)bi << (8 * k);           // from {w1:w0}
-                else {
-                    selB[d] |= (uint32_t)(bi - 8) << (8 * k);             // from w2
-                    mskB[d] |= 0xFFu << (8 * k);
-                }
-            }
-        }
+        const int r = W - x;
+        const int type = x == 0 ? 1 : (r <= 4 ? 3 : (r <= 8 ? 2 : 0));
+        const uint4 *t = (const uint4 *)(wtab + type * 12);
+        const uint4 t0 = t[0], t1 = t[1], t2 = t[2];
+        wt[0][0] = t0.x; wt[0][1] = t0.y; wt[0][2] = t0.z; wt[1][0] = t0.w;
+        wt[1][1] = t1.x; wt[1][2] = t1.y; wt[2][0] = t1.z; wt[2][1] = t1.w;
+        wt[2][2] = t2.x; wt[3][0] = t2.y; wt[3][1] = t2.z; wt[3][2] = t2.w;
     }
     const bool full = x + 4 <= W;
+    const uint32_t nrows = active ? (uint32_t)nrows_lane : 0u;
 
-    // Row sums are <= 255 * 257 = 65535, i.e. u16: ring slot k holds, per pixel, the pair (row sum of step s-1, row sum of
-    // step s) as two u16 halves, so the vertical pass is three v_dot2_u32_u16 (pairs of taps) plus one multiply-add
-    // for the newest row instead of seven multiply / add steps.
-    uint32_t S[7][4], Sprev[4];
+    // Row sums are <= 255 * 257 = 65535, i.e. u16.  Q[m & 3] holds, per pixel, the pair (row sum of step 2m, row sum of step
+    // 2m + 1) as two u16 halves; hs = the row sums of the even step the pair is waiting for.
+    uint32_t Q[4][4], hs[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) Sprev[j] = 0u;
+    for (int j = 0; j < 4; ++j) hs[j] = 0u;
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) S[k][j] = 0u;
+        for (int j = 0; j < 4; ++j) Q[k][j] = 0u;
 
-    // raw rows are fetched BL_PF steps ahead into the same 7-slot ring, so a wave keeps several rows in flight
-    uint32_t Lr[7][3];
+    // raw rows are fetched BL_PF steps ahead into an 8-slot ring (the unroll factor), so a wave keeps several rows in flight
+    uint32_t Lr[8][3];
     // A wave none of whose lanes comes within 3 rows of the level's top or bottom (three of four) walks plain rows: the
     // offset advances by the pitch, no reflected row index per step.
     // A lane walks its rows downwards from y0 - 3 or (flag bit 3, odd row blocks) upwards from yend + 2: the taps are symmetric,
-    // the sums are the same integers.  Row of step s: ystart + dir * s; the output row of step s lies 3 * dir behind it.
+    // the sums are the same integers.  Row of step s: ystart + dir * s; the output row of step s lies 3 * dir behind it, i.e. it is
+    // output row s - 6 of the lane's block counted from the end the walk started at.
     const int dir = up ? -1 : 1;
+    const int yend = y0 + nrows_lane;
     const int ystart = up ? yend + 2 : y0 - 3;
     const int ylast = ystart + dir * (nsteps + BL_PF - 1);   // last row the walk asks for (incl. the prefetch past its end)
     const bool plain_rows = orb_ballot(!(min(ystart, ylast) >= 0 && max(ystart, ylast) < H)) == 0ull;
     uint32_t ro = __umul24((uint32_t)min(max(ystart, 0), H - 1), (uint32_t)pitch) + (uint32_t)base;
     const uint32_t rstep = up ? 0u - (uint32_t)pitch : (uint32_t)pitch;
+    uint32_t oo = __umul24((uint32_t)(up ? max(yend - 1, 0) : y0), (uint32_t)dpitch) + (uint32_t)x;   // output offset of step 6
+    const uint32_t ostep = up ? 0u - (uint32_t)dpitch : (uint32_t)dpitch;
     auto fetch = [&](int s, uint32_t (&dst3)[3]) {
         const uint8_t *row;
         if (plain_rows) {
@@ -1544,50 +1541,62 @@ __device__ __forceinline__ void blur7_walk(const uint8_t *__restrict__ src, uint
 #pragma unroll
     for (int k = 0; k < BL_PF; ++k) fetch(k, Lr[k]);
 
-    for (int s0 = 0; s0 < nsteps; s0 += 7) {
+    constexpr uint32_t ACC0 = 0xFF000000u + 32768u;   // clamp bias (see above) + round half up
+    for (int s0 = 0; s0 < nsteps; s0 += 8) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int s = s0 + k;
+        for (int k = 0; k < 8; ++k) {
+            const int s = s0 + k;   // s0 is a multiple of 8: the parity of s is the parity of k
             if (s >= nsteps) break;  // wave-uniform
-            const int yin = ystart + dir * s;
-            fetch(s + BL_PF, Lr[(k + BL_PF) % 7]);  // rows past the run re-read a valid (reflected / clamped) row
-            const uint32_t l0 = Lr[k][0], l1 = Lr[k][1], l2 = Lr[k][2];
-            uint32_t w[3] = {l0, l1, l2};
-            if (!INTERIOR) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const uint32_t ta = __builtin_amdgcn_perm(l1, l0, selA[d]);
-                    const uint32_t tb = __builtin_amdgcn_perm(l2, l2, selB[d]);
-                    w[d] = (tb & mskB[d]) | (ta & ~mskB[d]);
-                }
-            }
-            // horizontal taps as byte dot products against per-(pixel, dword) weight constants
+            fetch(s + BL_PF, Lr[(k + BL_PF) % 8]);  // rows past the run re-read a valid (reflected / clamped) row
+            const uint32_t w[3] = {Lr[k][0], Lr[k][1], Lr[k][2]};
+            // horizontal taps as byte dot products against per-(pixel, dword) weight dwords: compile-time constants in interior
+            // waves, the lane's folded weights in border waves
+            uint32_t hn[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 uint32_t h = 0u;
 #pragma unroll
-                for (int d = 0; d < 3; ++d)
-                    if (blur_hw(j, d) != 0u) h = __builtin_amdgcn_udot4(w[d], blur_hw(j, d), h, false);
-                S[k][j] = Sprev[j] | (h << 16);
-                Sprev[j] = h;
+                for (int d = 0; d < 3; ++d) {
+                    if (INTERIOR) {
+                        if (blur_hw(j, d) != 0u) h = __builtin_amdgcn_udot4(w[d], blur_hw(j, d), h, false);
+                    } else {
+                        h = __builtin_amdgcn_udot4(w[d], wt[j][d], h, false);
+                    }
+                }
+                hn[j] = h;
+            }
+            const int m = k >> 1;
+            if (k & 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Q[m][j] = hs[j] | (hn[j] << 16);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hs[j] = hn[j];
             }
             if (s >= 6) {
-                const int y = yin - 3 * dir;
                 uint32_t tq[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    // rows y-3 .. y+3 are steps s-6 .. s: pairs (s-6, s-5), (s-4, s-3), (s-2, s-1) sit in the slots written at
-                    // steps s-5, s-3, s-1; the newest row sum is Sprev
-                    uint32_t acc = __umul24(18u, Sprev[j]) + 32768u;  // v_mad_u32_u24
-                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 2) % 7][j]), __builtin_bit_cast(orb_u2, 0x00220012u), acc, false);
-                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 4) % 7][j]), __builtin_bit_cast(orb_u2, 0x00370031u), acc, false);
-                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, S[(k + 6) % 7][j]), __builtin_bit_cast(orb_u2, 0x00220031u), acc, false);
-                    tq[j] = acc;  // (acc >> 16) = value rounded half-up, <= 257
+                    // rows y-3 .. y+3 are steps s-6 .. s with taps 18 34 49 55 49 34 18
+                    uint32_t acc;
+                    if (k & 1) {   // (s-7 | s-6) (s-5 | s-4) (s-3 | s-2) (s-1 | s): the pair just formed is the last
+                        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, Q[(m + 1) & 3][j]), __builtin_bit_cast(orb_u2, 0x00120000u), ACC0, true);
+                        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, Q[(m + 2) & 3][j]), __builtin_bit_cast(orb_u2, 0x00310022u), acc, true);
+                        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, Q[(m + 3) & 3][j]), __builtin_bit_cast(orb_u2, 0x00310037u), acc, true);
+                        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, Q[m][j]), __builtin_bit_cast(orb_u2, 0x00120022u), acc, true);
+                    } else {       // (s-6 | s-5) (s-4 | s-3) (s-2 | s-1) and the single row s (a u16 in a dword: its high half is 0)
+                        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, Q[(m + 1) & 3][j]), __builtin_bit_cast(orb_u2, 0x00220012u), ACC0, true);
+                        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, Q[(m + 2) & 3][j]), __builtin_bit_cast(orb_u2, 0x00370031u), acc, true);
+                        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, Q[(m + 3) & 3][j]), __builtin_bit_cast(orb_u2, 0x00220031u), acc, true);
+                        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, hn[j]), __builtin_bit_cast(orb_u2, 0x00000012u), acc, true);
+                    }
+                    tq[j] = acc;  // byte 2 = the value rounded half-up and saturated (0xFFFFFFFF when it was >= 256)
                 }
                 if (MODE == 1) {
                     // SSE2 half-even: an exact half (low 16 bits zero) rounds to the even value inside the vectorised part of
                     // the row.  One pixel in 65536 is an exact half, so the test is one wave-uniform branch on the smallest
-                    // low half of the lane's four sums; the per-pixel correction runs only when some lane has one.
+                    // low half of the lane's four sums; the per-pixel correction runs only when some lane has one.  (A saturated
+                    // sum has low half 0xFFFF: never corrected, and 256 or 257 saturate to 255 either way.)
                     const uint32_t lowmin = min(min(tq[0] & 0xFFFFu, tq[1] & 0xFFFFu), min(tq[2] & 0xFFFFu, tq[3] & 0xFFFFu));
                     if (orb_ballot(lowmin == 0u) != 0ull) {
 #pragma unroll
@@ -1595,19 +1604,19 @@ __device__ __forceinline__ void blur7_walk(const uint8_t *__restrict__ src, uint
                             if ((tq[j] & 0xFFFFu) == 0u && (x + j) < vec_w && (tq[j] & 0x10000u)) tq[j] -= 0x10000u;
                     }
                 }
-                // (acc >> 16) <= 257: the high halves of two sums side by side, saturate_cast<uchar> as one packed u16 min, then
-                // the four low bytes into one dword
-                const uint32_t h01 = pk_min_u16(__builtin_amdgcn_perm(tq[1], tq[0], 0x07060302u), 0x00FF00FFu);
-                const uint32_t h23 = pk_min_u16(__builtin_amdgcn_perm(tq[3], tq[2], 0x07060302u), 0x00FF00FFu);
-                const uint32_t packed = __builtin_amdgcn_perm(h23, h01, 0x06040200u);
-                if (active && (uint32_t)(y - y0) < (uint32_t)(yend - y0)) {
-                    uint8_t *o = dst + (__umul24((uint32_t)y, (uint32_t)dpitch) + (uint32_t)x);
+                const uint32_t p01 = __builtin_amdgcn_perm(tq[1], tq[0], 0x0c0c0602u);
+                const uint32_t p23 = __builtin_amdgcn_perm(tq[3], tq[2], 0x06020c0cu);
+                const uint32_t packed = p01 | p23;
+                if ((uint32_t)(s - 6) < nrows) {
                     if (full) {
-                        *(uint32_t *)o = packed;
+                        *(uint32_t *)(dst + oo) = packed;   // uniform base + 32-bit lane offset: no 64-bit address arithmetic
                     } else {
-                        for (int j = 0; j < 4 && x + j < W; ++j) o[j] = (uint8_t)(packed >> (8 * j));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (x + j < W) dst[oo + (uint32_t)j] = (uint8_t)(packed >> (8 * j));
                     }
                 }
+                oo += ostep;
             }
         }
     }
@@ -1630,22 +1639,23 @@ __global__ BL_BOUNDS void k_blur7(const OrbPlan *__restrict__ plan, FrameSrc fs,
     const uint8_t *src = level_ptr(fs, L, level, b, &pitch);
     uint8_t *dst = blur + (int64_t)b * blur_fstride + L.off;
     const int W = L.w, H = L.h;
-    const int x = ld.x, y0 = ld.ys, yend = y0 + ld.nrows;
+    const int x = ld.x, y0 = ld.ys, nr = ld.nrows;
     const bool active = !(ld.flags & 1);
     // wave-uniform by construction (the host packs interior and edge columns into separate waves): no reflected column
     const bool interior = __builtin_amdgcn_readfirstlane((int)(ld.flags & 2)) != 0;
     const int vec_w = W & ~3;
+    const uint32_t *wtab = plan->blur_wt[level][0];
     int nsteps = ld.nrows;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
     nsteps = __builtin_amdgcn_readfirstlane(nsteps) + 6;  // wave-uniform
     const bool up = __builtin_amdgcn_readfirstlane((int)(ld.flags & 8)) != 0;   // wave-uniform by construction, like `interior`
     if (interior) {
-        if (up) blur7_walk<MODE, true, true>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
-        else blur7_walk<MODE, true, false>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
+        if (up) blur7_walk<MODE, true, true>(src, dst, pitch, (int)L.pitch, W, H, x, y0, nr, active, nsteps, vec_w, wtab);
+        else blur7_walk<MODE, true, false>(src, dst, pitch, (int)L.pitch, W, H, x, y0, nr, active, nsteps, vec_w, wtab);
     } else {
-        if (up) blur7_walk<MODE, false, true>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
-        else blur7_walk<MODE, false, false>(src, dst, pitch, (int)L.pitch, W, H, x, y0, yend, active, nsteps, vec_w);
+        if (up) blur7_walk<MODE, false, true>(src, dst, pitch, (int)L.pitch, W, H, x, y0, nr, active, nsteps, vec_w, wtab);
+        else blur7_walk<MODE, false, false>(src, dst, pitch, (int)L.pitch, W, H, x, y0, nr, active, nsteps, vec_w, wtab);
     }
 }
 

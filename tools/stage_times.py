@@ -1,5 +1,5 @@
 """Stage times of the batched extractor on B distinct S(seed) frames (GPU box).
-usage: B=256 [W=1920 H=1080 NF=4000] [ORBFE_OVERLAP=0] python tools/stage_times.py"""
+usage: B=256 [W=1920 H=1080 NF=4000] [OVERLAP=0] [ROWS_BLUR=n] [ROWS_FAST=n] [ORBFE_LIB=ab/liborbfe_x.so] python tools/stage_times.py"""
 import os
 import sys
 
@@ -13,6 +13,11 @@ GEN = os.environ.get("GEN", "S")
 w, h, NF = int(os.environ.get("W", "640")), int(os.environ.get("H", "480")), int(os.environ.get("NF", "1000"))
 ext = ORBextractor(NF, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
 ext.set_fast_mode(int(os.environ.get("FAST_MODE", "0")))
+if "OVERLAP" in os.environ:      # the release library reads no environment: the option goes through the C-ABI
+    ext.set_option("overlap", int(os.environ["OVERLAP"]))
+for name in ("rows_blur", "rows_fast"):
+    if name.upper() in os.environ:
+        ext.set_option(name, int(os.environ[name.upper()]))
 cap = ext.capacity()
 fr = expand_frames(torch.from_numpy(base_frames(GEN, min(B, 32), w, h, 10000)).cuda(), B)
 dk = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda")
