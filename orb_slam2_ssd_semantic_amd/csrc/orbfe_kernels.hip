@@ -133,15 +133,200 @@ struct PyrArgs {
 // fetched PW_PF steps ahead (loads clamp to the last source row: the virtual row sh repeats row sh - 1, which is what
 // cv::resize's clamped second tap reads).  The loop issues loads only: completed dwords are parked in LDS
 // ([row of the run][thread], conflict-free) and stored in one burst after the walk, so that the wait for a prefetched row
-// never includes a store acknowledgement (stores and loads share one in-order counter on this part).  The level's
-// vertical taps sit in LDS as well.  The level pitch is a multiple of 64: the last column group stores its whole dword.
+// never includes a store acknowledgement (stores and loads share one in-order counter on this part).
+// The level pitch is a multiple of 64: the last column group stores its whole dword.
+//
+// Waves come in two kinds (round 6).  A ROW-BLOCK wave holds 64 column groups of ONE run of rows: which source steps complete a
+// destination row, the row's two vertical coefficients, the source row address and the loop bounds are then the same for all
+// lanes -- they live in scalar registers (the vertical taps come through the scalar cache), the vertical arithmetic runs only in
+// the steps that complete a row (about 5 of 6; a per-lane predicate had to run it in every step, and in the steps that pad a walk
+// to a multiple of four), and the walk ends at its last step.  Per completed row of 4 pixels: 1.2 x 12 (horizontal sums) + 16
+// VALU instructions against 1.5 x 40.  The column groups a run has beyond a multiple of 64 (fewer than 37; 37 and more take a
+// partly idle row-block wave of their own) are packed into MIXED waves, lanes of several runs side by side, which keep the
+// per-lane form with the taps in LDS.
+#ifndef PW_PF
 #define PW_PF 2
+#endif
 #define PW_ROWS 16  // destination rows per lane run (8, 24, 32 measured slower)
+// row-block waves per run of rows
+__host__ __device__ inline int pyr_nfull(int ncol4) { return (ncol4 + 27) >> 6; }
+static int pyr_walk_waves(int dw, int nrblk)
+{
+    const int ncol4 = (dw + 3) >> 2, nfull = pyr_nfull(ncol4), tail = std::max(ncol4 - nfull * 64, 0);
+    return nfull * nrblk + (tail * nrblk + 63) / 64;
+}
+typedef uint32_t pw_u2 __attribute__((ext_vector_type(2)));
+
+// the walk of one lane: column group cg of run rblk.  UNI: rblk (and with it every row quantity) is wave-uniform.
+template <bool UNI>
+__device__ __forceinline__ void pyr_walk_run(const PyrArgs &a, const int b, const int rblk, const int cg, const uint2 *s_yt, uint32_t *s_out)
+{
+    const int H = a.dh;
+    const int dx0 = cg * 4;
+    const int y0 = rblk * a.rb, yend = min(y0 + a.rb, H);
+    const uint8_t *src = a.src + (int64_t)b * a.src_fstride;
+    uint8_t *dst = a.dst + (int64_t)b * a.dst_fstride;
+    auto tap = [&](int d) -> uint2 {   // .x = b0 | b1 << 16, .y = sy (low half); UNI: d is uniform, the entry goes to scalar registers
+        if (!UNI) return s_yt[d];
+        const uint2 t = ((const uint2 *)a.ytab)[d];
+        return make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)t.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)t.y));
+    };
+
+    const uint4 tx01 = *(const uint4 *)(a.xtab + dx0), tx23 = *(const uint4 *)(a.xtab + dx0 + 2);
+    const uint32_t xc[4] = {tx01.x, tx01.z, tx23.x, tx23.z};
+    const int xs[4] = {(int)(short)tx01.y, (int)(short)tx01.w, (int)(short)tx23.y, (int)(short)tx23.w};
+    const int sx0 = min(xs[0], a.sw - 8);
+    uint32_t sel[4];
+    orb_u2 coef[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t o = (uint32_t)min(max(xs[j] - sx0, 0), 7);
+        sel[j] = 0x0c000c00u | (min(o + 1u, 7u) << 16) | o;
+        coef[j] = __builtin_bit_cast(orb_u2, xc[j]);
+    }
+    uint2 cur = tap(y0);
+    const int r0 = (int)(short)cur.y;
+    int nsteps = (int)(short)tap(yend - 1).y + 2 - r0;
+    if (!UNI) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o, 64));
+        nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+    }
+    const uint32_t sp = (uint32_t)a.spitch;
+    const int rlast = a.sh - 1;
+    // (stride 0, no bounds: the offsets are the kernel's own; word 3 = the untyped 32-bit format of gfx94x / gfx950)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, -1, 0x00020000);
+    // uniform base + 32-bit per-lane offset (global_load with an SGPR base; UNI: the row offset is part of the scalar base)
+    auto fetch = [&](int s, uint2 &q) {
+        if (UNI) {
+            // buffer addressing: resource base (the frame's level) + scalar row offset + the lane's column: no vector address arithmetic
+            const pw_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, sx0, (int)((uint32_t)min(r0 + s, rlast) * sp), 0);
+            q = make_uint2(v.x, v.y);
+        } else
+            q = *(const uint2 *)(src + (__umul24((uint32_t)min(r0 + s, rlast), sp) + (uint32_t)sx0));
+    };
+    auto hsum = [&](const uint2 &q, uint32_t (&h)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u2, __builtin_amdgcn_perm(q.y, q.x, sel[j])), coef[j], 0u, false) >> 4;
+            asm volatile("" : "+v"(h[j]));   // formed once: the compiler re-derived the shift from the raw sum wherever the value was used
+        }
+    };
+    // ((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2: the "+ 2" rides in the second product (+ 2 << 16, no carry into it from
+    // below), the two ">> 16" are the SDWA word selects of one add, whose result lands in the low / high half of a pair
+    // register; ">> 2" is then one packed shift per pixel pair
+    auto vertical = [&](const uint32_t bb, const uint32_t (&Hp)[4], const uint32_t (&Hs)[4]) -> uint32_t {
+        const uint32_t b0 = bb & 0xFFFFu, b1 = bb >> 16;
+        uint32_t pa[4], pb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pa[j] = __umul24(b0, Hp[j]);
+            pb[j] = __umul24(b1, Hs[j]) + 0x20000u;
+        }
+        uint32_t t01, t23;
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t01) : "v"(pa[0]), "v"(pb[0]));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t01) : "v"(pa[1]), "v"(pb[1]));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t23) : "v"(pa[2]), "v"(pb[2]));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t23) : "v"(pa[3]), "v"(pb[3]));
+        const uint32_t q01 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t01) >> (orb_u2)(2));
+        const uint32_t q23 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(orb_u2, t23) >> (orb_u2)(2));
+        return __builtin_amdgcn_perm(q23, q01, 0x06040200u);
+    };
+    // UNI: lane i keeps the taps of row y0 + i of the run (rb <= PW_ROWS < 64; the table is padded), and the completed row's successor
+    // is read from its lane: no memory access for the taps inside the walk.  (Requested before the first rows: loads return in order,
+    // so the wait for source row 0 covers it and no wait for it is left inside the loop.)
+    uint2 mytap = cur;
+    if (UNI) {
+        mytap = ((const uint2 *)a.ytab)[min(y0 + (int)(threadIdx.x & 63), H + 7)];
+        asm volatile("" : "+v"(mytap.x), "+v"(mytap.y));
+    }
+    uint2 raw[4];
+#pragma unroll
+    for (int k = 0; k <= PW_PF; ++k) fetch(k, raw[k]);
+    // horizontal sums of the previous and of the current source row, by the parity of the step (the unroll factor is even)
+    uint32_t Hh[2][4];
+    hsum(raw[0], Hh[0]);  // step 0: source row sy(y0), completes nothing
+    int d = y0;
+    uint32_t *park = s_out + threadIdx.x;
+    // steps run in groups of four (static ring indices).  Mixed waves: no exit inside a group, surplus steps re-read the clamped
+    // last row and complete nothing; row-block waves leave at their last step.
+    for (int s0 = 1; s0 < nsteps; s0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s = s0 + k;
+            if (UNI && s >= nsteps) break;
+            fetch(s + PW_PF, raw[(k + 1 + PW_PF) % 4]);
+            uint32_t(&Hp)[4] = Hh[k & 1];
+            uint32_t(&Hs)[4] = Hh[(k + 1) & 1];
+            hsum(raw[(k + 1) % 4], Hs);
+            const bool emit = d < yend && (int)(short)cur.y + 1 == r0 + s;
+            if (UNI) {
+                if (emit) {   // wave-uniform
+                    *park = vertical(cur.x, Hp, Hs);
+                    park += 256;
+                    d += 1;
+                    cur.x = (uint32_t)__builtin_amdgcn_readlane((int)mytap.x, d - y0);
+                    cur.y = (uint32_t)__builtin_amdgcn_readlane((int)mytap.y, d - y0);
+                }
+            } else {
+                const uint32_t v = vertical(cur.x, Hp, Hs);
+                if (emit) {
+                    *park = v;
+                    park += 256;
+                    d += 1;
+                }
+                cur = s_yt[d];
+            }
+        }
+    }
+    // burst store of the run (every lane reads back its own LDS column: no barrier)
+    const int nrows = yend - y0;
+    if (UNI) {
+        for (int i0 = 0; i0 < nrows; i0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = s_out[min(i0 + i, a.rb - 1) * 256 + threadIdx.x];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i0 + i < nrows) __builtin_amdgcn_raw_buffer_store_b32(v[i], rdst, dx0, (int)((uint32_t)(y0 + i0 + i) * (uint32_t)a.dpitch), 0);
+        }
+    } else {
+        uint32_t oofs = __umul24((uint32_t)y0, (uint32_t)a.dpitch) + (uint32_t)dx0;
+        for (int i0 = 0; i0 < a.rb; i0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = s_out[min(i0 + i, a.rb - 1) * 256 + threadIdx.x];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i0 + i < nrows) *(uint32_t *)(dst + (oofs + (uint32_t)(i0 + i) * (uint32_t)a.dpitch)) = v[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pyr_walk(PyrArgs a)
 {
+    extern __shared__ uint2 s_dyn[];
+    uint2 *s_yt = s_dyn;                                   // [dh + 8]: the vertical taps, for the mixed waves
+    uint32_t *s_out = (uint32_t *)(s_dyn + (a.dh + 8));    // [rb][256]
     const int b = blockIdx.y;
-    const uint32_t bxi = blockIdx.x;
-#include "orbfe_pyr_body.inc"
+    const int ncol4 = (a.dw + 3) >> 2;
+    const int nfull = pyr_nfull(ncol4), tail = max(ncol4 - nfull * 64, 0);
+    const int nuni = nfull * a.nrblk, nmix = tail * a.nrblk;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int gw = (int)blockIdx.x * 4 + wv;   // wave of the frame: row-block waves first (run-major), then the mixed waves
+    if ((int)blockIdx.x * 4 + 3 >= nuni) {     // a workgroup with a mixed wave (workgroup-uniform): the taps into LDS
+        for (int i = threadIdx.x; i < a.dh + 8; i += 256) s_yt[i] = ((const uint2 *)a.ytab)[i];
+        __syncthreads();
+    }
+    if (gw < nuni) {
+        const int rblk = gw / nfull;
+        pyr_walk_run<true>(a, b, rblk, min((gw - rblk * nfull) * 64 + lane, ncol4 - 1), s_yt, s_out);
+    } else if (gw < nuni + ((nmix + 63) >> 6)) {
+        const int fl = min((gw - nuni) * 64 + lane, nmix - 1);   // surplus lanes repeat the last lane's work
+        const int rblk = fl / tail;
+        pyr_walk_run<false>(a, b, rblk, nfull * 64 + fl - rblk * tail, s_yt, s_out);
+    }
 }
 
 #ifdef ORBFE_DEVELOPER   // measured slower than the default chain; compiled only into developer builds
@@ -2446,8 +2631,7 @@ hipError_t orbk_launch_pyramid(const OrbLaunch &a, hipStream_t st)
             continue;
         }
 #endif
-        const int nlanes = ((D.w + 3) / 4) * pa.nrblk;
-        dim3 grid((nlanes + 255) / 256, a.nframes);
+        dim3 grid((pyr_walk_waves(D.w, pa.nrblk) + 3) / 4, a.nframes);
         hipLaunchKernelGGL(k_pyr_walk, grid, dim3(256), orbk_pyramid_lds_bytes(D.h), st, pa);
     }
     return hipGetLastError();
@@ -2524,8 +2708,7 @@ hipError_t orbk_launch_fast_pyr(const OrbLaunch &a, int nfused, int spread, hipS
         for (int l = nfused + 1; l < nl; ++l) {
             PyrArgs pa;
             pyr_args(a, l, pa);
-            const int nlanes = ((P.lv[l].w + 3) / 4) * pa.nrblk;
-            hipLaunchKernelGGL(k_pyr_walk, dim3((nlanes + 255) / 256, a.nframes), dim3(256), orbk_pyramid_lds_bytes(P.lv[l].h), st, pa);
+            hipLaunchKernelGGL(k_pyr_walk, dim3((pyr_walk_waves(P.lv[l].w, pa.nrblk) + 3) / 4, a.nframes), dim3(256), orbk_pyramid_lds_bytes(P.lv[l].h), st, pa);
         }
         fast_pyr_one(a, P.fwave_off[nfused], P.nfwaves, 0, 0, st);
     }
