@@ -55,6 +55,16 @@ from orb_slam2_ssd_semantic_amd.synth import regular_vocabulary, synth_frame, sy
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 N_SIMD = 1024            # 256 CUs x 4 SIMDs
+# The round in which a kernel of the extractor chain last changed (round 6: k_blur7, k_pyr_walk).  Counter files under profiles/
+# are named rNN_*: figures from a file older than this round are NOT attached to a line -- the field says "stale" instead.
+KERNEL_ROUND = 6
+
+
+def profile_round(name):
+    try:
+        return int(name[1:3]) if name and name[0] == "r" else 0
+    except ValueError:
+        return 0
 
 
 def profile_for_shape(suffix, shape):
@@ -421,6 +431,12 @@ def main():
                     "through a host-staged gloo group, RCCL refuses two ranks per device).  Exercises every N > 1 code path with "
                     "real kernels on a one-GPU box; the line says same_device: true and is never a scaling figure")
     ap.add_argument("--config4-batch", type=int, default=1024, help="global batch of the config-4 leg (tests: an uneven 1023)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the exchange step out (compute only): with the default line's "
+                    "ms_per_step this decomposes scaling efficiency into compute and exchange")
+    ap.add_argument("--gather-full", action="store_true", help="N > 1: all `cap` slots of every frame travel (default: the valid prefix, "
+                    "the maximum count of a probe step rounded up to 64: 1024 of 1088 slots at 1000 features)")
+    ap.add_argument("--rccl-channels", type=int, default=None, help="N > 1: NCCL_MAX_NCHANNELS for RCCL (its copy kernels take compute "
+                    "units from a VALU-bound step; fewer channels = fewer of them)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -443,6 +459,8 @@ def main():
         torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.rccl_channels:
+            os.environ["NCCL_MAX_NCHANNELS"] = str(int(args.rccl_channels))   # read by RCCL when the communicator is made
         from datetime import timedelta
         if fake:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -492,9 +510,20 @@ def main():
     d_gray = expand_frames(base, B)
     stream = None if fake else torch.cuda.current_stream().cuda_stream
     # (n, kps, desc) order of distributed.all_gather_keyframes
-    gather = (OverlappedKeyframeGather([(o[2], o[0], o[1]) for o in eng.outs], group=CTL.get("gather"), host_staged=same)
-              if world > 1 else None)
+    gather, gcap = None, None
+    if world > 1 and not args.no_gather:
+        if not fake and not args.gather_full:
+            # the valid prefix travels: counts of a probe step, maximum over all ranks, rounded up to 64 slots (the counts are
+            # gathered whole every step, so a later frame with more keypoints than that is seen and reported: gather_truncated_frames)
+            eng.step(d_gray, 0, stream)
+            torch.cuda.synchronize()
+            mx = torch.tensor([int(eng.outs[0][2].max().item())], dtype=torch.int64)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=CTL.get("main"))
+            gcap = min(eng.cap, (int(mx.item()) + 63) // 64 * 64)
+        gather = OverlappedKeyframeGather([(o[2], o[0], o[1]) for o in eng.outs], group=CTL.get("gather"), host_staged=same,
+                                          gather_cap=gcap)
     counter = [0]
+    use_gather = [True]
 
     def step():
         k = counter[0] % len(eng.outs)
@@ -502,8 +531,8 @@ def main():
         if gather:
             gather.acquire(k)  # set k is free once its previous gather (two steps ago) has read it (stream-level wait)
         eng.step(d_gray, k, stream)   # ONE call of the library's pipeline; with N > 1 it joins the launch stream
-        if gather:
-            # the one exchange step of the batched keyframe mode, asynchronous: RCCL runs on its own stream after the
+        if gather and use_gather[0]:
+            # the one exchange step of the batched keyframe mode, asynchronous: RCCL runs on the gather stream after the
             # kernels above and overlaps the next step's kernels
             gather.launch(k)
 
@@ -525,9 +554,33 @@ def main():
     for _ in range(args.warmup):
         step()
     elapsed = timed(args.steps)
+    exch = None
     if gather:  # retire the work handles of the last gathers (already complete: fence() synchronised the device)
         for k in range(len(eng.outs)):
             gather.acquire(k)
+        # the exchange in numbers: HIP events on the gather stream around the collectives of every timed step, the bytes one rank
+        # contributes, the bus bandwidth an all-gather of that size reached ((N - 1) x bytes per rank leave and enter every GPU), and
+        # the same K steps WITHOUT the exchange: what of the gather the kernels did not hide is the difference
+        tm = gather.timing(last=args.steps)
+        trunc = 0 if fake else sum(gather.truncated(k) for k in range(len(eng.outs)))
+        use_gather[0] = False
+        el_ng = timed(args.steps)
+        use_gather[0] = True
+        step()      # the last output set gathered again (the checks below read the gathered blocks of the last step)
+        fence()
+        for k in range(len(eng.outs)):
+            gather.acquire(k)
+        ms_g, ms_ng = elapsed / args.steps * 1e3, el_ng / args.steps * 1e3
+        exch = {"gather_ms": round(tm["mean_ms"], 4) if tm else None, "gather_ms_max": round(tm["max_ms"], 4) if tm else None,
+                "gather_timed_by": ("wall clock of the host-staged worker (D2H + gloo + H2D)" if same else
+                                    "HIP events on the gather stream around the three collectives (RCCL)") if not fake else "not timed (CPU stand-in)",
+                "gather_bytes_per_rank": int(gather.bytes_per_rank), "gather_slots_per_frame": int(gcap or eng.cap),
+                "gather_slots_full": int(eng.cap), "gather_truncated_frames": int(trunc),
+                "gather_bus_GBps": round(gather.bytes_per_rank * (world - 1) / (tm["mean_ms"] * 1e-3) / 1e9, 2) if tm and tm["mean_ms"] > 0 else None,
+                "ms_per_step_no_gather": round(ms_ng, 4), "ms_per_step_with_gather": round(ms_g, 4),
+                "value_no_gather": round(B * world * args.steps / el_ng, 2),
+                "gather_hidden_frac": (round(max(0.0, min(1.0, 1.0 - max(0.0, ms_g - ms_ng) / tm["mean_ms"])), 4) if tm and tm["mean_ms"] > 0 else None),
+                "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS")}
     total_frames = B * world * args.steps
     value = total_frames / elapsed
 
@@ -568,6 +621,11 @@ def main():
                                       "every step joins the launch stream (the gather consumes it)"))},
         }
         result["value_hbm_resident"] = result["value"]
+        if world > 1:
+            result["exchange"] = exch if exch is not None else {"gather": "disabled (--no-gather): compute only"}
+            if exch:
+                for k in ("gather_ms", "gather_bytes_per_rank", "gather_bus_GBps", "gather_hidden_frac", "ms_per_step_no_gather", "value_no_gather"):
+                    result[k] = exch[k]
         if same:
             result["same_device"] = True
             result["config"]["workload"] = ("SAME-DEVICE TEST MODE -- %d ranks share ONE GPU, host-staged gloo exchange: exercises the N > 1 "
@@ -582,7 +640,7 @@ def main():
             result["exact_checked"] = False   # profiling runs: no oracle in the process
         else:
             result.update(self_check(eng, d_gray, (counter[0] - 1) % len(eng.outs), nf))
-    if not fake and world > 1 and not args.no_extras:
+    if not fake and world > 1 and not args.no_extras and gather:
         chk = gathered_check(eng, gather, d_gray, (counter[0] - 1) % len(eng.outs), nf, rank, world)
         if rank == 0:
             result.update(chk)
@@ -696,8 +754,8 @@ def stage_report(ext, stage, mean_kp, w, h, nf, F, workload, local_rank):
 
     def gbs(name, tab=ab):
         return tab[name] * F / (stage_k[name] * 1e-3) / 1e9 if stage_k[name] > 0 else 0.0
-    kname = {"pyramid": "k_pyr_walk (7 launches)", "fast": "k_fast_map", "octree": "k_octree",
-             "blur": "k_blur7", "describe": "k_orient_describe"}
+    kname = {"pyramid": "k_pyr_walk (7 launches)", "fast": "k_fast_map_c" if stage.get("fast_form") == "lane-compacting" else "k_fast_map",
+             "octree": "k_octree", "blur": "k_blur7", "describe": "k_orient_describe"}
     # k_fast_map is bound by VALU issue (VALUBusy 0.92: profiles/*_pmc_valubusy.json), not by HBM: the label says so; achieved /
     # peak / frac stay the HBM figures the contract defines (algorithmic bytes / kernel time against 8 TB/s), valu_frac beside them
     roof = {"bound": "valu" if dom == "fast" else "hbm", "frac_is": "hbm: achieved / peak", "kernel": kname[dom],
@@ -716,6 +774,9 @@ def stage_report(ext, stage, mean_kp, w, h, nf, F, workload, local_rank):
     shape = {"width": w, "height": h, "nfeatures": nf, "workload": workload, "frames_per_launch": F}
     kn = roof["kernel"].split(" ")[0]
     name, pj = profile_for_shape("_pmc_valubusy.json", shape)
+    if pj and profile_round(name) < KERNEL_ROUND:
+        roof["valu_ceiling"] = {"stale": f"profiles/{name} predates the round-{KERNEL_ROUND} kernels: not attached"}
+        pj = None
     if pj and kn in pj.get("VALUBusy_percent", {}):
         vbusy = pj["VALUBusy_percent"][kn] / 100.0
         vc = {"kernel": kn, "valu_busy_frac": round(vbusy, 4), "frac": round(vbusy, 4),
@@ -730,14 +791,17 @@ def stage_report(ext, stage, mean_kp, w, h, nf, F, workload, local_rank):
         roof["valu_ceiling"] = vc
         roof["valu_frac"] = vc["valu_busy_frac"]
     name, pj = profile_for_shape("_pmc_hbm.json", shape)
-    if pj and kn in pj.get("FETCH_SIZE_KB", {}):
+    stale = bool(pj) and profile_round(name) < KERNEL_ROUND
+    if stale:
+        roof["traffic_source"] = f"stale: profiles/{name} predates the round-{KERNEL_ROUND} kernels; traffic omitted"
+    elif pj and kn in pj.get("FETCH_SIZE_KB", {}):
         # gfx950: FETCH_SIZE reports half of the read bytes (calibrated on this repo's access shapes,
         # profiles/r01_fetch_calibration.txt), WRITE_SIZE is exact
         tb = (2 * pj["FETCH_SIZE_KB"][kn]["mean_per_launch"] + pj.get("WRITE_SIZE_KB", {}).get(kn, {"mean_per_launch": 0})["mean_per_launch"]) * 1024
         roof["traffic"] = int(tb)
         roof["traffic_source"] = (f"profiles/{name}: 2 x FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 "
                                   "--pmc passes of this command and shape (committed file, not measured in this run)")
-    else:
+    elif not stale:
         roof["traffic_source"] = ("no committed counter file for this shape (width, height, nfeatures, workload, "
                                   "frames_per_launch): traffic omitted rather than rescaled")
     try:  # what a plain device copy reaches on this part (tools/hbm_rate.py), next to the 8 TB/s datasheet peak
@@ -890,6 +954,36 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
         d_other = expand_frames(torch.from_numpy(base_frames(other, min(B, 256), w, h, 10000)).cuda(), B)
         eng.pl.set_fast_mode(args.fast_mode)   # another workload: the auto mode starts over (its dense runs last up to 256 calls)
         result["value_%s" % other.lower()] = round(rate(lambda: eng.step(d_other, 0, stream)), 2)
+        if not args.no_cpu_baseline:
+            # the output of THIS leg (on S_tum: the lane-compacting FAST kernel's timed output) against the oracle
+            chk = self_check(eng, d_other, 0, nf, seed=2027, nrandom=4)
+            result["%s_exact_checked" % other.lower()] = chk["exact_checked"]
+            result["%s_exact_checked_frames" % other.lower()] = chk["exact_checked_frames"]
+        # ... and its own stage table and roofline object (the kernel that dominates THESE frames)
+        n_other = eng.outs[0][2].cpu().numpy()
+        st2 = exclusive_stage_pass(eng, d_other, stream, local_rank)
+        roof2, stages2, ncand2 = stage_report(ext, st2, float(n_other.mean()), w, h, nf, F, other, local_rank)
+        stages2["match_ms"] = round(st2["match"], 4)
+        stages2["fast_form"] = st2.get("fast_form")
+        result["roofline_%s" % other.lower()] = roof2
+        result["stages_%s" % other.lower()] = stages2
+        result["roofline_frac_hbm_%s" % other.lower()] = roof2["frac"]
+        for k in ("pyramid", "fast", "octree", "blur", "describe"):
+            result["stage_ms_exclusive_%s_%s" % (other.lower(), k)] = round(st2[k], 4)
+        # north_star: ">= 60 % of HBM roofline on the pyramid/FAST pass" -- the pass as a whole (algorithmic bytes of the resize
+        # chain and of the FAST pass over the sum of their exclusive times), on both workloads
+        s_main = result["stages"]["pyramid+fast"]
+        s_oth = stages2["pyramid+fast"]
+        by = {args.workload: s_main, other: s_oth}
+        result["roofline_pass"] = {"what": "pyramid + FAST pass: algorithmic bytes (SURVEY 8(d)) / (exclusive pyramid ms + exclusive FAST ms) "
+                                           "against the 8 TB/s HBM peak; north_star asks for >= 0.60",
+                                   "target": 0.60, "unit": "fraction of 8000 GB/s",
+                                   **{k: {"frac": v["frac"], "frac_pixels_only": v["frac_pixels_only"], "ms": v["ms"], "GBps": v["GBps"]}
+                                      for k, v in by.items()},
+                                   "bound": "VALU issue, not HBM: the exact per-pixel FAST score costs more lane instructions than 0.60 leaves "
+                                            "room for (<= 22 per pixel for resize + FAST together; DESIGN.md)"}
+        result["roofline_pass_frac_S"] = by["S"]["frac"]
+        result["roofline_pass_frac_S_tum"] = by["S_tum"]["frac"]
         # the same two workloads with the FAST form pinned to dense (what rounds 1-4 shipped): the library's default, auto, picks
         # the lane-compacting kernel where few pixel pairs pass the necessary test (S_tum: 18 %) and dense elsewhere (S: 84 %)
         eng.pl.set_fast_mode(0)
@@ -899,6 +993,11 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
         eng.pl.set_fast_mode(args.fast_mode)
         result["workloads"] = workload_legs(args, eng, d_gray[:F], d_other[:F], local_rank)
         del d_other
+        rp = real_photo_leg(args, eng, stream, rate, check=not args.no_cpu_baseline)
+        if rp is not None:
+            result["real_photo"] = rp
+            result["value_real_photo"] = rp["frames_per_s"]
+            result["real_photo_exact_checked"] = rp.get("exact_checked", False)
         eng.pl.reset_sequence()
         step()   # the resident batch's results back in the output set
         eng.pl.synchronize()
@@ -966,6 +1065,12 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
             lat.append(time.perf_counter() - t2)
         result["single_frame_host_latency_ms"] = round(float(np.median(lat)) * 1e3, 4)
         del e1
+        sl = shim_latency_leg(img, nf)
+        if sl:
+            result["shim_single_frame"] = sl
+            result["shim_operator_ms_keep_pyramid"] = sl["keep_pyramid_true_ms"]
+            result["shim_operator_ms_no_pyramid"] = sl["keep_pyramid_false_ms"]
+            result["shim_operator_ms_identical_input"] = sl["identical_input_second_call_ms"]
         cb = cpu_baseline(w, h, nf)
         result["cpu_baseline"] = cb
         result["speedup_vs_cpu_1thread"] = round(value / cb["value"], 1)
@@ -976,6 +1081,86 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
             result["speedup_vs_cpu_1thread_vectorised"] = round(value / cv["value"], 1)
         result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(w, h, nf)
         result["cpu_baseline_all_cores_frames_per_s"] = result["cpu_baseline_all_cores"]["value"]
+
+
+def shim_latency_leg(img, nf, reps=40):
+    """ORB_SLAM2::ORBextractor::operator() of the product's C++ shim (shim/ORBextractor.cc), called the way the reference's Frame
+    calls it (Frame::ExtractORB, src/Frame.cc:337-343), median ms per 640x480 frame:
+      keep_pyramid true   the reference-faithful default: mvImagePyramid is filled after every call (one kernel + a 1.2 MB device-to-host
+                          copy + eight cv::Mat headers) -- only the stereo matcher reads it
+      keep_pyramid false  what INTEGRATION.md section 2 recommends for the RGB-D / monocular TUM configurations
+      identical input     ORBFE_OPT_REUSE_IDENTICAL_INPUT (on in a -DORBFE_SHIM_PERFECT build): the fork builds two Frames from one
+                          mImGray per image (perfect/src/Tracking.cc:685, :716); the second operator() is answered from the first
+    The shim is product source; the build that binds it to Python sits with the checkers (oracle/_ref/libshim_ext.so)."""
+    try:
+        from oracle import ref_ffi as RF
+        if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libshim_ext.so")):
+            return None
+        out = {}
+        for keep in (True, False):
+            e = RF.ShimExtractor(nf, 1.2, 8, 20, 7)
+            for _ in range(5):
+                e.extract_via_frame(img, keep_pyramid=keep)
+            lat = []
+            for _ in range(reps):
+                t = time.perf_counter()
+                e.extract_via_frame(img, keep_pyramid=keep)
+                lat.append(time.perf_counter() - t)
+            out["keep_pyramid_%s_ms" % str(keep).lower()] = round(float(np.median(lat)) * 1e3, 4)
+            del e
+        e = RF.ShimExtractor(nf, 1.2, 8, 20, 7)
+        e.set_reuse(True)
+        other = np.ascontiguousarray(img[::-1])
+        first, second = [], []
+        for i in range(reps + 3):
+            a = img if i % 2 == 0 else other      # a new image every pair of calls, as Tracking sees it
+            t = time.perf_counter()
+            e.extract_via_frame(a, keep_pyramid=False)
+            t1 = time.perf_counter()
+            e.extract_via_frame(a, keep_pyramid=False)
+            t2 = time.perf_counter()
+            if i >= 3:
+                first.append(t1 - t)
+                second.append(t2 - t1)
+        out["identical_input_first_call_ms"] = round(float(np.median(first)) * 1e3, 4)
+        out["identical_input_second_call_ms"] = round(float(np.median(second)) * 1e3, 4)
+        out["identical_input_reused_calls"] = e.reused_calls()
+        out["identical_input_pairs"] = reps + 3
+        out["includes"] = "the binding's copies of keypoints / descriptors into numpy arrays (both settings alike)"
+        return out
+    except Exception as ex:   # the checker-side build is optional on a box
+        return {"error": repr(ex)}
+
+
+def real_photo_leg(args, eng, stream, rate, check=True):
+    """The same step on REAL photographs: the 640 x 480 frame set of tests/golden/real (scikit-image / scipy images incl. the
+    motorcycle stereo pair, colour ones through Tracking's gray conversion with both Camera.RGB settings, JPEG re-encodes: the
+    nearest thing to TUM frames the boxes hold), tiled to the resident batch by the same lossless roll / flip transforms as the
+    synthetic sets.  FAST mode as shipped (auto).  Checked against the oracle like `value`."""
+    from orb_slam2_ssd_semantic_amd import photos
+    w, h, nf = args.width, args.height, args.nfeatures
+    if not photos.available() or (w, h) != (640, 480):
+        return None
+    fr = photos.vga_gray_frames()
+    base = torch.from_numpy(np.stack([a for _, a in fr])).cuda()
+    d_ph = expand_frames(base, eng.B)
+    eng.pl.set_fast_mode(args.fast_mode)
+    eng.pl.reset_sequence()
+    fps = rate(lambda: eng.step(d_ph, 0, stream))
+    out = {"frames_per_s": round(fps, 2), "distinct_photographs": len(fr), "frames": [t for t, _ in fr],
+           "resident_frames": int(eng.B), "fast_mode": "auto (library default)",
+           "mean_keypoints_per_frame": round(float(eng.outs[0][2].float().mean().item()), 1),
+           "source": "tests/golden/real (made by tests/golden/make_real_images.py from the build container's scikit-image / scipy "
+                     "images; golden vectors from the compiled reference in tests/golden/real/golden.npz)"}
+    st = eng.ext.fast_stats(reset=False)
+    if st.get("row_steps"):
+        out["fast_pass_rate_last_probe"] = round(st["parked_pairs"] / max(128.0 * st["row_steps"], 1), 4)
+    if check:
+        chk = self_check(eng, d_ph, 0, nf, seed=2028, nrandom=6)
+        out["exact_checked"] = chk["exact_checked"]
+        out["exact_checked_frames"] = chk["exact_checked_frames"]
+    del d_ph
+    return out
 
 
 def pcie_leg(eng, d_src, w, h, F, nbatches=24):

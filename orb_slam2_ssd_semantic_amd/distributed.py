@@ -77,6 +77,17 @@ class _HostStagedWork:
             torch.cuda.current_stream().wait_event(self.uploaded)
 
 
+class _StreamWork:
+    """the pending gather of one launch on the RCCL transport: wait() = the CURRENT stream waits (stream level) for the event
+    recorded behind the collectives on the gather stream"""
+
+    def __init__(self, done):
+        self.done = done
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.done)
+
+
 class OverlappedKeyframeGather:
     """Double-buffered, asynchronous form of `all_gather_keyframes` for a steady stream of batches.
 
@@ -85,6 +96,16 @@ class OverlappedKeyframeGather:
     all-gather of set k after the work already enqueued on the current stream; it then overlaps whatever is enqueued
     next.  `result(k)` waits for and returns the gathered (n, kps, desc) of set k in rank-major order.
 
+    RCCL transport (device tensors, backend "nccl"): the collectives of a launch are issued under a GATHER STREAM of this object that
+    first waits for an event recorded behind the producer's kernels; HIP events recorded on that stream around them time the
+    exchange itself (`timing()`), whatever it overlaps.
+
+    gather_cap: slots per frame that travel (None: all `cap` of them).  The extractor fills count(f) <= cap slots of a frame and zero
+    pads the rest; a caller that knows a bound on the counts (bench.py: the maximum over a probe step, rounded up to 64 -- 1024 of
+    1088 slots at 1000 features) sends the valid prefix only: the blocks are compacted on the gather stream ([S, cap, .] ->
+    [S, gather_cap, .]), the gathered blocks have gather_cap slots per frame, and the counts (always gathered whole) let the
+    receiver verify that nothing was cut (`truncated(k)`).
+
     host_staged=True: device blocks over a CPU-only group (gloo).  A worker thread waits for an event recorded behind the
     producer's launches, copies the blocks to pinned host memory, gathers them over `group`, uploads the result on a side stream.
     The producer keeps enqueuing the next step meanwhile, exactly as with the asynchronous RCCL collective -- this is the
@@ -92,18 +113,33 @@ class OverlappedKeyframeGather:
     nobody else (the worker thread issues its collectives in launch order on every rank).
     """
 
-    def __init__(self, sets, group=None, host_staged=False):
+    def __init__(self, sets, group=None, host_staged=False, gather_cap=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.sets = sets
         self.pending = [[] for _ in sets]
-        self.gathered = [tuple(torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
-                                           device=t.device) for t in s) for s in sets]
+        cap = max((t.shape[1] for s in sets for t in s if t.dim() >= 2), default=0)
+        self.cap = cap
+        self.gcap = int(gather_cap) if gather_cap and 0 < int(gather_cap) < cap else None
+
+        def travel_shape(t):   # what one rank sends of tensor t
+            return (t.shape[0], self.gcap) + tuple(t.shape[2:]) if (self.gcap and t.dim() >= 2) else tuple(t.shape)
+        self.compact = [tuple(torch.empty(travel_shape(t), dtype=t.dtype, device=t.device) if (self.gcap and t.dim() >= 2) else None
+                              for t in s) for s in sets]
+        self.gathered = [tuple(torch.empty((self.world * t.shape[0],) + travel_shape(t)[1:], dtype=t.dtype, device=t.device)
+                               for t in s) for s in sets]
+        import math
+        self.bytes_per_rank = int(sum(t.element_size() * math.prod(travel_shape(t)) for t in sets[0]))
         self.host_staged = bool(host_staged) and self.world > 1
+        self.times = []        # RCCL: (event before, event after) per launch; host-staged: seconds per launch
+        self.comm = None
+        on_gpu = any(t.is_cuda for s in sets for t in s)
+        if on_gpu and not self.host_staged:
+            self.comm = torch.cuda.Stream()
         if self.host_staged:
             import queue
             import threading
-            self.h_src = [tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in s) for s in sets]
+            self.h_src = [tuple(torch.empty(travel_shape(t), dtype=t.dtype).pin_memory() for t in s) for s in sets]
             self.h_dst = [tuple(torch.empty(g.shape, dtype=g.dtype).pin_memory() for g in gs) for gs in self.gathered]
             self.side = torch.cuda.Stream()
             self.device = torch.cuda.current_device()
@@ -111,7 +147,16 @@ class OverlappedKeyframeGather:
             self.thread = threading.Thread(target=self._worker, daemon=True)
             self.thread.start()
 
+    def _travel(self, k, i, src):
+        """tensor i of set k as it travels: the valid prefix, compacted into this object's buffer on the CURRENT stream"""
+        c = self.compact[k][i]
+        if c is None:
+            return src.contiguous()
+        c.copy_(src[:, :self.gcap])
+        return c
+
     def _worker(self):
+        import time
         torch.cuda.set_device(self.device)   # the current device is per thread
         while True:
             job = self.q.get()
@@ -121,8 +166,9 @@ class OverlappedKeyframeGather:
             try:
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(ready)
-                    for hs, src in zip(self.h_src[k], self.sets[k]):
-                        hs.copy_(src, non_blocking=True)
+                    t0 = time.perf_counter()
+                    for i, (hs, src) in enumerate(zip(self.h_src[k], self.sets[k])):
+                        hs.copy_(self._travel(k, i, src), non_blocking=True)
                     self.side.synchronize()
                     for hd, hs in zip(self.h_dst[k], self.h_src[k]):
                         dist.all_gather_into_tensor(hd, hs, group=self.group)
@@ -131,6 +177,7 @@ class OverlappedKeyframeGather:
                     ev = torch.cuda.Event()
                     ev.record(self.side)
                     self.side.synchronize()   # the pinned blocks are re-used by the next job
+                    self.times.append(time.perf_counter() - t0)
                 work.uploaded = ev
             except BaseException as e:   # noqa: BLE001 -- surfaced by wait()
                 work.error = e
@@ -142,9 +189,9 @@ class OverlappedKeyframeGather:
         self.pending[k] = []
 
     def launch(self, k):
-        if self.world == 1:
-            for dst, src in zip(self.gathered[k], self.sets[k]):
-                dst.copy_(src)
+        if self.world == 1 and self.comm is None:
+            for i, (dst, src) in enumerate(zip(self.gathered[k], self.sets[k])):
+                dst.copy_(self._travel(k, i, src))
             return
         if self.host_staged:
             ready = torch.cuda.Event()
@@ -153,12 +200,44 @@ class OverlappedKeyframeGather:
             self.pending[k].append(work)
             self.q.put((k, ready, work))
             return
-        for dst, src in zip(self.gathered[k], self.sets[k]):
-            self.pending[k].append(dist.all_gather_into_tensor(dst, src.contiguous(), group=self.group, async_op=True))
+        if self.comm is None:   # CPU tensors (gloo): asynchronous work handles
+            for i, (dst, src) in enumerate(zip(self.gathered[k], self.sets[k])):
+                self.pending[k].append(dist.all_gather_into_tensor(dst, self._travel(k, i, src), group=self.group, async_op=True))
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ready)
+            e0.record(self.comm)
+            for i, (dst, src) in enumerate(zip(self.gathered[k], self.sets[k])):
+                t = self._travel(k, i, src)
+                if self.world == 1 and not dist.is_initialized():
+                    dst.copy_(t)
+                else:   # synchronous form: the gather stream (not the producer's) waits for the collective
+                    dist.all_gather_into_tensor(dst, t, group=self.group)
+            e1.record(self.comm)
+        self.pending[k].append(_StreamWork(e1))
+        self.times.append((e0, e1))
 
     def result(self, k):
         self.acquire(k)
         return self.gathered[k]
+
+    def truncated(self, k):
+        """frames of the gathered set k whose count exceeds the slots that travelled (0 unless gather_cap was chosen too small)"""
+        if not self.gcap:
+            return 0
+        return int((self.result(k)[0] > self.gcap).sum().item())
+
+    def timing(self, last=None):
+        """mean / max milliseconds of the exchange of one launch (the device must be idle: events are read), over the last `last`
+        launches; None when nothing was timed"""
+        ts = self.times[-last:] if last else self.times
+        if not ts:
+            return None
+        ms = [t * 1e3 if isinstance(t, float) else t[0].elapsed_time(t[1]) for t in ts]
+        return {"mean_ms": sum(ms) / len(ms), "max_ms": max(ms), "min_ms": min(ms), "launches": len(ms)}
 
     def close(self):
         if self.host_staged and self.thread is not None:

@@ -26,6 +26,8 @@ def test_bench_spawns_its_own_ranks():
     assert j["n_gpus"] == 2 and j["fake"] is True and j["steps"] == 2 and j["warmup"] == 1
     assert j["config"]["frames_per_gpu_per_step"] == 16
     assert j["gathered_frames"] == 2 * 16     # the per-step all-gather covered both ranks' batches
+    ex = j["exchange"]                        # the exchange step's figures travel in the line (times are the GPU run's)
+    assert ex["gather_bytes_per_rank"] == 16 * 4 + 16 * 64 * (28 + 32) and ex["ms_per_step_no_gather"] > 0 and ex["value_no_gather"] > 0
     assert j["scaling"] == "weak" and j["higher_is_better"] is True
 
 

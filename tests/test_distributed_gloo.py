@@ -118,3 +118,54 @@ def test_overlapped_gather_world2():
                 assert (n[r * 3:(r + 1) * 3] == 100 * j + r).all()
                 assert (k[r * 3:(r + 1) * 3] == 1000 * j + r).all()
                 assert (d[r * 3:(r + 1) * 3] == (7 * j + r) % 256).all()
+
+
+def _prefix_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from orb_slam2_ssd_semantic_amd.distributed import OverlappedKeyframeGather
+        S, cap, gcap = 3, 8, 5
+        sets = [(torch.zeros(S, dtype=torch.int32), torch.zeros(S, cap, 7, dtype=torch.int32),
+                 torch.zeros(S, cap, 32, dtype=torch.uint8)) for _ in range(2)]
+        g = OverlappedKeyframeGather(sets, gather_cap=gcap)
+        full = OverlappedKeyframeGather(sets)
+        out = {"bytes": (g.bytes_per_rank, full.bytes_per_rank), "trunc": []}
+        for i in range(4):
+            k = i & 1
+            g.acquire(k)
+            n, kps, desc = sets[k]
+            cnt = [3, 5, 4] if i < 3 else [3, 7, 4]        # the last step has a frame with more keypoints than slots travel
+            n.copy_(torch.tensor(cnt, dtype=torch.int32))
+            for f in range(S):
+                kps[f].zero_(); desc[f].zero_()
+                kps[f, :cnt[f]] = 1000 * i + 10 * rank + f
+                desc[f, :cnt[f]] = (16 * i + 4 * rank + f) % 256
+            g.launch(k)
+            gn, gk, gd = g.result(k)
+            assert gk.shape == (world * S, gcap, 7) and gd.shape == (world * S, gcap, 32) and gn.shape == (world * S,)
+            for r in range(world):
+                for f in range(S):
+                    c = min(cnt[f], gcap)
+                    assert int(gn[r * S + f]) == cnt[f]
+                    assert (gk[r * S + f, :c] == 1000 * i + 10 * r + f).all() and not gk[r * S + f, c:].any()
+                    assert (gd[r * S + f, :c] == (16 * i + 4 * r + f) % 256).all()
+            out["trunc"].append(g.truncated(k))
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gather_of_the_valid_prefix_world2():
+    """gather_cap: only the first gather_cap slots of every frame travel (bench.py: 1024 of 1088 at 1000 features); the counts travel
+    whole, so a frame that had more keypoints than slots travelled is reported by truncated()."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_prefix_worker, args=(world, port, ret), nprocs=world, join=True)
+    for rank in range(world):
+        small, full = ret[rank]["bytes"]
+        assert small == 3 * 4 + 3 * 5 * 28 + 3 * 5 * 32 and full == 3 * 4 + 3 * 8 * 28 + 3 * 8 * 32
+        assert ret[rank]["trunc"] == [0, 0, 0, world]

@@ -47,3 +47,29 @@ def test_two_ranks_on_one_device_run_every_multi_gpu_path():
     assert ("frames_per_s" in cg) or ("error" in cg and cg["error"]), cg
     assert j["config4_cabi_group_status"]
     assert j["value"] > 0 and j["scaling"] == "weak"
+    # the exchange step in numbers (what the first 8-GPU run needs to be explainable): time, bytes, bus bandwidth, what of it
+    # the kernels hid, and the same steps without it
+    ex = j["exchange"]
+    for k in ("gather_ms", "gather_bytes_per_rank", "gather_bus_GBps", "gather_hidden_frac", "ms_per_step_no_gather", "value_no_gather"):
+        assert ex[k] is not None and j[k] == ex[k], k
+    cap, gcap = ex["gather_slots_full"], ex["gather_slots_per_frame"]
+    B = 128 * 4
+    assert gcap % 64 == 0 and 1004 <= gcap <= cap and ex["gather_truncated_frames"] == 0     # the valid prefix travels
+    assert ex["gather_bytes_per_rank"] == B * 4 + B * gcap * (28 + 32)
+    assert ex["gather_ms"] > 0 and 0.0 <= ex["gather_hidden_frac"] <= 1.0 and ex["ms_per_step_no_gather"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_device_without_the_gather_and_with_the_full_blocks():
+    base = [sys.executable, BENCH, "--gpus", "2", "--same-device", "--steps", "2", "--warmup", "1", "--frames", "64", "--launches", "2",
+            "--seeds", "64", "--no-extras"]
+    for extra in (["--no-gather"], ["--gather-full", "--rccl-channels", "4"]):
+        r = subprocess.run(base + extra, env=_env(), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        assert j["n_gpus"] == 2 and j["value"] > 0
+        if extra[0] == "--no-gather":
+            assert "disabled" in j["exchange"]["gather"] and "gather_ms" not in j
+        else:
+            ex = j["exchange"]
+            assert ex["gather_slots_per_frame"] == ex["gather_slots_full"] and ex["rccl_max_nchannels"] == "4" and ex["gather_ms"] > 0
