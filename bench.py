@@ -1016,6 +1016,8 @@ def extras(args, eng, d_gray, value, result, rank, local_rank, world, fence, ste
             cg = c4.get("cabi_group") or {}
             result["config4_cabi_group_frames_per_s"] = cg.get("frames_per_s")
             result["config4_cabi_group_status"] = "ok" if "frames_per_s" in cg else ("error: " + str(cg.get("error")))
+            if "roofline" in c4:
+                result["config4_roofline_frac_hbm"] = c4["roofline"]["frac"]
 
     if world == 1 and not args.no_cpu_baseline:
         result["projection_chain"] = projection_leg(local_rank)
@@ -1806,6 +1808,27 @@ def config4_leg(args, rank, local_rank, world, fence, global_batch=1024, nfeat=2
 
     run(allf[lo:hi].contiguous(), hi - lo, "strong")
     run(allf, global_batch, "weak")
+    if rank == 0:
+        # stage table and roofline object of this shape (the library's HIP events on the launch stream; counter fields only from a
+        # committed same-round profile of exactly this shape: `bench.py --nfeatures 2000 --no-match --no-extras`, profiles/r06_cfg4_*)
+        nfr = hi - lo
+        shard = allf[lo:hi].contiguous()
+        kps = torch.zeros((nfr, cap, 7), dtype=torch.int32, device="cuda")
+        desc = torch.zeros((nfr, cap, 32), dtype=torch.uint8, device="cuda")
+        n = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+        ext.set_option("overlap", 0)
+        for i in range(4):
+            if i == 1:
+                torch.cuda.synchronize()
+                ext.set_profiling(True)
+            ext.extract_batch_device(shard.data_ptr(), nfr, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr(), stream)
+        torch.cuda.synchronize()
+        st4 = ext.stage_ms()
+        ext.set_profiling(False)
+        ext.set_option("overlap", -1)
+        roof4, stages4, ncand4 = stage_report(ext, st4, float(n.float().mean().item()), w, h, nfeat, nfr, "S", local_rank)
+        out["roofline"], out["stages"], out["fast_candidates_frame0"] = roof4, stages4, ncand4
+        del kps, desc, n, shard
     if world == 1:   # the shard through ONE call of the sequence pipeline (extract only): 4 pipes x sub-batches of a quarter shard
         from orb_slam2_ssd_semantic_amd import FramePipeline
         nfr = hi - lo

@@ -1755,37 +1755,53 @@ __global__ __launch_bounds__(PJ_FT) void k_proj_fused(ProjFusedArgs p)
 }
 
 // the remaining rounds, ONE workgroup, launched behind k_proj_fused (the launch boundary makes the slabs visible; an in-kernel
-// hand-over to "the last workgroup to arrive" was measured: the agent-scope fences cost more than the launch, 95 against 82 us)
-__global__ __launch_bounds__(PJ_FT) void k_proj_rounds(ProjFusedArgs p)
+// hand-over to "the last workgroup to arrive" was measured: the agent-scope fences cost more than the launch, 95 against 82 us).
+// One workgroup is latency, not throughput: every dependent trip to memory is a microsecond.  The per-query state (choice, the
+// features of the two smallest free keys, flags, distances, list length) is therefore read ONCE into LDS, the rounds run on LDS
+// alone except for the entries of the queries that re-scan, and the results leave from LDS; 1024 threads (64 queries re-scan at
+// a time).  Round-5 form: three global phases per round with 256 threads, 47 us for 786 queries.
+#define PJ_RT 1024
+#define PJ_ROUNDS_WORDS 8        // LDS words per query: list, match, f1, f2, flags, best, second, cnt
+__global__ __launch_bounds__(PJ_RT) void k_proj_rounds(ProjFusedArgs p)
 {
-    extern __shared__ int32_t s_dyn[];     // [nF] owner table, then [nq] the queries that re-scan
+    extern __shared__ int32_t s_dyn[];     // [nF] owner table, then PJ_ROUNDS_WORDS arrays of [nq]
     __shared__ int s_changed, s_nlist;
     const ProjArgs &a = p.a;
     const int tid = threadIdx.x;
     const int nq = a.nq, nF = a.nF;
-    int32_t *s_owner = s_dyn, *s_list = s_dyn + nF;
+    int32_t *s_owner = s_dyn, *s_list = s_dyn + nF, *s_match = s_list + nq, *s_f1 = s_match + nq, *s_f2 = s_f1 + nq;
+    int32_t *s_flag = s_f2 + nq, *s_best = s_flag + nq, *s_second = s_best + nq, *s_cnt = s_second + nq;
     const uint32_t need = p.done[1];
+    for (int i = tid; i < nq; i += PJ_RT) {
+        s_match[i] = a.match[i];
+        s_f1[i] = p.f12[2 * i];
+        s_f2[i] = p.f12[2 * i + 1];
+        s_flag[i] = (a.q[i].flags & ORBFE_PROJ_CLAIMS) ? 1 : 0;   // bit 0: the query claims its slot; bit 1: it skipped an owned slot in its last scan
+        s_best[i] = a.best[i];
+        s_second[i] = a.second[i];
+        s_cnt[i] = (int32_t)a.cnt[i];
+    }
     int round = 1;
     if (need == 0) {
         for (; round <= nq + 2; ++round) {
-            for (int f = tid; f < nF; f += PJ_FT) s_owner[f] = 0x7FFFFFFF;
+            for (int f = tid; f < nF; f += PJ_RT) s_owner[f] = 0x7FFFFFFF;
             if (tid == 0) { s_changed = 0; s_nlist = 0; }
             __syncthreads();
-            for (int i = tid; i < nq; i += PJ_FT) {
-                const int mt = a.match[i];
-                if (mt >= 0 && (a.q[i].flags & ORBFE_PROJ_CLAIMS)) atomicMin(&s_owner[mt], i);
+            for (int i = tid; i < nq; i += PJ_RT) {
+                const int mt = s_match[i];
+                if (mt >= 0 && (s_flag[i] & 1)) atomicMin(&s_owner[mt], i);
             }
             __syncthreads();
-            for (int i = tid; i < nq; i += PJ_FT) {
-                const int f1 = p.f12[2 * i], f2 = p.f12[2 * i + 1];
-                if (p.constrained[i] || (f1 >= 0 && s_owner[f1] < i) || (f2 >= 0 && s_owner[f2] < i)) s_list[atomicAdd(&s_nlist, 1)] = i;
+            for (int i = tid; i < nq; i += PJ_RT) {
+                const int f1 = s_f1[i], f2 = s_f2[i];
+                if ((s_flag[i] & 2) || (f1 >= 0 && s_owner[f1] < i) || (f2 >= 0 && s_owner[f2] < i)) s_list[atomicAdd(&s_nlist, 1)] = i;
             }
             __syncthreads();
             const int nl = s_nlist;
             if (nl == 0) break;               // workgroup-uniform
             const int sub = tid % PJ_L, grp = tid / PJ_L;
             bool changed = false;
-            for (int l0 = 0; l0 < nl; l0 += PJ_FT / PJ_L) {
+            for (int l0 = 0; l0 < nl; l0 += PJ_RT / PJ_L) {
                 const int li = l0 + grp;
                 const int i = li < nl ? s_list[li] : -1;
                 uint32_t k1 = PJ_NOKEY, k2 = PJ_NOKEY;
@@ -1793,7 +1809,7 @@ __global__ __launch_bounds__(PJ_FT) void k_proj_rounds(ProjFusedArgs p)
                 bool skipped = false;
                 if (i >= 0) {
                     const uint32_t *ent = a.ent + (size_t)i * PJ_SLAB;
-                    const uint32_t e = a.cnt[i];
+                    const uint32_t e = (uint32_t)s_cnt[i];
                     for (uint32_t k = sub; k < e; k += PJ_L) {
                         const uint32_t en = ent[k];
                         const uint32_t f = en & 0xFFFFu, d = en >> 16;
@@ -1810,15 +1826,15 @@ __global__ __launch_bounds__(PJ_FT) void k_proj_rounds(ProjFusedArgs p)
                 if (i >= 0 && sub == 0) {
                     int bd, bd2;
                     const int mt = proj_decide(a, k1, k2, f1, f2, bd, bd2);
-                    if (mt != a.match[i]) {
-                        a.match[i] = mt;
+                    if (mt != s_match[i]) {
+                        s_match[i] = mt;
                         changed = true;
                     }
-                    a.best[i] = bd;
-                    a.second[i] = bd2;
-                    p.f12[2 * i] = f1;
-                    p.f12[2 * i + 1] = f2;
-                    p.constrained[i] = skipped ? 1 : 0;
+                    s_best[i] = bd;
+                    s_second[i] = bd2;
+                    s_f1[i] = f1;
+                    s_f2[i] = f2;
+                    s_flag[i] = (s_flag[i] & 1) | (skipped ? 2 : 0);
                 }
             }
             if (changed) s_changed = 1;
@@ -1829,10 +1845,10 @@ __global__ __launch_bounds__(PJ_FT) void k_proj_rounds(ProjFusedArgs p)
     }
     __syncthreads();
     // results to the host; the counters back to zero for the next call
-    for (int i = tid; i < nq; i += PJ_FT) {
-        p.h_out[i] = a.match[i];
-        p.h_out[nq + i] = a.best[i];
-        p.h_out[2 * (size_t)nq + i] = a.second[i];
+    for (int i = tid; i < nq; i += PJ_RT) {
+        p.h_out[i] = s_match[i];
+        p.h_out[nq + i] = s_best[i];
+        p.h_out[2 * (size_t)nq + i] = s_second[i];
     }
     if (tid == 0) {
         p.h_out[3 * (size_t)nq] = (int32_t)need;   // > 0: some query has that many candidates; nothing above is valid
@@ -1916,7 +1932,7 @@ extern "C" orbfe_status orbfe_search_by_projection_chi2(orbfe_matcher *m, const 
     const int32_t *hout = (const int32_t *)m->pin_out.p;
     // ONE launch (k_proj_fused) when the owner table and the re-scan list fit the LDS and no query overflows its slab; else (or on
     // overflow, reported in status[0]) the four-kernel path below
-    const size_t fused_lds = ((size_t)std::max(nF, 1) + (size_t)nq) * 4;
+    const size_t fused_lds = ((size_t)std::max(nF, 1) + (size_t)PJ_ROUNDS_WORDS * (size_t)nq) * 4;
     if (m->proj_fused && fused_lds <= 64 * 1024) {
         ORBFE_HIP(m->b[5].ensure((size_t)nq * PJ_SLAB * 4));
         ORBFE_HIP(m->b[6].ensure((size_t)nq * 8));
@@ -1935,7 +1951,7 @@ extern "C" orbfe_status orbfe_search_by_projection_chi2(orbfe_matcher *m, const 
         fa.h_out = (int32_t *)m->pin_out.p;   // page-locked and mapped: the kernel stores the results there
         const int nwg = (nq + PJ_FT / 64 - 1) / (PJ_FT / 64);
         hipLaunchKernelGGL(k_proj_fused, dim3(nwg), dim3(PJ_FT), 0, st, fa);
-        hipLaunchKernelGGL(k_proj_rounds, dim3(1), dim3(PJ_FT), fused_lds, st, fa);
+        hipLaunchKernelGGL(k_proj_rounds, dim3(1), dim3(PJ_RT), fused_lds, st, fa);
         ORBFE_HIP(hipGetLastError());
         ORBFE_HIP(hipStreamSynchronize(st));
         if (hout[3 * (size_t)nq] == 0) {
