@@ -14,7 +14,7 @@ CSRC = os.path.join(_PKG, "csrc")
 LIB = os.path.join(_PKG, "liborbfe.so")
 SOURCES = ["orbfe_kernels.hip", "orbfe_api.hip", "orbfe_match.hip", "orbfe_io.hip", "orbfe_group.hip", "orbfe_hostgeom.hip",
            "orbfe_pipeline.hip"]
-HEADERS = ["orbfe_common.h", "orbfe_kernels.h", "orbfe_pattern.inc", "orbfe_fast_body.inc", "orbfe_fast_body_c.inc", "orbfe_pyr_body.inc", os.path.join(_ROOT, "include", "orbfe.h")]
+HEADERS = ["orbfe_common.h", "orbfe_kernels.h", "orbfe_pattern.inc", "orbfe_fast_body.inc", "orbfe_fast_body_u.inc", "orbfe_fast_body_c.inc", "orbfe_pyr_body.inc", os.path.join(_ROOT, "include", "orbfe.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: no FMA contraction anywhere (outputs must be bit-exact)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall",

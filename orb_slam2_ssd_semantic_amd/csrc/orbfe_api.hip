@@ -507,33 +507,64 @@ static orbfe_status build_plan(orbfe_handle *h, int w, int ht)
         auto same_strip = [](const OrbLane &a, const OrbLane &b2) {
             return (a.flags >> 8) == (b2.flags >> 8) && a.ys == b2.ys && b2.x == a.x + 4;
         };
+        // The dense kernel of batch handles (k_fast_map_u) walks whole CELL ROWS: a run of rows starts on a cell-row boundary and
+        // ends on one (or at the end of the detectable interior), and a wave holds runs of ONE length only -- the reference's FAST
+        // never looks across a cell boundary (:798-838), so such a run needs no strength row of its neighbours, and everything that
+        // depends on the position inside the run alone is scalar in the kernel.  k cell rows per run, k = rows_fast / hcell rounded (1 for the default
+        // 40 rows and the ~31-row cells of every shipped configuration).  Handles made for a few frames per call (rows_fast < 24)
+        // keep short balanced runs and the generic kernel: such a call is bound by the length of one wave's walk.
+        const bool cellrows = rows_fast >= 24;
+        P.fast_cellrows = cellrows ? 1 : 0;
+        std::vector<OrbLane> ustream;
+        if (cellrows)
+            for (int l = 0; l < nl; ++l) {
+                const OrbLevel &L = P.lv[l];
+                const int rows = L.iy1 - ORBFE_EDGE, ncol = (L.ix1 - 16 + 3) / 4;
+                if (rows <= 0 || ncol <= 0) continue;
+                const int kc = std::max(1, (rows_fast + L.hcell / 2) / L.hcell), rb = kc * L.hcell;
+                for (int ys = ORBFE_EDGE; ys < L.iy1; ys += rb) {
+                    const int nr = std::min(rb, L.iy1 - ys);
+                    for (int c = 0; c < ncol; ++c) {
+                        OrbLane ln;
+                        ln.x = (uint16_t)(16 + 4 * c);
+                        ln.ys = (uint16_t)ys;
+                        ln.nrows = (uint16_t)nr;
+                        ln.flags = (uint16_t)(l << 8);
+                        ustream.push_back(ln);
+                    }
+                }
+            }
+        const std::vector<OrbLane> &dstream = cellrows ? ustream : stream;
         size_t i = 0;
         for (int l = 0; l <= ORBFE_MAX_LEVELS; ++l) P.fwave_off[l] = -1;
-        while (i < stream.size()) {
-            const int lvl = stream[i].flags >> 8;
+        while (i < dstream.size()) {
+            const int lvl = dstream[i].flags >> 8;
             const size_t w0 = flanes.size();
+            const OrbLane first = dstream[i];
+            // cell-row form: runs of ONE length per wave (every run starts on a cell row: the lanes are in step)
+            auto fits = [&](const OrbLane &ln) { return !cellrows || ln.nrows == first.nrows; };
             if (P.fwave_off[lvl] < 0) P.fwave_off[lvl] = (int)(w0 / 64);
-            if (i > 0 && same_strip(stream[i - 1], stream[i])) {  // continuing a cut strip: left halo first
-                OrbLane hl = stream[i - 1];
+            if (i > 0 && same_strip(dstream[i - 1], dstream[i])) {  // continuing a cut strip: left halo first
+                OrbLane hl = dstream[i - 1];
                 hl.flags |= 1;
                 flanes.push_back(hl);
             }
-            while (i < stream.size() && (stream[i].flags >> 8) == lvl && flanes.size() - w0 < 64) {
-                const bool more = i + 1 < stream.size() && same_strip(stream[i], stream[i + 1]);
+            while (i < dstream.size() && (dstream[i].flags >> 8) == lvl && fits(dstream[i]) && flanes.size() - w0 < 64) {
+                const bool more = i + 1 < dstream.size() && same_strip(dstream[i], dstream[i + 1]);
                 if (flanes.size() - w0 == 63 && more) {  // last slot and the strip goes on: right halo, lane moves on
-                    OrbLane hr = stream[i];
+                    OrbLane hr = dstream[i];
                     hr.flags |= 1;
                     flanes.push_back(hr);
                     break;
                 }
-                flanes.push_back(stream[i]);
+                flanes.push_back(dstream[i]);
                 ++i;
             }
-            while (flanes.size() - w0 < 64) {  // dead lanes
+            while (flanes.size() - w0 < 64) {  // dead lanes (cell-row form: they carry the wave's run, as its scalar row state wants)
                 OrbLane d;
                 d.x = 16;
-                d.ys = ORBFE_EDGE;
-                d.nrows = 0;
+                d.ys = cellrows ? first.ys : (uint16_t)ORBFE_EDGE;
+                d.nrows = cellrows ? first.nrows : (uint16_t)0;
                 d.flags = (uint16_t)((lvl << 8) | 1);
                 flanes.push_back(d);
             }

@@ -110,6 +110,7 @@ struct OrbPlan {
     int32_t dbg;               // developer knob (ORBFE_DEBUG env), 0 in production; 50 = quadtree streaming passes only
     int32_t nfwaves;           // FAST waves per frame (64 lane descriptors each)
     int32_t nfwaves_c;         // the same for the lane list of the lane-compacting form (every piece of a strip closed by halo lanes)
+    int32_t fast_cellrows;     // the dense lane list is made of whole cell rows, one run of rows per wave: k_fast_map_u (else k_fast_map)
     int32_t fwave_off[ORBFE_MAX_LEVELS + 1];  // first FAST wave of every level (waves are single-level, levels in order)
     int32_t nbwaves;           // blur waves per frame (64 lane descriptors each)
     int32_t bwave_off[ORBFE_MAX_LEVELS + 1];  // first blur wave of every level (the lanes of a level are contiguous)

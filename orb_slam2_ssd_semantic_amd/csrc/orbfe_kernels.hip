@@ -775,6 +775,26 @@ __global__ __launch_bounds__(256) FM_OCC void k_fast_map(const OrbPlan *__restri
 #include "orbfe_fast_body.inc"
 }
 
+// The same pass over a lane list made of whole CELL ROWS, one run of rows per wave (orbfe_fast_body_u.inc): what batch handles run.
+// k_fast_map above takes any run of rows per lane (handles made for a few frames per call walk short runs: a small call is bound by
+// the length of one wave's walk).
+template <int SPARSE>
+__global__ __launch_bounds__(256) FM_OCC void k_fast_map_u(const OrbPlan *__restrict__ plan, FrameSrc fs,
+                                                    const OrbLane *__restrict__ lanes, int nwaves,
+                                                    uint2 *__restrict__ skeys, int32_t *__restrict__ scount,
+                                                    uint32_t *__restrict__ cflags, int32_t cf_words,
+                                                    unsigned long long *__restrict__ fstat)
+{
+    FM_SHARED_DECLS
+    int b = blockIdx.y, bx = blockIdx.x;
+    xcd_frame_remap(bx, b);
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int t = bx * (blockDim.x >> 6) + wv;
+    if (t >= nwaves) return;
+#include "orbfe_fast_body_u.inc"
+}
+
 // The lane-compacting form of the same pass (orbfe_fast_body_c.inc): per wave a ring of the pixel rows its lanes fetched (one dword
 // per lane and row, 2 x FC_PN slots of FC_PW dwords), a queue of FC_QCAP one-dword tags of parked pixel pairs, four strength rows
 // in flight (a byte per pixel) and the survivor staging buffer -- 7.4 KB per wave and 96 registers: five waves per SIMD.
@@ -2650,7 +2670,14 @@ hipError_t orbk_launch_fast(const OrbLaunch &a, hipStream_t st)
     if (a.fast_sparse == 2)
         hipLaunchKernelGGL(k_fast_map_c, dim3((a.h_plan->nfwaves_c + 3) / 4, a.nframes), dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs,
                            a.d_flanes_c, a.h_plan->nfwaves_c, a.d_skeys, a.d_scount, a.d_cflag, a.cf_words, a.d_fstat);
-    else if (a.fast_sparse)
+    else if (a.h_plan->fast_cellrows) {
+        if (a.fast_sparse)
+            hipLaunchKernelGGL(k_fast_map_u<1>, grid, dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
+                               a.d_scount, a.d_cflag, a.cf_words, a.d_fstat);
+        else
+            hipLaunchKernelGGL(k_fast_map_u<0>, grid, dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
+                               a.d_scount, a.d_cflag, a.cf_words, (unsigned long long *)nullptr);
+    } else if (a.fast_sparse)
         hipLaunchKernelGGL(k_fast_map<1>, grid, dim3(256), (size_t)a.cf_words * 16, st, a.d_plan, fs, a.d_flanes, a.h_plan->nfwaves, a.d_skeys,
                            a.d_scount, a.d_cflag, a.cf_words, a.d_fstat);
     else
