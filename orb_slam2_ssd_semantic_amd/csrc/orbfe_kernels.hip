@@ -2318,7 +2318,10 @@ __global__ __launch_bounds__(DS_KPW * 16) void k_orient_describe(DescArgs da, Fr
                                                          int32_t *__restrict__ n_out, int32_t nl,
                                                          int32_t sel_per_frame, int32_t *__restrict__ ovf)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[DS_KPW][DS_PR * DS_PP];
+#ifndef DS_PATCH_PAD
+#define DS_PATCH_PAD 0   // bytes between the patches of neighbouring keypoints (A/B of a bank stagger: profiles/r06_ab_describe_pad.json)
+#endif
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[DS_KPW][DS_PR * DS_PP + DS_PATCH_PAD];
     __shared__ uint2 s_momw[31 * 8];
     __shared__ float4 s_pat[256];  // (x0, y0, x1, y1) of every test pair as floats
 #ifdef DS_EXTRA_LDS   // occupancy probe: dead LDS that costs a workgroup slot per CU
