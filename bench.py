@@ -494,7 +494,7 @@ def main():
         if world != 1 or fake:
             raise SystemExit("--path config5 is a single-GPU line")
         print(json.dumps(config5_leg(args, local_rank, warmup=args.warmup, reps=args.steps, standalone=True,
-                                     check=not args.no_extras)), flush=True)
+                                     check=not args.no_extras, pipeline=not args.no_extras)), flush=True)
         return
     w, h, F, NL, nf = args.width, args.height, args.frames, args.launches, args.nfeatures
     B = F * NL
@@ -754,7 +754,7 @@ def stage_report(ext, stage, mean_kp, w, h, nf, F, workload, local_rank):
 
     def gbs(name, tab=ab):
         return tab[name] * F / (stage_k[name] * 1e-3) / 1e9 if stage_k[name] > 0 else 0.0
-    kname = {"pyramid": "k_pyr_walk (7 launches)", "fast": "k_fast_map_c" if stage.get("fast_form") == "lane-compacting" else "k_fast_map",
+    kname = {"pyramid": "k_pyr_walk (7 launches)", "fast": "k_fast_map_c" if stage.get("fast_form") == "lane-compacting" else "k_fast_map_u",   # the dense kernel of batch handles (cell-row runs)
              "octree": "k_octree", "blur": "k_blur7", "describe": "k_orient_describe"}
     # k_fast_map is bound by VALU issue (VALUBusy 0.92: profiles/*_pmc_valubusy.json), not by HBM: the label says so; achieved /
     # peak / frac stay the HBM figures the contract defines (algorithmic bytes / kernel time against 8 TB/s), valu_frac beside them
@@ -1548,7 +1548,7 @@ def projection_leg(local_rank, reps=40):
     return out
 
 
-def config5_leg(args, local_rank, nframes=512, nfeat=4000, w=1920, h=1080, warmup=3, reps=10, check=True, standalone=False):
+def config5_leg(args, local_rank, nframes=512, nfeat=4000, w=1920, h=1080, warmup=3, reps=10, check=True, standalone=False, pipeline=True):
     """BASELINE config 5 as SURVEY 8(d) row 5 words it: 512 distinct device-resident 1920x1080 frames S(seed = 20000 + i)
     (1.06 GB: more than the 256 MB Infinity Cache), 4000 features, 8 levels, processed in ONE batched call; 3 warm-up + 10
     timed repetitions.  Stage times are the library's HIP events on the launch stream; the roofline object is the dominant
@@ -1584,7 +1584,18 @@ def config5_leg(args, local_rank, nframes=512, nfeat=4000, w=1920, h=1080, warmu
            "fast_candidates_frame0": ncand, "resident_input_bytes": int(frames.numel()), "warmup": warmup, "reps": reps,
            "roofline": roof, "stages": stages}
     # the same 512 frames through ONE call of the sequence pipeline (extract only): 8 pipes x sub-batches of 64 frames
+    # (not under the profiler: its 64-frame launches would be averaged into the per-launch counters of the 512-frame call)
     from orb_slam2_ssd_semantic_amd import FramePipeline
+    if not pipeline:
+        del ext, frames, kps, desc, n
+        torch.cuda.empty_cache()
+        return ({"metric": "ORB extract frames/sec on 1920x1080 (BASELINE config 5, HBM-roofline stress)", "value": out["frames_per_s"],
+                 "unit": "frames/s", "n_gpus": 1, "steps": reps, "warmup": warmup, "ms_per_step": out["ms_per_call"],
+                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                 "config": {"workload": "BASELINE config 5: 512 HBM-resident 1920x1080 frames S(seed), 4000 features, 8 levels, one "
+                                        "batched call per step, extract only (profiling run: no pipeline leg)", "frames_per_launch": nframes,
+                            "width": w, "height": h, "nfeatures": nfeat, "workload_name": "S"},
+                 "roofline": roof, "stages": stages, "config5": out} if standalone else out)
     k1, d1, n1 = kps.clone(), desc.clone(), n.clone()
     pl = FramePipeline(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, sub_batch=max(1, nframes // 8), npipes=8, device=local_rank)
 
