@@ -218,3 +218,39 @@ def test_blur_rounding_switched_on_an_existing_handle(oracle):
         outs.setdefault(mode, []).append(e.blurred_level(0))
     assert not np.array_equal(outs[0][0], outs[1][0])          # the constructed halves make the modes differ
     assert np.array_equal(outs[0][0], outs[0][1])
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (533, 401), (322, 243)])
+def test_saturating_sums_and_reflected_borders(oracle, w, h):
+    """The taps sum to 257, so a window of bright pixels overshoots 255 before saturate_cast<uchar> (:1095, 8-bit GaussianBlur):
+    255-blocks give column sums of 257 * 65535 >> 16 = 257 -> 255.  The kernel saturates through the dot product's clamp (an
+    accumulator that starts at 0xFF000000 + 2^15), and its border lanes fold BORDER_REFLECT_101 into their weights: saturated
+    blocks in the interior, on all four borders and in the corners, 254 / 255 / 0 checkerboards (values around the overshoot), every
+    level of three widths (w % 4 = 0, 1, 2), both roundings, against the oracle and -- level 0 -- the numpy twin."""
+    from orb_slam2_ssd_semantic_amd import ORBextractor
+    rng = np.random.default_rng(w)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[:40, :] = 255                                     # top border rows
+    img[-37:, :] = 255                                    # bottom
+    img[:, :29] = 255                                     # left columns (reflected taps land on 255s)
+    img[:, -31:] = 255                                    # right, incl. the scalar tail of odd widths
+    img[60:110, 150:230] = 255                            # interior block
+    yy, xx = np.mgrid[0:50, 0:70]
+    img[130:180, 60:130] = np.where((yy + xx) & 1, 255, 254).astype(np.uint8)
+    img[130:180, 140:210] = np.where((yy // 3 + xx // 3) & 1, 255, 0).astype(np.uint8)
+    img[190:205, :] = 253                                 # a band whose blur stays just below / at 255 next to 255s
+    for m in (0, 1):
+        oe = oracle.OracleExtractor(800, 1.2, 8, 20, 7)
+        oe.set_blur_mode(m)
+        ok, od = oe(img)
+        e = ORBextractor(800, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=16, blur_rounding=m)   # a batch handle: 40-row blur blocks, cell-row FAST
+        gk, gd = e(img)
+        for l in range(8):
+            assert np.array_equal(e.blurred_level(l), oe.blurred(l)), (m, l)
+        assert e.blurred_level(0).max() == 255 and _same(gk, gd, ok, od), m
+        tw, _ = twins.gaussian_blur7(img, sse2=bool(m))
+        assert np.array_equal(e.blurred_level(0), tw), m
+        # the batched path (row-block waves of 40 rows, other lane packing) on the same frame
+        kb, db = e.extract_batch([img, img[::-1].copy()])[0]
+        assert _same(kb, db, ok, od), m
+        e.close()
