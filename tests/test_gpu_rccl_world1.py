@@ -2,7 +2,9 @@
 bench.py's N > 1 branch (backend "nccl" = RCCL, `device_id` bound, rendezvous on 127.0.0.1) and the exact collective of
 `OverlappedKeyframeGather.launch` (asynchronous `all_gather_into_tensor` of the int32 count / int32-cast keypoint / uint8 descriptor
 blocks the library's pipeline wrote, behind the pipeline's kernels on the current stream) run once for real: RCCL loads, a
-communicator exists, the dtypes and shapes of the three blocks are accepted, the work handles order the streams.  What a world of
+communicator exists, the dtypes and shapes of the three blocks are accepted, the work handles order the streams; then bench.py's own
+exchange object (`OverlappedKeyframeGather` on its RCCL transport: gather stream, event timing, valid-prefix blocks) through five
+overlapped steps.  What a world of
 one cannot show -- xGMI transport, several ranks -- stays with the world-2 gloo tests and the driver's multi-GPU run.  Runs in a
 child process (a process group is process-wide state)."""
 import os
@@ -29,6 +31,7 @@ F, w, h = 6, 320, 240
 pl = FramePipeline(500, 1.2, 8, 20, 7, max_width=w, max_height=h, sub_batch=4, npipes=2)
 cap = pl.capacity()
 g = torch.from_numpy(np.stack([synth_tum_like(70 + i, h, w) for i in range(F)])).cuda()
+g_in = g
 kps = torch.zeros((F, cap, 7), dtype=torch.int32, device="cuda")
 desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device="cuda")
 n = torch.zeros(F, dtype=torch.int32, device="cuda")
@@ -47,10 +50,32 @@ for wk in works:
 torch.cuda.synchronize()
 assert all(torch.equal(o, t) for o, t in zip(outs, (n, kps, desc)))
 assert int(n.min()) > 50
+# ... and bench.py's own exchange object on the RCCL transport: the collectives of a launch issued under the object's gather
+# stream behind an event of the producer, HIP events around them (timing()), the valid prefix only (gather_cap), the producer
+# re-using a set only after acquire()
+from orb_slam2_ssd_semantic_amd.distributed import OverlappedKeyframeGather
+sets = [(n.clone(), kps.clone(), desc.clone()) for _ in range(2)]
+gcap = (int(n.max()) + 63) // 64 * 64
+assert gcap < cap
+g = OverlappedKeyframeGather(sets, gather_cap=gcap)
+assert g.comm is not None and not g.host_staged and g.bytes_per_rank == F * 4 + F * gcap * (28 + 32)
+for i in range(5):
+    k = i & 1
+    g.acquire(k)
+    pl.extract_match_device(g_in.data_ptr(), F, w, h, w, w * h, sets[k][1].data_ptr(), sets[k][2].data_ptr(), cap,
+                            sets[k][0].data_ptr(), match.data_ptr(), nm.data_ptr(), stream=st)
+    g.launch(k)
+for k in (0, 1):
+    gn, gk, gd = g.result(k)
+    torch.cuda.synchronize()
+    assert torch.equal(gn, n) and torch.equal(gk, kps[:, :gcap]) and torch.equal(gd, desc[:, :gcap]) and g.truncated(k) == 0
+tm = g.timing()
+assert tm["launches"] == 5 and tm["mean_ms"] > 0
+g.close()
 dist.barrier()
 dist.destroy_process_group()
 pl.close()
-print("RCCL_WORLD1_OK", int(n.sum()))
+print("RCCL_WORLD1_OK", int(n.sum()), round(tm["mean_ms"], 4))
 '''
 
 
