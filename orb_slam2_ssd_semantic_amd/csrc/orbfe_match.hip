@@ -2207,10 +2207,9 @@ extern "C" orbfe_status orbfe_search_for_triangulation(orbfe_matcher *m, const u
     for (int k = 0; k < 9; ++k) a.F[k] = F12[k];
     a.ex = ex; a.ey = ey;
     a.n1 = n1; a.th_low = th_low;
-    a.match12 = (int32_t *)m->b[1].p;
+    a.match12 = (int32_t *)m->pin_out.p;   // page-locked and mapped: the kernel stores its 4 n1 result bytes there, no copy back
     hipLaunchKernelGGL(k_triangulation, dim3((n1 + 255) / 256), dim3(256), 0, st, a);
     ORBFE_HIP(hipGetLastError());
-    ORBFE_HIP(hipMemcpyAsync(m->pin_out.p, m->b[1].p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
     ORBFE_HIP(hipStreamSynchronize(st));
     memcpy(match12, m->pin_out.p, (size_t)n1 * 4);
     return ORBFE_OK;
