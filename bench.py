@@ -1495,10 +1495,11 @@ def projection_leg(local_rank, reps=40):
                                          last["outlier"], last["world_pos"], last["octave"], last["obs_gt0"], 15.0, False)
     sel = valid.astype(bool)
     ci = PC.core_inputs(cur)
+    qq, qd = q[sel], last["mpdesc"][sel]   # selected once: the fancy indexing is not part of the call
 
     def core():
         t = time.perf_counter()
-        mat.SearchByProjectionCore(queries=q[sel], qdesc=last["mpdesc"][sel], th=100, nnratio=0.0, ratio_rule=0, **ci)
+        mat.SearchByProjectionCore(queries=qq, qdesc=qd, th=100, nnratio=0.0, ratio_rule=0, **ci)
         return (time.perf_counter() - t) * 1e3
     core()
     cpu = med(lambda: (R.search_by_projection_last_frame(cur, last, 15.0, False), R.last_call_ms())[1], 15)
