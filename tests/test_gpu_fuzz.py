@@ -257,7 +257,8 @@ def test_tum_sequence(oracle):
     from orb_slam2_ssd_semantic_amd import ORBextractor, tum
     if tum.sequence_dir() is None:
         pytest.skip("REAL-DATA PARITY NOT RUN: TUM fr3/walking_xyz (BASELINE configs 1-3) is not on this box; set $TUM_FR3_WALKING_XYZ. "
-                    "Everything bit-exact in this suite is on synthetic S / S_tum frames.")
+                    "The substitute for real camera frames is tests/test_gpu_real_photos.py (30 real photographs incl. a stereo pair "
+                    "and JPEG re-encodes == the compiled reference, stage by stage); this file's frames are synthetic S / S_tum.")
     frames = tum.load_gray_frames()
     N, h, w = frames.shape
     e = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=128)
