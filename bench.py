@@ -402,7 +402,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1024, help="frames per sub-batch of the library's pipeline")
     ap.add_argument("--launches", type=int, default=24, help="sub-batches per step: a step is ONE pipeline call over frames x "
                     "launches resident frames per GPU (default 24 576: twenty steps are > 1.5 s of GPU work)")
-    ap.add_argument("--pipes", type=int, default=int(os.environ.get("ORBFE_BENCH_PIPES", "12")), help="pipes of the pipeline (measured: 1: 277 k, 3: 296 k, 6: 306 k, 12: 316 k, 16-32: 311-313 k frames/s)")
+    ap.add_argument("--pipes", type=int, default=int(os.environ.get("ORBFE_BENCH_PIPES", "12")), help="pipes of the pipeline (round 6, 16 hardware queues: 8: 327 k, 12: 336-338 k, 16-24: 312-314 k frames/s; with 24-32 queues 16-20 pipes reach 335-337 k)")
     ap.add_argument("--step-join", action="store_true", help="join the launch stream after every step even on one GPU")
     ap.add_argument("--rows-fast", type=int, default=None, help="ORBFE_OPT_ROWS_FAST of the pipes' extractors (rows a FAST wave walks)")
     ap.add_argument("--rows-blur", type=int, default=None, help="ORBFE_OPT_ROWS_BLUR of the pipes' extractors")
